@@ -1,0 +1,233 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE -- only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this module).
+
+Every function takes/returns numpy float32 arrays shaped (B,C,D,H,W) like the reference operators.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libfluid_oracle.so")
+
+
+class OraGrid(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+                ("is3D", ctypes.c_int)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("fluid_oracle.c", "cnn_oracle.c")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfluid_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = ctypes.CDLL(_LIB)
+        _lib.ora_scalenet_weight_floats.restype = ctypes.c_size_t
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _grid(flags_like, is3d=None):
+    B, _, D, H, W = flags_like.shape
+    if is3d is None:
+        is3d = D > 1
+    return OraGrid(B, D, H, W, int(is3d))
+
+
+METHODS = {"eulerFluidNet": 0, "maccormackFluidNet": 1}
+
+
+def advect_scalar(dt, src, U, flags, method="maccormackFluidNet", bnd=1, sample_outside=False, strength=0.75,
+                  quirks=False):
+    g = _grid(flags, U.shape[1] == 3)
+    src, ps = _f(src); U, pu = _f(U); flags, pf = _f(flags)
+    dst = np.empty_like(src)
+    rc = lib().ora_advect_scalar(ctypes.byref(g), ctypes.c_float(dt), ps, pu, pf,
+                                 dst.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), METHODS[method], int(bnd),
+                                 int(sample_outside), ctypes.c_float(strength), int(quirks))
+    assert rc == 0, rc
+    return dst
+
+
+def advect_vel(dt, orig, U, flags, method="maccormackFluidNet", bnd=1, strength=0.75, quirks=False):
+    g = _grid(flags, U.shape[1] == 3)
+    orig, po = _f(orig); U, pu = _f(U); flags, pf = _f(flags)
+    dst = np.empty_like(U)
+    rc = lib().ora_advect_vel(ctypes.byref(g), ctypes.c_float(dt), po, pu, pf,
+                              dst.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), METHODS[method], int(bnd),
+                              ctypes.c_float(strength), int(quirks))
+    assert rc == 0, rc
+    return dst
+
+
+def velocity_divergence(U, flags):
+    g = _grid(flags, U.shape[1] == 3)
+    U, pu = _f(U); flags, pf = _f(flags)
+    div = np.empty_like(flags)
+    lib().ora_velocity_divergence(ctypes.byref(g), pu, pf, div.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return div
+
+
+def jacobi(flags, div, is3d, p_tol, max_iter, quirks=False):
+    g = _grid(flags, is3d)
+    flags, pf = _f(flags); div, pd = _f(div)
+    p = np.zeros_like(flags)
+    res = ctypes.c_float(0); it = ctypes.c_int(0)
+    rc = lib().ora_jacobi(ctypes.byref(g), pf, pd, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                          ctypes.byref(res), ctypes.c_float(p_tol), int(max_iter), int(quirks), ctypes.byref(it))
+    assert rc == 0, rc
+    return p, res.value, it.value
+
+
+def velocity_update(p, U, flags):
+    g = _grid(flags, U.shape[1] == 3)
+    p, pp = _f(p); flags, pf = _f(flags)
+    U = np.array(U, dtype=np.float32, order="C", copy=True)
+    lib().ora_velocity_update(ctypes.byref(g), pp, U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pf)
+    return U
+
+
+def add_buoyancy(U, flags, rho, gravity, rho_star, dt, quirks=False):
+    g = _grid(flags, U.shape[1] == 3)
+    flags, pf = _f(flags); rho, pr = _f(rho)
+    U = np.array(U, dtype=np.float32, order="C", copy=True)
+    gv = (ctypes.c_float * 3)(*[float(x) for x in gravity])
+    lib().ora_add_buoyancy(ctypes.byref(g), U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pf, pr, gv,
+                           ctypes.c_float(rho_star), ctypes.c_float(dt), int(quirks))
+    return U
+
+
+def set_wall_bcs(U, flags):
+    g = _grid(flags, U.shape[1] == 3)
+    flags, pf = _f(flags)
+    U = np.array(U, dtype=np.float32, order="C", copy=True)
+    lib().ora_set_wall_bcs(ctypes.byref(g), U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pf)
+    return U
+
+
+def set_const_vals(U, UBC, UBCInvMask, rho, rhoBC, rhoBCInvMask):
+    g = _grid(rho, U.shape[1] == 3)
+    U = np.array(U, dtype=np.float32, order="C", copy=True)
+    rho = np.array(rho, dtype=np.float32, order="C", copy=True)
+    a, pa = _f(UBC); b, pb = _f(UBCInvMask); c, pc = _f(rhoBC); d, pd = _f(rhoBCInvMask)
+    lib().ora_set_const_vals(ctypes.byref(g), U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pa, pb,
+                             rho.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pc, pd)
+    return U, rho
+
+
+def flags_to_occupancy(flags):
+    g = _grid(flags)
+    flags, pf = _f(flags)
+    occ = np.empty_like(flags)
+    lib().ora_flags_to_occupancy(ctypes.byref(g), pf, occ.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return occ
+
+
+def empty_domain(B, D, H, W, bnd=1):
+    g = OraGrid(B, D, H, W, int(D > 1))
+    flags = np.empty((B, 1, D, H, W), np.float32)
+    lib().ora_empty_domain(ctypes.byref(g), flags.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(bnd))
+    return flags
+
+
+def pack_weights(wdict, ndim=2):
+    """Flatten a torch-named weight dict into the canonical blob (see cnn_oracle.c header)."""
+    from fluidnet_cxx_amd.weights import scalenet_layers
+    parts = []
+    for L in scalenet_layers(2, ndim):
+        parts.append(np.ascontiguousarray(wdict[L["name"] + ".weight"], np.float32).ravel())
+        parts.append(np.ascontiguousarray(wdict[L["name"] + ".bias"], np.float32).ravel())
+    blob = np.concatenate(parts)
+    assert blob.size == lib().ora_scalenet_weight_floats(int(ndim == 3))
+    return blob
+
+
+def multiscale_forward(blob, x, is3d=False):
+    """x: (B,2,H,W) or (B,2,D,H,W) -> (B,1,...)"""
+    x5 = x if x.ndim == 5 else x[:, :, None]
+    B, _, D, H, W = x5.shape
+    g = OraGrid(B, D, H, W, int(is3d))
+    x5, px = _f(x5); blob, pb = _f(blob)
+    p = np.empty((B, 1, D, H, W), np.float32)
+    lib().ora_multiscale_forward(ctypes.byref(g), pb, px, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return p if x.ndim == 5 else p[:, :, 0]
+
+
+def scale_std(U, thr=1e-5):
+    B, nc, D, H, W = U.shape
+    g = OraGrid(B, D, H, W, int(nc == 3))
+    U, pu = _f(U)
+    s = np.empty((B,), np.float32)
+    lib().ora_scale_std(ctypes.byref(g), pu, ctypes.c_float(thr), s.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return s
+
+
+def fluidnet_forward(blob, inp, thr=1e-5):
+    B, cin, D, H, W = inp.shape
+    nc = cin - 3
+    g = OraGrid(B, D, H, W, int(nc == 3))
+    inp, pi = _f(inp); blob, pb = _f(blob)
+    p = np.empty((B, 1, D, H, W), np.float32); U = np.empty((B, nc, D, H, W), np.float32)
+    lib().ora_fluidnet_forward(ctypes.byref(g), pb, pi, ctypes.c_float(thr),
+                               p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                               U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return p, U
+
+
+def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False):
+    """One time step in the order of the reference's lib/simulate.py:28-171.
+
+    state: dict with p, U, flags, density (+ optional UBC, UBCInvMask, densityBC, densityBCInvMask);
+    cfg: dt, maccormackStrength, sampleOutsideFluid, buoyancyScale, gravityVec(x,y,z), operatingDensity,
+         pTol, jacobiIter.  Returns a new dict (inputs untouched)."""
+    U, flags, rho = state["U"], state["flags"], state["density"]
+    is3d = U.shape[1] == 3
+    dt = float(cfg["dt"])
+    has_bc = "UBC" in state
+
+    def const_vals(U, rho):
+        if has_bc:
+            return set_const_vals(U, state["UBC"], state["UBCInvMask"], rho, state["densityBC"],
+                                  state["densityBCInvMask"])
+        return U, rho
+
+    rho = advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, cfg.get("sampleOutsideFluid", False),
+                        cfg["maccormackStrength"], quirks)
+    U = advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, cfg["maccormackStrength"], quirks)
+    U, rho = const_vals(U, rho)
+    bs = cfg.get("buoyancyScale", 0)
+    if bs > 0:
+        gv = cfg["gravityVec"]
+        gvec = (np.array([gv["x"], gv["y"], gv["z"]], np.float32) * np.float32(-bs)).astype(np.float32)
+        U = add_buoyancy(U, flags, rho, gvec, cfg.get("operatingDensity", 0.0), dt, quirks)
+    if method == "jacobi":
+        U = set_wall_bcs(U, flags)
+    U, rho = const_vals(U, rho)
+    if method == "jacobi":
+        div = velocity_divergence(U, flags)
+        p, _, _ = jacobi(flags, div, is3d, cfg.get("pTol", 0.0), cfg["jacobiIter"], quirks)
+        U = velocity_update(p, U, flags)
+        U = set_wall_bcs(U, flags)
+    else:
+        inp = np.concatenate([state["p"], U, flags, rho], 1)
+        p, U = fluidnet_forward(blob, inp, cfg.get("normalizeInputThreshold", 1e-5))
+    U, rho = const_vals(U, rho)
+    out = dict(state)
+    out.update(p=p, U=U, density=rho)
+    return out
