@@ -1,0 +1,104 @@
+"""One fluid time step -- drop-in for the reference's `lib.simulate` (pytorch/lib/simulate.py:28-171).
+
+`simulate(mconf, batch_dict, net, sim_method)` keeps the reference's calling convention (in place on
+batch_dict, same mconf keys).  Two execution modes:
+  fused=True  (default): one call into the native `simulate_step_` (the whole step enqueued by C++, no
+              Python between kernels);
+  fused=False: operator by operator through the `fluid.*` surface in the reference's order (what the
+              parity tests use to compare stage by stage).
+"""
+import torch
+
+from . import fluid
+from ._ext import ext
+
+
+def setConstVals(batch_dict, p, U, flags, density):
+    fluid.setConstVals(batch_dict, p, U, flags, density)
+
+
+def _gravity(mconf, scale):
+    gv = mconf["gravityVec"]
+    return [float(gv["x"]), float(gv["y"]), float(gv["z"])], float(scale)
+
+
+def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None):
+    assert sim_method in ("convnet", "jacobi"), "Simulation method not supported. Choose either convnet or jacobi."
+    dt = float(mconf["dt"])
+    maccormackStrength = mconf["maccormackStrength"]
+    sampleOutsideFluid = mconf["sampleOutsideFluid"]
+    buoyancyScale = mconf["buoyancyScale"]
+    gravityScale = mconf.get("gravityScale", 0)
+    viscosity = mconf.get("viscosity", 0)
+    assert viscosity >= 0, "Viscosity must be positive"
+    p, U, flags = batch_dict["p"], batch_dict["U"], batch_dict["flags"]
+    has_density = "density" in batch_dict
+
+    simple = (viscosity == 0 and gravityScale == 0 and not mconf.get("correctScalar", False)
+              and "flags_stick" not in batch_dict and not output_div
+              and not ("periodic-x" in mconf and "periodic-y" in mconf))
+    if fused and simple:
+        gvec, _ = _gravity(mconf, 1.0)
+        density = batch_dict["density"] if has_density else None
+        packed = net.packed if (sim_method == "convnet") else None
+        ext.simulate_step_(p, U, flags, density, batch_dict.get("UBC"), batch_dict.get("UBCInvMask"),
+                           batch_dict.get("densityBC"), batch_dict.get("densityBCInvMask"), packed, dt,
+                           float(maccormackStrength), bool(sampleOutsideFluid), float(buoyancyScale), gvec,
+                           float(mconf.get("operatingDensity", 0.0)), float(mconf.get("pTol", 0.0)),
+                           int(mconf.get("jacobiIter", 1)), sim_method,
+                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace)
+        if not has_density:
+            batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
+        return
+
+    assert viscosity == 0 and gravityScale == 0 and "flags_stick" not in batch_dict, \
+        "viscosity / gravity / stick BCs are outside the accelerated path (reference configs keep them off)"
+    # ---- operator-by-operator path, reference order ----
+    if has_density:
+        density = fluid.advectScalar(dt, batch_dict["density"], U, flags, method="maccormackFluidNet",
+                                     boundary_width=1, sample_outside_fluid=sampleOutsideFluid,
+                                     maccormack_strength=maccormackStrength)
+        if mconf.get("correctScalar", False):
+            div = fluid.velocityDivergence(U, flags)
+            fluid.correctScalar(dt, density, div, flags)
+    else:
+        density = torch.zeros_like(flags)
+    U = fluid.advectVelocity(dt=dt, orig=U, U=U, flags=flags, method="maccormackFluidNet", boundary_width=1,
+                             maccormack_strength=maccormackStrength)
+    setConstVals(batch_dict, p, U, flags, density)
+    if has_density and buoyancyScale > 0:
+        gvec, _ = _gravity(mconf, 1.0)
+        gravity = (torch.tensor(gvec, dtype=torch.float32) * (-buoyancyScale)).tolist()
+        U = fluid.addBuoyancy(U, flags, density, gravity, mconf["operatingDensity"], dt)
+    if output_div:
+        return
+    periodic = "periodic-x" in mconf and "periodic-y" in mconf
+
+    def wall_bcs(U):
+        if periodic:
+            U_temp = U.clone()
+        U = fluid.setWallBcs(U, flags)
+        if periodic:
+            if mconf["periodic-x"]:
+                U[:, 1, :, :, 1] = U_temp[:, 1, :, :, U.size(4) - 1]
+            if mconf["periodic-y"]:
+                U[:, 0, :, 1] = U_temp[:, 0, :, U.size(3) - 1]
+        return U
+
+    if sim_method != "convnet":
+        U = wall_bcs(U)
+    setConstVals(batch_dict, p, U, flags, density)
+    if sim_method == "convnet":
+        data = torch.cat((p, U, flags, density), 1)
+        p, U = net(data)
+    else:
+        div = fluid.velocityDivergence(U, flags)
+        is3D = U.size(2) > 1
+        p, residual = fluid.solveLinearSystemJacobi(flags=flags, div=div, is_3d=is3D, p_tol=mconf["pTol"],
+                                                    max_iter=mconf["jacobiIter"])
+        fluid.velocityUpdate(pressure=p, U=U, flags=flags)
+        U = wall_bcs(U)
+    setConstVals(batch_dict, p, U, flags, density)
+    batch_dict["U"] = U
+    batch_dict["density"] = density
+    batch_dict["p"] = p

@@ -1,0 +1,100 @@
+"""In-tree build of the native pieces (gfx950 only).
+
+  libfluidnet_hip.so   HIP kernels + the C ABI of include/fluidnet_hip.h      (hipcc, cross-compiles without a GPU)
+  fluidnet_cpp.so      torch cpp-extension with the reference's pybind entry points, linked against the above
+
+Both land next to this file so they travel with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfluidnet_hip.so")
+EXT = os.path.join(HERE, "fluidnet_cpp.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# file -> extra flags.  Stencil/advection/Jacobi units must not contract a*b+c into FMA: bit-parity with the
+# reference's ATen arithmetic depends on it.  The CNN unit is tolerance-checked and may fuse.
+HIP_UNITS = {
+    "fnx_stencils.hip": ["-ffp-contract=off"],
+    "fnx_advect.hip": ["-ffp-contract=off"],
+    "fnx_jacobi.hip": ["-ffp-contract=off"],
+    "fnx_step.hip": ["-ffp-contract=off"],
+    "fnx_api.hip": ["-ffp-contract=off"],
+    "fnx_cnn.hip": [],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "fluidnet_hip.h"))
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for unit, extra in HIP_UNITS.items():
+        src = os.path.join(CSRC, unit)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(HERE, "build", unit.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs + [__file__]):
+            cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((unit, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for unit, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {unit} ---\n{out.decode()}\n")
+        elif verbose and out:
+            print(out.decode())
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_ext(force=False, verbose=False):
+    """fluidnet_cpp: pybind11 module over the C ABI (g++; needs torch headers, not a GPU)."""
+    src = os.path.join(CSRC, "fluidnet_cpp.cpp")
+    if not (force or _newer(EXT, [src, LIB, os.path.join(HERE, "..", "include", "fluidnet_hip.h"), __file__])):
+        return EXT
+    import torch
+    from torch.utils import cpp_extension as ce
+    tdir = os.path.dirname(torch.__file__)
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=fluidnet_cpp", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += [f"-isystem{i}" for i in inc]
+    cmd += [src, "-o", EXT, f"-L{HERE}", "-lfluidnet_hip", f"-L{tdir}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python",
+            "-lc10_hip", "-ltorch_hip", "-L/opt/rocm/lib", "-lamdhip64",
+            "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir}/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EXT
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_ext(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

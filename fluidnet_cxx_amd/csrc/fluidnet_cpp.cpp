@@ -1,0 +1,296 @@
+// torch cpp-extension `fluidnet_cpp` for MI355X: the reference's three pybind entry points
+// (pytorch/lib/fluid/cpp/fluids_init.cpp:1009-1014) with identical names and positional signatures, bound
+// to the C ABI of libfluidnet_hip.so, plus the operators the reference implements in Python
+// (lib/fluid/*.py) as additional entry points in the same style.
+//
+// This file is host plumbing only: shape/contiguity checks mirroring the reference's asserts, output and
+// workspace allocation from torch's caching allocator, the current HIP stream, status -> RuntimeError.
+// There is no CPU path: tensors must live on a HIP device.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include "../../include/fluidnet_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+bool g_ref_quirks = false;
+
+void check_status(int rc) {
+  TORCH_CHECK(rc == FNX_OK, fnx_last_error());
+}
+
+void check_field(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be on the GPU (libfluidnet_hip has no CPU path)");
+  TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32");
+  TORCH_CHECK(t.dim() == 5, "Dimension mismatch");
+  TORCH_CHECK(t.is_contiguous(), "Input is not contiguous");
+}
+
+FnxGrid grid_of(const Tensor& flags, bool is3D) {
+  check_field(flags, "flags");
+  TORCH_CHECK(flags.size(1) == 1, "flags is not scalar");
+  FnxGrid g;
+  g.B = (int)flags.size(0); g.D = (int)flags.size(2); g.H = (int)flags.size(3); g.W = (int)flags.size(4);
+  g.is3D = is3D ? 1 : 0;
+  g.ref_quirks = g_ref_quirks ? 1 : 0;
+  if (!is3D) TORCH_CHECK(g.D == 1, "2D velocity field but zdepth > 1");
+  return g;
+}
+
+void check_vel(const Tensor& U, const FnxGrid& g, const char* name) {
+  check_field(U, name);
+  TORCH_CHECK(U.size(1) == (g.is3D ? 3 : 2), g.is3D ? "3D velocity field must have 3 channels" : "2D velocity field must have only 2 channels");
+  TORCH_CHECK(U.size(0) == g.B && U.size(2) == g.D && U.size(3) == g.H && U.size(4) == g.W, "Size mismatch");
+}
+
+void check_scalar(const Tensor& s, const FnxGrid& g, const char* name) {
+  check_field(s, name);
+  TORCH_CHECK(s.size(1) == 1 && s.size(0) == g.B && s.size(2) == g.D && s.size(3) == g.H && s.size(4) == g.W, "Size mismatch");
+}
+
+struct Workspace {
+  Tensor t; void* ptr; size_t bytes;
+  Workspace(const FnxGrid& g, int op, const Tensor& like) {
+    bytes = fnx_workspace_bytes(&g, op);
+    t = at::empty({(int64_t)(bytes ? bytes : 1)}, like.options().dtype(at::kByte));
+    ptr = t.data_ptr();
+  }
+};
+
+void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+int method_of(const std::string& m) {
+  // cpp/advect_type.cpp:5-16
+  if (m == "eulerFluidNet") return FNX_ADVECT_EULER;
+  if (m == "maccormackFluidNet") return FNX_ADVECT_MACCORMACK;
+  TORCH_CHECK(false, "Advection method not supported: ", m);
+  return -1;
+}
+
+// ---- the reference's three entry points -------------------------------------------------------------
+Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::string method, int bnd,
+                     const bool sample_outside_fluid, const float maccormack_strength) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_scalar(src, g, "src");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor dst = at::empty_like(src);
+  Workspace ws(g, FNX_OP_ADVECT_SCALAR, src);
+  check_status(fnx_advect_scalar(&g, dt, src.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                                 dst.data_ptr<float>(), method_of(method), bnd, sample_outside_fluid,
+                                 maccormack_strength, ws.ptr, ws.bytes, cur_stream(src)));
+  return dst;
+}
+
+Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::string method, int bnd,
+                  const float maccormack_strength) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_vel(orig, g, "orig");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor dst = at::empty_like(U);
+  Workspace ws(g, FNX_OP_ADVECT_VEL, U);
+  check_status(fnx_advect_vel(&g, dt, orig.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                              dst.data_ptr<float>(), method_of(method), bnd, maccormack_strength, ws.ptr, ws.bytes,
+                              cur_stream(U)));
+  return dst;
+}
+
+std::vector<Tensor> solve_linear_system(Tensor flags, Tensor div, const bool is3D, const float p_tol,
+                                        const int max_iter, const bool verbose) {
+  FnxGrid g = grid_of(flags, is3D);
+  check_scalar(div, g, "div");
+  if (!is3D) TORCH_CHECK(g.D == 1, "d > 1 for a 2D domain");
+  TORCH_CHECK(max_iter >= 1, "At least 1 iteration is needed (maxIter < 1)");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor p = at::empty_like(flags);
+  Tensor residual = at::zeros({}, flags.options());
+  Workspace ws(g, FNX_OP_JACOBI, flags);
+  int iters = 0;
+  check_status(fnx_jacobi(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(),
+                          residual.data_ptr<float>(), p_tol, max_iter, &iters, ws.ptr, ws.bytes, cur_stream(flags)));
+  if (verbose) {
+    std::cout << "Jacobi: " << iters << " sweeps, residual " << residual.item<float>() << std::endl;
+  }
+  return {p, residual};
+}
+
+// ---- operators the reference writes in Python -------------------------------------------------------
+Tensor velocity_divergence(Tensor U, Tensor flags) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor div = at::empty_like(flags);
+  check_status(fnx_velocity_divergence(&g, U.data_ptr<float>(), flags.data_ptr<float>(), div.data_ptr<float>(), cur_stream(U)));
+  return div;
+}
+
+void velocity_update_(Tensor pressure, Tensor U, Tensor flags) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_scalar(pressure, g, "pressure");
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_velocity_update(&g, pressure.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(U)));
+}
+
+void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> gravity, double rho_star, double dt) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_scalar(density, g, "density");
+  TORCH_CHECK(gravity.size() == 3, "Gravity must be a 3D vector (even in 2D)");
+  const float gv[3] = {(float)gravity[0], (float)gravity[1], (float)gravity[2]};
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_add_buoyancy(&g, U.data_ptr<float>(), flags.data_ptr<float>(), density.data_ptr<float>(), gv,
+                                (float)rho_star, (float)dt, cur_stream(U)));
+}
+
+void set_wall_bcs_(Tensor U, Tensor flags) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U");
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_set_wall_bcs(&g, U.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(U)));
+}
+
+void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> density,
+                     c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask) {
+  check_field(U, "U");
+  FnxGrid g; g.B = (int)U.size(0); g.D = (int)U.size(2); g.H = (int)U.size(3); g.W = (int)U.size(4);
+  g.is3D = U.size(1) == 3; g.ref_quirks = 0;
+  auto ptr = [&](c10::optional<Tensor>& t, bool vel) -> float* {
+    if (!t.has_value() || !t->defined()) return nullptr;
+    if (vel) check_vel(*t, g, "UBC"); else check_scalar(*t, g, "densityBC");
+    return t->data_ptr<float>();
+  };
+  c10::hip::HIPGuard guard(U.get_device());
+  check_status(fnx_set_const_vals(&g, U.data_ptr<float>(), ptr(UBC, true), ptr(UBCInvMask, true), ptr(density, false),
+                                  ptr(densityBC, false), ptr(densityBCInvMask, false), cur_stream(U)));
+}
+
+Tensor flags_to_occupancy(Tensor flags) {
+  FnxGrid g = grid_of(flags, flags.size(2) > 1);
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor occ = at::empty_like(flags);
+  check_status(fnx_flags_to_occupancy(&g, flags.data_ptr<float>(), occ.data_ptr<float>(), cur_stream(flags)));
+  return occ;
+}
+
+void empty_domain_(Tensor flags, int boundary_width) {
+  FnxGrid g = grid_of(flags, flags.size(2) > 1);
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_empty_domain(&g, flags.data_ptr<float>(), boundary_width, cur_stream(flags)));
+}
+
+// ---- CNN pressure projection --------------------------------------------------------------------------
+Tensor scalenet_pack(Tensor blob, bool is3D) {
+  TORCH_CHECK(blob.is_cuda() && blob.scalar_type() == at::kFloat && blob.is_contiguous(), "weights blob must be a contiguous float32 GPU tensor");
+  TORCH_CHECK((size_t)blob.numel() == fnx_scalenet_weight_floats(is3D), "weights blob has ", blob.numel(), " floats, expected ",
+              fnx_scalenet_weight_floats(is3D));
+  c10::hip::HIPGuard guard(blob.get_device());
+  Tensor packed = at::zeros({(int64_t)fnx_scalenet_packed_bytes(is3D)}, blob.options().dtype(at::kByte));
+  check_status(fnx_scalenet_pack(is3D, blob.data_ptr<float>(), packed.data_ptr(), cur_stream(blob)));
+  return packed;
+}
+
+Tensor multiscale_forward(Tensor packed, Tensor x) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "x must be a contiguous float32 GPU tensor");
+  TORCH_CHECK((x.dim() == 4 || x.dim() == 5) && x.size(1) == 2, "x must be (B,2,H,W) or (B,2,D,H,W)");
+  const bool is3D = x.dim() == 5 && x.size(2) > 1;
+  FnxGrid g; g.B = (int)x.size(0); g.is3D = is3D; g.ref_quirks = 0;
+  g.D = x.dim() == 5 ? (int)x.size(2) : 1; g.H = (int)x.size(x.dim() - 2); g.W = (int)x.size(x.dim() - 1);
+  c10::hip::HIPGuard guard(x.get_device());
+  std::vector<int64_t> osz = x.sizes().vec(); osz[1] = 1;
+  Tensor p = at::empty(osz, x.options());
+  const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_FLUIDNET);
+  Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
+  check_status(fnx_multiscale_forward(&g, packed.data_ptr(), x.data_ptr<float>(), p.data_ptr<float>(), ws.data_ptr(), bytes, cur_stream(x)));
+  return p;
+}
+
+std::vector<Tensor> fluidnet_forward(Tensor packed, Tensor input, double normalize_threshold) {
+  check_field(input, "input");
+  const bool is3D = input.size(1) == 6;
+  TORCH_CHECK(input.size(1) == 5 || input.size(1) == 6, "input must have 5 (2D) or 6 (3D) channels [p, U, flags, density]");
+  FnxGrid g; g.B = (int)input.size(0); g.D = (int)input.size(2); g.H = (int)input.size(3); g.W = (int)input.size(4);
+  g.is3D = is3D; g.ref_quirks = 0;
+  c10::hip::HIPGuard guard(input.get_device());
+  Tensor p = at::empty({g.B, 1, g.D, g.H, g.W}, input.options());
+  Tensor U = at::empty({g.B, is3D ? 3 : 2, g.D, g.H, g.W}, input.options());
+  const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_FLUIDNET);
+  Tensor ws = at::empty({(int64_t)bytes}, input.options().dtype(at::kByte));
+  check_status(fnx_fluidnet_forward(&g, packed.data_ptr(), input.data_ptr<float>(), (float)normalize_threshold,
+                                    p.data_ptr<float>(), U.data_ptr<float>(), ws.data_ptr(), bytes, cur_stream(input)));
+  return {p, U};
+}
+
+// one whole step of lib/simulate.py:28-171, in place on p, U, density
+void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> density, c10::optional<Tensor> UBC,
+                    c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> densityBC,
+                    c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> net, double dt,
+                    double maccormack_strength, bool sample_outside_fluid, double buoyancy_scale,
+                    std::vector<double> gravity_vec, double operating_density, double p_tol, int jacobi_iter,
+                    const std::string method, double normalize_threshold, c10::optional<Tensor> workspace) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_scalar(p, g, "p");
+  TORCH_CHECK(method == "jacobi" || method == "convnet", "Simulation method not supported. Choose either convnet or jacobi.");
+  TORCH_CHECK(gravity_vec.size() == 3, "gravityVec needs x, y, z");
+  FnxStepParams prm;
+  prm.dt = (float)dt; prm.maccormack_strength = (float)maccormack_strength; prm.sample_outside_fluid = sample_outside_fluid;
+  prm.buoyancy_scale = (float)buoyancy_scale;
+  for (int a = 0; a < 3; ++a) prm.gravity_vec[a] = (float)gravity_vec[a];
+  prm.operating_density = (float)operating_density; prm.p_tol = (float)p_tol; prm.jacobi_iter = jacobi_iter;
+  prm.method = method == "convnet" ? 1 : 0; prm.normalize_threshold = (float)normalize_threshold;
+  auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> float* {
+    if (!t.has_value() || !t->defined()) return nullptr;
+    if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
+    return t->data_ptr<float>();
+  };
+  FnxState st;
+  st.p = p.data_ptr<float>(); st.U = U.data_ptr<float>(); st.flags = flags.data_ptr<float>();
+  st.density = opt(density, false, "density");
+  st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
+  st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
+  st.net = (net.has_value() && net->defined()) ? net->data_ptr() : nullptr;
+  c10::hip::HIPGuard guard(flags.get_device());
+  const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_STEP);
+  Tensor ws;
+  if (workspace.has_value() && workspace->defined() && (size_t)workspace->numel() * workspace->element_size() >= bytes) ws = *workspace;
+  else ws = at::empty({(int64_t)bytes}, flags.options().dtype(at::kByte));
+  check_status(fnx_simulate_step(&g, &prm, &st, ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), cur_stream(U)));
+}
+
+int64_t step_workspace_bytes(int B, int D, int H, int W, bool is3D) {
+  FnxGrid g{B, D, H, W, is3D ? 1 : 0, 0};
+  return (int64_t)fnx_workspace_bytes(&g, FNX_OP_STEP);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  // reference entry points (fluids_init.cpp:1009-1014)
+  m.def("advect_scalar", &advect_scalar, "Advect Scalar");
+  m.def("advect_vel", &advect_vel, "Advect Velocity");
+  m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method");
+  // operators the reference implements in Python
+  m.def("velocity_divergence", &velocity_divergence);
+  m.def("velocity_update_", &velocity_update_);
+  m.def("add_buoyancy_", &add_buoyancy_);
+  m.def("set_wall_bcs_", &set_wall_bcs_);
+  m.def("set_const_vals_", &set_const_vals_);
+  m.def("flags_to_occupancy", &flags_to_occupancy);
+  m.def("empty_domain_", &empty_domain_);
+  m.def("scalenet_pack", &scalenet_pack);
+  m.def("multiscale_forward", &multiscale_forward);
+  m.def("fluidnet_forward", &fluidnet_forward);
+  m.def("simulate_step_", &simulate_step_);
+  m.def("step_workspace_bytes", &step_workspace_bytes);
+  m.def("set_ref_quirks", [](bool on) { g_ref_quirks = on; }, "3D only: reproduce the reference's 3D defects bit-for-bit");
+  m.def("get_ref_quirks", []() { return g_ref_quirks; });
+  m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
+  m.def("abi_version", &fnx_abi_version);
+}

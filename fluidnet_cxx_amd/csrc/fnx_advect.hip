@@ -1,0 +1,310 @@
+// MacCormack / semi-Lagrangian advection kernels for gfx950.
+//
+// Replaces advectScalar (cpp/fluids_init.cpp:265-382) and advectVel (:656-807): the reference issues
+// ~3300 / ~1400 ATen ops per call; here each advection is two launches (forward pass; backward pass fused
+// with the MacCormack correction and clamp), one thread per cell, x fastest so every field read that is
+// not a gather is a coalesced 256-B wave access.  Gathers (trace end points, clamp neighbourhoods) stay
+// within a few cells of the thread's own cell and are served by L1/L2.
+//
+// Bit-parity: see fnx_device.h.  Compiled with -ffp-contract=off.
+#include "fnx_device.h"
+#include "fnx_kernels.h"
+
+namespace {
+
+constexpr int BX = 64, BY = 4;
+
+struct CellId { int b, k, j, i; bool valid; };
+
+template <bool IS3D>
+__device__ __forceinline__ CellId cell_id(const GridDims& g) {
+  CellId c;
+  c.i = blockIdx.x * BX + threadIdx.x;
+  c.j = blockIdx.y * BY + threadIdx.y;
+  const int bk = blockIdx.z;
+  c.b = IS3D ? bk / g.D : bk;
+  c.k = IS3D ? bk - c.b * g.D : 0;
+  c.valid = (c.i < g.W) & (c.j < g.H);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Scalar: one semi-Lagrangian pass (SemiLagrangeEulerFluidNet[SavePos], fluids_init.cpp:12-133).
+// Writes dst (border -> 0) and, if cell_out != nullptr, the clamped cell of the traced position
+// (what getClampBounds :175-178 derives from fwd_pos).
+// ---------------------------------------------------------------------------------------------------
+template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt, const float* __restrict__ src,
+                                                           const float* __restrict__ U,
+                                                           const float* __restrict__ flags, float* __restrict__ dst,
+                                                           int* __restrict__ cell_out) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const Field fs{src + (size_t)c.b * g.DHW}, ff{flags + (size_t)c.b * g.DHW}, fu{U + (size_t)c.b * NC * g.DHW};
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float ctr[3] = { (float)c.i + 0.5f, (float)c.j + 0.5f, (float)c.k + 0.5f };
+  float val = 0.f;
+  float p[3] = { ctr[0], ctr[1], ctr[2] };
+  if (!is_border<IS3D>(g, c.i, c.j, c.k)) {
+    if (ff.p[o] != FNX_FLUID) {
+      val = fs.p[o];                                   // "don't advect solid geometry"
+    } else {
+      float cen[3], disp[3];
+      get_centered<IS3D>(g, fu, c.i, c.j, c.k, cen);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) disp[a] = (-dt) * cen[a];
+      line_trace(g, ff, ctr, disp, p);
+      val = SAMPLE_OUTSIDE ? interpol<IS3D>(g, fs, 0, p[0], p[1], p[2])
+                           : interpol_with_fluid<IS3D, QUIRKS>(g, fs, ff, p[0], p[1], p[2]);
+    }
+  }
+  dst[(size_t)c.b * g.DHW + o] = val;
+  if (cell_out) {
+    const int i0 = clampi((int)p[0], 0, g.W - 1), j0 = clampi((int)p[1], 0, g.H - 1);
+    const int k0 = (IS3D && !QUIRKS) ? clampi((int)p[2], 0, g.D - 1) : 0;      // Q10: k0 = 0 in the reference
+    cell_out[(size_t)c.b * g.DHW + o] = k0 * g.HW + j0 * g.W + i0;
+  }
+}
+
+// Backward pass on fwd + MacCormackCorrect (:135-148) + MacCormackClampFluidNet (:154-263)
+template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g, float dt, float half_s,
+                                                                     const float* __restrict__ src,
+                                                                     const float* __restrict__ fwd,
+                                                                     const int* __restrict__ cell_in,
+                                                                     const float* __restrict__ U,
+                                                                     const float* __restrict__ flags,
+                                                                     float* __restrict__ dst) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const Field fs{src + (size_t)c.b * g.DHW}, fw{fwd + (size_t)c.b * g.DHW}, ff{flags + (size_t)c.b * g.DHW},
+      fu{U + (size_t)c.b * NC * g.DHW};
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const bool border = is_border<IS3D>(g, c.i, c.j, c.k);
+  const bool fluid = ff.p[o] == FNX_FLUID;
+  const float f = fw.p[o];
+  float bwd = 0.f;
+  if (!border) {
+    if (!fluid) {
+      bwd = f;
+    } else {
+      const float ctr[3] = { (float)c.i + 0.5f, (float)c.j + 0.5f, (float)c.k + 0.5f };
+      float cen[3], disp[3], p[3];
+      get_centered<IS3D>(g, fu, c.i, c.j, c.k, cen);
+      const float ndt = -dt;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) disp[a] = (-ndt) * cen[a];
+      line_trace(g, ff, ctr, disp, p);
+      bwd = SAMPLE_OUTSIDE ? interpol<IS3D>(g, fw, 0, p[0], p[1], p[2])
+                           : interpol_with_fluid<IS3D, QUIRKS>(g, fw, ff, p[0], p[1], p[2]);
+    }
+  }
+  float d = f;
+  if (fluid) d = f + half_s * (fs.p[o] - bwd);          // applied on border cells too (reference :371)
+  if (!border) {
+    const int cell = cell_in[(size_t)c.b * g.DHW + o];
+    const int k0 = IS3D ? cell / g.HW : 0;
+    const int r = cell - k0 * g.HW;
+    const int j0 = r / g.W, i0 = r - j0 * g.W;
+    float mn = INFINITY, mx = -INFINITY;
+    bool any = false;
+#pragma unroll
+    for (int dk = -1; dk <= 1; ++dk) {
+      const int kk = k0 + dk;
+      if (kk < 0 || kk >= g.D) continue;
+#pragma unroll
+      for (int dj = -1; dj <= 1; ++dj) {
+        const int jj = j0 + dj;
+        if (jj < 0 || jj >= g.H) continue;
+#pragma unroll
+        for (int di = -1; di <= 1; ++di) {
+          const int ii = i0 + di;
+          if (ii < 0 || ii >= g.W) continue;
+          const size_t q = (size_t)kk * g.HW + jj * g.W + ii;
+          if (SAMPLE_OUTSIDE || ff.p[q] == FNX_FLUID) {
+            const float s = fs.p[q];
+            mn = fminf(mn, s); mx = fmaxf(mx, s); any = true;
+          }
+        }
+      }
+    }
+    d = any ? fmaxf(mn, fminf(mx, d)) : f;
+  }
+  dst[(size_t)c.b * g.DHW + o] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Velocity: SemiLagrangeEulerFluidNetMAC (:388-451), no line trace.
+// ---------------------------------------------------------------------------------------------------
+template <bool IS3D, bool QUIRKS, int COMP>
+__device__ __forceinline__ float sl_mac_component(const GridDims& g, const Field& src, const Field& fu, int i, int j,
+                                                  int k, float dt) {
+  float v[3];
+  get_at_mac<IS3D, QUIRKS, COMP>(g, fu, i, j, k, v);
+  const float px = ((float)i + 0.5f) + v[0] * (-dt);
+  const float py = ((float)j + 0.5f) + v[1] * (-dt);
+  const float pz = ((float)k + 0.5f) + v[2] * (-dt);
+  return interpol<IS3D>(g, src, COMP, px, py, pz);
+}
+
+template <bool IS3D, bool QUIRKS>
+__global__ __launch_bounds__(BX* BY) void sl_mac_kernel(GridDims g, float dt, const float* __restrict__ src,
+                                                        const float* __restrict__ U, const float* __restrict__ flags,
+                                                        float* __restrict__ dst) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const Field fs{src + (size_t)c.b * NC * g.DHW}, fu{U + (size_t)c.b * NC * g.DHW};
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  float r[3] = { 0.f, 0.f, 0.f };
+  if (!is_border<IS3D>(g, c.i, c.j, c.k)) {
+    if (flags[(size_t)c.b * g.DHW + o] != FNX_FLUID) {
+      r[0] = fs.p[(size_t)g.DHW + o];                    // reference writes src channel 1 into channel 0 (:413-416)
+      if (IS3D) r[2] = fs.p[(size_t)2 * g.DHW + o];
+    } else {
+      r[0] = sl_mac_component<IS3D, QUIRKS, 0>(g, fs, fu, c.i, c.j, c.k, dt);
+      r[1] = sl_mac_component<IS3D, QUIRKS, 1>(g, fs, fu, c.i, c.j, c.k, dt);
+      if (IS3D && !QUIRKS) r[2] = sl_mac_component<IS3D, QUIRKS, 2>(g, fs, fu, c.i, c.j, c.k, dt);   // Q12: 0 in ref
+    }
+  }
+  float* d = dst + (size_t)c.b * NC * g.DHW + o;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = r[a];
+}
+
+// min/max of channel `comp` of orig over the 4(8) corners at trunc(pos -/+ v)  (doClampComponentMAC :500-614)
+template <bool IS3D>
+__device__ __forceinline__ void clamp_bounds_mac(const GridDims& g, const float* __restrict__ oc, const float pos[3],
+                                                 const float v[3], float& mn, float& mx) {
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const int qx = (int)(l == 0 ? pos[0] - v[0] : pos[0] + v[0]);
+    const int qy = (int)(l == 0 ? pos[1] - v[1] : pos[1] + v[1]);
+    const int qz = (int)(l == 0 ? pos[2] - v[2] : pos[2] + v[2]);
+    const int i0 = clampi(qx, 0, g.W - 2), j0 = clampi(qy, 0, g.H - 2);
+    const int k0 = IS3D ? clampi(qz, 0, g.D - 2) : 0;
+    const float* q = oc + (size_t)k0 * g.HW + j0 * g.W + i0;
+    // reference visiting order: 000, 100, 010, 110 [, 001, 101, 011, 111] (x is the first digit)
+    float o;
+    o = q[0]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+    o = q[1]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+    o = q[g.W]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+    o = q[g.W + 1]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+    if (IS3D) {
+      const float* r = q + g.HW;
+      o = r[0]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+      o = r[1]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+      o = r[g.W]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+      o = r[g.W + 1]; mn = fminf(mn, o); mx = fmaxf(mx, o);
+    }
+  }
+}
+
+template <bool IS3D, bool QUIRKS, int COMP>
+__device__ __forceinline__ float mac_bwd_correct_clamp(const GridDims& g, const Field& forig, const Field& ffwd,
+                                                       const Field& fu, const Field& ff, int i, int j, int k, float dt,
+                                                       float half_s, bool fluid) {
+  const size_t o = (size_t)k * g.HW + j * g.W + i;
+  const float f = ffwd.p[(size_t)COMP * g.DHW + o];
+  float v[3];
+  get_at_mac<IS3D, QUIRKS, COMP>(g, fu, i, j, k, v);
+  // backward pass: SL(fwd, -dt): displacement v * (-(-dt)) == v * dt, also the clamp velocity (:640-648)
+  const float vd[3] = { v[0] * dt, v[1] * dt, v[2] * dt };
+  float bwd;
+  if (!fluid) {
+    bwd = COMP == 0 ? ffwd.p[(size_t)g.DHW + o] : (COMP == 1 ? 0.f : f);   // Q1 pass-through of SL(fwd)
+  } else if (COMP == 2 && QUIRKS) {
+    bwd = 0.f;
+  } else {
+    bwd = interpol<IS3D>(g, ffwd, COMP, ((float)i + 0.5f) + vd[0], ((float)j + 0.5f) + vd[1], ((float)k + 0.5f) + vd[2]);
+  }
+  // MacCormackCorrectMAC :453-498
+  bool skip = !fluid;
+  const int idx = COMP == 0 ? i : (COMP == 1 ? j : k);
+  if (idx > 0) {
+    const size_t om = o - (COMP == 0 ? 1 : (COMP == 1 ? g.W : g.HW));
+    if (ff.p[om] != FNX_FLUID) skip = true;
+  }
+  const float corr = skip ? f : f + half_s * (forig.p[(size_t)COMP * g.DHW + o] - bwd);
+  float mn = INFINITY, mx = -INFINITY;
+  const float pos[3] = { (float)i, (float)j, (float)k };
+  clamp_bounds_mac<IS3D>(g, forig.p + (size_t)COMP * g.DHW, pos, vd, mn, mx);
+  return fmaxf(fminf(corr, mx), mn);
+}
+
+template <bool IS3D, bool QUIRKS>
+__global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, float dt, float half_s,
+                                                                  const float* __restrict__ orig,
+                                                                  const float* __restrict__ fwd,
+                                                                  const float* __restrict__ U,
+                                                                  const float* __restrict__ flags,
+                                                                  float* __restrict__ dst) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const Field fo{orig + (size_t)c.b * NC * g.DHW}, fw{fwd + (size_t)c.b * NC * g.DHW},
+      fu{U + (size_t)c.b * NC * g.DHW}, ff{flags + (size_t)c.b * g.DHW};
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  float r[3] = { 0.f, 0.f, 0.f };
+  if (!is_border<IS3D>(g, c.i, c.j, c.k)) {
+    const bool fluid = ff.p[o] == FNX_FLUID;
+    r[0] = mac_bwd_correct_clamp<IS3D, QUIRKS, 0>(g, fo, fw, fu, ff, c.i, c.j, c.k, dt, half_s, fluid);
+    r[1] = mac_bwd_correct_clamp<IS3D, QUIRKS, 1>(g, fo, fw, fu, ff, c.i, c.j, c.k, dt, half_s, fluid);
+    if (IS3D) r[2] = mac_bwd_correct_clamp<IS3D, QUIRKS, 2>(g, fo, fw, fu, ff, c.i, c.j, c.k, dt, half_s, fluid);
+  }
+  float* d = dst + (size_t)c.b * NC * g.DHW + o;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = r[a];
+}
+
+inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D); }
+
+}  // namespace
+
+namespace fnx {
+
+#define DISPATCH3(IS3D, Q, SO, KERNEL, ...)                                                   \
+  do {                                                                                        \
+    if (IS3D) {                                                                               \
+      if (Q) { if (SO) KERNEL<true, true, true> __VA_ARGS__; else KERNEL<true, true, false> __VA_ARGS__; } \
+      else   { if (SO) KERNEL<true, false, true> __VA_ARGS__; else KERNEL<true, false, false> __VA_ARGS__; } \
+    } else {                                                                                  \
+      if (SO) KERNEL<false, false, true> __VA_ARGS__; else KERNEL<false, false, false> __VA_ARGS__; \
+    }                                                                                         \
+  } while (0)
+
+#define DISPATCH2(IS3D, Q, KERNEL, ...)                                                       \
+  do {                                                                                        \
+    if (IS3D) { if (Q) KERNEL<true, true> __VA_ARGS__; else KERNEL<true, false> __VA_ARGS__; } \
+    else KERNEL<false, false> __VA_ARGS__;                                                    \
+  } while (0)
+
+void launch_sl_scalar(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, const float* src,
+                      const float* U, const float* flags, float* dst, int* cell_out, hipStream_t s) {
+  const dim3 grid = cell_grid(g), block(BX, BY);
+  DISPATCH3(is3d, quirks, sample_outside, sl_scalar_kernel, <<<grid, block, 0, s>>>(g, dt, src, U, flags, dst, cell_out));
+}
+
+void launch_sl_scalar_bwd_clamp(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, float half_s,
+                                const float* src, const float* fwd, const int* cell_in, const float* U,
+                                const float* flags, float* dst, hipStream_t s) {
+  const dim3 grid = cell_grid(g), block(BX, BY);
+  DISPATCH3(is3d, quirks, sample_outside, sl_scalar_bwd_clamp_kernel,
+            <<<grid, block, 0, s>>>(g, dt, half_s, src, fwd, cell_in, U, flags, dst));
+}
+
+void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const float* src, const float* U,
+                   const float* flags, float* dst, hipStream_t s) {
+  const dim3 grid = cell_grid(g), block(BX, BY);
+  DISPATCH2(is3d, quirks, sl_mac_kernel, <<<grid, block, 0, s>>>(g, dt, src, U, flags, dst));
+}
+
+void launch_sl_mac_bwd_clamp(const GridDims& g, bool is3d, bool quirks, float dt, float half_s, const float* orig,
+                             const float* fwd, const float* U, const float* flags, float* dst, hipStream_t s) {
+  const dim3 grid = cell_grid(g), block(BX, BY);
+  DISPATCH2(is3d, quirks, sl_mac_bwd_clamp_kernel, <<<grid, block, 0, s>>>(g, dt, half_s, orig, fwd, U, flags, dst));
+}
+
+}  // namespace fnx

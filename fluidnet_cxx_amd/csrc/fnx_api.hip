@@ -1,0 +1,323 @@
+// C-ABI of libfluidnet_hip.so (include/fluidnet_hip.h): argument checks, workspace carving and the launch
+// sequences.  No allocation, no synchronisation (except fnx_jacobi with p_tol > 0), no CPU fallback.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fluidnet_hip.h"
+#include "fnx_cnn.h"
+#include "fnx_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_OK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return fail(FNX_EHIP, "HIP error: %s (%s)", hipGetErrorString(e_), #expr); \
+  } while (0)
+
+int check_grid(const FnxGrid* g) {
+  if (!g) return fail(FNX_EINVAL, "grid descriptor is NULL");
+  if (g->B < 1 || g->D < 1 || g->H < 3 || g->W < 3) return fail(FNX_EINVAL, "Dimension mismatch: B=%d D=%d H=%d W=%d", g->B, g->D, g->H, g->W);
+  if (!g->is3D && g->D != 1) return fail(FNX_EINVAL, "2D velocity field but zdepth > 1");
+  if (g->is3D && g->D < 3) return fail(FNX_EINVAL, "3D domain needs D >= 3");
+  if ((long long)g->D * g->H * g->W >= (1ll << 31)) return fail(FNX_EINVAL, "more than 2^31 cells per sample");
+  if ((long long)g->B * g->D > 65535) return fail(FNX_EINVAL, "B*D > 65535 not supported");
+  return FNX_OK;
+}
+
+inline GridDims dims(const FnxGrid* g) { return make_dims(g->B, g->D, g->H, g->W); }
+inline bool quirks(const FnxGrid* g) { return g->is3D && g->ref_quirks; }
+inline size_t ncell(const FnxGrid* g) { return (size_t)g->B * g->D * g->H * g->W; }
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+  char* base; size_t off, cap;
+  Carver(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+  void* take(size_t bytes) { void* r = base ? base + off : nullptr; off += al(bytes); return r; }
+  bool ok() const { return base != nullptr && off <= cap; }
+};
+
+size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4); }
+size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
+size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4); }
+size_t ws_step(const FnxGrid* g) {
+  const size_t nc = g->is3D ? 3 : 2;
+  size_t adv = ws_advect_scalar(g) > ws_advect_vel(g) ? ws_advect_scalar(g) : ws_advect_vel(g);
+  size_t solve = ws_jacobi(g);
+  size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D) + al(ncell(g) * 4 * (nc + 3));
+  size_t tail = adv > solve ? adv : solve;
+  if (cnn > tail) tail = cnn;
+  return al(ncell(g) * 4) /*rho2*/ + al(ncell(g) * 4 * nc) /*U2*/ + al(ncell(g) * 4) /*div*/ + tail;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fnx_last_error(void) { return g_err; }
+int fnx_abi_version(void) { return FNX_ABI_VERSION; }
+
+const char* fnx_device_name(void) {
+  static thread_local char name[256];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { fail(FNX_EHIP, "no HIP device"); return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { fail(FNX_EHIP, "no HIP device"); return nullptr; }
+  snprintf(name, sizeof(name), "%s (%s)", prop.name, prop.gcnArchName);
+  return name;
+}
+
+size_t fnx_workspace_bytes(const FnxGrid* g, int op) {
+  if (check_grid(g) != FNX_OK) return 0;
+  switch (op) {
+    case FNX_OP_ADVECT_SCALAR: return ws_advect_scalar(g);
+    case FNX_OP_ADVECT_VEL: return ws_advect_vel(g);
+    case FNX_OP_JACOBI: return ws_jacobi(g);
+    case FNX_OP_STEP: return ws_step(g);
+    case FNX_OP_FLUIDNET: return fnx::fluidnet_ws_bytes(dims(g), g->is3D);
+  }
+  fail(FNX_EINVAL, "unknown op %d", op);
+  return 0;
+}
+
+int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float* U, const float* flags, float* dst,
+                      int method, int bnd, int sample_outside, float strength, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!src || !U || !flags || !dst) return fail(FNX_EINVAL, "advect_scalar: NULL tensor");
+  if (dst == src) return fail(FNX_EINVAL, "advect_scalar: dst must not alias src");
+  if (method != FNX_ADVECT_EULER && method != FNX_ADVECT_MACCORMACK) return fail(FNX_EMETHOD, "Advection method not supported");
+  if (bnd != 1) return fail(FNX_EINVAL, "advect_scalar: only boundary_width == 1 is supported (the reference's MAC sampling strips exactly one border cell)");
+  hipStream_t s = (hipStream_t)stream;
+  const GridDims d = dims(g);
+  if (method == FNX_ADVECT_EULER) {
+    fnx::launch_sl_scalar(d, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, dst, nullptr, s);
+  } else {
+    Carver c(ws, ws_bytes);
+    float* fwd = (float*)c.take(ncell(g) * 4);
+    int* cell = (int*)c.take(ncell(g) * 4);
+    if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_scalar: workspace too small (%zu < %zu)", ws_bytes, c.off);
+    fnx::launch_sl_scalar(d, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s);
+    fnx::launch_sl_scalar_bwd_clamp(d, g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, src, fwd, cell, U,
+                                    flags, dst, s);
+  }
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags, float* dst,
+                   int method, int bnd, float strength, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!orig || !U || !flags || !dst) return fail(FNX_EINVAL, "advect_vel: NULL tensor");
+  if (dst == orig || dst == U) return fail(FNX_EINVAL, "advect_vel: dst must not alias orig or U");
+  if (method != FNX_ADVECT_EULER && method != FNX_ADVECT_MACCORMACK) return fail(FNX_EMETHOD, "Advection method not supported");
+  if (bnd != 1) return fail(FNX_EINVAL, "advect_vel: only boundary_width == 1 is supported");
+  hipStream_t s = (hipStream_t)stream;
+  const GridDims d = dims(g);
+  if (method == FNX_ADVECT_EULER) {
+    fnx::launch_sl_mac(d, g->is3D, quirks(g), dt, orig, U, flags, dst, s);
+  } else {
+    Carver c(ws, ws_bytes);
+    float* fwd = (float*)c.take(ncell(g) * 4 * (g->is3D ? 3 : 2));
+    if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_vel: workspace too small (%zu < %zu)", ws_bytes, c.off);
+    fnx::launch_sl_mac(d, g->is3D, quirks(g), dt, orig, U, flags, fwd, s);
+    fnx::launch_sl_mac_bwd_clamp(d, g->is3D, quirks(g), dt, strength * 0.5f, orig, fwd, U, flags, dst, s);
+  }
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags, float* div, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!U || !flags || !div) return fail(FNX_EINVAL, "velocity_divergence: NULL tensor");
+  fnx::launch_divergence(dims(g), g->is3D, U, flags, div, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual, float p_tol,
+               int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!flags || !div || !p) return fail(FNX_EINVAL, "solve_linear_system: NULL tensor");
+  if (max_iter < 1) return fail(FNX_EINVAL, "At least 1 iteration is needed (maxIter < 1)");
+  hipStream_t s = (hipStream_t)stream;
+  const GridDims d = dims(g);
+  Carver c(ws, ws_bytes);
+  float* tmp = (float*)c.take(ncell(g) * 4);
+  float* sumsq = (float*)c.take((size_t)g->B * 4);
+  float* res_ws = (float*)c.take(4);
+  if (!c.ok()) return fail(FNX_EWORKSPACE, "solve_linear_system: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  const bool q = quirks(g);
+  if (!(p_tol > 0.f)) {
+    const int kmax = fnx::jacobi_max_sweeps_per_launch(d, g->is3D);
+    const int nl = (max_iter + kmax - 1) / kmax;
+    if (residual) HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
+    int done = 0;
+    const float* in = nullptr;
+    for (int l = 0; l < nl; ++l) {
+      int k = max_iter - done < kmax ? max_iter - done : kmax;
+      // spread the remainder so that no launch runs a single sweep needlessly late
+      float* out = ((nl - 1 - l) % 2 == 0) ? p : tmp;
+      const bool last = l == nl - 1;
+      fnx::launch_jacobi(d, g->is3D, q, flags, div, in, out, k, l == 0, (last && residual) ? sumsq : nullptr, s);
+      in = out;
+      done += k;
+    }
+    if (residual) fnx::launch_residual_finish(g->B, sumsq, residual, s);
+    if (iters_done) *iters_done = done;
+  } else {
+    // the reference's own per-sweep convergence test (fluids_init.cpp:961-979): one host read per sweep
+    const float* in = nullptr;
+    float* bufs[2] = { p, tmp };
+    int sweeps = 0;
+    float r = 0.f;
+    for (;;) {
+      float* out = bufs[sweeps & 1];
+      HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
+      fnx::launch_jacobi(d, g->is3D, q, flags, div, in, out, 1, sweeps == 0, sumsq, s);
+      fnx::launch_residual_finish(g->B, sumsq, res_ws, s);
+      HIP_OK(hipMemcpyAsync(&r, res_ws, 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      in = out;
+      ++sweeps;
+      if (r < p_tol) break;
+      if (sweeps >= max_iter) break;
+    }
+    if (in != p) HIP_OK(hipMemcpyAsync(p, in, ncell(g) * 4, hipMemcpyDeviceToDevice, s));
+    if (residual) HIP_OK(hipMemcpyAsync(residual, res_ws, 4, hipMemcpyDeviceToDevice, s));
+    if (iters_done) *iters_done = sweeps;
+  }
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!p || !U || !flags) return fail(FNX_EINVAL, "velocity_update: NULL tensor");
+  fnx::launch_velocity_update(dims(g), g->is3D, p, U, flags, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_add_buoyancy(const FnxGrid* g, float* U, const float* flags, const float* density, const float gravity[3],
+                     float rho_star, float dt, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!U || !flags || !density || !gravity) return fail(FNX_EINVAL, "add_buoyancy: NULL tensor");
+  const float sx = gravity[0] * dt, sy = gravity[1] * dt, sz = gravity[2] * dt;   // strength = gravity * dt
+  fnx::launch_add_buoyancy(dims(g), g->is3D, quirks(g), U, flags, density, sx, sy, sz, rho_star, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_set_wall_bcs(const FnxGrid* g, float* U, const float* flags, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!U || !flags) return fail(FNX_EINVAL, "set_wall_bcs: NULL tensor");
+  fnx::launch_set_wall_bcs(dims(g), g->is3D, U, flags, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_set_const_vals(const FnxGrid* g, float* U, const float* UBC, const float* UBCInvMask, float* density,
+                       const float* densityBC, const float* densityBCInvMask, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (U && UBC && UBCInvMask) fnx::launch_set_const_vals(ncell(g) * (g->is3D ? 3 : 2), U, UBC, UBCInvMask, s);
+  if (density && densityBC && densityBCInvMask) fnx::launch_set_const_vals(ncell(g), density, densityBC, densityBCInvMask, s);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_flags_to_occupancy(const FnxGrid* g, const float* flags, float* occupancy, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!flags || !occupancy) return fail(FNX_EINVAL, "flags_to_occupancy: NULL tensor");
+  fnx::launch_flags_to_occupancy(ncell(g), flags, occupancy, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!flags) return fail(FNX_EINVAL, "empty_domain: NULL tensor");
+  if (boundary_width < 1) return fail(FNX_EINVAL, "Boundary width must be greater than zero!");
+  fnx::launch_empty_domain(dims(g), g->is3D, flags, boundary_width, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!prm || !st || !st->p || !st->U || !st->flags) return fail(FNX_EINVAL, "simulate_step: NULL state");
+  if (prm->method != 0 && prm->method != 1) return fail(FNX_EINVAL, "Simulation method not supported. Choose either convnet or jacobi.");
+  if (prm->method == 1 && !st->net) return fail(FNX_EINVAL, "simulate_step: convnet method needs packed weights");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = ncell(g), nc = g->is3D ? 3 : 2;
+  Carver c(ws, ws_bytes);
+  float* rho2 = (float*)c.take(n * 4);
+  float* U2 = (float*)c.take(n * 4 * nc);
+  float* div = (float*)c.take(n * 4);
+  void* tail = c.take(0);
+  const size_t tail_bytes = ws_bytes > c.off ? ws_bytes - c.off : 0;
+  if (!c.ok() || ws_bytes < ws_step(g)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small (%zu < %zu)", ws_bytes, ws_step(g));
+  const bool has_rho = st->density != nullptr;
+  // simulate.py:75-93: advect density then velocity (both by the OLD U)
+  if (has_rho) {
+    if (int rc = fnx_advect_scalar(g, prm->dt, st->density, st->U, st->flags, rho2, FNX_ADVECT_MACCORMACK, 1,
+                                   prm->sample_outside_fluid, prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
+  }
+  if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
+                              prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
+  if (has_rho) HIP_OK(hipMemcpyAsync(st->density, rho2, n * 4, hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipMemcpyAsync(st->U, U2, n * 4 * nc, hipMemcpyDeviceToDevice, s));
+  float* rho = has_rho ? st->density : nullptr;
+  // simulate.py:96
+  fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
+  // simulate.py:98-107
+  if (has_rho && prm->buoyancy_scale > 0.f) {
+    const float ns = -prm->buoyancy_scale;
+    const float grav[3] = { prm->gravity_vec[0] * ns, prm->gravity_vec[1] * ns, prm->gravity_vec[2] * ns };
+    if (int rc = fnx_add_buoyancy(g, st->U, st->flags, rho, grav, prm->operating_density, prm->dt, stream)) return rc;
+  }
+  // simulate.py:120-133
+  if (prm->method == 0) fnx_set_wall_bcs(g, st->U, st->flags, stream);
+  fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
+  if (prm->method == 0) {
+    // simulate.py:144-166
+    fnx_velocity_divergence(g, st->U, st->flags, div, stream);
+    if (int rc = fnx_jacobi(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, stream)) return rc;
+    fnx_velocity_update(g, st->p, st->U, st->flags, stream);
+    fnx_set_wall_bcs(g, st->U, st->flags, stream);
+  } else {
+    // simulate.py:136-142: data = cat(p, U, flags, density); p, U = net(data)
+    Carver t(tail, tail_bytes);
+    float* data = (float*)t.take(n * 4 * (nc + 3));
+    void* cws = t.take(0);
+    const size_t cws_bytes = tail_bytes > t.off ? tail_bytes - t.off : 0;
+    const size_t per = (size_t)g->D * g->H * g->W * 4;
+    for (int b = 0; b < g->B; ++b) {
+      char* dst = (char*)data + (size_t)b * (nc + 3) * per;
+      HIP_OK(hipMemcpyAsync(dst, (char*)st->p + b * per, per, hipMemcpyDeviceToDevice, s));
+      HIP_OK(hipMemcpyAsync(dst + per, (char*)st->U + b * nc * per, nc * per, hipMemcpyDeviceToDevice, s));
+      HIP_OK(hipMemcpyAsync(dst + (1 + nc) * per, (const char*)st->flags + b * per, per, hipMemcpyDeviceToDevice, s));
+      if (has_rho) HIP_OK(hipMemcpyAsync(dst + (2 + nc) * per, (char*)rho + b * per, per, hipMemcpyDeviceToDevice, s));
+      else HIP_OK(hipMemsetAsync(dst + (2 + nc) * per, 0, per, s));
+    }
+    if (int rc = fnx_fluidnet_forward(g, st->net, data, prm->normalize_threshold, st->p, st->U, cws, cws_bytes, stream)) return rc;
+  }
+  fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// MultiScale pressure-net (lib/multi_scale_net.py:21-127) -- internal interface of the conv stack.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fnx_device.h"
+
+namespace fnx {
+
+struct ConvLayer { int cin, cout, k, relu; };
+
+// channel plan, multi_scale_net.py:111-116 (Dropout = identity in eval)
+constexpr int N_LAYERS = 17;
+constexpr ConvLayer LAYERS[N_LAYERS] = {
+    // convN_4 (quarter resolution)
+    {2, 32, 3, 1}, {32, 64, 3, 1}, {64, 32, 3, 0}, {32, 1, 3, 0},
+    // convN_2 (half resolution)
+    {3, 32, 5, 1}, {32, 64, 3, 1}, {64, 128, 3, 1}, {128, 64, 3, 1}, {64, 32, 3, 0}, {32, 1, 3, 0},
+    // convN_1 (full resolution)
+    {3, 32, 5, 1}, {32, 64, 3, 1}, {64, 128, 3, 1}, {128, 64, 3, 1}, {64, 32, 3, 0}, {32, 8, 5, 0},
+    // final 1x1
+    {8, 1, 1, 0}};
+
+inline int layer_taps(const ConvLayer& L, bool is3d) { return L.k * L.k * (is3d ? L.k : 1); }
+inline size_t layer_weight_floats(const ConvLayer& L, bool is3d) { return (size_t)L.cout * L.cin * layer_taps(L, is3d); }
+
+size_t scalenet_weight_floats(bool is3d);
+size_t scalenet_packed_bytes(bool is3d);
+void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s);
+
+size_t multiscale_ws_bytes(const GridDims& g, bool is3d);
+size_t fluidnet_ws_bytes(const GridDims& g, bool is3d);
+
+// x (B,2,D,H,W) -> p (B,1,D,H,W)
+void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, void* ws,
+                        hipStream_t s);
+
+// pieces of FluidNet.forward (lib/model.py:76-227)
+void launch_scale_std(const GridDims& g, int nc, const float* U, float thr, double* partial /*2*B doubles*/,
+                      float* scale /*B*/, hipStream_t s);
+void launch_pack_input(const GridDims& g, int nc, const float* div, const float* flags, const float* scale, float* U,
+                       float* x, hipStream_t s);
+void launch_unscale(const GridDims& g, int nc, const float* scale, float* p, float* U, hipStream_t s);
+void launch_gather_input(const GridDims& g, int nc, const float* input, float* U, float* flags, hipStream_t s);
+
+}  // namespace fnx

@@ -1,0 +1,405 @@
+// MultiScale pressure-net forward (lib/multi_scale_net.py:118-127, lib/model.py:76-227) for gfx950.
+//
+// v0 conv path: direct fp32 convolution, one thread per output pixel x CO_T output channels, weights
+// streamed through the scalar cache (their address is wave-uniform), input taps through L1/L2.
+// (The implicit-GEMM MFMA kernel replaces conv_direct_kernel for the 32/64/128-channel layers.)
+#include "fnx_cnn.h"
+
+namespace fnx {
+
+namespace {
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int co_tile(int cout) { return cout >= 16 ? 16 : cout; }
+
+struct PackedLayer { size_t w_off, b_off; };   // float offsets into the packed buffer
+
+PackedLayer packed_layer(int l, bool is3d) {
+  size_t off = 0;
+  PackedLayer r{0, 0};
+  for (int i = 0; i <= l; ++i) {
+    r.w_off = off;
+    off += layer_weight_floats(LAYERS[i], is3d);
+    r.b_off = off;
+    off += LAYERS[i].cout;
+    off = (off + 63) & ~(size_t)63;
+  }
+  return r;
+}
+
+// blob: (Cout,Cin,taps) -> packed [Cout/CO_T][Cin][taps][CO_T]
+__global__ void pack_layer_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ pw,
+                                  float* __restrict__ pb, int cin, int cout, int taps, int cot) {
+  const int n = cin * cout * taps;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int co = q / (cin * taps);
+    const int r = q - co * cin * taps;
+    const int ci = r / taps, t = r - ci * taps;
+    const int grp = co / cot, tt = co - grp * cot;
+    pw[(((size_t)grp * cin + ci) * taps + t) * cot + tt] = w[q];
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
+}
+
+struct ConvArgs {
+  const float* x; float* y; const float* w; const float* bias;
+  int B, cin, cout, D, H, W, relu, groups;
+};
+
+template <int KS, int CO_T, bool IS3D>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+  constexpr int KD = IS3D ? KS : 1, PAD = KS / 2, PD = IS3D ? PAD : 0, TAPS = KD * KS * KS;
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  int z = blockIdx.z;
+  const int k = z % a.D; z /= a.D;
+  const int grp = z % a.groups; const int b = z / a.groups;
+  if (i >= a.W || j >= a.H) return;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
+  float acc[CO_T];
+#pragma unroll
+  for (int t = 0; t < CO_T; ++t) acc[t] = a.bias[grp * CO_T + t];
+  const float* wg = a.w + (size_t)grp * a.cin * TAPS * CO_T;
+  const float* xb = a.x + (size_t)b * a.cin * vol;
+  for (int ci = 0; ci < a.cin; ++ci) {
+    const float* xc = xb + (size_t)ci * vol;
+    const float* wc = wg + (size_t)ci * TAPS * CO_T;
+#pragma unroll
+    for (int dz = 0; dz < KD; ++dz) {
+      const int zz = k + dz - PD;
+      const bool zin = (zz >= 0) & (zz < a.D);
+#pragma unroll
+      for (int r = 0; r < KS; ++r) {
+        const int yy = j + r - PAD;
+        const bool yin = zin & (yy >= 0) & (yy < a.H);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int xx = i + s - PAD;
+          const bool in = yin & (xx >= 0) & (xx < a.W);
+          const float v = in ? xc[(size_t)zz * plane + (size_t)yy * a.W + xx] : 0.f;
+          const float* wt = wc + ((dz * KS + r) * KS + s) * CO_T;
+#pragma unroll
+          for (int t = 0; t < CO_T; ++t) acc[t] = fmaf(v, wt[t], acc[t]);
+        }
+      }
+    }
+  }
+  float* yb = a.y + ((size_t)b * a.cout + grp * CO_T) * vol + (size_t)k * plane + (size_t)j * a.W + i;
+#pragma unroll
+  for (int t = 0; t < CO_T; ++t) {
+    float v = acc[t];
+    if (a.relu) v = fmaxf(v, 0.f);
+    yb[(size_t)t * vol] = v;
+  }
+}
+
+template <int KS, bool IS3D>
+void launch_conv_k(const ConvArgs& a, hipStream_t s) {
+  const dim3 grid((a.W + 63) / 64, (a.H + 3) / 4, a.B * a.groups * a.D), block(64, 4);
+  const int cot = co_tile(a.cout);
+  if (cot == 16) conv_direct_kernel<KS, 16, IS3D><<<grid, block, 0, s>>>(a);
+  else if (cot == 8) conv_direct_kernel<KS, 8, IS3D><<<grid, block, 0, s>>>(a);
+  else conv_direct_kernel<KS, 1, IS3D><<<grid, block, 0, s>>>(a);
+}
+
+void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const PackedLayer& pl, const float* x, float* y,
+                 int B, int D, int H, int W, hipStream_t s) {
+  ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
+  if (is3d) {
+    if (L.k == 3) launch_conv_k<3, true>(a, s);
+    else if (L.k == 5) launch_conv_k<5, true>(a, s);
+    else launch_conv_k<1, true>(a, s);
+  } else {
+    if (L.k == 3) launch_conv_k<3, false>(a, s);
+    else if (L.k == 5) launch_conv_k<5, false>(a, s);
+    else launch_conv_k<1, false>(a, s);
+  }
+}
+
+// torch upsample_{bi,tri}linear(align_corners=False): src = scale*(dst+0.5)-0.5, clamped at 0
+__device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = (float)in / (float)out;
+  float sidx = scale * ((float)dst + 0.5f) - 0.5f;
+  if (sidx < 0.f) sidx = 0.f;
+  i0 = (int)sidx;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = sidx - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// x (B,C,Di,Hi,Wi) -> channels [c_off, c_off+C) of y (B,Ctot,Do,Ho,Wo)
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
+                                                     int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Ctot,
+                                                     int c_off) {
+  const size_t n = (size_t)B * C * Do * Ho * Wo;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    size_t r = q;
+    const int i = r % Wo; r /= Wo;
+    const int j = r % Ho; r /= Ho;
+    const int k = r % Do; r /= Do;
+    const int c = r % C; const int b = r / C;
+    int x0, x1, y0, y1, z0, z1; float s0, s1, t0, t1, f0, f1;
+    src_index(i, Wi, Wo, x0, x1, s0, s1);
+    src_index(j, Hi, Ho, y0, y1, t0, t1);
+    src_index(k, Di, Do, z0, z1, f0, f1);
+    const float* xi = x + ((size_t)b * C + c) * Di * Hi * Wi;
+#define XI(zz, yy, xx) xi[((size_t)(zz) * Hi + (yy)) * Wi + (xx)]
+    const float lo = t0 * (s0 * XI(z0, y0, x0) + s1 * XI(z0, y0, x1)) + t1 * (s0 * XI(z0, y1, x0) + s1 * XI(z0, y1, x1));
+    float v = lo;
+    if (Di > 1 || Do > 1) {
+      const float hi = t0 * (s0 * XI(z1, y0, x0) + s1 * XI(z1, y0, x1)) + t1 * (s0 * XI(z1, y1, x0) + s1 * XI(z1, y1, x1));
+      v = f0 * lo + f1 * hi;
+    }
+#undef XI
+    y[(((size_t)b * Ctot + c_off + c) * Do + k) * Ho * Wo + (size_t)j * Wo + i] = v;
+  }
+}
+
+void launch_resize(const float* x, float* y, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Ctot,
+                   int c_off, hipStream_t s) {
+  const size_t n = (size_t)B * C * Do * Ho * Wo;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  resize_kernel<<<(int)blocks, 256, 0, s>>>(x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, Ctot, c_off);
+}
+
+struct Sizes { int Dq, Hq, Wq, Dh, Hh, Wh; };
+inline Sizes sizes(const GridDims& g, bool is3d) {
+  Sizes z;
+  z.Dq = is3d ? (int)(g.D * 0.25) : 1; z.Hq = (int)(g.H * 0.25); z.Wq = (int)(g.W * 0.25);
+  z.Dh = is3d ? (int)(g.D * 0.5) : 1; z.Hh = (int)(g.H * 0.5); z.Wh = (int)(g.W * 0.5);
+  return z;
+}
+
+}  // namespace
+
+size_t scalenet_weight_floats(bool is3d) {
+  size_t n = 0;
+  for (int l = 0; l < N_LAYERS; ++l) n += layer_weight_floats(LAYERS[l], is3d) + LAYERS[l].cout;
+  return n;
+}
+
+size_t scalenet_packed_bytes(bool is3d) {
+  const PackedLayer last = packed_layer(N_LAYERS - 1, is3d);
+  return al256((last.b_off + LAYERS[N_LAYERS - 1].cout + 64) * sizeof(float));
+}
+
+void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
+  size_t off = 0;
+  float* pk = (float*)packed;
+  for (int l = 0; l < N_LAYERS; ++l) {
+    const ConvLayer& L = LAYERS[l];
+    const PackedLayer pl = packed_layer(l, is3d);
+    const size_t nw = layer_weight_floats(L, is3d);
+    pack_layer_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
+                                         layer_taps(L, is3d), co_tile(L.cout));
+    off += nw + L.cout;
+  }
+}
+
+// workspace: two ping-pong activation buffers of 128 channels at full resolution + the small tower I/O
+size_t multiscale_ws_bytes(const GridDims& g, bool is3d) {
+  const Sizes z = sizes(g, is3d);
+  const size_t full = (size_t)g.B * g.DHW, half = (size_t)g.B * z.Dh * z.Hh * z.Wh, quart = (size_t)g.B * z.Dq * z.Hq * z.Wq;
+  return 2 * al256(full * 128 * 4) + al256(full * 3 * 4) + al256(half * 3 * 4) + al256(quart * 2 * 4) +
+         al256(half * 4) + al256(quart * 4);
+}
+
+void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, void* ws,
+                        hipStream_t s) {
+  const Sizes z = sizes(g, is3d);
+  const size_t full = (size_t)g.B * g.DHW, half = (size_t)g.B * z.Dh * z.Hh * z.Wh, quart = (size_t)g.B * z.Dq * z.Hq * z.Wq;
+  char* w = (char*)ws;
+  float* bufA = (float*)w; w += al256(full * 128 * 4);
+  float* bufB = (float*)w; w += al256(full * 128 * 4);
+  float* in1 = (float*)w; w += al256(full * 3 * 4);
+  float* in2 = (float*)w; w += al256(half * 3 * 4);
+  float* xq = (float*)w; w += al256(quart * 2 * 4);
+  float* c2 = (float*)w; w += al256(half * 4);
+  float* c4 = (float*)w;
+  const float* pk = (const float*)packed;
+  auto tower = [&](int l0, int n, const float* in, float* out, int D, int H, int W) {
+    const float* cur = in;
+    for (int l = 0; l < n; ++l) {
+      float* dst = (l == n - 1) ? out : ((l & 1) ? bufB : bufA);
+      launch_conv(LAYERS[l0 + l], is3d, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s);
+      cur = dst;
+    }
+  };
+  // multi_scale_net.py:119-126
+  launch_resize(x, xq, g.B, 2, g.D, g.H, g.W, z.Dq, z.Hq, z.Wq, 2, 0, s);
+  tower(0, 4, xq, c4, z.Dq, z.Hq, z.Wq);
+  launch_resize(x, in2, g.B, 2, g.D, g.H, g.W, z.Dh, z.Hh, z.Wh, 3, 0, s);
+  launch_resize(c4, in2, g.B, 1, z.Dq, z.Hq, z.Wq, z.Dh, z.Hh, z.Wh, 3, 2, s);
+  tower(4, 6, in2, c2, z.Dh, z.Hh, z.Wh);
+  launch_resize(x, in1, g.B, 2, g.D, g.H, g.W, g.D, g.H, g.W, 3, 0, s);
+  launch_resize(c2, in1, g.B, 1, z.Dh, z.Hh, z.Wh, g.D, g.H, g.W, 3, 2, s);
+  // convN_1 (6 layers) then final 1x1: 7 convs, the last one writes p
+  tower(10, 7, in1, p, g.D, g.H, g.W);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FluidNet.forward glue
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// _ScaleNet (model.py:8-23): unbiased std over C*D*H*W per sample, clamp(thr, inf)
+__global__ __launch_bounds__(256) void std_partial_kernel(size_t n, const float* __restrict__ U, double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const float* u = U + (size_t)b * n;
+  double s = 0.0, ss = 0.0;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const double v = u[q];
+    s += v; ss += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&partial[2 * b], s); atomicAdd(&partial[2 * b + 1], ss); }
+}
+
+__global__ void std_finish_kernel(int B, size_t n, const double* __restrict__ partial, float thr, float* __restrict__ scale) {
+  const int b = threadIdx.x;
+  if (b < B) {
+    const double s = partial[2 * b], ss = partial[2 * b + 1];
+    double var = (ss - s * s / (double)n) / (double)(n - 1);
+    if (var < 0.0) var = 0.0;
+    const float sd = (float)sqrt(var);
+    scale[b] = sd < thr ? thr : sd;
+  }
+}
+
+// x[b,0] = div/s ; x[b,1] = occupancy(flags) ; U /= s      (model.py:129-168)
+__global__ __launch_bounds__(256) void pack_input_kernel(size_t n1, int nc, const float* __restrict__ div,
+                                                         const float* __restrict__ flags,
+                                                         const float* __restrict__ scale, float* __restrict__ U,
+                                                         float* __restrict__ x) {
+  const int b = blockIdx.y;
+  const float s = scale[b];
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n1; q += (size_t)gridDim.x * 256) {
+    x[((size_t)b * 2) * n1 + q] = div[(size_t)b * n1 + q] / s;
+    const float f = flags[(size_t)b * n1 + q];
+    x[((size_t)b * 2 + 1) * n1 + q] = f == FNX_FLUID ? 0.f : (f == FNX_OBST ? 1.f : f);
+    for (int c = 0; c < nc; ++c) {
+      const size_t o = ((size_t)b * nc + c) * n1 + q;
+      U[o] = U[o] / s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void unscale_kernel(size_t n1, int nc, const float* __restrict__ scale,
+                                                      float* __restrict__ p, float* __restrict__ U) {
+  const int b = blockIdx.y;
+  const float s = scale[b];
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n1; q += (size_t)gridDim.x * 256) {
+    p[(size_t)b * n1 + q] = p[(size_t)b * n1 + q] * s;
+    for (int c = 0; c < nc; ++c) {
+      const size_t o = ((size_t)b * nc + c) * n1 + q;
+      U[o] = U[o] * s;
+    }
+  }
+}
+
+// input (B, nc+3, ...) = [p, U, flags, rho] -> U (B,nc,...), flags (B,1,...)
+__global__ __launch_bounds__(256) void gather_input_kernel(size_t n1, int nc, const float* __restrict__ input,
+                                                           float* __restrict__ U, float* __restrict__ flags) {
+  const int b = blockIdx.y;
+  const float* in = input + (size_t)b * (nc + 3) * n1;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n1; q += (size_t)gridDim.x * 256) {
+    for (int c = 0; c < nc; ++c) U[((size_t)b * nc + c) * n1 + q] = in[(size_t)(1 + c) * n1 + q];
+    flags[(size_t)b * n1 + q] = in[(size_t)(1 + nc) * n1 + q];
+  }
+}
+
+inline dim3 bgrid(size_t n1, int B) {
+  size_t blocks = (n1 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  return dim3((unsigned)blocks, B);
+}
+
+}  // namespace
+
+void launch_scale_std(const GridDims& g, int nc, const float* U, float thr, double* partial, float* scale, hipStream_t s) {
+  const size_t n = (size_t)nc * g.DHW;
+  hipMemsetAsync(partial, 0, sizeof(double) * 2 * g.B, s);
+  std_partial_kernel<<<bgrid(n, g.B), 256, 0, s>>>(n, U, partial);
+  std_finish_kernel<<<1, 64 * ((g.B + 63) / 64), 0, s>>>(g.B, n, partial, thr, scale);
+}
+
+void launch_pack_input(const GridDims& g, int nc, const float* div, const float* flags, const float* scale, float* U,
+                       float* x, hipStream_t s) {
+  pack_input_kernel<<<bgrid(g.DHW, g.B), 256, 0, s>>>((size_t)g.DHW, nc, div, flags, scale, U, x);
+}
+
+void launch_unscale(const GridDims& g, int nc, const float* scale, float* p, float* U, hipStream_t s) {
+  unscale_kernel<<<bgrid(g.DHW, g.B), 256, 0, s>>>((size_t)g.DHW, nc, scale, p, U);
+}
+
+void launch_gather_input(const GridDims& g, int nc, const float* input, float* U, float* flags, hipStream_t s) {
+  gather_input_kernel<<<bgrid(g.DHW, g.B), 256, 0, s>>>((size_t)g.DHW, nc, input, U, flags);
+}
+
+size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
+  const size_t full = (size_t)g.B * g.DHW;
+  return multiscale_ws_bytes(g, is3d) + al256(full * 4) /*flags*/ + al256(full * 4) /*div*/ + al256(full * 2 * 4) /*x*/ +
+         al256(sizeof(double) * 2 * g.B) + al256(sizeof(float) * g.B);
+}
+
+}  // namespace fnx
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI (include/fluidnet_hip.h)
+// ---------------------------------------------------------------------------------------------------
+#include "../../include/fluidnet_hip.h"
+
+extern "C" {
+
+size_t fnx_scalenet_weight_floats(int is3D) { return fnx::scalenet_weight_floats(is3D != 0); }
+size_t fnx_scalenet_packed_bytes(int is3D) { return fnx::scalenet_packed_bytes(is3D != 0); }
+
+int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* stream) {
+  if (!weights_blob || !packed) return FNX_EINVAL;
+  fnx::scalenet_pack(is3D != 0, weights_blob, packed, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+}
+
+int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, void* ws, size_t ws_bytes,
+                           void* stream) {
+  if (!g || !packed || !x || !p || !ws) return FNX_EINVAL;
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W);
+  if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
+  fnx::multiscale_forward(d, g->is3D, packed, x, p, ws, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+}
+
+int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float thr, float* p_out,
+                         float* U_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !packed || !input || !p_out || !U_out || !ws) return FNX_EINVAL;
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W);
+  if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = g->is3D ? 3 : 2;
+  const size_t full = (size_t)g->B * d.DHW;
+  char* w = (char*)ws;
+  auto take = [&](size_t bytes) { void* r = w; w += (bytes + 255) & ~(size_t)255; return r; };
+  float* flags = (float*)take(full * 4);
+  float* div = (float*)take(full * 4);
+  float* x = (float*)take(full * 2 * 4);
+  double* partial = (double*)take(sizeof(double) * 2 * g->B);
+  float* scale = (float*)take(sizeof(float) * g->B);
+  void* msws = w;
+  // model.py:104-126
+  fnx::launch_gather_input(d, nc, input, U_out, flags, s);
+  if (int rc = fnx_velocity_divergence(g, U_out, flags, div, stream)) return rc;
+  // model.py:129-168
+  fnx::launch_scale_std(d, nc, U_out, thr, partial, scale, s);
+  fnx::launch_pack_input(d, nc, div, flags, scale, U_out, x, s);
+  // model.py:174-175
+  fnx::multiscale_forward(d, g->is3D, packed, x, p_out, msws, s);
+  // model.py:213-227
+  if (int rc = fnx_velocity_update(g, p_out, U_out, flags, stream)) return rc;
+  fnx::launch_unscale(d, nc, scale, p_out, U_out, s);
+  if (int rc = fnx_set_wall_bcs(g, U_out, flags, stream)) return rc;
+  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// Host-side launch wrappers of the gfx950 kernels (internal to libfluidnet_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fnx_device.h"
+
+namespace fnx {
+
+// advection (fnx_advect.hip)
+void launch_sl_scalar(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, const float* src,
+                      const float* U, const float* flags, float* dst, int* cell_out, hipStream_t s);
+void launch_sl_scalar_bwd_clamp(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, float half_s,
+                                const float* src, const float* fwd, const int* cell_in, const float* U,
+                                const float* flags, float* dst, hipStream_t s);
+void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const float* src, const float* U,
+                   const float* flags, float* dst, hipStream_t s);
+void launch_sl_mac_bwd_clamp(const GridDims& g, bool is3d, bool quirks, float dt, float half_s, const float* orig,
+                             const float* fwd, const float* U, const float* flags, float* dst, hipStream_t s);
+
+// stencils (fnx_stencils.hip)
+void launch_divergence(const GridDims& g, bool is3d, const float* U, const float* flags, float* div, hipStream_t s);
+void launch_velocity_update(const GridDims& g, bool is3d, const float* p, float* U, const float* flags, hipStream_t s);
+void launch_add_buoyancy(const GridDims& g, bool is3d, bool quirks, float* U, const float* flags, const float* rho,
+                         float sx, float sy, float sz, float rho_star, hipStream_t s);
+void launch_set_wall_bcs(const GridDims& g, bool is3d, float* U, const float* flags, hipStream_t s);
+void launch_set_const_vals(size_t n, float* x, const float* bc, const float* inv_mask, hipStream_t s);
+void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStream_t s);
+void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s);
+
+// Jacobi (fnx_jacobi.hip)
+// `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is
+// not read.  sumsq (B floats, pre-zeroed) receives sum (p_n - p_{n-1})^2 of the last sweep when non-null.
+void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags, const float* div, const float* p_in,
+                   float* p_out, int nsweeps, bool from_zero, float* sumsq, hipStream_t s);
+int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d);
+void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
+void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s);
+
+}  // namespace fnx

@@ -1,0 +1,206 @@
+// Radius-1 stencil operators of the fluid step for gfx950: velocityDivergence, velocityUpdate,
+// addBuoyancy, setWallBcs, setConstVals, flagsToOccupancy, emptyDomain.
+//
+// All are HBM-bound streaming kernels (arithmetic intensity < 1 FLOP/B): one thread per cell, x fastest,
+// 64x4 blocks so each wave reads/writes 256 contiguous bytes per field row; the +-1 neighbours in x come
+// out of the same cache lines, the +-1 rows out of L1/L2.  The reference implements these as 29-92 ATen
+// ops each.
+#include "fnx_device.h"
+#include "fnx_kernels.h"
+
+namespace {
+
+constexpr int BX = 64, BY = 4;
+
+struct CellId { int b, k, j, i; bool valid; };
+
+template <bool IS3D>
+__device__ __forceinline__ CellId cell_id(const GridDims& g) {
+  CellId c;
+  c.i = blockIdx.x * BX + threadIdx.x;
+  c.j = blockIdx.y * BY + threadIdx.y;
+  const int bk = blockIdx.z;
+  c.b = IS3D ? bk / g.D : bk;
+  c.k = IS3D ? bk - c.b * g.D : 0;
+  c.valid = (c.i < g.W) & (c.j < g.H);
+  return c;
+}
+
+inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D); }
+
+// velocityDivergence, lib/fluid/velocity_divergence.py:46-74
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void divergence_kernel(GridDims g, const float* __restrict__ U,
+                                                            const float* __restrict__ flags, float* __restrict__ div) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* u = U + (size_t)c.b * NC * g.DHW + o;
+  float d = 0.f;
+  if (!is_border<IS3D>(g, c.i, c.j, c.k)) {
+    d = ((u[0] - u[1]) + u[g.DHW]) - u[(size_t)g.DHW + g.W];
+    if (IS3D) d = d + (u[(size_t)2 * g.DHW] - u[(size_t)2 * g.DHW + g.HW]);
+  }
+  if (flags[(size_t)c.b * g.DHW + o] == FNX_OBST) d = 0.f;
+  div[(size_t)c.b * g.DHW + o] = d;
+}
+
+// velocityUpdate, lib/fluid/velocity_update.py:47-149 (2D); 3D: fluid-fluid faces only
+// (solver_cpp/src/projection/update_vel.cpp:58-117 -- the reference's own 3D branch raises)
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void velocity_update_kernel(GridDims g, const float* __restrict__ p,
+                                                                 float* __restrict__ U,
+                                                                 const float* __restrict__ flags) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid || is_border<IS3D>(g, c.i, c.j, c.k)) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  const float* pp = p + (size_t)c.b * g.DHW + o;
+  float* u = U + (size_t)c.b * NC * g.DHW + o;
+  const float fc = fl[0], P = pp[0];
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+    const float fm = *(fl - off), Pm = *(pp - off);
+    const float uc = u[(size_t)a * g.DHW];
+    const float m_ff = (fc == FNX_FLUID && fm == FNX_FLUID) ? 1.f : 0.f;
+    float r;
+    if (!IS3D) {
+      const float m_fe = (fc == FNX_FLUID && fm == FNX_EMPTY) ? 1.f : 0.f;
+      const float m_ef = (fc == FNX_EMPTY && fm == FNX_FLUID) ? 1.f : 0.f;
+      const float m_nf = (fc == FNX_EMPTY && fm == FNX_EMPTY) ? 1.f : 0.f;
+      r = ((m_ff * (uc - (P - Pm)) + m_fe * (uc - P)) + m_ef * (uc + Pm)) + m_nf * 0.f;
+    } else {
+      r = m_ff * (uc - (P - Pm));
+    }
+    u[(size_t)a * g.DHW] = r;
+  }
+}
+
+// addBuoyancy, lib/fluid/source_terms.py:47-116
+template <bool IS3D, bool QUIRKS>
+__global__ __launch_bounds__(BX* BY) void add_buoyancy_kernel(GridDims g, float* __restrict__ U,
+                                                              const float* __restrict__ flags,
+                                                              const float* __restrict__ rho, float sx, float sy,
+                                                              float sz, float rho_star) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid || is_border<IS3D>(g, c.i, c.j, c.k)) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  if (fl[0] != FNX_FLUID) return;
+  const float* r = rho + (size_t)c.b * g.DHW + o;
+  float* u = U + (size_t)c.b * NC * g.DHW + o;
+  const float rc = r[0];
+  if (*(fl - 1) == FNX_FLUID) u[0] = u[0] + sx * ((0.5f * (rc + *(r - 1))) - rho_star);
+  if (*(fl - g.W) == FNX_FLUID) u[g.DHW] = u[g.DHW] + sy * ((0.5f * (rc + *(r - g.W))) - rho_star);
+  if (IS3D) {
+    if (*(fl - g.HW) == FNX_FLUID) {
+      float* uz = u + (size_t)2 * g.DHW;
+      if (!QUIRKS) *uz = *uz + sz * ((0.5f * (rc + *(r - g.HW))) - rho_star);
+      else *uz = *uz + sz * (0.5f * (rc + (c.k <= 1 ? 0.f : *(r - g.HW))));      // source_terms.py:110-114
+    }
+  }
+}
+
+// setWallBcs, lib/fluid/set_wall_bcs.py:45-84
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void set_wall_bcs_kernel(GridDims g, float* __restrict__ U,
+                                                              const float* __restrict__ flags) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  const float fc = fl[0];
+  if (fc != FNX_FLUID && fc != FNX_OBST) return;
+  float* u = U + (size_t)c.b * NC * g.DHW + o;
+  const float fx = c.i > 0 ? *(fl - 1) : fc;          // i_l = max(i-1, 0): column 0 sees itself
+  const float fy = c.j > 0 ? *(fl - g.W) : fc;
+  if (fx == FNX_OBST || (fc == FNX_OBST && fx == FNX_FLUID)) u[0] = 0.f;
+  if (fy == FNX_OBST || (fc == FNX_OBST && fy == FNX_FLUID)) u[g.DHW] = 0.f;
+  if (IS3D && c.k > 0) {
+    const float fz = *(fl - g.HW);
+    if (fz == FNX_OBST || (fc == FNX_OBST && fz == FNX_FLUID)) u[(size_t)2 * g.DHW] = 0.f;
+  }
+}
+
+// setConstVals, lib/simulate.py:16-25: x = x*inv_mask + bc (two roundings)
+__global__ __launch_bounds__(256) void set_const_vals_kernel(size_t n, float* __restrict__ x,
+                                                             const float* __restrict__ bc,
+                                                             const float* __restrict__ inv_mask) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const float t = x[q] * inv_mask[q];
+    x[q] = t + bc[q];
+  }
+}
+
+// flagsToOccupancy, lib/fluid/flags_to_occupancy.py:14-19
+__global__ __launch_bounds__(256) void occupancy_kernel(size_t n, const float* __restrict__ flags,
+                                                        float* __restrict__ occ) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const float f = flags[q];
+    occ[q] = f == FNX_FLUID ? 0.f : (f == FNX_OBST ? 1.f : f);
+  }
+}
+
+// emptyDomain, lib/fluid/util.py:5-47
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void empty_domain_kernel(GridDims g, float* __restrict__ flags, int bnd) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  bool border = (c.i < bnd) | (c.i > g.W - 1 - bnd) | (c.j < bnd) | (c.j > g.H - 1 - bnd);
+  if (IS3D) border = border | (c.k < bnd) | (c.k > g.D - 1 - bnd);
+  flags[(size_t)c.b * g.DHW + (size_t)c.k * g.HW + c.j * g.W + c.i] = border ? FNX_OBST : FNX_FLUID;
+}
+
+inline int stream_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+}  // namespace
+
+namespace fnx {
+
+void launch_divergence(const GridDims& g, bool is3d, const float* U, const float* flags, float* div, hipStream_t s) {
+  if (is3d) divergence_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, div);
+  else divergence_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, div);
+}
+
+void launch_velocity_update(const GridDims& g, bool is3d, const float* p, float* U, const float* flags, hipStream_t s) {
+  if (is3d) velocity_update_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, p, U, flags);
+  else velocity_update_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, p, U, flags);
+}
+
+void launch_add_buoyancy(const GridDims& g, bool is3d, bool quirks, float* U, const float* flags, const float* rho,
+                         float sx, float sy, float sz, float rho_star, hipStream_t s) {
+  if (is3d) {
+    if (quirks) add_buoyancy_kernel<true, true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, rho, sx, sy, sz, rho_star);
+    else add_buoyancy_kernel<true, false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, rho, sx, sy, sz, rho_star);
+  } else {
+    add_buoyancy_kernel<false, false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, rho, sx, sy, sz, rho_star);
+  }
+}
+
+void launch_set_wall_bcs(const GridDims& g, bool is3d, float* U, const float* flags, hipStream_t s) {
+  if (is3d) set_wall_bcs_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags);
+  else set_wall_bcs_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags);
+}
+
+void launch_set_const_vals(size_t n, float* x, const float* bc, const float* inv_mask, hipStream_t s) {
+  set_const_vals_kernel<<<stream_blocks(n), 256, 0, s>>>(n, x, bc, inv_mask);
+}
+
+void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStream_t s) {
+  occupancy_kernel<<<stream_blocks(n), 256, 0, s>>>(n, flags, occ);
+}
+
+void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s) {
+  if (is3d) empty_domain_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, bnd);
+  else empty_domain_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, bnd);
+}
+
+}  // namespace fnx

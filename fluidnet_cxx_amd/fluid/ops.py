@@ -1,0 +1,122 @@
+"""Operator wrappers with the reference's Python signatures.
+
+Each function cites the reference function it replaces; argument checks mirror the reference's asserts
+(AssertionError for shape errors raised on the Python side, RuntimeError from the native side).
+"""
+import torch
+
+from .._ext import ext
+
+
+def _check_advection_method(method):
+    # cpp/advection.py:4-7
+    assert method in ("eulerFluidNet", "maccormackFluidNet"), \
+        "Error: Advection method not supported. Options are: maccormackFluidNet, eulerFluidNet"
+
+
+def _check5(*ts):
+    for t in ts:
+        assert t.dim() == 5, "Dimension mismatch"
+        assert t.is_contiguous(), "Input is not contiguous"
+
+
+def getDx(self):
+    """lib/fluid/grid.py:3-6"""
+    return 1.0 / max(self.size(2), self.size(3), self.size(4))
+
+
+def advectScalar(dt, src, U, flags, method="maccormackFluidNet", boundary_width=1, sample_outside_fluid=False,
+                 maccormack_strength=0.75):
+    """cpp/advection.py:14-66 -> pybind advect_scalar (cpp/fluids_init.cpp:265-382). 3D is supported here."""
+    _check_advection_method(method)
+    _check5(src, U, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    is3D = U.size(1) == 3
+    if not is3D:
+        assert flags.size(2) == 1, "2D velocity field but zdepth > 1"
+        assert U.size(1) == 2, "2D velocity field must have only 2 channels"
+    assert U.size(0) == flags.size(0) and U.shape[2:] == flags.shape[2:], "Size mismatch"
+    return ext.advect_scalar(float(dt), src, U, flags, method, int(boundary_width), bool(sample_outside_fluid),
+                             float(maccormack_strength))
+
+
+def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_width=1, maccormack_strength=0.75):
+    """cpp/advection.py:68-118 -> pybind advect_vel (cpp/fluids_init.cpp:656-807)."""
+    _check_advection_method(method)
+    _check5(orig, U, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    is3D = U.size(1) == 3
+    if not is3D:
+        assert flags.size(2) == 1, "2D velocity field but zdepth > 1"
+        assert orig.size(1) == 2 and U.size(1) == 2, "2D velocity field must have only 2 channels"
+    assert U.shape == orig.shape and U.size(0) == flags.size(0) and U.shape[2:] == flags.shape[2:], "Size mismatch"
+    return ext.advect_vel(float(dt), orig, U, flags, method, int(boundary_width), float(maccormack_strength))
+
+
+def correctScalar(dt, src, div, flags):
+    """cpp/advection.py:9-12 (off in all shipped configs): src += dt*0.5*src*div on fluid cells, in place."""
+    maskFluid = flags.eq(1)
+    src.copy_(torch.where(maskFluid, src + dt * 0.5 * src * div, src))
+
+
+def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, verbose=False):
+    """cpp/solve_linear_sys.py:4-40 -> pybind solve_linear_system (cpp/fluids_init.cpp:809-1004).
+    Returns (p, residual) with residual a 0-dim tensor, like the reference."""
+    _check5(div, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    assert div.shape == flags.shape, "Size mismatch"
+    p, res = ext.solve_linear_system(flags, div, bool(is_3d), float(p_tol), int(max_iter), bool(verbose))
+    return p, res
+
+
+def velocityDivergence(U, flags):
+    """lib/fluid/velocity_divergence.py:4-74"""
+    _check5(U, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    return ext.velocity_divergence(U, flags)
+
+
+def velocityUpdate(pressure, U, flags):
+    """lib/fluid/velocity_update.py:6-162 -- in place on U, returns None."""
+    _check5(pressure, U, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    assert pressure.shape == flags.shape, "size mismatch"
+    ext.velocity_update_(pressure, U, flags)
+
+
+def addBuoyancy(U, flags, density, gravity, rho_star, dt):
+    """lib/fluid/source_terms.py:6-116 -- in place on U, returns U.  gravity: 3 floats (tensor or sequence)."""
+    _check5(U, flags, density)
+    assert flags.size(1) == 1, "flags is not scalar"
+    g = gravity.detach().cpu().tolist() if torch.is_tensor(gravity) else [float(x) for x in gravity]
+    assert len(g) == 3, "Gravity must be a 3D vector (even in 2D)"
+    ext.add_buoyancy_(U, flags, density, g, float(rho_star), float(dt))
+    return U
+
+
+def setWallBcs(U, flags):
+    """lib/fluid/set_wall_bcs.py:4-86 -- in place on U, returns U."""
+    _check5(U, flags)
+    assert flags.size(1) == 1, "flags is not a scalar"
+    ext.set_wall_bcs_(U, flags)
+    return U
+
+
+def flagsToOccupancy(flags):
+    """lib/fluid/flags_to_occupancy.py:6-19"""
+    return ext.flags_to_occupancy(flags)
+
+
+def setConstVals(batch_dict, p, U, flags, density):
+    """lib/simulate.py:4-26 (same side effects on batch_dict: stores clones)."""
+    has_u = ("UBCInvMask" in batch_dict) and ("UBC" in batch_dict)
+    has_r = ("densityBCInvMask" in batch_dict) and ("densityBC" in batch_dict)
+    if not (has_u or has_r):
+        return
+    ext.set_const_vals_(U, batch_dict["UBC"] if has_u else None, batch_dict["UBCInvMask"] if has_u else None,
+                        density if has_r else None, batch_dict["densityBC"] if has_r else None,
+                        batch_dict["densityBCInvMask"] if has_r else None)
+    if has_u:
+        batch_dict["U"] = U.clone()
+    if has_r:
+        batch_dict["density"] = density.clone()

@@ -1,0 +1,150 @@
+/*
+ * fluidnet_hip.h -- C ABI of libfluidnet_hip.so, the MI355X (gfx950) fluid time-step library.
+ *
+ * This is the drop-in boundary for fluidnet_cxx's operator surface.  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference repo root).  The torch
+ * cpp-extension `fluidnet_cpp` (fluidnet_cxx_amd/csrc/fluidnet_cpp.cpp) binds these 1:1 behind
+ * the reference's three pybind names (pytorch/lib/fluid/cpp/fluids_init.cpp:1009-1014) plus the
+ * operators the reference implements in Python; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every tensor is a caller-owned DEVICE pointer on the current HIP device, fp32, contiguous
+ *    (B,C,D,H,W) with x fastest; 2D == D=1 with 2 velocity channels, 3D has 3.  `flags` is fp32
+ *    holding Manta cell types exactly as the reference passes them (cpp/cell_type.h:7-18).
+ *  - nothing is allocated, retained or freed; scratch comes from the caller's `ws` buffer
+ *    (size from fnx_workspace_bytes); outputs are caller-allocated.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t, may be NULL = default stream) and
+ *    returns without synchronising, except fnx_jacobi with p_tol > 0 (the reference's own
+ *    per-sweep host test, fluids_init.cpp:973).
+ *  - return value: FNX_OK or an FNX_E* code; fnx_last_error() gives the message (thread local).
+ *    There is no CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef FLUIDNET_HIP_H
+#define FLUIDNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNX_ABI_VERSION 1
+
+enum {
+  FNX_OK = 0,
+  FNX_EINVAL = 1,    /* bad argument (shape, bnd != 1, null pointer, max_iter < 1 ...) */
+  FNX_EMETHOD = 2,   /* "Advection method not supported" (cpp/advect_type.cpp:14) */
+  FNX_EWORKSPACE = 3,/* workspace too small */
+  FNX_EHIP = 4       /* HIP runtime error / no device */
+};
+
+/* Cell types, cpp/cell_type.h:7-18 and lib/fluid/cell_type.py:5-14 */
+enum { FNX_TYPE_NONE = 0, FNX_TYPE_FLUID = 1, FNX_TYPE_OBSTACLE = 2, FNX_TYPE_EMPTY = 4,
+       FNX_TYPE_INFLOW = 8, FNX_TYPE_OUTFLOW = 16, FNX_TYPE_OPEN = 32, FNX_TYPE_STICK = 128 };
+
+/* Advection methods, cpp/advect_type.cpp:5-16 ("eulerFluidNet", "maccormackFluidNet") */
+enum { FNX_ADVECT_EULER = 0, FNX_ADVECT_MACCORMACK = 1 };
+
+typedef struct FnxGrid {
+  int B, D, H, W;   /* batch, depth (1 for 2D), height, width */
+  int is3D;         /* 0: U has 2 channels and D must be 1; 1: U has 3 channels */
+  int ref_quirks;   /* 3D only: 1 reproduces the reference's 3D defects bit-for-bit,
+                       0 (default) gives the intended 3D semantics.  Ignored in 2D. */
+} FnxGrid;
+
+/* Workspace sizing. */
+enum { FNX_OP_ADVECT_SCALAR = 0, FNX_OP_ADVECT_VEL = 1, FNX_OP_JACOBI = 2, FNX_OP_STEP = 3, FNX_OP_FLUIDNET = 4 };
+size_t fnx_workspace_bytes(const FnxGrid* g, int op);
+
+const char* fnx_last_error(void);
+int fnx_abi_version(void);
+/* name of the HIP device the library would run on, or NULL (and FNX_EHIP set) when there is none */
+const char* fnx_device_name(void);
+
+/* advectScalar: pybind `advect_scalar`, cpp/fluids_init.cpp:265-382 (wrapper cpp/advection.py:14-66).
+ * dst must not alias src. */
+int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float* U, const float* flags,
+                      float* dst, int method, int bnd, int sample_outside_fluid, float maccormack_strength,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* advectVel: pybind `advect_vel`, cpp/fluids_init.cpp:656-807 (wrapper cpp/advection.py:68-118).
+ * orig may alias U (self-advection); dst must alias neither. */
+int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags,
+                   float* dst, int method, int bnd, float maccormack_strength,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* velocityDivergence, lib/fluid/velocity_divergence.py:4-74 */
+int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags, float* div, void* stream);
+
+/* solveLinearSystemJacobi: pybind `solve_linear_system`, cpp/fluids_init.cpp:809-1004.
+ * p: output (B,1,D,H,W).  residual: DEVICE pointer to 1 float (max over batch of ||p - p_prev||_2 of the
+ * last sweep) or NULL.  iters_done: HOST pointer or NULL.  p_tol <= 0 never synchronises. */
+int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual,
+               float p_tol, int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream);
+
+/* velocityUpdate (in place on U), lib/fluid/velocity_update.py:6-162 */
+int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream);
+
+/* addBuoyancy (in place on U), lib/fluid/source_terms.py:6-116.  gravity: 3 HOST floats. */
+int fnx_add_buoyancy(const FnxGrid* g, float* U, const float* flags, const float* density,
+                     const float gravity[3], float rho_star, float dt, void* stream);
+
+/* setWallBcs (in place on U), lib/fluid/set_wall_bcs.py:4-86 */
+int fnx_set_wall_bcs(const FnxGrid* g, float* U, const float* flags, void* stream);
+
+/* setConstVals (in place), lib/simulate.py:4-26.  Either triple may be NULL (key absent in batch_dict). */
+int fnx_set_const_vals(const FnxGrid* g, float* U, const float* UBC, const float* UBCInvMask,
+                       float* density, const float* densityBC, const float* densityBCInvMask, void* stream);
+
+/* flagsToOccupancy, lib/fluid/flags_to_occupancy.py:6-19 */
+int fnx_flags_to_occupancy(const FnxGrid* g, const float* flags, float* occupancy, void* stream);
+
+/* emptyDomain (writes flags), lib/fluid/util.py:5-47 */
+int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* stream);
+
+/* One whole time step, lib/simulate.py:28-171 (the keys simulate() reads from mconf). */
+typedef struct FnxStepParams {
+  float dt;                   /* mconf['dt'] */
+  float maccormack_strength;  /* mconf['maccormackStrength'] */
+  int   sample_outside_fluid; /* mconf['sampleOutsideFluid'] */
+  float buoyancy_scale;       /* mconf['buoyancyScale'] ; <= 0 skips addBuoyancy */
+  float gravity_vec[3];       /* mconf['gravityVec'] x,y,z (scaled by -buoyancyScale inside, simulate.py:101-105) */
+  float operating_density;    /* mconf['operatingDensity'] */
+  float p_tol;                /* mconf['pTol'] */
+  int   jacobi_iter;          /* mconf['jacobiIter'] */
+  int   method;               /* 0 = 'jacobi', 1 = 'convnet' */
+  float normalize_threshold;  /* mconf['normalizeInputThreshold'] (convnet) */
+} FnxStepParams;
+
+typedef struct FnxState {
+  float* p;        /* (B,1,D,H,W) in/out */
+  float* U;        /* (B,2|3,D,H,W) in/out */
+  float* density;  /* (B,1,D,H,W) in/out, may be NULL (simulate.py:71-83: no 'density' key) */
+  const float* flags;
+  const float* UBC; const float* UBCInvMask;                 /* may be NULL */
+  const float* densityBC; const float* densityBCInvMask;     /* may be NULL */
+  const void*  net;  /* packed ScaleNet weights from fnx_scalenet_pack (method 1), else NULL */
+} FnxState;
+
+int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* MultiScaleNet / FluidNet.forward, lib/multi_scale_net.py:118-127 and lib/model.py:76-227 (ScaleNet variant).
+ * weights_blob: 17 convs in the order convN_4[0..3], convN_2[0..5], convN_1[0..5], final; for each conv the
+ * torch-layout weight (Cout,Cin,[kd,]kh,kw) then bias (Cout); fp32, DEVICE pointer.
+ * fnx_scalenet_pack repacks it for the MFMA kernels into `packed` (size fnx_scalenet_packed_bytes). */
+size_t fnx_scalenet_weight_floats(int is3D);
+size_t fnx_scalenet_packed_bytes(int is3D);
+int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* stream);
+/* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
+int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p,
+                           void* ws, size_t ws_bytes, void* stream);
+/* input: (B,5|6,D,H,W) = [p, U, flags, density] -> p_out (B,1,..), U_out (B,2|3,..) */
+int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float normalize_threshold,
+                         float* p_out, float* U_out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDNET_HIP_H */

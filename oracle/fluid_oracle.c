@@ -197,12 +197,15 @@ static void line_trace(const OraGrid* g, const float* flags, int b, const float 
   out[0] = pos[0]; out[1] = pos[1]; out[2] = pos[2];
   if (out_of_domain(g, pos)) return;
   if (blocked_cell(g, flags, b, pos)) return;
-  const float length = sqrtf((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2]);
+  /* delta.norm(2,1): ATen's reduction accumulates acc = fma(d,d,acc) on FMA-capable hosts (verified
+   * bit-for-bit against the reference build here), so the squares are fused, not rounded. */
+  const float length = sqrtf(fmaf(delta[2], delta[2], fmaf(delta[1], delta[1], delta[0] * delta[0])));
   if (length <= EPSILON) return;
   const float dir[3] = { delta[0] / length, delta[1] / length, delta[2] / length };
   const float size[3] = { (float)g->W, (float)g->H, (float)g->D };
   float cur = 0.f, next[3];
-  for (;;) {
+  const int max_steps = g->W + g->H + g->D + 8;   /* NaN guard only: a unit-step ray exits the domain sooner */
+  for (int it = 0; it < max_steps; ++it) {
     if (cur >= length - HIT_MARGIN) return;
     const float step = fminf(length - cur, 1.f);
     for (int c = 0; c < 3; ++c) next[c] = out[c] + dir[c] * step;

@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares, the torch extension exposes the reference's entry points, and the product path fails loudly
+(no CPU fallback) when handed CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from fluidnet_cxx_amd import build
+    build.build_all()
+    return build
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(REPO, "include", "fluidnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(fnx_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 18, names
+    lib = ctypes.CDLL(built.LIB)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fluidnet_hip.h but not exported"
+    lib.fnx_abi_version.restype = ctypes.c_int
+    assert lib.fnx_abi_version() == 1
+
+
+def test_no_oracle_in_product(built):
+    """The shipped library must not link or reference the oracle."""
+    import subprocess
+    out = subprocess.check_output(["readelf", "-d", built.LIB]).decode() + subprocess.check_output(["readelf", "-d", built.EXT]).decode()
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(REPO, "fluidnet_cxx_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "ora_" not in txt, f
+
+
+def test_extension_entry_points(built):
+    from fluidnet_cxx_amd._ext import ext
+    # the reference's pybind names (pytorch/lib/fluid/cpp/fluids_init.cpp:1009-1014)
+    for n in ("advect_scalar", "advect_vel", "solve_linear_system"):
+        assert hasattr(ext, n)
+    for n in ("velocity_divergence", "velocity_update_", "add_buoyancy_", "set_wall_bcs_", "set_const_vals_",
+              "flags_to_occupancy", "empty_domain_", "fluidnet_forward", "simulate_step_"):
+        assert hasattr(ext, n)
+
+
+def test_python_surface_matches_reference(built):
+    import inspect
+    from fluidnet_cxx_amd import fluid
+    sig = inspect.signature(fluid.advectScalar)
+    assert list(sig.parameters) == ["dt", "src", "U", "flags", "method", "boundary_width", "sample_outside_fluid", "maccormack_strength"]
+    assert sig.parameters["maccormack_strength"].default == 0.75 and sig.parameters["method"].default == "maccormackFluidNet"
+    sig = inspect.signature(fluid.advectVelocity)
+    assert list(sig.parameters) == ["dt", "orig", "U", "flags", "method", "boundary_width", "maccormack_strength"]
+    sig = inspect.signature(fluid.solveLinearSystemJacobi)
+    assert list(sig.parameters) == ["flags", "div", "is_3d", "p_tol", "max_iter", "verbose"]
+    assert sig.parameters["p_tol"].default == 1e-5 and sig.parameters["max_iter"].default == 1000
+    assert int(fluid.CellType.TypeFluid) == 1 and int(fluid.CellType.TypeObstacle) == 2 and int(fluid.CellType.TypeEmpty) == 4
+
+
+def test_cpu_tensors_fail_loudly(built):
+    from fluidnet_cxx_amd import fluid
+    U = torch.zeros(1, 2, 1, 8, 8); flags = torch.ones(1, 1, 1, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        fluid.velocityDivergence(U, flags)
+    with pytest.raises(RuntimeError, match="GPU"):
+        fluid.advectScalar(0.1, flags.clone(), U, flags)
+    with pytest.raises(AssertionError):
+        fluid.advectScalar(0.1, flags.clone(), U, flags, method="semiLagrange")
+    with pytest.raises(AssertionError):
+        fluid.velocityDivergence(U[0], flags)
+
+
+def test_weights_deterministic_and_param_count():
+    from fluidnet_cxx_amd.weights import make_scalenet_weights, scalenet_layers
+    w1, w2 = make_scalenet_weights(0), make_scalenet_weights(0)
+    assert all((w1[k] == w2[k]).all() for k in w1)
+    assert sum(v.size for v in w1.values()) == 418643          # reference MultiScaleNet parameter count
+    assert len(scalenet_layers()) == 17
+    w3 = make_scalenet_weights(1)
+    assert not (w1["multiScale.final.weight"] == w3["multiScale.final.weight"]).all()
+    assert abs(float(w1["multiScale.convN_1.encode.2.weight"].mean())) < 1e-2

@@ -1,0 +1,279 @@
+"""Parity of the HIP path (through the `fluidnet_cpp` extension == the C ABI) with
+  (1) golden vectors captured from the reference, (2) the CPU oracle on seeded inputs (ragged sizes, B>1, 3D in
+  both semantic modes), (3) size-independent properties at the benchmark sizes.
+Integer-like fields (flags, occupancy) and every stencil/advection op are bit-exact; the Jacobi residual and
+the CNN are fp32-tolerance statements (tolerances written at the assert)."""
+import numpy as np
+import pytest
+import torch
+
+from util import PLUME_CFG, assert_bitexact, assert_close, make_flags, plume_state, random_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def fl():
+    from fluidnet_cxx_amd import fluid
+    return fluid
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from fluidnet_cxx_amd._ext import ext
+    return ext
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def run_ops(fl, dev, flags, U, rho, p, dt, gravity, rho_star, is3d, orig=None, jac_iters=7):
+    tf, tU, trho, tp = T(flags, dev), T(U, dev), T(rho, dev), T(p, dev)
+    out = {}
+    for meth in ("maccormackFluidNet", "eulerFluidNet"):
+        for so in (0, 1):
+            out[f"advect_scalar_{meth}_{so}"] = N(fl.advectScalar(dt, trho, tU, tf, meth, 1, bool(so), 0.6))
+        out[f"advect_vel_{meth}"] = N(fl.advectVelocity(dt, tU, tU, tf, meth, 1, 0.6))
+    if orig is not None:
+        out["advect_vel_orig"] = N(fl.advectVelocity(dt, T(orig, dev), tU, tf, "maccormackFluidNet", 1, 0.75))
+    div = fl.velocityDivergence(tU, tf)
+    out["divergence"] = N(div)
+    pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, jac_iters)
+    out["jacobi_p"], out["jacobi_res"] = N(pj), float(res)
+    pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, 1)
+    out["jacobi1_p"], out["jacobi1_res"] = N(pj), float(res)
+    Uu = tU.clone(); assert fl.velocityUpdate(tp, Uu, tf) is None; out["velocity_update"] = N(Uu)
+    Uw = tU.clone(); r = fl.setWallBcs(Uw, tf); assert r is Uw; out["set_wall_bcs"] = N(Uw)
+    Ub = tU.clone(); r = fl.addBuoyancy(Ub, tf, trho, gravity, rho_star, dt); assert r is Ub; out["add_buoyancy"] = N(Ub)
+    out["occupancy"] = N(fl.flagsToOccupancy(tf))
+    # inputs untouched (reference: advect_* and solve_linear_system never write to inputs)
+    assert_bitexact(N(tU), U, "U unchanged"); assert_bitexact(N(trho), rho, "rho unchanged"); assert_bitexact(N(tf), flags, "flags unchanged")
+    return out
+
+
+@pytest.mark.parametrize("case", ["ops_2d_a", "ops_2d_b", "ops_2d_c", "ops_2d_d", "ops_3d_a", "ops_3d_b"])
+def test_ops_vs_reference_golden(fl, ext, dev, golden, case):
+    z = golden(case)
+    is3d = bool(z["is3d"])
+    ext.set_ref_quirks(is3d)          # 3D goldens are the reference's own (defective) 3D behaviour
+    try:
+        out = run_ops(fl, dev, z["flags"], z["U"], z["rho"], z["p"], float(z["dt"]), z["gravity"].tolist(), float(z["rho_star"]),
+                      is3d, z["orig"], int(z["jacobi_iters"]))
+    finally:
+        ext.set_ref_quirks(False)
+    for k, v in out.items():
+        if k.endswith("_res"):
+            assert abs(v - float(z[k])) <= 1e-5 * max(1.0, float(z[k])), (k, v, float(z[k]))   # reduction order differs
+        elif k in z.files:
+            assert_bitexact(v, z[k], f"{case}:{k}")
+    if "jacobi_tol" in z.files:
+        tf, div = T(z["flags"], dev), T(z["divergence"], dev)
+        pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, float(z["jacobi_tol"]), 50)
+        assert_bitexact(N(pj), z["jacobi_tol_p"], "jacobi p_tol early exit")
+
+
+SHAPES = [  # B, D, H, W, sigma, empties
+    (1, 1, 17, 19, 3.0, False), (2, 1, 64, 64, 1.0, True), (1, 1, 65, 130, 8.0, False), (3, 1, 40, 257, 4.0, True),
+    (1, 1, 200, 72, 20.0, False), (1, 5, 9, 11, 2.0, False), (2, 12, 20, 33, 6.0, False), (1, 16, 16, 70, 12.0, False),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("quirks", [False, True])
+def test_ops_vs_oracle(fl, ext, dev, oracle, shape, quirks):
+    B, D, H, W, sigma, empties = shape
+    is3d = D > 1
+    if quirks and not is3d:
+        pytest.skip("quirks only change 3D")
+    s = random_state(B, D, H, W, sigma, seed=B * 1000 + H, empties=empties)
+    flags, U, rho, p = s["flags"], s["U"], s["rho"], s["p"]
+    dt, grav, rstar = 0.17, [0.3, 0.25, -0.2], 0.05
+    ext.set_ref_quirks(quirks)
+    try:
+        out = run_ops(fl, dev, flags, U, rho, p, dt, grav, rstar, is3d, jac_iters=11)
+    finally:
+        ext.set_ref_quirks(False)
+    O = oracle
+    for meth in ("maccormackFluidNet", "eulerFluidNet"):
+        for so in (0, 1):
+            assert_bitexact(out[f"advect_scalar_{meth}_{so}"], O.advect_scalar(dt, rho, U, flags, meth, 1, bool(so), 0.6, quirks), f"advect_scalar {meth} {so}")
+        assert_bitexact(out[f"advect_vel_{meth}"], O.advect_vel(dt, U, U, flags, meth, 1, 0.6, quirks), f"advect_vel {meth}")
+    div = O.velocity_divergence(U, flags)
+    assert_bitexact(out["divergence"], div, "divergence")
+    pj, res, _ = O.jacobi(flags, div, is3d, 0.0, 11, quirks)
+    assert_bitexact(out["jacobi_p"], pj, "jacobi 11 sweeps"); assert abs(out["jacobi_res"] - res) <= 1e-5 * max(1.0, res)
+    pj, res, _ = O.jacobi(flags, div, is3d, 0.0, 1, quirks)
+    assert_bitexact(out["jacobi1_p"], pj, "jacobi 1 sweep")
+    assert_bitexact(out["velocity_update"], O.velocity_update(p, U, flags), "velocity_update")
+    assert_bitexact(out["set_wall_bcs"], O.set_wall_bcs(U, flags), "set_wall_bcs")
+    assert_bitexact(out["add_buoyancy"], O.add_buoyancy(U, flags, rho, grav, rstar, dt, quirks), "add_buoyancy")
+    assert_bitexact(out["occupancy"], O.flags_to_occupancy(flags), "occupancy")
+
+
+@pytest.mark.parametrize("iters", [1, 2, 7, 8, 9, 16, 28, 37, 100])
+def test_jacobi_sweep_counts(fl, dev, oracle, iters):
+    """The temporally blocked kernel for every split of max_iter into launches."""
+    s = random_state(2, 1, 96, 150, 2.0, seed=iters)
+    div = oracle.velocity_divergence(s["U"], s["flags"])
+    pj, res = fl.solveLinearSystemJacobi(T(s["flags"], dev), T(div, dev), False, 0.0, iters)
+    po, ro, _ = oracle.jacobi(s["flags"], div, False, 0.0, iters)
+    assert_bitexact(N(pj), po, f"jacobi {iters}")
+    assert abs(float(res) - ro) <= 1e-5 * max(1.0, ro)
+
+
+def test_jacobi_tolerance_exit(fl, dev, oracle):
+    s = random_state(1, 1, 48, 80, 2.0, seed=3)
+    div = oracle.velocity_divergence(s["U"], s["flags"])
+    _, r5, _ = oracle.jacobi(s["flags"], div, False, 0.0, 5)
+    _, r6, _ = oracle.jacobi(s["flags"], div, False, 0.0, 6)
+    tol = 0.5 * (r5 + r6)
+    po, ro, it = oracle.jacobi(s["flags"], div, False, tol, 100)
+    pj, res = fl.solveLinearSystemJacobi(T(s["flags"], dev), T(div, dev), False, tol, 100)
+    assert_bitexact(N(pj), po, "early exit pressure")
+    with pytest.raises(RuntimeError, match="At least 1 iteration"):
+        fl.solveLinearSystemJacobi(T(s["flags"], dev), T(div, dev), False, 0.0, 0)
+
+
+def test_error_behaviour(fl, dev):
+    U = torch.zeros(1, 2, 1, 8, 8, device=dev); flags = torch.ones(1, 1, 1, 8, 8, device=dev)
+    with pytest.raises(RuntimeError, match="Advection method not supported"):
+        from fluidnet_cxx_amd._ext import ext
+        ext.advect_scalar(0.1, flags.clone(), U, flags, "semiLagrange", 1, False, 0.5)
+    with pytest.raises(RuntimeError):
+        fl.advectScalar(0.1, flags.clone(), U, flags, boundary_width=2)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        fl.velocityDivergence(U.transpose(3, 4), flags) if False else fl.ops.ext.velocity_divergence(U.transpose(3, 4), flags)
+
+
+def to_dev(st, dev):
+    return {k: T(v, dev) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_plume128_simulation_vs_reference(dev, golden, fused):
+    """Config C1 (128^2 plume, Jacobi-28): whole-step parity with the reference after 1, 5, 20 steps -- bit-exact."""
+    from fluidnet_cxx_amd import simulate
+    z = golden("plume128")
+    bd = to_dev(plume_state(128), dev)
+    for it in range(1, 21):
+        simulate(PLUME_CFG, bd, None, "jacobi", fused=fused)
+        if it in (1, 5, 20):
+            for k in ("U", "density", "p"):
+                assert_bitexact(N(bd[k]), z[f"{k}_{it}"], f"{k} after {it} steps (fused={fused})")
+
+
+def test_generators_bitexact(fl, dev, golden):
+    z = golden("generators")
+    f3 = torch.zeros(2, 1, 6, 7, 8, device=dev); fl.emptyDomain(f3)
+    assert_bitexact(N(f3), z["empty3d"], "emptyDomain 3D")
+    for res in (16, 128):
+        bd = dict(p=torch.zeros(1, 1, 1, res, res, device=dev), U=torch.zeros(1, 2, 1, res, res, device=dev),
+                  flags=torch.zeros(1, 1, 1, res, res, device=dev), density=torch.zeros(1, 1, 1, res, res, device=dev))
+        fl.emptyDomain(bd["flags"]); fl.createPlumeBCs(bd, 0.1, 2, 0.145)
+        assert_bitexact(N(bd["flags"]), z[f"plume{res}_flags"], "flags")
+        for k in ("UBC", "UBCInvMask", "densityBC", "densityBCInvMask"):
+            assert_bitexact(N(bd[k]), z[f"plume{res}_{k}"], k)
+    bd = dict(p=torch.zeros(1, 1, 1, 40, 32, device=dev), U=torch.zeros(1, 2, 1, 40, 32, device=dev),
+              flags=torch.zeros(1, 1, 1, 40, 32, device=dev), density=torch.zeros(1, 1, 1, 40, 32, device=dev))
+    fl.createRayleighTaylorBCs(bd, dict(perturbThickness=100, perturbAmplitude=0.01, height=0.5), -0.01, 0.01)
+    assert_close(N(bd["density"]), z["rt_density"], 1e-6, "Rayleigh-Taylor density")
+
+
+# ---- CNN --------------------------------------------------------------------------------------------
+def test_cnn_vs_reference_golden(dev, golden):
+    """MultiScaleNet / FluidNet.forward vs torch-2.10-CPU golden vectors: |d| <= 2e-5 * max(1,|ref|max)
+    (fp32 conv with a different summation order; SURVEY.md noise floor)."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    c = golden("cnn")
+    mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False)
+    net = FluidNet(mconf, make_scalenet_weights(0), dev)
+    out = net.multiScale(T(c["x"], dev))
+    assert_close(N(out), c["multiscale"], 2e-5, "MultiScaleNet")
+    p, U = net(T(c["fluidnet_in"], dev))
+    assert_close(N(p), c["fluidnet_p"], 2e-5, "FluidNet p"); assert_close(N(U), c["fluidnet_U"], 2e-5, "FluidNet U")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 36, 52), (2, 1, 64, 128), (1, 8, 12, 16)])
+def test_cnn_vs_oracle(dev, oracle, shape):
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    B, D, H, W = shape
+    is3d = D > 1
+    w = make_scalenet_weights(0, ndim=3 if is3d else 2)
+    mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d)
+    net = FluidNet(mconf, w, dev)
+    s = random_state(B, D, H, W, 0.5, seed=11)
+    inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
+    p, U = net(T(inp, dev))
+    blob = oracle.pack_weights(w, 3 if is3d else 2)
+    po, Uo = oracle.fluidnet_forward(blob, inp)
+    assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
+
+
+def test_sim64_convnet_vs_reference(dev, golden):
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    s = golden("sim64")
+    mconf = dict(PLUME_CFG, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", is3D=False)
+    net = FluidNet(mconf, make_scalenet_weights(0), dev)
+    for fused in (True, False):
+        bd = to_dev(plume_state(64), dev)
+        for it in range(1, 11):
+            simulate(mconf, bd, net, "convnet", fused=fused)
+            if it in (1, 3, 10):
+                for k in ("U", "density", "p"):
+                    assert_close(N(bd[k]), s[f"convnet_{k}_{it}"], 2e-5, f"convnet {k} after {it} (fused={fused})")
+
+
+# ---- properties at benchmark sizes ----------------------------------------------------------------------
+@pytest.mark.parametrize("size", [(1, 1024, 1024), (1, 2048, 2048), (64, 128, 128)])
+def test_properties_full_size(fl, dev, size):
+    D, H, W = size
+    is3d = D > 1
+    nc = 3 if is3d else 2
+    flags = torch.zeros(1, 1, D, H, W, device=dev); fl.emptyDomain(flags)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rho = torch.rand(1, 1, D, H, W, generator=g).to(dev)
+    U0 = torch.zeros(1, nc, D, H, W, device=dev)
+    # zero velocity: advection is the identity on the interior, border -> 0 (measured on the reference)
+    out = fl.advectScalar(0.1, rho, U0, flags)
+    inner = (slice(None), slice(None), slice(1, -1) if is3d else slice(None), slice(1, -1), slice(1, -1))
+    assert torch.equal(out[inner], rho[inner])
+    assert float(out[..., 0, :].abs().max()) == 0 and float(out[..., :, 0].abs().max()) == 0
+    assert float(fl.advectVelocity(0.1, U0, U0, flags).abs().max()) == 0
+    # zero rhs -> zero pressure, zero residual
+    p, res = fl.solveLinearSystemJacobi(flags, torch.zeros_like(rho), is3d, 0.0, 28)
+    assert float(p.abs().max()) == 0 and float(res) == 0
+    # Jacobi is linear in its rhs: J(2*d) == 2*J(d) exactly (power-of-two scaling is exact in fp32)
+    div = (torch.rand(1, 1, D, H, W, generator=g) - 0.5).to(dev)
+    p1, _ = fl.solveLinearSystemJacobi(flags, div, is3d, 0.0, 16)
+    p2, _ = fl.solveLinearSystemJacobi(flags, 2 * div, is3d, 0.0, 16)
+    assert torch.equal(2 * p1, p2)
+    # setWallBcs is idempotent; divergence of a projected field shrinks
+    U = (torch.randn(1, nc, D, H, W, generator=g)).to(dev)
+    Ua = fl.setWallBcs(U.clone(), flags); Ub = fl.setWallBcs(Ua.clone(), flags)
+    assert torch.equal(Ua, Ub)
+    d0 = fl.velocityDivergence(Ua, flags)
+    p, _ = fl.solveLinearSystemJacobi(flags, d0, is3d, 0.0, 200 if not is3d else 60)
+    fl.velocityUpdate(p, Ua, flags); fl.setWallBcs(Ua, flags)
+    d1 = fl.velocityDivergence(Ua, flags)
+    assert float(d1.norm()) < 0.7 * float(d0.norm())
+    # unit shift (euler, sample outside): exact one-cell shift away from the walls
+    U1 = torch.zeros_like(U0); U1[:, 0] = 1.0
+    sh = fl.advectScalar(1.0, rho, U1, flags, "eulerFluidNet", 1, True)
+    assert torch.equal(sh[..., 2:-2, 3:-2], rho[..., 2:-2, 2:-3]) if not is3d else torch.equal(sh[:, :, 2:-2, 2:-2, 3:-2], rho[:, :, 2:-2, 2:-2, 2:-3])

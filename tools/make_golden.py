@@ -129,17 +129,26 @@ def gen_ops(torch, lib, ext, name, B, D, H, W, sigma, dt, seed, empties=False, b
 
     div = fluid.velocityDivergence(tU.clone(), tf)
     out["divergence"] = div.numpy().copy()
-    pj, res = ext.solve_linear_system(tf, div, is3d, 0.0, jac_iters, False)
-    out["jacobi_p"] = pj.numpy().copy(); out["jacobi_res"] = np.float32(res.item()); out["jacobi_iters"] = np.int32(jac_iters)
-    pj1, res1 = ext.solve_linear_system(tf, div, is3d, 0.0, 1, False)
-    out["jacobi1_p"] = pj1.numpy().copy(); out["jacobi1_res"] = np.float32(res1.item())
-    # early exit on tolerance: pick a tolerance between the residual at sweep 3 and 4
-    _, r3 = ext.solve_linear_system(tf, div, is3d, 0.0, 3, False)
-    _, r4 = ext.solve_linear_system(tf, div, is3d, 0.0, 4, False)
-    tol = 0.5 * (r3.item() + r4.item())
-    pt, rt = ext.solve_linear_system(tf, div, is3d, tol, 50, False)
-    out["jacobi_tol"] = np.float32(tol); out["jacobi_tol_p"] = pt.numpy().copy(); out["jacobi_tol_res"] = np.float32(rt.item())
-
+    # NOTE (reference defect, B>1 only): solve_linear_system indexes with idx_b (B,D,H,W) next to a
+    # (B,1,D,H,W) zero index (fluids_init.cpp:870-901), which broadcasts to (B,B,D,H,W) and mixes samples;
+    # its B>1 output is garbage.  The per-sample semantics are pinned by calling it sample by sample.
+    def jac(tol, iters):
+        ps, rs = [], []
+        for b in range(B):
+            pb, rb = ext.solve_linear_system(tf[b:b + 1].contiguous(), div[b:b + 1].contiguous(), is3d, tol, iters, False)
+            ps.append(pb); rs.append(rb.item())
+        return torch.cat(ps, 0), max(rs), rs
+    pj, res, _ = jac(0.0, jac_iters)
+    out["jacobi_p"] = pj.numpy().copy(); out["jacobi_res"] = np.float32(res); out["jacobi_iters"] = np.int32(jac_iters)
+    pj1, res1, _ = jac(0.0, 1)
+    out["jacobi1_p"] = pj1.numpy().copy(); out["jacobi1_res"] = np.float32(res1)
+    if B == 1:
+        # early exit on tolerance: pick a tolerance between the residual at sweep 3 and 4
+        _, r3, _ = jac(0.0, 3)
+        _, r4, _ = jac(0.0, 4)
+        tol = 0.5 * (r3 + r4)
+        pt, rt, _ = jac(tol, 50)
+        out["jacobi_tol"] = np.float32(tol); out["jacobi_tol_p"] = pt.numpy().copy(); out["jacobi_tol_res"] = np.float32(rt)
     g = torch.tensor([0.3, 0.25, -0.2], dtype=torch.float32)
     out["gravity"] = g.numpy().copy(); out["rho_star"] = np.float32(0.05)
     if not is3d:
