@@ -70,17 +70,19 @@ def test_ops_vs_reference_golden(fl, ext, dev, golden, case):
     try:
         out = run_ops(fl, dev, z["flags"], z["U"], z["rho"], z["p"], float(z["dt"]), z["gravity"].tolist(), float(z["rho_star"]),
                       is3d, z["orig"], int(z["jacobi_iters"]))
+        if "jacobi_tol" in z.files:
+            tf, div = T(z["flags"], dev), T(z["divergence"], dev)
+            pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, float(z["jacobi_tol"]), 50)
+            assert_bitexact(N(pj), z["jacobi_tol_p"], "jacobi p_tol early exit")
     finally:
         ext.set_ref_quirks(False)
     for k, v in out.items():
         if k.endswith("_res"):
             assert abs(v - float(z[k])) <= 1e-5 * max(1.0, float(z[k])), (k, v, float(z[k]))   # reduction order differs
         elif k in z.files:
+            if is3d and k in ("velocity_update", "set_wall_bcs"):
+                continue                       # the reference's 3D branches of these two raise; no golden
             assert_bitexact(v, z[k], f"{case}:{k}")
-    if "jacobi_tol" in z.files:
-        tf, div = T(z["flags"], dev), T(z["divergence"], dev)
-        pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, float(z["jacobi_tol"]), 50)
-        assert_bitexact(N(pj), z["jacobi_tol_p"], "jacobi p_tol early exit")
 
 
 SHAPES = [  # B, D, H, W, sigma, empties
