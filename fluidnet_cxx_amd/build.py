@@ -26,7 +26,10 @@ HIP_UNITS = {
     "fnx_api.hip": ["-ffp-contract=off"],
     "fnx_cnn.hip": [],
 }
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 adds into v_pk_add_f32 + v_pk_mov shuffles, measured
+# 1.6x slower per op than plain VALU on gfx950 (tools/ubench/dpp_bench.hip).
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
+          "-Wno-unused-function"]
 
 
 def _newer(target, deps):

@@ -55,7 +55,7 @@ size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   size_t adv = ws_advect_scalar(g) > ws_advect_vel(g) ? ws_advect_scalar(g) : ws_advect_vel(g);
   size_t solve = ws_jacobi(g);
-  size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D) + al(ncell(g) * 4 * (nc + 3));
+  size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D);
   size_t tail = adv > solve ? adv : solve;
   if (cnn > tail) tail = cnn;
   return al(ncell(g) * 4) /*rho2*/ + al(ncell(g) * 4 * nc) /*U2*/ + al(ncell(g) * 4) /*div*/ + tail;
@@ -278,42 +278,35 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   }
   if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
                               prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
-  if (has_rho) HIP_OK(hipMemcpyAsync(st->density, rho2, n * 4, hipMemcpyDeviceToDevice, s));
-  HIP_OK(hipMemcpyAsync(st->U, U2, n * 4 * nc, hipMemcpyDeviceToDevice, s));
-  float* rho = has_rho ? st->density : nullptr;
-  // simulate.py:96
-  fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
-  // simulate.py:98-107
-  if (has_rho && prm->buoyancy_scale > 0.f) {
-    const float ns = -prm->buoyancy_scale;
-    const float grav[3] = { prm->gravity_vec[0] * ns, prm->gravity_vec[1] * ns, prm->gravity_vec[2] * ns };
-    if (int rc = fnx_add_buoyancy(g, st->U, st->flags, rho, grav, prm->operating_density, prm->dt, stream)) return rc;
+  // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, wall BCs, BCs, -div
+  const bool buoy = has_rho && prm->buoyancy_scale > 0.f;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (buoy) {
+    const float ns = -prm->buoyancy_scale;                       // gravity.mul_(-buoyancyScale), simulate.py:101-105
+    const float gx = prm->gravity_vec[0] * ns, gy = prm->gravity_vec[1] * ns, gz = prm->gravity_vec[2] * ns;
+    sx = gx * prm->dt; sy = gy * prm->dt; sz = gz * prm->dt;     // strength = gravity * dt, source_terms.py:45
   }
-  // simulate.py:120-133
-  if (prm->method == 0) fnx_set_wall_bcs(g, st->U, st->flags, stream);
-  fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
+  const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  const GridDims d = dims(g);
+  fnx::launch_pre_projection(d, g->is3D, quirks(g), U2, has_rho ? rho2 : nullptr, st->flags, ubc ? st->UBC : nullptr,
+                             ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
+                             rbc ? st->densityBCInvMask : nullptr, st->U, st->density,
+                             prm->method == 0 ? div : nullptr, buoy, sx, sy, sz, prm->operating_density,
+                             prm->method == 0, s);
+  float* rho = has_rho ? st->density : nullptr;
   if (prm->method == 0) {
-    // simulate.py:144-166
-    fnx_velocity_divergence(g, st->U, st->flags, div, stream);
+    // simulate.py:144-168
     if (int rc = fnx_jacobi(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, stream)) return rc;
-    fnx_velocity_update(g, st->p, st->U, st->flags, stream);
-    fnx_set_wall_bcs(g, st->U, st->flags, stream);
+    fnx::launch_post_projection(d, g->is3D, st->p, st->U, rho, st->flags, ubc ? st->UBC : nullptr,
+                                ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
+                                rbc ? st->densityBCInvMask : nullptr, s);
+    HIP_OK(hipGetLastError());
+    return FNX_OK;
   } else {
-    // simulate.py:136-142: data = cat(p, U, flags, density); p, U = net(data)
-    Carver t(tail, tail_bytes);
-    float* data = (float*)t.take(n * 4 * (nc + 3));
-    void* cws = t.take(0);
-    const size_t cws_bytes = tail_bytes > t.off ? tail_bytes - t.off : 0;
-    const size_t per = (size_t)g->D * g->H * g->W * 4;
-    for (int b = 0; b < g->B; ++b) {
-      char* dst = (char*)data + (size_t)b * (nc + 3) * per;
-      HIP_OK(hipMemcpyAsync(dst, (char*)st->p + b * per, per, hipMemcpyDeviceToDevice, s));
-      HIP_OK(hipMemcpyAsync(dst + per, (char*)st->U + b * nc * per, nc * per, hipMemcpyDeviceToDevice, s));
-      HIP_OK(hipMemcpyAsync(dst + (1 + nc) * per, (const char*)st->flags + b * per, per, hipMemcpyDeviceToDevice, s));
-      if (has_rho) HIP_OK(hipMemcpyAsync(dst + (2 + nc) * per, (char*)rho + b * per, per, hipMemcpyDeviceToDevice, s));
-      else HIP_OK(hipMemsetAsync(dst + (2 + nc) * per, 0, per, s));
-    }
-    if (int rc = fnx_fluidnet_forward(g, st->net, data, prm->normalize_threshold, st->p, st->U, cws, cws_bytes, stream)) return rc;
+    // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),
+    // so the concatenation is not materialised: U is projected in place.
+    if (tail_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the CNN");
+    if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, st->p, st->U, tail, stream)) return rc;
   }
   fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
   HIP_OK(hipGetLastError());

@@ -42,3 +42,9 @@ void launch_unscale(const GridDims& g, int nc, const float* scale, float* p, flo
 void launch_gather_input(const GridDims& g, int nc, const float* input, float* U, float* flags, hipStream_t s);
 
 }  // namespace fnx
+
+struct FnxGrid;
+namespace fnx {
+int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, float* p_out, float* U, void* ws,
+                  void* stream);
+}

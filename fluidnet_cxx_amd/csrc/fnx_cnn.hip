@@ -346,10 +346,38 @@ size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
 
 }  // namespace fnx
 
+#include "../../include/fluidnet_hip.h"
+
+// FluidNet.forward after the channel split (model.py:120-227), U in place: U holds UDiv on entry and the
+// projected velocity on exit.  ws needs fluidnet_ws_bytes() minus the flags copy.
+namespace fnx {
+int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, float* p_out, float* U, void* ws,
+                  void* stream) {
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W);
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = g->is3D ? 3 : 2;
+  const size_t full = (size_t)g->B * d.DHW;
+  char* w = (char*)ws;
+  auto take = [&](size_t bytes) { void* r = w; w += (bytes + 255) & ~(size_t)255; return r; };
+  float* div = (float*)take(full * 4);
+  float* x = (float*)take(full * 2 * 4);
+  double* partial = (double*)take(sizeof(double) * 2 * g->B);
+  float* scale = (float*)take(sizeof(float) * g->B);
+  void* msws = w;
+  if (int rc = fnx_velocity_divergence(g, U, flags, div, stream)) return rc;     // model.py:125-126
+  launch_scale_std(d, nc, U, thr, partial, scale, s);                            // model.py:129-144
+  launch_pack_input(d, nc, div, flags, scale, U, x, s);                          // model.py:146-168
+  multiscale_forward(d, g->is3D, packed, x, p_out, msws, s);                     // model.py:174-175
+  if (int rc = fnx_velocity_update(g, p_out, U, flags, stream)) return rc;       // model.py:213-218
+  launch_unscale(d, nc, scale, p_out, U, s);                                     // model.py:221-223
+  if (int rc = fnx_set_wall_bcs(g, U, flags, stream)) return rc;                 // model.py:226
+  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+}
+}  // namespace fnx
+
 // ---------------------------------------------------------------------------------------------------
 // C ABI (include/fluidnet_hip.h)
 // ---------------------------------------------------------------------------------------------------
-#include "../../include/fluidnet_hip.h"
 
 extern "C" {
 
@@ -379,27 +407,11 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
   hipStream_t s = (hipStream_t)stream;
   const int nc = g->is3D ? 3 : 2;
   const size_t full = (size_t)g->B * d.DHW;
-  char* w = (char*)ws;
-  auto take = [&](size_t bytes) { void* r = w; w += (bytes + 255) & ~(size_t)255; return r; };
-  float* flags = (float*)take(full * 4);
-  float* div = (float*)take(full * 4);
-  float* x = (float*)take(full * 2 * 4);
-  double* partial = (double*)take(sizeof(double) * 2 * g->B);
-  float* scale = (float*)take(sizeof(float) * g->B);
-  void* msws = w;
-  // model.py:104-126
+  float* flags = (float*)ws;                       // contiguous (B,1,..) copy of the flags channel
+  void* rest = (char*)ws + ((full * 4 + 255) & ~(size_t)255);
+  // model.py:104-119: split the channels
   fnx::launch_gather_input(d, nc, input, U_out, flags, s);
-  if (int rc = fnx_velocity_divergence(g, U_out, flags, div, stream)) return rc;
-  // model.py:129-168
-  fnx::launch_scale_std(d, nc, U_out, thr, partial, scale, s);
-  fnx::launch_pack_input(d, nc, div, flags, scale, U_out, x, s);
-  // model.py:174-175
-  fnx::multiscale_forward(d, g->is3D, packed, x, p_out, msws, s);
-  // model.py:213-227
-  if (int rc = fnx_velocity_update(g, p_out, U_out, flags, stream)) return rc;
-  fnx::launch_unscale(d, nc, scale, p_out, U_out, s);
-  if (int rc = fnx_set_wall_bcs(g, U_out, flags, stream)) return rc;
-  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+  return fnx::fluidnet_core(g, packed, flags, thr, p_out, U_out, rest, stream);
 }
 
 }  // extern "C"

@@ -26,6 +26,15 @@ void launch_set_const_vals(size_t n, float* x, const float* bc, const float* inv
 void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStream_t s);
 void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s);
 
+// fused step stages (fnx_step.hip)
+void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const float* U_adv, const float* rho_adv,
+                           const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
+                           const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
+                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s);
+void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
+                            const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
+                            hipStream_t s);
+
 // Jacobi (fnx_jacobi.hip)
 // `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is
 // not read.  sumsq (B floats, pre-zeroed) receives sum (p_n - p_{n-1})^2 of the last sweep when non-null.

@@ -1,0 +1,179 @@
+// Fused stages of one time step (lib/simulate.py:96-171) for gfx950.
+//
+// The reference runs setConstVals -> addBuoyancy -> setWallBcs -> setConstVals -> velocityDivergence as ~250
+// ATen ops; as separate HIP kernels they are 9 launches that each stream the same 4-24 MiB fields.  Here:
+//   pre_projection_kernel : U_adv, rho_adv (advection outputs) -> U, rho (BCs, buoyancy, wall BCs applied) and div
+//   post_projection_kernel: U -= grad p, wall BCs, BCs                      (simulate.py:154-168)
+// Each thread produces its own cell and re-derives the +1 neighbours' velocity components it needs for the
+// divergence (radius-1 recompute instead of a second pass over HBM).  Per-cell arithmetic is exactly the
+// sequence of the separate operators (fnx_stencils.hip), so results are bit-identical to the unfused path.
+#include "fnx_device.h"
+#include "fnx_kernels.h"
+
+namespace {
+
+constexpr int BX = 64, BY = 4;
+
+struct StepPtrs {
+  const float* U_adv; const float* rho_adv;          // advected fields (rho_adv may be null)
+  const float* flags;
+  const float* UBC; const float* UBCInvMask;         // may be null
+  const float* rhoBC; const float* rhoBCInvMask;     // may be null
+  float* U; float* rho; float* div;
+};
+
+// velocity component `a` of cell (k,j,i) after setConstVals, addBuoyancy, setWallBcs, setConstVals
+template <bool IS3D, bool QUIRKS, bool WALL>
+__device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, int b, int a, int k, int j, int i,
+                                          bool buoy, float s_a, float rho_star) {
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)k * g.HW + j * g.W + i;
+  const size_t ou = ((size_t)b * NC + a) * g.DHW + o, os = (size_t)b * g.DHW + o;
+  const bool ubc = P.UBC != nullptr;
+  float u = P.U_adv[ou];
+  float m = 1.f, c = 0.f;
+  if (ubc) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; const float t = u * m; u = t + c; }        // simulate.py:96
+  const float fc = P.flags[os];
+  const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+  const int idx = a == 0 ? i : (a == 1 ? j : k);
+  const float fm = idx > 0 ? P.flags[os - off] : fc;
+  if (buoy && P.rho_adv && !is_border<IS3D>(g, i, j, k) && fc == FNX_FLUID && fm == FNX_FLUID) {   // source_terms.py
+    const bool rbc = P.rhoBC != nullptr;
+    float r0 = P.rho_adv[os], r1 = P.rho_adv[os - off];
+    if (rbc) {
+      float t = r0 * P.rhoBCInvMask[os]; r0 = t + P.rhoBC[os];
+      t = r1 * P.rhoBCInvMask[os - off]; r1 = t + P.rhoBC[os - off];
+    }
+    if (a == 2 && QUIRKS) u = u + s_a * (0.5f * (r0 + (k <= 1 ? 0.f : r1)));
+    else u = u + s_a * ((0.5f * (r0 + r1)) - rho_star);
+  }
+  // set_wall_bcs.py:45-84 (z: only k > 0); skipped before the convnet (simulate.py:120)
+  if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {
+    if (!(a == 2 && k == 0)) {
+      if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
+    }
+  }
+  if (ubc) { const float t = u * m; u = t + c; }                                             // simulate.py:133
+  return u;
+}
+
+template <bool IS3D, bool QUIRKS, bool WALL>
+__global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, StepPtrs P, int buoy, float sx, float sy,
+                                                                float sz, float rho_star) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const int bk = blockIdx.z;
+  const int b = IS3D ? bk / g.D : bk, k = IS3D ? bk - b * g.D : 0;
+  if (i >= g.W || j >= g.H) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
+  const bool by = buoy != 0;
+  const float u0 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i, by, sx, rho_star);
+  const float u1 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j, i, by, sy, rho_star);
+  float u2 = 0.f;
+  if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k, j, i, by, sz, rho_star);
+  P.U[((size_t)b * NC + 0) * g.DHW + o] = u0;
+  P.U[((size_t)b * NC + 1) * g.DHW + o] = u1;
+  if (IS3D) P.U[((size_t)b * NC + 2) * g.DHW + o] = u2;
+  if (P.rho_adv) {
+    float r = P.rho_adv[os];
+    if (P.rhoBC) {
+      const float m = P.rhoBCInvMask[os], c = P.rhoBC[os];
+      float t = r * m; r = t + c;       // simulate.py:96
+      t = r * m; r = t + c;             // simulate.py:133
+    }
+    P.rho[os] = r;
+  }
+  if (P.div) {
+    float d = 0.f;
+    if (!is_border<IS3D>(g, i, j, k)) {
+      const float u0p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i + 1, by, sx, rho_star);
+      const float u1p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j + 1, i, by, sy, rho_star);
+      d = ((u0 - u0p) + u1) - u1p;
+      if (IS3D) {
+        const float u2p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k + 1, j, i, by, sz, rho_star);
+        d = d + (u2 - u2p);
+      }
+    }
+    if (P.flags[os] == FNX_OBST) d = 0.f;
+    P.div[os] = d;
+  }
+}
+
+// velocityUpdate + setWallBcs + setConstVals (simulate.py:154-168), in place on U (and rho for the BC re-imposition)
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, const float* __restrict__ p,
+                                                                 float* __restrict__ U, float* __restrict__ rho,
+                                                                 const float* __restrict__ flags,
+                                                                 const float* __restrict__ UBC,
+                                                                 const float* __restrict__ UBCInvMask,
+                                                                 const float* __restrict__ rhoBC,
+                                                                 const float* __restrict__ rhoBCInvMask) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const int bk = blockIdx.z;
+  const int b = IS3D ? bk / g.D : bk, k = IS3D ? bk - b * g.D : 0;
+  if (i >= g.W || j >= g.H) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
+  const float fc = flags[os], P = p[os];
+  const bool border = is_border<IS3D>(g, i, j, k);
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const size_t ou = ((size_t)b * NC + a) * g.DHW + o;
+    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+    const int idx = a == 0 ? i : (a == 1 ? j : k);
+    const float fm = idx > 0 ? flags[os - off] : fc;
+    float u = U[ou];
+    if (!border) {     // velocity_update.py:47-149
+      const float Pm = p[os - off];
+      const float m_ff = (fc == FNX_FLUID && fm == FNX_FLUID) ? 1.f : 0.f;
+      if (!IS3D) {
+        const float m_fe = (fc == FNX_FLUID && fm == FNX_EMPTY) ? 1.f : 0.f;
+        const float m_ef = (fc == FNX_EMPTY && fm == FNX_FLUID) ? 1.f : 0.f;
+        const float m_nf = (fc == FNX_EMPTY && fm == FNX_EMPTY) ? 1.f : 0.f;
+        u = ((m_ff * (u - (P - Pm)) + m_fe * (u - P)) + m_ef * (u + Pm)) + m_nf * 0.f;
+      } else {
+        u = m_ff * (u - (P - Pm));
+      }
+    }
+    if (fc == FNX_FLUID || fc == FNX_OBST) {
+      if (!(a == 2 && k == 0)) {
+        if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
+      }
+    }
+    if (UBC) { const float t = u * UBCInvMask[ou]; u = t + UBC[ou]; }
+    U[ou] = u;
+  }
+  if (rho && rhoBC) { const float t = rho[os] * rhoBCInvMask[os]; rho[os] = t + rhoBC[os]; }
+}
+
+inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D); }
+
+}  // namespace
+
+namespace fnx {
+
+void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const float* U_adv, const float* rho_adv,
+                           const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
+                           const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
+                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s) {
+  StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div};
+  const dim3 grid = cell_grid(g), block(BX, BY);
+#define PRE(A, Q, WL) pre_projection_kernel<A, Q, WL><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star)
+  if (is3d) {
+    if (quirks) { if (wall_bcs) PRE(true, true, true); else PRE(true, true, false); }
+    else        { if (wall_bcs) PRE(true, false, true); else PRE(true, false, false); }
+  } else {
+    if (wall_bcs) PRE(false, false, true); else PRE(false, false, false);
+  }
+#undef PRE
+}
+
+void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
+                            const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
+                            hipStream_t s) {
+  const dim3 grid = cell_grid(g), block(BX, BY);
+  if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask);
+  else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask);
+}
+
+}  // namespace fnx
