@@ -1,8 +1,8 @@
 // MultiScale pressure-net forward (lib/multi_scale_net.py:118-127, lib/model.py:76-227) for gfx950.
 //
-// v0 conv path: direct fp32 convolution, one thread per output pixel x CO_T output channels, weights
-// streamed through the scalar cache (their address is wave-uniform), input taps through L1/L2.
-// (The implicit-GEMM MFMA kernel replaces conv_direct_kernel for the 32/64/128-channel layers.)
+// The 32/64/128-channel 3x3(x3) layers (95 % of the FLOPs) run as implicit GEMM on the matrix cores in exact fp32
+// (conv3_mfma_kernel); the thin first/last layers (Cin 2-3, Cout 1-8) are bandwidth-shaped and use a direct kernel
+// (one thread per output pixel x CO_T output channels, weights through the scalar cache).
 #include "fnx_cnn.h"
 
 namespace fnx {
@@ -25,6 +25,22 @@ PackedLayer packed_layer(int l, bool is3d) {
     off = (off + 63) & ~(size_t)63;
   }
   return r;
+}
+
+inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 && L.cout % 32 == 0; }
+
+// blob: (Cout,Cin,taps) -> packed [taps][Cin][Cout]   (implicit-GEMM layers: the A operand of the MFMA reads 32
+// consecutive output channels per lane half)
+__global__ void pack_layer_mfma_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                       float* __restrict__ pw, float* __restrict__ pb, int cin, int cout, int taps) {
+  const int n = cin * cout * taps;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int co = q / (cin * taps);
+    const int r = q - co * cin * taps;
+    const int ci = r / taps, t = r - ci * taps;
+    pw[((size_t)t * cin + ci) * cout + co] = w[q];
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
 }
 
 // blob: (Cout,Cin,taps) -> packed [Cout/CO_T][Cin][taps][CO_T]
@@ -101,9 +117,146 @@ void launch_conv_k(const ConvArgs& a, hipStream_t s) {
   else conv_direct_kernel<KS, 1, IS3D><<<grid, block, 0, s>>>(a);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Implicit-GEMM 3x3(x3) convolution on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//   D[cout 32][pixel 32] += A[cout][k] * B[k][pixel],  k = two consecutive input channels of one tap
+//   A: lane -> W[tap][c + (lane>>5)][cout0 + (lane&31)]      (one coalesced 256-B global/L1 read per wave)
+//   B: lane -> X[c + (lane>>5)][y + r - 1][x0 + (lane&31) + s - 1]  from the LDS halo tile (conflict-free rows)
+//   D: lane holds pixel (lane&31) and 16 output channels -> every store is a 128-B row segment
+// Workgroup = 4 waves stacked in y; wave tile = 32 px x PR rows x (CB*32) output channels (PR*CB accumulators of
+// 16 VGPRs).  Input channels are staged through LDS 8 at a time ((4PR+2) x 34 halo rows).  3D: the z taps are an
+// outer loop over the three input planes.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_CHUNK = 8;       // input channels per LDS stage
+constexpr int MF_COLS = 34;       // 32 + halo
+
+template <int CB, int PR, bool IS3D>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
+  constexpr int ROWS = 4 * PR + 2;
+  constexpr int KD = IS3D ? 3 : 1;
+  __shared__ float tile[MF_CHUNK * ROWS * MF_COLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * PR);
+  int zb = blockIdx.z;
+  const int ngrp = a.cout / (CB * 32);
+  const int grp = zb % ngrp; zb /= ngrp;
+  const int z = zb % a.D; const int b = zb / a.D;
+  const int cout0 = grp * CB * 32;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
+
+  f32x16 acc[PR][CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bv = a.bias[cout0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+      for (int pr = 0; pr < PR; ++pr) acc[pr][cb][r] = bv;
+    }
+  }
+
+  const float* xb = a.x + (size_t)b * a.cin * vol;
+  // Per-thread staging slots: element idx = threadIdx.x + 256*t of the [MF_CHUNK][ROWS][34] halo tile.  The global
+  // offset (relative to the chunk's first channel and the z plane) and the in-image predicate never change, so they
+  // are computed once; each stage is then NLD independent loads issued back to back (clamped address + select).
+  constexpr int NEL = MF_CHUNK * ROWS * MF_COLS;
+  constexpr int NLD = (NEL + 255) / 256;
+  int goff[NLD];
+  unsigned valid = 0;
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    const int cc = idx / (ROWS * MF_COLS);
+    const int rem = idx - cc * ROWS * MF_COLS;
+    const int row = rem / MF_COLS, col = rem - row * MF_COLS;
+    const int gx = x0 - 1 + col, gy = y0 - 1 + row;
+    const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+    goff[t] = ok ? (int)((size_t)cc * vol + (size_t)gy * a.W + gx) : 0;      // vol*MF_CHUNK < 2^31 is checked by the host
+    valid |= (unsigned)ok << t;
+  }
+  float stage[NLD];
+  auto prefetch = [&](int dz, int c0) {
+    const int zz = IS3D ? z + dz - 1 : 0;
+    const float* src = xb + (size_t)c0 * vol + (size_t)zz * plane;
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) stage[t] = src[goff[t]];
+  };
+  // iteration space: (dz, c0) pairs with an in-range z plane
+  const int nchunk = a.cin / MF_CHUNK;
+  int dz_lo = 0, dz_hi = KD;
+  if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = KD - 1; }
+  const int niter = (dz_hi - dz_lo) * nchunk;
+  if (niter > 0) prefetch(dz_lo, 0);
+  for (int it = 0; it < niter; ++it) {
+    const int dz = dz_lo + it / nchunk, c0 = (it % nchunk) * MF_CHUNK;
+    __syncthreads();                                   // everyone is done reading the previous tile
+#pragma unroll
+    for (int t = 0; t < NLD; ++t)
+      if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = ((valid >> t) & 1) ? stage[t] : 0.f;
+    __syncthreads();
+    if (it + 1 < niter) prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK);   // in flight during the MFMAs
+    {
+      const float* wz = a.w + ((size_t)(dz * 9) * a.cin + c0) * a.cout + cout0 + l31;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const float* wt = wz + (size_t)(r * 3 + s) * a.cin * a.cout;
+#pragma unroll
+          for (int cp = 0; cp < MF_CHUNK; cp += 2) {
+            float av[CB], bv[PR];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) av[cb] = wt[(size_t)(cp + half) * a.cout + cb * 32];
+#pragma unroll
+            for (int pr = 0; pr < PR; ++pr) bv[pr] = tile[(cp + half) * ROWS * MF_COLS + (wave * PR + pr + r) * MF_COLS + l31 + s];
+#pragma unroll
+            for (int pr = 0; pr < PR; ++pr)
+#pragma unroll
+              for (int cb = 0; cb < CB; ++cb) acc[pr][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[pr], acc[pr][cb], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  const int x = x0 + l31;
+  if (x < a.W) {
+#pragma unroll
+    for (int pr = 0; pr < PR; ++pr) {
+      const int y = y0 + wave * PR + pr;
+      if (y >= a.H) continue;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cout0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[pr][cb][r];
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.y[((size_t)b * a.cout + co) * vol + (size_t)z * plane + (size_t)y * a.W + x] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int CB, int PR>
+void launch_conv_mfma_t(const ConvArgs& a, bool is3d, hipStream_t s) {
+  const dim3 grid((a.W + 31) / 32, (a.H + 4 * PR - 1) / (4 * PR), a.B * a.D * (a.cout / (CB * 32)));
+  if (is3d) conv3_mfma_kernel<CB, PR, true><<<grid, 256, 0, s>>>(a);
+  else conv3_mfma_kernel<CB, PR, false><<<grid, 256, 0, s>>>(a);
+}
+
+void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
+  if (a.cout % 128 == 0) launch_conv_mfma_t<4, 2>(a, is3d, s);
+  else if (a.cout % 64 == 0) launch_conv_mfma_t<2, 4>(a, is3d, s);
+  else launch_conv_mfma_t<1, 4>(a, is3d, s);
+}
+
 void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const PackedLayer& pl, const float* x, float* y,
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
+  if (mfma_layer(L)) { launch_conv_mfma(a, is3d, s); return; }
   if (is3d) {
     if (L.k == 3) launch_conv_k<3, true>(a, s);
     else if (L.k == 5) launch_conv_k<5, true>(a, s);
@@ -191,8 +344,12 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     const ConvLayer& L = LAYERS[l];
     const PackedLayer pl = packed_layer(l, is3d);
     const size_t nw = layer_weight_floats(L, is3d);
-    pack_layer_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
-                                         layer_taps(L, is3d), co_tile(L.cout));
+    if (mfma_layer(L))
+      pack_layer_mfma_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
+                                                layer_taps(L, is3d));
+    else
+      pack_layer_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
+                                           layer_taps(L, is3d), co_tile(L.cout));
     off += nw + L.cout;
   }
 }
@@ -254,7 +411,14 @@ __global__ __launch_bounds__(256) void std_partial_kernel(size_t n, const float*
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&partial[2 * b], s); atomicAdd(&partial[2 * b + 1], ss); }
+  __shared__ double red[8];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[2 * wave] = s; red[2 * wave + 1] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {     // one atomic pair per workgroup
+    atomicAdd(&partial[2 * b], (red[0] + red[2]) + (red[4] + red[6]));
+    atomicAdd(&partial[2 * b + 1], (red[1] + red[3]) + (red[5] + red[7]));
+  }
 }
 
 __global__ void std_finish_kernel(int B, size_t n, const double* __restrict__ partial, float thr, float* __restrict__ scale) {
@@ -321,7 +485,10 @@ inline dim3 bgrid(size_t n1, int B) {
 void launch_scale_std(const GridDims& g, int nc, const float* U, float thr, double* partial, float* scale, hipStream_t s) {
   const size_t n = (size_t)nc * g.DHW;
   hipMemsetAsync(partial, 0, sizeof(double) * 2 * g.B, s);
-  std_partial_kernel<<<bgrid(n, g.B), 256, 0, s>>>(n, U, partial);
+  size_t nb = (n + 256 * 16 - 1) / (256 * 16);
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  std_partial_kernel<<<dim3((unsigned)nb, g.B), 256, 0, s>>>(n, U, partial);
   std_finish_kernel<<<1, 64 * ((g.B + 63) / 64), 0, s>>>(g.B, n, partial, thr, scale);
 }
 
