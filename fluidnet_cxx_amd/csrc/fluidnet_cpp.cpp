@@ -17,6 +17,7 @@ namespace {
 using at::Tensor;
 
 bool g_ref_quirks = false;
+int g_z_offset = 0, g_D_global = 0;   // z-slab view (set_slab): arrays hold planes [z_offset, z_offset+D) of D_global
 
 void check_status(int rc) {
   TORCH_CHECK(rc == FNX_OK, fnx_last_error());
@@ -36,6 +37,7 @@ FnxGrid grid_of(const Tensor& flags, bool is3D) {
   g.B = (int)flags.size(0); g.D = (int)flags.size(2); g.H = (int)flags.size(3); g.W = (int)flags.size(4);
   g.is3D = is3D ? 1 : 0;
   g.ref_quirks = g_ref_quirks ? 1 : 0;
+  g.z_offset = g_z_offset; g.D_global = is3D ? g_D_global : 0;
   if (!is3D) TORCH_CHECK(g.D == 1, "2D velocity field but zdepth > 1");
   return g;
 }
@@ -160,7 +162,7 @@ void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> 
                      c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask) {
   check_field(U, "U");
   FnxGrid g; g.B = (int)U.size(0); g.D = (int)U.size(2); g.H = (int)U.size(3); g.W = (int)U.size(4);
-  g.is3D = U.size(1) == 3; g.ref_quirks = 0;
+  g.is3D = U.size(1) == 3; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   auto ptr = [&](c10::optional<Tensor>& t, bool vel) -> float* {
     if (!t.has_value() || !t->defined()) return nullptr;
     if (vel) check_vel(*t, g, "UBC"); else check_scalar(*t, g, "densityBC");
@@ -200,7 +202,7 @@ Tensor multiscale_forward(Tensor packed, Tensor x) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "x must be a contiguous float32 GPU tensor");
   TORCH_CHECK((x.dim() == 4 || x.dim() == 5) && x.size(1) == 2, "x must be (B,2,H,W) or (B,2,D,H,W)");
   const bool is3D = x.dim() == 5 && x.size(2) > 1;
-  FnxGrid g; g.B = (int)x.size(0); g.is3D = is3D; g.ref_quirks = 0;
+  FnxGrid g; g.B = (int)x.size(0); g.is3D = is3D; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   g.D = x.dim() == 5 ? (int)x.size(2) : 1; g.H = (int)x.size(x.dim() - 2); g.W = (int)x.size(x.dim() - 1);
   c10::hip::HIPGuard guard(x.get_device());
   std::vector<int64_t> osz = x.sizes().vec(); osz[1] = 1;
@@ -216,7 +218,7 @@ std::vector<Tensor> fluidnet_forward(Tensor packed, Tensor input, double normali
   const bool is3D = input.size(1) == 6;
   TORCH_CHECK(input.size(1) == 5 || input.size(1) == 6, "input must have 5 (2D) or 6 (3D) channels [p, U, flags, density]");
   FnxGrid g; g.B = (int)input.size(0); g.D = (int)input.size(2); g.H = (int)input.size(3); g.W = (int)input.size(4);
-  g.is3D = is3D; g.ref_quirks = 0;
+  g.is3D = is3D; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   c10::hip::HIPGuard guard(input.get_device());
   Tensor p = at::empty({g.B, 1, g.D, g.H, g.W}, input.options());
   Tensor U = at::empty({g.B, is3D ? 3 : 2, g.D, g.H, g.W}, input.options());
@@ -264,8 +266,68 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   check_status(fnx_simulate_step(&g, &prm, &st, ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), cur_stream(U)));
 }
 
+// `nsweeps` more sweeps on an existing pressure field (in place) -- used by the z-slab driver
+void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps) {
+  FnxGrid g = grid_of(flags, is3D);
+  check_scalar(div, g, "div"); check_scalar(p, g, "p");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Workspace ws(g, FNX_OP_JACOBI, flags);
+  check_status(fnx_jacobi_sweeps(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(), nsweeps, ws.ptr,
+                                 ws.bytes, cur_stream(flags)));
+}
+
+static FnxState make_state(const FnxGrid& g, Tensor& p, Tensor& U, Tensor& flags, c10::optional<Tensor>& density,
+                           c10::optional<Tensor>& UBC, c10::optional<Tensor>& UBCInvMask,
+                           c10::optional<Tensor>& densityBC, c10::optional<Tensor>& densityBCInvMask) {
+  auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> float* {
+    if (!t.has_value() || !t->defined()) return nullptr;
+    if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
+    return t->data_ptr<float>();
+  };
+  FnxState st;
+  st.p = p.data_ptr<float>(); st.U = U.data_ptr<float>(); st.flags = flags.data_ptr<float>();
+  st.density = opt(density, false, "density");
+  st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
+  st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
+  st.net = nullptr;
+  return st;
+}
+
+// simulate.py:96-133 (+ divergence): U_adv/rho_adv -> U, density (written), returns div
+Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Tensor U, Tensor flags,
+                       c10::optional<Tensor> density, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
+                       c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask, double dt,
+                       double buoyancy_scale, std::vector<double> gravity_vec, double operating_density,
+                       bool jacobi_method) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_vel(U_adv, g, "U_adv"); check_scalar(p, g, "p");
+  FnxStepParams prm{};
+  prm.dt = (float)dt; prm.buoyancy_scale = (float)buoyancy_scale;
+  for (int a = 0; a < 3; ++a) prm.gravity_vec[a] = (float)gravity_vec[a];
+  prm.operating_density = (float)operating_density; prm.method = jacobi_method ? 0 : 1;
+  FnxState st = make_state(g, p, U, flags, density, UBC, UBCInvMask, densityBC, densityBCInvMask);
+  const float* ra = nullptr;
+  if (rho_adv.has_value() && rho_adv->defined()) { check_scalar(*rho_adv, g, "rho_adv"); ra = rho_adv->data_ptr<float>(); }
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor div = at::empty_like(flags);
+  check_status(fnx_pre_projection(&g, &prm, &st, U_adv.data_ptr<float>(), ra, div.data_ptr<float>(), cur_stream(U)));
+  return div;
+}
+
+void post_projection_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> density, c10::optional<Tensor> UBC,
+                      c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> densityBC,
+                      c10::optional<Tensor> densityBCInvMask) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_scalar(p, g, "p");
+  FnxState st = make_state(g, p, U, flags, density, UBC, UBCInvMask, densityBC, densityBCInvMask);
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_post_projection(&g, &st, cur_stream(U)));
+}
+
 int64_t step_workspace_bytes(int B, int D, int H, int W, bool is3D) {
-  FnxGrid g{B, D, H, W, is3D ? 1 : 0, 0};
+  FnxGrid g{B, D, H, W, is3D ? 1 : 0, 0, 0, 0};
   return (int64_t)fnx_workspace_bytes(&g, FNX_OP_STEP);
 }
 
@@ -289,8 +351,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("fluidnet_forward", &fluidnet_forward);
   m.def("simulate_step_", &simulate_step_);
   m.def("step_workspace_bytes", &step_workspace_bytes);
+  m.def("jacobi_sweeps_", &jacobi_sweeps_);
+  m.def("pre_projection_", &pre_projection_);
+  m.def("post_projection_", &post_projection_);
   m.def("set_ref_quirks", [](bool on) { g_ref_quirks = on; }, "3D only: reproduce the reference's 3D defects bit-for-bit");
   m.def("get_ref_quirks", []() { return g_ref_quirks; });
+  m.def("set_slab", [](int z_offset, int D_global) { g_z_offset = z_offset; g_D_global = D_global; },
+        "3D multi-GPU: subsequent calls treat their tensors as planes [z_offset, z_offset+D) of a D_global-deep domain (0,0 resets)");
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
 }

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt,
   constexpr int NC = IS3D ? 3 : 2;
   const Field fs{src + (size_t)c.b * g.DHW}, ff{flags + (size_t)c.b * g.DHW}, fu{U + (size_t)c.b * NC * g.DHW};
   const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
-  const float ctr[3] = { (float)c.i + 0.5f, (float)c.j + 0.5f, (float)c.k + 0.5f };
+  const float ctr[3] = { (float)c.i + 0.5f, (float)c.j + 0.5f, (float)(c.k + g.zoff) + 0.5f };   // global z
   float val = 0.f;
   float p[3] = { ctr[0], ctr[1], ctr[2] };
   if (!is_border<IS3D>(g, c.i, c.j, c.k)) {
@@ -62,8 +62,9 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt,
   dst[(size_t)c.b * g.DHW + o] = val;
   if (cell_out) {
     const int i0 = clampi((int)p[0], 0, g.W - 1), j0 = clampi((int)p[1], 0, g.H - 1);
-    const int k0 = (IS3D && !QUIRKS) ? clampi((int)p[2], 0, g.D - 1) : 0;      // Q10: k0 = 0 in the reference
-    cell_out[(size_t)c.b * g.DHW + o] = k0 * g.HW + j0 * g.W + i0;
+    // Q10: k0 = 0 in the reference.  Stored with a +1 plane bias so that global plane -1.. maps to a valid int
+    const int k0 = (IS3D && !QUIRKS) ? clampi((int)p[2], 0, g.Dglob - 1) - g.zoff : -g.zoff;
+    cell_out[(size_t)c.b * g.DHW + o] = (k0 + 1) * g.HW + j0 * g.W + i0;
   }
 }
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
     if (!fluid) {
       bwd = f;
     } else {
-      const float ctr[3] = { (float)c.i + 0.5f, (float)c.j + 0.5f, (float)c.k + 0.5f };
+      const float ctr[3] = { (float)c.i + 0.5f, (float)c.j + 0.5f, (float)(c.k + g.zoff) + 0.5f };
       float cen[3], disp[3], p[3];
       get_centered<IS3D>(g, fu, c.i, c.j, c.k, cen);
       const float ndt = -dt;
@@ -105,15 +106,17 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
   if (fluid) d = f + half_s * (fs.p[o] - bwd);          // applied on border cells too (reference :371)
   if (!border) {
     const int cell = cell_in[(size_t)c.b * g.DHW + o];
-    const int k0 = IS3D ? cell / g.HW : 0;
-    const int r = cell - k0 * g.HW;
+    const int kb = cell / g.HW;                           // local plane + 1
+    const int k0 = kb - 1;
+    const int r = cell - kb * g.HW;
     const int j0 = r / g.W, i0 = r - j0 * g.W;
     float mn = INFINITY, mx = -INFINITY;
     bool any = false;
 #pragma unroll
     for (int dk = -1; dk <= 1; ++dk) {
       const int kk = k0 + dk;
-      if (kk < 0 || kk >= g.D) continue;
+      if (kk + g.zoff < 0 || kk + g.zoff >= g.Dglob) continue;        // outside the domain
+      if (kk < 0 || kk >= g.D) continue;                              // beyond this slab's ghost planes (stale cell)
 #pragma unroll
       for (int dj = -1; dj <= 1; ++dj) {
         const int jj = j0 + dj;
@@ -145,7 +148,7 @@ __device__ __forceinline__ float sl_mac_component(const GridDims& g, const Field
   get_at_mac<IS3D, QUIRKS, COMP>(g, fu, i, j, k, v);
   const float px = ((float)i + 0.5f) + v[0] * (-dt);
   const float py = ((float)j + 0.5f) + v[1] * (-dt);
-  const float pz = ((float)k + 0.5f) + v[2] * (-dt);
+  const float pz = ((float)(k + g.zoff) + 0.5f) + v[2] * (-dt);
   return interpol<IS3D>(g, src, COMP, px, py, pz);
 }
 
@@ -184,7 +187,7 @@ __device__ __forceinline__ void clamp_bounds_mac(const GridDims& g, const float*
     const int qy = (int)(l == 0 ? pos[1] - v[1] : pos[1] + v[1]);
     const int qz = (int)(l == 0 ? pos[2] - v[2] : pos[2] + v[2]);
     const int i0 = clampi(qx, 0, g.W - 2), j0 = clampi(qy, 0, g.H - 2);
-    const int k0 = IS3D ? clampi(qz, 0, g.D - 2) : 0;
+    const int k0 = IS3D ? clampi(clampi(qz, 0, g.Dglob - 2) - g.zoff, 0, g.D - 2) : 0;
     const float* q = oc + (size_t)k0 * g.HW + j0 * g.W + i0;
     // reference visiting order: 000, 100, 010, 110 [, 001, 101, 011, 111] (x is the first digit)
     float o;
@@ -218,18 +221,18 @@ __device__ __forceinline__ float mac_bwd_correct_clamp(const GridDims& g, const 
   } else if (COMP == 2 && QUIRKS) {
     bwd = 0.f;
   } else {
-    bwd = interpol<IS3D>(g, ffwd, COMP, ((float)i + 0.5f) + vd[0], ((float)j + 0.5f) + vd[1], ((float)k + 0.5f) + vd[2]);
+    bwd = interpol<IS3D>(g, ffwd, COMP, ((float)i + 0.5f) + vd[0], ((float)j + 0.5f) + vd[1], ((float)(k + g.zoff) + 0.5f) + vd[2]);
   }
   // MacCormackCorrectMAC :453-498
   bool skip = !fluid;
-  const int idx = COMP == 0 ? i : (COMP == 1 ? j : k);
-  if (idx > 0) {
+  const int idx = COMP == 0 ? i : (COMP == 1 ? j : k + g.zoff);
+  if (idx > 0 && !(COMP == 2 && k == 0)) {
     const size_t om = o - (COMP == 0 ? 1 : (COMP == 1 ? g.W : g.HW));
     if (ff.p[om] != FNX_FLUID) skip = true;
   }
   const float corr = skip ? f : f + half_s * (forig.p[(size_t)COMP * g.DHW + o] - bwd);
   float mn = INFINITY, mx = -INFINITY;
-  const float pos[3] = { (float)i, (float)j, (float)k };
+  const float pos[3] = { (float)i, (float)j, (float)(k + g.zoff) };
   clamp_bounds_mac<IS3D>(g, forig.p + (size_t)COMP * g.DHW, pos, vd, mn, mx);
   return fmaxf(fminf(corr, mx), mn);
 }

@@ -33,10 +33,12 @@ int check_grid(const FnxGrid* g) {
   if (g->is3D && g->D < 3) return fail(FNX_EINVAL, "3D domain needs D >= 3");
   if ((long long)g->D * g->H * g->W >= (1ll << 31)) return fail(FNX_EINVAL, "more than 2^31 cells per sample");
   if ((long long)g->B * g->D > 65535) return fail(FNX_EINVAL, "B*D > 65535 not supported");
+  if (g->D_global != 0 && (!g->is3D || g->z_offset < 0 || g->z_offset + g->D > g->D_global))
+    return fail(FNX_EINVAL, "bad z-slab: z_offset=%d D=%d D_global=%d", g->z_offset, g->D, g->D_global);
   return FNX_OK;
 }
 
-inline GridDims dims(const FnxGrid* g) { return make_dims(g->B, g->D, g->H, g->W); }
+inline GridDims dims(const FnxGrid* g) { return make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global); }
 inline bool quirks(const FnxGrid* g) { return g->is3D && g->ref_quirks; }
 inline size_t ncell(const FnxGrid* g) { return (size_t)g->B * g->D * g->H * g->W; }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -202,6 +204,32 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
   return FNX_OK;
 }
 
+int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps, void* ws,
+                      size_t ws_bytes, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!flags || !div || !p) return fail(FNX_EINVAL, "jacobi_sweeps: NULL tensor");
+  if (nsweeps < 1) return fail(FNX_EINVAL, "At least 1 iteration is needed (maxIter < 1)");
+  hipStream_t s = (hipStream_t)stream;
+  const GridDims d = dims(g);
+  Carver c(ws, ws_bytes);
+  float* tmp = (float*)c.take(ncell(g) * 4);
+  if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  const int kmax = fnx::jacobi_max_sweeps_per_launch(d, g->is3D);
+  const int nl = (nsweeps + kmax - 1) / kmax;
+  // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
+  const float* in = p;
+  int done = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int k = nsweeps - done < kmax ? nsweeps - done : kmax;
+    float* out = (l % 2 == 0) ? tmp : p;
+    fnx::launch_jacobi(d, g->is3D, quirks(g), flags, div, in, out, k, false, nullptr, s);
+    in = out; done += k;
+  }
+  if (in != p) HIP_OK(hipMemcpyAsync(p, in, ncell(g) * 4, hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream) {
   if (int rc = check_grid(g)) return rc;
   if (!p || !U || !flags) return fail(FNX_EINVAL, "velocity_update: NULL tensor");
@@ -255,6 +283,39 @@ int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* s
   return FNX_OK;
 }
 
+int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
+                       const float* rho_adv, float* div, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!prm || !st || !st->U || !st->flags || !U_adv) return fail(FNX_EINVAL, "pre_projection: NULL state");
+  if (rho_adv && !st->density) return fail(FNX_EINVAL, "pre_projection: rho_adv given but state has no density");
+  const bool has_rho = rho_adv != nullptr;
+  const bool buoy = has_rho && prm->buoyancy_scale > 0.f;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (buoy) {
+    const float ns = -prm->buoyancy_scale;                       // gravity.mul_(-buoyancyScale), simulate.py:101-105
+    const float gx = prm->gravity_vec[0] * ns, gy = prm->gravity_vec[1] * ns, gz = prm->gravity_vec[2] * ns;
+    sx = gx * prm->dt; sy = gy * prm->dt; sz = gz * prm->dt;     // strength = gravity * dt, source_terms.py:45
+  }
+  const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  fnx::launch_pre_projection(dims(g), g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
+                             ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
+                             rbc ? st->densityBCInvMask : nullptr, st->U, st->density, div, buoy, sx, sy, sz,
+                             prm->operating_density, prm->method == 0, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!st || !st->U || !st->flags || !st->p) return fail(FNX_EINVAL, "post_projection: NULL state");
+  const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  fnx::launch_post_projection(dims(g), g->is3D, st->p, st->U, st->density, st->flags, ubc ? st->UBC : nullptr,
+                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
+                              rbc ? st->densityBCInvMask : nullptr, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes,
                       void* stream) {
   if (int rc = check_grid(g)) return rc;
@@ -279,29 +340,13 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
                               prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, wall BCs, BCs, -div
-  const bool buoy = has_rho && prm->buoyancy_scale > 0.f;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  if (buoy) {
-    const float ns = -prm->buoyancy_scale;                       // gravity.mul_(-buoyancyScale), simulate.py:101-105
-    const float gx = prm->gravity_vec[0] * ns, gy = prm->gravity_vec[1] * ns, gz = prm->gravity_vec[2] * ns;
-    sx = gx * prm->dt; sy = gy * prm->dt; sz = gz * prm->dt;     // strength = gravity * dt, source_terms.py:45
-  }
-  const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  if (int rc = fnx_pre_projection(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream)) return rc;
   const GridDims d = dims(g);
-  fnx::launch_pre_projection(d, g->is3D, quirks(g), U2, has_rho ? rho2 : nullptr, st->flags, ubc ? st->UBC : nullptr,
-                             ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
-                             rbc ? st->densityBCInvMask : nullptr, st->U, st->density,
-                             prm->method == 0 ? div : nullptr, buoy, sx, sy, sz, prm->operating_density,
-                             prm->method == 0, s);
   float* rho = has_rho ? st->density : nullptr;
   if (prm->method == 0) {
     // simulate.py:144-168
     if (int rc = fnx_jacobi(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, stream)) return rc;
-    fnx::launch_post_projection(d, g->is3D, st->p, st->U, rho, st->flags, ubc ? st->UBC : nullptr,
-                                ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
-                                rbc ? st->densityBCInvMask : nullptr, s);
-    HIP_OK(hipGetLastError());
-    return FNX_OK;
+    return fnx_post_projection(g, st, stream);
   } else {
     // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),
     // so the concatenation is not materialised: U is projected in place.

@@ -520,7 +520,7 @@ size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
 namespace fnx {
 int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, float* p_out, float* U, void* ws,
                   void* stream) {
-  const GridDims d = make_dims(g->B, g->D, g->H, g->W);
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   hipStream_t s = (hipStream_t)stream;
   const int nc = g->is3D ? 3 : 2;
   const size_t full = (size_t)g->B * d.DHW;
@@ -560,7 +560,7 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, void* ws, size_t ws_bytes,
                            void* stream) {
   if (!g || !packed || !x || !p || !ws) return FNX_EINVAL;
-  const GridDims d = make_dims(g->B, g->D, g->H, g->W);
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   fnx::multiscale_forward(d, g->is3D, packed, x, p, ws, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
@@ -569,7 +569,7 @@ int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x,
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float thr, float* p_out,
                          float* U_out, void* ws, size_t ws_bytes, void* stream) {
   if (!g || !packed || !input || !p_out || !U_out || !ws) return FNX_EINVAL;
-  const GridDims d = make_dims(g->B, g->D, g->H, g->W);
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int nc = g->is3D ? 3 : 2;

@@ -20,10 +20,15 @@ struct GridDims {
   int B, D, H, W;
   int HW;        // H*W
   int DHW;       // D*H*W (cells per sample; < 2^31 per sample is required)
+  // z-slab decomposition: this array holds planes [zoff, zoff + D) of a domain that is Dglob planes deep.
+  // Only the border test looks at them; single-GPU grids have zoff = 0, Dglob = D.
+  int zoff, Dglob;
 };
 
-__host__ __device__ inline GridDims make_dims(int B, int D, int H, int W) {
-  GridDims d; d.B = B; d.D = D; d.H = H; d.W = W; d.HW = H * W; d.DHW = D * H * W; return d;
+__host__ __device__ inline GridDims make_dims(int B, int D, int H, int W, int zoff = 0, int Dglob = 0) {
+  GridDims d; d.B = B; d.D = D; d.H = H; d.W = W; d.HW = H * W; d.DHW = D * H * W;
+  d.zoff = zoff; d.Dglob = Dglob > 0 ? Dglob : D;
+  return d;
 }
 
 // per-sample field views: pointer to channel 0 of sample b; channel stride = DHW
@@ -37,7 +42,8 @@ struct Field {
 template <bool IS3D>
 __device__ __forceinline__ bool is_border(const GridDims& g, int i, int j, int k) {
   bool r = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2);
-  if (IS3D) r = r | (k < 1) | (k > g.D - 2);
+  // a slab's first/last local plane has no z neighbour in this array: never evaluated (it is a stale ghost plane)
+  if (IS3D) r = r | (k + g.zoff < 1) | (k + g.zoff > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
   return r;
 }
 
@@ -93,7 +99,9 @@ __device__ __forceinline__ Lerp lerp_setup(const GridDims& g, float px, float py
   const float s0 = 1.f - s1, t0 = 1.f - t1, f0 = 1.f - f1;
   L.x0 = clampi(qx, 0, g.W - 2);
   L.y0 = clampi(qy, 0, g.H - 2);
-  L.z0 = IS3D ? clampi(qz, 0, g.D - 2) : 0;               // 2D: clamp(.,0,-1) = -1 -> wraps to plane 0
+  // positions are GLOBAL z; the plane index is clamped in the global domain (reference semantics) and then moved
+  // into this array (and clamped again only so that a stale ghost cell can never read out of bounds)
+  L.z0 = IS3D ? clampi(clampi(qz, 0, g.Dglob - 2) - g.zoff, 0, g.D - 2) : 0;   // 2D: plane 0
   L.s1 = clamp01(s1); L.t1 = clamp01(t1); L.f1 = clamp01(f1);
   L.s0 = clamp01(s0); L.t0 = clamp01(t0); L.f0 = clamp01(f0);
   return L;
@@ -158,11 +166,11 @@ __device__ __forceinline__ float interpol_with_fluid(const GridDims& g, const Fi
 // Line trace, cpp/calc_line_trace.cpp:259-424 -- one ray per thread, bounded loops.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool out_of_domain(const GridDims& g, const float p[3]) {   // :16-27
-  return (p[0] <= 0.f) | (p[0] >= (float)g.W) | (p[1] <= 0.f) | (p[1] >= (float)g.H) | (p[2] <= 0.f) | (p[2] >= (float)g.D);
+  return (p[0] <= 0.f) | (p[0] >= (float)g.W) | (p[1] <= 0.f) | (p[1] >= (float)g.H) | (p[2] <= 0.f) | (p[2] >= (float)g.Dglob);
 }
 __device__ __forceinline__ bool blocked_cell(const GridDims& g, const Field& flags, const float p[3]) {  // :33-64
   if (out_of_domain(g, p)) return false;
-  return flags.at(g, 0, (int)p[2], (int)p[1], (int)p[0]) != FNX_FLUID;
+  return flags.at(g, 0, clampi((int)p[2] - g.zoff, 0, g.D - 1), (int)p[1], (int)p[0]) != FNX_FLUID;
 }
 
 // HitBoundingBox, :73-149, batched-reference semantics (including the origin-inside-box case)
@@ -206,10 +214,10 @@ __device__ inline void line_trace(const GridDims& g, const Field& flags, const f
   const float length = sqrtf(fmaf(delta[2], delta[2], fmaf(delta[1], delta[1], delta[0] * delta[0])));
   if (length <= FNX_EPSILON) return;
   const float dir[3] = { delta[0] / length, delta[1] / length, delta[2] / length };
-  const float size[3] = { (float)g.W, (float)g.H, (float)g.D };
+  const float size[3] = { (float)g.W, (float)g.H, (float)g.Dglob };
   float cur = 0.f, next[3];
   // unit steps: a ray leaves the domain within W+H+D steps; the cap only guards against NaN inputs
-  const int max_steps = g.W + g.H + g.D + 8;
+  const int max_steps = g.W + g.H + g.Dglob + 8;
   for (int it = 0; it < max_steps; ++it) {
     if (cur >= length - FNX_HIT_MARGIN) return;
     const float step = fminf(length - cur, 1.f);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(BX* BY) void add_buoyancy_kernel(GridDims g, float*
     if (*(fl - g.HW) == FNX_FLUID) {
       float* uz = u + (size_t)2 * g.DHW;
       if (!QUIRKS) *uz = *uz + sz * ((0.5f * (rc + *(r - g.HW))) - rho_star);
-      else *uz = *uz + sz * (0.5f * (rc + (c.k <= 1 ? 0.f : *(r - g.HW))));      // source_terms.py:110-114
+      else *uz = *uz + sz * (0.5f * (rc + (c.k + g.zoff <= 1 ? 0.f : *(r - g.HW))));      // source_terms.py:110-114
     }
   }
 }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BX* BY) void set_wall_bcs_kernel(GridDims g, float*
   const float fy = c.j > 0 ? *(fl - g.W) : fc;
   if (fx == FNX_OBST || (fc == FNX_OBST && fx == FNX_FLUID)) u[0] = 0.f;
   if (fy == FNX_OBST || (fc == FNX_OBST && fy == FNX_FLUID)) u[g.DHW] = 0.f;
-  if (IS3D && c.k > 0) {
+  if (IS3D && c.k + g.zoff > 0 && c.k > 0) {
     const float fz = *(fl - g.HW);
     if (fz == FNX_OBST || (fc == FNX_OBST && fz == FNX_FLUID)) u[(size_t)2 * g.DHW] = 0.f;
   }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BX* BY) void empty_domain_kernel(GridDims g, float*
   const CellId c = cell_id<IS3D>(g);
   if (!c.valid) return;
   bool border = (c.i < bnd) | (c.i > g.W - 1 - bnd) | (c.j < bnd) | (c.j > g.H - 1 - bnd);
-  if (IS3D) border = border | (c.k < bnd) | (c.k > g.D - 1 - bnd);
+  if (IS3D) border = border | (c.k + g.zoff < bnd) | (c.k + g.zoff > g.Dglob - 1 - bnd);
   flags[(size_t)c.b * g.DHW + (size_t)c.k * g.HW + c.j * g.W + c.i] = border ? FNX_OBST : FNX_FLUID;
 }
 

@@ -35,7 +35,7 @@ __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, 
   if (ubc) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; const float t = u * m; u = t + c; }        // simulate.py:96
   const float fc = P.flags[os];
   const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
-  const int idx = a == 0 ? i : (a == 1 ? j : k);
+  const int idx = a == 0 ? i : (a == 1 ? j : k);          // local index: guards the read
   const float fm = idx > 0 ? P.flags[os - off] : fc;
   if (buoy && P.rho_adv && !is_border<IS3D>(g, i, j, k) && fc == FNX_FLUID && fm == FNX_FLUID) {   // source_terms.py
     const bool rbc = P.rhoBC != nullptr;
@@ -44,12 +44,12 @@ __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, 
       float t = r0 * P.rhoBCInvMask[os]; r0 = t + P.rhoBC[os];
       t = r1 * P.rhoBCInvMask[os - off]; r1 = t + P.rhoBC[os - off];
     }
-    if (a == 2 && QUIRKS) u = u + s_a * (0.5f * (r0 + (k <= 1 ? 0.f : r1)));
+    if (a == 2 && QUIRKS) u = u + s_a * (0.5f * (r0 + (k + g.zoff <= 1 ? 0.f : r1)));
     else u = u + s_a * ((0.5f * (r0 + r1)) - rho_star);
   }
   // set_wall_bcs.py:45-84 (z: only k > 0); skipped before the convnet (simulate.py:120)
   if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {
-    if (!(a == 2 && k == 0)) {
+    if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
       if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
     }
   }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
       }
     }
     if (fc == FNX_FLUID || fc == FNX_OBST) {
-      if (!(a == 2 && k == 0)) {
+      if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
         if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
       }
     }

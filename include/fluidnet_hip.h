@@ -51,6 +51,9 @@ typedef struct FnxGrid {
   int is3D;         /* 0: U has 2 channels and D must be 1; 1: U has 3 channels */
   int ref_quirks;   /* 3D only: 1 reproduces the reference's 3D defects bit-for-bit,
                        0 (default) gives the intended 3D semantics.  Ignored in 2D. */
+  /* z-slab decomposition (3D, multi-GPU): the arrays hold planes [z_offset, z_offset + D) of a domain that is
+     D_global planes deep; only the domain-border test uses them.  0 / 0 = a whole domain (the default). */
+  int z_offset, D_global;
 } FnxGrid;
 
 /* Workspace sizing. */
@@ -82,6 +85,12 @@ int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags
  * last sweep) or NULL.  iters_done: HOST pointer or NULL.  p_tol <= 0 never synchronises. */
 int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual,
                float p_tol, int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream);
+
+/* `nsweeps` more Jacobi sweeps starting from the pressure already in `p` (in place).  Same per-sweep arithmetic as
+ * fnx_jacobi (cpp/fluids_init.cpp:858-994); used by the z-slab driver, which exchanges ghost planes of p between
+ * blocks of sweeps.  No residual. */
+int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
+                      void* ws, size_t ws_bytes, void* stream);
 
 /* velocityUpdate (in place on U), lib/fluid/velocity_update.py:6-162 */
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream);
@@ -129,6 +138,14 @@ typedef struct FnxState {
 
 int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st,
                       void* ws, size_t ws_bytes, void* stream);
+
+/* The two fused stages of fnx_simulate_step, exposed for drivers that interleave their own work (halo exchange):
+ *   pre : simulate.py:96-133 + :144  U_adv, rho_adv (advection outputs) -> st->U, st->density, div
+ *         (setConstVals, addBuoyancy, setWallBcs [method 0 only], setConstVals, velocityDivergence [div != NULL])
+ *   post: simulate.py:154-168        velocityUpdate(st->p), setWallBcs, setConstVals, in place on st->U / st->density */
+int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
+                       const float* rho_adv, float* div, void* stream);
+int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream);
 
 /* MultiScaleNet / FluidNet.forward, lib/multi_scale_net.py:118-127 and lib/model.py:76-227 (ScaleNet variant).
  * weights_blob: 17 convs in the order convN_4[0..3], convN_2[0..5], convN_1[0..5], final; for each conv the

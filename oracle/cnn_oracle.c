@@ -22,7 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct { int B, D, H, W, is3D; } OraGrid;
+typedef struct { int B, D, H, W, is3D, zoff, Dglob; } OraGrid;
 
 int ora_velocity_divergence(const OraGrid* g, const float* U, const float* flags, float* div);
 int ora_velocity_update(const OraGrid* g, const float* p, float* U, const float* flags);

@@ -25,7 +25,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct { int B, D, H, W, is3D; } OraGrid;
+/* zoff/Dglob: the arrays hold planes [zoff, zoff+D) of a Dglob-deep domain (z-slab tests); 0/0 = whole domain */
+typedef struct { int B, D, H, W, is3D, zoff, Dglob; } OraGrid;
+#define DG(g) ((g)->Dglob > 0 ? (g)->Dglob : (g)->D)
 
 #define HIT_MARGIN 1e-5f   /* calc_line_trace.cpp:7 */
 #define EPSILON    1e-12f  /* calc_line_trace.cpp:8 */
@@ -39,7 +41,7 @@ typedef struct { int B, D, H, W, is3D; } OraGrid;
 static inline int is_border(const OraGrid* g, int i, int j, int k, int bnd) {
   /* fluids_init.cpp:313-320 */
   int r = (i < bnd) || (i > g->W - 1 - bnd) || (j < bnd) || (j > g->H - 1 - bnd);
-  if (g->is3D) r = r || (k < bnd) || (k > g->D - 1 - bnd);
+  if (g->is3D) r = r || (k + g->zoff < bnd) || (k + g->zoff > DG(g) - 1 - bnd) || (bnd == 1 && (k < 1 || k > g->D - 2));
   return r;
 }
 
@@ -94,8 +96,8 @@ static void lerp_setup(const OraGrid* g, const float pos[3], Lerp* L) {
   float s0 = 1.f - s1, t0 = 1.f - t1, f0 = 1.f - f1;
   L->x0 = clampl(qx, 0, g->W - 2);
   L->y0 = clampl(qy, 0, g->H - 2);
-  L->z0 = clampl(qz, 0, g->D - 2);
-  if (L->z0 < 0) L->z0 += g->D;    /* 2D: clamp(.,0,-1) = -1, which wraps to plane 0 */
+  if (g->is3D) L->z0 = clampl(clampl(qz, 0, DG(g) - 2) - g->zoff, 0, g->D - 2);   /* global plane -> this array */
+  else L->z0 = 0;                    /* 2D: clamp(.,0,-1) = -1, which wraps to plane 0 */
   L->s1 = clamp01(s1); L->t1 = clamp01(t1); L->f1 = clamp01(f1);
   L->s0 = clamp01(s0); L->t0 = clamp01(t0); L->f0 = clamp01(f0);
 }
@@ -156,11 +158,11 @@ static float interpol_with_fluid(const OraGrid* g, const float* f, const float* 
  * ---------------------------------------------------------------------------------------- */
 static inline int out_of_domain(const OraGrid* g, const float p[3]) {   /* :16-27 */
   return (p[0] <= 0.f) || (p[0] >= (float)g->W) || (p[1] <= 0.f) || (p[1] >= (float)g->H) ||
-         (p[2] <= 0.f) || (p[2] >= (float)g->D);
+         (p[2] <= 0.f) || (p[2] >= (float)DG(g));
 }
 static inline int blocked_cell(const OraGrid* g, const float* flags, int b, const float p[3]) {   /* :33-64 */
   if (out_of_domain(g, p)) return 0;
-  long ix = (long)p[0], iy = (long)p[1], iz = (long)p[2];
+  long ix = (long)p[0], iy = (long)p[1], iz = clampl((long)p[2] - g->zoff, 0, g->D - 1);
   return flags[IDX(g, 1, b, 0, iz, iy, ix)] != T_FLUID;
 }
 
@@ -202,9 +204,9 @@ static void line_trace(const OraGrid* g, const float* flags, int b, const float 
   const float length = sqrtf(fmaf(delta[2], delta[2], fmaf(delta[1], delta[1], delta[0] * delta[0])));
   if (length <= EPSILON) return;
   const float dir[3] = { delta[0] / length, delta[1] / length, delta[2] / length };
-  const float size[3] = { (float)g->W, (float)g->H, (float)g->D };
+  const float size[3] = { (float)g->W, (float)g->H, (float)DG(g) };
   float cur = 0.f, next[3];
-  const int max_steps = g->W + g->H + g->D + 8;   /* NaN guard only: a unit-step ray exits the domain sooner */
+  const int max_steps = g->W + g->H + DG(g) + 8;   /* NaN guard only: a unit-step ray exits the domain sooner */
   for (int it = 0; it < max_steps; ++it) {
     if (cur >= length - HIT_MARGIN) return;
     const float step = fminf(length - cur, 1.f);
@@ -266,7 +268,7 @@ static void sl_scalar_pass(const OraGrid* g, float dt, const float* src, const f
       for (int j = 0; j < g->H; ++j)
         for (int i = 0; i < g->W; ++i) {
           const size_t c = IDX(g, 1, b, 0, k, j, i);
-          const float ctr[3] = { (float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f };
+          const float ctr[3] = { (float)i + 0.5f, (float)j + 0.5f, (float)(k + g->zoff) + 0.5f };
           float val = 0.f, p[3] = { ctr[0], ctr[1], ctr[2] };
           if (!is_border(g, i, j, k, 1)) {
             if (flags[c] != T_FLUID) {
@@ -314,12 +316,13 @@ int ora_advect_scalar(const OraGrid* g, float dt, const float* src, const float*
             /* getClampBounds :154-222 */
             long i0 = clampl((long)fpos[IDX(g, 3, b, 0, k, j, i)], 0, g->W - 1);
             long j0 = clampl((long)fpos[IDX(g, 3, b, 1, k, j, i)], 0, g->H - 1);
-            long k0 = (g->is3D && !quirks) ? clampl((long)fpos[IDX(g, 3, b, 2, k, j, i)], 0, g->D - 1) : 0;  /* Q10 */
+            long k0 = (g->is3D && !quirks) ? clampl((long)fpos[IDX(g, 3, b, 2, k, j, i)], 0, DG(g) - 1) - g->zoff : -g->zoff;  /* Q10 */
             float mn = INFINITY, mx = -INFINITY; int cnt = 0;
             for (int dk = -1; dk <= 1; ++dk)
               for (int dj = -1; dj <= 1; ++dj)
                 for (int di = -1; di <= 1; ++di) {
                   long kk = k0 + dk, jj = j0 + dj, ii = i0 + di;
+                  if (kk + g->zoff < 0 || kk + g->zoff >= DG(g)) continue;
                   if (kk < 0 || kk >= g->D || jj < 0 || jj >= g->H || ii < 0 || ii >= g->W) continue;
                   const size_t q = IDX(g, 1, b, 0, kk, jj, ii);
                   if (flags[q] == T_FLUID || sample_outside) {
@@ -351,7 +354,7 @@ static void sl_mac_pass(const OraGrid* g, float dt, const float* src, const floa
               r[0] = src[IDX(g, nc, b, 1, k, j, i)];                       /* Q1, :413-416 */
               if (g->is3D) r[2] = src[IDX(g, nc, b, 2, k, j, i)];
             } else {
-              const float ctr[3] = { (float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f };
+              const float ctr[3] = { (float)i + 0.5f, (float)j + 0.5f, (float)(k + g->zoff) + 0.5f };
               for (int c = 0; c < nc; ++c) {
                 if (c == 2 && quirks) { r[2] = 0.f; break; }               /* Q12, :441-447 */
                 float v[3], p[3];
@@ -386,12 +389,12 @@ int ora_advect_vel(const OraGrid* g, float dt, const float* orig, const float* U
             continue;
           }
           const int fl = flags[IDX(g, 1, b, 0, k, j, i)] == T_FLUID;
-          const int idx[3] = { i, j, k };
+          const int idx[3] = { i, j, k + g->zoff };
           for (int c = 0; c < nc; ++c) {
             const size_t q = IDX(g, nc, b, c, k, j, i);
             /* MacCormackCorrectMAC :453-498 */
             int skip = !fl;
-            if (idx[c] > 0) {
+            if (idx[c] > 0 && !(c == 2 && k == 0)) {
               const size_t qm = IDX(g, 1, b, 0, k - (c == 2), j - (c == 1), i - (c == 0));
               if (flags[qm] != T_FLUID) skip = 1;
             }
@@ -400,13 +403,13 @@ int ora_advect_vel(const OraGrid* g, float dt, const float* orig, const float* U
             float v[3];
             get_at_mac(g, U, nc, b, i, j, k, c, quirks, v);
             for (int a = 0; a < 3; ++a) v[a] = v[a] * dt;
-            const float pos[3] = { (float)i, (float)j, (float)k };
+            const float pos[3] = { (float)i, (float)j, (float)(k + g->zoff) };
             float mn = INFINITY, mx = -INFINITY;
             for (int l = 0; l < 2; ++l) {
               int q0[3];
               for (int a = 0; a < 3; ++a) q0[a] = (int)(l == 0 ? pos[a] - v[a] : pos[a] + v[a]);
               long i0 = clampl(q0[0], 0, g->W - 2), j0 = clampl(q0[1], 0, g->H - 2);
-              long k0 = clampl(q0[2], 0, g->is3D ? g->D - 2 : 0);
+              long k0 = g->is3D ? clampl(clampl(q0[2], 0, DG(g) - 2) - g->zoff, 0, g->D - 2) : 0;
               long k1 = g->is3D ? k0 + 1 : k0;
               for (long kk = k0; kk <= k1; ++kk)
                 for (long jj = j0; jj <= j0 + 1; ++jj)
@@ -508,6 +511,42 @@ int ora_jacobi(const OraGrid* g, const float* flags, const float* div, float* p,
   return 0;
 }
 
+/* `nsweeps` more sweeps on an existing pressure field, in place (same per-cell update as ora_jacobi). */
+int ora_jacobi_sweeps(const OraGrid* g, const float* flags, const float* div, float* p, int nsweeps, int quirks) {
+  const size_t n = (size_t)g->B * g->D * g->H * g->W;
+  float* prev = (float*)malloc(n * sizeof(float));
+  const float denom = g->is3D ? 6.f : 4.f;
+  for (int it = 0; it < nsweeps; ++it) {
+    memcpy(prev, p, n * sizeof(float));
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < g->B; ++b)
+      for (int k = 0; k < g->D; ++k)
+        for (int j = 0; j < g->H; ++j)
+          for (int i = 0; i < g->W; ++i) {
+            const size_t c = IDX(g, 1, b, 0, k, j, i);
+            float v = 0.f;
+            if (!is_border(g, i, j, k, 1) && flags[c] != T_OBST) {
+              const float pc = prev[c];
+#define NB(q, sub) ((sub) && flags[q] == T_OBST ? pc : prev[q])
+              float s = NB(c - 1, 1) + NB(c + 1, 1);
+              s = s + NB(c - g->W, 1);
+              s = s + NB(c + g->W, 1);
+              if (g->is3D) {
+                s = s + NB(c - (size_t)g->H * g->W, !quirks);
+                s = s + NB(c + (size_t)g->H * g->W, !quirks);
+              } else {
+                s = s + 0.f; s = s + 0.f;
+              }
+#undef NB
+              v = (s + div[c]) / denom;
+            }
+            p[c] = v;
+          }
+  }
+  free(prev);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * velocityUpdate (velocity_update.py:47-149; 3D intent solver_cpp/src/projection/update_vel.cpp:58-117)
  * ---------------------------------------------------------------------------------------- */
@@ -572,7 +611,7 @@ int ora_add_buoyancy(const OraGrid* g, float* U, const float* flags, const float
               if (flags[zl] == T_FLUID) U[q] = U[q] + st[2] * ((0.5f * (rho[c] + rho[zl])) - rho_star);
             } else {
               /* Q14, source_terms.py:110-114: tests j<=0 (never true inside), no rho_star, zero for k<=1 */
-              if (flags[zl] == T_FLUID) U[q] = U[q] + st[2] * (0.5f * (rho[c] + (k <= 1 ? 0.f : rho[zl])));
+              if (flags[zl] == T_FLUID) U[q] = U[q] + st[2] * (0.5f * (rho[c] + (k + g->zoff <= 1 ? 0.f : rho[zl])));
             }
           }
         }
@@ -597,7 +636,7 @@ int ora_set_wall_bcs(const OraGrid* g, float* U, const float* flags) {
           const float fy = flags[IDX(g, 1, b, 0, k, jl, i)];
           if (fx == T_OBST || (fc == T_OBST && fx == T_FLUID)) U[IDX(g, nc, b, 0, k, j, i)] = 0.f;
           if (fy == T_OBST || (fc == T_OBST && fy == T_FLUID)) U[IDX(g, nc, b, 1, k, j, i)] = 0.f;
-          if (g->is3D && k > 0) {
+          if (g->is3D && k > 0 && k + g->zoff > 0) {
             const float fz = flags[IDX(g, 1, b, 0, k - 1, j, i)];
             if (fz == T_OBST || (fc == T_OBST && fz == T_FLUID)) U[IDX(g, nc, b, 2, k, j, i)] = 0.f;
           }

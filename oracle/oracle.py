@@ -15,7 +15,15 @@ _LIB = os.path.join(_HERE, "libfluid_oracle.so")
 
 class OraGrid(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
-                ("is3D", ctypes.c_int)]
+                ("is3D", ctypes.c_int), ("zoff", ctypes.c_int), ("Dglob", ctypes.c_int)]
+
+
+# z-slab view used by the multi-GPU decomposition tests: arrays hold planes [zoff, zoff+D) of a Dglob-deep domain
+_SLAB = [0, 0]
+
+
+def set_slab(zoff=0, dglob=0):
+    _SLAB[0], _SLAB[1] = int(zoff), int(dglob)
 
 
 def build(force=False):
@@ -47,7 +55,7 @@ def _grid(flags_like, is3d=None):
     B, _, D, H, W = flags_like.shape
     if is3d is None:
         is3d = D > 1
-    return OraGrid(B, D, H, W, int(is3d))
+    return OraGrid(B, D, H, W, int(is3d), _SLAB[0] if is3d else 0, _SLAB[1] if is3d else 0)
 
 
 METHODS = {"eulerFluidNet": 0, "maccormackFluidNet": 1}
@@ -95,6 +103,14 @@ def jacobi(flags, div, is3d, p_tol, max_iter, quirks=False):
     return p, res.value, it.value
 
 
+def jacobi_sweeps(flags, div, p, is3d, nsweeps, quirks=False):
+    g = _grid(flags, is3d)
+    flags, pf = _f(flags); div, pd = _f(div)
+    p = np.array(p, dtype=np.float32, order="C", copy=True)
+    lib().ora_jacobi_sweeps(ctypes.byref(g), pf, pd, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(nsweeps), int(quirks))
+    return p
+
+
 def velocity_update(p, U, flags):
     g = _grid(flags, U.shape[1] == 3)
     p, pp = _f(p); flags, pf = _f(flags)
@@ -140,7 +156,7 @@ def flags_to_occupancy(flags):
 
 
 def empty_domain(B, D, H, W, bnd=1):
-    g = OraGrid(B, D, H, W, int(D > 1))
+    g = OraGrid(B, D, H, W, int(D > 1), _SLAB[0] if D > 1 else 0, _SLAB[1] if D > 1 else 0)
     flags = np.empty((B, 1, D, H, W), np.float32)
     lib().ora_empty_domain(ctypes.byref(g), flags.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(bnd))
     return flags
@@ -162,7 +178,7 @@ def multiscale_forward(blob, x, is3d=False):
     """x: (B,2,H,W) or (B,2,D,H,W) -> (B,1,...)"""
     x5 = x if x.ndim == 5 else x[:, :, None]
     B, _, D, H, W = x5.shape
-    g = OraGrid(B, D, H, W, int(is3d))
+    g = OraGrid(B, D, H, W, int(is3d), 0, 0)
     x5, px = _f(x5); blob, pb = _f(blob)
     p = np.empty((B, 1, D, H, W), np.float32)
     lib().ora_multiscale_forward(ctypes.byref(g), pb, px, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
@@ -171,7 +187,7 @@ def multiscale_forward(blob, x, is3d=False):
 
 def scale_std(U, thr=1e-5):
     B, nc, D, H, W = U.shape
-    g = OraGrid(B, D, H, W, int(nc == 3))
+    g = OraGrid(B, D, H, W, int(nc == 3), 0, 0)
     U, pu = _f(U)
     s = np.empty((B,), np.float32)
     lib().ora_scale_std(ctypes.byref(g), pu, ctypes.c_float(thr), s.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
@@ -181,7 +197,7 @@ def scale_std(U, thr=1e-5):
 def fluidnet_forward(blob, inp, thr=1e-5):
     B, cin, D, H, W = inp.shape
     nc = cin - 3
-    g = OraGrid(B, D, H, W, int(nc == 3))
+    g = OraGrid(B, D, H, W, int(nc == 3), 0, 0)
     inp, pi = _f(inp); blob, pb = _f(blob)
     p = np.empty((B, 1, D, H, W), np.float32); U = np.empty((B, nc, D, H, W), np.float32)
     lib().ora_fluidnet_forward(ctypes.byref(g), pb, pi, ctypes.c_float(thr),
