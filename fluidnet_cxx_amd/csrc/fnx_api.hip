@@ -52,7 +52,7 @@ struct Carver {
 
 size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4); }
 size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
-size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4); }
+size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + (g->is3D ? al(ncell(g)) : 0); }
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   size_t adv = ws_advect_scalar(g) > ws_advect_vel(g) ? ws_advect_scalar(g) : ws_advect_vel(g);
@@ -159,8 +159,14 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
   float* tmp = (float*)c.take(ncell(g) * 4);
   float* sumsq = (float*)c.take((size_t)g->B * 4);
   float* res_ws = (float*)c.take(4);
+  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "solve_linear_system: workspace too small (%zu < %zu)", ws_bytes, c.off);
   const bool q = quirks(g);
+  if (g->is3D) fnx::launch_jacobi3d_mask(d, q, flags, mask, s);
+  auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss) {
+    if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
+    else fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
+  };
   if (!(p_tol > 0.f)) {
     const int kmax = fnx::jacobi_max_sweeps_per_launch(d, g->is3D);
     const int nl = (max_iter + kmax - 1) / kmax;
@@ -172,7 +178,7 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
       // spread the remainder so that no launch runs a single sweep needlessly late
       float* out = ((nl - 1 - l) % 2 == 0) ? p : tmp;
       const bool last = l == nl - 1;
-      fnx::launch_jacobi(d, g->is3D, q, flags, div, in, out, k, l == 0, (last && residual) ? sumsq : nullptr, s);
+      sweep(in, out, k, l == 0, (last && residual) ? sumsq : nullptr);
       in = out;
       done += k;
     }
@@ -187,7 +193,7 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
     for (;;) {
       float* out = bufs[sweeps & 1];
       HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
-      fnx::launch_jacobi(d, g->is3D, q, flags, div, in, out, 1, sweeps == 0, sumsq, s);
+      sweep(in, out, 1, sweeps == 0, sumsq);
       fnx::launch_residual_finish(g->B, sumsq, res_ws, s);
       HIP_OK(hipMemcpyAsync(&r, res_ws, 4, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
@@ -213,7 +219,10 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
   const GridDims d = dims(g);
   Carver c(ws, ws_bytes);
   float* tmp = (float*)c.take(ncell(g) * 4);
+  c.take((size_t)g->B * 4); c.take(4);
+  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  if (g->is3D) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   const int kmax = fnx::jacobi_max_sweeps_per_launch(d, g->is3D);
   const int nl = (nsweeps + kmax - 1) / kmax;
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
@@ -222,7 +231,8 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
   for (int l = 0; l < nl; ++l) {
     const int k = nsweeps - done < kmax ? nsweeps - done : kmax;
     float* out = (l % 2 == 0) ? tmp : p;
-    fnx::launch_jacobi(d, g->is3D, quirks(g), flags, div, in, out, k, false, nullptr, s);
+    if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
+    else fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s);
     in = out; done += k;
   }
   if (in != p) HIP_OK(hipMemcpyAsync(p, in, ncell(g) * 4, hipMemcpyDeviceToDevice, s));

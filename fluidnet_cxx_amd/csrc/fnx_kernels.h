@@ -41,6 +41,10 @@ void launch_post_projection(const GridDims& g, bool is3d, const float* p, float*
 void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags, const float* div, const float* p_in,
                    float* p_out, int nsweeps, bool from_zero, float* sumsq, hipStream_t s);
 int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d);
+// 3D: flags -> 7-bit neighbour mask (once per solve), then one z-marching sweep per launch
+void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, unsigned char* mask, hipStream_t s);
+void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
+                     bool from_zero, float* sumsq, hipStream_t s);
 void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
 void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s);
 
