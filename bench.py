@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the fluid time step (BASELINE.json metric: steps/s + Mcells/s).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-graph] [--no-cpu-baseline]
 
 A "step" is one pass of `simulate` over one synthetic plume state that is already resident in HBM.
 Workloads (BASELINE.json configs):
-  plume2d_1024_cnn     config[1]: 2D plume 1024^2, CNN pressure (ScaleNet, hash-seeded random-init weights)   [default, N=1]
-  plume2d_1024_jacobi  2D plume 1024^2, Jacobi-28
-  rt2d_2048_jacobi     config[2]: 2D Rayleigh-Taylor 2048^2, Jacobi-100
-  plume2d_128_jacobi   config[0]: 2D plume 128^2, Jacobi-28
-  plume3d_slab_jacobi  config[4] per-GPU share: 3D plume 512x512x(64 per rank), Jacobi-100  [default, N>1: independent
-                       replicas of the slab until the RCCL halo exchange lands -- "scaling": "weak"]
+  plume2d_1024_cnn     configs[1]: 2D plume 1024^2, CNN pressure (ScaleNet, hash-seeded random-init weights)  [default, N=1]
+  plume2d_1024_jacobi  2D plume 1024^2, Jacobi-28 (the north star's "advection+Jacobi step at 1024^2")
+  rt2d_2048_jacobi     configs[2]: 2D Rayleigh-Taylor 2048^2, Jacobi-100
+  plume2d_128_jacobi   configs[0]: 2D plume 128^2, Jacobi-28
+  plume3d_256_jacobi   3D plume 256^3, Jacobi-100
+  plume3d_slab_jacobi  configs[4]: 3D plume 512x512x(64 per GPU), Jacobi-100, z-slabs + P2P ghost exchange  [default, N>1]
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -24,12 +25,12 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-MFMA_F32_PEAK_TF = 157.3     # exact-f32 MFMA peak
+MFMA_F32_PEAK_TF = 157.3     # exact-f32 MFMA peak (v_mfma_f32_32x32x2_f32)
 
 # algorithmic bytes per cell, 2D / 3D
 STEP_BYTES = {False: lambda n: 340 + 16 * n, True: lambda n: 452 + 16 * n}
 CNN_FLOP_PER_CELL = {False: 484476, True: 1338929}
-CNN_GLUE_BYTES = 16 + 8 + 12 + 24 + 24 + 20   # div, std, pack, velUpdate, scale, wallBcs (2D)
+PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4)
 
 WORKLOADS = {
     "plume2d_1024_cnn": dict(res=1024, D=1, method="convnet", iters=0, kind="plume"),
@@ -37,18 +38,54 @@ WORKLOADS = {
     "rt2d_2048_jacobi": dict(res=2048, D=1, method="jacobi", iters=100, kind="rt"),
     "plume2d_128_jacobi": dict(res=128, D=1, method="jacobi", iters=28, kind="plume"),
     "plume3d_256_jacobi": dict(res=256, D=256, method="jacobi", iters=100, kind="plume"),
-    "plume3d_slab_jacobi": dict(res=512, D=64, method="jacobi", iters=100, kind="plume"),
+    "plume3d_slab_jacobi": dict(res=512, D=64, method="jacobi", iters=100, kind="plume", slab=True),
 }
 
 
-def build_state(w, dev):
-    import numpy as np
+def mfma_flops_per_cell(is3d):
+    """FLOPs of the layers that run on the matrix cores (3x3 convs with 32/64/128 channels), per full-res cell."""
+    taps = 27 if is3d else 9
+    t1 = 2 * taps * (32 * 64 + 64 * 128 + 128 * 64 + 64 * 32)
+    t4 = 2 * taps * (32 * 64 + 64 * 32)
+    s = 8 if is3d else 4
+    return t1 * (1 + 1.0 / s) + t4 / (s * s)
+
+
+def plume_state_torch(res, D_local, dev, z_offset=0, D_global=None):
+    """Plume initial state + BC masks (reference plume.py:131-163 / createPlumeBCs; 3D: inlet disc) for the planes
+    [z_offset, z_offset + D_local) of a D_global-deep domain, built on the device."""
     import torch
-    from util import plume_state
+    is3d = (D_global or D_local) > 1
+    Dg = D_global or D_local
+    nc = 3 if is3d else 2
+    shp = (1, 1, D_local, res, res)
+    z = torch.arange(z_offset, z_offset + D_local, device=dev).view(D_local, 1, 1)
+    y = torch.arange(res, device=dev).view(1, res, 1)
+    x = torch.arange(res, device=dev).view(1, 1, res)
+    border = (x < 1) | (x > res - 2) | (y < 1) | (y > res - 2)
+    if is3d:
+        border = border | (z < 1) | (z > Dg - 2)
+    flags = torch.where(border, 2.0, 1.0).to(torch.float32).expand(D_local, res, res).reshape(shp).contiguous()
+    rad = math.floor(res * 0.145)
+    r2 = (x - res // 2) ** 2
+    if is3d:
+        r2 = r2 + (z - Dg // 2) ** 2
+    inside = (r2 <= rad * rad).expand(D_local, 4, res)
+    st = dict(p=torch.zeros(shp, device=dev), U=torch.zeros((1, nc, D_local, res, res), device=dev),
+              density=torch.zeros(shp, device=dev), flags=flags)
+    UBC = torch.zeros_like(st["U"]); UBC[0, 1, :, 0:4] = inside.float() * 2.0
+    UBCInvMask = torch.ones_like(st["U"]); UBCInvMask[:, :, :, 0:4] = 0
+    dBC = torch.zeros(shp, device=dev); dBC[0, 0, :, 0:4] = inside.float() * 0.1
+    dMask = torch.ones(shp, device=dev); dMask[0, 0, :, 0:4] = (~inside).float()
+    st.update(UBC=UBC, UBCInvMask=UBCInvMask, densityBC=dBC, densityBCInvMask=dMask)
+    return st
+
+
+def build_state(w, dev):
+    import torch
     res, D = w["res"], w["D"]
     if w["kind"] == "plume":
-        st = plume_state(res, D)
-        return {k: torch.from_numpy(v).to(dev) for k, v in st.items()}
+        return plume_state_torch(res, D, dev)
     # Rayleigh-Taylor (reference init_conditions.py:121-125, rayleighTaylorConfig.yaml)
     from fluidnet_cxx_amd import fluid
     bd = dict(p=torch.zeros(1, 1, 1, res, res, device=dev), U=torch.zeros(1, 2, 1, res, res, device=dev),
@@ -69,35 +106,34 @@ def mconf_for(w):
     return m
 
 
-def cpu_baseline(w, budget_s=20.0):
-    """The oracle ("port") timed on the host cores on a bounded sample of the same workload."""
-    import numpy as np
+def cpu_baseline(w, budget_s=15.0):
+    """The oracle ("port": plain-C restatement of the reference, OpenMP) timed on this box's host cores on a bounded
+    sample of the same workload: the same step on a smaller grid of the same configuration, scaled per cell."""
     from oracle import oracle as O
     from util import plume_state
     O.build()
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 64)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     is3d = w["D"] > 1
-    # sample: a smaller grid of the same configuration, scaled per cell
-    res = min(w["res"], 256 if not is3d else 64)
-    D = 1 if not is3d else min(w["D"], 32)
-    st = plume_state(res, D)
     m = mconf_for(w)
     blob = None
     if w["method"] == "convnet":
         from fluidnet_cxx_amd.weights import make_scalenet_weights
         blob = O.pack_weights(make_scalenet_weights(0, ndim=3 if is3d else 2), 3 if is3d else 2)
-        res_c = 128
-        st = plume_state(res_c, 1); res = res_c
+        res, D = 128, 1
+    else:
+        res, D = (min(w["res"], 512), 1) if not is3d else (64, 32)
+    st = plume_state(res, D)
     st = O.simulate_step(st, m, w["method"], blob)      # warm-up
     t0 = time.time(); n = 0
     while True:
         st = O.simulate_step(st, m, w["method"], blob); n += 1
-        if time.time() - t0 > budget_s or n >= 50:
+        if time.time() - t0 > budget_s or n >= 40:
             break
     dt = (time.time() - t0) / n
     cells = res * res * D
     return dict(value=cells / dt / 1e6, unit="Mcells/s", cores=threads, kind="port",
-                sample=f"{n} steps of the same step on a {D}x{res}x{res} grid ({w['method']}), OpenMP {threads} threads, scaled per cell")
+                sample=f"{n} steps of the same {w['method']} step on a {D}x{res}x{res} grid, OpenMP {threads} threads; per-cell rate")
 
 
 def main():
@@ -106,6 +142,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -118,23 +155,52 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    name = a.workload or ("plume2d_1024_cnn" if a.gpus == 1 else "plume3d_slab_jacobi")
+    name = a.workload or ("plume2d_1024_cnn" if world == 1 else "plume3d_slab_jacobi")
     w = WORKLOADS[name]
     is3d = w["D"] > 1
+    slab = bool(w.get("slab"))
 
     from fluidnet_cxx_amd import FluidNet, simulate
     from fluidnet_cxx_amd._ext import ext
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     m = mconf_for(w)
-    bd = build_state(w, dev)
-    net = FluidNet(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
-    ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
+    graph_used = False
+    if slab:
+        # weak scaling: every GPU owns 64 planes of a 512 x 512 x (64*world) plume
+        from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
+        layout = SlabLayout(w["D"] * world, world, rank, halo=6)
+        bd = plume_state_torch(w["res"], layout.D_local, dev, layout.z_offset, layout.D_global)
+        sim = SlabSimulator(layout, m, sweeps_per_exchange=4)
+        net = None
 
-    def step():
-        simulate(m, bd, net, w["method"], workspace=ws)
+        def step():
+            sim.step(bd)
+        cells = w["res"] * w["res"] * layout.owned
+    else:
+        bd = build_state(w, dev)
+        net = FluidNet(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
+        ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
+
+        def eager_step():
+            simulate(m, bd, net, w["method"], workspace=ws)
+        step = eager_step
+        cells = w["res"] * w["res"] * w["D"]
 
     for _ in range(a.warmup):
         step()
+    torch.cuda.synchronize()
+    if not slab and not a.no_graph:
+        # the step is a fixed launch sequence on fixed buffers: capture it once, replay it per step
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eager_step()
+            g.replay(); torch.cuda.synchronize()
+            step = g.replay
+            graph_used = True
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"bench: graph capture failed ({e}); running eagerly\n")
+            step = eager_step
 
     def barrier():
         torch.cuda.synchronize()
@@ -152,55 +218,60 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    cells = w["res"] * w["res"] * w["D"]
     ms = elapsed / a.steps * 1e3
     mcells = cells * world * a.steps / elapsed / 1e6
 
-    # ---- dominant kernel, timed with HIP events on the launch stream (torch's current stream) ----
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(3, min(a.steps, 20))
+    # ---- dominant kernel: HIP events around every launch of its class, on the launch stream, over K more steps of the
+    # same workload (eager launches: events cannot be recorded inside a captured graph) ----
+    ext.profile_enable(True)
+    prof_steps = max(2, min(a.steps, 10))
+    estep = step if slab else eager_step
+    for _ in range(prof_steps):
+        estep()
+    torch.cuda.synchronize()
+    times = {k: ext.profile_read(v) for k, v in PROF.items()}
+    ext.profile_enable(False)
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(name)
     if w["method"] == "convnet":
-        x = torch.randn(1, 2, w["res"], w["res"], device=dev) if not is3d else torch.randn(1, 2, w["D"], w["res"], w["res"], device=dev)
-        net.multiScale(x); torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            net.multiScale(x)
-        e1.record(); torch.cuda.synchronize()
-        kms = e0.elapsed_time(e1) / reps
-        flops = CNN_FLOP_PER_CELL[is3d] * cells
-        ach = flops / (kms * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="MultiScaleNet conv stack (17 conv launches)", achieved=ach, peak=MFMA_F32_PEAK_TF,
-                    unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=None, ms_per_launch=kms,
-                    algorithmic=f"{CNN_FLOP_PER_CELL[is3d]} FLOP/cell x {cells} cells per forward")
+        tms, nl = times["conv_mfma"]
+        flops = mfma_flops_per_cell(is3d) * cells * prof_steps
+        ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
+        roof = dict(bound="mfma", kernel="conv3_mfma_kernel (implicit-GEMM 3x3 conv, v_mfma_f32_32x32x2_f32)", achieved=ach,
+                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=traffic,
+                    launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
+                    algorithmic=f"{mfma_flops_per_cell(is3d):.0f} FLOP/cell in the 10 MFMA conv launches x {cells} cells per step")
     else:
-        from fluidnet_cxx_amd import fluid
-        div = fluid.velocityDivergence(bd["U"], bd["flags"])
-        fluid.solveLinearSystemJacobi(bd["flags"], div, is3d, 0.0, w["iters"]); torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fluid.solveLinearSystemJacobi(bd["flags"], div, is3d, 0.0, w["iters"])
-        e1.record(); torch.cuda.synchronize()
-        kms = e0.elapsed_time(e1) / reps
-        byts = 16.0 * w["iters"] * cells
-        ach = byts / (kms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel=f"Jacobi solve ({w['iters']} sweeps)", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=ach / HBM_PEAK_GBS, traffic=None, ms_per_launch=kms,
-                    algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} cells per solve")
-    step_bytes = (STEP_BYTES[is3d](w["iters"]) if w["method"] == "jacobi" else STEP_BYTES[is3d](0) - 44 + CNN_GLUE_BYTES) * cells
-    out = dict(metric="fluid time-step throughput (steps/s; Mcells/s = cells*steps/s/1e6)", value=mcells, unit="Mcells/s",
-               steps_per_s=a.steps * world / elapsed if world == 1 else a.steps / elapsed,
-               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms, higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=name, grid=[w["D"], w["res"], w["res"]], cells_per_gpu=cells, method=w["method"],
-                           jacobi_iters=w["iters"], parallelism="1 GPU" if world == 1 else f"{world} independent z-slab replicas",
+        tms, nl = times["jacobi"]
+        byts = 16.0 * w["iters"] * cells * prof_steps
+        ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        kname = "jacobi3d_march_kernel (z-marching sweep)" if is3d else "jacobi2d_reg_kernel (register/DPP temporal blocking)"
+        roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    traffic=traffic, launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
+                    algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} cells per step")
+    if w["method"] == "jacobi":
+        step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
+    else:
+        step_bytes = (STEP_BYTES[is3d](0) - (44 if not is3d else 60) + 104) * cells   # advection + CNN glue
+    out = dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
+               unit="Mcells/s", steps_per_s=a.steps / elapsed, n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms,
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
+                           cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
+                           parallelism="1 GPU" if world == 1 else f"{world} z-slabs, P2P ghost exchange (RCCL send/recv), halo 6, 4 sweeps per exchange",
+                           launch="hip-graph replay" if graph_used else "eager",
                            weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
                step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               kernel_ms_per_step={k: v[0] / prof_steps for k, v in times.items() if v[1] > 0},
                roofline=roof)
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
+        if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -360,4 +360,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "3D multi-GPU: subsequent calls treat their tensors as planes [z_offset, z_offset+D) of a D_global-deep domain (0,0 resets)");
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
+  m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });
+  m.def("profile_read", [](int tag) { double ms = 0; int n = 0; fnx_profile_read(tag, &ms, &n); return std::make_pair(ms, n); });
 }

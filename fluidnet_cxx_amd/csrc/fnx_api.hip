@@ -65,7 +65,59 @@ size_t ws_step(const FnxGrid* g) {
 
 }  // namespace
 
+// ---- event-pair profiler ----------------------------------------------------------------------------
+namespace fnx {
+namespace {
+constexpr int PROF_MAX = 16384;
+struct Prof {
+  bool on = false;
+  int n = 0;
+  hipEvent_t ev[PROF_MAX][2];
+  int tag[PROF_MAX];
+  int created = 0;
+  int open_idx[FNX_PROF_NTAGS];
+} g_prof;
+}  // namespace
+
+void prof_begin(int tag, hipStream_t s) {
+  if (!g_prof.on || g_prof.n >= PROF_MAX) { if (g_prof.on) g_prof.open_idx[tag] = -1; return; }
+  const int i = g_prof.n++;
+  if (i >= g_prof.created) {
+    hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]);
+    g_prof.created = i + 1;
+  }
+  g_prof.tag[i] = tag;
+  g_prof.open_idx[tag] = i;
+  hipEventRecord(g_prof.ev[i][0], s);
+}
+
+void prof_end(int tag, hipStream_t s) {
+  if (!g_prof.on) return;
+  const int i = g_prof.open_idx[tag];
+  if (i >= 0) hipEventRecord(g_prof.ev[i][1], s);
+}
+}  // namespace fnx
+
 extern "C" {
+
+int fnx_profile_enable(int on) {
+  fnx::g_prof.on = on != 0;
+  if (on) { fnx::g_prof.n = 0; for (int t = 0; t < FNX_PROF_NTAGS; ++t) fnx::g_prof.open_idx[t] = -1; }
+  return FNX_OK;
+}
+
+int fnx_profile_read(int tag, double* total_ms, int* launches) {
+  double tot = 0.0; int cnt = 0;
+  for (int i = 0; i < fnx::g_prof.n; ++i) {
+    if (fnx::g_prof.tag[i] != tag) continue;
+    if (hipEventSynchronize(fnx::g_prof.ev[i][1]) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, fnx::g_prof.ev[i][0], fnx::g_prof.ev[i][1]) == hipSuccess) { tot += ms; ++cnt; }
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
+  return FNX_OK;
+}
 
 const char* fnx_last_error(void) { return g_err; }
 int fnx_abi_version(void) { return FNX_ABI_VERSION; }
@@ -110,7 +162,8 @@ int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float*
     float* fwd = (float*)c.take(ncell(g) * 4);
     int* cell = (int*)c.take(ncell(g) * 4);
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_scalar: workspace too small (%zu < %zu)", ws_bytes, c.off);
-    fnx::launch_sl_scalar(d, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s);
+    { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_scalar(d, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s); }
+    fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_scalar_bwd_clamp(d, g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, src, fwd, cell, U,
                                     flags, dst, s);
   }
@@ -133,7 +186,8 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
     Carver c(ws, ws_bytes);
     float* fwd = (float*)c.take(ncell(g) * 4 * (g->is3D ? 3 : 2));
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_vel: workspace too small (%zu < %zu)", ws_bytes, c.off);
-    fnx::launch_sl_mac(d, g->is3D, quirks(g), dt, orig, U, flags, fwd, s);
+    { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_mac(d, g->is3D, quirks(g), dt, orig, U, flags, fwd, s); }
+    fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_mac_bwd_clamp(d, g->is3D, quirks(g), dt, strength * 0.5f, orig, fwd, U, flags, dst, s);
   }
   HIP_OK(hipGetLastError());
@@ -164,6 +218,7 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
   const bool q = quirks(g);
   if (g->is3D) fnx::launch_jacobi3d_mask(d, q, flags, mask, s);
   auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss) {
+    fnx::ProfScope ps(FNX_PROF_JACOBI, s);
     if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
     else fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
   };
@@ -231,8 +286,9 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
   for (int l = 0; l < nl; ++l) {
     const int k = nsweeps - done < kmax ? nsweeps - done : kmax;
     float* out = (l % 2 == 0) ? tmp : p;
-    if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
-    else fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s);
+    { fnx::ProfScope ps(FNX_PROF_JACOBI, s);
+      if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
+      else fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s); }
     in = out; done += k;
   }
   if (in != p) HIP_OK(hipMemcpyAsync(p, in, ncell(g) * 4, hipMemcpyDeviceToDevice, s));
@@ -307,6 +363,7 @@ int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxStat
     sx = gx * prm->dt; sy = gy * prm->dt; sz = gz * prm->dt;     // strength = gravity * dt, source_terms.py:45
   }
   const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  fnx::ProfScope ps(FNX_PROF_STAGE, (hipStream_t)stream);
   fnx::launch_pre_projection(dims(g), g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                              rbc ? st->densityBCInvMask : nullptr, st->U, st->density, div, buoy, sx, sy, sz,
@@ -319,6 +376,7 @@ int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream) {
   if (int rc = check_grid(g)) return rc;
   if (!st || !st->U || !st->flags || !st->p) return fail(FNX_EINVAL, "post_projection: NULL state");
   const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  fnx::ProfScope ps(FNX_PROF_STAGE, (hipStream_t)stream);
   fnx::launch_post_projection(dims(g), g->is3D, st->p, st->U, st->density, st->flags, ubc ? st->UBC : nullptr,
                               ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                               rbc ? st->densityBCInvMask : nullptr, (hipStream_t)stream);

@@ -4,6 +4,9 @@
 // (conv3_mfma_kernel); the thin first/last layers (Cin 2-3, Cout 1-8) are bandwidth-shaped and use a direct kernel
 // (one thread per output pixel x CO_T output channels, weights through the scalar cache).
 #include "fnx_cnn.h"
+#include <stdlib.h>
+#include "fnx_kernels.h"
+#include "../../include/fluidnet_hip.h"
 
 namespace fnx {
 
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
     if (it + 1 < niter) prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK);   // in flight during the MFMAs
     {
       const float* wz = a.w + ((size_t)(dz * 9) * a.cin + c0) * a.cout + cout0 + l31;
-#pragma unroll
+      // the tap-row loop stays rolled: fully unrolling all 36 k-steps makes hipcc hoist every weight load and spill
+#pragma unroll 1
       for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -248,7 +252,8 @@ void launch_conv_mfma_t(const ConvArgs& a, bool is3d, hipStream_t s) {
 }
 
 void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
-  if (a.cout % 128 == 0) launch_conv_mfma_t<4, 2>(a, is3d, s);
+  static const bool wide = getenv("FNX_CONV_WIDE") != nullptr;     // experiment switch: 128 output channels per wave
+  if (a.cout % 128 == 0 && wide) launch_conv_mfma_t<4, 2>(a, is3d, s);
   else if (a.cout % 64 == 0) launch_conv_mfma_t<2, 4>(a, is3d, s);
   else launch_conv_mfma_t<1, 4>(a, is3d, s);
 }
@@ -256,7 +261,8 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
 void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const PackedLayer& pl, const float* x, float* y,
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
-  if (mfma_layer(L)) { launch_conv_mfma(a, is3d, s); return; }
+  if (mfma_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA, s); launch_conv_mfma(a, is3d, s); return; }
+  ProfScope ps(FNX_PROF_CONV_DIRECT, s);
   if (is3d) {
     if (L.k == 3) launch_conv_k<3, true>(a, s);
     else if (L.k == 5) launch_conv_k<5, true>(a, s);

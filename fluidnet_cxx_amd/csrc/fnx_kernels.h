@@ -5,6 +5,15 @@
 
 namespace fnx {
 
+// event-pair timing of kernel classes (fnx_api.hip); no-ops unless fnx_profile_enable(1)
+void prof_begin(int tag, hipStream_t s);
+void prof_end(int tag, hipStream_t s);
+struct ProfScope {
+  int tag; hipStream_t s;
+  ProfScope(int t, hipStream_t st) : tag(t), s(st) { prof_begin(tag, s); }
+  ~ProfScope() { prof_end(tag, s); }
+};
+
 // advection (fnx_advect.hip)
 void launch_sl_scalar(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, const float* src,
                       const float* U, const float* flags, float* dst, int* cell_out, hipStream_t s);

@@ -161,6 +161,15 @@ int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x,
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float normalize_threshold,
                          float* p_out, float* U_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Optional timing of the dominant kernels with HIP events on the launch stream (used by bench.py for the roofline
+ * figures).  While enabled, every launch of the tagged kernel class is bracketed by an event pair (up to 16384 pairs,
+ * later launches are not recorded).  fnx_profile_read synchronises the recorded events and returns the summed
+ * kernel time and the number of launches of that class; fnx_profile_enable(1) also clears earlier records. */
+enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PROF_STAGE = 3, FNX_PROF_CONV_DIRECT = 4,
+       FNX_PROF_NTAGS = 5 };
+int fnx_profile_enable(int on);
+int fnx_profile_read(int tag, double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif
