@@ -65,18 +65,25 @@ struct ConvArgs {
   int B, cin, cout, D, H, W, relu, groups;
 };
 
-template <int KS, int CO_T, bool IS3D>
+// Thin layers (Cin 2-3 or Cout 1-8): direct convolution.  A thread owns a vertical strip of RY output pixels x CO_T
+// output channels, so each input row it loads (coalesced along x across the wave) feeds up to KS output rows:
+// (RY+KS-1)*KS loads per RY*KS*KS taps instead of one load per tap.
+template <int KS, int CO_T, bool IS3D, int RY>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   constexpr int KD = IS3D ? KS : 1, PAD = KS / 2, PD = IS3D ? PAD : 0, TAPS = KD * KS * KS;
-  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.x * 64 + threadIdx.x, j0 = (blockIdx.y * 4 + threadIdx.y) * RY;
   int z = blockIdx.z;
   const int k = z % a.D; z /= a.D;
   const int grp = z % a.groups; const int b = z / a.groups;
-  if (i >= a.W || j >= a.H) return;
+  if (i >= a.W || j0 >= a.H) return;
   const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
-  float acc[CO_T];
+  float acc[RY][CO_T];
 #pragma unroll
-  for (int t = 0; t < CO_T; ++t) acc[t] = a.bias[grp * CO_T + t];
+  for (int t = 0; t < CO_T; ++t) {
+    const float bv = a.bias[grp * CO_T + t];
+#pragma unroll
+    for (int ry = 0; ry < RY; ++ry) acc[ry][t] = bv;
+  }
   const float* wg = a.w + (size_t)grp * a.cin * TAPS * CO_T;
   const float* xb = a.x + (size_t)b * a.cin * vol;
   for (int ci = 0; ci < a.cin; ++ci) {
@@ -87,37 +94,48 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
       const int zz = k + dz - PD;
       const bool zin = (zz >= 0) & (zz < a.D);
 #pragma unroll
-      for (int r = 0; r < KS; ++r) {
-        const int yy = j + r - PAD;
+      for (int row = 0; row < RY + KS - 1; ++row) {        // input row j0 - PAD + row
+        const int yy = j0 + row - PAD;
         const bool yin = zin & (yy >= 0) & (yy < a.H);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const int xx = i + s - PAD;
           const bool in = yin & (xx >= 0) & (xx < a.W);
-          const float v = in ? xc[(size_t)zz * plane + (size_t)yy * a.W + xx] : 0.f;
-          const float* wt = wc + ((dz * KS + r) * KS + s) * CO_T;
+          const float v = in ? xc[(size_t)(zin ? zz : 0) * plane + (size_t)(yin ? yy : 0) * a.W + (in ? xx : 0)] : 0.f;
 #pragma unroll
-          for (int t = 0; t < CO_T; ++t) acc[t] = fmaf(v, wt[t], acc[t]);
+          for (int ry = 0; ry < RY; ++ry) {
+            const int r = row - ry;                        // tap row for output row ry
+            if (r >= 0 && r < KS) {
+              const float* wt = wc + ((dz * KS + r) * KS + s) * CO_T;
+#pragma unroll
+              for (int t = 0; t < CO_T; ++t) acc[ry][t] = fmaf(v, wt[t], acc[ry][t]);
+            }
+          }
         }
       }
     }
   }
-  float* yb = a.y + ((size_t)b * a.cout + grp * CO_T) * vol + (size_t)k * plane + (size_t)j * a.W + i;
 #pragma unroll
-  for (int t = 0; t < CO_T; ++t) {
-    float v = acc[t];
-    if (a.relu) v = fmaxf(v, 0.f);
-    yb[(size_t)t * vol] = v;
+  for (int ry = 0; ry < RY; ++ry) {
+    if (j0 + ry >= a.H) break;
+    float* yb = a.y + ((size_t)b * a.cout + grp * CO_T) * vol + (size_t)k * plane + (size_t)(j0 + ry) * a.W + i;
+#pragma unroll
+    for (int t = 0; t < CO_T; ++t) {
+      float v = acc[ry][t];
+      if (a.relu) v = fmaxf(v, 0.f);
+      yb[(size_t)t * vol] = v;
+    }
   }
 }
 
 template <int KS, bool IS3D>
 void launch_conv_k(const ConvArgs& a, hipStream_t s) {
-  const dim3 grid((a.W + 63) / 64, (a.H + 3) / 4, a.B * a.groups * a.D), block(64, 4);
+  constexpr int RY = (KS == 1) ? 1 : 4;
+  const dim3 grid((a.W + 63) / 64, (a.H + 4 * RY - 1) / (4 * RY), a.B * a.groups * a.D), block(64, 4);
   const int cot = co_tile(a.cout);
-  if (cot == 16) conv_direct_kernel<KS, 16, IS3D><<<grid, block, 0, s>>>(a);
-  else if (cot == 8) conv_direct_kernel<KS, 8, IS3D><<<grid, block, 0, s>>>(a);
-  else conv_direct_kernel<KS, 1, IS3D><<<grid, block, 0, s>>>(a);
+  if (cot == 16) conv_direct_kernel<KS, 16, IS3D, RY><<<grid, block, 0, s>>>(a);
+  else if (cot == 8) conv_direct_kernel<KS, 8, IS3D, RY><<<grid, block, 0, s>>>(a);
+  else conv_direct_kernel<KS, 1, IS3D, RY><<<grid, block, 0, s>>>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -138,7 +156,13 @@ template <int CB, int PR, bool IS3D>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
   constexpr int ROWS = 4 * PR + 2;
   constexpr int KD = IS3D ? 3 : 1;
-  __shared__ float tile[MF_CHUNK * ROWS * MF_COLS];
+  constexpr int RW = CB * 32;                    // output channels (floats) per weight row
+  constexpr int WROWS = 9 * MF_CHUNK;            // (tap, cin) rows per stage
+  constexpr int LPR = RW / 4;                    // lanes per row at 16 B per lane
+  constexpr int RPI = 64 / LPR;                  // rows per wave-wide global_load_lds
+  constexpr int NWI = (WROWS + RPI - 1) / RPI;   // wave-instructions per stage
+  __shared__ __attribute__((aligned(16))) float tile2[2][MF_CHUNK * ROWS * MF_COLS];     // halo tile, double-buffered
+  __shared__ __attribute__((aligned(16))) float wbuf[2][NWI * 256];    // weights of the stage, [tap][cin][cout], double-buffered
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * PR);
@@ -186,33 +210,53 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < NLD; ++t) stage[t] = src[goff[t]];
   };
+  // Weights of one stage go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs),
+  // one stage ahead of their use; the A operand is then a conflict-free ds_read_b32.
+  auto stage_weights = [&](int dz, int c0, int buf) {
+#pragma unroll
+    for (int q = 0; q < (NWI + 3) / 4; ++q) {
+      const int wi = wave + 4 * q;                      // wave-uniform
+      if (wi < NWI) {
+        int row = wi * RPI + lane / LPR;
+        if (row > WROWS - 1) row = WROWS - 1;           // tail lanes re-read the last row (their LDS slots are never used)
+        const int tap = row / MF_CHUNK, ci = row - tap * MF_CHUNK;
+        const float* src = a.w + ((size_t)(dz * 9 + tap) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(&wbuf[buf][wi * 256]), 16, 0, 0);
+      }
+    }
+  };
   // iteration space: (dz, c0) pairs with an in-range z plane
   const int nchunk = a.cin / MF_CHUNK;
   int dz_lo = 0, dz_hi = KD;
   if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = KD - 1; }
   const int niter = (dz_hi - dz_lo) * nchunk;
-  if (niter > 0) prefetch(dz_lo, 0);
+  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, 0); }
   for (int it = 0; it < niter; ++it) {
     const int dz = dz_lo + it / nchunk, c0 = (it % nchunk) * MF_CHUNK;
-    __syncthreads();                                   // everyone is done reading the previous tile
+    // Both LDS images are double-buffered: buffer (it&1) was last read in iteration it-2 and every wave has passed
+    // the barrier of iteration it-1 since, so it can be overwritten without a barrier in front -> one barrier per stage.
+    float* tile = tile2[it & 1];
 #pragma unroll
     for (int t = 0; t < NLD; ++t)
       if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = ((valid >> t) & 1) ? stage[t] : 0.f;
-    __syncthreads();
-    if (it + 1 < niter) prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK);   // in flight during the MFMAs
+    __syncthreads();                                   // tile stores + the stage's weight DMA (vmcnt(0)) visible to all
+    if (it + 1 < niter) {                              // both in flight during the MFMAs
+      prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK);
+      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK, (it + 1) & 1);
+    }
     {
-      const float* wz = a.w + ((size_t)(dz * 9) * a.cin + c0) * a.cout + cout0 + l31;
-      // the tap-row loop stays rolled: fully unrolling all 36 k-steps makes hipcc hoist every weight load and spill
-#pragma unroll 1
+      const float* wl = &wbuf[it & 1][l31];
+      (void)dz; (void)c0;
+#pragma unroll
       for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-          const float* wt = wz + (size_t)(r * 3 + s) * a.cin * a.cout;
 #pragma unroll
           for (int cp = 0; cp < MF_CHUNK; cp += 2) {
             float av[CB], bv[PR];
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) av[cb] = wt[(size_t)(cp + half) * a.cout + cb * 32];
+            for (int cb = 0; cb < CB; ++cb) av[cb] = wl[((r * 3 + s) * MF_CHUNK + cp + half) * RW + cb * 32];
 #pragma unroll
             for (int pr = 0; pr < PR; ++pr) bv[pr] = tile[(cp + half) * ROWS * MF_COLS + (wave * PR + pr + r) * MF_COLS + l31 + s];
 #pragma unroll
