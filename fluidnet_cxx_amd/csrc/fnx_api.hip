@@ -219,23 +219,29 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
   if (g->is3D) fnx::launch_jacobi3d_mask(d, q, flags, mask, s);
   auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss) {
     fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-    if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
-    else fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
+    if (g->is3D) {
+      if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, ss, s);
+      else fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
+    } else {
+      fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
+    }
   };
   if (!(p_tol > 0.f)) {
-    const int kmax = fnx::jacobi_max_sweeps_per_launch(d, g->is3D);
-    const int nl = (max_iter + kmax - 1) / kmax;
+    // sweeps per launch: 2D up to kmax (register temporal blocking); 3D one sweep from zero, then pairs
+    int plan[1024]; int nl = 0, left = max_iter;
+    if (g->is3D) { plan[nl++] = 1; --left; }
+    const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
+    while (left > 0 && nl < 1023) { const int k = left < kmax ? left : kmax; plan[nl++] = k; left -= k; }
+    if (left > 0) return fail(FNX_EINVAL, "solve_linear_system: max_iter too large for one call (%d)", max_iter);
     if (residual) HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
-    int done = 0;
     const float* in = nullptr;
+    int done = 0;
     for (int l = 0; l < nl; ++l) {
-      int k = max_iter - done < kmax ? max_iter - done : kmax;
-      // spread the remainder so that no launch runs a single sweep needlessly late
-      float* out = ((nl - 1 - l) % 2 == 0) ? p : tmp;
+      float* out = ((nl - 1 - l) % 2 == 0) ? p : tmp;      // the last launch writes p
       const bool last = l == nl - 1;
-      sweep(in, out, k, l == 0, (last && residual) ? sumsq : nullptr);
+      sweep(in, out, plan[l], l == 0, (last && residual) ? sumsq : nullptr);
       in = out;
-      done += k;
+      done += plan[l];
     }
     if (residual) fnx::launch_residual_finish(g->B, sumsq, residual, s);
     if (iters_done) *iters_done = done;
@@ -278,7 +284,7 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
   unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (g->is3D) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
-  const int kmax = fnx::jacobi_max_sweeps_per_launch(d, g->is3D);
+  const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
   const int nl = (nsweeps + kmax - 1) / kmax;
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
   const float* in = p;
@@ -287,8 +293,12 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
     const int k = nsweeps - done < kmax ? nsweeps - done : kmax;
     float* out = (l % 2 == 0) ? tmp : p;
     { fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-      if (g->is3D) fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
-      else fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s); }
+      if (g->is3D) {
+        if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s);
+        else fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
+      } else {
+        fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s);
+      } }
     in = out; done += k;
   }
   if (in != p) HIP_OK(hipMemcpyAsync(p, in, ncell(g) * 4, hipMemcpyDeviceToDevice, s));
