@@ -10,6 +10,7 @@ Workloads (BASELINE.json configs):
   rt2d_2048_jacobi     configs[2]: 2D Rayleigh-Taylor 2048^2, Jacobi-100
   plume2d_128_jacobi   configs[0]: 2D plume 128^2, Jacobi-28
   plume3d_256_jacobi   3D plume 256^3, Jacobi-100
+  plume3d_256_cnn      configs[3]: 3D plume 256^3, CNN pressure (Conv3d analogue of ScaleNet, MFMA implicit GEMM)
   plume3d_slab_jacobi  configs[4]: 3D plume 512x512x(64 per GPU), Jacobi-100, z-slabs + P2P ghost exchange  [default, N>1]
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
@@ -38,6 +39,8 @@ WORKLOADS = {
     "rt2d_2048_jacobi": dict(res=2048, D=1, method="jacobi", iters=100, kind="rt"),
     "plume2d_128_jacobi": dict(res=128, D=1, method="jacobi", iters=28, kind="plume"),
     "plume3d_256_jacobi": dict(res=256, D=256, method="jacobi", iters=100, kind="plume"),
+    "plume3d_256_cnn": dict(res=256, D=256, method="convnet", iters=0, kind="plume"),      # configs[3]
+    "plume3d_128_cnn": dict(res=128, D=128, method="convnet", iters=0, kind="plume"),
     "plume3d_slab_jacobi": dict(res=512, D=64, method="jacobi", iters=100, kind="plume", slab=True),
 }
 

@@ -110,26 +110,30 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
     const int k0 = kb - 1;
     const int r = cell - kb * g.HW;
     const int j0 = r / g.W, i0 = r - j0 * g.W;
+    // 3x3(x3) neighbourhood of the traced cell: every load is unconditional (clamped address) and the
+    // in-domain / is-fluid tests only gate the min/max, so the 18-54 loads are independent and issue back to back.
     float mn = INFINITY, mx = -INFINITY;
     bool any = false;
 #pragma unroll
-    for (int dk = -1; dk <= 1; ++dk) {
+    for (int dk = (IS3D ? -1 : 0); dk <= (IS3D ? 1 : 0); ++dk) {
       const int kk = k0 + dk;
-      if (kk + g.zoff < 0 || kk + g.zoff >= g.Dglob) continue;        // outside the domain
-      if (kk < 0 || kk >= g.D) continue;                              // beyond this slab's ghost planes (stale cell)
+      const bool vk = (kk + g.zoff >= 0) & (kk + g.zoff < g.Dglob) & (kk >= 0) & (kk < g.D);   // in the domain and in this slab
+      const int kc = clampi(kk, 0, g.D - 1);
 #pragma unroll
       for (int dj = -1; dj <= 1; ++dj) {
         const int jj = j0 + dj;
-        if (jj < 0 || jj >= g.H) continue;
+        const bool vj = vk & (jj >= 0) & (jj < g.H);
+        const int jc = clampi(jj, 0, g.H - 1);
 #pragma unroll
         for (int di = -1; di <= 1; ++di) {
           const int ii = i0 + di;
-          if (ii < 0 || ii >= g.W) continue;
-          const size_t q = (size_t)kk * g.HW + jj * g.W + ii;
-          if (SAMPLE_OUTSIDE || ff.p[q] == FNX_FLUID) {
-            const float s = fs.p[q];
-            mn = fminf(mn, s); mx = fmaxf(mx, s); any = true;
-          }
+          const bool vi = vj & (ii >= 0) & (ii < g.W);
+          const size_t q = (size_t)kc * g.HW + jc * g.W + clampi(ii, 0, g.W - 1);
+          const float s = fs.p[q];
+          const bool ok = vi & (SAMPLE_OUTSIDE || ff.p[q] == FNX_FLUID);
+          mn = ok ? fminf(mn, s) : mn;
+          mx = ok ? fmaxf(mx, s) : mx;
+          any = any | ok;
         }
       }
     }

@@ -279,3 +279,65 @@ def test_properties_full_size(fl, dev, size):
     U1 = torch.zeros_like(U0); U1[:, 0] = 1.0
     sh = fl.advectScalar(1.0, rho, U1, flags, "eulerFluidNet", 1, True)
     assert torch.equal(sh[..., 2:-2, 3:-2], rho[..., 2:-2, 2:-3]) if not is3d else torch.equal(sh[:, :, 2:-2, 2:-2, 3:-2], rho[:, :, 2:-2, 2:-2, 2:-3])
+
+
+# ---- driver-facing entry points ------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 1, 70, 130), (1, 10, 24, 66)])
+def test_jacobi_sweeps_continue(fl, ext, dev, oracle, shape):
+    """k more sweeps on an existing field == the same total number of sweeps from zero (every launch plan)."""
+    B, D, H, W = shape
+    is3d = D > 1
+    s = random_state(B, D, H, W, 2.0, seed=5)
+    tf = T(s["flags"], dev)
+    div = fl.velocityDivergence(T(s["U"], dev), tf)
+    for first, more in ((1, 1), (3, 2), (4, 5), (7, 9)):
+        p, _ = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, first)
+        ext.jacobi_sweeps_(tf, div, p, is3d, more)
+        ref, _ = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, first + more)
+        assert_bitexact(N(p), N(ref), f"{first}+{more} sweeps")
+        po, _, _ = oracle.jacobi(s["flags"], N(div), is3d, 0.0, first + more)
+        assert_bitexact(N(p), po, f"{first}+{more} sweeps vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 33, 70), (1, 9, 14, 66)])
+def test_fused_stages_equal_operator_sequence(fl, ext, dev, shape):
+    """pre_projection_ / post_projection_ == setConstVals, addBuoyancy, setWallBcs, setConstVals, velocityDivergence /
+    velocityUpdate, setWallBcs, setConstVals applied one by one (simulate.py:96-168), bit for bit."""
+    B, D, H, W = shape
+    is3d = D > 1
+    s = random_state(B, D, H, W, 2.0, seed=9)
+    rng = np.random.default_rng(1)
+    nc = 3 if is3d else 2
+    UBC = rng.standard_normal((B, nc, D, H, W)).astype(np.float32)
+    Um = (rng.random((B, nc, D, H, W)) > 0.2).astype(np.float32)
+    rBC = rng.random((B, 1, D, H, W)).astype(np.float32) * 0.3
+    rm = (rng.random((B, 1, D, H, W)) > 0.2).astype(np.float32)
+    tf = T(s["flags"], dev)
+    bd = dict(UBC=T(UBC, dev), UBCInvMask=T(Um, dev), densityBC=T(rBC, dev), densityBCInvMask=T(rm, dev))
+    # operator sequence
+    U, rho, p = T(s["U"], dev), T(s["rho"], dev), T(s["p"], dev)
+    fl.setConstVals(dict(bd), p, U, tf, rho)
+    fl.addBuoyancy(U, tf, rho, [0.1, -0.25, 0.05], 0.02, 0.1)
+    fl.setWallBcs(U, tf)
+    fl.setConstVals(dict(bd), p, U, tf, rho)
+    div_ref = fl.velocityDivergence(U, tf)
+    # fused
+    U2, rho2 = torch.empty_like(U), torch.empty_like(rho)
+    div = ext.pre_projection_(T(s["U"], dev), T(s["rho"], dev), p, U2, tf, rho2, bd["UBC"], bd["UBCInvMask"], bd["densityBC"],
+                              bd["densityBCInvMask"], 0.1, 1.0, [-0.1, 0.25, -0.05], 0.02, True)
+    assert_bitexact(N(U2), N(U), "pre_projection U"); assert_bitexact(N(rho2), N(rho), "pre_projection rho")
+    assert_bitexact(N(div), N(div_ref), "pre_projection div")
+    fl.velocityUpdate(p, U, tf); fl.setWallBcs(U, tf); fl.setConstVals(dict(bd), p, U, tf, rho)
+    ext.post_projection_(p, U2, tf, rho2, bd["UBC"], bd["UBCInvMask"], bd["densityBC"], bd["densityBCInvMask"])
+    assert_bitexact(N(U2), N(U), "post_projection U"); assert_bitexact(N(rho2), N(rho), "post_projection rho")
+
+
+def test_profile_hooks(fl, ext, dev):
+    flags = torch.zeros(1, 1, 1, 256, 256, device=dev); fl.emptyDomain(flags)
+    div = torch.randn(1, 1, 1, 256, 256, device=dev)
+    ext.profile_enable(True)
+    fl.solveLinearSystemJacobi(flags, div, False, 0.0, 12)
+    torch.cuda.synchronize()
+    ms, n = ext.profile_read(0)
+    ext.profile_enable(False)
+    assert n == 3 and 0 < ms < 50, (ms, n)        # 12 sweeps = 3 launches of 4 on a small grid
