@@ -4,14 +4,21 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-graph] [--no-cpu-baseline]
 
 A "step" is one pass of `simulate` over one synthetic plume state that is already resident in HBM.
+
+Default workload.  BASELINE.json's metric is quoted on two configurations ("2D 1024^2 CNN plume & 3D ... Jacobi, 1-8
+GPUs").  The 1->8 GPU series only means something if every N runs the SAME workload, and only the 3D Jacobi step
+shards (the CNN configs are single-GPU in BASELINE.json), so the default for every N is `plume3d_slab_jacobi`:
+512 x 512 x 64 cells per GPU, Jacobi-100 -- one z-slab of configs[4]; at N=8 it is exactly configs[4] (512^3).
+At N=1 the same JSON line carries configs[1] (2D 1024^2 CNN plume) under "also", measured in the same run.
+
 Workloads (BASELINE.json configs):
-  plume2d_1024_cnn     configs[1]: 2D plume 1024^2, CNN pressure (ScaleNet, hash-seeded random-init weights)  [default, N=1]
+  plume3d_slab_jacobi  configs[4]: 3D plume 512x512x(64 per GPU), Jacobi-100, z-slabs + P2P ghost exchange  [default]
+  plume2d_1024_cnn     configs[1]: 2D plume 1024^2, CNN pressure (ScaleNet, hash-seeded random-init weights)  [also, N=1]
   plume2d_1024_jacobi  2D plume 1024^2, Jacobi-28 (the north star's "advection+Jacobi step at 1024^2")
   rt2d_2048_jacobi     configs[2]: 2D Rayleigh-Taylor 2048^2, Jacobi-100
   plume2d_128_jacobi   configs[0]: 2D plume 128^2, Jacobi-28
   plume3d_256_jacobi   3D plume 256^3, Jacobi-100
   plume3d_256_cnn      configs[3]: 3D plume 256^3, CNN pressure (Conv3d analogue of ScaleNet, MFMA implicit GEMM)
-  plume3d_slab_jacobi  configs[4]: 3D plume 512x512x(64 per GPU), Jacobi-100, z-slabs + P2P ghost exchange  [default, N>1]
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -139,35 +146,20 @@ def cpu_baseline(w, budget_s=15.0):
                 sample=f"{n} steps of the same {w['method']} step on a {D}x{res}x{res} grid, OpenMP {threads} threads; per-cell rate")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-
+def run_workload(name, steps, warmup, use_graph, world, rank, dev):
+    """Warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then profile the dominant
+    kernel class with HIP events.  Returns the JSON-able result dict (without cpu_baseline)."""
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    name = a.workload or ("plume2d_1024_cnn" if world == 1 else "plume3d_slab_jacobi")
-    w = WORKLOADS[name]
-    is3d = w["D"] > 1
-    slab = bool(w.get("slab"))
-
     from fluidnet_cxx_amd import FluidNet, simulate
     from fluidnet_cxx_amd._ext import ext
     from fluidnet_cxx_amd.weights import make_scalenet_weights
+    w = WORKLOADS[name]
+    is3d = w["D"] > 1
+    slab = bool(w.get("slab"))
     m = mconf_for(w)
     graph_used = False
+    layout = None
     if slab:
         # weak scaling: every GPU owns 64 planes of a 512 x 512 x (64*world) plume
         from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
@@ -176,7 +168,7 @@ def main():
         sim = SlabSimulator(layout, m, sweeps_per_exchange=4)
         net = None
 
-        def step():
+        def eager_step():
             sim.step(bd)
         cells = w["res"] * w["res"] * layout.owned
     else:
@@ -186,13 +178,13 @@ def main():
 
         def eager_step():
             simulate(m, bd, net, w["method"], workspace=ws)
-        step = eager_step
         cells = w["res"] * w["res"] * w["D"]
+    step = eager_step
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if not slab and not a.no_graph:
+    if not slab and use_graph:
         # the step is a fixed launch sequence on fixed buffers: capture it once, replay it per step
         try:
             g = torch.cuda.CUDAGraph()
@@ -213,7 +205,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -221,16 +213,15 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms = elapsed / a.steps * 1e3
-    mcells = cells * world * a.steps / elapsed / 1e6
+    ms = elapsed / steps * 1e3
+    mcells = cells * world * steps / elapsed / 1e6
 
-    # ---- dominant kernel: HIP events around every launch of its class, on the launch stream, over K more steps of the
+    # ---- dominant kernel: HIP events around every launch of its class, on the launch stream, over more steps of the
     # same workload (eager launches: events cannot be recorded inside a captured graph) ----
     ext.profile_enable(True)
-    prof_steps = max(2, min(a.steps, 10))
-    estep = step if slab else eager_step
+    prof_steps = max(2, min(steps, 10))
     for _ in range(prof_steps):
-        estep()
+        eager_step()
     torch.cuda.synchronize()
     times = {k: ext.profile_read(v) for k, v in PROF.items()}
     ext.profile_enable(False)
@@ -245,33 +236,64 @@ def main():
         roof = dict(bound="mfma", kernel="conv3_mfma_kernel (implicit-GEMM 3x3 conv, v_mfma_f32_32x32x2_f32)", achieved=ach,
                     peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=traffic,
                     launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
-                    algorithmic=f"{mfma_flops_per_cell(is3d):.0f} FLOP/cell in the 10 MFMA conv launches x {cells} cells per step")
+                    algorithmic=f"{mfma_flops_per_cell(is3d):.0f} FLOP/cell in the MFMA conv launches x {cells} cells per step")
     else:
         tms, nl = times["jacobi"]
         byts = 16.0 * w["iters"] * cells * prof_steps
         ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-        kname = "jacobi3d_march_kernel (z-marching sweep)" if is3d else "jacobi2d_reg_kernel (register/DPP temporal blocking)"
+        kname = ("jacobi3d_march2_kernel (z-marching, 2 sweeps per pass)" if is3d
+                 else "jacobi2d_reg_kernel (register/DPP temporal blocking)")
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                     traffic=traffic, launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
-                    algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} cells per step")
+                    algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} owned cells per step")
     if w["method"] == "jacobi":
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
     else:
         step_bytes = (STEP_BYTES[is3d](0) - (44 if not is3d else 60) + 104) * cells   # advection + CNN glue
-    out = dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
-               unit="Mcells/s", steps_per_s=a.steps / elapsed, n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms,
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
-                           cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
-                           parallelism="1 GPU" if world == 1 else f"{world} z-slabs, P2P ghost exchange (RCCL send/recv), halo 6, 4 sweeps per exchange",
-                           launch="hip-graph replay" if graph_used else "eager",
-                           weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
-               step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               kernel_ms_per_step={k: v[0] / prof_steps for k, v in times.items() if v[1] > 0},
-               roofline=roof)
+    return dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
+                unit="Mcells/s", steps_per_s=steps / elapsed, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=ms,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
+                            global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]],
+                            cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
+                            parallelism=("1 GPU" if world == 1 else
+                                         f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 4 sweeps per exchange"),
+                            launch="hip-graph replay" if graph_used else "eager",
+                            weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
+                step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                kernel_ms_per_step={k: v[0] / prof_steps for k, v in times.items() if v[1] > 0},
+                roofline=roof)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the configs[1] line reported under 'also' at N=1")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    name = a.workload or "plume3d_slab_jacobi"
+    out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev)
+    if world == 1 and a.workload is None and not a.no_also:
+        # configs[1], the other configuration the metric is quoted on (single-GPU by definition)
+        also = run_workload("plume2d_1024_cnn", min(a.steps, 20), min(a.warmup, 5), not a.no_graph, 1, 0, dev)
+        out["also"] = {k: also[k] for k in ("value", "unit", "steps_per_s", "ms_per_step", "config", "roofline", "kernel_ms_per_step")}
     if rank == 0:
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = cpu_baseline(WORKLOADS[name])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -267,13 +267,22 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
 }
 
 // `nsweeps` more sweeps on an existing pressure field (in place) -- used by the z-slab driver
-void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps) {
+void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, c10::optional<Tensor> workspace,
+                    bool reuse_mask) {
   FnxGrid g = grid_of(flags, is3D);
   check_scalar(div, g, "div"); check_scalar(p, g, "p");
   c10::hip::HIPGuard guard(flags.get_device());
-  Workspace ws(g, FNX_OP_JACOBI, flags);
-  check_status(fnx_jacobi_sweeps(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(), nsweeps, ws.ptr,
-                                 ws.bytes, cur_stream(flags)));
+  const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_JACOBI);
+  Tensor ws;
+  if (workspace.has_value() && workspace->defined() && (size_t)workspace->numel() * workspace->element_size() >= bytes) ws = *workspace;
+  else { ws = at::empty({(int64_t)bytes}, flags.options().dtype(at::kByte)); reuse_mask = false; }
+  check_status(fnx_jacobi_sweeps_ex(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(), nsweeps,
+                                    ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+}
+
+int64_t jacobi_workspace_bytes(int B, int D, int H, int W, bool is3D) {
+  FnxGrid g{B, D, H, W, is3D ? 1 : 0, 0, 0, 0};
+  return (int64_t)fnx_workspace_bytes(&g, FNX_OP_JACOBI);
 }
 
 static FnxState make_state(const FnxGrid& g, Tensor& p, Tensor& U, Tensor& flags, c10::optional<Tensor>& density,
@@ -351,7 +360,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("fluidnet_forward", &fluidnet_forward);
   m.def("simulate_step_", &simulate_step_);
   m.def("step_workspace_bytes", &step_workspace_bytes);
-  m.def("jacobi_sweeps_", &jacobi_sweeps_);
+  m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
+        py::arg("workspace") = py::none(), py::arg("reuse_mask") = false);
+  m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
   m.def("pre_projection_", &pre_projection_);
   m.def("post_projection_", &post_projection_);
   m.def("set_ref_quirks", [](bool on) { g_ref_quirks = on; }, "3D only: reproduce the reference's 3D defects bit-for-bit");

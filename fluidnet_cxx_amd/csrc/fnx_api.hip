@@ -273,6 +273,11 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
 
 int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps, void* ws,
                       size_t ws_bytes, void* stream) {
+  return fnx_jacobi_sweeps_ex(g, flags, div, p, nsweeps, ws, ws_bytes, 0, stream);
+}
+
+int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps, void* ws,
+                         size_t ws_bytes, int reuse_mask, void* stream) {
   if (int rc = check_grid(g)) return rc;
   if (!flags || !div || !p) return fail(FNX_EINVAL, "jacobi_sweeps: NULL tensor");
   if (nsweeps < 1) return fail(FNX_EINVAL, "At least 1 iteration is needed (maxIter < 1)");
@@ -283,7 +288,7 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
   c.take((size_t)g->B * 4); c.take(4);
   unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
-  if (g->is3D) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
+  if (g->is3D && !reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
   const int nl = (nsweeps + kmax - 1) / kmax;
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back

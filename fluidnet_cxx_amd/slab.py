@@ -87,6 +87,12 @@ class NativeOps:
     def __init__(self):
         from ._ext import ext
         self.ext = ext
+        self._ws = None          # persistent Jacobi workspace: holds the 3D neighbour mask between sweep blocks
+        self._ws_key = None
+        self._mask_valid = False
+
+    def begin_step(self):
+        self._mask_valid = False
 
     def set_slab(self, z_offset, D_global):
         self.ext.set_slab(int(z_offset), int(D_global))
@@ -106,7 +112,13 @@ class NativeOps:
                                         float(cfg.get("operatingDensity", 0.0)), True)
 
     def jacobi_sweeps(self, flags, div, p, n):
-        self.ext.jacobi_sweeps_(flags, div, p, True, int(n))
+        key = (tuple(flags.shape), flags.device)
+        if self._ws is None or self._ws_key != key:
+            B, _, D, H, W = flags.shape
+            self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
+            self._ws_key, self._mask_valid = key, False
+        self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid)
+        self._mask_valid = True      # same flags for the rest of this step (begin_step resets)
 
     def post_projection(self, st):
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
@@ -129,6 +141,8 @@ class SlabSimulator:
         `step` serves the requests with the real communicator; tests can drive several ranks in lock-step."""
         l, cfg, ops = self.l, self.cfg, self.ops
         dt = float(cfg["dt"])
+        if hasattr(ops, "begin_step"):
+            ops.begin_step()
         yield [st["U"], st["density"]], l.halo
         ops.set_slab(l.z_offset, l.D_global)
         rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], float(cfg["maccormackStrength"]),

@@ -91,6 +91,10 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
  * blocks of sweeps.  No residual. */
 int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
                       void* ws, size_t ws_bytes, void* stream);
+/* Same, for callers that keep `ws` alive between calls on the SAME flags: reuse_mask != 0 skips rebuilding the 3D
+ * neighbour mask that an earlier call (with reuse_mask == 0) left in `ws`. */
+int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
+                         void* ws, size_t ws_bytes, int reuse_mask, void* stream);
 
 /* velocityUpdate (in place on U), lib/fluid/velocity_update.py:6-162 */
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream);
