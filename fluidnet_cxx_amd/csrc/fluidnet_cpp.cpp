@@ -280,6 +280,17 @@ void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, 
                                     ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
 }
 
+// one pass (1|2 sweeps) p_in -> p_out on the output planes [k_begin, k_end) -- z-slab driver (overlap with exchange)
+void jacobi_pass_(Tensor flags, Tensor div, Tensor p_in, Tensor p_out, int nsweeps, int k_begin, int k_end,
+                  Tensor workspace, bool reuse_mask) {
+  FnxGrid g = grid_of(flags, true);
+  check_scalar(div, g, "div"); check_scalar(p_in, g, "p_in"); check_scalar(p_out, g, "p_out");
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_jacobi_pass(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p_in.data_ptr<float>(),
+                               p_out.data_ptr<float>(), nsweeps, k_begin, k_end, workspace.data_ptr(),
+                               (size_t)workspace.numel() * workspace.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+}
+
 int64_t jacobi_workspace_bytes(int B, int D, int H, int W, bool is3D) {
   FnxGrid g{B, D, H, W, is3D ? 1 : 0, 0, 0, 0};
   return (int64_t)fnx_workspace_bytes(&g, FNX_OP_JACOBI);
@@ -363,6 +374,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
         py::arg("workspace") = py::none(), py::arg("reuse_mask") = false);
   m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
+  m.def("jacobi_pass_", &jacobi_pass_);
   m.def("pre_projection_", &pre_projection_);
   m.def("post_projection_", &post_projection_);
   m.def("set_ref_quirks", [](bool on) { g_ref_quirks = on; }, "3D only: reproduce the reference's 3D defects bit-for-bit");

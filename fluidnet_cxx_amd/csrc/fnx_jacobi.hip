@@ -265,13 +265,13 @@ __global__ __launch_bounds__(256) void jacobi3d_first_kernel(size_t n, int B, si
 __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const unsigned char* __restrict__ mask,
                                                              const float* __restrict__ div,
                                                              const float* __restrict__ p_in, float* __restrict__ p_out,
-                                                             float* __restrict__ sumsq, int nzc) {
+                                                             float* __restrict__ sumsq, int nzc, int kb, int ke) {
   const int lane = threadIdx.x;                          // blockDim = (64, 4): one wave per threadIdx.y
   const int i = blockIdx.x * 64 + lane;
   const int j0 = (blockIdx.y * 4 + threadIdx.y) * ZR;
   int bz = blockIdx.z;
   const int zc = bz % nzc; const int b = bz / nzc;
-  const int k_lo = zc * ZCHUNK, k_hi = min(k_lo + ZCHUNK, g.D);     // planes [k_lo, k_hi)
+  const int k_lo = kb + zc * ZCHUNK, k_hi = min(k_lo + ZCHUNK, ke); // planes [k_lo, k_hi) of the requested range [kb, ke)
   const bool xin = i < g.W;
   const int ic = xin ? i : g.W - 1;
   const size_t base = (size_t)b * g.DHW;
@@ -363,14 +363,14 @@ __global__ __launch_bounds__(256, 4) void jacobi3d_march2_kernel(GridDims g, con
                                                               const float* __restrict__ div,
                                                               const float* __restrict__ p_in,
                                                               float* __restrict__ p_out, float* __restrict__ sumsq,
-                                                              int nzc) {
+                                                              int nzc, int kb, int ke) {
   constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
   const int lane = threadIdx.x;
   const int x = blockIdx.x * 60 - 2 + lane;
   const int j0 = (blockIdx.y * 4 + threadIdx.y) * Z2R;
   int bz = blockIdx.z;
   const int zc = bz % nzc; const int b = bz / nzc;
-  const int k_lo = zc * Z2C, k_hi = min(k_lo + Z2C, g.D);
+  const int k_lo = kb + zc * Z2C, k_hi = min(k_lo + Z2C, ke);      // output planes of the requested range [kb, ke)
   const bool xin = (x >= 0) & (x < g.W);
   const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
   const size_t base = (size_t)b * g.DHW;
@@ -622,23 +622,25 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 
 // two sweeps in one pass: p_in = p^n, p_out = p^{n+2}; sumsq receives ||p^{n+2} - p^{n+1}||^2
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s) {
-  const int nzc = (g.D + Z2C - 1) / Z2C;
+                        float* sumsq, hipStream_t s, int kb, int ke) {
+  if (ke <= kb) { kb = 0; ke = g.D; }
+  const int nzc = (ke - kb + Z2C - 1) / Z2C;
   const dim3 grid((g.W + 59) / 60, (g.H + 4 * Z2R - 1) / (4 * Z2R), g.B * nzc), block(64, 4);
-  jacobi3d_march2_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nzc);
+  jacobi3d_march2_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nzc, kb, ke);
 }
 
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                     bool from_zero, float* sumsq, hipStream_t s) {
+                     bool from_zero, float* sumsq, hipStream_t s, int kb, int ke) {
+  if (ke <= kb) { kb = 0; ke = g.D; }
   if (from_zero) {
     size_t nb = ((size_t)g.DHW + 256 * 4 - 1) / (256 * 4);
     if (nb > 4096) nb = 4096;
     jacobi3d_first_kernel<<<(unsigned)nb, 256, 0, s>>>((size_t)g.B * g.DHW, g.B, (size_t)g.DHW, div, mask, p_out, sumsq);
     return;
   }
-  const int nzc = (g.D + ZCHUNK - 1) / ZCHUNK;
+  const int nzc = (ke - kb + ZCHUNK - 1) / ZCHUNK;
   const dim3 grid((g.W + 63) / 64, (g.H + 4 * ZR - 1) / (4 * ZR), g.B * nzc), block(64, 4);
-  jacobi3d_march_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nzc);
+  jacobi3d_march_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nzc, kb, ke);
 }
 
 void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s) {

@@ -52,10 +52,11 @@ void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags
 int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d);
 // 3D: flags -> 7-bit neighbour mask (once per solve), then one z-marching sweep per launch
 void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, unsigned char* mask, hipStream_t s);
+// kb/ke: restrict the OUTPUT to planes [kb, ke) (0,0 = all planes); inputs are read from kb-1 (kb-2 for x2) on
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                     bool from_zero, float* sumsq, hipStream_t s);
+                     bool from_zero, float* sumsq, hipStream_t s, int kb = 0, int ke = 0);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s);
+                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0);
 void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
 void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s);
 

@@ -6,9 +6,10 @@ ghost planes towards each neighbour.  All geometry runs in GLOBAL z coordinates 
 the native side), so every owned cell goes through bit-for-bit the same arithmetic as in a single-GPU run.
 
 Per step (Jacobi method):
-  1. exchange U, density ghosts (width `halo`)            -> advection + BC/buoyancy/wall stage valid on owned +- 1
+  1. exchange U, density ghosts (4 planes)                -> advection + BC/buoyancy/wall stage valid on owned +- 1
   2. exchange div ghosts (width w-1) once
-  3. [exchange p ghosts (width w); w Jacobi sweeps] * ceil(N/w)   -- temporal blocking in z: one message per w sweeps
+  3. blocks of w Jacobi sweeps (temporal blocking in z: one message per w sweeps); the last pass of a block first
+     produces the planes the neighbours need, posts the exchange, and computes the interior while it is in flight
   4. exchange p (width 1), velocity update + wall BCs + BCs on the owned planes
 Communication is point-to-point between z-neighbours only (`torch.distributed` P2P = RCCL send/recv over xGMI on
 GPUs, gloo in the CPU tests): each rank talks to at most two peers, there is no collective on the data path.
@@ -50,10 +51,11 @@ class SlabComm:
         self.l = layout
         self.group = group
 
-    def exchange(self, fields, width):
+    def start(self, fields, width):
+        """Post the sends/receives of `width` ghost planes of every field; returns a handle for finish()."""
         l = self.l
         if l.world == 1:
-            return
+            return None
         assert width <= l.halo
         ops, recvs = [], []
         for f in fields:
@@ -75,10 +77,19 @@ class SlabComm:
                 ops += [dist.P2POp(dist.isend, sb, l.rank + 1, self.group), dist.P2POp(dist.irecv, rb, l.rank + 1, self.group)]
                 if C != 1:
                     recvs.append((recv, rb))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        return dist.batch_isend_irecv(ops), recvs
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        works, recvs = handle
+        for w in works:
+            w.wait()                 # NCCL: the current stream waits for the transfer; gloo: the host does
         for dst, buf in recvs:
             dst.copy_(buf)
+
+    def exchange(self, fields, width):
+        self.finish(self.start(fields, width))
 
 
 class NativeOps:
@@ -120,6 +131,15 @@ class NativeOps:
         self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid)
         self._mask_valid = True      # same flags for the rest of this step (begin_step resets)
 
+    def jacobi_pass(self, flags, div, p_in, p_out, n, k_begin, k_end):
+        key = (tuple(flags.shape), flags.device)
+        if self._ws is None or self._ws_key != key:
+            B, _, D, H, W = flags.shape
+            self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
+            self._ws_key, self._mask_valid = key, False
+        self.ext.jacobi_pass_(flags, div, p_in, p_out, int(n), int(k_begin), int(k_end), self._ws, self._mask_valid)
+        self._mask_valid = True
+
     def post_projection(self, st):
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
                                   st.get("densityBC"), st.get("densityBCInvMask"))
@@ -134,48 +154,90 @@ class SlabSimulator:
         self.ops = ops if ops is not None else NativeOps()
         self.comm = SlabComm(layout, group)
         self.w = min(sweeps_per_exchange, layout.halo)
+        self._pbuf = None
+        assert layout.world == 1 or layout.owned >= 2 * self.w, "slab too thin for the sweep block"
         assert layout.world == 1 or layout.halo >= 5, "advection + projection need 5 valid ghost planes (CFL <= 1)"
 
     def phases(self, st):
-        """Generator over the step: computes up to the next ghost exchange and yields (fields, width).
-        `step` serves the requests with the real communicator; tests can drive several ranks in lock-step."""
+        """Generator over the step: computes up to the next communication point and yields a request
+             ("xchg", fields, width)   blocking ghost exchange
+             ("start", fields, width)  post a ghost exchange and keep computing
+             ("wait",)                 the posted exchange must have landed
+        `step` serves the requests with the real communicator; tests drive several ranks in lock-step."""
         l, cfg, ops = self.l, self.cfg, self.ops
         dt = float(cfg["dt"])
+        w = self.w
         if hasattr(ops, "begin_step"):
             ops.begin_step()
-        yield [st["U"], st["density"]], l.halo
+        # advection reaches <= 2 planes beyond its inputs at CFL <= 1 and the BC/buoyancy/divergence stage one more:
+        # 4 fresh ghost planes of U and density are enough (the arrays keep `halo` planes for the pressure solve)
+        yield "xchg", [st["U"], st["density"]], min(4, l.halo)
         ops.set_slab(l.z_offset, l.D_global)
         rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], float(cfg["maccormackStrength"]),
                                     cfg.get("sampleOutsideFluid", False))
         U_adv = ops.advect_vel(dt, st["U"], st["flags"], float(cfg["maccormackStrength"]))
         div = ops.pre_projection(U_adv, rho_adv, st, cfg)
-        yield [div], max(self.w - 1, 1)
-        st["p"].zero_()
-        remaining, first = int(cfg["jacobiIter"]), True
+        yield "xchg", [div], max(w - 1, 1)
+
+        # Jacobi: blocks of w sweeps between ghost exchanges (temporal blocking in z).  The last pass of a block first
+        # produces the w planes each neighbour needs, posts their exchange, and computes the interior meanwhile.
+        ops.set_slab(l.z_offset, l.D_global)
+        if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
+            self._pbuf = torch.zeros_like(st["p"])
+        cur, nxt = st["p"], self._pbuf
+        cur.zero_()
+        lo, top = l.lo, l.lo + l.owned
+        remaining, pending = int(cfg["jacobiIter"]), False
         while remaining > 0:
-            k = min(self.w, remaining)
-            if not first:
-                yield [st["p"]], self.w
-            ops.set_slab(l.z_offset, l.D_global)
-            ops.jacobi_sweeps(st["flags"], div, st["p"], k)
+            k = min(w, remaining)
             remaining -= k
-            first = False
-        yield [st["p"]], 1
+            if pending:
+                yield ("wait",)
+                ops.set_slab(l.z_offset, l.D_global)
+                pending = False
+            passes = [2] * (k // 2) + [1] * (k % 2)
+            for pi, n in enumerate(passes):
+                if pi == len(passes) - 1 and remaining > 0 and l.world > 1:
+                    if l.rank > 0:
+                        ops.jacobi_pass(st["flags"], div, cur, nxt, n, lo, lo + w)
+                    if l.rank < l.world - 1:
+                        ops.jacobi_pass(st["flags"], div, cur, nxt, n, top - w, top)
+                    yield "start", [nxt], w
+                    ops.set_slab(l.z_offset, l.D_global)
+                    pending = True
+                    ia = lo + w if l.rank > 0 else 0
+                    ib = top - w if l.rank < l.world - 1 else l.D_local
+                    if ib > ia:
+                        ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)   # overlaps the exchange
+                else:
+                    ops.jacobi_pass(st["flags"], div, cur, nxt, n, 0, 0)
+                cur, nxt = nxt, cur
+        if cur is not st["p"]:
+            st["p"].copy_(cur)
+        yield "xchg", [st["p"]], 1
         ops.set_slab(l.z_offset, l.D_global)
         ops.post_projection(st)
         ops.set_slab(0, 0)
 
     def step(self, st):
+        handle = None
         try:
-            for fields, width in self.phases(st):
-                self.comm.exchange(fields, width)
+            for req in self.phases(st):
+                if req[0] == "xchg":
+                    self.comm.exchange(req[1], req[2])
+                elif req[0] == "start":
+                    handle = self.comm.start(req[1], req[2])
+                else:
+                    self.comm.finish(handle)
+                    handle = None
         finally:
             self.ops.set_slab(0, 0)
 
 
 def lockstep_step(sims, states):
     """Single-process stand-in for n ranks: advances all slabs phase by phase and serves their ghost exchanges with
-    direct copies.  Used to validate the decomposition on ONE device (tests); production uses SlabSimulator.step."""
+    direct copies (a posted exchange is served at once, so any later write into the planes in flight shows up as a
+    mismatch).  Used to validate the decomposition on ONE device (tests); production uses SlabSimulator.step."""
     gens = [s.phases(st) for s, st in zip(sims, states)]
     while True:
         reqs = []
@@ -186,11 +248,13 @@ def lockstep_step(sims, states):
                 reqs.append(None)
         if all(r is None for r in reqs):
             break
-        assert all(r is not None for r in reqs), "ranks fell out of step"
-        width = reqs[0][1]
+        assert all(r is not None for r in reqs) and len({r[0] for r in reqs}) == 1, "ranks fell out of step"
+        if reqs[0][0] == "wait":
+            continue
+        width = reqs[0][2]
         for r in range(len(sims) - 1):           # pair (r, r+1)
             lo, hi = sims[r].l, sims[r + 1].l
-            for f_lo, f_hi in zip(reqs[r][0], reqs[r + 1][0]):
+            for f_lo, f_hi in zip(reqs[r][1], reqs[r + 1][1]):
                 top = lo.lo + lo.owned
                 f_lo[:, :, top:top + width].copy_(f_hi[:, :, hi.lo:hi.lo + width])
                 f_hi[:, :, hi.lo - width:hi.lo].copy_(f_lo[:, :, top - width:top])
