@@ -51,9 +51,13 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return
 
-    assert viscosity == 0 and gravityScale == 0 and "flags_stick" not in batch_dict, \
-        "viscosity / gravity / stick BCs are outside the accelerated path (reference configs keep them off)"
+    assert "flags_stick" not in batch_dict, \
+        "stick BCs: the reference's setWallBcsStick does not run (SURVEY Q15); not provided"
     # ---- operator-by-operator path, reference order ----
+    orig = U
+    if viscosity > 0:                                           # simulate.py:66-69
+        orig = U.clone()
+        fluid.addViscosity(dt, orig, flags, viscosity)
     if has_density:
         density = fluid.advectScalar(dt, batch_dict["density"], U, flags, method="maccormackFluidNet",
                                      boundary_width=1, sample_outside_fluid=sampleOutsideFluid,
@@ -63,13 +67,17 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
             fluid.correctScalar(dt, density, div, flags)
     else:
         density = torch.zeros_like(flags)
-    U = fluid.advectVelocity(dt=dt, orig=U, U=U, flags=flags, method="maccormackFluidNet", boundary_width=1,
+    U = fluid.advectVelocity(dt=dt, orig=orig, U=U, flags=flags, method="maccormackFluidNet", boundary_width=1,
                              maccormack_strength=maccormackStrength)
     setConstVals(batch_dict, p, U, flags, density)
     if has_density and buoyancyScale > 0:
         gvec, _ = _gravity(mconf, 1.0)
         gravity = (torch.tensor(gvec, dtype=torch.float32) * (-buoyancyScale)).tolist()
         U = fluid.addBuoyancy(U, flags, density, gravity, mconf["operatingDensity"], dt)
+    if has_density and gravityScale > 0:                        # simulate.py:107-114 (inside the density branch)
+        gvec, _ = _gravity(mconf, 1.0)
+        gravity = (torch.tensor(gvec, dtype=torch.float32) * (-gravityScale)).tolist()
+        U = fluid.addGravity(U, flags, gravity, dt)
     if output_div:
         return
     periodic = "periodic-x" in mconf and "periodic-y" in mconf

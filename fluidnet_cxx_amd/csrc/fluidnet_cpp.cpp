@@ -150,6 +150,26 @@ void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> g
                                 (float)rho_star, (float)dt, cur_stream(U)));
 }
 
+void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U");
+  TORCH_CHECK(gravity.size() == 3, "Gravity must be a 3D vector (even in 2D)");
+  const float gv[3] = {(float)gravity[0], (float)gravity[1], (float)gravity[2]};
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_add_gravity(&g, U.data_ptr<float>(), flags.data_ptr<float>(), gv, (float)dt, cur_stream(U)));
+}
+
+void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor old = U.clone();
+  check_status(fnx_add_viscosity(&g, (float)dt, old.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                                 (float)viscosity, cur_stream(U)));
+}
+
 void set_wall_bcs_(Tensor U, Tensor flags) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
@@ -362,6 +382,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("velocity_divergence", &velocity_divergence);
   m.def("velocity_update_", &velocity_update_);
   m.def("add_buoyancy_", &add_buoyancy_);
+  m.def("add_gravity_", &add_gravity_);
+  m.def("add_viscosity_", &add_viscosity_);
   m.def("set_wall_bcs_", &set_wall_bcs_);
   m.def("set_const_vals_", &set_const_vals_);
   m.def("flags_to_occupancy", &flags_to_occupancy);

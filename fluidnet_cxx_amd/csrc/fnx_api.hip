@@ -340,6 +340,28 @@ int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float*
   return FNX_OK;
 }
 
+int fnx_add_gravity(const FnxGrid* g, float* U, const float* flags, const float gravity[3], float dt, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!U || !flags || !gravity) return fail(FNX_EINVAL, "add_gravity: NULL tensor");
+  fnx::launch_add_gravity(dims(g), g->is3D, U, flags, gravity[0] * dt, gravity[1] * dt, gravity[2] * dt,
+                          (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_add_viscosity(const FnxGrid* g, float dt, const float* U_in, float* U_out, const float* flags, float viscosity,
+                      void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!U_in || !U_out || !flags) return fail(FNX_EINVAL, "add_viscosity: NULL tensor");
+  if (g->is3D) return fail(FNX_EINVAL, "add_viscosity: 2D only (reference viscosity.py:5)");
+  if (U_in == U_out) return fail(FNX_EINVAL, "add_viscosity: U_out must not alias U_in");
+  if (!(viscosity >= 0.f)) return fail(FNX_EINVAL, "add_viscosity: viscosity must be positive");
+  const float coef = (float)((double)dt * (double)viscosity);
+  fnx::launch_add_viscosity(dims(g), U_in, U_out, flags, coef, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_add_buoyancy(const FnxGrid* g, float* U, const float* flags, const float* density, const float gravity[3],
                      float rho_star, float dt, void* stream) {
   if (int rc = check_grid(g)) return rc;

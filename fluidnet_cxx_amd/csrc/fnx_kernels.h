@@ -28,6 +28,10 @@ void launch_sl_mac_bwd_clamp(const GridDims& g, bool is3d, bool quirks, float dt
 // stencils (fnx_stencils.hip)
 void launch_divergence(const GridDims& g, bool is3d, const float* U, const float* flags, float* div, hipStream_t s);
 void launch_velocity_update(const GridDims& g, bool is3d, const float* p, float* U, const float* flags, hipStream_t s);
+void launch_add_gravity(const GridDims& g, bool is3d, float* U, const float* flags, float fx, float fy, float fz,
+                        hipStream_t s);
+void launch_add_viscosity(const GridDims& g, const float* Uin, float* Uout, const float* flags, float coef,
+                          hipStream_t s);
 void launch_add_buoyancy(const GridDims& g, bool is3d, bool quirks, float* U, const float* flags, const float* rho,
                          float sx, float sy, float sz, float rho_star, hipStream_t s);
 void launch_set_wall_bcs(const GridDims& g, bool is3d, float* U, const float* flags, hipStream_t s);

@@ -105,6 +105,58 @@ __global__ __launch_bounds__(BX* BY) void add_buoyancy_kernel(GridDims g, float*
   }
 }
 
+// addGravity, lib/fluid/source_terms.py:122-219
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void add_gravity_kernel(GridDims g, float* __restrict__ U,
+                                                             const float* __restrict__ flags, float fx, float fy,
+                                                             float fz) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid || is_border<IS3D>(g, c.i, c.j, c.k)) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  const float fc = fl[0];
+  if (fc != FNX_FLUID && fc != FNX_EMPTY) return;
+  float* u = U + (size_t)c.b * NC * g.DHW + o;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const float fm = *(fl - (a == 0 ? 1 : (a == 1 ? g.W : g.HW)));
+    if (fm == FNX_FLUID || (fm == FNX_EMPTY && fc == FNX_FLUID)) {
+      float* q = u + (size_t)a * g.DHW;
+      *q = *q + (a == 0 ? fx : (a == 1 ? fy : fz));
+    }
+  }
+}
+
+// addViscosity (2D), lib/fluid/viscosity.py:57-70: out = m * (u + coef * (u[i+1] + u[j+1] + u[i-1] + u[i-1,j-1] - 4u)),
+// border cells copied; the fourth neighbour is the reference's (i-1, j-1).
+__global__ __launch_bounds__(BX* BY) void add_viscosity_kernel(GridDims g, const float* __restrict__ Uin,
+                                                               float* __restrict__ Uout,
+                                                               const float* __restrict__ flags, float coef) {
+  const CellId c = cell_id<false>(g);
+  if (!c.valid) return;
+  const size_t o = (size_t)c.j * g.W + c.i;
+  const float* u = Uin + (size_t)c.b * 2 * g.DHW + o;
+  float* w = Uout + (size_t)c.b * 2 * g.DHW + o;
+  if (is_border<false>(g, c.i, c.j, c.k)) {
+    w[0] = u[0];
+    w[g.DHW] = u[g.DHW];
+    return;
+  }
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  const bool fluid = fl[0] == FNX_FLUID;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float* q = u + (size_t)a * g.DHW;
+    const float m = (fluid && *(fl - (a == 0 ? 1 : g.W)) == FNX_FLUID) ? 1.f : 0.f;
+    float s = q[1] + q[g.W];
+    s = s + *(q - 1);
+    s = s + *(q - 1 - g.W);
+    s = s - (4.f * q[0]);
+    w[(size_t)a * g.DHW] = m * (q[0] + coef * s);
+  }
+}
+
 // setWallBcs, lib/fluid/set_wall_bcs.py:45-84
 template <bool IS3D>
 __global__ __launch_bounds__(BX* BY) void set_wall_bcs_kernel(GridDims g, float* __restrict__ U,
@@ -183,6 +235,17 @@ void launch_add_buoyancy(const GridDims& g, bool is3d, bool quirks, float* U, co
   } else {
     add_buoyancy_kernel<false, false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, rho, sx, sy, sz, rho_star);
   }
+}
+
+void launch_add_gravity(const GridDims& g, bool is3d, float* U, const float* flags, float fx, float fy, float fz,
+                        hipStream_t s) {
+  if (is3d) add_gravity_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, fx, fy, fz);
+  else add_gravity_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, fx, fy, fz);
+}
+
+void launch_add_viscosity(const GridDims& g, const float* Uin, float* Uout, const float* flags, float coef,
+                          hipStream_t s) {
+  add_viscosity_kernel<<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, Uin, Uout, flags, coef);
 }
 
 void launch_set_wall_bcs(const GridDims& g, bool is3d, float* U, const float* flags, hipStream_t s) {

@@ -94,6 +94,24 @@ def addBuoyancy(U, flags, density, gravity, rho_star, dt):
     return U
 
 
+def addGravity(U, flags, gravity, dt):
+    """lib/fluid/source_terms.py:122-219 -- in place on U, returns U."""
+    _check5(U, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    g = gravity.detach().cpu().tolist() if torch.is_tensor(gravity) else [float(x) for x in gravity]
+    assert len(g) == 3, "Gravity must be a 3D vector (even in 2D)"
+    ext.add_gravity_(U, flags, g, float(dt))
+    return U
+
+
+def addViscosity(dt, U, flags, viscosity):
+    """lib/fluid/viscosity.py:7-70 -- in place on U (2D only, like the reference)."""
+    _check5(U, flags)
+    assert flags.size(1) == 1, "flags is not scalar"
+    assert U.size(1) == 2 and U.size(2) == 1, "addViscosity: ONLY IN 2D"
+    ext.add_viscosity_(float(dt), U, flags, float(viscosity))
+
+
 def setWallBcs(U, flags):
     """lib/fluid/set_wall_bcs.py:4-86 -- in place on U, returns U."""
     _check5(U, flags)

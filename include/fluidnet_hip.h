@@ -110,6 +110,14 @@ int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float*
 int fnx_add_buoyancy(const FnxGrid* g, float* U, const float* flags, const float* density,
                      const float gravity[3], float rho_star, float dt, void* stream);
 
+/* addGravity (in place on U), lib/fluid/source_terms.py:122-219.  gravity: 3 HOST floats. */
+int fnx_add_gravity(const FnxGrid* g, float* U, const float* flags, const float gravity[3], float dt, void* stream);
+
+/* addViscosity, lib/fluid/viscosity.py:7-70 (2D only, like the reference).  The reference updates U in place from
+ * a fully evaluated right-hand side; here U_in is the old field and U_out (a distinct buffer) receives the result. */
+int fnx_add_viscosity(const FnxGrid* g, float dt, const float* U_in, float* U_out, const float* flags,
+                      float viscosity, void* stream);
+
 /* setWallBcs (in place on U), lib/fluid/set_wall_bcs.py:4-86 */
 int fnx_set_wall_bcs(const FnxGrid* g, float* U, const float* flags, void* stream);
 

@@ -619,6 +619,63 @@ int ora_add_buoyancy(const OraGrid* g, float* U, const float* flags, const float
 }
 
 /* ------------------------------------------------------------------------------------------
+ * addGravity (source_terms.py:122-219): U_c += gravity_c*dt on interior fluid/empty cells whose -1 neighbour is
+ * fluid, or is empty while the cell itself is fluid.
+ * ---------------------------------------------------------------------------------------- */
+int ora_add_gravity(const OraGrid* g, float* U, const float* flags, const float gravity[3], float dt) {
+  const int nc = g->is3D ? 3 : 2;
+  const float f[3] = { gravity[0] * dt, gravity[1] * dt, gravity[2] * dt };
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int b = 0; b < g->B; ++b)
+    for (int k = 0; k < g->D; ++k)
+      for (int j = 0; j < g->H; ++j)
+        for (int i = 0; i < g->W; ++i) {
+          if (is_border(g, i, j, k, 1)) continue;
+          const size_t c = IDX(g, 1, b, 0, k, j, i);
+          const float fc = flags[c];
+          if (fc != T_FLUID && fc != T_EMPTY) continue;
+          for (int a = 0; a < nc; ++a) {
+            const float fm = flags[IDX(g, 1, b, 0, k - (a == 2), j - (a == 1), i - (a == 0))];
+            if (fm == T_FLUID || (fm == T_EMPTY && fc == T_FLUID)) {
+              const size_t q = IDX(g, nc, b, a, k, j, i);
+              U[q] = U[q] + f[a];
+            }
+          }
+        }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * addViscosity (viscosity.py:7-70, 2D only): U = m * (U + (dt*nu) * (U[i+1] + U[j+1] + U[i-1] + U[i-1,j-1] - 4U))
+ * on interior cells, m_c = fluid(cell) && fluid(cell - e_c); the fourth neighbour is (i-1,j-1) as in the reference
+ * (:68).  Reads the old field throughout (the reference evaluates the right-hand side before assigning).
+ * ---------------------------------------------------------------------------------------- */
+int ora_add_viscosity(const OraGrid* g, float dt, float* U, const float* flags, float viscosity) {
+  if (g->is3D) return 1;
+  const size_t n = (size_t)g->B * 2 * g->H * g->W;
+  float* old = (float*)malloc(n * sizeof(float));
+  memcpy(old, U, n * sizeof(float));
+  const float coef = (float)((double)dt * (double)viscosity);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < g->B; ++b)
+    for (int j = 1; j < g->H - 1; ++j)
+      for (int i = 1; i < g->W - 1; ++i) {
+        const size_t c = IDX(g, 1, b, 0, 0, j, i);
+        for (int a = 0; a < 2; ++a) {
+          const float m = (flags[c] == T_FLUID && flags[c - (a == 0 ? 1 : g->W)] == T_FLUID) ? 1.f : 0.f;
+          const size_t q = IDX(g, 2, b, a, 0, j, i);
+          float s = old[q + 1] + old[q + g->W];
+          s = s + old[q - 1];
+          s = s + old[q - 1 - g->W];
+          s = s - (4.f * old[q]);
+          U[q] = m * (old[q] + coef * s);
+        }
+      }
+  free(old);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * setWallBcs (set_wall_bcs.py:45-84)
  * ---------------------------------------------------------------------------------------- */
 int ora_set_wall_bcs(const OraGrid* g, float* U, const float* flags) {

@@ -129,6 +129,25 @@ def add_buoyancy(U, flags, rho, gravity, rho_star, dt, quirks=False):
     return U
 
 
+def add_gravity(U, flags, gravity, dt):
+    g = _grid(flags, U.shape[1] == 3)
+    flags, pf = _f(flags)
+    U = np.array(U, dtype=np.float32, order="C", copy=True)
+    gv = (ctypes.c_float * 3)(*[float(x) for x in gravity])
+    lib().ora_add_gravity(ctypes.byref(g), U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pf, gv, ctypes.c_float(dt))
+    return U
+
+
+def add_viscosity(dt, U, flags, viscosity):
+    g = _grid(flags, U.shape[1] == 3)
+    flags, pf = _f(flags)
+    U = np.array(U, dtype=np.float32, order="C", copy=True)
+    rc = lib().ora_add_viscosity(ctypes.byref(g), ctypes.c_float(dt), U.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pf,
+                                 ctypes.c_float(viscosity))
+    assert rc == 0, "addViscosity is 2D only (reference viscosity.py:5)"
+    return U
+
+
 def set_wall_bcs(U, flags):
     g = _grid(flags, U.shape[1] == 3)
     flags, pf = _f(flags)
@@ -223,23 +242,45 @@ def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False):
                                   state["densityBCInvMask"])
         return U, rho
 
+    orig = U
+    if cfg.get("viscosity", 0) > 0:                              # simulate.py:66-69
+        orig = add_viscosity(dt, U, flags, cfg["viscosity"])
     rho = advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, cfg.get("sampleOutsideFluid", False),
                         cfg["maccormackStrength"], quirks)
-    U = advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, cfg["maccormackStrength"], quirks)
+    if cfg.get("correctScalar", False):                          # cpp/advection.py:9-12
+        div = velocity_divergence(U, flags)
+        half = np.float32(dt * 0.5)
+        rho = np.where(flags == 1, rho + (half * rho) * div, rho).astype(np.float32)
+    U = advect_vel(dt, orig, U, flags, "maccormackFluidNet", 1, cfg["maccormackStrength"], quirks)
     U, rho = const_vals(U, rho)
     bs = cfg.get("buoyancyScale", 0)
     if bs > 0:
         gv = cfg["gravityVec"]
         gvec = (np.array([gv["x"], gv["y"], gv["z"]], np.float32) * np.float32(-bs)).astype(np.float32)
         U = add_buoyancy(U, flags, rho, gvec, cfg.get("operatingDensity", 0.0), dt, quirks)
+    gs = cfg.get("gravityScale", 0)
+    if gs > 0:                                                   # simulate.py:107-114
+        gv = cfg["gravityVec"]
+        gvec = (np.array([gv["x"], gv["y"], gv["z"]], np.float32) * np.float32(-gs)).astype(np.float32)
+        U = add_gravity(U, flags, gvec, dt)
+    periodic = "periodic-x" in cfg and "periodic-y" in cfg
+
+    def wall_bcs(U):                                             # simulate.py:120-128
+        out = set_wall_bcs(U, flags)
+        if periodic and cfg["periodic-x"]:
+            out[:, 1, :, :, 1] = U[:, 1, :, :, -1]
+        if periodic and cfg["periodic-y"]:
+            out[:, 0, :, 1] = U[:, 0, :, -1]
+        return out
+
     if method == "jacobi":
-        U = set_wall_bcs(U, flags)
+        U = wall_bcs(U)
     U, rho = const_vals(U, rho)
     if method == "jacobi":
         div = velocity_divergence(U, flags)
         p, _, _ = jacobi(flags, div, is3d, cfg.get("pTol", 0.0), cfg["jacobiIter"], quirks)
         U = velocity_update(p, U, flags)
-        U = set_wall_bcs(U, flags)
+        U = wall_bcs(U)
     else:
         inp = np.concatenate([state["p"], U, flags, rho], 1)
         p, U = fluidnet_forward(blob, inp, cfg.get("normalizeInputThreshold", 1e-5))

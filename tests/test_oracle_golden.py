@@ -36,6 +36,9 @@ def test_ops_bitexact(oracle, golden, case):
         assert_bitexact(O.set_wall_bcs(U, flags), z["set_wall_bcs"], "set_wall_bcs")
     assert_bitexact(O.add_buoyancy(U, flags, rho, z["gravity"], float(z["rho_star"]), dt, q), z["add_buoyancy"], "add_buoyancy")
     assert_bitexact(O.flags_to_occupancy(flags), z["occupancy"], "occupancy")
+    assert_bitexact(O.add_gravity(U, flags, z["gravity"], dt), z["add_gravity"], "add_gravity")
+    if not is3d:
+        assert_bitexact(O.add_viscosity(dt, U, flags, float(z["viscosity"])), z["add_viscosity"], "add_viscosity")
 
 
 def test_plume128_ops(oracle, golden):
@@ -96,6 +99,18 @@ def test_sim64_convnet(oracle, golden):
                         assert_bitexact(st[k], s[f"{method}_{k}_{it}"], f"{method} {k} {it}")
                     else:
                         assert_close(st[k], s[f"{method}_{k}_{it}"], 1e-5, f"{method} {k} {it}")
+
+
+def test_sim64_optional_stages(oracle, golden):
+    """lib.simulate with viscosity, correctScalar, gravity and the periodic patches on (all off in shipped configs)."""
+    from util import F2_CFG
+    s = golden("sim64")
+    st = plume_state(64)
+    for it in range(1, 7):
+        st = oracle.simulate_step(st, dict(PLUME_CFG, **F2_CFG), "jacobi")
+        if it in (1, 3, 6):
+            for k in ("U", "density", "p"):
+                assert_bitexact(st[k], s[f"f2_{k}_{it}"], f"{k} after {it} steps")
 
 
 def test_known_answers(oracle):

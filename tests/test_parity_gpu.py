@@ -57,6 +57,9 @@ def run_ops(fl, dev, flags, U, rho, p, dt, gravity, rho_star, is3d, orig=None, j
     Uw = tU.clone(); r = fl.setWallBcs(Uw, tf); assert r is Uw; out["set_wall_bcs"] = N(Uw)
     Ub = tU.clone(); r = fl.addBuoyancy(Ub, tf, trho, gravity, rho_star, dt); assert r is Ub; out["add_buoyancy"] = N(Ub)
     out["occupancy"] = N(fl.flagsToOccupancy(tf))
+    Ug = tU.clone(); r = fl.addGravity(Ug, tf, gravity, dt); assert r is Ug; out["add_gravity"] = N(Ug)
+    if not is3d:
+        Uv = tU.clone(); fl.addViscosity(dt, Uv, tf, 0.07); out["add_viscosity"] = N(Uv)
     # inputs untouched (reference: advect_* and solve_linear_system never write to inputs)
     assert_bitexact(N(tU), U, "U unchanged"); assert_bitexact(N(trho), rho, "rho unchanged"); assert_bitexact(N(tf), flags, "flags unchanged")
     return out
@@ -121,6 +124,9 @@ def test_ops_vs_oracle(fl, ext, dev, oracle, shape, quirks):
     assert_bitexact(out["set_wall_bcs"], O.set_wall_bcs(U, flags), "set_wall_bcs")
     assert_bitexact(out["add_buoyancy"], O.add_buoyancy(U, flags, rho, grav, rstar, dt, quirks), "add_buoyancy")
     assert_bitexact(out["occupancy"], O.flags_to_occupancy(flags), "occupancy")
+    assert_bitexact(out["add_gravity"], O.add_gravity(U, flags, grav, dt), "add_gravity")
+    if not is3d:
+        assert_bitexact(out["add_viscosity"], O.add_viscosity(dt, U, flags, 0.07), "add_viscosity")
 
 
 @pytest.mark.parametrize("iters", [1, 2, 7, 8, 9, 16, 28, 37, 100])
@@ -240,6 +246,20 @@ def test_sim64_convnet_vs_reference(dev, golden):
             if it in (1, 3, 10):
                 for k in ("U", "density", "p"):
                     assert_close(N(bd[k]), s[f"convnet_{k}_{it}"], 2e-5, f"convnet {k} after {it} (fused={fused})")
+
+
+def test_sim64_optional_stages_vs_reference(dev, golden):
+    """viscosity + correctScalar + gravity + periodic patches through simulate(): bit-exact against the reference."""
+    from fluidnet_cxx_amd import simulate
+    from util import F2_CFG
+    s = golden("sim64")
+    mconf = dict(PLUME_CFG, **F2_CFG)
+    bd = to_dev(plume_state(64), dev)
+    for it in range(1, 7):
+        simulate(mconf, bd, None, "jacobi")
+        if it in (1, 3, 6):
+            for k in ("U", "density", "p"):
+                assert_bitexact(N(bd[k]), s[f"f2_{k}_{it}"], f"{k} after {it} steps")
 
 
 # ---- properties at benchmark sizes ----------------------------------------------------------------------

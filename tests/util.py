@@ -5,6 +5,9 @@ PLUME_CFG = dict(dt=0.1, maccormackStrength=0.6, sampleOutsideFluid=False, buoya
                  pTol=0.0, jacobiIter=28, normalizeInputThreshold=1e-5)
 
 
+F2_CFG = {"viscosity": 0.02, "gravityScale": 0.5, "correctScalar": True, "periodic-x": True, "periodic-y": True}
+
+
 def make_flags(B, D, H, W, boxes=True, empties=False, seed=0):
     """Border wall + interior obstacles (box, single cell, bar) like tools/make_golden.py."""
     f = np.full((B, 1, D, H, W), 1.0, np.float32)

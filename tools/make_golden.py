@@ -155,6 +155,10 @@ def gen_ops(torch, lib, ext, name, B, D, H, W, sigma, dt, seed, empties=False, b
         Uu = tU.clone(); fluid.velocityUpdate(tp, Uu, tf); out["velocity_update"] = Uu.numpy().copy()
         Uw = tU.clone(); fluid.setWallBcs(Uw, tf); out["set_wall_bcs"] = Uw.numpy().copy()
     Ub = tU.clone(); fluid.addBuoyancy(Ub, tf, trho, g, 0.05, float(dt)); out["add_buoyancy"] = Ub.numpy().copy()
+    Ug = tU.clone(); fluid.addGravity(Ug, tf, g, float(dt)); out["add_gravity"] = Ug.numpy().copy()
+    if not is3d:
+        Uv = tU.clone(); fluid.addViscosity(float(dt), Uv, tf, 0.07); out["add_viscosity"] = Uv.numpy().copy()
+        out["viscosity"] = np.float32(0.07)
     out["occupancy"] = fluid.flagsToOccupancy(tf).numpy().copy()
     np.savez_compressed(os.path.join(OUT, f"ops_{name}.npz"), **out)
     print(f"  wrote ops_{name}.npz")
@@ -222,6 +226,9 @@ def gen_plume(torch, lib, ext):
     print("  wrote plume128.npz")
 
 
+F2_CFG = {"viscosity": 0.02, "gravityScale": 0.5, "correctScalar": True, "periodic-x": True, "periodic-y": True}
+
+
 def gen_sim_small(torch, lib, ext):
     """64x64 plume, Jacobi-28 and convnet (hash-seeded weights), states after 1, 3, 10 steps."""
     mconf = plume_mconf(torch)
@@ -238,6 +245,15 @@ def gen_sim_small(torch, lib, ext):
             if method == "jacobi":
                 for k in ("flags", "UBC", "UBCInvMask", "densityBC", "densityBCInvMask"):
                     out[k] = bd[k].numpy().copy()
+        # every optional stage of lib.simulate switched on (all off in the shipped configs): viscosity, correctScalar,
+        # gravity, periodic patches
+        m2 = dict(mconf); m2.update(F2_CFG)
+        bd = plume_setup(torch, lib, 64)
+        for it in range(1, 7):
+            lib.simulate(m2, bd, None, "jacobi")
+            if it in (1, 3, 6):
+                for k in ("U", "density", "p"):
+                    out[f"f2_{k}_{it}"] = bd[k].numpy().copy()
     np.savez_compressed(os.path.join(OUT, "sim64.npz"), **out)
     print("  wrote sim64.npz")
 
