@@ -116,7 +116,7 @@ def mconf_for(w):
     return m
 
 
-def cpu_baseline(w, budget_s=15.0):
+def cpu_baseline(w, budget_s=12.0):
     """The oracle ("port": plain-C restatement of the reference, OpenMP) timed on this box's host cores on a bounded
     sample of the same workload: the same step on a smaller grid of the same configuration, scaled per cell."""
     from oracle import oracle as O
@@ -132,13 +132,13 @@ def cpu_baseline(w, budget_s=15.0):
         blob = O.pack_weights(make_scalenet_weights(0, ndim=3 if is3d else 2), 3 if is3d else 2)
         res, D = 128, 1
     else:
-        res, D = (min(w["res"], 512), 1) if not is3d else (64, 32)
+        res, D = (min(w["res"], 512), 1) if not is3d else (128, 64)
     st = plume_state(res, D)
     st = O.simulate_step(st, m, w["method"], blob)      # warm-up
     t0 = time.time(); n = 0
     while True:
         st = O.simulate_step(st, m, w["method"], blob); n += 1
-        if time.time() - t0 > budget_s or n >= 40:
+        if time.time() - t0 > budget_s or n >= 400:
             break
     dt = (time.time() - t0) / n
     cells = res * res * D
