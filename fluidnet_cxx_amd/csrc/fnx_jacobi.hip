@@ -351,120 +351,255 @@ __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const u
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3D, two sweeps per pass (temporal blocking along the z-march).  The thread keeps p^0 on rows j0-2..j0+5 and
-// p^1 on rows j0-1..j0+4 for three planes each; at step t it builds p^1(plane t) and, from p^1(t-2..t), the
-// finished p^2(plane t-1) for its 4 rows.  The extra halo rows / the two extra planes per chunk / the wave's two
-// edge columns are recomputed instead of exchanged: HBM traffic per sweep drops from ~20 B/cell to ~10 B/cell.
-// Wave tile: 60 output columns (lanes 2..61; lanes 0,1,62,63 are halo columns, so no edge loads) x 4 rows x Z2C planes.
+// 3D, two sweeps per pass (temporal blocking along the z-march).
+//
+// A wave owns 60 output columns (lanes 2..61; lanes 0,1,62,63 are halo columns) x 4 rows and marches along z.  It
+// keeps p^0 on rows j0-2..j0+5 and p^1 on rows j0-1..j0+4 for three planes each; at step t it builds p^1(plane t)
+// and, from p^1(t-2..t), the finished p^2(plane t-1) of its 4 rows.  The Z2NW waves of a block are stacked in y and
+// hand each other their halo rows of p^0 / div / mask through LDS (one barrier per plane), so only the block's two
+// outer waves fetch halo rows from memory.  The plane rings are rotated by unrolling the march 4x (no register
+// moves), all row/plane addressing is wave-uniform (SALU, saddr loads), blocks are renumbered so that the tiles an
+// XCD works on at one time are spatial neighbours (their halos then hit that XCD's L2).
+//
+// VALU budget per cell-update: the obstacle-free path (wave-uniform test per plane) is 6 adds + the /6 + the 'cont'
+// blend; with obstacles each neighbour costs a v_bfe_i32 + v_bfi_b32 more.
 // ---------------------------------------------------------------------------------------------------
-constexpr int Z2R = 4, Z2C = 16;
+constexpr int Z2R = 4, Z2NW = 4;
+constexpr int Z2C_DEFAULT = 16;
 
-__global__ __launch_bounds__(256, 4) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
-                                                              const float* __restrict__ div,
-                                                              const float* __restrict__ p_in,
-                                                              float* __restrict__ p_out, float* __restrict__ sumsq,
-                                                              int nzc, int kb, int ke) {
+// x / 6.0f, correctly rounded, without the v_rcp/v_div_scale expansion: q = x*zh, r = x - 6q (exact), q + r*zh with
+// zh = RN(1/6), then v_div_fixup for -0/inf/nan.  Checked against x / 6.0f for all 2^32 inputs on gfx950
+// (tools/ubench/div6_test.hip): the only differing inputs give a denormal quotient (v_cmp_class 0x90), which the
+// caller sends through the true division.
+__device__ __forceinline__ float div6_fast(float x) {
+  const float zh = 0x1.555556p-3f;
+  const float q1 = x * zh;
+  const float r = __builtin_fmaf(-6.0f, q1, x);
+  return __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, zh, q1), 6.0f, x);
+}
+
+template <bool FREE>
+__device__ __forceinline__ float relax3(unsigned m, float c, float xl, float xr, float yd, float yu, float zb,
+                                        float zf, float dv, float& num) {
+  const int mi = (int)m;
+  if (!FREE) {                                          // Neumann: an obstacle neighbour is replaced by the centre
+    xl = bfi_blend(__builtin_amdgcn_sbfe(mi, 1, 1), c, xl);
+    xr = bfi_blend(__builtin_amdgcn_sbfe(mi, 2, 1), c, xr);
+    yd = bfi_blend(__builtin_amdgcn_sbfe(mi, 3, 1), c, yd);
+    yu = bfi_blend(__builtin_amdgcn_sbfe(mi, 4, 1), c, yu);
+    zb = bfi_blend(__builtin_amdgcn_sbfe(mi, 5, 1), c, zb);
+    zf = bfi_blend(__builtin_amdgcn_sbfe(mi, 6, 1), c, zf);
+  }
+  float sum = xl + xr;
+  sum = sum + yd;
+  sum = sum + yu;
+  sum = sum + zb;
+  sum = sum + zf;
+  num = sum + dv;
+  return div6_fast(num);
+}
+
+template <int N> struct IC { static constexpr int value = N; };
+
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+
+template <bool RES>
+__global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
+                                                                      const float* __restrict__ div,
+                                                                      const float* __restrict__ p_in,
+                                                                      float* __restrict__ p_out,
+                                                                      float* __restrict__ sumsq, int nxt, int nyt,
+                                                                      int zchunk, int kb, int ke) {
   constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
+  __shared__ float lds_p[2][Z2NW][4][64];
+  __shared__ float lds_d[2][Z2NW][2][64];
+  __shared__ unsigned lds_m[2][Z2NW][2][64];
   const int lane = threadIdx.x;
-  const int x = blockIdx.x * 60 - 2 + lane;
-  const int j0 = (blockIdx.y * 4 + threadIdx.y) * Z2R;
-  int bz = blockIdx.z;
-  const int zc = bz % nzc; const int b = bz / nzc;
-  const int k_lo = kb + zc * Z2C, k_hi = min(k_lo + Z2C, ke);      // output planes of the requested range [kb, ke)
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const bool first_w = w == 0, last_w = w == Z2NW - 1;
+  // One resident set of blocks.  zchunk > 0: every tile is cut into the same plane chunks and a block takes one
+  // (tile, chunk); all blocks of a chunk start together and march the same planes at the same pace, so the halo
+  // columns/rows two neighbouring tiles both touch are fetched from HBM once and hit in L2 the second time.  Workgroup
+  // ids go round-robin over the 8 XCDs; renumbering gives XCD q the tiles [q*G/8, (q+1)*G/8), i.e. whole bands of
+  // x-neighbouring tiles.  zchunk == 0: the (tile, plane) space is cut into gridDim.x equal contiguous ranges instead.
+  const int G = gridDim.x, np = ke - kb;
+  const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int ntiles = nxt * nyt * g.B;
+  int L0, L1;
+  if (zchunk > 0) {
+    const int zc = gid / ntiles, tl = gid - zc * ntiles;
+    L0 = tl * np + zc * zchunk;
+    L1 = min(L0 + zchunk, (tl + 1) * np);
+    if (zc * zchunk >= np) L1 = L0;                      // padding block
+  } else {
+    const long long T = (long long)ntiles * np;
+    auto cut = [&](int q) {                              // range boundary, snapped away from 1-2 plane slivers at tile ends
+      int L = (int)(T * q / G);
+      const int pk = L % np;
+      if (pk < 3) L -= pk; else if (pk > np - 3) L += np - pk;
+      return L;
+    };
+    L0 = cut(gid); L1 = cut(gid + 1);
+  }
+  for (; L0 < L1;) {
+  const int tile = L0 / np, pk = L0 - tile * np;
+  const int seg = min(np - pk, L1 - L0);
+  L0 += seg;
+  const int bx = tile % nxt, l1 = tile / nxt;
+  const int by = l1 % nyt, b = l1 / nyt;
+  const int x = bx * 60 - 2 + lane;
+  const int j0 = (by * Z2NW + w) * Z2R;
+  const int k_lo = kb + pk, k_hi = k_lo + seg;           // output planes [k_lo, k_hi) of this segment
   const bool xin = (x >= 0) & (x < g.W);
   const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
   const size_t base = (size_t)b * g.DHW;
-  int jc0[R0];                                           // clamped row of p^0 row slot rr (j = j0-2+rr)
-#pragma unroll
-  for (int rr = 0; rr < R0; ++rr) { const int j = j0 - 2 + rr; jc0[rr] = j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j); }
-  unsigned rin1 = 0;                                     // bit rr: p^1 row slot rr (j = j0-1+rr) lies inside the grid
-#pragma unroll
-  for (int rr = 0; rr < R1; ++rr) { const int j = j0 - 1 + rr; rin1 |= (unsigned)((j >= 0) & (j < g.H)) << rr; }
-  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
-  auto ldrow = [&](int k, int rr, int xx) { return p_in[base + (size_t)clampk(k) * g.HW + (size_t)jc0[rr] * g.W + xx]; };
-  struct Aux { float dv[R1]; unsigned mk[R1]; };
-  auto load_aux = [&](int k, Aux& a) {                   // everything sweep 1 of plane k needs besides p^0 itself
-    const bool kin = (k >= 0) & (k < g.D);
-    const size_t ok = base + (size_t)clampk(k) * g.HW;
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) {
-      const size_t o = ok + (size_t)jc0[rr + 1] * g.W + xc;
-      a.dv[rr] = div[o];
-      const bool in = kin & xin & (((rin1 >> rr) & 1) != 0);
-      a.mk[rr] = in ? (unsigned)mask[o] : 0u;            // cells outside the grid are never 'cont'
-    }
-  };
-  auto relax = [](unsigned m, float c, float xl, float xr, float yd, float yu, float zb, float zf, float dv) {
-    const float n1 = (m & MZ_L) ? c : xl;
-    const float n2 = (m & MZ_R) ? c : xr;
-    const float n3 = (m & MZ_D) ? c : yd;
-    const float n4 = (m & MZ_U) ? c : yu;
-    const float n5 = (m & MZ_B) ? c : zb;
-    const float n6 = (m & MZ_F) ? c : zf;
-    float sum = n1 + n2;
-    sum = sum + n3;
-    sum = sum + n4;
-    sum = sum + n5;
-    sum = sum + n6;
-    const float v = (sum + dv) / 6.f;
-    return (m & MZ_CONT) ? v : 0.f;
-  };
+  __syncthreads();                                       // the previous segment's last LDS reads are done
 
-  float p0m[R0], p0c[R0], p0p[R0], p0n[R0];              // p^0 planes t-1, t, t+1, (prefetch) t+2
-  float p1m[R1], p1c[R1], p1n[R1];                       // p^1 planes t-2, t-1, t
-  float dprev[Z2R]; unsigned mprev[Z2R];                 // div / mask of plane t-1 on the output rows
+  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
+  // Rows / planes / columns outside the grid are clamped onto the border, whose mask byte is 0 (border cells are
+  // never 'cont'), so no validity selects are needed: a clamped cell relaxes to 0 like the border cell it aliases.
+  unsigned rowb[R0];                                     // wave-uniform cell offset of row slot rr (j = j0-2+rr) in a plane
+#pragma unroll
+  for (int rr = 0; rr < R0; ++rr) {
+    const int j = j0 - 2 + rr;
+    rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
+  }
+  auto planeoff = [&](int k) { return (unsigned)(clampk(k) * g.HW); };
+  // buffer addressing: per-lane voffset (the column) + wave-uniform soffset (plane/row), no 64-bit VALU address math
+  const unsigned xoff = (unsigned)xc * 4u;
+  const unsigned nbytes = (unsigned)g.DHW * 4u;
+  const BufRsrc r_p = make_rsrc(p_in + base, nbytes), r_d = make_rsrc(div + base, nbytes);
+  const BufRsrc r_m = make_rsrc(mask + base, (unsigned)g.DHW), r_o = make_rsrc(p_out + base, nbytes);
+  auto ldf = [&](const BufRsrc& r, unsigned cell) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
+  };
+  auto ldm = [&](unsigned cell) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, (unsigned)xc, cell, 0); };
+
+  float P0[4][R0];                                       // p^0 plane ring: slot (t+d)&3 for planes t-1..t+2
+  float P1[4][R1];                                       // p^1 plane ring (3 live)
+  float AD[4][R1]; unsigned AM[4][R1];                   // div / mask ring, row slot rr <-> j = j0-1+rr
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int rr = 0; rr < R1; ++rr) { P1[q][rr] = 0.f; AD[q][rr] = 0.f; AM[q][rr] = 0u; }
+#pragma unroll
+    for (int rr = 0; rr < R0; ++rr) P0[q][rr] = 0.f;
+  }
   int t = k_lo - 1;
+  // prologue: planes t-1, t, t+1 of p^0 (slots 3, 0, 1) and the aux data of plane t (slot 0), all rows from memory
+  {
+    const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
 #pragma unroll
-  for (int rr = 0; rr < R0; ++rr) { p0m[rr] = ldrow(t - 1, rr, xc); p0c[rr] = ldrow(t, rr, xc); p0p[rr] = ldrow(t + 1, rr, xc); }
+    for (int rr = 0; rr < R0; ++rr) {
+      P0[3][rr] = ldf(r_p, pm + rowb[rr]); P0[0][rr] = ldf(r_p, pc + rowb[rr]); P0[1][rr] = ldf(r_p, pp + rowb[rr]);
+    }
 #pragma unroll
-  for (int rr = 0; rr < R1; ++rr) { p1m[rr] = 0.f; p1c[rr] = 0.f; }
-#pragma unroll
-  for (int r = 0; r < Z2R; ++r) { dprev[r] = 0.f; mprev[r] = 0u; }
-  Aux cur, nxt;
-  load_aux(t, cur);
+    for (int rr = 0; rr < R1; ++rr) { AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]); AM[0][rr] = ldm(pc + rowb[rr + 1]); }
+  }
   float local = 0.f;
   const bool lane_out = (lane >= 2) & (lane <= 61) & xin;
-  for (; t <= k_hi; ++t) {
-    // prefetch: p^0 plane t+2 and the aux data of plane t+1
+  bool prev_free = false;
+
+  // one sweep over N rows: centre rows C[0..N), y-neighbours from the same plane, z-neighbours B / F
+  auto sweep = [&](auto nn, bool free, const unsigned* M, const float* Cm1, const float* B, const float* F,
+                   const float* DV, float* out) __attribute__((always_inline)) {
+    constexpr int N = decltype(nn)::value;
+    float xs[N];
+    bool bad = false;
+    if (free) {
 #pragma unroll
-    for (int rr = 0; rr < R0; ++rr) p0n[rr] = ldrow(t + 2, rr, xc);
-    load_aux(t + 1, nxt);
-    // sweep 1 on plane t, rows j0-1 .. j0+4
+      for (int r = 0; r < N; ++r) {
+        const float c = Cm1[r + 1];
+        out[r] = relax3<true>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        bad |= __builtin_amdgcn_classf(out[r], 0x90);
+      }
+    } else {
 #pragma unroll
-    for (int rr = 0; rr < R1; ++rr) {
-      const float c = p0c[rr + 1];
-      const float xl = dpp_from_left(c), xr = dpp_from_right(c);     // lanes 0/63 get garbage: they are halo columns
-      p1n[rr] = relax(cur.mk[rr], c, xl, xr, p0c[rr], p0c[rr + 2], p0m[rr + 1], p0p[rr + 1], cur.dv[rr]);
+      for (int r = 0; r < N; ++r) {
+        const float c = Cm1[r + 1];
+        out[r] = relax3<false>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        bad |= __builtin_amdgcn_classf(out[r], 0x90);
+      }
     }
-    // sweep 2 on plane t-1, rows j0 .. j0+3 (needs p^1 of planes t-2, t-1, t)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: true division
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+        if (__builtin_amdgcn_classf(out[r], 0x90)) out[r] = xs[r] / 6.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)                            // cont ? v : 0
+      out[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[r]) & __builtin_amdgcn_sbfe((int)M[r], 0, 1));
+  };
+
+  auto step = [&](auto ph, int t) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph)::value;
+    constexpr int SM = (PH + 3) & 3, SC = PH, SP = (PH + 1) & 3, SN = (PH + 2) & 3, BUF = PH & 1;
+    // ---- issue the loads of p^0 plane t+2 (own rows; the block's outer waves also their halo rows) and of the
+    //      aux data of plane t+1
+    const unsigned p2 = planeoff(t + 2), p1 = planeoff(t + 1);
+#pragma unroll
+    for (int r = 0; r < Z2R; ++r) P0[SN][2 + r] = ldf(r_p, p2 + rowb[2 + r]);
+#pragma unroll
+    for (int r = 0; r < Z2R; ++r) { AD[SP][1 + r] = ldf(r_d, p1 + rowb[2 + r]); AM[SP][1 + r] = ldm(p1 + rowb[2 + r]); }
+    if (first_w) {
+      P0[SN][0] = ldf(r_p, p2 + rowb[0]); P0[SN][1] = ldf(r_p, p2 + rowb[1]);
+      AD[SP][0] = ldf(r_d, p1 + rowb[1]); AM[SP][0] = ldm(p1 + rowb[1]);
+    }
+    if (last_w) {
+      P0[SN][6] = ldf(r_p, p2 + rowb[6]); P0[SN][7] = ldf(r_p, p2 + rowb[7]);
+      AD[SP][5] = ldf(r_d, p1 + rowb[6]); AM[SP][5] = ldm(p1 + rowb[6]);
+    }
+    // ---- sweep 1 on plane t, rows j0-1 .. j0+4
+    unsigned ob = AM[SC][0];
+#pragma unroll
+    for (int rr = 1; rr < R1; ++rr) ob |= AM[SC][rr];
+    const bool free1 = __builtin_amdgcn_ballot_w64((ob & 0x7eu) != 0) == 0;     // no cell of these rows has an obstacle neighbour
+    sweep(IC<R1>{}, free1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
+    // ---- sweep 2 on plane t-1, rows j0 .. j0+3 (p^1 of planes t-2, t-1, t = slots SN, SM, SC)
     if (t - 1 >= k_lo) {
-      const size_t ok = base + (size_t)(t - 1) * g.HW;
+      float v[Z2R];
+      sweep(IC<Z2R>{}, prev_free, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
+      const unsigned ok = (unsigned)((t - 1) * g.HW + j0 * g.W) * 4u;
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
-        const float c = p1c[r + 1];
-        const float xl = dpp_from_left(c), xr = dpp_from_right(c);
-        const float v = relax(mprev[r], c, xl, xr, p1c[r], p1c[r + 2], p1m[r + 1], p1n[r + 1], dprev[r]);
         if (lane_out && j0 + r < g.H) {
-          p_out[ok + (size_t)(j0 + r) * g.W + x] = v;
-          const float d = v - c;
-          local += d * d;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
+          if (RES) { const float d = v[r] - P1[SM][r + 1]; local += d * d; }
         }
       }
     }
-    // rotate the pipelines
+    prev_free = free1;
+    // ---- hand the halo rows of p^0(t+2) and aux(t+1) to the y-neighbour waves
 #pragma unroll
-    for (int rr = 0; rr < R0; ++rr) { p0m[rr] = p0c[rr]; p0c[rr] = p0p[rr]; p0p[rr] = p0n[rr]; }
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { p1m[rr] = p1c[rr]; p1c[rr] = p1n[rr]; }
-#pragma unroll
-    for (int r = 0; r < Z2R; ++r) { dprev[r] = cur.dv[r + 1]; mprev[r] = cur.mk[r + 1]; }
-    cur = nxt;
+    for (int r = 0; r < Z2R; ++r) lds_p[BUF][w][r][lane] = P0[SN][2 + r];
+    lds_d[BUF][w][0][lane] = AD[SP][1]; lds_d[BUF][w][1][lane] = AD[SP][Z2R];
+    lds_m[BUF][w][0][lane] = AM[SP][1]; lds_m[BUF][w][1][lane] = AM[SP][Z2R];
+    __syncthreads();
+    if (!first_w) {
+      P0[SN][0] = lds_p[BUF][w - 1][2][lane]; P0[SN][1] = lds_p[BUF][w - 1][3][lane];
+      AD[SP][0] = lds_d[BUF][w - 1][1][lane]; AM[SP][0] = lds_m[BUF][w - 1][1][lane];
+    }
+    if (!last_w) {
+      P0[SN][6] = lds_p[BUF][w + 1][0][lane]; P0[SN][7] = lds_p[BUF][w + 1][1][lane];
+      AD[SP][5] = lds_d[BUF][w + 1][0][lane]; AM[SP][5] = lds_m[BUF][w + 1][0][lane];
+    }
+  };
+
+  while (true) {
+    step(IC<0>{}, t); if (++t > k_hi) break;
+    step(IC<1>{}, t); if (++t > k_hi) break;
+    step(IC<2>{}, t); if (++t > k_hi) break;
+    step(IC<3>{}, t); if (++t > k_hi) break;
   }
-  if (sumsq) {
+  if (RES) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if (lane == 0) atomicAdd(&sumsq[b], local);
   }
+  }  // segments
 }
 
 // Generic single sweep (3D, and any 2D shape): one thread per cell.
@@ -624,9 +759,37 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                         float* sumsq, hipStream_t s, int kb, int ke) {
   if (ke <= kb) { kb = 0; ke = g.D; }
-  const int nzc = (ke - kb + Z2C - 1) / Z2C;
-  const dim3 grid((g.W + 59) / 60, (g.H + 4 * Z2R - 1) / (4 * Z2R), g.B * nzc), block(64, 4);
-  jacobi3d_march2_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nzc, kb, ke);
+  static const int slots = [] {                          // resident 256-thread blocks: 4 per CU (128 VGPRs, 16 KB LDS)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* e = getenv("FNX_JACOBI_BLOCKS");
+    return e ? atoi(e) : 4 * cus;
+  }();
+  static const int zenv = [] { const char* e = getenv("FNX_JACOBI_ZCHUNK"); return e ? atoi(e) : -1; }();
+  const int nxt = (g.W + 59) / 60, nyt = (g.H + Z2NW * Z2R - 1) / (Z2NW * Z2R);
+  const int np = ke - kb, ntiles = nxt * nyt * g.B;
+  int zchunk = zenv;
+  if (zchunk < 0) {
+    // as many equal plane chunks per tile as fit one resident set (a chunk pays 2 lead-in planes, so >= 8 planes)
+    int nzc = slots / ntiles;
+    if (nzc < 1) nzc = 1;
+    zchunk = (np + nzc - 1) / nzc;
+    if (zchunk < 8) zchunk = 8;
+    if (ntiles > slots) zchunk = 0;                      // more tiles than slots: even split of the (tile, plane) space
+  }
+  long long G;
+  if (zchunk > 0) {
+    G = (long long)ntiles * ((np + zchunk - 1) / zchunk);
+    G = ((G + 7) / 8) * 8;
+  } else {
+    G = (long long)ntiles * np / 8;
+    if (G > slots) G = slots;
+    G = (G / 8) * 8;
+    if (G < 8) G = 8;
+  }
+  const dim3 grid((unsigned)G), block(64, Z2NW);
+  if (sumsq) jacobi3d_march2_kernel<true><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke);
+  else jacobi3d_march2_kernel<false><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke);
 }
 
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
