@@ -176,8 +176,11 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev):
         net = FluidNet(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
         ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
 
+        seen = []                          # flags never change here: after the first step the solver keeps its mask
+
         def eager_step():
-            simulate(m, bd, net, w["method"], workspace=ws)
+            simulate(m, bd, net, w["method"], workspace=ws, static_flags=bool(seen))
+            seen.append(1)
         cells = w["res"] * w["res"] * w["D"]
     step = eager_step
 

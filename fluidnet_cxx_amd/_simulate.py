@@ -6,6 +6,9 @@ batch_dict, same mconf keys).  Two execution modes:
               Python between kernels);
   fused=False: operator by operator through the `fluid.*` surface in the reference's order (what the
               parity tests use to compare stage by stage).
+`workspace` (a uint8 tensor of ext.step_workspace_bytes) avoids a per-step allocation; with it, `static_flags=True`
+promises that batch_dict['flags'] has not changed since the previous call on that workspace (3D Jacobi then reuses
+its obstacle mask).
 """
 import torch
 
@@ -22,7 +25,7 @@ def _gravity(mconf, scale):
     return [float(gv["x"]), float(gv["y"]), float(gv["z"])], float(scale)
 
 
-def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None):
+def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None, static_flags=False):
     assert sim_method in ("convnet", "jacobi"), "Simulation method not supported. Choose either convnet or jacobi."
     dt = float(mconf["dt"])
     maccormackStrength = mconf["maccormackStrength"]
@@ -46,7 +49,7 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
                            float(maccormackStrength), bool(sampleOutsideFluid), float(buoyancyScale), gvec,
                            float(mconf.get("operatingDensity", 0.0)), float(mconf.get("pTol", 0.0)),
                            int(mconf.get("jacobiIter", 1)), sim_method,
-                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace)
+                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, bool(static_flags))
         if not has_density:
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return

@@ -255,7 +255,8 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
                     c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> net, double dt,
                     double maccormack_strength, bool sample_outside_fluid, double buoyancy_scale,
                     std::vector<double> gravity_vec, double operating_density, double p_tol, int jacobi_iter,
-                    const std::string method, double normalize_threshold, c10::optional<Tensor> workspace) {
+                    const std::string method, double normalize_threshold, c10::optional<Tensor> workspace,
+                    bool static_flags) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
@@ -281,8 +282,11 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   c10::hip::HIPGuard guard(flags.get_device());
   const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_STEP);
   Tensor ws;
-  if (workspace.has_value() && workspace->defined() && (size_t)workspace->numel() * workspace->element_size() >= bytes) ws = *workspace;
+  const bool given = workspace.has_value() && workspace->defined() && (size_t)workspace->numel() * workspace->element_size() >= bytes;
+  if (given) ws = *workspace;
   else ws = at::empty({(int64_t)bytes}, flags.options().dtype(at::kByte));
+  // the mask lives in the workspace: only a caller-owned workspace carries it from one step to the next
+  prm.static_flags = (static_flags && given) ? 1 : 0;
   check_status(fnx_simulate_step(&g, &prm, &st, ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), cur_stream(U)));
 }
 
@@ -391,7 +395,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("scalenet_pack", &scalenet_pack);
   m.def("multiscale_forward", &multiscale_forward);
   m.def("fluidnet_forward", &fluidnet_forward);
-  m.def("simulate_step_", &simulate_step_);
+  m.def("simulate_step_", &simulate_step_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),
+        py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("net"), py::arg("dt"),
+        py::arg("maccormack_strength"), py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"),
+        py::arg("operating_density"), py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("method"),
+        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = false);
   m.def("step_workspace_bytes", &step_workspace_bytes);
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
         py::arg("workspace") = py::none(), py::arg("reuse_mask") = false);

@@ -406,7 +406,8 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
 
-template <bool RES>
+// ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
+template <bool RES, bool ZERO>
 __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
@@ -476,6 +477,7 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
   auto ldf = [&](const BufRsrc& r, unsigned cell) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
   };
+  auto ldp = [&](unsigned cell) { return ZERO ? 0.f : ldf(r_p, cell); };
   auto ldm = [&](unsigned cell) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, (unsigned)xc, cell, 0); };
 
   float P0[4][R0];                                       // p^0 plane ring: slot (t+d)&3 for planes t-1..t+2
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
     const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
 #pragma unroll
     for (int rr = 0; rr < R0; ++rr) {
-      P0[3][rr] = ldf(r_p, pm + rowb[rr]); P0[0][rr] = ldf(r_p, pc + rowb[rr]); P0[1][rr] = ldf(r_p, pp + rowb[rr]);
+      P0[3][rr] = ldp(pm + rowb[rr]); P0[0][rr] = ldp(pc + rowb[rr]); P0[1][rr] = ldp(pp + rowb[rr]);
     }
 #pragma unroll
     for (int rr = 0; rr < R1; ++rr) { AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]); AM[0][rr] = ldm(pc + rowb[rr + 1]); }
@@ -541,15 +543,15 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
     //      aux data of plane t+1
     const unsigned p2 = planeoff(t + 2), p1 = planeoff(t + 1);
 #pragma unroll
-    for (int r = 0; r < Z2R; ++r) P0[SN][2 + r] = ldf(r_p, p2 + rowb[2 + r]);
+    for (int r = 0; r < Z2R; ++r) P0[SN][2 + r] = ldp(p2 + rowb[2 + r]);
 #pragma unroll
     for (int r = 0; r < Z2R; ++r) { AD[SP][1 + r] = ldf(r_d, p1 + rowb[2 + r]); AM[SP][1 + r] = ldm(p1 + rowb[2 + r]); }
     if (first_w) {
-      P0[SN][0] = ldf(r_p, p2 + rowb[0]); P0[SN][1] = ldf(r_p, p2 + rowb[1]);
+      P0[SN][0] = ldp(p2 + rowb[0]); P0[SN][1] = ldp(p2 + rowb[1]);
       AD[SP][0] = ldf(r_d, p1 + rowb[1]); AM[SP][0] = ldm(p1 + rowb[1]);
     }
     if (last_w) {
-      P0[SN][6] = ldf(r_p, p2 + rowb[6]); P0[SN][7] = ldf(r_p, p2 + rowb[7]);
+      P0[SN][6] = ldp(p2 + rowb[6]); P0[SN][7] = ldp(p2 + rowb[7]);
       AD[SP][5] = ldf(r_d, p1 + rowb[6]); AM[SP][5] = ldm(p1 + rowb[6]);
     }
     // ---- sweep 1 on plane t, rows j0-1 .. j0+4
@@ -573,17 +575,19 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
     }
     prev_free = free1;
     // ---- hand the halo rows of p^0(t+2) and aux(t+1) to the y-neighbour waves
+    if (!ZERO) {
 #pragma unroll
-    for (int r = 0; r < Z2R; ++r) lds_p[BUF][w][r][lane] = P0[SN][2 + r];
+      for (int r = 0; r < Z2R; ++r) lds_p[BUF][w][r][lane] = P0[SN][2 + r];
+    }
     lds_d[BUF][w][0][lane] = AD[SP][1]; lds_d[BUF][w][1][lane] = AD[SP][Z2R];
     lds_m[BUF][w][0][lane] = AM[SP][1]; lds_m[BUF][w][1][lane] = AM[SP][Z2R];
     __syncthreads();
     if (!first_w) {
-      P0[SN][0] = lds_p[BUF][w - 1][2][lane]; P0[SN][1] = lds_p[BUF][w - 1][3][lane];
+      if (!ZERO) { P0[SN][0] = lds_p[BUF][w - 1][2][lane]; P0[SN][1] = lds_p[BUF][w - 1][3][lane]; }
       AD[SP][0] = lds_d[BUF][w - 1][1][lane]; AM[SP][0] = lds_m[BUF][w - 1][1][lane];
     }
     if (!last_w) {
-      P0[SN][6] = lds_p[BUF][w + 1][0][lane]; P0[SN][7] = lds_p[BUF][w + 1][1][lane];
+      if (!ZERO) { P0[SN][6] = lds_p[BUF][w + 1][0][lane]; P0[SN][7] = lds_p[BUF][w + 1][1][lane]; }
       AD[SP][5] = lds_d[BUF][w + 1][0][lane]; AM[SP][5] = lds_m[BUF][w + 1][0][lane];
     }
   };
@@ -757,7 +761,7 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 
 // two sweeps in one pass: p_in = p^n, p_out = p^{n+2}; sumsq receives ||p^{n+2} - p^{n+1}||^2
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb, int ke) {
+                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero) {
   if (ke <= kb) { kb = 0; ke = g.D; }
   static const int slots = [] {                          // resident 256-thread blocks: 4 per CU (128 VGPRs, 16 KB LDS)
     int dev = 0, cus = 256;
@@ -788,8 +792,10 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
-  if (sumsq) jacobi3d_march2_kernel<true><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke);
-  else jacobi3d_march2_kernel<false><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke);
+#define J3D(R, Z) jacobi3d_march2_kernel<R, Z><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke)
+  if (from_zero) { if (sumsq) J3D(true, true); else J3D(false, true); }
+  else { if (sumsq) J3D(true, false); else J3D(false, false); }
+#undef J3D
 }
 
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,

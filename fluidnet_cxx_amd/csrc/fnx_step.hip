@@ -71,9 +71,7 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
   const float u1 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j, i, by, sy, rho_star);
   float u2 = 0.f;
   if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k, j, i, by, sz, rho_star);
-  P.U[((size_t)b * NC + 0) * g.DHW + o] = u0;
-  P.U[((size_t)b * NC + 1) * g.DHW + o] = u1;
-  if (IS3D) P.U[((size_t)b * NC + 2) * g.DHW + o] = u2;
+  float rnew = 0.f;
   if (P.rho_adv) {
     float r = P.rho_adv[os];
     if (P.rhoBC) {
@@ -81,10 +79,10 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
       float t = r * m; r = t + c;       // simulate.py:96
       t = r * m; r = t + c;             // simulate.py:133
     }
-    P.rho[os] = r;
+    rnew = r;
   }
+  float d = 0.f;
   if (P.div) {
-    float d = 0.f;
     if (!is_border<IS3D>(g, i, j, k)) {
       const float u0p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i + 1, by, sx, rho_star);
       const float u1p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j + 1, i, by, sy, rho_star);
@@ -95,8 +93,14 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
       }
     }
     if (P.flags[os] == FNX_OBST) d = 0.f;
-    P.div[os] = d;
   }
+  // all loads above, all stores below: identical loads of the six staged_u evaluations (flags, rho, masks of the
+  // shared cells) are then merged by the compiler instead of being re-issued after a possibly aliasing store
+  P.U[((size_t)b * NC + 0) * g.DHW + o] = u0;
+  P.U[((size_t)b * NC + 1) * g.DHW + o] = u1;
+  if (IS3D) P.U[((size_t)b * NC + 2) * g.DHW + o] = u2;
+  if (P.rho_adv) P.rho[os] = rnew;
+  if (P.div) P.div[os] = d;
 }
 
 // velocityUpdate + setWallBcs + setConstVals (simulate.py:154-168), in place on U (and rho for the BC re-imposition)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 1
+#define FNX_ABI_VERSION 2
 
 enum {
   FNX_OK = 0,
@@ -143,6 +143,9 @@ typedef struct FnxStepParams {
   int   jacobi_iter;          /* mconf['jacobiIter'] */
   int   method;               /* 0 = 'jacobi', 1 = 'convnet' */
   float normalize_threshold;  /* mconf['normalizeInputThreshold'] (convnet) */
+  int   static_flags;         /* != 0: `flags` is unchanged since the previous fnx_simulate_step on this workspace,
+                                 so the 3D Jacobi solver reuses the obstacle mask it left there (no reference key;
+                                 every reference simulation keeps its flags fixed) */
 } FnxStepParams;
 
 typedef struct FnxState {

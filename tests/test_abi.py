@@ -27,7 +27,8 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fluidnet_hip.h but not exported"
     lib.fnx_abi_version.restype = ctypes.c_int
-    assert lib.fnx_abi_version() == 1
+    m = re.search(r"#define FNX_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "fluidnet_hip.h")).read())
+    assert lib.fnx_abi_version() == int(m.group(1))
 
 
 def test_no_oracle_in_product(built):

@@ -248,6 +248,26 @@ def test_sim64_convnet_vs_reference(dev, golden):
                     assert_close(N(bd[k]), s[f"convnet_{k}_{it}"], 2e-5, f"convnet {k} after {it} (fused={fused})")
 
 
+def test_static_flags_reuses_mask_3d(dev, oracle, ext):
+    """3D fused step with a caller-owned workspace: static_flags=True (mask kept from the previous step) gives the
+    same bits as rebuilding it, and both match the oracle."""
+    from fluidnet_cxx_amd import simulate
+    cfg = dict(PLUME_CFG, jacobiIter=7)
+    runs = []
+    for static in (False, True):
+        bd = to_dev(plume_state(24, D=12), dev)
+        ws = torch.empty(ext.step_workspace_bytes(1, 12, 24, 24, True), dtype=torch.uint8, device=dev)
+        for it in range(3):
+            simulate(cfg, bd, None, "jacobi", workspace=ws, static_flags=static and it > 0)
+        runs.append({k: N(bd[k]) for k in ("U", "density", "p")})
+    st = plume_state(24, D=12)
+    for it in range(3):
+        st = oracle.simulate_step(st, cfg, "jacobi")
+    for k in ("U", "density", "p"):
+        assert_bitexact(runs[0][k], st[k], f"{k} (mask rebuilt)")
+        assert_bitexact(runs[1][k], st[k], f"{k} (mask reused)")
+
+
 def test_sim64_optional_stages_vs_reference(dev, golden):
     """viscosity + correctScalar + gravity + periodic patches through simulate(): bit-exact against the reference."""
     from fluidnet_cxx_amd import simulate
