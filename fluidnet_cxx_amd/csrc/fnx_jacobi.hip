@@ -407,7 +407,7 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 }
 
 // ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
-template <bool RES, bool ZERO>
+template <bool RES, bool ZERO, bool SPLIT>
 __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
   const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int ntiles = nxt * nyt * g.B;
   int L0, L1;
-  if (zchunk > 0) {
+  if (!SPLIT) {
     const int zc = gid / ntiles, tl = gid - zc * ntiles;
     L0 = tl * np + zc * zchunk;
     L1 = min(L0 + zchunk, (tl + 1) * np);
@@ -445,10 +445,10 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
     };
     L0 = cut(gid); L1 = cut(gid + 1);
   }
-  for (; L0 < L1;) {
+  for (; L0 < L1;) {                                     // one pass unless SPLIT
   const int tile = L0 / np, pk = L0 - tile * np;
   const int seg = min(np - pk, L1 - L0);
-  L0 += seg;
+  L0 = SPLIT ? L0 + seg : L1;
   const int bx = tile % nxt, l1 = tile / nxt;
   const int by = l1 % nyt, b = l1 / nyt;
   const int x = bx * 60 - 2 + lane;
@@ -792,9 +792,11 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
-#define J3D(R, Z) jacobi3d_march2_kernel<R, Z><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke)
-  if (from_zero) { if (sumsq) J3D(true, true); else J3D(false, true); }
-  else { if (sumsq) J3D(true, false); else J3D(false, false); }
+#define J3D(R, Z, S) jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke)
+#define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \
+                       else { if (sumsq) J3D(true, false, S); else J3D(false, false, S); } } while (0)
+  if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true);
+#undef J3D_RZ
 #undef J3D
 }
 
