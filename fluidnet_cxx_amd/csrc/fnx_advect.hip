@@ -68,6 +68,99 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Clamp bounds of MacCormackClampFluidNet (:154-263) as a field: for every cell c the min / max of src over the
+// 3x3(x3) box around c, taken over the cells that are inside the (local) domain and -- unless sample_outside_fluid --
+// fluid.  The backward kernel then fetches ONE 8-byte pair at the traced cell instead of walking 27 cells x 2 fields
+// per thread.  min/max are exact, commutative and NaN-ignoring (v_min_f32 / v_max_f32 order -0 < +0), so the
+// separable evaluation gives the same bits as the reference's 27-step fold; "no cell qualified" (the reference then
+// keeps the forward value) is encoded as mn = NaN.
+// A wave covers 62 columns (lanes 0 / 63 are halo columns) x BOX_R rows and marches along z: per plane it reduces
+// rows j0-1..j0+BOX_R in x (DPP) and y, and keeps the reduced planes k-1, k, k+1 in registers.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BOX_R = 8, BOX_ZC = 16;
+
+__device__ __forceinline__ float dppf_left(float v) {     // lane-1 (0.0 into lane 0: a halo lane, never stored)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dppf_right(float v) {    // lane+1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ unsigned dppu_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned dppu_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+
+template <bool IS3D, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(256) void box_minmax_kernel(GridDims g, const float* __restrict__ src,
+                                                         const float* __restrict__ flags, float2* __restrict__ box,
+                                                         int nzc) {
+  const int lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int x = blockIdx.x * 62 - 1 + lane;
+  const int j0 = (blockIdx.y * 4 + w) * BOX_R;
+  const int bz = blockIdx.z;
+  const int zc = bz % nzc, b = bz / nzc;
+  const int k_lo = zc * BOX_ZC, k_hi = min(k_lo + BOX_ZC, g.D);
+  if (j0 >= g.H) return;
+  const bool xin = (x >= 0) & (x < g.W);
+  const int xc = clampi(x, 0, g.W - 1);
+  const size_t base = (size_t)b * g.DHW;
+  // all loads of a plane are unconditional (clamped rows / planes) so they issue back to back; validity only gates `ok`
+  auto plane = [&](int k, float* omn, float* omx, unsigned* oan) {
+    float sv[BOX_R + 2], fv[BOX_R + 2];
+    const bool kin = (k >= 0) & (k < g.D);                           // the reference's box is clipped to the grid
+    const size_t ok_ = base + (size_t)clampi(k, 0, g.D - 1) * g.HW + xc;
+#pragma unroll
+    for (int rr = 0; rr < BOX_R + 2; ++rr) {
+      const size_t o = ok_ + (size_t)clampi(j0 - 1 + rr, 0, g.H - 1) * g.W;
+      sv[rr] = src[o];
+      fv[rr] = SAMPLE_OUTSIDE ? FNX_FLUID : flags[o];
+    }
+    float rmn[BOX_R + 2], rmx[BOX_R + 2]; unsigned ran[BOX_R + 2];
+#pragma unroll
+    for (int rr = 0; rr < BOX_R + 2; ++rr) {
+      const int j = j0 - 1 + rr;
+      const bool ok = xin & kin & (j >= 0) & (j < g.H) & (fv[rr] == FNX_FLUID);
+      const float vmn = ok ? sv[rr] : INFINITY, vmx = ok ? sv[rr] : -INFINITY;
+      const unsigned va = ok ? 1u : 0u;
+      rmn[rr] = fminf(fminf(dppf_left(vmn), vmn), dppf_right(vmn));
+      rmx[rr] = fmaxf(fmaxf(dppf_left(vmx), vmx), dppf_right(vmx));
+      ran[rr] = dppu_left(va) | va | dppu_right(va);
+    }
+#pragma unroll
+    for (int r = 0; r < BOX_R; ++r) {
+      omn[r] = fminf(fminf(rmn[r], rmn[r + 1]), rmn[r + 2]);
+      omx[r] = fmaxf(fmaxf(rmx[r], rmx[r + 1]), rmx[r + 2]);
+      oan[r] = ran[r] | ran[r + 1] | ran[r + 2];
+    }
+  };
+  const bool lane_out = (lane >= 1) & (lane <= 62) & xin;
+  auto store = [&](int k, int r, float lo, float hi, bool any) {
+    if (lane_out && j0 + r < g.H)
+      box[base + (size_t)k * g.HW + (size_t)(j0 + r) * g.W + x] = make_float2(any ? lo : __builtin_nanf(""), hi);
+  };
+  float mn[3][BOX_R], mx[3][BOX_R]; unsigned an[3][BOX_R];           // xy-reduced planes k-1, k, k+1
+  if (!IS3D) {
+    plane(0, mn[0], mx[0], an[0]);
+#pragma unroll
+    for (int r = 0; r < BOX_R; ++r) store(0, r, mn[0][r], mx[0][r], an[0][r] != 0);
+    return;
+  }
+  plane(k_lo - 1, mn[0], mx[0], an[0]);
+  plane(k_lo, mn[1], mx[1], an[1]);
+  for (int k = k_lo; k < k_hi; ++k) {
+    plane(k + 1, mn[2], mx[2], an[2]);
+#pragma unroll
+    for (int r = 0; r < BOX_R; ++r)
+      store(k, r, fminf(fminf(mn[0][r], mn[1][r]), mn[2][r]), fmaxf(fmaxf(mx[0][r], mx[1][r]), mx[2][r]),
+            (an[0][r] | an[1][r] | an[2][r]) != 0);
+#pragma unroll
+    for (int r = 0; r < BOX_R; ++r) {
+      mn[0][r] = mn[1][r]; mx[0][r] = mx[1][r]; an[0][r] = an[1][r];
+      mn[1][r] = mn[2][r]; mx[1][r] = mx[2][r]; an[1][r] = an[2][r];
+    }
+  }
+}
+
 // Backward pass on fwd + MacCormackCorrect (:135-148) + MacCormackClampFluidNet (:154-263)
 template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
 __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g, float dt, float half_s,
@@ -76,6 +169,7 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
                                                                      const int* __restrict__ cell_in,
                                                                      const float* __restrict__ U,
                                                                      const float* __restrict__ flags,
+                                                                     const float2* __restrict__ box,
                                                                      float* __restrict__ dst) {
   const CellId c = cell_id<IS3D>(g);
   if (!c.valid) return;
@@ -110,30 +204,40 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
     const int k0 = kb - 1;
     const int r = cell - kb * g.HW;
     const int j0 = r / g.W, i0 = r - j0 * g.W;
-    // 3x3(x3) neighbourhood of the traced cell: every load is unconditional (clamped address) and the
-    // in-domain / is-fluid tests only gate the min/max, so the 18-54 loads are independent and issue back to back.
-    float mn = INFINITY, mx = -INFINITY;
-    bool any = false;
+    float mn, mx;
+    bool any;
+    if (box != nullptr && k0 >= 0 && k0 < g.D) {
+      // the traced cell lies in this slab: its clamp bounds were reduced once by box_minmax_kernel (3D only)
+      const float2 bb = box[(size_t)c.b * g.DHW + (size_t)k0 * g.HW + r];
+      mn = bb.x; mx = bb.y;
+      any = !(mn != mn);
+    } else {
+      // 2D (9 cells: cheaper than a separate pass), or traced into a plane this slab does not hold: walk the clipped
+      // box directly, as the reference does
+      mn = INFINITY; mx = -INFINITY; any = false;
+      // 3x3(x3) neighbourhood of the traced cell: every load is unconditional (clamped address) and the
+      // in-domain / is-fluid tests only gate the min/max, so the 18-54 loads are independent and issue back to back.
 #pragma unroll
-    for (int dk = (IS3D ? -1 : 0); dk <= (IS3D ? 1 : 0); ++dk) {
-      const int kk = k0 + dk;
-      const bool vk = (kk + g.zoff >= 0) & (kk + g.zoff < g.Dglob) & (kk >= 0) & (kk < g.D);   // in the domain and in this slab
-      const int kc = clampi(kk, 0, g.D - 1);
+      for (int dk = (IS3D ? -1 : 0); dk <= (IS3D ? 1 : 0); ++dk) {
+        const int kk = k0 + dk;
+        const bool vk = (kk + g.zoff >= 0) & (kk + g.zoff < g.Dglob) & (kk >= 0) & (kk < g.D);   // in the domain and in this slab
+        const int kc = clampi(kk, 0, g.D - 1);
 #pragma unroll
-      for (int dj = -1; dj <= 1; ++dj) {
-        const int jj = j0 + dj;
-        const bool vj = vk & (jj >= 0) & (jj < g.H);
-        const int jc = clampi(jj, 0, g.H - 1);
+        for (int dj = -1; dj <= 1; ++dj) {
+          const int jj = j0 + dj;
+          const bool vj = vk & (jj >= 0) & (jj < g.H);
+          const int jc = clampi(jj, 0, g.H - 1);
 #pragma unroll
-        for (int di = -1; di <= 1; ++di) {
-          const int ii = i0 + di;
-          const bool vi = vj & (ii >= 0) & (ii < g.W);
-          const size_t q = (size_t)kc * g.HW + jc * g.W + clampi(ii, 0, g.W - 1);
-          const float s = fs.p[q];
-          const bool ok = vi & (SAMPLE_OUTSIDE || ff.p[q] == FNX_FLUID);
-          mn = ok ? fminf(mn, s) : mn;
-          mx = ok ? fmaxf(mx, s) : mx;
-          any = any | ok;
+          for (int di = -1; di <= 1; ++di) {
+            const int ii = i0 + di;
+            const bool vi = vj & (ii >= 0) & (ii < g.W);
+            const size_t q = (size_t)kc * g.HW + jc * g.W + clampi(ii, 0, g.W - 1);
+            const float s = fs.p[q];
+            const bool ok = vi & (SAMPLE_OUTSIDE || ff.p[q] == FNX_FLUID);
+            mn = ok ? fminf(mn, s) : mn;
+            mx = ok ? fmaxf(mx, s) : mx;
+            any = any | ok;
+          }
         }
       }
     }
@@ -296,10 +400,23 @@ void launch_sl_scalar(const GridDims& g, bool is3d, bool quirks, bool sample_out
 
 void launch_sl_scalar_bwd_clamp(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, float half_s,
                                 const float* src, const float* fwd, const int* cell_in, const float* U,
-                                const float* flags, float* dst, hipStream_t s) {
+                                const float* flags, const float* box, float* dst, hipStream_t s) {
   const dim3 grid = cell_grid(g), block(BX, BY);
   DISPATCH3(is3d, quirks, sample_outside, sl_scalar_bwd_clamp_kernel,
-            <<<grid, block, 0, s>>>(g, dt, half_s, src, fwd, cell_in, U, flags, dst));
+            <<<grid, block, 0, s>>>(g, dt, half_s, src, fwd, cell_in, U, flags, (const float2*)box, dst));
+}
+
+void launch_box_minmax(const GridDims& g, bool sample_outside, const float* src, const float* flags, float* box,
+                       hipStream_t s) {
+  const int nzc = (g.D + BOX_ZC - 1) / BOX_ZC;
+  const dim3 grid((g.W + 61) / 62, (g.H + 4 * BOX_R - 1) / (4 * BOX_R), g.B * nzc), block(64, 4);
+  if (g.D > 1) {
+    if (sample_outside) box_minmax_kernel<true, true><<<grid, block, 0, s>>>(g, src, flags, (float2*)box, nzc);
+    else box_minmax_kernel<true, false><<<grid, block, 0, s>>>(g, src, flags, (float2*)box, nzc);
+  } else {
+    if (sample_outside) box_minmax_kernel<false, true><<<grid, block, 0, s>>>(g, src, flags, (float2*)box, nzc);
+    else box_minmax_kernel<false, false><<<grid, block, 0, s>>>(g, src, flags, (float2*)box, nzc);
+  }
 }
 
 void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const float* src, const float* U,

@@ -50,7 +50,7 @@ struct Carver {
   bool ok() const { return base != nullptr && off <= cap; }
 };
 
-size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4); }
+size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4) + (g->is3D ? al(ncell(g) * 8) : 0); }   // fwd, traced cell, 3D clamp bounds
 size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
 size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + (g->is3D ? al(ncell(g)) : 0); }
 size_t ws_step(const FnxGrid* g) {
@@ -162,11 +162,14 @@ int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float*
     Carver c(ws, ws_bytes);
     float* fwd = (float*)c.take(ncell(g) * 4);
     int* cell = (int*)c.take(ncell(g) * 4);
+    float* box = g->is3D ? (float*)c.take(ncell(g) * 8) : nullptr;
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_scalar: workspace too small (%zu < %zu)", ws_bytes, c.off);
     { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_scalar(d, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s); }
+    if (g->is3D) { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_box_minmax(d, sample_outside != 0, src, flags, box, s); }
+    else box = nullptr;                                  // 2D: the 3x3 clamp box is walked in the backward kernel
     fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_scalar_bwd_clamp(d, g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, src, fwd, cell, U,
-                                    flags, dst, s);
+                                    flags, box, dst, s);
   }
   HIP_OK(hipGetLastError());
   return FNX_OK;

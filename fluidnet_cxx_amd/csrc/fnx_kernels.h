@@ -19,7 +19,9 @@ void launch_sl_scalar(const GridDims& g, bool is3d, bool quirks, bool sample_out
                       const float* U, const float* flags, float* dst, int* cell_out, hipStream_t s);
 void launch_sl_scalar_bwd_clamp(const GridDims& g, bool is3d, bool quirks, bool sample_outside, float dt, float half_s,
                                 const float* src, const float* fwd, const int* cell_in, const float* U,
-                                const float* flags, float* dst, hipStream_t s);
+                                const float* flags, const float* box, float* dst, hipStream_t s);
+void launch_box_minmax(const GridDims& g, bool sample_outside, const float* src, const float* flags, float* box,
+                       hipStream_t s);
 void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const float* src, const float* U,
                    const float* flags, float* dst, hipStream_t s);
 void launch_sl_mac_bwd_clamp(const GridDims& g, bool is3d, bool quirks, float dt, float half_s, const float* orig,
