@@ -353,18 +353,23 @@ __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const u
 // ---------------------------------------------------------------------------------------------------
 // 3D, two sweeps per pass (temporal blocking along the z-march).
 //
-// A wave owns 60 output columns (lanes 2..61; lanes 0,1,62,63 are halo columns) x 4 rows and marches along z.  It
-// keeps p^0 on rows j0-2..j0+5 and p^1 on rows j0-1..j0+4 for three planes each; at step t it builds p^1(plane t)
-// and, from p^1(t-2..t), the finished p^2(plane t-1) of its 4 rows.  The Z2NW waves of a block are stacked in y and
-// hand each other their halo rows of p^0 / div / mask through LDS (one barrier per plane), so only the block's two
-// outer waves fetch halo rows from memory.  The plane rings are rotated by unrolling the march 4x (no register
-// moves), all row/plane addressing is wave-uniform (SALU, saddr loads), blocks are renumbered so that the tiles an
-// XCD works on at one time are spatial neighbours (their halos then hit that XCD's L2).
+// A wave (one 64-thread block) owns 60 output columns (lanes 2..61; lanes 0,1,62,63 are halo columns) x Z2R rows and
+// marches along z.  It keeps p^0 on rows j0-2..j0+Z2R+1 and p^1 on rows j0-1..j0+Z2R for three planes each; at step
+// t it builds p^1(plane t) and, from p^1(t-2..t), the finished p^2(plane t-1) of its rows.  Waves are independent (no
+// LDS, no barrier): the halo rows / columns a wave re-reads are its neighbours' own rows, and the launch puts
+// neighbouring tiles on the same XCD marching the same planes at the same time, so those re-reads hit L2 and HBM
+// traffic stays near one read of p, div, mask and one write of p per pass.  (An earlier version handed the halo rows
+// between y-stacked waves through LDS with one barrier per plane: 8-10 % slower -- the barrier couples four SIMDs.)
+// The plane rings are rotated by unrolling the march 4x (no register moves); all row / plane addressing is
+// wave-uniform (buffer loads: per-lane voffset = column, SGPR soffset = plane + row).
 //
 // VALU budget per cell-update: the obstacle-free path (wave-uniform test per plane) is 6 adds + the /6 + the 'cont'
 // blend; with obstacles each neighbour costs a v_bfe_i32 + v_bfi_b32 more.
+// Measured alternatives at 16.7M cells (us per pass): Z2R=4 at 4 waves/SIMD 48-52; Z2R=3 at 5 waves/SIMD 49-53;
+// Z2R=2 at 6 waves/SIMD 53-59; Z2R=8 at 2 waves/SIMD 59-61.
 // ---------------------------------------------------------------------------------------------------
-constexpr int Z2R = 4, Z2NW = 4;
+constexpr int Z2R = 4, Z2NW = 1;
+constexpr int Z2WPS = 4;                   // waves per SIMD the register budget is sized for
 constexpr int Z2C_DEFAULT = 16;
 
 // x / 6.0f, correctly rounded, without the v_rcp/v_div_scale expansion: q = x*zh, r = x - 6q (exact), q + r*zh with
@@ -408,24 +413,21 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 
 // ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
 template <bool RES, bool ZERO, bool SPLIT>
-__global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
+__global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
                                                                       float* __restrict__ p_out,
                                                                       float* __restrict__ sumsq, int nxt, int nyt,
                                                                       int zchunk, int kb, int ke) {
   constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
-  __shared__ float lds_p[2][Z2NW][4][64];
-  __shared__ float lds_d[2][Z2NW][2][64];
-  __shared__ unsigned lds_m[2][Z2NW][2][64];
   const int lane = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const bool first_w = w == 0, last_w = w == Z2NW - 1;
-  // One resident set of blocks.  zchunk > 0: every tile is cut into the same plane chunks and a block takes one
-  // (tile, chunk); all blocks of a chunk start together and march the same planes at the same pace, so the halo
+  // One resident set of waves.  !SPLIT: every tile is cut into the same plane chunks and a wave takes one
+  // (tile, chunk); all waves of a chunk start together and march the same planes at the same pace, so the halo
   // columns/rows two neighbouring tiles both touch are fetched from HBM once and hit in L2 the second time.  Workgroup
   // ids go round-robin over the 8 XCDs; renumbering gives XCD q the tiles [q*G/8, (q+1)*G/8), i.e. whole bands of
-  // x-neighbouring tiles.  zchunk == 0: the (tile, plane) space is cut into gridDim.x equal contiguous ranges instead.
+  // neighbouring tiles.  SPLIT (more tiles than resident waves): the (tile, plane) space is cut into gridDim.x equal
+  // contiguous ranges instead.
   const int G = gridDim.x, np = ke - kb;
   const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int ntiles = nxt * nyt * g.B;
@@ -457,7 +459,6 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
   const bool xin = (x >= 0) & (x < g.W);
   const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
   const size_t base = (size_t)b * g.DHW;
-  __syncthreads();                                       // the previous segment's last LDS reads are done
 
   auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
   // Rows / planes / columns outside the grid are clamped onto the border, whose mask byte is 0 (border cells are
@@ -539,21 +540,12 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
   auto step = [&](auto ph, int t) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph)::value;
     constexpr int SM = (PH + 3) & 3, SC = PH, SP = (PH + 1) & 3, SN = (PH + 2) & 3, BUF = PH & 1;
-    // ---- issue the loads of p^0 plane t+2 (own rows; the block's outer waves also their halo rows) and of the
-    //      aux data of plane t+1
+    // ---- issue the loads of p^0 plane t+2 and of the aux data of plane t+1 (used one step later)
     const unsigned p2 = planeoff(t + 2), p1 = planeoff(t + 1);
 #pragma unroll
-    for (int r = 0; r < Z2R; ++r) P0[SN][2 + r] = ldp(p2 + rowb[2 + r]);
+    for (int rr = 0; rr < R0; ++rr) P0[SN][rr] = ldp(p2 + rowb[rr]);
 #pragma unroll
-    for (int r = 0; r < Z2R; ++r) { AD[SP][1 + r] = ldf(r_d, p1 + rowb[2 + r]); AM[SP][1 + r] = ldm(p1 + rowb[2 + r]); }
-    if (first_w) {
-      P0[SN][0] = ldp(p2 + rowb[0]); P0[SN][1] = ldp(p2 + rowb[1]);
-      AD[SP][0] = ldf(r_d, p1 + rowb[1]); AM[SP][0] = ldm(p1 + rowb[1]);
-    }
-    if (last_w) {
-      P0[SN][6] = ldp(p2 + rowb[6]); P0[SN][7] = ldp(p2 + rowb[7]);
-      AD[SP][5] = ldf(r_d, p1 + rowb[6]); AM[SP][5] = ldm(p1 + rowb[6]);
-    }
+    for (int rr = 0; rr < R1; ++rr) { AD[SP][rr] = ldf(r_d, p1 + rowb[rr + 1]); AM[SP][rr] = ldm(p1 + rowb[rr + 1]); }
     // ---- sweep 1 on plane t, rows j0-1 .. j0+4
     unsigned ob = AM[SC][0];
 #pragma unroll
@@ -574,22 +566,6 @@ __global__ __launch_bounds__(64 * Z2NW, 4) void jacobi3d_march2_kernel(GridDims 
       }
     }
     prev_free = free1;
-    // ---- hand the halo rows of p^0(t+2) and aux(t+1) to the y-neighbour waves
-    if (!ZERO) {
-#pragma unroll
-      for (int r = 0; r < Z2R; ++r) lds_p[BUF][w][r][lane] = P0[SN][2 + r];
-    }
-    lds_d[BUF][w][0][lane] = AD[SP][1]; lds_d[BUF][w][1][lane] = AD[SP][Z2R];
-    lds_m[BUF][w][0][lane] = AM[SP][1]; lds_m[BUF][w][1][lane] = AM[SP][Z2R];
-    __syncthreads();
-    if (!first_w) {
-      if (!ZERO) { P0[SN][0] = lds_p[BUF][w - 1][2][lane]; P0[SN][1] = lds_p[BUF][w - 1][3][lane]; }
-      AD[SP][0] = lds_d[BUF][w - 1][1][lane]; AM[SP][0] = lds_m[BUF][w - 1][1][lane];
-    }
-    if (!last_w) {
-      if (!ZERO) { P0[SN][6] = lds_p[BUF][w + 1][0][lane]; P0[SN][7] = lds_p[BUF][w + 1][1][lane]; }
-      AD[SP][5] = lds_d[BUF][w + 1][0][lane]; AM[SP][5] = lds_m[BUF][w + 1][0][lane];
-    }
   };
 
   while (true) {
@@ -763,11 +739,11 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                         float* sumsq, hipStream_t s, int kb, int ke, bool from_zero) {
   if (ke <= kb) { kb = 0; ke = g.D; }
-  static const int slots = [] {                          // resident 256-thread blocks: 4 per CU (128 VGPRs, 16 KB LDS)
+  static const int slots = [] {                          // resident waves: Z2WPS per SIMD (<= 128 VGPRs each)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("FNX_JACOBI_BLOCKS");
-    return e ? atoi(e) : 4 * cus;
+    return e ? atoi(e) : (Z2WPS * 4 / Z2NW) * cus;
   }();
   static const int zenv = [] { const char* e = getenv("FNX_JACOBI_ZCHUNK"); return e ? atoi(e) : -1; }();
   const int nxt = (g.W + 59) / 60, nyt = (g.H + Z2NW * Z2R - 1) / (Z2NW * Z2R);
