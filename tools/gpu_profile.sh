@@ -7,5 +7,5 @@ export TMPDIR=/tmp
 out=gpurun_out/prof_$tag/$w
 mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out -o r --output-format csv -- python bench.py --workload $w --no-cpu-baseline "$@" > $out/bench.log 2>&1
-tail -1 $out/bench.log > $out/bench.json
+grep "^{\"metric\"" $out/bench.log | tail -1 > $out/bench.json
 rm -f $out/r_kernel_trace.csv.gz
