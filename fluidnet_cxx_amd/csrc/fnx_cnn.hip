@@ -1,8 +1,9 @@
 // MultiScale pressure-net forward (lib/multi_scale_net.py:118-127, lib/model.py:76-227) for gfx950.
 //
 // The 32/64/128-channel 3x3(x3) layers (95 % of the FLOPs) run as implicit GEMM on the matrix cores in exact fp32
-// (conv3_mfma_kernel); the thin first/last layers (Cin 2-3, Cout 1-8) are bandwidth-shaped and use a direct kernel
-// (one thread per output pixel x CO_T output channels, weights through the scalar cache).
+// (conv3_mfma_kernel, 32x32x2 MFMA); the 5x5(x5) layers 3->32 and 32->8 on the 16x16x4 MFMA (conv5_mfma16_kernel);
+// the remaining thin layers (2->32 and 32->1 3x3, the final 1x1) are bandwidth-shaped and use a direct kernel
+// (a strip of output pixels x CO_T output channels per thread, weights through the scalar cache).
 #include "fnx_cnn.h"
 #include <stdlib.h>
 #include "fnx_kernels.h"
@@ -17,12 +18,24 @@ inline int co_tile(int cout) { return cout >= 16 ? 16 : cout; }
 
 struct PackedLayer { size_t w_off, b_off; };   // float offsets into the packed buffer
 
+// 5x5(x5) layers (Cin 3 or 32, Cout 32 or 8) run on v_mfma_f32_16x16x4_f32: Cin is padded to a multiple of 4 (one
+// k-step) and Cout to a multiple of 16 (one M block) with zero weights.
+inline bool mfma16_layer(const ConvLayer& L) {
+  static const bool thin_direct = getenv("FNX_CONV_THIN_DIRECT") != nullptr;   // A/B switch: keep them on the direct kernel
+  return !thin_direct && L.k == 5 && (L.cin % 8 == 0 || L.cin <= 4) && L.cout <= 32;
+}
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
+  if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
+  return layer_weight_floats(L, is3d);
+}
+
 PackedLayer packed_layer(int l, bool is3d) {
   size_t off = 0;
   PackedLayer r{0, 0};
   for (int i = 0; i <= l; ++i) {
     r.w_off = off;
-    off += layer_weight_floats(LAYERS[i], is3d);
+    off += packed_weight_floats(LAYERS[i], is3d);
     r.b_off = off;
     off += LAYERS[i].cout;
     off = (off + 63) & ~(size_t)63;
@@ -42,6 +55,20 @@ __global__ void pack_layer_mfma_kernel(const float* __restrict__ w, const float*
     const int r = q - co * cin * taps;
     const int ci = r / taps, t = r - ci * taps;
     pw[((size_t)t * cin + ci) * cout + co] = w[q];
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
+}
+
+// blob: (Cout,Cin,taps) -> packed [taps][Cin padded to 4][Cout padded to 16], zeros in the padding
+__global__ void pack_layer_mfma16_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                         float* __restrict__ pw, float* __restrict__ pb, int cin, int cout, int taps,
+                                         int cin_pad, int cout_pad) {
+  const int n = taps * cin_pad * cout_pad;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int co = q % cout_pad;
+    const int r = q / cout_pad;
+    const int ci = r % cin_pad, t = r / cin_pad;
+    pw[q] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + t] : 0.f;
   }
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
 }
@@ -288,6 +315,166 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Implicit-GEMM 5x5(x5) convolution for the thin layers (3->32 and 32->8) on v_mfma_f32_16x16x4_f32 (exact fp32):
+//   D[cout 16][pixel 16] += A[cout][k] * B[k][pixel],  k = four consecutive input channels of one tap
+//   A: lane -> W[tap][c + (lane>>4)][m*16 + (lane&15)]       (LDS image [tap][CHS][CO], conflict-free)
+//   B: lane -> X[c + (lane>>4)][y + r - 2][x + (lane&15) + s - 2]  from the LDS halo tile (the four 16-lane groups read
+//      four channel planes whose stride, 12*68 floats, spreads them over disjoint banks)
+//   D: lane holds pixel (lane&15) and output channels 4*(lane>>4)..+3
+// Workgroup = 4 waves stacked in y; wave tile = 64 px (4 segments of 16) x 2 rows x MB*16 output channels.  A stage
+// is one z plane x CHS input channels: the halo tile goes global -> registers -> LDS (prefetched during the previous
+// stage's MFMAs), the stage's 25 x CHS x CO weights go global -> LDS by global_load_lds_dwordx4; both double-buffered,
+// one barrier per stage (25*CHS/4*8*MB MFMAs per wave between barriers).  Padded output channels (32->8 uses half
+// of the 16-row M block) cost MFMA cycles, not memory traffic.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CHS, int MB, bool IS3D>
+__global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int cin_pad) {
+  constexpr int KS = 5, PAD = 2, NX = 4, PR = 2;
+  constexpr int ROWS = 4 * PR + KS - 1, COLS = 16 * NX + KS - 1;      // 12 x 68 halo tile per channel
+  constexpr int CO = 16 * MB;
+  constexpr int NEL = CHS * ROWS * COLS, NLD = (NEL + 255) / 256;
+  constexpr int TAPF = CHS * CO;                                      // floats per tap in a stage (128)
+  static_assert(TAPF == 128, "a wave-wide 16-byte load covers two taps");
+  constexpr int NWI = (KS * KS + 1) / 2;                              // wave-instructions per stage (13)
+  __shared__ __attribute__((aligned(16))) float tile2[2][NEL];
+  __shared__ __attribute__((aligned(16))) float wbuf[2][NWI * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = lane & 15, kq = lane >> 4;
+  const int x0 = blockIdx.x * (16 * NX), y0 = blockIdx.y * (4 * PR);
+  int zb = blockIdx.z;
+  const int z = zb % a.D; const int b = zb / a.D;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
+
+  f32x4 acc[PR][NX][MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = mb * 16 + 4 * kq + r;
+      const float bv = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int pr = 0; pr < PR; ++pr)
+#pragma unroll
+        for (int nx = 0; nx < NX; ++nx) acc[pr][nx][mb][r] = bv;
+    }
+  }
+
+  const float* xb = a.x + (size_t)b * a.cin * vol;
+  // per-thread staging slots of the [CHS][ROWS][COLS] halo tile (offsets and predicates are stage-invariant: Cin is a
+  // multiple of CHS, or smaller than CHS with a single chunk whose missing channels read as zero)
+  int goff[NLD];
+  unsigned valid = 0;
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    const int cc = idx / (ROWS * COLS);
+    const int rem = idx - cc * ROWS * COLS;
+    const int row = rem / COLS, col = rem - row * COLS;
+    const int gx = x0 - PAD + col, gy = y0 - PAD + row;
+    const bool ok = (idx < NEL) & (cc < a.cin) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+    goff[t] = ok ? (int)((size_t)cc * vol + (size_t)gy * a.W + gx) : 0;
+    valid |= (unsigned)ok << t;
+  }
+  float stage[NLD];
+  auto prefetch = [&](int dz, int c0) {
+    const int zz = IS3D ? z + dz - PAD : 0;
+    const float* src = xb + (size_t)c0 * vol + (size_t)zz * plane;
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) stage[t] = src[goff[t]];
+  };
+  auto stage_weights = [&](int dz, int c0, int buf) {
+#pragma unroll
+    for (int q = 0; q < (NWI + 3) / 4; ++q) {
+      const int wi = wave + 4 * q;                        // wave-uniform
+      if (wi < NWI) {
+        int tap = 2 * wi + (lane >> 5);
+        if (tap > KS * KS - 1) tap = KS * KS - 1;         // the 26th half re-reads tap 24 into slots nobody reads
+        const float* src = a.w + ((size_t)(dz * KS * KS + tap) * cin_pad + c0) * CO + (lane & 31) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(&wbuf[buf][wi * 256]), 16, 0, 0);
+      }
+    }
+  };
+  const int nchunk = cin_pad / CHS;
+  int dz_lo = 0, dz_hi = IS3D ? KS : 1;
+  if (IS3D) { dz_lo = PAD - z > 0 ? PAD - z : 0; dz_hi = a.D + PAD - z < KS ? a.D + PAD - z : KS; }
+  const int niter = (dz_hi - dz_lo) * nchunk;
+  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, 0); }
+  for (int it = 0; it < niter; ++it) {
+    float* tile = tile2[it & 1];
+#pragma unroll
+    for (int t = 0; t < NLD; ++t)
+      if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = ((valid >> t) & 1) ? stage[t] : 0.f;
+    __syncthreads();                                     // tile stores + the stage's weight DMA visible to all
+    if (it + 1 < niter) {
+      prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CHS);
+      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CHS, (it + 1) & 1);
+    }
+    const float* wl = &wbuf[it & 1][kq * CO + seg];
+    const float* tl = &tile[kq * ROWS * COLS + (wave * PR) * COLS + seg];
+#pragma unroll
+    for (int r = 0; r < KS; ++r) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < CHS / 4; ++ks) {
+          float av[MB], bv[PR][NX];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) av[mb] = wl[((r * KS + s) * CHS + ks * 4) * CO + mb * 16];
+#pragma unroll
+          for (int pr = 0; pr < PR; ++pr)
+#pragma unroll
+            for (int nx = 0; nx < NX; ++nx) bv[pr][nx] = tl[(ks * 4) * ROWS * COLS + (pr + r) * COLS + nx * 16 + s];
+#pragma unroll
+          for (int pr = 0; pr < PR; ++pr)
+#pragma unroll
+            for (int nx = 0; nx < NX; ++nx)
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb)
+                acc[pr][nx][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[pr][nx], acc[pr][nx][mb], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int pr = 0; pr < PR; ++pr) {
+    const int y = y0 + wave * PR + pr;
+    if (y >= a.H) continue;
+#pragma unroll
+    for (int nx = 0; nx < NX; ++nx) {
+      const int x = x0 + nx * 16 + seg;
+      if (x >= a.W) continue;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = mb * 16 + 4 * kq + r;
+          if (co < a.cout) {
+            float v = acc[pr][nx][mb][r];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.y[((size_t)b * a.cout + co) * vol + (size_t)z * plane + (size_t)y * a.W + x] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+void launch_conv_mfma16(const ConvArgs& a, bool is3d, hipStream_t s) {
+  const dim3 grid((a.W + 63) / 64, (a.H + 7) / 8, a.B * a.D);
+  const int cin_pad = pad_to(a.cin, 4);
+  if (a.cin % 8 == 0 && a.cout <= 16) {
+    if (is3d) conv5_mfma16_kernel<8, 1, true><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<8, 1, false><<<grid, 256, 0, s>>>(a, cin_pad);
+  } else {
+    if (is3d) conv5_mfma16_kernel<4, 2, true><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<4, 2, false><<<grid, 256, 0, s>>>(a, cin_pad);
+  }
+}
+
 template <int CB, int PR>
 void launch_conv_mfma_t(const ConvArgs& a, bool is3d, hipStream_t s) {
   const dim3 grid((a.W + 31) / 32, (a.H + 4 * PR - 1) / (4 * PR), a.B * a.D * (a.cout / (CB * 32)));
@@ -306,6 +493,7 @@ void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const Packe
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
   if (mfma_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA, s); launch_conv_mfma(a, is3d, s); return; }
+  if (mfma16_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA, s); launch_conv_mfma16(a, is3d, s); return; }
   ProfScope ps(FNX_PROF_CONV_DIRECT, s);
   if (is3d) {
     if (L.k == 3) launch_conv_k<3, true>(a, s);
@@ -397,6 +585,9 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     if (mfma_layer(L))
       pack_layer_mfma_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 layer_taps(L, is3d));
+    else if (mfma16_layer(L))
+      pack_layer_mfma16_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
+                                                  layer_taps(L, is3d), pad_to(L.cin, 4), pad_to(L.cout, 16));
     else
       pack_layer_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                            layer_taps(L, is3d), co_tile(L.cout));
