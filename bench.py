@@ -165,7 +165,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev):
         from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
         layout = SlabLayout(w["D"] * world, world, rank, halo=6)
         bd = plume_state_torch(w["res"], layout.D_local, dev, layout.z_offset, layout.D_global)
-        sim = SlabSimulator(layout, m, sweeps_per_exchange=4)
+        sim = SlabSimulator(layout, m, sweeps_per_exchange=6)     # = halo: 17 ghost exchanges of p per 100 sweeps
         net = None
 
         def eager_step():

@@ -98,10 +98,10 @@ def check_owned(st, ref, layout, what):
         assert not bad.any(), f"{what}: {k} differs on {int(bad.sum())} owned cells (rank {layout.rank}), max {np.abs(a - b).max():.3e}"
 
 
-@pytest.mark.parametrize("world,halo,w", [(3, 6, 4), (2, 5, 2), (2, 8, 5), (2, 6, 3)])
+@pytest.mark.parametrize("world,halo,w", [(3, 6, 4), (2, 5, 2), (2, 8, 5), (2, 6, 3), (2, 6, 6)])
 def test_lockstep_slabs_match_single_domain_cpu(world, halo, w):
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
-    D, H, W = 24 if world == 3 else 20, 14, 18
+    D, H, W = 24 if (world == 3 or w == 6) else 20, 14, 18
     gs = global_state(D, H, W)
     ref = reference_steps(gs, 2)
     ops = OracleOps()
@@ -160,7 +160,7 @@ def test_layout_arithmetic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,halo,w", [(2, 6, 4), (4, 6, 3)])
+@pytest.mark.parametrize("world,halo,w", [(2, 6, 4), (4, 6, 3), (2, 6, 6)])
 def test_lockstep_slabs_match_single_domain_gpu(world, halo, w):
     """Same decomposition check with the native HIP operators on one device (global-z geometry in the kernels)."""
     from fluidnet_cxx_amd import simulate
