@@ -38,7 +38,7 @@ MFMA_F32_PEAK_TF = 157.3     # exact-f32 MFMA peak (v_mfma_f32_32x32x2_f32)
 # algorithmic bytes per cell, 2D / 3D
 STEP_BYTES = {False: lambda n: 340 + 16 * n, True: lambda n: 452 + 16 * n}
 CNN_FLOP_PER_CELL = {False: 484476, True: 1338929}
-PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4)
+PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4, conv_mfma16=5)
 
 WORKLOADS = {
     "plume2d_1024_cnn": dict(res=1024, D=1, method="convnet", iters=0, kind="plume"),

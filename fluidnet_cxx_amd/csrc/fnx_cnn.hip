@@ -493,7 +493,7 @@ void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const Packe
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
   if (mfma_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA, s); launch_conv_mfma(a, is3d, s); return; }
-  if (mfma16_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA, s); launch_conv_mfma16(a, is3d, s); return; }
+  if (mfma16_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA16, s); launch_conv_mfma16(a, is3d, s); return; }
   ProfScope ps(FNX_PROF_CONV_DIRECT, s);
   if (is3d) {
     if (L.k == 3) launch_conv_k<3, true>(a, s);

@@ -196,7 +196,15 @@ class SlabSimulator:
                 ops.set_slab(l.z_offset, l.D_global)
                 pending = False
             passes = [2] * (k // 2) + [1] * (k % 2)
+            done = 0
             for pi, n in enumerate(passes):
+                done += n
+                # After the exchange the w ghost planes next to the owned block are fresh; every sweep makes the
+                # outermost fresh one stale, so a pass that ends `done` sweeps into the block only has to produce the
+                # planes within w - done of the owned block (sides without a neighbour: up to the array end).
+                g = max(self.w - done, 0)
+                a = lo - g if l.rank > 0 else 0
+                b = top + g if l.rank < l.world - 1 else l.D_local
                 if pi == len(passes) - 1 and remaining > 0 and l.world > 1:
                     if l.rank > 0:
                         ops.jacobi_pass(st["flags"], div, cur, nxt, n, lo, lo + w)
@@ -205,10 +213,12 @@ class SlabSimulator:
                     yield "start", [nxt], w
                     ops.set_slab(l.z_offset, l.D_global)
                     pending = True
-                    ia = lo + w if l.rank > 0 else 0
-                    ib = top - w if l.rank < l.world - 1 else l.D_local
+                    ia = lo + w if l.rank > 0 else a
+                    ib = top - w if l.rank < l.world - 1 else b
                     if ib > ia:
                         ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)   # overlaps the exchange
+                elif l.world > 1:
+                    ops.jacobi_pass(st["flags"], div, cur, nxt, n, a, b)
                 else:
                     ops.jacobi_pass(st["flags"], div, cur, nxt, n, 0, 0)
                 cur, nxt = nxt, cur

@@ -188,7 +188,7 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
  * later launches are not recorded).  fnx_profile_read synchronises the recorded events and returns the summed
  * kernel time and the number of launches of that class; fnx_profile_enable(1) also clears earlier records. */
 enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PROF_STAGE = 3, FNX_PROF_CONV_DIRECT = 4,
-       FNX_PROF_NTAGS = 5 };
+       FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_NTAGS = 6 };
 int fnx_profile_enable(int on);
 int fnx_profile_read(int tag, double* total_ms, int* launches);
 
