@@ -214,7 +214,7 @@ def test_cnn_vs_reference_golden(dev, golden):
     assert_close(N(p), c["fluidnet_p"], 2e-5, "FluidNet p"); assert_close(N(U), c["fluidnet_U"], 2e-5, "FluidNet U")
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 36, 52), (2, 1, 64, 128), (1, 8, 12, 16)])
+@pytest.mark.parametrize("shape", [(1, 1, 36, 52), (2, 1, 64, 128), (1, 8, 12, 16), (1, 1, 44, 200), (1, 6, 20, 72)])
 def test_cnn_vs_oracle(dev, oracle, shape):
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
