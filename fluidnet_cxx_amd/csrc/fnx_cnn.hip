@@ -273,25 +273,33 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK, (it + 1) & 1);
     }
     {
-      const float* wl = &wbuf[it & 1][l31];
+      // Operand pipeline: the A/B values of group g+1 (one tap x 2 channels: CB + PR LDS values) are read while the
+      // PR*CB MFMAs of group g issue, so no MFMA waits on an LDS round trip (left to itself the scheduler parks each
+      // ds_read right in front of its first use).
+      const float* wl = &wbuf[it & 1][l31 + half * RW];
+      const float* tl = &tile[half * ROWS * MF_COLS + (wave * PR) * MF_COLS + l31];
       (void)dz; (void)c0;
+      constexpr int NCP = MF_CHUNK / 2, NG = 9 * NCP;
+      float av[2][CB], bv[2][PR];
+      auto load_group = [&](int g, float (&A)[CB], float (&B)[PR]) __attribute__((always_inline)) {
+        const int tap = g / NCP, cp = (g % NCP) * 2;
+        const int r = tap / 3, sx = tap - 3 * r;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+        for (int cb = 0; cb < CB; ++cb) A[cb] = wl[(tap * MF_CHUNK + cp) * RW + cb * 32];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int pr = 0; pr < PR; ++pr) B[pr] = tl[cp * ROWS * MF_COLS + (pr + r) * MF_COLS + sx];
+      };
+      load_group(0, av[0], bv[0]);
 #pragma unroll
-          for (int cp = 0; cp < MF_CHUNK; cp += 2) {
-            float av[CB], bv[PR];
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) load_group(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) av[cb] = wl[((r * 3 + s) * MF_CHUNK + cp + half) * RW + cb * 32];
+        for (int pr = 0; pr < PR; ++pr)
 #pragma unroll
-            for (int pr = 0; pr < PR; ++pr) bv[pr] = tile[(cp + half) * ROWS * MF_COLS + (wave * PR + pr + r) * MF_COLS + l31 + s];
-#pragma unroll
-            for (int pr = 0; pr < PR; ++pr)
-#pragma unroll
-              for (int cb = 0; cb < CB; ++cb) acc[pr][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[pr], acc[pr][cb], 0, 0, 0);
-          }
-        }
+          for (int cb = 0; cb < CB; ++cb)
+            acc[pr][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][cb], bv[g & 1][pr], acc[pr][cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
     }
     const float* wl = &wbuf[it & 1][kq * CO + seg];
     const float* tl = &tile[kq * ROWS * COLS + (wave * PR) * COLS + seg];
+    // (an explicit operand pipeline as in conv3_mfma_kernel measured slower here: 2.27 -> 2.74 ms at 128^3)
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
 #pragma unroll
