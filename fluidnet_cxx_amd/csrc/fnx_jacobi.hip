@@ -469,12 +469,17 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     const int j = j0 - 2 + rr;
     rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
   }
-  auto planeoff = [&](int k) { return (unsigned)(clampk(k) * g.HW); };
+  // buffer offsets are 32-bit: they are taken relative to the first plane this segment touches, so only the segment
+  // (<= a few dozen planes), not the whole field, has to stay below 4 GB
+  const int k0 = clampk(k_lo - 2);
+  auto planeoff = [&](int k) { return (unsigned)((clampk(k) - k0) * g.HW); };
   // buffer addressing: per-lane voffset (the column) + wave-uniform soffset (plane/row), no 64-bit VALU address math
   const unsigned xoff = (unsigned)xc * 4u;
-  const unsigned nbytes = (unsigned)g.DHW * 4u;
-  const BufRsrc r_p = make_rsrc(p_in + base, nbytes), r_d = make_rsrc(div + base, nbytes);
-  const BufRsrc r_m = make_rsrc(mask + base, (unsigned)g.DHW), r_o = make_rsrc(p_out + base, nbytes);
+  const size_t seg0 = base + (size_t)k0 * g.HW;
+  const size_t left = (size_t)(g.D - k0) * g.HW;                       // cells from plane k0 to the end of the sample
+  const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
+  const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
+  const BufRsrc r_m = make_rsrc(mask + seg0, ncell), r_o = make_rsrc(p_out + seg0, ncell * 4u);
   auto ldf = [&](const BufRsrc& r, unsigned cell) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
   };
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     if (t - 1 >= k_lo) {
       float v[Z2R];
       sweep(IC<Z2R>{}, prev_free, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
-      const unsigned ok = (unsigned)((t - 1) * g.HW + j0 * g.W) * 4u;
+      const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
         if (lane_out && j0 + r < g.H) {
@@ -756,6 +761,7 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     zchunk = (np + nzc - 1) / nzc;
     if (zchunk < 8) zchunk = 8;
     if (ntiles > slots) zchunk = 0;                      // more tiles than slots: even split of the (tile, plane) space
+    if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
   }
   long long G;
   if (zchunk > 0) {

@@ -140,6 +140,24 @@ def test_jacobi_sweep_counts(fl, dev, oracle, iters):
     assert abs(float(res) - ro) <= 1e-5 * max(1.0, ro)
 
 
+@pytest.mark.parametrize("shape", [(1, 6, 8, 100), (1, 1, 8, 120)])
+def test_jacobi_denormal_front(fl, dev, oracle, shape):
+    """A point source far from the other end of a long domain: the pressure front decays by ~1/6 (1/4) per cell and
+    runs through the fp32 denormal range.  The 3D kernel's fast exact /6 hands denormal quotients to the true
+    division; both must match the CPU's IEEE division bit for bit."""
+    B, D, H, W = shape
+    is3d = D > 1
+    flags = make_flags(B, D, H, W, boxes=False)
+    div = np.zeros((B, 1, D, H, W), np.float32)
+    div[0, 0, D // 2, H // 2, 2] = -0.37
+    n = 95
+    pg, _ = fl.solveLinearSystemJacobi(T(flags, dev), T(div, dev), is3d, 0.0, n)
+    po, _, _ = oracle.jacobi(flags, div, is3d, 0.0, n)
+    tiny = np.abs(po[po != 0]).min()
+    assert tiny < 1.2e-38, f"the case does not reach the denormal range (min |p| = {tiny})"
+    assert_bitexact(N(pg), po, "jacobi through the denormal range")
+
+
 def test_jacobi_tolerance_exit(fl, dev, oracle):
     s = random_state(1, 1, 48, 80, 2.0, seed=3)
     div = oracle.velocity_divergence(s["U"], s["flags"])
