@@ -59,23 +59,24 @@ class SlabComm:
         assert width <= l.halo
         ops, recvs = [], []
         for f in fields:
-            C = f.size(1)
             if l.rank > 0:           # lower neighbour
                 send = f[:, :, l.lo:l.lo + width]
                 recv = f[:, :, l.lo - width:l.lo]
-                sb = send if (C == 1) else send.contiguous()
-                rb = recv if (C == 1) else torch.empty_like(sb)
+                direct = send.is_contiguous() and recv.is_contiguous()     # one plane block (B = C = 1): no staging copy
+                sb = send if direct else send.contiguous()
+                rb = recv if direct else torch.empty_like(sb)
                 ops += [dist.P2POp(dist.isend, sb, l.rank - 1, self.group), dist.P2POp(dist.irecv, rb, l.rank - 1, self.group)]
-                if C != 1:
+                if not direct:
                     recvs.append((recv, rb))
             if l.rank < l.world - 1:  # upper neighbour
                 top = l.lo + l.owned
                 send = f[:, :, top - width:top]
                 recv = f[:, :, top:top + width]
-                sb = send if (C == 1) else send.contiguous()
-                rb = recv if (C == 1) else torch.empty_like(sb)
+                direct = send.is_contiguous() and recv.is_contiguous()     # one plane block (B = C = 1): no staging copy
+                sb = send if direct else send.contiguous()
+                rb = recv if direct else torch.empty_like(sb)
                 ops += [dist.P2POp(dist.isend, sb, l.rank + 1, self.group), dist.P2POp(dist.irecv, rb, l.rank + 1, self.group)]
-                if C != 1:
+                if not direct:
                     recvs.append((recv, rb))
         return dist.batch_isend_irecv(ops), recvs
 
