@@ -17,6 +17,7 @@ namespace {
 using at::Tensor;
 
 bool g_ref_quirks = false;
+int g_k_begin = 0, g_k_end = 0;       // compute window (set_window): plane-parallel operators produce planes [k_begin, k_end) only
 int g_z_offset = 0, g_D_global = 0;   // z-slab view (set_slab): arrays hold planes [z_offset, z_offset+D) of D_global
 
 void check_status(int rc) {
@@ -33,11 +34,12 @@ void check_field(const Tensor& t, const char* name) {
 FnxGrid grid_of(const Tensor& flags, bool is3D) {
   check_field(flags, "flags");
   TORCH_CHECK(flags.size(1) == 1, "flags is not scalar");
-  FnxGrid g;
+  FnxGrid g{};
   g.B = (int)flags.size(0); g.D = (int)flags.size(2); g.H = (int)flags.size(3); g.W = (int)flags.size(4);
   g.is3D = is3D ? 1 : 0;
   g.ref_quirks = g_ref_quirks ? 1 : 0;
   g.z_offset = g_z_offset; g.D_global = is3D ? g_D_global : 0;
+  g.k_begin = is3D ? g_k_begin : 0; g.k_end = is3D ? g_k_end : 0;
   if (!is3D) TORCH_CHECK(g.D == 1, "2D velocity field but zdepth > 1");
   return g;
 }
@@ -181,7 +183,7 @@ void set_wall_bcs_(Tensor U, Tensor flags) {
 void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> density,
                      c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask) {
   check_field(U, "U");
-  FnxGrid g; g.B = (int)U.size(0); g.D = (int)U.size(2); g.H = (int)U.size(3); g.W = (int)U.size(4);
+  FnxGrid g{}; g.B = (int)U.size(0); g.D = (int)U.size(2); g.H = (int)U.size(3); g.W = (int)U.size(4);
   g.is3D = U.size(1) == 3; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   auto ptr = [&](c10::optional<Tensor>& t, bool vel) -> float* {
     if (!t.has_value() || !t->defined()) return nullptr;
@@ -222,7 +224,7 @@ Tensor multiscale_forward(Tensor packed, Tensor x) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "x must be a contiguous float32 GPU tensor");
   TORCH_CHECK((x.dim() == 4 || x.dim() == 5) && x.size(1) == 2, "x must be (B,2,H,W) or (B,2,D,H,W)");
   const bool is3D = x.dim() == 5 && x.size(2) > 1;
-  FnxGrid g; g.B = (int)x.size(0); g.is3D = is3D; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
+  FnxGrid g{}; g.B = (int)x.size(0); g.is3D = is3D; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   g.D = x.dim() == 5 ? (int)x.size(2) : 1; g.H = (int)x.size(x.dim() - 2); g.W = (int)x.size(x.dim() - 1);
   c10::hip::HIPGuard guard(x.get_device());
   std::vector<int64_t> osz = x.sizes().vec(); osz[1] = 1;
@@ -237,7 +239,7 @@ std::vector<Tensor> fluidnet_forward(Tensor packed, Tensor input, double normali
   check_field(input, "input");
   const bool is3D = input.size(1) == 6;
   TORCH_CHECK(input.size(1) == 5 || input.size(1) == 6, "input must have 5 (2D) or 6 (3D) channels [p, U, flags, density]");
-  FnxGrid g; g.B = (int)input.size(0); g.D = (int)input.size(2); g.H = (int)input.size(3); g.W = (int)input.size(4);
+  FnxGrid g{}; g.B = (int)input.size(0); g.D = (int)input.size(2); g.H = (int)input.size(3); g.W = (int)input.size(4);
   g.is3D = is3D; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   c10::hip::HIPGuard guard(input.get_device());
   Tensor p = at::empty({g.B, 1, g.D, g.H, g.W}, input.options());
@@ -411,6 +413,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("get_ref_quirks", []() { return g_ref_quirks; });
   m.def("set_slab", [](int z_offset, int D_global) { g_z_offset = z_offset; g_D_global = D_global; },
         "3D multi-GPU: subsequent calls treat their tensors as planes [z_offset, z_offset+D) of a D_global-deep domain (0,0 resets)");
+  m.def("set_window", [](int k_begin, int k_end) { g_k_begin = k_begin; g_k_end = k_end; },
+        "3D z-slab driver: subsequent plane-parallel operators only produce local planes [k_begin, k_end) (0,0 resets)");
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
   m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });

@@ -22,8 +22,8 @@ __device__ __forceinline__ CellId cell_id(const GridDims& g) {
   c.i = blockIdx.x * BX + threadIdx.x;
   c.j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
-  c.b = IS3D ? bk / g.D : bk;
-  c.k = IS3D ? bk - c.b * g.D : 0;
+  c.b = IS3D ? bk / g.KN : bk;
+  c.k = IS3D ? g.K0 + (bk - c.b * g.KN) : 0;
   c.valid = (c.i < g.W) & (c.j < g.H);
   return c;
 }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void box_minmax_kernel(GridDims g, const float
   const int j0 = (blockIdx.y * 4 + w) * BOX_R;
   const int bz = blockIdx.z;
   const int zc = bz % nzc, b = bz / nzc;
-  const int k_lo = zc * BOX_ZC, k_hi = min(k_lo + BOX_ZC, g.D);
+  const int k_lo = g.K0 + zc * BOX_ZC, k_hi = min(k_lo + BOX_ZC, g.K0 + g.KN);      // planes of the compute window
   if (j0 >= g.H) return;
   const bool xin = (x >= 0) & (x < g.W);
   const int xc = clampi(x, 0, g.W - 1);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, fl
   for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = r[a];
 }
 
-inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D); }
+inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
 
 }  // namespace
 
@@ -408,7 +408,7 @@ void launch_sl_scalar_bwd_clamp(const GridDims& g, bool is3d, bool quirks, bool 
 
 void launch_box_minmax(const GridDims& g, bool sample_outside, const float* src, const float* flags, float* box,
                        hipStream_t s) {
-  const int nzc = (g.D + BOX_ZC - 1) / BOX_ZC;
+  const int nzc = (g.KN + BOX_ZC - 1) / BOX_ZC;
   const dim3 grid((g.W + 61) / 62, (g.H + 4 * BOX_R - 1) / (4 * BOX_R), g.B * nzc), block(64, 4);
   if (g.D > 1) {
     if (sample_outside) box_minmax_kernel<true, true><<<grid, block, 0, s>>>(g, src, flags, (float2*)box, nzc);

@@ -33,12 +33,26 @@ int check_grid(const FnxGrid* g) {
   if (g->is3D && g->D < 3) return fail(FNX_EINVAL, "3D domain needs D >= 3");
   if ((long long)g->D * g->H * g->W >= (1ll << 31)) return fail(FNX_EINVAL, "more than 2^31 cells per sample");
   if ((long long)g->B * g->D > 65535) return fail(FNX_EINVAL, "B*D > 65535 not supported");
+  if (g->k_end != 0 || g->k_begin != 0) {
+    if (!g->is3D || g->k_begin < 0 || g->k_end > g->D || g->k_end <= g->k_begin)
+      return fail(FNX_EINVAL, "bad compute window [%d, %d) for D=%d", g->k_begin, g->k_end, g->D);
+  }
   if (g->D_global != 0 && (!g->is3D || g->z_offset < 0 || g->z_offset + g->D > g->D_global))
     return fail(FNX_EINVAL, "bad z-slab: z_offset=%d D=%d D_global=%d", g->z_offset, g->D, g->D_global);
   return FNX_OK;
 }
 
-inline GridDims dims(const FnxGrid* g) { return make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global); }
+inline GridDims dims(const FnxGrid* g) {
+  GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
+  if (g->is3D && g->k_end > g->k_begin) { d.K0 = g->k_begin; d.KN = g->k_end - g->k_begin; }
+  return d;
+}
+// the same grid with the compute window widened by `by` planes (clipped to the array)
+inline GridDims widened(GridDims d, int by) {
+  const int a = d.K0 - by < 0 ? 0 : d.K0 - by, b = d.K0 + d.KN + by > d.D ? d.D : d.K0 + d.KN + by;
+  d.K0 = a; d.KN = b - a;
+  return d;
+}
 inline bool quirks(const FnxGrid* g) { return g->is3D && g->ref_quirks; }
 inline size_t ncell(const FnxGrid* g) { return (size_t)g->B * g->D * g->H * g->W; }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -164,8 +178,9 @@ int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float*
     int* cell = (int*)c.take(ncell(g) * 4);
     float* box = g->is3D ? (float*)c.take(ncell(g) * 8) : nullptr;
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_scalar: workspace too small (%zu < %zu)", ws_bytes, c.off);
-    { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_scalar(d, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s); }
-    if (g->is3D) { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_box_minmax(d, sample_outside != 0, src, flags, box, s); }
+    const GridDims dw = widened(d, 2);                  // what the backward pass / clamp read at |U dt| <= 1
+    { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_scalar(dw, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s); }
+    if (g->is3D) { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_box_minmax(dw, sample_outside != 0, src, flags, box, s); }
     else box = nullptr;                                  // 2D: the 3x3 clamp box is walked in the backward kernel
     fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_scalar_bwd_clamp(d, g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, src, fwd, cell, U,
@@ -190,7 +205,7 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
     Carver c(ws, ws_bytes);
     float* fwd = (float*)c.take(ncell(g) * 4 * (g->is3D ? 3 : 2));
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_vel: workspace too small (%zu < %zu)", ws_bytes, c.off);
-    { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_mac(d, g->is3D, quirks(g), dt, orig, U, flags, fwd, s); }
+    { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_mac(widened(d, 2), g->is3D, quirks(g), dt, orig, U, flags, fwd, s); }
     fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_mac_bwd_clamp(d, g->is3D, quirks(g), dt, strength * 0.5f, orig, fwd, U, flags, dst, s);
   }
@@ -440,7 +455,10 @@ int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxStat
   // 3D: the fused kernel re-derives three neighbour velocities per cell (~54 loads); staging then a plain divergence
   // pass is faster there (measured 0.67 -> 0.59 ms at 256^3).  2D keeps the single fused pass.
   const bool split = g->is3D != 0;
-  fnx::launch_pre_projection(dims(g), g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
+  // split: the divergence pass reads the staged U of the +1 neighbours, so the staging pass covers one more plane
+  GridDims ds = dims(g);
+  if (split && div && ds.K0 + ds.KN < ds.D) ds.KN += 1;
+  fnx::launch_pre_projection(ds, g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                              rbc ? st->densityBCInvMask : nullptr, st->U, st->density, (split && div) ? nullptr : div, buoy, sx, sy, sz,
                              prm->operating_density, prm->method == 0, (hipStream_t)stream);

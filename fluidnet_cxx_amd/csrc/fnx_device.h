@@ -23,11 +23,14 @@ struct GridDims {
   // z-slab decomposition: this array holds planes [zoff, zoff + D) of a domain that is Dglob planes deep.
   // Only the border test looks at them; single-GPU grids have zoff = 0, Dglob = D.
   int zoff, Dglob;
+  // compute window: plane-parallel kernels launch B*KN plane slices and produce planes [K0, K0+KN) only
+  int K0, KN;
 };
 
 __host__ __device__ inline GridDims make_dims(int B, int D, int H, int W, int zoff = 0, int Dglob = 0) {
   GridDims d; d.B = B; d.D = D; d.H = H; d.W = W; d.HW = H * W; d.DHW = D * H * W;
   d.zoff = zoff; d.Dglob = Dglob > 0 ? Dglob : D;
+  d.K0 = 0; d.KN = D;
   return d;
 }
 

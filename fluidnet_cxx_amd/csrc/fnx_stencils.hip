@@ -20,13 +20,13 @@ __device__ __forceinline__ CellId cell_id(const GridDims& g) {
   c.i = blockIdx.x * BX + threadIdx.x;
   c.j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
-  c.b = IS3D ? bk / g.D : bk;
-  c.k = IS3D ? bk - c.b * g.D : 0;
+  c.b = IS3D ? bk / g.KN : bk;
+  c.k = IS3D ? g.K0 + (bk - c.b * g.KN) : 0;
   c.valid = (c.i < g.W) & (c.j < g.H);
   return c;
 }
 
-inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D); }
+inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
 
 // velocityDivergence, lib/fluid/velocity_divergence.py:46-74
 template <bool IS3D>

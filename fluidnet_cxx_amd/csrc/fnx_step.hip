@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
                                                                 float sz, float rho_star) {
   const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
-  const int b = IS3D ? bk / g.D : bk, k = IS3D ? bk - b * g.D : 0;
+  const int b = IS3D ? bk / g.KN : bk, k = IS3D ? g.K0 + (bk - b * g.KN) : 0;
   if (i >= g.W || j >= g.H) return;
   constexpr int NC = IS3D ? 3 : 2;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
                                                                  const float* __restrict__ rhoBCInvMask) {
   const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
-  const int b = IS3D ? bk / g.D : bk, k = IS3D ? bk - b * g.D : 0;
+  const int b = IS3D ? bk / g.KN : bk, k = IS3D ? g.K0 + (bk - b * g.KN) : 0;
   if (i >= g.W || j >= g.H) return;
   constexpr int NC = IS3D ? 3 : 2;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
   if (rho && rhoBC) { const float t = rho[os] * rhoBCInvMask[os]; rho[os] = t + rhoBC[os]; }
 }
 
-inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D); }
+inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
 
 }  // namespace
 

@@ -109,6 +109,9 @@ class NativeOps:
     def set_slab(self, z_offset, D_global):
         self.ext.set_slab(int(z_offset), int(D_global))
 
+    def set_window(self, k_begin, k_end):
+        self.ext.set_window(int(k_begin), int(k_end))
+
     def advect_scalar(self, dt, rho, U, flags, strength, sample_outside):
         return self.ext.advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, bool(sample_outside), strength)
 
@@ -174,10 +177,20 @@ class SlabSimulator:
         # 4 fresh ghost planes of U and density are enough (the arrays keep `halo` planes for the pressure solve)
         yield "xchg", [st["U"], st["density"]], min(4, l.halo)
         ops.set_slab(l.z_offset, l.D_global)
+        # Compute windows: only the owned planes (+1 for the advected fields, whose +1 neighbours the divergence reads)
+        # are produced; ghost planes are refreshed by the exchanges anyway.  Ranks at the domain ends own their border.
+        window = getattr(ops, "set_window", None)
+        lo_, top_ = l.lo, l.lo + l.owned
+        if window and l.world > 1:
+            window(max(lo_ - 1, 0), min(top_ + 1, l.D_local))
         rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], float(cfg["maccormackStrength"]),
                                     cfg.get("sampleOutsideFluid", False))
         U_adv = ops.advect_vel(dt, st["U"], st["flags"], float(cfg["maccormackStrength"]))
+        if window and l.world > 1:
+            window(lo_, top_)
         div = ops.pre_projection(U_adv, rho_adv, st, cfg)
+        if window:
+            window(0, 0)
         yield "xchg", [div], max(w - 1, 1)
 
         # Jacobi: blocks of w sweeps between ghost exchanges (temporal blocking in z).  The last pass of a block first
@@ -227,7 +240,11 @@ class SlabSimulator:
             st["p"].copy_(cur)
         yield "xchg", [st["p"]], 1
         ops.set_slab(l.z_offset, l.D_global)
+        if window and l.world > 1:
+            window(lo_, top_)
         ops.post_projection(st)
+        if window:
+            window(0, 0)
         ops.set_slab(0, 0)
 
     def step(self, st):
@@ -243,6 +260,8 @@ class SlabSimulator:
                     handle = None
         finally:
             self.ops.set_slab(0, 0)
+            if hasattr(self.ops, "set_window"):
+                self.ops.set_window(0, 0)
 
 
 def lockstep_step(sims, states):
@@ -271,3 +290,5 @@ def lockstep_step(sims, states):
                 f_hi[:, :, hi.lo - width:hi.lo].copy_(f_lo[:, :, top - width:top])
     for s in sims:
         s.ops.set_slab(0, 0)
+        if hasattr(s.ops, "set_window"):
+            s.ops.set_window(0, 0)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 2
+#define FNX_ABI_VERSION 3
 
 enum {
   FNX_OK = 0,
@@ -54,6 +54,13 @@ typedef struct FnxGrid {
   /* z-slab decomposition (3D, multi-GPU): the arrays hold planes [z_offset, z_offset + D) of a domain that is
      D_global planes deep; only the domain-border test uses them.  0 / 0 = a whole domain (the default). */
   int z_offset, D_global;
+  /* Compute window (z-slab driver): the cell-parallel operators -- advection, the BC/buoyancy/wall/divergence stage,
+     velocity update and the stand-alone stencils -- only produce local planes [k_begin, k_end); planes outside keep
+     their old contents.  They still READ outside the window.  MacCormack advection evaluates its forward pass on the
+     window widened by 2 planes, which covers what the backward pass and the clamp read while |U dt| <= 1 cell (the
+     same bound the ghost width of the decomposition rests on).  0 / 0 = all planes (the default).  The Jacobi entry
+     points take their own plane range. */
+  int k_begin, k_end;
 } FnxGrid;
 
 /* Workspace sizing. */
