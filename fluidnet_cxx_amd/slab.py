@@ -162,6 +162,15 @@ class SlabSimulator:
         assert layout.world == 1 or layout.owned >= 2 * self.w, "slab too thin for the sweep block"
         assert layout.world == 1 or layout.halo >= 5, "advection + projection need 5 valid ghost planes (CFL <= 1)"
 
+    def _side_stream(self, t):
+        """A second HIP stream for work that may run next to the main stream's (device tensors with the native
+        operators only)."""
+        if not (t.is_cuda and isinstance(self.ops, NativeOps)):
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=t.device)
+        return self._side
+
     def phases(self, st):
         """Generator over the step: computes up to the next communication point and yields a request
              ("xchg", fields, width)   blocking ghost exchange
@@ -220,6 +229,17 @@ class SlabSimulator:
                 a = lo - g if l.rank > 0 else 0
                 b = top + g if l.rank < l.world - 1 else l.D_local
                 if pi == len(passes) - 1 and remaining > 0 and l.world > 1:
+                    # Last pass of the block: the w planes each neighbour needs go first and their exchange is posted;
+                    # the interior planes are independent of them (same input, disjoint output) and run on a side
+                    # stream at the same time, so the small edge launches fill CUs instead of serialising with it.
+                    ia = lo + w if l.rank > 0 else a
+                    ib = top - w if l.rank < l.world - 1 else b
+                    side = self._side_stream(cur)
+                    if side is not None and ib > ia:
+                        side.wait_stream(torch.cuda.current_stream(cur.device))
+                        with torch.cuda.stream(side):
+                            ops.set_slab(l.z_offset, l.D_global)
+                            ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)
                     if l.rank > 0:
                         ops.jacobi_pass(st["flags"], div, cur, nxt, n, lo, lo + w)
                     if l.rank < l.world - 1:
@@ -227,10 +247,11 @@ class SlabSimulator:
                     yield "start", [nxt], w
                     ops.set_slab(l.z_offset, l.D_global)
                     pending = True
-                    ia = lo + w if l.rank > 0 else a
-                    ib = top - w if l.rank < l.world - 1 else b
-                    if ib > ia:
-                        ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)   # overlaps the exchange
+                    if side is None:
+                        if ib > ia:
+                            ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)   # overlaps the exchange
+                    else:
+                        torch.cuda.current_stream(cur.device).wait_stream(side)
                 elif l.world > 1:
                     ops.jacobi_pass(st["flags"], div, cur, nxt, n, a, b)
                 else:

@@ -25,4 +25,11 @@ t0 = time.perf_counter(); e0.record()
 for _ in range(n): lockstep_step(sims, states)
 e1.record(); t1 = time.perf_counter(); torch.cuda.synchronize()
 gpu = e0.elapsed_time(e1) / n
+from fluidnet_cxx_amd._ext import ext
+ext.profile_enable(True)
+for _ in range(2): lockstep_step(sims, states)
+torch.cuda.synchronize()
+tags = {k: ext.profile_read(v) for k, v in bench.PROF.items()}
+ext.profile_enable(False)
+print("  per rank and step: " + ", ".join(f"{k} {ms / 2 / world:.3f} ms ({n // 2 // world} launches)" for k, (ms, n) in tags.items() if n))
 print(f"world={world} w={wsw}: GPU {gpu:.3f} ms per lock-step of {world} slabs = {gpu / world:.3f} ms per rank (host enqueue {(t1 - t0) / n * 1e3:.3f} ms)")
