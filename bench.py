@@ -260,7 +260,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev):
                             global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]],
                             cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
                             parallelism=("1 GPU" if world == 1 else
-                                         f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 4 sweeps per exchange"),
+                                         f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 6 sweeps per exchange"),
                             launch="hip-graph replay" if graph_used else "eager",
                             weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
                 step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -295,7 +295,7 @@ def main():
         also = run_workload("plume2d_1024_cnn", min(a.steps, 20), min(a.warmup, 5), not a.no_graph, 1, 0, dev)
         out["also"] = {k: also[k] for k in ("value", "unit", "steps_per_s", "ms_per_step", "config", "roofline", "kernel_ms_per_step")}
     if rank == 0:
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # the host baseline is reported with the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(WORKLOADS[name])
         print(json.dumps(out))
     if world > 1:
