@@ -366,7 +366,10 @@ __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const u
 // VALU budget per cell-update: the obstacle-free path (wave-uniform test per plane) is 6 adds + the /6 + the 'cont'
 // blend; with obstacles each neighbour costs a v_bfe_i32 + v_bfi_b32 more.
 // Measured alternatives at 16.7M cells (us per pass): Z2R=4 at 4 waves/SIMD 48-52; Z2R=3 at 5 waves/SIMD 49-53;
-// Z2R=2 at 6 waves/SIMD 53-59; Z2R=8 at 2 waves/SIMD 59-61.
+// Z2R=2 at 6 waves/SIMD 53-59; Z2R=8 at 2 waves/SIMD 59-61; a two-step-deep load pipeline (loads into the ring slots
+// that die mid-step) 48.6-51.4, i.e. no change; a third select-free path for all-'cont' planes 49.5-53.4.  At 255 MB
+// of HBM traffic per pass the kernel moves 5.3 TB/s: it sits on the HBM bound of a 2-sweep pass, and more sweeps per
+// pass in registers would pay (R+2K)/R redundant rows.
 // ---------------------------------------------------------------------------------------------------
 constexpr int Z2R = 4, Z2NW = 1;
 constexpr int Z2WPS = 4;                   // waves per SIMD the register budget is sized for
