@@ -75,13 +75,16 @@ int method_of(const std::string& m) {
 }
 
 // ---- the reference's three entry points -------------------------------------------------------------
+// `out` (not in the reference): write into an existing tensor -- with a compute window (set_window) the z-slab driver
+// fills one advected field from several calls.
 Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::string method, int bnd,
-                     const bool sample_outside_fluid, const float maccormack_strength) {
+                     const bool sample_outside_fluid, const float maccormack_strength, c10::optional<Tensor> out) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
   check_vel(U, g, "U"); check_scalar(src, g, "src");
   c10::hip::HIPGuard guard(flags.get_device());
-  Tensor dst = at::empty_like(src);
+  Tensor dst = (out.has_value() && out->defined()) ? *out : at::empty_like(src);
+  check_scalar(dst, g, "out");
   Workspace ws(g, FNX_OP_ADVECT_SCALAR, src);
   check_status(fnx_advect_scalar(&g, dt, src.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
                                  dst.data_ptr<float>(), method_of(method), bnd, sample_outside_fluid,
@@ -90,12 +93,13 @@ Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::st
 }
 
 Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::string method, int bnd,
-                  const float maccormack_strength) {
+                  const float maccormack_strength, c10::optional<Tensor> out) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
   check_vel(U, g, "U"); check_vel(orig, g, "orig");
   c10::hip::HIPGuard guard(flags.get_device());
-  Tensor dst = at::empty_like(U);
+  Tensor dst = (out.has_value() && out->defined()) ? *out : at::empty_like(U);
+  check_vel(dst, g, "out");
   Workspace ws(g, FNX_OP_ADVECT_VEL, U);
   check_status(fnx_advect_vel(&g, dt, orig.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
                               dst.data_ptr<float>(), method_of(method), bnd, maccormack_strength, ws.ptr, ws.bytes,
@@ -381,8 +385,11 @@ int64_t step_workspace_bytes(int B, int D, int H, int W, bool is3D) {
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // reference entry points (fluids_init.cpp:1009-1014)
-  m.def("advect_scalar", &advect_scalar, "Advect Scalar");
-  m.def("advect_vel", &advect_vel, "Advect Velocity");
+  m.def("advect_scalar", &advect_scalar, "Advect Scalar", py::arg("dt"), py::arg("src"), py::arg("U"), py::arg("flags"),
+        py::arg("method"), py::arg("boundary_width"), py::arg("sample_outside_fluid"), py::arg("maccormack_strength"),
+        py::arg("out") = py::none());
+  m.def("advect_vel", &advect_vel, "Advect Velocity", py::arg("dt"), py::arg("orig"), py::arg("U"), py::arg("flags"),
+        py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none());
   m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method");
   // operators the reference implements in Python
   m.def("velocity_divergence", &velocity_divergence);

@@ -112,11 +112,11 @@ class NativeOps:
     def set_window(self, k_begin, k_end):
         self.ext.set_window(int(k_begin), int(k_end))
 
-    def advect_scalar(self, dt, rho, U, flags, strength, sample_outside):
-        return self.ext.advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, bool(sample_outside), strength)
+    def advect_scalar(self, dt, rho, U, flags, strength, sample_outside, out=None):
+        return self.ext.advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, bool(sample_outside), strength, out)
 
-    def advect_vel(self, dt, U, flags, strength):
-        return self.ext.advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, strength)
+    def advect_vel(self, dt, U, flags, strength, out=None):
+        return self.ext.advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, strength, out)
 
     def pre_projection(self, U_adv, rho_adv, st, cfg):
         gv = cfg["gravityVec"]
@@ -184,17 +184,38 @@ class SlabSimulator:
             ops.begin_step()
         # advection reaches <= 2 planes beyond its inputs at CFL <= 1 and the BC/buoyancy/divergence stage one more:
         # 4 fresh ghost planes of U and density are enough (the arrays keep `halo` planes for the pressure solve)
-        yield "xchg", [st["U"], st["density"]], min(4, l.halo)
-        ops.set_slab(l.z_offset, l.D_global)
-        # Compute windows: only the owned planes (+1 for the advected fields, whose +1 neighbours the divergence reads)
-        # are produced; ghost planes are refreshed by the exchanges anyway.  Ranks at the domain ends own their border.
         window = getattr(ops, "set_window", None)
         lo_, top_ = l.lo, l.lo + l.owned
-        if window and l.world > 1:
-            window(max(lo_ - 1, 0), min(top_ + 1, l.D_local))
-        rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], float(cfg["maccormackStrength"]),
-                                    cfg.get("sampleOutsideFluid", False))
-        U_adv = ops.advect_vel(dt, st["U"], st["flags"], float(cfg["maccormackStrength"]))
+        strength, so = float(cfg["maccormackStrength"]), cfg.get("sampleOutsideFluid", False)
+        # Compute windows: only the owned planes (+1 for the advected fields, whose +1 neighbours the divergence reads)
+        # are produced; ghost planes are refreshed by the exchanges anyway.  Ranks at the domain ends own their border.
+        a_, b_ = max(lo_ - 1, 0), min(top_ + 1, l.D_local)
+        # planes whose advection reads no ghost plane (output k reads k-3..k+3 at CFL <= 1)
+        ia_ = lo_ + 3 if l.rank > 0 else a_
+        ib_ = top_ - 3 if l.rank < l.world - 1 else b_
+        if window and l.world > 1 and ib_ - ia_ >= 8:
+            # the ghost exchange of U and density is in flight while the interior planes are advected
+            yield "start", [st["U"], st["density"]], min(4, l.halo)
+            ops.set_slab(l.z_offset, l.D_global)
+            rho_adv, U_adv = torch.empty_like(st["density"]), torch.empty_like(st["U"])
+            window(ia_, ib_)
+            ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so, out=rho_adv)
+            ops.advect_vel(dt, st["U"], st["flags"], strength, out=U_adv)
+            window(0, 0)
+            yield ("wait",)
+            ops.set_slab(l.z_offset, l.D_global)
+            for ea, eb in ((a_, ia_), (ib_, b_)):
+                if eb > ea:
+                    window(ea, eb)
+                    ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so, out=rho_adv)
+                    ops.advect_vel(dt, st["U"], st["flags"], strength, out=U_adv)
+        else:
+            yield "xchg", [st["U"], st["density"]], min(4, l.halo)
+            ops.set_slab(l.z_offset, l.D_global)
+            if window and l.world > 1:
+                window(a_, b_)
+            rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so)
+            U_adv = ops.advect_vel(dt, st["U"], st["flags"], strength)
         if window and l.world > 1:
             window(lo_, top_)
         div = ops.pre_projection(U_adv, rho_adv, st, cfg)

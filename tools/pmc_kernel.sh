@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 i=0
 for grp in "${groups[@]}"; do
   d=$out/pass$i; mkdir -p $d
-  rocprofv3 --pmc $grp --kernel-trace -d $d -o r --output-format csv -- "$@" > $d/cmd.log 2>&1
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $d -o r --output-format csv -- "$@" > $d/cmd.log 2>&1
   rm -f $d/r_kernel_trace.csv
   i=$((i+1))
 done
