@@ -301,8 +301,8 @@ def test_sim64_optional_stages_vs_reference(dev, golden):
 
 
 # ---- properties at benchmark sizes ----------------------------------------------------------------------
-@pytest.mark.parametrize("size", [(1, 1024, 1024), (1, 2048, 2048), (64, 128, 128)])
-def test_properties_full_size(fl, dev, size):
+@pytest.mark.parametrize("size", [(1, 1024, 1024), (1, 2048, 2048), (64, 128, 128), (256, 256, 256), (64, 512, 512)])
+def test_properties_full_size(fl, ext, dev, size):
     D, H, W = size
     is3d = D > 1
     nc = 3 if is3d else 2
@@ -324,6 +324,11 @@ def test_properties_full_size(fl, dev, size):
     p1, _ = fl.solveLinearSystemJacobi(flags, div, is3d, 0.0, 16)
     p2, _ = fl.solveLinearSystemJacobi(flags, 2 * div, is3d, 0.0, 16)
     assert torch.equal(2 * p1, p2)
+    # launch plans agree: 16 sweeps from zero == 6 sweeps from zero continued by 10 more (pairs, a first pass that
+    # knows p = 0, plane chunking: all different between the two routes)
+    p6, _ = fl.solveLinearSystemJacobi(flags, div, is3d, 0.0, 6)
+    ext.jacobi_sweeps_(flags, div, p6, is3d, 10)
+    assert torch.equal(p6, p1)
     # setWallBcs is idempotent; divergence of a projected field shrinks
     U = (torch.randn(1, nc, D, H, W, generator=g)).to(dev)
     Ua = fl.setWallBcs(U.clone(), flags); Ub = fl.setWallBcs(Ua.clone(), flags)
