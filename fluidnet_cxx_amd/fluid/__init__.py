@@ -15,7 +15,8 @@ CellType = IntEnum("CellType", dict(TypeNone=0, TypeFluid=1, TypeObstacle=2, Typ
 from .ops import (advectScalar, advectVelocity, correctScalar, solveLinearSystemJacobi, velocityDivergence,
                   velocityUpdate, addBuoyancy, addGravity, addViscosity, setWallBcs, flagsToOccupancy, setConstVals, getDx)
 from .init_conditions import emptyDomain, createPlumeBCs, createRayleighTaylorBCs
+from .geometry_utils import createCylinder, createBox2D
 
 __all__ = ["CellType", "advectScalar", "advectVelocity", "correctScalar", "solveLinearSystemJacobi",
            "velocityDivergence", "velocityUpdate", "addBuoyancy", "addGravity", "addViscosity", "setWallBcs", "flagsToOccupancy", "setConstVals",
-           "getDx", "emptyDomain", "createPlumeBCs", "createRayleighTaylorBCs"]
+           "getDx", "emptyDomain", "createPlumeBCs", "createRayleighTaylorBCs", "createCylinder", "createBox2D"]

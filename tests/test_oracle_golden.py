@@ -75,6 +75,23 @@ def test_generators(oracle, golden):
             assert_bitexact(st[k], z[f"plume{res}_{k}"], k)
 
 
+def test_geometry_generators(golden):
+    """createCylinder against the reference's flags (2D and 3D); createBox2D (the reference's cannot run) against its
+    documented meaning.  Host logic: plain torch on whatever device the flags live on."""
+    import torch
+    from fluidnet_cxx_amd.fluid import geometry_utils as G
+    from util import make_flags
+    z = golden("generators")
+    for tag, shape in (("cyl2d", (1, 1, 40, 32)), ("cyl3d", (1, 5, 24, 28))):
+        bd = dict(flags=torch.from_numpy(make_flags(*shape, boxes=False)))
+        G.createCylinder(bd, 15.5, 20.0, 6.3)
+        assert_bitexact(bd["flags"].numpy(), z[tag + "_flags"], tag)
+    bd = dict(flags=torch.from_numpy(make_flags(1, 1, 20, 30, boxes=False)))
+    G.createBox2D(bd, 5, 9, 3, 6)
+    want = make_flags(1, 1, 20, 30, boxes=False); want[0, 0, 0, 3:6, 5:9] = 2
+    assert_bitexact(bd["flags"].numpy(), want, "box2d")
+
+
 def test_cnn_tolerance(oracle, golden):
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     c = golden("cnn")

@@ -305,6 +305,12 @@ def gen_generators(torch, lib, ext):
     fluid.emptyDomain(bd["flags"])
     fluid.createRayleighTaylorBCs(bd, dict(perturbThickness=100, perturbAmplitude=0.01, height=0.5), -0.01, 0.01)
     out["rt_density"] = bd["density"].numpy().astype(np.float32)
+    # createCylinder (geometry_utils.py:4-34) on a 2D and a 3D grid
+    for tag, shape in (("cyl2d", (1, 1, 1, 40, 32)), ("cyl3d", (1, 1, 5, 24, 28))):
+        cd = dict(flags=torch.zeros(shape))
+        fluid.emptyDomain(cd["flags"])
+        lib.fluid.geometry_utils.createCylinder(cd, 15.5, 20.0, 6.3) if hasattr(lib.fluid, "geometry_utils") else None
+        out[tag + "_flags"] = cd["flags"].numpy().copy()
     np.savez_compressed(os.path.join(OUT, "generators.npz"), **out)
     print("  wrote generators.npz")
 
