@@ -12,6 +12,8 @@ def __getattr__(name):
         return importlib.import_module(".fluid", __name__)
     if name == "simulate":
         return importlib.import_module("._simulate", __name__).simulate
+    if name in ("save_restart", "load_restart", "rollout"):
+        return getattr(importlib.import_module(".state_io", __name__), name)
     if name in ("FluidNet", "MultiScaleNet"):
         return getattr(importlib.import_module(".model", __name__), name)
     raise AttributeError(name)

@@ -89,3 +89,21 @@ def test_weights_deterministic_and_param_count():
     w3 = make_scalenet_weights(1)
     assert not (w1["multiScale.final.weight"] == w3["multiScale.final.weight"]).all()
     assert abs(float(w1["multiScale.convN_1.encode.2.weight"].mean())) < 1e-2
+
+
+def test_restart_file_round_trip(tmp_path):
+    """The reference drivers' checkpoint format ({'batch_dict', 'it'} via torch.save, plume.py:168-175,423-424)."""
+    import torch
+    from fluidnet_cxx_amd import load_restart, save_restart
+    from util import plume_state
+    st = {k: torch.from_numpy(v) for k, v in plume_state(16).items()}
+    st["U"] += 0.25
+    f = tmp_path / "restart.pth"
+    save_restart(str(f), st, 17)
+    raw = torch.load(str(f), weights_only=False)                      # what the reference's restart branch sees
+    assert set(raw) == {"batch_dict", "it"} and raw["it"] == 17 and torch.equal(raw["batch_dict"]["U"], st["U"])
+    bd, it = load_restart(str(f), torch.device("cpu"))
+    assert it == 17 and all(torch.equal(bd[k], st[k]) for k in st)
+    torch.save({"batch_dict": {k: v.double() if k == "density" else v for k, v in st.items()}, "it": 3}, str(f))
+    bd, it = load_restart(str(f), torch.device("cpu"))                # a foreign file: dtype normalised
+    assert it == 3 and bd["density"].dtype == torch.float32 and bd["density"].is_contiguous()

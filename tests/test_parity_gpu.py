@@ -286,6 +286,22 @@ def test_static_flags_reuses_mask_3d(dev, oracle, ext):
         assert_bitexact(runs[1][k], st[k], f"{k} (mask reused)")
 
 
+def test_rollout_batch_of_two(dev, oracle):
+    """Long-term loop with batch > 1 (fluid_net_train.py:349-373): every sample evolves exactly as it does alone."""
+    from fluidnet_cxx_amd import rollout
+    sts = [plume_state(48), plume_state(48)]
+    sts[1]["U"] = sts[1]["U"] + np.float32(0.3)
+    sts[1]["density"] = sts[1]["density"] + np.float32(0.05)
+    bd = to_dev({k: np.concatenate([sts[0][k], sts[1][k]], 0) for k in sts[0]}, dev)
+    rollout(PLUME_CFG, bd, None, "jacobi", 4)
+    for b in range(2):
+        st = sts[b]
+        for _ in range(4):
+            st = oracle.simulate_step(st, PLUME_CFG, "jacobi")
+        for k in ("U", "density", "p"):
+            assert_bitexact(N(bd[k])[b:b + 1], st[k], f"sample {b}: {k}")
+
+
 def test_sim64_optional_stages_vs_reference(dev, golden):
     """viscosity + correctScalar + gravity + periodic patches through simulate(): bit-exact against the reference."""
     from fluidnet_cxx_amd import simulate
