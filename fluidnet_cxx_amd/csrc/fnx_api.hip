@@ -442,6 +442,8 @@ int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxStat
   if (int rc = check_grid(g)) return rc;
   if (!prm || !st || !st->U || !st->flags || !U_adv) return fail(FNX_EINVAL, "pre_projection: NULL state");
   if (rho_adv && !st->density) return fail(FNX_EINVAL, "pre_projection: rho_adv given but state has no density");
+  // a cell reads the advected fields of its +1 / -1 neighbours while other threads write theirs: no in-place use
+  if (U_adv == st->U || (rho_adv && rho_adv == st->density)) return fail(FNX_EINVAL, "pre_projection: the advected fields must not alias the state");
   const bool has_rho = rho_adv != nullptr;
   const bool buoy = has_rho && prm->buoyancy_scale > 0.f;
   float sx = 0.f, sy = 0.f, sz = 0.f;
