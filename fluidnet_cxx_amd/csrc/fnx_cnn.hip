@@ -25,7 +25,13 @@ inline bool mfma16_layer(const ConvLayer& L) {
   return !thin_direct && L.k == 5 && (L.cin % 8 == 0 || L.cin <= 4) && L.cout <= 32;
 }
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+// Cout <= 8 (and a Cin the 8-channel stage fits): two x-adjacent pixels share one 16-row M block (conv5_mfma16_kernel PAIR)
+inline bool pair_layer(int cin, int cout) {
+  static const bool off = getenv("FNX_CONV_NOPAIR") != nullptr;       // A/B switch
+  return !off && cout <= 8 && cin % 8 == 0;
+}
 inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
+  if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
 }
@@ -69,6 +75,24 @@ __global__ void pack_layer_mfma16_kernel(const float* __restrict__ w, const floa
     const int r = q / cout_pad;
     const int ci = r % cin_pad, t = r / cin_pad;
     pw[q] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + t] : 0.f;
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
+}
+
+// blob: (Cout<=8,Cin,taps 5x5[x5]) -> packed [dz][r][wx 0..5][Cin padded to 4][dx*8 + cout]: the weight of tap (r, wx-dx)
+// for output pixel dx of a pair, zero where wx-dx is not one of the 5 taps
+__global__ void pack_layer_pair_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                       float* __restrict__ pw, float* __restrict__ pb, int cin, int cout, int kd,
+                                       int cin_pad) {
+  const int n = kd * 30 * cin_pad * 16;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int m = q % 16, r1 = q / 16;
+    const int ci = r1 % cin_pad, r2 = r1 / cin_pad;
+    const int wx = r2 % 6, r3 = r2 / 6;
+    const int r = r3 % 5, dz = r3 / 5;
+    const int dx = m >> 3, co = m & 7, sx = wx - dx;
+    const int taps = kd * 25;
+    pw[q] = (co < cout && ci < cin && sx >= 0 && sx < 5) ? w[((size_t)co * cin + ci) * taps + (dz * 5 + r) * 5 + sx] : 0.f;
   }
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
 }
@@ -338,20 +362,29 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CHS, int MB, bool IS3D>
+// PAIR (Cout <= 8): the 16 rows of the M block are (dx, cout) for TWO x-adjacent output pixels, the 16 columns are pixel
+// pairs, and k runs over a 6-wide window per tap row (weights zero where the tap falls outside an output's 5): 30
+// k-positions per row-plane instead of 2 x 25 half-empty ones -- 0.6x the MFMAs of the plain mapping for 32->8.
+template <int CHS, int MB, bool IS3D, bool PAIR>
 __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int cin_pad) {
-  constexpr int KS = 5, PAD = 2, NX = 4, PR = 2;
-  constexpr int ROWS = 4 * PR + KS - 1, COLS = 16 * NX + KS - 1;      // 12 x 68 halo tile per channel
+  constexpr int KS = 5, PAD = 2, PR = 2;
+  constexpr int NX = PAIR ? 2 : 4;                                    // MFMA column blocks per wave row (64 px either way)
+  constexpr int KW = PAIR ? KS + 1 : KS;                              // k positions along x per tap row
+  constexpr int XSEG = PAIR ? 32 : 16, XSTEP = PAIR ? 2 : 1;          // pixels per column block, pixel stride of a lane
+  static_assert(!PAIR || MB == 1, "pairs fill one M block");
+  constexpr int ROWS = 4 * PR + KS - 1, COLS = 64 + KS - 1;           // 12 x 68 halo tile per channel
   constexpr int CO = 16 * MB;
   constexpr int NEL = CHS * ROWS * COLS, NLD = (NEL + 255) / 256;
-  constexpr int TAPF = CHS * CO;                                      // floats per tap in a stage (128)
-  static_assert(TAPF == 128, "a wave-wide 16-byte load covers two taps");
-  constexpr int NWI = (KS * KS + 1) / 2;                              // wave-instructions per stage (13)
+  constexpr int TAPF = CHS * CO;                                      // floats per tap in a stage (128 or 64)
+  static_assert(TAPF == 128 || TAPF == 64, "a wave-wide 16-byte load covers 2 or 4 taps");
+  constexpr int TPI = 256 / TAPF, LPT = 64 / TPI;                     // taps per wave-instruction, lanes per tap
+  constexpr int NTAP = KS * KW;                                       // k positions per plane (25, or 30 for PAIR)
+  constexpr int NWI = (NTAP + TPI - 1) / TPI;                         // wave-instructions per stage
   __shared__ __attribute__((aligned(16))) float tile2[2][NEL];
   __shared__ __attribute__((aligned(16))) float wbuf[2][NWI * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg = lane & 15, kq = lane >> 4;
-  const int x0 = blockIdx.x * (16 * NX), y0 = blockIdx.y * (4 * PR);
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (4 * PR);
   int zb = blockIdx.z;
   const int z = zb % a.D; const int b = zb / a.D;
   const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
@@ -361,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = mb * 16 + 4 * kq + r;
+      const int co = PAIR ? (4 * kq + r) % 8 : mb * 16 + 4 * kq + r;
       const float bv = co < a.cout ? a.bias[co] : 0.f;
 #pragma unroll
       for (int pr = 0; pr < PR; ++pr)
@@ -398,9 +431,9 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
     for (int q = 0; q < (NWI + 3) / 4; ++q) {
       const int wi = wave + 4 * q;                        // wave-uniform
       if (wi < NWI) {
-        int tap = 2 * wi + (lane >> 5);
-        if (tap > KS * KS - 1) tap = KS * KS - 1;         // the 26th half re-reads tap 24 into slots nobody reads
-        const float* src = a.w + ((size_t)(dz * KS * KS + tap) * cin_pad + c0) * CO + (lane & 31) * 4;
+        int tap = TPI * wi + lane / LPT;
+        if (tap > NTAP - 1) tap = NTAP - 1;               // the tail re-reads the last tap into slots nobody reads
+        const float* src = a.w + ((size_t)(dz * NTAP + tap) * cin_pad + c0) * CO + (lane % LPT) * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(&wbuf[buf][wi * 256]), 16, 0, 0);
       }
@@ -422,21 +455,21 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
       stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CHS, (it + 1) & 1);
     }
     const float* wl = &wbuf[it & 1][kq * CO + seg];
-    const float* tl = &tile[kq * ROWS * COLS + (wave * PR) * COLS + seg];
+    const float* tl = &tile[kq * ROWS * COLS + (wave * PR) * COLS + XSTEP * seg];
     // (an explicit operand pipeline as in conv3_mfma_kernel measured slower here: 2.27 -> 2.74 ms at 128^3)
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      for (int s = 0; s < KW; ++s) {
 #pragma unroll
         for (int ks = 0; ks < CHS / 4; ++ks) {
           float av[MB], bv[PR][NX];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) av[mb] = wl[((r * KS + s) * CHS + ks * 4) * CO + mb * 16];
+          for (int mb = 0; mb < MB; ++mb) av[mb] = wl[((r * KW + s) * CHS + ks * 4) * CO + mb * 16];
 #pragma unroll
           for (int pr = 0; pr < PR; ++pr)
 #pragma unroll
-            for (int nx = 0; nx < NX; ++nx) bv[pr][nx] = tl[(ks * 4) * ROWS * COLS + (pr + r) * COLS + nx * 16 + s];
+            for (int nx = 0; nx < NX; ++nx) bv[pr][nx] = tl[(ks * 4) * ROWS * COLS + (pr + r) * COLS + nx * XSEG + s];
 #pragma unroll
           for (int pr = 0; pr < PR; ++pr)
 #pragma unroll
@@ -454,13 +487,13 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
     if (y >= a.H) continue;
 #pragma unroll
     for (int nx = 0; nx < NX; ++nx) {
-      const int x = x0 + nx * 16 + seg;
+      const int x = x0 + nx * XSEG + XSTEP * seg + (PAIR ? (kq >> 1) : 0);   // PAIR: rows 8..15 of the block are the +1 pixel
       if (x >= a.W) continue;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = mb * 16 + 4 * kq + r;
+          const int co = PAIR ? (4 * kq + r) % 8 : mb * 16 + 4 * kq + r;
           if (co < a.cout) {
             float v = acc[pr][nx][mb][r];
             if (a.relu) v = fmaxf(v, 0.f);
@@ -475,12 +508,15 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
 void launch_conv_mfma16(const ConvArgs& a, bool is3d, hipStream_t s) {
   const dim3 grid((a.W + 63) / 64, (a.H + 7) / 8, a.B * a.D);
   const int cin_pad = pad_to(a.cin, 4);
-  if (a.cin % 8 == 0 && a.cout <= 16) {
-    if (is3d) conv5_mfma16_kernel<8, 1, true><<<grid, 256, 0, s>>>(a, cin_pad);
-    else conv5_mfma16_kernel<8, 1, false><<<grid, 256, 0, s>>>(a, cin_pad);
+  if (pair_layer(a.cin, a.cout)) {
+    if (is3d) conv5_mfma16_kernel<4, 1, true, true><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<4, 1, false, true><<<grid, 256, 0, s>>>(a, cin_pad);
+  } else if (a.cin % 8 == 0 && a.cout <= 16) {
+    if (is3d) conv5_mfma16_kernel<8, 1, true, false><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<8, 1, false, false><<<grid, 256, 0, s>>>(a, cin_pad);
   } else {
-    if (is3d) conv5_mfma16_kernel<4, 2, true><<<grid, 256, 0, s>>>(a, cin_pad);
-    else conv5_mfma16_kernel<4, 2, false><<<grid, 256, 0, s>>>(a, cin_pad);
+    if (is3d) conv5_mfma16_kernel<4, 2, true, false><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<4, 2, false, false><<<grid, 256, 0, s>>>(a, cin_pad);
   }
 }
 
@@ -594,6 +630,9 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     if (mfma_layer(L))
       pack_layer_mfma_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 layer_taps(L, is3d));
+    else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
+      pack_layer_pair_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
+                                                is3d ? 5 : 1, pad_to(L.cin, 4));
     else if (mfma16_layer(L))
       pack_layer_mfma16_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                   layer_taps(L, is3d), pad_to(L.cin, 4), pad_to(L.cout, 16));
