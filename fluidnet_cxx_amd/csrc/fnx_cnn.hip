@@ -529,9 +529,17 @@ void launch_conv_mfma_t(const ConvArgs& a, bool is3d, hipStream_t s) {
 
 void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
   static const bool wide = getenv("FNX_CONV_WIDE") != nullptr;     // experiment switch: 128 output channels per wave
+  // small images (the quarter-resolution tower): shorter tiles (16 -> 8 -> 4 rows per block) until the launch has a
+  // block for every CU slot
+  const int ngrp = a.cout / (a.cout % 64 == 0 ? 64 : 32);
+  auto blocks = [&](int rows) { return (long)((a.W + 31) / 32) * ((a.H + rows - 1) / rows) * a.B * a.D * ngrp; };
+  const int pr = blocks(16) >= 512 ? 4 : (blocks(8) >= 512 ? 2 : 1);
   if (a.cout % 128 == 0 && wide) launch_conv_mfma_t<4, 2>(a, is3d, s);
-  else if (a.cout % 64 == 0) launch_conv_mfma_t<2, 4>(a, is3d, s);
-  else launch_conv_mfma_t<1, 4>(a, is3d, s);
+  else if (a.cout % 64 == 0) {
+    if (pr == 4) launch_conv_mfma_t<2, 4>(a, is3d, s); else if (pr == 2) launch_conv_mfma_t<2, 2>(a, is3d, s); else launch_conv_mfma_t<2, 1>(a, is3d, s);
+  } else {
+    if (pr == 4) launch_conv_mfma_t<1, 4>(a, is3d, s); else if (pr == 2) launch_conv_mfma_t<1, 2>(a, is3d, s); else launch_conv_mfma_t<1, 1>(a, is3d, s);
+  }
 }
 
 void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const PackedLayer& pl, const float* x, float* y,
