@@ -533,7 +533,8 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
   // block for every CU slot
   const int ngrp = a.cout / (a.cout % 64 == 0 ? 64 : 32);
   auto blocks = [&](int rows) { return (long)((a.W + 31) / 32) * ((a.H + rows - 1) / rows) * a.B * a.D * ngrp; };
-  const int pr = blocks(16) >= 512 ? 4 : (blocks(8) >= 512 ? 2 : 1);
+  static const int pr_env = [] { const char* e = getenv("FNX_CONV_PR"); return e ? atoi(e) : 0; }();   // experiment switch
+  const int pr = pr_env ? pr_env : (blocks(16) >= 512 ? 4 : (blocks(8) >= 512 ? 2 : 1));
   if (a.cout % 128 == 0 && wide) launch_conv_mfma_t<4, 2>(a, is3d, s);
   else if (a.cout % 64 == 0) {
     if (pr == 4) launch_conv_mfma_t<2, 4>(a, is3d, s); else if (pr == 2) launch_conv_mfma_t<2, 2>(a, is3d, s); else launch_conv_mfma_t<2, 1>(a, is3d, s);
