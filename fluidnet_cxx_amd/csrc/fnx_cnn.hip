@@ -203,16 +203,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_CHUNK = 8;       // input channels per LDS stage
 constexpr int MF_COLS = 34;       // 32 + halo
 
-template <int CB, int PR, bool IS3D>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
+// CH = input channels per LDS stage; WPS = waves per SIMD the register budget is sized for (2: 256 VGPRs, 3: 168)
+template <int CB, int PR, bool IS3D, int CH = MF_CHUNK, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
   constexpr int ROWS = 4 * PR + 2;
   constexpr int KD = IS3D ? 3 : 1;
   constexpr int RW = CB * 32;                    // output channels (floats) per weight row
-  constexpr int WROWS = 9 * MF_CHUNK;            // (tap, cin) rows per stage
+  constexpr int WROWS = 9 * CH;            // (tap, cin) rows per stage
   constexpr int LPR = RW / 4;                    // lanes per row at 16 B per lane
   constexpr int RPI = 64 / LPR;                  // rows per wave-wide global_load_lds
   constexpr int NWI = (WROWS + RPI - 1) / RPI;   // wave-instructions per stage
-  __shared__ __attribute__((aligned(16))) float tile2[2][MF_CHUNK * ROWS * MF_COLS];     // halo tile, double-buffered
+  __shared__ __attribute__((aligned(16))) float tile2[2][CH * ROWS * MF_COLS];     // halo tile, double-buffered
   __shared__ __attribute__((aligned(16))) float wbuf[2][NWI * 256];    // weights of the stage, [tap][cin][cout], double-buffered
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -236,10 +237,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
   }
 
   const float* xb = a.x + (size_t)b * a.cin * vol;
-  // Per-thread staging slots: element idx = threadIdx.x + 256*t of the [MF_CHUNK][ROWS][34] halo tile.  The global
+  // Per-thread staging slots: element idx = threadIdx.x + 256*t of the [CH][ROWS][34] halo tile.  The global
   // offset (relative to the chunk's first channel and the z plane) and the in-image predicate never change, so they
   // are computed once; each stage is then NLD independent loads issued back to back (clamped address + select).
-  constexpr int NEL = MF_CHUNK * ROWS * MF_COLS;
+  constexpr int NEL = CH * ROWS * MF_COLS;
   constexpr int NLD = (NEL + 255) / 256;
   int goff[NLD];
   unsigned valid = 0;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
     const int row = rem / MF_COLS, col = rem - row * MF_COLS;
     const int gx = x0 - 1 + col, gy = y0 - 1 + row;
     const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    goff[t] = ok ? (int)((size_t)cc * vol + (size_t)gy * a.W + gx) : 0;      // vol*MF_CHUNK < 2^31 is checked by the host
+    goff[t] = ok ? (int)((size_t)cc * vol + (size_t)gy * a.W + gx) : 0;      // vol*CH < 2^31 is checked by the host
     valid |= (unsigned)ok << t;
   }
   float stage[NLD];
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       if (wi < NWI) {
         int row = wi * RPI + lane / LPR;
         if (row > WROWS - 1) row = WROWS - 1;           // tail lanes re-read the last row (their LDS slots are never used)
-        const int tap = row / MF_CHUNK, ci = row - tap * MF_CHUNK;
+        const int tap = row / CH, ci = row - tap * CH;
         const float* src = a.w + ((size_t)(dz * 9 + tap) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(&wbuf[buf][wi * 256]), 16, 0, 0);
@@ -278,13 +279,13 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
     }
   };
   // iteration space: (dz, c0) pairs with an in-range z plane
-  const int nchunk = a.cin / MF_CHUNK;
+  const int nchunk = a.cin / CH;
   int dz_lo = 0, dz_hi = KD;
   if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = KD - 1; }
   const int niter = (dz_hi - dz_lo) * nchunk;
   if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, 0); }
   for (int it = 0; it < niter; ++it) {
-    const int dz = dz_lo + it / nchunk, c0 = (it % nchunk) * MF_CHUNK;
+    const int dz = dz_lo + it / nchunk, c0 = (it % nchunk) * CH;
     // Both LDS images are double-buffered: buffer (it&1) was last read in iteration it-2 and every wave has passed
     // the barrier of iteration it-1 since, so it can be overwritten without a barrier in front -> one barrier per stage.
     float* tile = tile2[it & 1];
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = ((valid >> t) & 1) ? stage[t] : 0.f;
     __syncthreads();                                   // tile stores + the stage's weight DMA (vmcnt(0)) visible to all
     if (it + 1 < niter) {                              // both in flight during the MFMAs
-      prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK);
-      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * MF_CHUNK, (it + 1) & 1);
+      prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CH);
+      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CH, (it + 1) & 1);
     }
     {
       // Operand pipeline: the A/B values of group g+1 (one tap x 2 channels: CB + PR LDS values) are read while the
@@ -303,13 +304,13 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       const float* wl = &wbuf[it & 1][l31 + half * RW];
       const float* tl = &tile[half * ROWS * MF_COLS + (wave * PR) * MF_COLS + l31];
       (void)dz; (void)c0;
-      constexpr int NCP = MF_CHUNK / 2, NG = 9 * NCP;
+      constexpr int NCP = CH / 2, NG = 9 * NCP;
       float av[2][CB], bv[2][PR];
       auto load_group = [&](int g, float (&A)[CB], float (&B)[PR]) __attribute__((always_inline)) {
         const int tap = g / NCP, cp = (g % NCP) * 2;
         const int r = tap / 3, sx = tap - 3 * r;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) A[cb] = wl[(tap * MF_CHUNK + cp) * RW + cb * 32];
+        for (int cb = 0; cb < CB; ++cb) A[cb] = wl[(tap * CH + cp) * RW + cb * 32];
 #pragma unroll
         for (int pr = 0; pr < PR; ++pr) B[pr] = tl[cp * ROWS * MF_COLS + (pr + r) * MF_COLS + sx];
       };
@@ -520,11 +521,11 @@ void launch_conv_mfma16(const ConvArgs& a, bool is3d, hipStream_t s) {
   }
 }
 
-template <int CB, int PR>
+template <int CB, int PR, int CH = MF_CHUNK, int WPS = 2>
 void launch_conv_mfma_t(const ConvArgs& a, bool is3d, hipStream_t s) {
   const dim3 grid((a.W + 31) / 32, (a.H + 4 * PR - 1) / (4 * PR), a.B * a.D * (a.cout / (CB * 32)));
-  if (is3d) conv3_mfma_kernel<CB, PR, true><<<grid, 256, 0, s>>>(a);
-  else conv3_mfma_kernel<CB, PR, false><<<grid, 256, 0, s>>>(a);
+  if (is3d) conv3_mfma_kernel<CB, PR, true, CH, WPS><<<grid, 256, 0, s>>>(a);
+  else conv3_mfma_kernel<CB, PR, false, CH, WPS><<<grid, 256, 0, s>>>(a);
 }
 
 void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
@@ -535,6 +536,8 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
   auto blocks = [&](int rows) { return (long)((a.W + 31) / 32) * ((a.H + rows - 1) / rows) * a.B * a.D * ngrp; };
   static const int pr_env = [] { const char* e = getenv("FNX_CONV_PR"); return e ? atoi(e) : 0; }();   // experiment switch
   const int pr = pr_env ? pr_env : (blocks(16) >= 512 ? 4 : (blocks(8) >= 512 ? 2 : 1));
+  static const bool occ3 = getenv("FNX_CONV_OCC3") != nullptr;     // experiment: 8-row tiles, 4-channel stages, 3 waves/SIMD
+  if (occ3 && a.cout % 64 == 0 && a.cin % 4 == 0) { launch_conv_mfma_t<2, 2, 4, 3>(a, is3d, s); return; }
   if (a.cout % 128 == 0 && wide) launch_conv_mfma_t<4, 2>(a, is3d, s);
   else if (a.cout % 64 == 0) {
     if (pr == 4) launch_conv_mfma_t<2, 4>(a, is3d, s); else if (pr == 2) launch_conv_mfma_t<2, 2>(a, is3d, s); else launch_conv_mfma_t<2, 1>(a, is3d, s);
