@@ -34,12 +34,10 @@ __device__ __forceinline__ CellId cell_id(const GridDims& g) {
 // (what getClampBounds :175-178 derives from fwd_pos).
 // ---------------------------------------------------------------------------------------------------
 template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
-__global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt, const float* __restrict__ src,
+__device__ __forceinline__ void sl_scalar_cell(const GridDims& g, const CellId& c, float dt, const float* __restrict__ src,
                                                            const float* __restrict__ U,
                                                            const float* __restrict__ flags, float* __restrict__ dst,
                                                            int* __restrict__ cell_out) {
-  const CellId c = cell_id<IS3D>(g);
-  if (!c.valid) return;
   constexpr int NC = IS3D ? 3 : 2;
   const Field fs{src + (size_t)c.b * g.DHW}, ff{flags + (size_t)c.b * g.DHW}, fu{U + (size_t)c.b * NC * g.DHW};
   const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
@@ -66,6 +64,16 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt,
     const int k0 = (IS3D && !QUIRKS) ? clampi((int)p[2], 0, g.Dglob - 1) - g.zoff : -g.zoff;
     cell_out[(size_t)c.b * g.DHW + o] = (k0 + 1) * g.HW + j0 * g.W + i0;
   }
+}
+
+template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void sl_scalar_kernel(GridDims g, float dt, const float* __restrict__ src,
+                                                           const float* __restrict__ U,
+                                                           const float* __restrict__ flags, float* __restrict__ dst,
+                                                           int* __restrict__ cell_out) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  sl_scalar_cell<IS3D, QUIRKS, SAMPLE_OUTSIDE>(g, c, dt, src, U, flags, dst, cell_out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void box_minmax_kernel(GridDims g, const float
 
 // Backward pass on fwd + MacCormackCorrect (:135-148) + MacCormackClampFluidNet (:154-263)
 template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
-__global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g, float dt, float half_s,
+__device__ __forceinline__ void sl_scalar_bwd_clamp_cell(const GridDims& g, const CellId& c, float dt, float half_s,
                                                                      const float* __restrict__ src,
                                                                      const float* __restrict__ fwd,
                                                                      const int* __restrict__ cell_in,
@@ -171,8 +179,6 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
                                                                      const float* __restrict__ flags,
                                                                      const float2* __restrict__ box,
                                                                      float* __restrict__ dst) {
-  const CellId c = cell_id<IS3D>(g);
-  if (!c.valid) return;
   constexpr int NC = IS3D ? 3 : 2;
   const Field fs{src + (size_t)c.b * g.DHW}, fw{fwd + (size_t)c.b * g.DHW}, ff{flags + (size_t)c.b * g.DHW},
       fu{U + (size_t)c.b * NC * g.DHW};
@@ -246,6 +252,20 @@ __global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g,
   dst[(size_t)c.b * g.DHW + o] = d;
 }
 
+template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void sl_scalar_bwd_clamp_kernel(GridDims g, float dt, float half_s,
+                                                                     const float* __restrict__ src,
+                                                                     const float* __restrict__ fwd,
+                                                                     const int* __restrict__ cell_in,
+                                                                     const float* __restrict__ U,
+                                                                     const float* __restrict__ flags,
+                                                                     const float2* __restrict__ box,
+                                                                     float* __restrict__ dst) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  sl_scalar_bwd_clamp_cell<IS3D, QUIRKS, SAMPLE_OUTSIDE>(g, c, dt, half_s, src, fwd, cell_in, U, flags, box, dst);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Velocity: SemiLagrangeEulerFluidNetMAC (:388-451), no line trace.
 // ---------------------------------------------------------------------------------------------------
@@ -261,11 +281,9 @@ __device__ __forceinline__ float sl_mac_component(const GridDims& g, const Field
 }
 
 template <bool IS3D, bool QUIRKS>
-__global__ __launch_bounds__(BX* BY) void sl_mac_kernel(GridDims g, float dt, const float* __restrict__ src,
+__device__ __forceinline__ void sl_mac_cell(const GridDims& g, const CellId& c, float dt, const float* __restrict__ src,
                                                         const float* __restrict__ U, const float* __restrict__ flags,
                                                         float* __restrict__ dst) {
-  const CellId c = cell_id<IS3D>(g);
-  if (!c.valid) return;
   constexpr int NC = IS3D ? 3 : 2;
   const Field fs{src + (size_t)c.b * NC * g.DHW}, fu{U + (size_t)c.b * NC * g.DHW};
   const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
@@ -283,6 +301,15 @@ __global__ __launch_bounds__(BX* BY) void sl_mac_kernel(GridDims g, float dt, co
   float* d = dst + (size_t)c.b * NC * g.DHW + o;
 #pragma unroll
   for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = r[a];
+}
+
+template <bool IS3D, bool QUIRKS>
+__global__ __launch_bounds__(BX* BY) void sl_mac_kernel(GridDims g, float dt, const float* __restrict__ src,
+                                                        const float* __restrict__ U, const float* __restrict__ flags,
+                                                        float* __restrict__ dst) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  sl_mac_cell<IS3D, QUIRKS>(g, c, dt, src, U, flags, dst);
 }
 
 // min/max of channel `comp` of orig over the 4(8) corners at trunc(pos -/+ v)  (doClampComponentMAC :500-614)
@@ -346,14 +373,12 @@ __device__ __forceinline__ float mac_bwd_correct_clamp(const GridDims& g, const 
 }
 
 template <bool IS3D, bool QUIRKS>
-__global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, float dt, float half_s,
+__device__ __forceinline__ void sl_mac_bwd_clamp_cell(const GridDims& g, const CellId& c, float dt, float half_s,
                                                                   const float* __restrict__ orig,
                                                                   const float* __restrict__ fwd,
                                                                   const float* __restrict__ U,
                                                                   const float* __restrict__ flags,
                                                                   float* __restrict__ dst) {
-  const CellId c = cell_id<IS3D>(g);
-  if (!c.valid) return;
   constexpr int NC = IS3D ? 3 : 2;
   const Field fo{orig + (size_t)c.b * NC * g.DHW}, fw{fwd + (size_t)c.b * NC * g.DHW},
       fu{U + (size_t)c.b * NC * g.DHW}, ff{flags + (size_t)c.b * g.DHW};
@@ -368,6 +393,50 @@ __global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, fl
   float* d = dst + (size_t)c.b * NC * g.DHW + o;
 #pragma unroll
   for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = r[a];
+}
+
+template <bool IS3D, bool QUIRKS>
+__global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, float dt, float half_s,
+                                                                  const float* __restrict__ orig,
+                                                                  const float* __restrict__ fwd,
+                                                                  const float* __restrict__ U,
+                                                                  const float* __restrict__ flags,
+                                                                  float* __restrict__ dst) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  sl_mac_bwd_clamp_cell<IS3D, QUIRKS>(g, c, dt, half_s, orig, fwd, U, flags, dst);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2D: the density and the velocity MacCormack advections of one time step in two launches instead of four (forward
+// passes together, backward/clamp passes together).  At 128^2 .. 1024^2 each pass is a 7-14 us launch that is mostly
+// ramp-up; the cell functions are the ones above, so the results are the same bits.
+// ---------------------------------------------------------------------------------------------------
+template <bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void advect2d_fwd_kernel(GridDims g, float dt, const float* __restrict__ rho,
+                                                              const float* __restrict__ U,
+                                                              const float* __restrict__ flags,
+                                                              float* __restrict__ rho_fwd, int* __restrict__ cell_out,
+                                                              float* __restrict__ U_fwd) {
+  const CellId c = cell_id<false>(g);
+  if (!c.valid) return;
+  sl_scalar_cell<false, false, SAMPLE_OUTSIDE>(g, c, dt, rho, U, flags, rho_fwd, cell_out);
+  sl_mac_cell<false, false>(g, c, dt, U, U, flags, U_fwd);
+}
+
+template <bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void advect2d_bwd_kernel(GridDims g, float dt, float half_s,
+                                                              const float* __restrict__ rho,
+                                                              const float* __restrict__ rho_fwd,
+                                                              const int* __restrict__ cell_in,
+                                                              const float* __restrict__ U,
+                                                              const float* __restrict__ U_fwd,
+                                                              const float* __restrict__ flags,
+                                                              float* __restrict__ rho_dst, float* __restrict__ U_dst) {
+  const CellId c = cell_id<false>(g);
+  if (!c.valid) return;
+  sl_scalar_bwd_clamp_cell<false, false, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, nullptr, rho_dst);
+  sl_mac_bwd_clamp_cell<false, false>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
 }
 
 inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
@@ -423,6 +492,20 @@ void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const fl
                    const float* flags, float* dst, hipStream_t s) {
   const dim3 grid = cell_grid(g), block(BX, BY);
   DISPATCH2(is3d, quirks, sl_mac_kernel, <<<grid, block, 0, s>>>(g, dt, src, U, flags, dst));
+}
+
+// 2D MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches
+void launch_advect2d_fused(const GridDims& g, bool sample_outside, float dt, float half_s, const float* rho, const float* U,
+                           const float* flags, float* rho_fwd, int* cell, float* U_fwd, float* rho_dst, float* U_dst,
+                           hipStream_t s) {
+  const dim3 grid = cell_grid(g), block(BX, BY);
+  if (sample_outside) {
+    advect2d_fwd_kernel<true><<<grid, block, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd);
+    advect2d_bwd_kernel<true><<<grid, block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst);
+  } else {
+    advect2d_fwd_kernel<false><<<grid, block, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd);
+    advect2d_bwd_kernel<false><<<grid, block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst);
+  }
 }
 
 void launch_sl_mac_bwd_clamp(const GridDims& g, bool is3d, bool quirks, float dt, float half_s, const float* orig,

@@ -69,7 +69,9 @@ size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 :
 size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + (g->is3D ? al(ncell(g)) : 0); }
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
-  size_t adv = ws_advect_scalar(g) > ws_advect_vel(g) ? ws_advect_scalar(g) : ws_advect_vel(g);
+  // 2D: the fused advection launches keep both forward fields at once
+  size_t adv = g->is3D ? (ws_advect_scalar(g) > ws_advect_vel(g) ? ws_advect_scalar(g) : ws_advect_vel(g))
+                       : ws_advect_scalar(g) + ws_advect_vel(g);
   size_t solve = ws_jacobi(g);
   size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D);
   size_t tail = adv > solve ? adv : solve;
@@ -499,12 +501,25 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   if (!c.ok() || ws_bytes < ws_step(g)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small (%zu < %zu)", ws_bytes, ws_step(g));
   const bool has_rho = st->density != nullptr;
   // simulate.py:75-93: advect density then velocity (both by the OLD U)
-  if (has_rho) {
-    if (int rc = fnx_advect_scalar(g, prm->dt, st->density, st->U, st->flags, rho2, FNX_ADVECT_MACCORMACK, 1,
-                                   prm->sample_outside_fluid, prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
+  static const bool no_fuse = getenv("FNX_ADVECT_NOFUSE") != nullptr;       // A/B switch
+  if (has_rho && !g->is3D && !no_fuse) {
+    // 2D: forward passes of both advections in one launch, backward/clamp passes in another (same cell functions)
+    Carver t(tail, tail_bytes);
+    float* rho_fwd = (float*)t.take(n * 4);
+    int* cell = (int*)t.take(n * 4);
+    float* U_fwd = (float*)t.take(n * 4 * nc);
+    if (!t.ok()) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the fused advection");
+    fnx::ProfScope ps(FNX_PROF_ADVECT, s);
+    fnx::launch_advect2d_fused(dims(g), prm->sample_outside_fluid != 0, prm->dt, prm->maccormack_strength * 0.5f,
+                               st->density, st->U, st->flags, rho_fwd, cell, U_fwd, rho2, U2, s);
+  } else {
+    if (has_rho) {
+      if (int rc = fnx_advect_scalar(g, prm->dt, st->density, st->U, st->flags, rho2, FNX_ADVECT_MACCORMACK, 1,
+                                     prm->sample_outside_fluid, prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
+    }
+    if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
+                                prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   }
-  if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
-                              prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, wall BCs, BCs, -div
   if (int rc = fnx_pre_projection(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream)) return rc;
   const GridDims d = dims(g);
