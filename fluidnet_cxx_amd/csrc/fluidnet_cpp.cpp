@@ -107,6 +107,24 @@ Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::stri
   return dst;
 }
 
+// the two advections of one step fused (fnx_advect_step): returns {density_adv, U_adv}
+std::vector<Tensor> advect_step(float dt, Tensor density, Tensor U, Tensor flags, const bool sample_outside_fluid,
+                                const float maccormack_strength, c10::optional<Tensor> out_density,
+                                c10::optional<Tensor> out_U) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U"); check_scalar(density, g, "density");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor rd = (out_density.has_value() && out_density->defined()) ? *out_density : at::empty_like(density);
+  Tensor ud = (out_U.has_value() && out_U->defined()) ? *out_U : at::empty_like(U);
+  check_scalar(rd, g, "out_density"); check_vel(ud, g, "out_U");
+  Workspace ws(g, FNX_OP_ADVECT_STEP, U);
+  check_status(fnx_advect_step(&g, dt, density.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                               rd.data_ptr<float>(), ud.data_ptr<float>(), sample_outside_fluid, maccormack_strength, ws.ptr,
+                               ws.bytes, cur_stream(U)));
+  return {rd, ud};
+}
+
 std::vector<Tensor> solve_linear_system(Tensor flags, Tensor div, const bool is3D, const float p_tol,
                                         const int max_iter, const bool verbose) {
   FnxGrid g = grid_of(flags, is3D);
@@ -388,6 +406,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("advect_scalar", &advect_scalar, "Advect Scalar", py::arg("dt"), py::arg("src"), py::arg("U"), py::arg("flags"),
         py::arg("method"), py::arg("boundary_width"), py::arg("sample_outside_fluid"), py::arg("maccormack_strength"),
         py::arg("out") = py::none());
+  m.def("advect_step", &advect_step, py::arg("dt"), py::arg("density"), py::arg("U"), py::arg("flags"),
+        py::arg("sample_outside_fluid"), py::arg("maccormack_strength"), py::arg("out_density") = py::none(),
+        py::arg("out_U") = py::none());
   m.def("advect_vel", &advect_vel, "Advect Velocity", py::arg("dt"), py::arg("orig"), py::arg("U"), py::arg("flags"),
         py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none());
   m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method");

@@ -408,35 +408,37 @@ __global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, fl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 2D: the density and the velocity MacCormack advections of one time step in two launches instead of four (forward
-// passes together, backward/clamp passes together).  At 128^2 .. 1024^2 each pass is a 7-14 us launch that is mostly
-// ramp-up; the cell functions are the ones above, so the results are the same bits.
+// The density and the velocity MacCormack advections of one time step in two launches instead of four (forward passes
+// together, backward/clamp passes together; 3D: the clamp-bounds pass in between).  In 2D at 128^2 .. 1024^2 each pass
+// is a 7-14 us launch that is mostly ramp-up; in 3D the two chains share their velocity loads (1.13 -> 1.06 ms at
+// 256^3).  The cell functions are the ones above, so the results are the same bits.
 // ---------------------------------------------------------------------------------------------------
-template <bool SAMPLE_OUTSIDE>
-__global__ __launch_bounds__(BX* BY) void advect2d_fwd_kernel(GridDims g, float dt, const float* __restrict__ rho,
+template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void advect_fwd_kernel(GridDims g, float dt, const float* __restrict__ rho,
                                                               const float* __restrict__ U,
                                                               const float* __restrict__ flags,
                                                               float* __restrict__ rho_fwd, int* __restrict__ cell_out,
                                                               float* __restrict__ U_fwd) {
-  const CellId c = cell_id<false>(g);
+  const CellId c = cell_id<IS3D>(g);
   if (!c.valid) return;
-  sl_scalar_cell<false, false, SAMPLE_OUTSIDE>(g, c, dt, rho, U, flags, rho_fwd, cell_out);
-  sl_mac_cell<false, false>(g, c, dt, U, U, flags, U_fwd);
+  sl_scalar_cell<IS3D, QUIRKS, SAMPLE_OUTSIDE>(g, c, dt, rho, U, flags, rho_fwd, cell_out);
+  sl_mac_cell<IS3D, QUIRKS>(g, c, dt, U, U, flags, U_fwd);
 }
 
-template <bool SAMPLE_OUTSIDE>
-__global__ __launch_bounds__(BX* BY) void advect2d_bwd_kernel(GridDims g, float dt, float half_s,
+template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(BX* BY) void advect_bwd_kernel(GridDims g, float dt, float half_s,
                                                               const float* __restrict__ rho,
                                                               const float* __restrict__ rho_fwd,
                                                               const int* __restrict__ cell_in,
                                                               const float* __restrict__ U,
                                                               const float* __restrict__ U_fwd,
                                                               const float* __restrict__ flags,
+                                                              const float2* __restrict__ box,
                                                               float* __restrict__ rho_dst, float* __restrict__ U_dst) {
-  const CellId c = cell_id<false>(g);
+  const CellId c = cell_id<IS3D>(g);
   if (!c.valid) return;
-  sl_scalar_bwd_clamp_cell<false, false, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, nullptr, rho_dst);
-  sl_mac_bwd_clamp_cell<false, false>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
+  sl_scalar_bwd_clamp_cell<IS3D, QUIRKS, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, box, rho_dst);
+  sl_mac_bwd_clamp_cell<IS3D, QUIRKS>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
 }
 
 inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
@@ -494,18 +496,16 @@ void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const fl
   DISPATCH2(is3d, quirks, sl_mac_kernel, <<<grid, block, 0, s>>>(g, dt, src, U, flags, dst));
 }
 
-// 2D MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches
-void launch_advect2d_fused(const GridDims& g, bool sample_outside, float dt, float half_s, const float* rho, const float* U,
-                           const float* flags, float* rho_fwd, int* cell, float* U_fwd, float* rho_dst, float* U_dst,
-                           hipStream_t s) {
-  const dim3 grid = cell_grid(g), block(BX, BY);
-  if (sample_outside) {
-    advect2d_fwd_kernel<true><<<grid, block, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd);
-    advect2d_bwd_kernel<true><<<grid, block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst);
-  } else {
-    advect2d_fwd_kernel<false><<<grid, block, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd);
-    advect2d_bwd_kernel<false><<<grid, block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst);
-  }
+// MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches
+void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, bool sample_outside, float dt,
+                         float half_s, const float* rho, const float* U, const float* flags, float* rho_fwd, int* cell,
+                         float* U_fwd, float* box, float* rho_dst, float* U_dst, hipStream_t s) {
+  const dim3 block(BX, BY);
+  // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
+  DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
+  if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
+  DISPATCH3(is3d, quirks, sample_outside, advect_bwd_kernel,
+            <<<cell_grid(g), block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst));
 }
 
 void launch_sl_mac_bwd_clamp(const GridDims& g, bool is3d, bool quirks, float dt, float half_s, const float* orig,

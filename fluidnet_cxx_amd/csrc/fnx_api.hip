@@ -70,8 +70,7 @@ size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B *
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   // 2D: the fused advection launches keep both forward fields at once
-  size_t adv = g->is3D ? (ws_advect_scalar(g) > ws_advect_vel(g) ? ws_advect_scalar(g) : ws_advect_vel(g))
-                       : ws_advect_scalar(g) + ws_advect_vel(g);
+  size_t adv = ws_advect_scalar(g) + ws_advect_vel(g);
   size_t solve = ws_jacobi(g);
   size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D);
   size_t tail = adv > solve ? adv : solve;
@@ -157,6 +156,7 @@ size_t fnx_workspace_bytes(const FnxGrid* g, int op) {
     case FNX_OP_JACOBI: return ws_jacobi(g);
     case FNX_OP_STEP: return ws_step(g);
     case FNX_OP_FLUIDNET: return fnx::fluidnet_ws_bytes(dims(g), g->is3D);
+    case FNX_OP_ADVECT_STEP: return ws_advect_scalar(g) + ws_advect_vel(g);
   }
   fail(FNX_EINVAL, "unknown op %d", op);
   return 0;
@@ -211,6 +211,28 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
     fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_mac_bwd_clamp(d, g->is3D, quirks(g), dt, strength * 0.5f, orig, fwd, U, flags, dst, s);
   }
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
+                    float* density_dst, float* U_dst, int sample_outside, float strength, void* ws, size_t ws_bytes,
+                    void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!density || !U || !flags || !density_dst || !U_dst) return fail(FNX_EINVAL, "advect_step: NULL tensor");
+  if (density_dst == density || U_dst == U) return fail(FNX_EINVAL, "advect_step: dst must not alias the inputs");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = ncell(g), nc = g->is3D ? 3 : 2;
+  Carver c(ws, ws_bytes);
+  float* rho_fwd = (float*)c.take(n * 4);
+  int* cell = (int*)c.take(n * 4);
+  float* box = g->is3D ? (float*)c.take(n * 8) : nullptr;
+  float* U_fwd = (float*)c.take(n * 4 * nc);
+  if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_step: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  const GridDims d = dims(g);
+  fnx::ProfScope ps(FNX_PROF_ADVECT, s);
+  fnx::launch_advect_fused(d, widened(d, 2), g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, density, U, flags,
+                           rho_fwd, cell, U_fwd, box, density_dst, U_dst, s);
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }
@@ -502,16 +524,10 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   const bool has_rho = st->density != nullptr;
   // simulate.py:75-93: advect density then velocity (both by the OLD U)
   static const bool no_fuse = getenv("FNX_ADVECT_NOFUSE") != nullptr;       // A/B switch
-  if (has_rho && !g->is3D && !no_fuse) {
-    // 2D: forward passes of both advections in one launch, backward/clamp passes in another (same cell functions)
-    Carver t(tail, tail_bytes);
-    float* rho_fwd = (float*)t.take(n * 4);
-    int* cell = (int*)t.take(n * 4);
-    float* U_fwd = (float*)t.take(n * 4 * nc);
-    if (!t.ok()) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the fused advection");
-    fnx::ProfScope ps(FNX_PROF_ADVECT, s);
-    fnx::launch_advect2d_fused(dims(g), prm->sample_outside_fluid != 0, prm->dt, prm->maccormack_strength * 0.5f,
-                               st->density, st->U, st->flags, rho_fwd, cell, U_fwd, rho2, U2, s);
+  if (has_rho && !no_fuse) {
+    // forward passes of both advections in one launch, backward/clamp passes in another (same cell functions)
+    if (int rc = fnx_advect_step(g, prm->dt, st->density, st->U, st->flags, rho2, U2, prm->sample_outside_fluid,
+                                 prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   } else {
     if (has_rho) {
       if (int rc = fnx_advect_scalar(g, prm->dt, st->density, st->U, st->flags, rho2, FNX_ADVECT_MACCORMACK, 1,

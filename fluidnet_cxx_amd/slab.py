@@ -118,6 +118,11 @@ class NativeOps:
     def advect_vel(self, dt, U, flags, strength, out=None):
         return self.ext.advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, strength, out)
 
+    def advect_both(self, dt, rho, U, flags, strength, sample_outside, out_rho=None, out_U=None):
+        """density and velocity advection of one step as the fused pair of launches (same bits as the two calls)"""
+        r, u = self.ext.advect_step(dt, rho, U, flags, bool(sample_outside), strength, out_rho, out_U)
+        return r, u
+
     def pre_projection(self, U_adv, rho_adv, st, cfg):
         gv = cfg["gravityVec"]
         return self.ext.pre_projection_(U_adv, rho_adv, st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"),
@@ -199,23 +204,24 @@ class SlabSimulator:
             ops.set_slab(l.z_offset, l.D_global)
             rho_adv, U_adv = torch.empty_like(st["density"]), torch.empty_like(st["U"])
             window(ia_, ib_)
-            ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so, out=rho_adv)
-            ops.advect_vel(dt, st["U"], st["flags"], strength, out=U_adv)
+            ops.advect_both(dt, st["density"], st["U"], st["flags"], strength, so, rho_adv, U_adv)
             window(0, 0)
             yield ("wait",)
             ops.set_slab(l.z_offset, l.D_global)
             for ea, eb in ((a_, ia_), (ib_, b_)):
                 if eb > ea:
                     window(ea, eb)
-                    ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so, out=rho_adv)
-                    ops.advect_vel(dt, st["U"], st["flags"], strength, out=U_adv)
+                    ops.advect_both(dt, st["density"], st["U"], st["flags"], strength, so, rho_adv, U_adv)
         else:
             yield "xchg", [st["U"], st["density"]], min(4, l.halo)
             ops.set_slab(l.z_offset, l.D_global)
             if window and l.world > 1:
                 window(a_, b_)
-            rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so)
-            U_adv = ops.advect_vel(dt, st["U"], st["flags"], strength)
+            if hasattr(ops, "advect_both"):
+                rho_adv, U_adv = ops.advect_both(dt, st["density"], st["U"], st["flags"], strength, so)
+            else:
+                rho_adv = ops.advect_scalar(dt, st["density"], st["U"], st["flags"], strength, so)
+                U_adv = ops.advect_vel(dt, st["U"], st["flags"], strength)
         if window and l.world > 1:
             window(lo_, top_)
         div = ops.pre_projection(U_adv, rho_adv, st, cfg)

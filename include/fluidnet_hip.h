@@ -64,7 +64,8 @@ typedef struct FnxGrid {
 } FnxGrid;
 
 /* Workspace sizing. */
-enum { FNX_OP_ADVECT_SCALAR = 0, FNX_OP_ADVECT_VEL = 1, FNX_OP_JACOBI = 2, FNX_OP_STEP = 3, FNX_OP_FLUIDNET = 4 };
+enum { FNX_OP_ADVECT_SCALAR = 0, FNX_OP_ADVECT_VEL = 1, FNX_OP_JACOBI = 2, FNX_OP_STEP = 3, FNX_OP_FLUIDNET = 4,
+       FNX_OP_ADVECT_STEP = 5 };
 size_t fnx_workspace_bytes(const FnxGrid* g, int op);
 
 const char* fnx_last_error(void);
@@ -83,6 +84,13 @@ int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float*
 int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags,
                    float* dst, int method, int bnd, float maccormack_strength,
                    void* ws, size_t ws_bytes, void* stream);
+
+/* The two advections of one time step (lib/simulate.py:75-93): density by U and U by itself, both MacCormack, both
+ * from the OLD U, as one fused pair of launches (forward passes together, backward/clamp passes together).  Results
+ * are bit-identical to fnx_advect_scalar + fnx_advect_vel.  dst buffers must not alias the inputs. */
+int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
+                    float* density_dst, float* U_dst, int sample_outside, float strength, void* ws, size_t ws_bytes,
+                    void* stream);
 
 /* velocityDivergence, lib/fluid/velocity_divergence.py:4-74 */
 int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags, float* div, void* stream);
