@@ -286,6 +286,18 @@ def test_static_flags_reuses_mask_3d(dev, oracle, ext):
         assert_bitexact(runs[1][k], st[k], f"{k} (mask reused)")
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 40, 70, 3.0), (1, 9, 20, 66, 2.0)])
+def test_advect_step_equals_the_two_advections(fl, ext, dev, shape):
+    """fnx_advect_step (fused forward / backward launches) == advectScalar + advectVelocity, bit for bit."""
+    B, D, H, W, sigma = shape
+    s = random_state(B, D, H, W, sigma, seed=21, empties=True)
+    tf, tU, trho = T(s["flags"], dev), T(s["U"], dev), T(s["rho"], dev)
+    for so in (False, True):
+        r, u = ext.advect_step(0.13, trho, tU, tf, so, 0.7)
+        assert_bitexact(N(r), N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7)), f"density so={so}")
+        assert_bitexact(N(u), N(fl.advectVelocity(0.13, tU, tU, tf, "maccormackFluidNet", 1, 0.7)), f"U so={so}")
+
+
 def test_rollout_batch_of_two(dev, oracle):
     """Long-term loop with batch > 1 (fluid_net_train.py:349-373): every sample evolves exactly as it does alone."""
     from fluidnet_cxx_amd import rollout
