@@ -378,12 +378,25 @@ constexpr int Z2C_DEFAULT = 16;
 // x / 6.0f, correctly rounded, without the v_rcp/v_div_scale expansion: q = x*zh, r = x - 6q (exact), q + r*zh with
 // zh = RN(1/6), then v_div_fixup for -0/inf/nan.  Checked against x / 6.0f for all 2^32 inputs on gfx950
 // (tools/ubench/div6_test.hip): the only differing inputs give a denormal quotient (v_cmp_class 0x90), which the
-// caller sends through the true division.
+// caller sends through div6_tiny.
 __device__ __forceinline__ float div6_fast(float x) {
   const float zh = 0x1.555556p-3f;
   const float q1 = x * zh;
   const float r = __builtin_fmaf(-6.0f, q1, x);
   return __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, zh, q1), 6.0f, x);
+}
+
+// The denormal-quotient case of div6_fast, exact in 5 instructions: v_div_scale lifts the numerator out of the denormal
+// range, the same two-step refinement runs on the scaled value, v_div_fmas undoes the scale inside the last rounding.
+// Checked against x / 6.0f for every |x| < 2^-63 (tools/ubench/div6_test.hip, variant c: 0 mismatches; for large |x|
+// the hardware scheme would scale the denominator instead, which a constant reciprocal cannot follow).
+__device__ __forceinline__ float div6_tiny(float x) {
+  const float zh = 0x1.555556p-3f;
+  bool vcc;
+  const float n = __builtin_amdgcn_div_scalef(x, 6.0f, true, &vcc);
+  const float q1 = n * zh;
+  const float r = __builtin_fmaf(-6.0f, q1, n);
+  return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r, zh, q1, vcc), 6.0f, x);
 }
 
 template <bool FREE>
@@ -535,10 +548,10 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: true division
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: scaled division
 #pragma unroll
       for (int r = 0; r < N; ++r)
-        if (__builtin_amdgcn_classf(out[r], 0x90)) out[r] = xs[r] / 6.0f;
+        if (__builtin_amdgcn_classf(out[r], 0x90)) out[r] = div6_tiny(xs[r]);
     }
 #pragma unroll
     for (int r = 0; r < N; ++r)                            // cont ? v : 0

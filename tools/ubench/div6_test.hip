@@ -25,7 +25,7 @@ __device__ __forceinline__ float div6_c(float x) {          // v_div_scale + mul
 
 __global__ void check(unsigned long long* bad, uint32_t* example) {
   const uint32_t u0 = (blockIdx.x * blockDim.x + threadIdx.x);
-  unsigned long long na = 0, nb = 0, nc = 0, nbd = 0;
+  unsigned long long na = 0, nb = 0, nc = 0, nbd = 0, nct = 0;
   for (uint32_t hi = 0; hi < 16; ++hi) {
     const uint32_t u = u0 | (hi << 28);
     const float x = __uint_as_float(u);
@@ -39,23 +39,25 @@ __global__ void check(unsigned long long* bad, uint32_t* example) {
       const uint32_t e = __float_as_uint(b) & 0x7f800000u;
       if (!(e == 0 && (__float_as_uint(b) & 0x7fffffu) != 0)) { ++nbd; example[0] = u; }
     }
-    if (__float_as_uint(div6_c(x)) != t) { ++nc; example[1] = u; }
+    if (__float_as_uint(div6_c(x)) != t) { ++nc; example[1] = u; if ((u & 0x7fffffffu) < 0x20000000u) ++nct; }   // nct: |x| < 2^-63
   }
   if (na) atomicAdd(&bad[0], na);
   if (nb) atomicAdd(&bad[1], nb);
   if (nc) atomicAdd(&bad[2], nc);
   if (nbd) atomicAdd(&bad[3], nbd);
+  if (nct) atomicAdd(&bad[4], nct);
 }
 
 int main() {
   unsigned long long* bad; uint32_t* ex;
-  hipMalloc(&bad, 32); hipMemset(bad, 0, 32);
+  hipMalloc(&bad, 64); hipMemset(bad, 0, 64);
   hipMalloc(&ex, 8); hipMemset(ex, 0, 8);
   check<<<(1u << 28) / 256, 256>>>(bad, ex);
-  unsigned long long h[4]; uint32_t he[2];
-  hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost); hipMemcpy(he, ex, 8, hipMemcpyDeviceToHost);
+  unsigned long long h[8]; uint32_t he[2];
+  hipMemcpy(h, bad, 64, hipMemcpyDeviceToHost); hipMemcpy(he, ex, 8, hipMemcpyDeviceToHost);
   printf("mismatches vs x/6.0f over all non-NaN floats: a(mul,fma,fma)=%llu  b(+div_fixup)=%llu  c(div_scale..div_fmas,div_fixup)=%llu\n",
          h[0], h[1], h[2]);
+  printf("c mismatches with |x| < 2^-63 (the range whose quotient can be denormal): %llu\n", h[4]);
   printf("b mismatches NOT flagged by 'result is denormal': %llu (example x bits %08x); c example %08x\n", h[3], he[0], he[1]);
   return 0;
 }
