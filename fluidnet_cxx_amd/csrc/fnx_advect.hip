@@ -62,7 +62,7 @@ __device__ __forceinline__ void sl_scalar_cell(const GridDims& g, const CellId& 
     const int i0 = clampi((int)p[0], 0, g.W - 1), j0 = clampi((int)p[1], 0, g.H - 1);
     // Q10: k0 = 0 in the reference.  Stored with a +1 plane bias so that global plane -1.. maps to a valid int
     const int k0 = (IS3D && !QUIRKS) ? clampi((int)p[2], 0, g.Dglob - 1) - g.zoff : -g.zoff;
-    cell_out[(size_t)c.b * g.DHW + o] = (k0 + 1) * g.HW + j0 * g.W + i0;
+    cell_out[(size_t)c.b * g.DHW + o] = IS3D ? (k0 + 1) * g.HW + j0 * g.W + i0 : ((j0 << 16) | i0);   // 2D: W, H < 65536 (host check)
   }
 }
 
@@ -205,19 +205,25 @@ __device__ __forceinline__ void sl_scalar_bwd_clamp_cell(const GridDims& g, cons
   float d = f;
   if (fluid) d = f + half_s * (fs.p[o] - bwd);          // applied on border cells too (reference :371)
   if (!border) {
+    // traced cell: 3D (k0+1)*HW + j0*W + i0 (no integer division on the common path), 2D (j0 << 16) | i0
     const int cell = cell_in[(size_t)c.b * g.DHW + o];
-    const int kb = cell / g.HW;                           // local plane + 1
-    const int k0 = kb - 1;
-    const int r = cell - kb * g.HW;
-    const int j0 = r / g.W, i0 = r - j0 * g.W;
     float mn, mx;
     bool any;
-    if (box != nullptr && k0 >= 0 && k0 < g.D) {
-      // the traced cell lies in this slab: its clamp bounds were reduced once by box_minmax_kernel (3D only)
-      const float2 bb = box[(size_t)c.b * g.DHW + (size_t)k0 * g.HW + r];
+    int k0 = 0, j0 = 0, i0 = 0;
+    if (IS3D && box != nullptr && cell >= g.HW && cell < g.HW + g.DHW) {
+      // the traced cell lies in this slab: its clamp bounds were reduced once by box_minmax_kernel
+      const float2 bb = box[(size_t)c.b * g.DHW + (size_t)(cell - g.HW)];
       mn = bb.x; mx = bb.y;
       any = !(mn != mn);
     } else {
+      if (IS3D) {
+        const int kb = cell / g.HW;                         // local plane + 1
+        k0 = kb - 1;
+        const int r = cell - kb * g.HW;
+        j0 = r / g.W; i0 = r - j0 * g.W;
+      } else {
+        j0 = cell >> 16; i0 = cell & 0xffff;
+      }
       // 2D (9 cells: cheaper than a separate pass), or traced into a plane this slab does not hold: walk the clipped
       // box directly, as the reference does
       mn = INFINITY; mx = -INFINITY; any = false;

@@ -33,6 +33,7 @@ int check_grid(const FnxGrid* g) {
   if (g->is3D && g->D < 3) return fail(FNX_EINVAL, "3D domain needs D >= 3");
   if ((long long)g->D * g->H * g->W >= (1ll << 31)) return fail(FNX_EINVAL, "more than 2^31 cells per sample");
   if ((long long)g->B * g->D > 65535) return fail(FNX_EINVAL, "B*D > 65535 not supported");
+  if (!g->is3D && (g->W > 65535 || g->H > 65535)) return fail(FNX_EINVAL, "2D grids wider or taller than 65535 are not supported");
   if (g->k_end != 0 || g->k_begin != 0) {
     if (!g->is3D || g->k_begin < 0 || g->k_end > g->D || g->k_end <= g->k_begin)
       return fail(FNX_EINVAL, "bad compute window [%d, %d) for D=%d", g->k_begin, g->k_end, g->D);
