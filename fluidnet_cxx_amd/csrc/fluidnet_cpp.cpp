@@ -329,12 +329,14 @@ void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, 
 }
 
 // one pass (1|2 sweeps) p_in -> p_out on the output planes [k_begin, k_end) -- z-slab driver (overlap with exchange)
-void jacobi_pass_(Tensor flags, Tensor div, Tensor p_in, Tensor p_out, int nsweeps, int k_begin, int k_end,
-                  Tensor workspace, bool reuse_mask) {
+void jacobi_pass_(Tensor flags, Tensor div, c10::optional<Tensor> p_in_opt, Tensor p_out, int nsweeps, int k_begin,
+                  int k_end, Tensor workspace, bool reuse_mask) {
   FnxGrid g = grid_of(flags, true);
+  const bool zero = !(p_in_opt.has_value() && p_in_opt->defined());     // None: p = 0 (first pass of a solve)
+  Tensor p_in = zero ? p_out : *p_in_opt;
   check_scalar(div, g, "div"); check_scalar(p_in, g, "p_in"); check_scalar(p_out, g, "p_out");
   c10::hip::HIPGuard guard(flags.get_device());
-  check_status(fnx_jacobi_pass(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p_in.data_ptr<float>(),
+  check_status(fnx_jacobi_pass(&g, flags.data_ptr<float>(), div.data_ptr<float>(), zero ? nullptr : p_in.data_ptr<float>(),
                                p_out.data_ptr<float>(), nsweeps, k_begin, k_end, workspace.data_ptr(),
                                (size_t)workspace.numel() * workspace.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
 }

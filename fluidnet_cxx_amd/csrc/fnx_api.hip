@@ -369,8 +369,9 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                     int nsweeps, int k_begin, int k_end, void* ws, size_t ws_bytes, int reuse_mask, void* stream) {
   if (int rc = check_grid(g)) return rc;
-  if (!flags || !div || !p_in || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
+  if (!flags || !div || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
   if (!g->is3D) return fail(FNX_EINVAL, "jacobi_pass: 3D only (2D uses fnx_jacobi_sweeps)");
+  const bool from_zero = p_in == nullptr;                 // the first pass of a solve: p = 0 everywhere, nothing to read
   if (nsweeps != 1 && nsweeps != 2) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1 or 2");
   if (k_begin < 0 || k_end > g->D || (k_end != 0 && k_end <= k_begin)) return fail(FNX_EINVAL, "jacobi_pass: bad plane range");
   hipStream_t s = (hipStream_t)stream;
@@ -381,8 +382,8 @@ int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, cons
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_pass: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end);
-  else fnx::launch_jacobi3d(d, mask, div, p_in, p_out, false, nullptr, s, k_begin, k_end);
+  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero);
+  else fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin, k_end);
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }

@@ -96,6 +96,8 @@ class SlabComm:
 class NativeOps:
     """The production operator set: hand-written HIP through the `fluidnet_cpp` extension."""
 
+    zero_start = True            # jacobi_pass takes p_in=None for "the pressure is 0 everywhere"
+
     def __init__(self):
         from ._ext import ext
         self.ext = ext
@@ -235,9 +237,12 @@ class SlabSimulator:
         if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
             self._pbuf = torch.zeros_like(st["p"])
         cur, nxt = st["p"], self._pbuf
-        cur.zero_()
+        fresh = getattr(ops, "zero_start", False)      # the operator set takes p_in=None for "p is 0 everywhere"
+        if not fresh:
+            cur.zero_()
         lo, top = l.lo, l.lo + l.owned
         remaining, pending = int(cfg["jacobiIter"]), False
+        first_pass = True
         while remaining > 0:
             k = min(w, remaining)
             remaining -= k
@@ -249,6 +254,8 @@ class SlabSimulator:
             done = 0
             for pi, n in enumerate(passes):
                 done += n
+                pin = None if (fresh and first_pass) else cur      # None: p = 0 everywhere, nothing to read
+                first_pass = False
                 # After the exchange the w ghost planes next to the owned block are fresh; every sweep makes the
                 # outermost fresh one stale, so a pass that ends `done` sweeps into the block only has to produce the
                 # planes within w - done of the owned block (sides without a neighbour: up to the array end).
@@ -266,23 +273,23 @@ class SlabSimulator:
                         side.wait_stream(torch.cuda.current_stream(cur.device))
                         with torch.cuda.stream(side):
                             ops.set_slab(l.z_offset, l.D_global)
-                            ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)
+                            ops.jacobi_pass(st["flags"], div, pin, nxt, n, ia, ib)
                     if l.rank > 0:
-                        ops.jacobi_pass(st["flags"], div, cur, nxt, n, lo, lo + w)
+                        ops.jacobi_pass(st["flags"], div, pin, nxt, n, lo, lo + w)
                     if l.rank < l.world - 1:
-                        ops.jacobi_pass(st["flags"], div, cur, nxt, n, top - w, top)
+                        ops.jacobi_pass(st["flags"], div, pin, nxt, n, top - w, top)
                     yield "start", [nxt], w
                     ops.set_slab(l.z_offset, l.D_global)
                     pending = True
                     if side is None:
                         if ib > ia:
-                            ops.jacobi_pass(st["flags"], div, cur, nxt, n, ia, ib)   # overlaps the exchange
+                            ops.jacobi_pass(st["flags"], div, pin, nxt, n, ia, ib)   # overlaps the exchange
                     else:
                         torch.cuda.current_stream(cur.device).wait_stream(side)
                 elif l.world > 1:
-                    ops.jacobi_pass(st["flags"], div, cur, nxt, n, a, b)
+                    ops.jacobi_pass(st["flags"], div, pin, nxt, n, a, b)
                 else:
-                    ops.jacobi_pass(st["flags"], div, cur, nxt, n, 0, 0)
+                    ops.jacobi_pass(st["flags"], div, pin, nxt, n, 0, 0)
                 cur, nxt = nxt, cur
         if cur is not st["p"]:
             st["p"].copy_(cur)

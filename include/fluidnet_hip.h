@@ -112,7 +112,7 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
                          void* ws, size_t ws_bytes, int reuse_mask, void* stream);
 
 /* One pass of 1 or 2 sweeps (3D) from p_in into p_out restricted to the output planes [k_begin, k_end)
- * (0,0 = all); explicit buffers, no ping-pong.  Lets the z-slab driver compute the planes its neighbours need
+ * (0,0 = all); explicit buffers, no ping-pong.  p_in == NULL: the pressure is 0 everywhere (first pass of a solve).  Lets the z-slab driver compute the planes its neighbours need
  * first, start the ghost exchange, and compute the interior while the exchange is in flight.  `ws` as for
  * fnx_jacobi_sweeps_ex (holds the neighbour mask). */
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
