@@ -44,6 +44,25 @@ class OracleOps:
     def advect_scalar(self, dt, rho, U, flags, strength, so):
         return torch.from_numpy(self.O.advect_scalar(dt, rho.numpy(), U.numpy(), flags.numpy(), "maccormackFluidNet", 1, so, strength))
 
+    # The oracle has no compute windows: with `windows=True` it accepts them and always produces whole fields, which
+    # drives the driver's overlapped schedule (posted U/rho exchange, interior first, edges after the wait) over gloo.
+    windows = False
+
+    def __getattr__(self, name):
+        if name == "set_window" and self.windows:
+            return lambda a, b: None
+        if name == "advect_both" and self.windows:
+            return self._advect_both
+        raise AttributeError(name)
+
+    def _advect_both(self, dt, rho, U, flags, strength, so, out_rho=None, out_U=None):
+        r = self.advect_scalar(dt, rho, U, flags, strength, so)
+        u = self.advect_vel(dt, U, flags, strength)
+        if out_rho is not None:
+            out_rho.copy_(r); out_U.copy_(u)
+            return out_rho, out_U
+        return r, u
+
     def advect_vel(self, dt, U, flags, strength):
         return torch.from_numpy(self.O.advect_vel(dt, U.numpy(), U.numpy(), flags.numpy(), "maccormackFluidNet", 1, strength))
 
@@ -124,7 +143,8 @@ def _dist_worker(rank, world, port, D, H, W, halo, w, out_dir):
         torch.set_num_threads(2)
         gs = global_state(D, H, W)
         layout = SlabLayout(D, world, rank, halo)
-        sim = SlabSimulator(layout, CFG, ops=OracleOps(), sweeps_per_exchange=w)
+        ops = OracleOps(); ops.windows = True
+        sim = SlabSimulator(layout, CFG, ops=ops, sweeps_per_exchange=w)
         st = local_state(gs, layout)
         for _ in range(2):
             sim.step(st)
@@ -137,7 +157,7 @@ def test_gloo_two_ranks_match_single_domain(tmp_path):
     """world_size 2 over gloo: real send/recv between two processes."""
     import torch.multiprocessing as mp
     from fluidnet_cxx_amd.slab import SlabLayout
-    D, H, W, halo, w, world = 20, 12, 16, 6, 4, 2
+    D, H, W, halo, w, world = 24, 12, 16, 6, 4, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     os.environ.setdefault("OMP_NUM_THREADS", "2")
