@@ -319,11 +319,24 @@ class SlabSimulator:
                 self.ops.set_window(0, 0)
 
 
-def lockstep_step(sims, states):
+def lockstep_step(sims, states, defer=False):
     """Single-process stand-in for n ranks: advances all slabs phase by phase and serves their ghost exchanges with
-    direct copies (a posted exchange is served at once, so any later write into the planes in flight shows up as a
-    mismatch).  Used to validate the decomposition on ONE device (tests); production uses SlabSimulator.step."""
+    direct copies.  Used to validate the decomposition on ONE device (tests); production uses SlabSimulator.step.
+    A posted ("start") exchange is served at once by default, so any later write into the planes in flight shows up as
+    a mismatch; with defer=True it is served only at the matching "wait", so any READ of a ghost plane before the wait
+    (or a write into the planes being sent) shows up instead -- the two orders an asynchronous transfer can take."""
     gens = [s.phases(st) for s, st in zip(sims, states)]
+    posted = None
+
+    def serve(reqs):
+        width = reqs[0][2]
+        for r in range(len(sims) - 1):           # pair (r, r+1)
+            lo, hi = sims[r].l, sims[r + 1].l
+            for f_lo, f_hi in zip(reqs[r][1], reqs[r + 1][1]):
+                top = lo.lo + lo.owned
+                f_lo[:, :, top:top + width].copy_(f_hi[:, :, hi.lo:hi.lo + width])
+                f_hi[:, :, hi.lo - width:hi.lo].copy_(f_lo[:, :, top - width:top])
+
     while True:
         reqs = []
         for g in gens:
@@ -335,14 +348,16 @@ def lockstep_step(sims, states):
             break
         assert all(r is not None for r in reqs) and len({r[0] for r in reqs}) == 1, "ranks fell out of step"
         if reqs[0][0] == "wait":
+            if posted is not None:
+                serve(posted)
+                posted = None
             continue
-        width = reqs[0][2]
-        for r in range(len(sims) - 1):           # pair (r, r+1)
-            lo, hi = sims[r].l, sims[r + 1].l
-            for f_lo, f_hi in zip(reqs[r][1], reqs[r + 1][1]):
-                top = lo.lo + lo.owned
-                f_lo[:, :, top:top + width].copy_(f_hi[:, :, hi.lo:hi.lo + width])
-                f_hi[:, :, hi.lo - width:hi.lo].copy_(f_lo[:, :, top - width:top])
+        if reqs[0][0] == "start" and defer:
+            assert posted is None, "two exchanges in flight"
+            posted = reqs
+            continue
+        serve(reqs)
+    assert posted is None, "an exchange was posted and never waited for"
     for s in sims:
         s.ops.set_slab(0, 0)
         if hasattr(s.ops, "set_window"):

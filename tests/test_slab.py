@@ -195,8 +195,8 @@ def test_lockstep_slabs_match_single_domain_gpu(world, halo, w):
     layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
     sims = [SlabSimulator(l, CFG, sweeps_per_exchange=w) for l in layouts]
     states = [local_state(gs, l, dev) for l in layouts]
-    for _ in range(2):
-        lockstep_step(sims, states)
+    for n in range(2):
+        lockstep_step(sims, states, defer=(n == 1))          # both orders an asynchronous transfer can take
     for l, st in zip(layouts, states):
         check_owned(st, ref, l, f"gpu lockstep world={world}")
     # and against the CPU oracle (single domain)
