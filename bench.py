@@ -149,7 +149,7 @@ def cpu_baseline(w, budget_s=12.0):
                 sample=f"{n} steps of the same {w['method']} step on a {D}x{res}x{res} grid, OpenMP {threads} threads; per-cell rate")
 
 
-def run_workload(name, steps, warmup, use_graph, world, rank, dev):
+def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edge_first"):
     """Warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then profile the dominant
     kernel class with HIP events.  Returns the JSON-able result dict (without cpu_baseline)."""
     import torch
@@ -168,7 +168,8 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev):
         from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
         layout = SlabLayout(w["D"] * world, world, rank, halo=6)
         bd = plume_state_torch(w["res"], layout.D_local, dev, layout.z_offset, layout.D_global)
-        sim = SlabSimulator(layout, m, sweeps_per_exchange=6)     # = halo: 17 ghost exchanges of p per 100 sweeps
+        # 6 sweeps per exchange = halo: 17 ghost exchanges of p per 100 sweeps; the plume's flags never change
+        sim = SlabSimulator(layout, m, sweeps_per_exchange=6, schedule=schedule, static_flags=True)
         net = None
 
         def eager_step():
@@ -263,7 +264,8 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev):
                             global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]],
                             cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
                             parallelism=("1 GPU" if world == 1 else
-                                         f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 6 sweeps per exchange"),
+                                         f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 6 sweeps per exchange, "
+                                         f"schedule {schedule}"),
                             launch="hip-graph replay" if graph_used else "eager",
                             weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
                 step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -279,6 +281,8 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", default="edge_first", choices=["edge_first", "last_pass"],
+                    help="N > 1: how the slab driver orders a sweep block around its ghost exchange (slab.py)")
     ap.add_argument("--no-also", action="store_true", help="skip the configs[1] line reported under 'also' at N=1")
     a = ap.parse_args()
 
@@ -292,7 +296,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     name = a.workload or "plume3d_slab_jacobi"
-    out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev)
+    out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev, a.schedule)
     if world == 1 and a.workload is None and not a.no_also:
         # configs[1], the other configuration the metric is quoted on (single-GPU by definition)
         also = run_workload("plume2d_1024_cnn", min(a.steps, 20), min(a.warmup, 5), not a.no_graph, 1, 0, dev)

@@ -767,15 +767,19 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     return e ? atoi(e) : (Z2WPS * 4 / Z2NW) * cus;
   }();
   static const int zenv = [] { const char* e = getenv("FNX_JACOBI_ZCHUNK"); return e ? atoi(e) : -1; }();
+  // Smallest plane chunk.  Every (tile, chunk) wave is resident at once, so a launch lasts (chunk + 4 lead-in planes) x
+  // the per-plane latency of ONE wave, whatever the occupancy: small plane ranges (the slab driver's edge parts, small
+  // grids) are cut as finely as the wave slots allow (measured 20 -> 14 us for 14 planes of 512^2).
+  static const int zmin = [] { const char* e = getenv("FNX_JACOBI_ZMIN"); return e ? atoi(e) : 2; }();
   const int nxt = (g.W + 59) / 60, nyt = (g.H + Z2NW * Z2R - 1) / (Z2NW * Z2R);
   const int np = ke - kb, ntiles = nxt * nyt * g.B;
   int zchunk = zenv;
   if (zchunk < 0) {
-    // as many equal plane chunks per tile as fit one resident set (a chunk pays 2 lead-in planes, so >= 8 planes)
+    // as many equal plane chunks per tile as fit one resident set
     int nzc = slots / ntiles;
     if (nzc < 1) nzc = 1;
     zchunk = (np + nzc - 1) / nzc;
-    if (zchunk < 8) zchunk = 8;
+    if (zchunk < zmin) zchunk = zmin;
     if (ntiles > slots) zchunk = 0;                      // more tiles than slots: even split of the (tile, plane) space
     if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
   }

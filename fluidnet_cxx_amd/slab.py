@@ -17,6 +17,8 @@ GPUs, gloo in the CPU tests): each rank talks to at most two peers, there is no 
 The driver is backend-agnostic: `ops` supplies the operators (native HIP ops on GPU tensors in production; the tests
 plug in the CPU oracle on numpy-backed tensors to check the decomposition itself with gloo).
 """
+from contextlib import nullcontext as _nullctx
+
 import torch
 import torch.distributed as dist
 
@@ -51,16 +53,17 @@ class SlabComm:
         self.l = layout
         self.group = group
 
-    def start(self, fields, width):
-        """Post the sends/receives of `width` ghost planes of every field; returns a handle for finish()."""
+    def start(self, fields, width, sources=None):
+        """Post the sends/receives of `width` ghost planes of every field; returns a handle for finish().  `sources`
+        (default: the fields themselves) are the arrays whose owned edge planes are sent."""
         l = self.l
         if l.world == 1:
             return None
         assert width <= l.halo
         ops, recvs = [], []
-        for f in fields:
+        for f, src in zip(fields, sources if sources is not None else fields):
             if l.rank > 0:           # lower neighbour
-                send = f[:, :, l.lo:l.lo + width]
+                send = src[:, :, l.lo:l.lo + width]
                 recv = f[:, :, l.lo - width:l.lo]
                 direct = send.is_contiguous() and recv.is_contiguous()     # one plane block (B = C = 1): no staging copy
                 sb = send if direct else send.contiguous()
@@ -70,7 +73,7 @@ class SlabComm:
                     recvs.append((recv, rb))
             if l.rank < l.world - 1:  # upper neighbour
                 top = l.lo + l.owned
-                send = f[:, :, top - width:top]
+                send = src[:, :, top - width:top]
                 recv = f[:, :, top:top + width]
                 direct = send.is_contiguous() and recv.is_contiguous()     # one plane block (B = C = 1): no staging copy
                 sb = send if direct else send.contiguous()
@@ -159,7 +162,12 @@ class NativeOps:
 class SlabSimulator:
     """`simulate(mconf, batch_dict, None, 'jacobi')` for one rank's slab of a 3D domain (in place on `state`)."""
 
-    def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4):
+    def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4, schedule="edge_first",
+                 static_flags=False):
+        assert schedule in ("last_pass", "edge_first")
+        self.schedule = schedule
+        self.static_flags = static_flags     # the caller promises that flags do not change between steps
+        self._steps = 0
         self.l = layout
         self.cfg = mconf
         self.ops = ops if ops is not None else NativeOps()
@@ -187,8 +195,9 @@ class SlabSimulator:
         l, cfg, ops = self.l, self.cfg, self.ops
         dt = float(cfg["dt"])
         w = self.w
-        if hasattr(ops, "begin_step"):
-            ops.begin_step()
+        if hasattr(ops, "begin_step") and not (self.static_flags and self._steps > 0):
+            ops.begin_step()                 # (forget the solver's neighbour mask)
+        self._steps += 1
         # advection reaches <= 2 planes beyond its inputs at CFL <= 1 and the BC/buoyancy/divergence stage one more:
         # 4 fresh ghost planes of U and density are enough (the arrays keep `halo` planes for the pressure solve)
         window = getattr(ops, "set_window", None)
@@ -200,7 +209,7 @@ class SlabSimulator:
         # planes whose advection reads no ghost plane (output k reads k-3..k+3 at CFL <= 1)
         ia_ = lo_ + 3 if l.rank > 0 else a_
         ib_ = top_ - 3 if l.rank < l.world - 1 else b_
-        if window and l.world > 1 and ib_ - ia_ >= 8:
+        if window and l.world > 1 and l.owned - 6 >= 8:      # (the same decision on every rank)
             # the ghost exchange of U and density is in flight while the interior planes are advected
             yield "start", [st["U"], st["density"]], min(4, l.halo)
             ops.set_slab(l.z_offset, l.D_global)
@@ -231,9 +240,96 @@ class SlabSimulator:
             window(0, 0)
         yield "xchg", [div], max(w - 1, 1)
 
-        # Jacobi: blocks of w sweeps between ghost exchanges (temporal blocking in z).  The last pass of a block first
-        # produces the w planes each neighbour needs, posts their exchange, and computes the interior meanwhile.
         ops.set_slab(l.z_offset, l.D_global)
+        if self.schedule == "edge_first" and l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w:
+            cur = yield from self._jacobi_edge_first(st, div)
+        else:
+            cur = yield from self._jacobi_last_pass(st, div)
+        if cur is not st["p"]:
+            st["p"].copy_(cur)
+        yield "xchg", [st["p"]], 1
+        ops.set_slab(l.z_offset, l.D_global)
+        if window and l.world > 1:
+            window(lo_, top_)
+        ops.post_projection(st)
+        if window:
+            window(0, 0)
+        ops.set_slab(0, 0)
+
+    def _jacobi_edge_first(self, st, div):
+        """Jacobi schedule "edge_first": the same blocks of w sweeps and the same shrinking plane ranges as "last_pass"
+        (after `done` sweeps of a block only the planes within w - done of the owned block are still needed), but every
+        pass's range is cut at 2w - done planes inside each internal face and the EDGE parts of ALL passes of the block
+        run first:
+
+            edge part of pass i      [lo - w + done_i, lo + 2w - done_i)    (and its mirror image at the upper face)
+            interior part of pass i  [lo + 2w - done_i, top - 2w + done_i)
+
+        The edge parts form a closed chain (part i+1 reads exactly what part i wrote) that ends in the w owned planes
+        the neighbour needs at sweep s + w; their exchange is posted as soon as the chain is through, and the interior
+        parts -- all w/2 passes, not one -- run while it is in flight.  Both chains ping-pong between the SAME two
+        arrays: the edge part of pass i+1 overwrites the array of pass i-1 only below plane lo + 2w - done_(i+1), and
+        the interior part of pass i reads that array from plane lo + 2w - done_i - n_i upwards, which is not lower as
+        long as the passes' sweep counts do not decrease (an odd block runs its single sweep first).  No plane is
+        computed twice: the work is that of "last_pass"."""
+        l, cfg, ops, w = self.l, self.cfg, self.ops, self.w
+        if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
+            self._pbuf = torch.zeros_like(st["p"])
+        cur, nxt = st["p"], self._pbuf
+        fresh = getattr(ops, "zero_start", False)
+        if not fresh:
+            cur.zero_()
+        lo, top = l.lo, l.lo + l.owned
+        has_lo, has_hi = l.rank > 0, l.rank < l.world - 1
+        flags = st["flags"]
+        passes = [1] * (w % 2) + [2] * (w // 2)
+        remaining = int(cfg["jacobiIter"])
+        zero_in = fresh                      # the block starts from p = 0 everywhere: nothing to read
+        block = 0
+        while remaining > w:                 # a block that is followed by another one
+            remaining -= w
+            block += 1
+            if block > 1:
+                yield ("wait",)              # the ghost planes of `cur`
+                ops.set_slab(l.z_offset, l.D_global)
+            src, dst, done = cur, nxt, 0
+            for pi, n in enumerate(passes):
+                done += n
+                pin = None if (zero_in and pi == 0) else src
+                if has_lo:
+                    ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done)
+                if has_hi:
+                    ops.jacobi_pass(flags, div, pin, dst, n, top - 2 * w + done, top + w - done)
+                src, dst = dst, src
+            fin = src
+            yield "start", [fin], w
+            ops.set_slab(l.z_offset, l.D_global)
+            src, dst, done = cur, nxt, 0
+            for pi, n in enumerate(passes):
+                done += n
+                ops.jacobi_pass(flags, div, None if (zero_in and pi == 0) else src, dst, n,
+                                lo + 2 * w - done if has_lo else 0, top - 2 * w + done if has_hi else l.D_local)
+                src, dst = dst, src
+            if fin is not cur:
+                cur, nxt = nxt, cur
+            zero_in = False
+
+        # the last block (<= w sweeps, no exchange after it): whole shrinking ranges
+        yield ("wait",)
+        ops.set_slab(l.z_offset, l.D_global)
+        done = 0
+        for n in [2] * (remaining // 2) + [1] * (remaining % 2):
+            done += n
+            g = max(w - done, 0)
+            ops.jacobi_pass(flags, div, cur, nxt, n, lo - g if has_lo else 0, top + g if has_hi else l.D_local)
+            cur, nxt = nxt, cur
+        return cur
+
+    def _jacobi_last_pass(self, st, div):
+        """Jacobi schedule "last_pass": blocks of w sweeps between ghost exchanges (temporal blocking in z); the last
+        pass of a block first produces the w planes each neighbour needs, posts their exchange, and computes the interior
+        meanwhile.  One pass of compute (of w/2) is available to hide a transfer."""
+        l, cfg, ops, w = self.l, self.cfg, self.ops, self.w
         if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
             self._pbuf = torch.zeros_like(st["p"])
         cur, nxt = st["p"], self._pbuf
@@ -268,16 +364,19 @@ class SlabSimulator:
                     # stream at the same time, so the small edge launches fill CUs instead of serialising with it.
                     ia = lo + w if l.rank > 0 else a
                     ib = top - w if l.rank < l.world - 1 else b
-                    side = self._side_stream(cur)
-                    if side is not None and ib > ia:
+                    # The edge launches are issued FIRST: a pass of the solver fills every wave slot for its whole
+                    # duration, so small launches issued after it would only start when it ends (and the exchange
+                    # with them).
+                    side = self._side_stream(cur) if ib > ia else None
+                    if side is not None:
                         side.wait_stream(torch.cuda.current_stream(cur.device))
-                        with torch.cuda.stream(side):
-                            ops.set_slab(l.z_offset, l.D_global)
-                            ops.jacobi_pass(st["flags"], div, pin, nxt, n, ia, ib)
                     if l.rank > 0:
                         ops.jacobi_pass(st["flags"], div, pin, nxt, n, lo, lo + w)
                     if l.rank < l.world - 1:
                         ops.jacobi_pass(st["flags"], div, pin, nxt, n, top - w, top)
+                    if side is not None:
+                        with torch.cuda.stream(side):
+                            ops.jacobi_pass(st["flags"], div, pin, nxt, n, ia, ib)
                     yield "start", [nxt], w
                     ops.set_slab(l.z_offset, l.D_global)
                     pending = True
@@ -291,16 +390,7 @@ class SlabSimulator:
                 else:
                     ops.jacobi_pass(st["flags"], div, pin, nxt, n, 0, 0)
                 cur, nxt = nxt, cur
-        if cur is not st["p"]:
-            st["p"].copy_(cur)
-        yield "xchg", [st["p"]], 1
-        ops.set_slab(l.z_offset, l.D_global)
-        if window and l.world > 1:
-            window(lo_, top_)
-        ops.post_projection(st)
-        if window:
-            window(0, 0)
-        ops.set_slab(0, 0)
+        return cur
 
     def step(self, st):
         handle = None
@@ -309,7 +399,7 @@ class SlabSimulator:
                 if req[0] == "xchg":
                     self.comm.exchange(req[1], req[2])
                 elif req[0] == "start":
-                    handle = self.comm.start(req[1], req[2])
+                    handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None)
                 else:
                     self.comm.finish(handle)
                     handle = None
@@ -332,10 +422,11 @@ def lockstep_step(sims, states, defer=False):
         width = reqs[0][2]
         for r in range(len(sims) - 1):           # pair (r, r+1)
             lo, hi = sims[r].l, sims[r + 1].l
-            for f_lo, f_hi in zip(reqs[r][1], reqs[r + 1][1]):
+            srcs = [q[3] if len(q) > 3 else q[1] for q in (reqs[r], reqs[r + 1])]     # arrays the edge planes are sent from
+            for f_lo, f_hi, s_lo, s_hi in zip(reqs[r][1], reqs[r + 1][1], *srcs):
                 top = lo.lo + lo.owned
-                f_lo[:, :, top:top + width].copy_(f_hi[:, :, hi.lo:hi.lo + width])
-                f_hi[:, :, hi.lo - width:hi.lo].copy_(f_lo[:, :, top - width:top])
+                f_lo[:, :, top:top + width].copy_(s_hi[:, :, hi.lo:hi.lo + width])
+                f_hi[:, :, hi.lo - width:hi.lo].copy_(s_lo[:, :, top - width:top])
 
     while True:
         reqs = []

@@ -117,23 +117,27 @@ def check_owned(st, ref, layout, what):
         assert not bad.any(), f"{what}: {k} differs on {int(bad.sum())} owned cells (rank {layout.rank}), max {np.abs(a - b).max():.3e}"
 
 
-@pytest.mark.parametrize("world,halo,w", [(3, 6, 4), (2, 5, 2), (2, 8, 5), (2, 6, 3), (2, 6, 6)])
-def test_lockstep_slabs_match_single_domain_cpu(world, halo, w):
+@pytest.mark.parametrize("world,halo,w,schedule", [(3, 6, 4, "last_pass"), (2, 5, 2, "last_pass"), (2, 8, 5, "last_pass"),
+                                                   (2, 6, 3, "last_pass"), (2, 6, 6, "last_pass"),
+                                                   (2, 6, 4, "edge_first"), (3, 6, 3, "edge_first"), (2, 5, 5, "edge_first")])
+def test_lockstep_slabs_match_single_domain_cpu(world, halo, w, schedule):
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
     D, H, W = 24 if (world == 3 or w == 6) else 20, 14, 18
+    if schedule == "edge_first":
+        D = 4 * w * world                     # the schedule needs 4w owned planes per rank
     gs = global_state(D, H, W)
     ref = reference_steps(gs, 2)
     ops = OracleOps()
     layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
-    sims = [SlabSimulator(l, CFG, ops=ops, sweeps_per_exchange=w) for l in layouts]
+    sims = [SlabSimulator(l, CFG, ops=ops, sweeps_per_exchange=w, schedule=schedule) for l in layouts]
     states = [local_state(gs, l) for l in layouts]
-    for _ in range(2):
-        lockstep_step(sims, states)
+    for n in range(2):
+        lockstep_step(sims, states, defer=(n == 1 and schedule == "edge_first"))
     for l, st in zip(layouts, states):
         check_owned(st, ref, l, f"lockstep world={world}")
 
 
-def _dist_worker(rank, world, port, D, H, W, halo, w, out_dir):
+def _dist_worker(rank, world, port, D, H, W, halo, w, schedule, out_dir):
     sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
     import torch.distributed as dist
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
@@ -144,7 +148,7 @@ def _dist_worker(rank, world, port, D, H, W, halo, w, out_dir):
         gs = global_state(D, H, W)
         layout = SlabLayout(D, world, rank, halo)
         ops = OracleOps(); ops.windows = True
-        sim = SlabSimulator(layout, CFG, ops=ops, sweeps_per_exchange=w)
+        sim = SlabSimulator(layout, CFG, ops=ops, sweeps_per_exchange=w, schedule=schedule)
         st = local_state(gs, layout)
         for _ in range(2):
             sim.step(st)
@@ -153,15 +157,16 @@ def _dist_worker(rank, world, port, D, H, W, halo, w, out_dir):
         dist.destroy_process_group()
 
 
-def test_gloo_two_ranks_match_single_domain(tmp_path):
+@pytest.mark.parametrize("schedule", ["last_pass", "edge_first"])
+def test_gloo_two_ranks_match_single_domain(tmp_path, schedule):
     """world_size 2 over gloo: real send/recv between two processes."""
     import torch.multiprocessing as mp
     from fluidnet_cxx_amd.slab import SlabLayout
-    D, H, W, halo, w, world = 24, 12, 16, 6, 4, 2
+    D, H, W, halo, w, world = (32 if schedule == "edge_first" else 24), 12, 16, 6, 4, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     os.environ.setdefault("OMP_NUM_THREADS", "2")
-    mp.spawn(_dist_worker, args=(world, port, D, H, W, halo, w, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_dist_worker, args=(world, port, D, H, W, halo, w, schedule, str(tmp_path)), nprocs=world, join=True)
     ref = reference_steps(global_state(D, H, W), 2)
     for r in range(world):
         l = SlabLayout(D, world, r, halo)
@@ -180,20 +185,21 @@ def test_layout_arithmetic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,halo,w", [(2, 6, 4), (4, 6, 3), (2, 6, 6)])
-def test_lockstep_slabs_match_single_domain_gpu(world, halo, w):
+@pytest.mark.parametrize("world,halo,w,schedule", [(2, 6, 4, "last_pass"), (4, 6, 3, "last_pass"), (2, 6, 6, "last_pass"),
+                                                   (2, 6, 4, "edge_first"), (4, 6, 3, "edge_first"), (2, 6, 6, "edge_first")])
+def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule):
     """Same decomposition check with the native HIP operators on one device (global-z geometry in the kernels)."""
     from fluidnet_cxx_amd import simulate
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
     dev = torch.device("cuda:0")
-    D, H, W = 32, 20, 70
+    D, H, W = (4 * w * world if schedule == "edge_first" else 32), 20, 70
     gs = global_state(D, H, W, seed=3)
     bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
     for _ in range(2):
         simulate(CFG, bd, None, "jacobi")
     ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
     layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
-    sims = [SlabSimulator(l, CFG, sweeps_per_exchange=w) for l in layouts]
+    sims = [SlabSimulator(l, CFG, sweeps_per_exchange=w, schedule=schedule) for l in layouts]
     states = [local_state(gs, l, dev) for l in layouts]
     for n in range(2):
         lockstep_step(sims, states, defer=(n == 1))          # both orders an asynchronous transfer can take

@@ -13,10 +13,11 @@ dev = torch.device("cuda:0")
 w = bench.WORKLOADS["plume3d_slab_jacobi"]; m = bench.mconf_for(w)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 wsw = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+schedule = sys.argv[3] if len(sys.argv) > 3 else "last_pass"
 D = 64 * world
 layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
 states = [bench.plume_state_torch(512, l.D_local, dev, l.z_offset, D) for l in layouts]
-sims = [SlabSimulator(l, m, sweeps_per_exchange=wsw) for l in layouts]
+sims = [SlabSimulator(l, m, sweeps_per_exchange=wsw, schedule=schedule, static_flags=True) for l in layouts]
 for _ in range(3): lockstep_step(sims, states)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,4 +33,4 @@ torch.cuda.synchronize()
 tags = {k: ext.profile_read(v) for k, v in bench.PROF.items()}
 ext.profile_enable(False)
 print("  per rank and step: " + ", ".join(f"{k} {ms / 2 / world:.3f} ms ({n // 2 // world} launches)" for k, (ms, n) in tags.items() if n))
-print(f"world={world} w={wsw}: GPU {gpu:.3f} ms per lock-step of {world} slabs = {gpu / world:.3f} ms per rank (host enqueue {(t1 - t0) / n * 1e3:.3f} ms)")
+print(f"world={world} w={wsw} {schedule}: GPU {gpu:.3f} ms per lock-step of {world} slabs = {gpu / world:.3f} ms per rank (host enqueue {(t1 - t0) / n * 1e3:.3f} ms)")
