@@ -54,8 +54,7 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return
 
-    assert "flags_stick" not in batch_dict, \
-        "stick BCs: the reference's setWallBcsStick does not run (SURVEY Q15); not provided"
+    stick = "flags_stick" in batch_dict                          # simulate.py:61-64
     # ---- operator-by-operator path, reference order ----
     orig = U
     if viscosity > 0:                                           # simulate.py:66-69
@@ -98,10 +97,14 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
 
     if sim_method != "convnet":
         U = wall_bcs(U)
+    elif stick:                                                  # simulate.py:129-130
+        fluid.setWallBcsStick(U, flags, batch_dict["flags_stick"])
     setConstVals(batch_dict, p, U, flags, density)
     if sim_method == "convnet":
         data = torch.cat((p, U, flags, density), 1)
         p, U = net(data)
+        if stick:                                                # simulate.py:165-166
+            fluid.setWallBcsStick(U, flags, batch_dict["flags_stick"])
     else:
         div = fluid.velocityDivergence(U, flags)
         is3D = U.size(2) > 1

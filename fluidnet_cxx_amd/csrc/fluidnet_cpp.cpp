@@ -194,6 +194,18 @@ void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
                                  (float)viscosity, cur_stream(U)));
 }
 
+// set_wall_bcs_stick.py:5-157 (2D; in place on U like the reference)
+void set_wall_bcs_stick_(Tensor U, Tensor flags, Tensor flags_stick) {
+  check_field(U, "U");
+  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  check_vel(U, g, "U");
+  check_scalar(flags_stick, g, "flags_stick");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor old = U.clone();
+  check_status(fnx_set_wall_bcs_stick(&g, old.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                                      flags_stick.data_ptr<float>(), cur_stream(U)));
+}
+
 void set_wall_bcs_(Tensor U, Tensor flags) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
@@ -421,6 +433,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("add_gravity_", &add_gravity_);
   m.def("add_viscosity_", &add_viscosity_);
   m.def("set_wall_bcs_", &set_wall_bcs_);
+  m.def("set_wall_bcs_stick_", &set_wall_bcs_stick_);
   m.def("set_const_vals_", &set_const_vals_);
   m.def("flags_to_occupancy", &flags_to_occupancy);
   m.def("empty_domain_", &empty_domain_);

@@ -436,6 +436,17 @@ int fnx_set_wall_bcs(const FnxGrid* g, float* U, const float* flags, void* strea
   return FNX_OK;
 }
 
+int fnx_set_wall_bcs_stick(const FnxGrid* g, const float* U_in, float* U_out, const float* flags, const float* flags_stick,
+                           void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!U_in || !U_out || !flags || !flags_stick) return fail(FNX_EINVAL, "set_wall_bcs_stick: NULL tensor");
+  if (g->is3D || g->D != 1) return fail(FNX_EINVAL, "set_wall_bcs_stick: 2D only (the reference's 3D branch cannot run, set_wall_bcs_stick.py:85-86)");
+  if (U_in == U_out) return fail(FNX_EINVAL, "set_wall_bcs_stick: U_out must not alias U_in");
+  fnx::launch_set_wall_bcs_stick(dims(g), U_in, U_out, flags, flags_stick, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_set_const_vals(const FnxGrid* g, float* U, const float* UBC, const float* UBCInvMask, float* density,
                        const float* densityBC, const float* densityBCInvMask, void* stream) {
   if (int rc = check_grid(g)) return rc;

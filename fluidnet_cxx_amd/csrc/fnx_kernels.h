@@ -40,6 +40,8 @@ void launch_add_viscosity(const GridDims& g, const float* Uin, float* Uout, cons
 void launch_add_buoyancy(const GridDims& g, bool is3d, bool quirks, float* U, const float* flags, const float* rho,
                          float sx, float sy, float sz, float rho_star, hipStream_t s);
 void launch_set_wall_bcs(const GridDims& g, bool is3d, float* U, const float* flags, hipStream_t s);
+void launch_set_wall_bcs_stick(const GridDims& g, const float* Uin, float* Uout, const float* flags, const float* stick,
+                               hipStream_t s);
 void launch_set_const_vals(size_t n, float* x, const float* bc, const float* inv_mask, hipStream_t s);
 void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStream_t s);
 void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s);

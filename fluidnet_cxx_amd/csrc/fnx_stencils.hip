@@ -179,6 +179,67 @@ __global__ __launch_bounds__(BX* BY) void set_wall_bcs_kernel(GridDims g, float*
   }
 }
 
+// setWallBcsStick (2D), lib/fluid/set_wall_bcs_stick.py:57-156 with its three unbound names bound (see the header).
+// Out of place: every neighbour velocity is the value after the slip phase (:57-77), which is a function of the INPUT
+// field and the flags of the neighbour and its own -1 neighbour, so one pass suffices.
+#define FNX_STICK 128.0f
+__device__ __forceinline__ float stick_slip(const GridDims& g, const float* __restrict__ u, const float* __restrict__ fl,
+                                            const float* __restrict__ st, int comp, int j, int i) {
+  // u, fl, st: sample base pointers (u: channel 0); (:57) obstacle cells -> 0, (:61-62,73-74) -1 neighbour is an obstacle -> 0
+  const size_t o = (size_t)j * g.W + i;
+  const float fc = fl[o];
+  if (fc == FNX_OBST) return 0.f;
+  const bool cont = fc == FNX_FLUID || st[o] == FNX_STICK;
+  const bool at0 = comp == 0 ? i <= 0 : j <= 0;
+  if (cont && !at0 && fl[o - (comp == 0 ? 1 : g.W)] == FNX_OBST) return 0.f;
+  return u[(size_t)comp * g.DHW + o];
+}
+
+__global__ __launch_bounds__(BX* BY) void set_wall_bcs_stick_kernel(GridDims g, const float* __restrict__ Uin,
+                                                                    float* __restrict__ Uout,
+                                                                    const float* __restrict__ flags,
+                                                                    const float* __restrict__ stick) {
+  const CellId c = cell_id<false>(g);
+  if (!c.valid) return;
+  const int i = c.i, j = c.j;
+  const float* u = Uin + (size_t)c.b * 2 * g.DHW;
+  const float* fl = flags + (size_t)c.b * g.DHW;
+  const float* st = stick + (size_t)c.b * g.DHW;
+  const size_t o = (size_t)j * g.W + i;
+  const float fc = fl[o];
+  const bool S = st[o] == FNX_STICK;
+  const bool cont = fc == FNX_FLUID || fc == FNX_OBST || S;
+  float uu = stick_slip(g, u, fl, st, 0, j, i);
+  float vv = stick_slip(g, u, fl, st, 1, j, i);
+  const int il = i > 0 ? i - 1 : 0, ir = i < g.W - 1 ? i + 1 : g.W - 1;
+  const int jl = j > 0 ? j - 1 : 0, jr = j < g.H - 1 ? j + 1 : g.H - 1;
+  if (S) {
+    // (:97-116) vertical component mirrors the fluid neighbour left / right; the later rule wins, both -> mean
+    const bool f_l = fl[(size_t)j * g.W + il] == FNX_FLUID, f_r = fl[(size_t)j * g.W + ir] == FNX_FLUID;
+    const float v_l = i > 0 ? stick_slip(g, u, fl, st, 1, j, i - 1) : 0.f;
+    const float v_r = i < g.W - 1 ? stick_slip(g, u, fl, st, 1, j, i + 1) : 0.f;
+    if (f_l) vv = -v_l;
+    if (f_r) vv = -v_r;
+    if (f_l && f_r) vv = 0.5f * ((-v_l) - v_r);
+    // (:118-136) horizontal component, neighbours below / above; the reference's "both" test reads the lower
+    // neighbour twice (:131): the mean is taken whenever the lower neighbour is fluid
+    const bool f_d = fl[(size_t)jl * g.W + i] == FNX_FLUID, f_u = fl[(size_t)jr * g.W + i] == FNX_FLUID;
+    const float u_d = j > 0 ? stick_slip(g, u, fl, st, 0, j - 1, i) : 0.f;
+    const float u_u = j < g.H - 1 ? stick_slip(g, u, fl, st, 0, j + 1, i) : 0.f;
+    if (f_d) uu = -u_d;
+    if (f_u) uu = -u_u;
+    if (f_d) uu = 0.5f * ((-u_d) - u_u);
+  }
+  // (:138-156) corners; the doubled terms are the reference's sums
+  const int ls = cont && st[(size_t)j * g.W + il] == FNX_STICK, rs = cont && st[(size_t)j * g.W + ir] == FNX_STICK;
+  const int bs = cont && st[(size_t)jl * g.W + i] == FNX_STICK, us = cont && st[(size_t)jr * g.W + i] == FNX_STICK;
+  if (2 * (int)S + 2 * ls + bs + us == 3) uu = 0.f;
+  if (2 * (int)S + ls + 2 * bs + rs == 3) vv = 0.f;
+  float* w = Uout + (size_t)c.b * 2 * g.DHW + o;
+  w[0] = uu;
+  w[g.DHW] = vv;
+}
+
 // setConstVals, lib/simulate.py:16-25: x = x*inv_mask + bc (two roundings)
 __global__ __launch_bounds__(256) void set_const_vals_kernel(size_t n, float* __restrict__ x,
                                                              const float* __restrict__ bc,
@@ -246,6 +307,11 @@ void launch_add_gravity(const GridDims& g, bool is3d, float* U, const float* fla
 void launch_add_viscosity(const GridDims& g, const float* Uin, float* Uout, const float* flags, float coef,
                           hipStream_t s) {
   add_viscosity_kernel<<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, Uin, Uout, flags, coef);
+}
+
+void launch_set_wall_bcs_stick(const GridDims& g, const float* Uin, float* Uout, const float* flags, const float* stick,
+                               hipStream_t s) {
+  set_wall_bcs_stick_kernel<<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, Uin, Uout, flags, stick);
 }
 
 void launch_set_wall_bcs(const GridDims& g, bool is3d, float* U, const float* flags, hipStream_t s) {

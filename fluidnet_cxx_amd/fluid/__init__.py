@@ -13,10 +13,11 @@ from .._ext import ext as _ext
 CellType = IntEnum("CellType", dict(TypeNone=0, TypeFluid=1, TypeObstacle=2, TypeEmpty=4, TypeInflow=8, TypeOutflow=16,
                                     TypeOpen=32, TypeStick=128, TypeReserved=256))
 from .ops import (advectScalar, advectVelocity, correctScalar, solveLinearSystemJacobi, velocityDivergence,
-                  velocityUpdate, addBuoyancy, addGravity, addViscosity, setWallBcs, flagsToOccupancy, setConstVals, getDx)
+                  velocityUpdate, addBuoyancy, addGravity, addViscosity, setWallBcs, setWallBcsStick, flagsToOccupancy, setConstVals,
+                  getDx)
 from .init_conditions import emptyDomain, createPlumeBCs, createRayleighTaylorBCs
 from .geometry_utils import createCylinder, createBox2D
 
 __all__ = ["CellType", "advectScalar", "advectVelocity", "correctScalar", "solveLinearSystemJacobi",
-           "velocityDivergence", "velocityUpdate", "addBuoyancy", "addGravity", "addViscosity", "setWallBcs", "flagsToOccupancy", "setConstVals",
+           "velocityDivergence", "velocityUpdate", "addBuoyancy", "addGravity", "addViscosity", "setWallBcs", "setWallBcsStick", "flagsToOccupancy", "setConstVals",
            "getDx", "emptyDomain", "createPlumeBCs", "createRayleighTaylorBCs", "createCylinder", "createBox2D"]

@@ -120,6 +120,18 @@ def setWallBcs(U, flags):
     return U
 
 
+def setWallBcsStick(U, flags, flags_stick):
+    """lib/fluid/set_wall_bcs_stick.py:5-157 -- no-slip walls, in place on U (2D).  `flags_stick` is a copy of flags
+    with the no-slip obstacle cells set to CellType.TypeStick (cylinder.py:76).  The reference function raises
+    NameError as shipped; this is its body with the three unbound names bound (include/fluidnet_hip.h)."""
+    _check5(U, flags)
+    assert flags.dim() == 5 and flags_stick.dim() == 5, "Dimension mismatch"
+    assert flags.size(1) == 1, "flags is not a scalar"
+    assert flags_stick.size(1) == 1, "flags is not a scalar"
+    assert flags_stick.is_contiguous(), "Input is not contiguous"
+    ext.set_wall_bcs_stick_(U, flags, flags_stick)
+
+
 def flagsToOccupancy(flags):
     """lib/fluid/flags_to_occupancy.py:6-19"""
     return ext.flags_to_occupancy(flags)

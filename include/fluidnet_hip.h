@@ -136,6 +136,14 @@ int fnx_add_viscosity(const FnxGrid* g, float dt, const float* U_in, float* U_ou
 /* setWallBcs (in place on U), lib/fluid/set_wall_bcs.py:4-86 */
 int fnx_set_wall_bcs(const FnxGrid* g, float* U, const float* flags, void* stream);
 
+/* setWallBcsStick, lib/fluid/set_wall_bcs_stick.py:5-157 (no-slip walls: `flags_stick` is a copy of flags with the
+ * no-slip obstacle cells set to 128, cylinder.py:76).  2D only.  As shipped the reference function raises NameError
+ * on three unbound names (:62 ff.); with them bound its 2D body runs, and that is what this reproduces bit for bit
+ * (tests/golden/stick.npz).  The reference updates U in place from gathered copies; here U_in is the old field and
+ * U_out (a distinct buffer) receives the result. */
+int fnx_set_wall_bcs_stick(const FnxGrid* g, const float* U_in, float* U_out, const float* flags,
+                           const float* flags_stick, void* stream);
+
 /* setConstVals (in place), lib/simulate.py:4-26.  Either triple may be NULL (key absent in batch_dict). */
 int fnx_set_const_vals(const FnxGrid* g, float* U, const float* UBC, const float* UBCInvMask,
                        float* density, const float* densityBC, const float* densityBCInvMask, void* stream);

@@ -34,6 +34,7 @@ typedef struct { int B, D, H, W, is3D, zoff, Dglob; } OraGrid;
 #define T_FLUID 1.0f
 #define T_OBST  2.0f
 #define T_EMPTY 4.0f
+#define T_STICK 128.0f   /* cell_type.py:13, only in the separate flags_stick grid */
 
 #define IDX(g, nc, b, c, k, j, i) \
   ((((((size_t)(b)) * (nc) + (c)) * (g)->D + (k)) * (g)->H + (j)) * (size_t)(g)->W + (i))
@@ -698,6 +699,73 @@ int ora_set_wall_bcs(const OraGrid* g, float* U, const float* flags) {
             if (fz == T_OBST || (fc == T_OBST && fz == T_FLUID)) U[IDX(g, nc, b, 2, k, j, i)] = 0.f;
           }
         }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * setWallBcsStick (set_wall_bcs_stick.py:5-157), 2D.  The reference file raises NameError as shipped (bare
+ * TypeObstacle / TypeFluid / TypeStick from :62 on); with those three names bound it runs as written in 2D, and that
+ * body is what is restated here, quirks included:
+ *   phase 1 (:57-77)   U = 0 in obstacle cells; U_c = 0 where the -1 neighbour along c is an obstacle (cells of type
+ *                      fluid / obstacle / stick only);
+ *   phase 2 (:97-136)  in stick cells the tangential component mirrors the fluid neighbour across the wall:
+ *                      v = -v(i-1) if the left neighbour is fluid, -v(i+1) if the right one is (the later rule wins),
+ *                      0.5*((-v(i-1)) - v(i+1)) if both; u likewise with the neighbours below / above -- except that
+ *                      the reference's "both" test checks the lower neighbour twice (:131), so the mean is taken
+ *                      whenever the lower neighbour is fluid;
+ *   phase 3 (:138-156) corners: u = 0 where 2*cur + 2*left + below + above == 3, v = 0 where
+ *                      2*cur + left + 2*below + right == 3 (stick indicators; the doubled terms are the reference's).
+ * All neighbour velocities are the values after phase 1 (the reference gathers them before it scatters).  Neighbour
+ * indices clamp to the cell itself at the domain edge (:60,:72,:94-95); the gathered velocity is 0 there (:103-104).
+ * U_in and U_out are distinct buffers.
+ * ---------------------------------------------------------------------------------------- */
+static inline float stick_phase1(const OraGrid* g, const float* U, const float* flags, const float* stick, int b, int c,
+                                 int j, int i) {
+  const float fc = flags[IDX(g, 1, b, 0, 0, j, i)];
+  float u = U[IDX(g, 2, b, c, 0, j, i)];
+  if (fc == T_OBST) return 0.f;
+  const int cont = fc == T_FLUID || fc == T_OBST || stick[IDX(g, 1, b, 0, 0, j, i)] == T_STICK;
+  if (c == 0 && i > 0 && cont && flags[IDX(g, 1, b, 0, 0, j, i - 1)] == T_OBST) u = 0.f;
+  if (c == 1 && j > 0 && cont && flags[IDX(g, 1, b, 0, 0, j - 1, i)] == T_OBST) u = 0.f;
+  return u;
+}
+
+int ora_set_wall_bcs_stick(const OraGrid* g, const float* U_in, float* U_out, const float* flags, const float* stick) {
+  if (g->is3D || g->D != 1) return -1;
+  const int H = g->H, W = g->W;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < g->B; ++b)
+    for (int j = 0; j < H; ++j)
+      for (int i = 0; i < W; ++i) {
+        const size_t c = IDX(g, 1, b, 0, 0, j, i);
+        const float fc = flags[c];
+        const int S = stick[c] == T_STICK;
+        const int cont = fc == T_FLUID || fc == T_OBST || S;
+        float u = stick_phase1(g, U_in, flags, stick, b, 0, j, i);
+        float v = stick_phase1(g, U_in, flags, stick, b, 1, j, i);
+        const int il = i > 0 ? i - 1 : 0, ir = i < W - 1 ? i + 1 : W - 1;
+        const int jl = j > 0 ? j - 1 : 0, jr = j < H - 1 ? j + 1 : H - 1;
+        if (S && cont) {
+          const int f_l = flags[IDX(g, 1, b, 0, 0, j, il)] == T_FLUID, f_r = flags[IDX(g, 1, b, 0, 0, j, ir)] == T_FLUID;
+          const float v_l = i > 0 ? stick_phase1(g, U_in, flags, stick, b, 1, j, i - 1) : 0.f;
+          const float v_r = i < W - 1 ? stick_phase1(g, U_in, flags, stick, b, 1, j, i + 1) : 0.f;
+          if (f_l) v = -v_l;
+          if (f_r) v = -v_r;
+          if (f_l && f_r) v = 0.5f * ((-v_l) - v_r);
+          const int f_d = flags[IDX(g, 1, b, 0, 0, jl, i)] == T_FLUID, f_u = flags[IDX(g, 1, b, 0, 0, jr, i)] == T_FLUID;
+          const float u_d = j > 0 ? stick_phase1(g, U_in, flags, stick, b, 0, j - 1, i) : 0.f;
+          const float u_u = j < H - 1 ? stick_phase1(g, U_in, flags, stick, b, 0, j + 1, i) : 0.f;
+          if (f_d) u = -u_d;
+          if (f_u) u = -u_u;
+          if (f_d) u = 0.5f * ((-u_d) - u_u);                       /* :131 tests the lower neighbour twice */
+        }
+        const int ls = cont && stick[IDX(g, 1, b, 0, 0, j, il)] == T_STICK, rs = cont && stick[IDX(g, 1, b, 0, 0, j, ir)] == T_STICK;
+        const int bs = cont && stick[IDX(g, 1, b, 0, 0, jl, i)] == T_STICK, us = cont && stick[IDX(g, 1, b, 0, 0, jr, i)] == T_STICK;
+        if (2 * S + 2 * ls + bs + us == 3) u = 0.f;
+        if (2 * S + ls + 2 * bs + rs == 3) v = 0.f;
+        U_out[IDX(g, 2, b, 0, 0, j, i)] = u;
+        U_out[IDX(g, 2, b, 1, 0, j, i)] = v;
+      }
   return 0;
 }
 

@@ -156,6 +156,19 @@ def set_wall_bcs(U, flags):
     return U
 
 
+def set_wall_bcs_stick(U, flags, flags_stick):
+    """setWallBcsStick (2D): returns the new U."""
+    g = _grid(flags, False)
+    flags, pf = _f(flags)
+    fs, ps = _f(flags_stick)
+    Uin, pu = _f(U)
+    out = np.empty_like(Uin)
+    rc = lib().ora_set_wall_bcs_stick(ctypes.byref(g), pu, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), pf, ps)
+    if rc != 0:
+        raise RuntimeError("setWallBcsStick: 2D only")
+    return out
+
+
 def set_const_vals(U, UBC, UBCInvMask, rho, rhoBC, rhoBCInvMask):
     g = _grid(rho, U.shape[1] == 3)
     U = np.array(U, dtype=np.float32, order="C", copy=True)
@@ -273,8 +286,11 @@ def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False):
             out[:, 0, :, 1] = U[:, 0, :, -1]
         return out
 
+    stick = state.get("flags_stick")                             # simulate.py:61-64
     if method == "jacobi":
         U = wall_bcs(U)
+    elif stick is not None:                                      # simulate.py:129-130
+        U = set_wall_bcs_stick(U, flags, stick)
     U, rho = const_vals(U, rho)
     if method == "jacobi":
         div = velocity_divergence(U, flags)
@@ -284,6 +300,8 @@ def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False):
     else:
         inp = np.concatenate([state["p"], U, flags, rho], 1)
         p, U = fluidnet_forward(blob, inp, cfg.get("normalizeInputThreshold", 1e-5))
+        if stick is not None:                                    # simulate.py:165-166
+            U = set_wall_bcs_stick(U, flags, stick)
     U, rho = const_vals(U, rho)
     out = dict(state)
     out.update(p=p, U=U, density=rho)

@@ -130,6 +130,28 @@ def test_sim64_optional_stages(oracle, golden):
                 assert_bitexact(st[k], s[f"f2_{k}_{it}"], f"{k} after {it} steps")
 
 
+def test_set_wall_bcs_stick(oracle, golden):
+    """setWallBcsStick (2D): the reference's body with its three unbound names bound by the harness (tools/make_golden.py)."""
+    z = golden("stick")
+    for n in "ab":
+        out = oracle.set_wall_bcs_stick(z[f"{n}_U"], z[f"{n}_flags"], z[f"{n}_flags_stick"])
+        assert_bitexact(out, z[f"{n}_out"], f"set_wall_bcs_stick {n}")
+        assert (out != z[f"{n}_U"]).sum() > 100          # (the case does exercise the operator)
+
+
+def test_sim64_stick_convnet(oracle, golden):
+    """lib.simulate with 'flags_stick' in the batch (convnet method, no-slip cylinder)."""
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    z = golden("stick")
+    blob = oracle.pack_weights(make_scalenet_weights(0))
+    st = plume_state(64)
+    st["flags"] = z["sim_flags"]; st["flags_stick"] = z["sim_flags_stick"]
+    for it in range(1, 3):
+        st = oracle.simulate_step(st, PLUME_CFG, "convnet", blob)
+        for k in ("U", "density", "p"):
+            assert_close(st[k], z[f"sim_{k}_{it}"], 1e-5, f"stick convnet {k} {it}")
+
+
 def test_known_answers(oracle):
     """Properties measured on the reference."""
     from util import make_flags

@@ -328,6 +328,45 @@ def test_sim64_optional_stages_vs_reference(dev, golden):
                 assert_bitexact(N(bd[k]), s[f"f2_{k}_{it}"], f"{k} after {it} steps")
 
 
+def test_set_wall_bcs_stick_vs_reference(dev, fl, ext, golden, oracle):
+    """setWallBcsStick: HIP == reference golden == oracle, bit for bit; also on a larger random case against the oracle."""
+    z = golden("stick")
+    for n in "ab":
+        U = torch.from_numpy(z[f"{n}_U"]).to(dev)
+        r = fl.setWallBcsStick(U, torch.from_numpy(z[f"{n}_flags"]).to(dev), torch.from_numpy(z[f"{n}_flags_stick"]).to(dev))
+        assert r is None
+        assert_bitexact(N(U), z[f"{n}_out"], f"setWallBcsStick {n}")
+    rng = np.random.default_rng(5)
+    flags = make_flags(2, 1, 96, 130, boxes=True)
+    fs = flags.copy()
+    sel = (flags == 2) & (rng.random(flags.shape) < 0.6)
+    fs[sel] = 128
+    fs[0, 0, 0, 40:44, 50:60] = 128                       # a few stick cells that are NOT obstacles
+    U = rng.standard_normal((2, 2, 1, 96, 130)).astype(np.float32)
+    tU = torch.from_numpy(U).to(dev)
+    fl.setWallBcsStick(tU, torch.from_numpy(flags).to(dev), torch.from_numpy(fs).to(dev))
+    assert_bitexact(N(tU), oracle.set_wall_bcs_stick(U, flags, fs), "setWallBcsStick random")
+    with pytest.raises(RuntimeError, match="2D only"):
+        f3 = torch.ones(1, 1, 4, 8, 8, device=dev)
+        ext.set_wall_bcs_stick_(torch.zeros(1, 3, 4, 8, 8, device=dev), f3, f3.clone())
+
+
+def test_sim64_stick_convnet_vs_reference(dev, golden):
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    z = golden("stick")
+    mconf = dict(PLUME_CFG, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", is3D=False)
+    net = FluidNet(mconf, make_scalenet_weights(0), dev)
+    st = plume_state(64)
+    st["flags"] = z["sim_flags"]; st["flags_stick"] = z["sim_flags_stick"]
+    bd = to_dev(st, dev)
+    for it in range(1, 4):
+        simulate(mconf, bd, net, "convnet")
+        for k in ("U", "density", "p"):
+            assert_close(N(bd[k]), z[f"sim_{k}_{it}"], 2e-5, f"stick convnet {k} after {it}")
+
+
 # ---- properties at benchmark sizes ----------------------------------------------------------------------
 @pytest.mark.parametrize("size", [(1, 1024, 1024), (1, 2048, 2048), (64, 128, 128), (256, 256, 256), (64, 512, 512)])
 def test_properties_full_size(fl, ext, dev, size):

@@ -315,9 +315,63 @@ def gen_generators(torch, lib, ext):
     print("  wrote generators.npz")
 
 
+def stick_flags(flags):
+    """flags_stick as cylinder.py:76 builds it: a copy of flags with the no-slip cells set to TypeStick (128).  Marked
+    here: the obstacle box (thick), the single obstacle cell, the 1-cell bar (fluid on both sides) and a stretch of the
+    bottom and left domain walls (corner included)."""
+    B, _, D, H, W = flags.shape
+    fs = flags.copy()
+    fs[:, :, :, H // 3:H // 3 + 4, W // 4:W // 4 + 5] = 128
+    fs[:, :, :, 2 * H // 3, 2 * W // 3] = 128
+    fs[:, :, :, H // 2, W // 2:W // 2 + 7] = 128
+    fs[:, :, :, 0, 0:W // 2] = 128
+    fs[:, :, :, 0:H // 2, 0] = 128
+    fs[flags != 2] = flags[flags != 2]           # stick cells are obstacles (set_wall_bcs_stick.py:50-51)
+    return fs
+
+
+def gen_stick(torch, lib, ext):
+    """setWallBcsStick (set_wall_bcs_stick.py:5-157).  As shipped it raises NameError on the bare names TypeObstacle /
+    TypeFluid / TypeStick (:62 ff.); the harness binds those three names in the module's namespace (no source edit) --
+    the 2D body then runs as written, including its own quirks (the 'both neighbours' test of the horizontal component
+    checks the lower neighbour twice, :131; the corner sums count cur and left twice, :146-152).  The 3D branch has
+    further typos (:85-86) and no z handling in the no-slip part: 2D only."""
+    fluid = lib.fluid
+    mod = sys.modules[fluid.setWallBcsStick.__module__]
+    ct = fluid.CellType
+    mod.TypeObstacle, mod.TypeFluid, mod.TypeStick = ct.TypeObstacle, ct.TypeFluid, ct.TypeStick
+    out = {}
+    for name, B, H, W, sigma, seed, empties in (("a", 2, 20, 33, 2.0, 11, False), ("b", 1, 24, 40, 5.0, 12, True)):
+        rng = np.random.default_rng(seed)
+        flags = make_flags(rng, B, 1, H, W, True, empties)
+        fs = stick_flags(flags)
+        U = (rng.standard_normal((B, 2, 1, H, W)) * sigma).astype(np.float32)
+        tU = t(U, torch).clone()
+        fluid.setWallBcsStick(tU, t(flags, torch), t(fs, torch))
+        out.update({f"{name}_flags": flags, f"{name}_flags_stick": fs, f"{name}_U": U, f"{name}_out": tU.numpy().copy()})
+    # lib.simulate with 'flags_stick' in the batch (convnet method: simulate.py:129-130,165-166), 64x64 plume around a
+    # no-slip cylinder, hash-seeded weights, 3 steps
+    mconf = plume_mconf(torch)
+    with torch.no_grad():
+        bd = plume_setup(torch, lib, 64)
+        fluid.createCylinder(bd, 32, 30, 6)
+        fsk = bd["flags"].clone()
+        fsk[(bd["flags"] == 2) & (torch.arange(64).view(1, 1, 1, 64, 1) > 5) & (torch.arange(64).view(1, 1, 1, 64, 1) < 58)
+            & (torch.arange(64).view(1, 1, 1, 1, 64) > 5) & (torch.arange(64).view(1, 1, 1, 1, 64) < 58)] = 128
+        bd["flags_stick"] = fsk
+        out["sim_flags"] = bd["flags"].numpy().copy(); out["sim_flags_stick"] = fsk.numpy().copy()
+        net = load_net(torch, lib, mconf)
+        for it in range(1, 4):
+            lib.simulate(mconf, bd, net, "convnet")
+            for k in ("U", "density", "p"):
+                out[f"sim_{k}_{it}"] = bd[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "stick.npz"), **out)
+    print("  wrote stick.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops2d,ops3d,plume,sim,cnn,gen")
+    ap.add_argument("--only", default="ops2d,ops3d,plume,sim,cnn,gen,stick")
     a = ap.parse_args()
     only = set(a.only.split(","))
     os.makedirs(OUT, exist_ok=True)
@@ -339,6 +393,8 @@ def main():
         gen_cnn(torch, lib, ext)
     if "gen" in only:
         gen_generators(torch, lib, ext)
+    if "stick" in only:
+        gen_stick(torch, lib, ext)
 
 
 if __name__ == "__main__":
