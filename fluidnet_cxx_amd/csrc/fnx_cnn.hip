@@ -30,7 +30,12 @@ inline bool pair_layer(int cin, int cout) {
   static const bool off = getenv("FNX_CONV_NOPAIR") != nullptr;       // A/B switch
   return !off && cout <= 8 && cin % 8 == 0;
 }
+inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 && L.cout % 32 == 0; }
+// 2D 3x3 MFMA layers also run in the Winograd domain (conv3_wino_kernel): their transformed weights G g G^T
+// ([16][Cin][Cout]) follow the [tap][Cin][Cout] image in the packed buffer
+inline bool wino_layer(const ConvLayer& L, bool is3d) { return !is3d && mfma_layer(L); }
 inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
+  if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + (size_t)16 * L.cin * L.cout;
   if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
@@ -48,8 +53,6 @@ PackedLayer packed_layer(int l, bool is3d) {
   }
   return r;
 }
-
-inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 && L.cout % 32 == 0; }
 
 // blob: (Cout,Cin,taps) -> packed [taps][Cin][Cout]   (implicit-GEMM layers: the A operand of the MFMA reads 32
 // consecutive output channels per lane half)
@@ -204,6 +207,11 @@ constexpr int MF_CHUNK = 8;       // input channels per LDS stage
 constexpr int MF_COLS = 34;       // 32 + halo
 
 // CH = input channels per LDS stage; WPS = waves per SIMD the register budget is sized for (2: 256 VGPRs, 3: 168)
+typedef __amdgpu_buffer_rsrc_t BufRsrcC;
+__device__ __forceinline__ BufRsrcC make_rsrc_c(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+
 template <int CB, int PR, bool IS3D, int CH = MF_CHUNK, int WPS = 2>
 __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
   constexpr int ROWS = 4 * PR + 2;
@@ -214,7 +222,11 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
   constexpr int RPI = 64 / LPR;                  // rows per wave-wide global_load_lds
   constexpr int NWI = (WROWS + RPI - 1) / RPI;   // wave-instructions per stage
   __shared__ __attribute__((aligned(16))) float tile2[2][CH * ROWS * MF_COLS];     // halo tile, double-buffered
-  __shared__ __attribute__((aligned(16))) float wbuf[2][NWI * 256];    // weights of the stage, [tap][cin][cout], double-buffered
+  // weights of the stage, [tap][cin][cout], double-buffered in two SEPARATE arrays: the compiler then knows that the DMA
+  // into one cannot alias the reads of the other and does not drain vmcnt (the next stage's loads, just issued) in
+  // front of the MFMAs
+  __shared__ __attribute__((aligned(16))) float wbuf0[NWI * 256];
+  __shared__ __attribute__((aligned(16))) float wbuf1[NWI * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * PR);
@@ -242,8 +254,10 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
   // are computed once; each stage is then NLD independent loads issued back to back (clamped address + select).
   constexpr int NEL = CH * ROWS * MF_COLS;
   constexpr int NLD = (NEL + 255) / 256;
-  int goff[NLD];
-  unsigned valid = 0;
+  // Loads go through a buffer resource spanning the stage's CH channel volumes: an out-of-image element gets an
+  // out-of-range offset and the hardware returns 0 -- no select between the load and the LDS store (the compiler hoists
+  // such a select to the load and drains vmcnt there, in front of the MFMAs the load is supposed to hide under).
+  unsigned uoff[NLD];
 #pragma unroll
   for (int t = 0; t < NLD; ++t) {
     const int idx = threadIdx.x + 256 * t;
@@ -252,19 +266,21 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
     const int row = rem / MF_COLS, col = rem - row * MF_COLS;
     const int gx = x0 - 1 + col, gy = y0 - 1 + row;
     const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    goff[t] = ok ? (int)((size_t)cc * vol + (size_t)gy * a.W + gx) : 0;      // vol*CH < 2^31 is checked by the host
-    valid |= (unsigned)ok << t;
+    uoff[t] = ok ? (unsigned)(((size_t)cc * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;   // vol*CH*4 < 2^32 is checked by the host
   }
+  const unsigned stage_bytes = (unsigned)((size_t)CH * vol * 4 - 1) + 1u;
   float stage[NLD];
   auto prefetch = [&](int dz, int c0) {
     const int zz = IS3D ? z + dz - 1 : 0;
-    const float* src = xb + (size_t)c0 * vol + (size_t)zz * plane;
+    // (the plane offset is folded into the base; the range then ends zz planes late, inside the next channel or the
+    // allocation's tail, never beyond what an in-image offset of this stage can reach)
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
 #pragma unroll
-    for (int t = 0; t < NLD; ++t) stage[t] = src[goff[t]];
+    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
   };
   // Weights of one stage go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs),
   // one stage ahead of their use; the A operand is then a conflict-free ds_read_b32.
-  auto stage_weights = [&](int dz, int c0, int buf) {
+  auto stage_weights = [&](int dz, int c0, float* wdst) {
 #pragma unroll
     for (int q = 0; q < (NWI + 3) / 4; ++q) {
       const int wi = wave + 4 * q;                      // wave-uniform
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
         const int tap = row / CH, ci = row - tap * CH;
         const float* src = a.w + ((size_t)(dz * 9 + tap) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(&wbuf[buf][wi * 256]), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
       }
     }
   };
@@ -283,27 +299,25 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
   int dz_lo = 0, dz_hi = KD;
   if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = KD - 1; }
   const int niter = (dz_hi - dz_lo) * nchunk;
-  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, 0); }
-  for (int it = 0; it < niter; ++it) {
-    const int dz = dz_lo + it / nchunk, c0 = (it % nchunk) * CH;
+  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, wbuf0); }
+  auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
     // Both LDS images are double-buffered: buffer (it&1) was last read in iteration it-2 and every wave has passed
     // the barrier of iteration it-1 since, so it can be overwritten without a barrier in front -> one barrier per stage.
     float* tile = tile2[it & 1];
 #pragma unroll
     for (int t = 0; t < NLD; ++t)
-      if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = ((valid >> t) & 1) ? stage[t] : 0.f;
+      if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = stage[t];
     __syncthreads();                                   // tile stores + the stage's weight DMA (vmcnt(0)) visible to all
     if (it + 1 < niter) {                              // both in flight during the MFMAs
       prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CH);
-      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CH, (it + 1) & 1);
+      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CH, wnext);
     }
     {
       // Operand pipeline: the A/B values of group g+1 (one tap x 2 channels: CB + PR LDS values) are read while the
       // PR*CB MFMAs of group g issue, so no MFMA waits on an LDS round trip (left to itself the scheduler parks each
       // ds_read right in front of its first use).
-      const float* wl = &wbuf[it & 1][l31 + half * RW];
+      const float* wl = &wcur[l31 + half * RW];
       const float* tl = &tile[half * ROWS * MF_COLS + (wave * PR) * MF_COLS + l31];
-      (void)dz; (void)c0;
       constexpr int NCP = CH / 2, NG = 9 * NCP;
       float av[2][CB], bv[2][PR];
       auto load_group = [&](int g, float (&A)[CB], float (&B)[PR]) __attribute__((always_inline)) {
@@ -327,6 +341,10 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+  };
+  for (int it = 0; it < niter; it += 2) {                // niter is even: Cin is a multiple of 2*CH
+    stage_body(it, wbuf0, wbuf1);
+    stage_body(it + 1, wbuf1, wbuf0);
   }
   const int x = x0 + l31;
   if (x < a.W) {
@@ -344,6 +362,203 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
           a.y[((size_t)b * a.cout + co) * vol + (size_t)z * plane + (size_t)y * a.W + x] = v;
         }
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2D 3x3 convolution in the Winograd domain, F(2x2, 3x3), fp32 on v_mfma_f32_32x32x2_f32:
+//   Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A      (Lavin & Gray; d = 4x4 input patch of a 2x2 output block)
+// 16 multiplies per 4 outputs instead of 36: the contraction over input channels becomes 16 independent GEMMs (one per
+// position p of the 4x4 transform domain)
+//   D_p[cout 32][block 32] += Wt_p[cout][k] * Xt_p[k][block],   k = two consecutive input channels
+// A wave owns 32 output channels x 32 blocks (16 x 2 blocks = 32 x 4 pixels) and ALL 16 positions: 16 accumulators of
+// 16 registers (the AGPR half of a 512-register budget, one wave per SIMD).  Workgroup = 4 waves = NCG output-channel
+// groups x NPG pixel groups (stacked in y).  A stage is WCH input channels:
+//   raw halo tile  global -> registers (prefetched during the previous stage's MFMAs) -> LDS
+//   B^T d B        per (channel, block) patch by the 256 threads, LDS -> LDS [p][c][block]
+//   G g G^T        precomputed at pack time, [p][cin][cout]; the stage's slice goes global -> LDS by global_load_lds (DMA,
+//                  double-buffered, one stage ahead)
+//   16 * WCH/2 MFMAs per wave with the operand reads of k-step i+1 issued under the MFMAs of k-step i
+// and the epilogue applies A^T . A per output channel register, adds the bias, clamps (ReLU) and stores pixel pairs.
+// Numerics: not the summation order of a direct convolution; the transforms are exact in binary up to the roundings of
+// their additions (|error| ~ 1e-6 relative, inside the CNN's stated 2e-5 tolerance; tests/test_parity_gpu.py).
+// ---------------------------------------------------------------------------------------------------
+constexpr int WCH = 8;            // input channels per stage
+constexpr int WCOLS = 34;         // 32 pixels + halo
+
+template <int NCG>
+__global__ __launch_bounds__(256, 1) void conv3_wino_kernel(ConvArgs a, const float* __restrict__ wt) {
+  constexpr int NPG = 4 / NCG;
+  constexpr int ROWS = 4 * NPG + 2;              // raw tile rows: y0-1 .. y0+4*NPG
+  constexpr int NB = 32 * NPG;                   // blocks per workgroup
+  constexpr int RW = 32 * NCG;                   // output channels per workgroup = floats per weight row
+  constexpr int WROWS = 16 * WCH;                // (position, cin) rows per stage
+  constexpr int LPR = RW / 4, RPI = 64 / LPR, NWI = WROWS / RPI;
+  constexpr int NEL = WCH * ROWS * WCOLS, NLD = (NEL + 255) / 256;
+  constexpr int NPATCH = WCH * NB, PPT = NPATCH / 256;         // patches per thread (1, 2 or 4)
+  __shared__ __attribute__((aligned(16))) float raw[NEL];
+  __shared__ __attribute__((aligned(16))) float xt[16 * WCH * NB];
+  // two separate arrays (not wbuf[2][..]): the compiler then knows that the DMA into one cannot alias the reads of the
+  // other and does not drain vmcnt (the next stage's loads, just issued) in front of the MFMA phase
+  __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];
+  __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int cg = wave % NCG, pg = wave / NCG;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * NPG);
+  const int ngrp = a.cout / RW;
+  const int grp = blockIdx.z % ngrp, b = blockIdx.z / ngrp;
+  const int cout0 = grp * RW;
+  const size_t plane = (size_t)a.H * a.W;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  const float* xb = a.x + (size_t)b * a.cin * plane;
+  // Staging slots: element idx = threadIdx.x + 256*t of the [WCH][ROWS][34] halo tile.  Loads go through a buffer
+  // resource that spans the stage's WCH channel planes: an out-of-image element gets an out-of-range offset and the
+  // hardware returns 0 for it -- no select between the load and the LDS store (the compiler hoists such a select to
+  // the load and drains vmcnt there, in front of the MFMA phase the load is supposed to hide under).
+  unsigned uoff[NLD];
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    const int cc = idx / (ROWS * WCOLS);
+    const int rem = idx - cc * ROWS * WCOLS;
+    const int row = rem / WCOLS, col = rem - row * WCOLS;
+    const int gx = x0 - 1 + col, gy = y0 - 1 + row;
+    const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+    uoff[t] = ok ? (unsigned)(((size_t)cc * plane + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
+  }
+  const unsigned stage_bytes = (unsigned)((size_t)WCH * plane * 4);        // < 2^32: checked by the host (launch_conv)
+  float stage[NLD];
+  auto prefetch = [&](int c0) {
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * plane, stage_bytes);
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
+  };
+  auto stage_weights = [&](int c0, float* wdst) {
+#pragma unroll
+    for (int q = 0; q < NWI / 4; ++q) {
+      const int wi = wave + 4 * q;                      // wave-uniform
+      const int row = wi * RPI + lane / LPR;            // (p, ci)
+      const int pp = row / WCH, ci = row - pp * WCH;
+      const float* src = wt + ((size_t)pp * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
+    }
+  };
+  const int niter = a.cin / WCH;                        // even (checked by the host)
+  prefetch(0); stage_weights(0, wbuf0);
+  auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
+    // raw tile of this stage -> LDS (the previous stage's transform reads finished before its second barrier)
+#pragma unroll
+    for (int t = 0; t < NLD; ++t)
+      if (threadIdx.x + 256 * t < NEL) raw[threadIdx.x + 256 * t] = stage[t];
+    __syncthreads();                                   // raw visible; every wave is done with xt of the previous stage
+    // input transform B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int q = threadIdx.x + 256 * i;
+      const int n = q % NB, c = q / NB;
+      const int bx = n & 15, by = n >> 4;
+      const float* d = &raw[c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx];
+      float t[4][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float d0 = d[s], d1 = d[WCOLS + s], d2 = d[2 * WCOLS + s], d3 = d[3 * WCOLS + s];
+        t[0][s] = d0 - d2; t[1][s] = d1 + d2; t[2][s] = d2 - d1; t[3][s] = d1 - d3;
+      }
+      float* o = &xt[c * NB + n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[(4 * r + 0) * WCH * NB] = t[r][0] - t[r][2];
+        o[(4 * r + 1) * WCH * NB] = t[r][1] + t[r][2];
+        o[(4 * r + 2) * WCH * NB] = t[r][2] - t[r][1];
+        o[(4 * r + 3) * WCH * NB] = t[r][1] - t[r][3];
+      }
+    }
+    __syncthreads();                                   // xt + this stage's weight DMA (issued one stage ago) visible
+    // next stage's raw tile (-> registers) and weights (-> LDS) are in flight during the MFMAs; issued after the barrier so
+    // that its vmcnt(0) only covers transfers that had a whole MFMA phase to land
+    if (it + 1 < niter) { prefetch((it + 1) * WCH); stage_weights((it + 1) * WCH, wnext); }
+    {
+      const float* wl = &wcur[half * RW + cg * 32 + l31];
+      const float* tl = &xt[half * NB + pg * 32 + l31];
+      float av[2][16], bv[2][16];
+      auto load_k = [&](int ks, float (&A)[16], float (&B)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          A[p] = wl[(p * WCH + 2 * ks) * RW];
+          B[p] = tl[(p * WCH + 2 * ks) * NB];
+        }
+      };
+      load_k(0, av[0], bv[0]);
+#pragma unroll
+      for (int ks = 0; ks < WCH / 2; ++ks) {
+        if (ks + 1 < WCH / 2) load_k(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][p], bv[ks & 1][p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  for (int it = 0; it < niter; it += 2) {
+    stage_body(it, wbuf0, wbuf1);
+    stage_body(it + 1, wbuf1, wbuf0);
+  }
+  // output transform A^T M A, A^T = [1 1 1 0; 0 1 -1 -1], per output-channel register
+  const int bx = l31 & 15, byl = l31 >> 4;
+  const int x = x0 + 2 * bx, y = y0 + 2 * (2 * pg + byl);
+  if (x < a.W && y < a.H) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cout0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float bias = a.bias[co];
+      float t0[4], t1[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        t0[s] = (acc[s][r] + acc[4 + s][r]) + acc[8 + s][r];
+        t1[s] = (acc[4 + s][r] - acc[8 + s][r]) - acc[12 + s][r];
+      }
+      float y00 = ((t0[0] + t0[1]) + t0[2]) + bias, y01 = ((t0[1] - t0[2]) - t0[3]) + bias;
+      float y10 = ((t1[0] + t1[1]) + t1[2]) + bias, y11 = ((t1[1] - t1[2]) - t1[3]) + bias;
+      if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+      float* o = a.y + ((size_t)b * a.cout + co) * plane + (size_t)y * a.W + x;
+      if (x + 1 < a.W) {
+        *(float2*)o = make_float2(y00, y01);
+        if (y + 1 < a.H) *(float2*)(o + a.W) = make_float2(y10, y11);
+      } else {
+        o[0] = y00;
+        if (y + 1 < a.H) o[a.W] = y10;
+      }
+    }
+  }
+}
+
+// blob: (Cout,Cin,3x3) -> G g G^T as [16][Cin][Cout], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+__global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
+  const int n = cin * cout;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int co = q / cin, ci = q - co * cin;
+    const float* g = w + (size_t)q * 9;
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float g0 = g[s], g1 = g[3 + s], g2 = g[6 + s];
+      t[0][s] = g0; t[1][s] = 0.5f * ((g0 + g1) + g2); t[2][s] = 0.5f * ((g0 - g1) + g2); t[3][s] = g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float u[4] = { t[r][0], 0.5f * ((t[r][0] + t[r][1]) + t[r][2]), 0.5f * ((t[r][0] - t[r][1]) + t[r][2]), t[r][2] };
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pw[((size_t)(4 * r + s) * cin + ci) * cout + co] = u[s];
     }
   }
 }
@@ -546,10 +761,30 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
   }
 }
 
+// Winograd F(2x2,3x3) for the 2D 3x3 MFMA layers, when the launch fills the chip (one workgroup per CU at a time)
+bool launch_conv_wino(const ConvArgs& a, const float* wt, hipStream_t s) {
+  static const bool off = [] { const char* e = getenv("FNX_CONV_WINO"); return e && atoi(e) == 0; }();   // A/B switch
+  if (off || a.D != 1 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
+  const int ncg = a.cout % 128 == 0 ? 4 : (a.cout % 64 == 0 ? 2 : 1), npg = 4 / ncg;
+  const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * (a.cout / (32 * ncg)));
+  if ((long)grid.x * grid.y * grid.z < 512) return false;
+  if (ncg == 4) conv3_wino_kernel<4><<<grid, 256, 0, s>>>(a, wt);
+  else if (ncg == 2) conv3_wino_kernel<2><<<grid, 256, 0, s>>>(a, wt);
+  else conv3_wino_kernel<1><<<grid, 256, 0, s>>>(a, wt);
+  return true;
+}
+
 void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const PackedLayer& pl, const float* x, float* y,
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
-  if (mfma_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA, s); launch_conv_mfma(a, is3d, s); return; }
+  // (the MFMA kernels address a stage of 8 channel volumes through one 32-bit buffer range: 2^27 cells per sample at
+  // most; beyond that -- 137 GB per 128-channel activation -- the direct kernel below still works)
+  if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
+    ProfScope ps(FNX_PROF_CONV_MFMA, s);
+    if (wino_layer(L, is3d) && launch_conv_wino(a, packed + pl.w_off + layer_weight_floats(L, is3d), s)) return;
+    launch_conv_mfma(a, is3d, s);
+    return;
+  }
   if (mfma16_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA16, s); launch_conv_mfma16(a, is3d, s); return; }
   ProfScope ps(FNX_PROF_CONV_DIRECT, s);
   if (is3d) {
@@ -639,9 +874,11 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     const ConvLayer& L = LAYERS[l];
     const PackedLayer pl = packed_layer(l, is3d);
     const size_t nw = layer_weight_floats(L, is3d);
-    if (mfma_layer(L))
+    if (mfma_layer(L)) {
       pack_layer_mfma_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 layer_taps(L, is3d));
+      if (wino_layer(L, is3d)) pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + nw, L.cin, L.cout);
+    }
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
       pack_layer_pair_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 is3d ? 5 : 1, pad_to(L.cin, 4));
