@@ -542,6 +542,192 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(ConvArgs a, const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Second Winograd kernel: the same F(2x2,3x3) GEMMs with the 16 positions of a (32 output channels x 32 blocks) tile
+// split over TWO waves (8 positions = 128 accumulator registers each), so that a wave fits a 256-register budget and
+// TWO workgroups share a CU: while one is between its barriers (halo tile -> LDS, input transform, operand latency)
+// the other one's MFMAs keep the matrix cores busy -- with one 512-register wave per SIMD (conv3_wino_kernel) every
+// such gap is exposed (measured: MFMA phase 407 us of a 1073 us layer).  Workgroup = 4 waves = 2 position halves x
+// NCG output-channel groups x (2/NCG) pixel groups; stage = 4 input channels (43 KB of LDS per workgroup).  Each wave
+// ends with partial outputs (A^T . A is linear in the positions); the two halves swap half of their 16 output-channel
+// registers through LDS and each finishes (bias, ReLU, store) its own 8.
+// ---------------------------------------------------------------------------------------------------
+constexpr int W2CH = 4;           // input channels per stage
+
+template <int NCG>
+__global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const float* __restrict__ wt) {
+  constexpr int NPG = 2 / NCG;
+  constexpr int ROWS = 4 * NPG + 2;
+  constexpr int NB = 32 * NPG;
+  constexpr int RW = 32 * NCG;
+  constexpr int WROWS = 16 * W2CH;
+  constexpr int LPR = RW / 4, RPI = 64 / LPR, NWI = WROWS / RPI;
+  constexpr int NEL = W2CH * ROWS * WCOLS, NLD = (NEL + 255) / 256;
+  constexpr int NPATCH = W2CH * NB;                     // 128 or 256 patches per stage
+  __shared__ __attribute__((aligned(16))) float raw[NEL];
+  __shared__ __attribute__((aligned(16))) float xt[16 * W2CH * NB];
+  __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];     // (separate arrays: see conv3_mfma_kernel)
+  __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
+  __shared__ __attribute__((aligned(16))) float exch[4 * 16 * 64];     // per wave and round: 4 registers x 4 outputs x 64 lanes
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int h = wave & 1, g = wave >> 1;                // position half; output-channel or pixel group
+  const int cg = NCG == 2 ? g : 0, pg = NCG == 2 ? 0 : g;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * NPG);
+  const int ngrp = a.cout / RW;
+  const int grp = blockIdx.z % ngrp, b = blockIdx.z / ngrp;
+  const int cout0 = grp * RW;
+  const size_t plane = (size_t)a.H * a.W;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  const float* xb = a.x + (size_t)b * a.cin * plane;
+  unsigned uoff[NLD];                                   // (out-of-image slots: out-of-range offset, the load returns 0)
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    const int cc = idx / (ROWS * WCOLS);
+    const int rem = idx - cc * ROWS * WCOLS;
+    const int row = rem / WCOLS, col = rem - row * WCOLS;
+    const int gx = x0 - 1 + col, gy = y0 - 1 + row;
+    const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+    uoff[t] = ok ? (unsigned)(((size_t)cc * plane + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
+  }
+  const unsigned stage_bytes = (unsigned)((size_t)W2CH * plane * 4);
+  float stage[NLD];
+  auto prefetch = [&](int c0) {
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * plane, stage_bytes);
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
+  };
+  auto stage_weights = [&](int c0, float* wdst) {
+#pragma unroll
+    for (int q = 0; q < NWI / 4; ++q) {
+      const int wi = wave + 4 * q;
+      const int row = wi * RPI + lane / LPR;            // (p, ci)
+      const int pp = row / W2CH, ci = row - pp * W2CH;
+      const float* src = wt + ((size_t)pp * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
+    }
+  };
+  const int niter = a.cin / W2CH;                       // even (checked by the host)
+  prefetch(0); stage_weights(0, wbuf0);
+  // (A prefetch distance of two stages -- three weight buffers, two register sets -- was tried and changes nothing: the
+  // workgroup-scope fence of every barrier waits for ALL outstanding LDS DMA, so the distance is one stage either way.)
+  auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NLD; ++t)
+      if (threadIdx.x + 256 * t < NEL) raw[threadIdx.x + 256 * t] = stage[t];
+    __syncthreads();
+    if (NPATCH == 256 || threadIdx.x < NPATCH) {        // B^T d B
+      const int q = threadIdx.x;
+      const int n = q % NB, c = q / NB;
+      const int bx = n & 15, by = n >> 4;
+      const float* d = &raw[c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx];
+      float t[4][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float d0 = d[s], d1 = d[WCOLS + s], d2 = d[2 * WCOLS + s], d3 = d[3 * WCOLS + s];
+        t[0][s] = d0 - d2; t[1][s] = d1 + d2; t[2][s] = d2 - d1; t[3][s] = d1 - d3;
+      }
+      float* o = &xt[c * NB + n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[(4 * r + 0) * W2CH * NB] = t[r][0] - t[r][2];
+        o[(4 * r + 1) * W2CH * NB] = t[r][1] + t[r][2];
+        o[(4 * r + 2) * W2CH * NB] = t[r][2] - t[r][1];
+        o[(4 * r + 3) * W2CH * NB] = t[r][1] - t[r][3];
+      }
+    }
+    __syncthreads();
+    if (it + 1 < niter) { prefetch((it + 1) * W2CH); stage_weights((it + 1) * W2CH, wnext); }
+    {
+      const float* wl = &wcur[(8 * h * W2CH + half) * RW + cg * 32 + l31];
+      const float* tl = &xt[(8 * h * W2CH + half) * NB + pg * 32 + l31];
+      float av[2][8], bv[2][8];
+      auto load_k = [&](int ks, float (&A)[8], float (&B)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          A[p] = wl[(p * W2CH + 2 * ks) * RW];
+          B[p] = tl[(p * W2CH + 2 * ks) * NB];
+        }
+      };
+      load_k(0, av[0], bv[0]);
+#pragma unroll
+      for (int ks = 0; ks < W2CH / 2; ++ks) {
+        if (ks + 1 < W2CH / 2) load_k(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][p], bv[ks & 1][p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  for (int it = 0; it < niter; it += 2) {
+    stage_body(it, wbuf0, wbuf1);
+    stage_body(it + 1, wbuf1, wbuf0);
+  }
+  // Output transform A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]); this wave holds rows 2h, 2h+1 of M (acc[4*(row-2h) + s]):
+  //   h = 0:  t0 = M0 + M1, t1 = M1          h = 1:  t0 = M2, t1 = -M2 - M3
+  // Register r belongs to half (r >> 3): the partial outputs of the other half's registers go to LDS, the own ones are
+  // completed with the partner's.
+  float part[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float t0[4], t1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (h == 0) { t0[s] = acc[s][r] + acc[4 + s][r]; t1[s] = acc[4 + s][r]; }
+      else { t0[s] = acc[s][r]; t1[s] = (-acc[s][r]) - acc[4 + s][r]; }
+    }
+    part[r][0] = (t0[0] + t0[1]) + t0[2]; part[r][1] = (t0[1] - t0[2]) - t0[3];
+    part[r][2] = (t1[0] + t1[1]) + t1[2]; part[r][3] = (t1[1] - t1[2]) - t1[3];
+  }
+  const int bx = l31 & 15, byl = l31 >> 4;
+  const int x = x0 + 2 * bx, y = y0 + 2 * (2 * pg + byl);
+  float* ex_out = &exch[wave * 16 * 64 + lane];          // what this wave sends: registers of the other half
+  const float* ex_in = &exch[(wave ^ 1) * 16 * 64 + lane];
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {              // 4 of the 8 registers per round (16 KB of LDS)
+    __syncthreads();                                     // (round 0: every wave is done with the stage buffers' neighbours; round 1: round 0 was read)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((r >> 3) != h && ((r >> 2) & 1) == round) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ex_out[((r & 3) * 4 + q) * 64] = part[r][q];
+      }
+    __syncthreads();
+    if (x < a.W && y < a.H) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((r >> 3) == h && ((r >> 2) & 1) == round) {
+          const int co = cout0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float bias = a.bias[co];
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[q] = (part[r][q] + ex_in[((r & 3) * 4 + q) * 64]) + bias;
+            if (a.relu) v[q] = fmaxf(v[q], 0.f);
+          }
+          float* o = a.y + ((size_t)b * a.cout + co) * plane + (size_t)y * a.W + x;
+          if (x + 1 < a.W) {
+            *(float2*)o = make_float2(v[0], v[1]);
+            if (y + 1 < a.H) *(float2*)(o + a.W) = make_float2(v[2], v[3]);
+          } else {
+            o[0] = v[0];
+            if (y + 1 < a.H) o[a.W] = v[2];
+          }
+        }
+    }
+  }
+}
+
 // blob: (Cout,Cin,3x3) -> G g G^T as [16][Cin][Cout], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 __global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
   const int n = cin * cout;
@@ -763,8 +949,17 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
 
 // Winograd F(2x2,3x3) for the 2D 3x3 MFMA layers, when the launch fills the chip (one workgroup per CU at a time)
 bool launch_conv_wino(const ConvArgs& a, const float* wt, hipStream_t s) {
-  static const bool off = [] { const char* e = getenv("FNX_CONV_WINO"); return e && atoi(e) == 0; }();   // A/B switch
-  if (off || a.D != 1 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
+  // FNX_CONV_WINO: 0 = off (direct implicit GEMM), 1 = conv3_wino_kernel, 2 (default) = conv3_wino2_kernel
+  static const int mode = [] { const char* e = getenv("FNX_CONV_WINO"); return e ? atoi(e) : 2; }();
+  if (mode == 0 || a.D != 1 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
+  if (mode == 2) {
+    const int ncg = a.cout % 64 == 0 ? 2 : 1, npg = 2 / ncg;
+    const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * (a.cout / (32 * ncg)));
+    if ((long)grid.x * grid.y * grid.z < 1024) return false;
+    if (ncg == 2) conv3_wino2_kernel<2><<<grid, 256, 0, s>>>(a, wt);
+    else conv3_wino2_kernel<1><<<grid, 256, 0, s>>>(a, wt);
+    return true;
+  }
   const int ncg = a.cout % 128 == 0 ? 4 : (a.cout % 64 == 0 ? 2 : 1), npg = 4 / ncg;
   const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * (a.cout / (32 * ncg)));
   if ((long)grid.x * grid.y * grid.z < 512) return false;
