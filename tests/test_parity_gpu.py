@@ -250,6 +250,27 @@ def test_cnn_vs_oracle(dev, oracle, shape):
     assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352)])
+def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
+    """Grids large enough for the full-resolution 3x3 layers to take the Winograd kernels (>= 1024 tiles; both the
+    64-channel-group and the 32-channel instantiation), with partial tiles, an odd width and an odd height."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    B, D, H, W = shape
+    w = make_scalenet_weights(0)
+    mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False)
+    net = FluidNet(mconf, w, dev)
+    s = random_state(B, D, H, W, 0.5, seed=12)
+    inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
+    p, U = net(T(inp, dev))
+    po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, 2), inp)
+    assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
+    # the MultiScaleNet alone, on inputs of O(1) magnitude
+    x = np.random.default_rng(3).standard_normal((B, 2, 1, H, W)).astype(np.float32)
+    assert_close(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 2e-5, "MultiScaleNet")
+
+
 def test_sim64_convnet_vs_reference(dev, golden):
     from fluidnet_cxx_amd import FluidNet, simulate
     from fluidnet_cxx_amd.weights import make_scalenet_weights
