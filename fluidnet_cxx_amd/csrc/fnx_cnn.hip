@@ -553,9 +553,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(ConvArgs a, const fl
 // ends with partial outputs (A^T . A is linear in the positions); the two halves swap half of their 16 output-channel
 // registers through LDS and each finishes (bias, ReLU, store) its own 8.
 // ---------------------------------------------------------------------------------------------------
-constexpr int W2CH = 4;           // input channels per stage
-
-template <int NCG>
+template <int NCG, int W2CH>      // W2CH = input channels per stage
 __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const float* __restrict__ wt) {
   constexpr int NPG = 2 / NCG;
   constexpr int ROWS = 4 * NPG + 2;
@@ -564,12 +562,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   constexpr int WROWS = 16 * W2CH;
   constexpr int LPR = RW / 4, RPI = 64 / LPR, NWI = WROWS / RPI;
   constexpr int NEL = W2CH * ROWS * WCOLS, NLD = (NEL + 255) / 256;
-  constexpr int NPATCH = W2CH * NB;                     // 128 or 256 patches per stage
+  constexpr int NPATCH = W2CH * NB, PPT = (NPATCH + 255) / 256;     // (channel, block) patches per stage / per thread
   __shared__ __attribute__((aligned(16))) float raw[NEL];
   __shared__ __attribute__((aligned(16))) float xt[16 * W2CH * NB];
   __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];     // (separate arrays: see conv3_mfma_kernel)
   __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
-  __shared__ __attribute__((aligned(16))) float exch[4 * 16 * 64];     // per wave and round: 4 registers x 4 outputs x 64 lanes
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int h = wave & 1, g = wave >> 1;                // position half; output-channel or pixel group
@@ -625,8 +622,10 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
     for (int t = 0; t < NLD; ++t)
       if (threadIdx.x + 256 * t < NEL) raw[threadIdx.x + 256 * t] = stage[t];
     __syncthreads();
-    if (NPATCH == 256 || threadIdx.x < NPATCH) {        // B^T d B
-      const int q = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+    if (NPATCH % 256 == 0 || threadIdx.x + 256 * i < NPATCH) {        // B^T d B
+      const int q = threadIdx.x + 256 * i;
       const int n = q % NB, c = q / NB;
       const int bx = n & 15, by = n >> 4;
       const float* d = &raw[c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx];
@@ -692,6 +691,10 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   }
   const int bx = l31 & 15, byl = l31 >> 4;
   const int x = x0 + 2 * bx, y = y0 + 2 * (2 * pg + byl);
+  // exchange buffer (per wave and round: 4 registers x 4 outputs x 64 lanes): xt itself when it is large enough
+  constexpr bool XT_BIG = 16 * W2CH * NB >= 4 * 16 * 64;
+  __shared__ __attribute__((aligned(16))) float exch_sep[XT_BIG ? 1 : 4 * 16 * 64];
+  float* exch = XT_BIG ? xt : exch_sep;
   float* ex_out = &exch[wave * 16 * 64 + lane];          // what this wave sends: registers of the other half
   const float* ex_in = &exch[(wave ^ 1) * 16 * 64 + lane];
 #pragma unroll
@@ -954,11 +957,14 @@ bool launch_conv_wino(const ConvArgs& a, const float* wt, hipStream_t s) {
   static const int mode = [] { const char* e = getenv("FNX_CONV_WINO"); return e ? atoi(e) : 2; }();
   if (mode == 0 || a.D != 1 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
   if (mode == 2) {
+    // 64 output channels per workgroup with 4-channel stages; the 32-channel layers: two pixel groups, 8-channel stages
+    // (measured at 1024^2: 64->32 297 -> 274 us; 8-channel stages with 32 output channels per workgroup on the wider
+    // layers: 918 -> 1065 us, the input tile is read and transformed once per 32 instead of 64 output channels)
     const int ncg = a.cout % 64 == 0 ? 2 : 1, npg = 2 / ncg;
     const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * (a.cout / (32 * ncg)));
     if ((long)grid.x * grid.y * grid.z < 1024) return false;
-    if (ncg == 2) conv3_wino2_kernel<2><<<grid, 256, 0, s>>>(a, wt);
-    else conv3_wino2_kernel<1><<<grid, 256, 0, s>>>(a, wt);
+    if (ncg == 2) conv3_wino2_kernel<2, 4><<<grid, 256, 0, s>>>(a, wt);
+    else conv3_wino2_kernel<1, 8><<<grid, 256, 0, s>>>(a, wt);
     return true;
   }
   const int ncg = a.cout % 128 == 0 ? 4 : (a.cout % 64 == 0 ? 2 : 1), npg = 4 / ncg;
