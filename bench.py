@@ -240,9 +240,10 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         tms, nl = times["conv_mfma"]
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
         ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
-        kname = ("conv3_mfma_kernel (implicit-GEMM 3x3x3 conv, v_mfma_f32_32x32x2_f32)" if is3d else
-                 "conv3_wino2_kernel (3x3 conv in the Winograd F(2x2,3x3) domain: 16 multiplies per 4 outputs instead of 36, "
-                 "v_mfma_f32_32x32x2_f32); achieved = DIRECT-convolution FLOPs / time, so it can exceed the MFMA peak")
+        kname = ("conv3_wino2_kernel (3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
+                 (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
+                 "instead of 36, v_mfma_f32_32x32x2_f32); achieved = DIRECT-convolution FLOPs / time, so it can exceed "
+                 "the MFMA peak")
         roof = dict(bound="mfma", kernel=kname, achieved=ach,
                     peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=traffic,
                     launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),

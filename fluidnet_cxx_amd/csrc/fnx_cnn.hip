@@ -33,9 +33,9 @@ inline bool pair_layer(int cin, int cout) {
 inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 && L.cout % 32 == 0; }
 // 2D 3x3 MFMA layers also run in the Winograd domain (conv3_wino_kernel): their transformed weights G g G^T
 // ([16][Cin][Cout]) follow the [tap][Cin][Cout] image in the packed buffer
-inline bool wino_layer(const ConvLayer& L, bool is3d) { return !is3d && mfma_layer(L); }
+inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_layer(L); }
 inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
-  if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + (size_t)16 * L.cin * L.cout;
+  if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
   if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
@@ -553,7 +553,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(ConvArgs a, const fl
 // ends with partial outputs (A^T . A is linear in the positions); the two halves swap half of their 16 output-channel
 // registers through LDS and each finishes (bias, ReLU, store) its own 8.
 // ---------------------------------------------------------------------------------------------------
-template <int NCG, int W2CH>      // W2CH = input channels per stage
+// IS3D: a 3x3x3 convolution is the sum over its three z taps of 3x3 convolutions of the planes z-1, z, z+1 -- the same
+// 16 GEMMs with three times the contraction length (transformed weights [dz][16][Cin][Cout]); Winograd in x and y only.
+template <int NCG, int W2CH, bool IS3D = false>      // W2CH = input channels per stage
 __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const float* __restrict__ wt) {
   constexpr int NPG = 2 / NCG;
   constexpr int ROWS = 4 * NPG + 2;
@@ -573,9 +575,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   const int cg = NCG == 2 ? g : 0, pg = NCG == 2 ? 0 : g;
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * NPG);
   const int ngrp = a.cout / RW;
-  const int grp = blockIdx.z % ngrp, b = blockIdx.z / ngrp;
+  int zb = blockIdx.z;
+  const int grp = zb % ngrp; zb /= ngrp;
+  const int z = zb % a.D, b = zb / a.D;
   const int cout0 = grp * RW;
-  const size_t plane = (size_t)a.H * a.W;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
 
   f32x16 acc[8];
 #pragma unroll
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-  const float* xb = a.x + (size_t)b * a.cin * plane;
+  const float* xb = a.x + (size_t)b * a.cin * vol;
   unsigned uoff[NLD];                                   // (out-of-image slots: out-of-range offset, the load returns 0)
 #pragma unroll
   for (int t = 0; t < NLD; ++t) {
@@ -593,28 +597,33 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
     const int row = rem / WCOLS, col = rem - row * WCOLS;
     const int gx = x0 - 1 + col, gy = y0 - 1 + row;
     const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    uoff[t] = ok ? (unsigned)(((size_t)cc * plane + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
+    uoff[t] = ok ? (unsigned)(((size_t)cc * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
   }
-  const unsigned stage_bytes = (unsigned)((size_t)W2CH * plane * 4);
+  const unsigned stage_bytes = (unsigned)((size_t)W2CH * vol * 4 - 1) + 1u;
   float stage[NLD];
-  auto prefetch = [&](int c0) {
-    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * plane, stage_bytes);
+  auto prefetch = [&](int dz, int c0) {
+    const int zz = IS3D ? z + dz - 1 : 0;
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
 #pragma unroll
     for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
   };
-  auto stage_weights = [&](int c0, float* wdst) {
+  auto stage_weights = [&](int dz, int c0, float* wdst) {
 #pragma unroll
     for (int q = 0; q < NWI / 4; ++q) {
       const int wi = wave + 4 * q;
       const int row = wi * RPI + lane / LPR;            // (p, ci)
       const int pp = row / W2CH, ci = row - pp * W2CH;
-      const float* src = wt + ((size_t)pp * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
+      const float* src = wt + ((size_t)(dz * 16 + pp) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
     }
   };
-  const int niter = a.cin / W2CH;                       // even (checked by the host)
-  prefetch(0); stage_weights(0, wbuf0);
+  // iteration space: (dz, c0) pairs with an in-range z plane; Cin / W2CH is even (checked by the host), so is niter
+  const int nchunk = a.cin / W2CH;
+  int dz_lo = 0, dz_hi = IS3D ? 3 : 1;
+  if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = 2; }
+  const int niter = (dz_hi - dz_lo) * nchunk;
+  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, wbuf0); }
   // (A prefetch distance of two stages -- three weight buffers, two register sets -- was tried and changes nothing: the
   // workgroup-scope fence of every barrier waits for ALL outstanding LDS DMA, so the distance is one stage either way.)
   auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
@@ -645,7 +654,10 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
       }
     }
     __syncthreads();
-    if (it + 1 < niter) { prefetch((it + 1) * W2CH); stage_weights((it + 1) * W2CH, wnext); }
+    if (it + 1 < niter) {
+      const int dzn = dz_lo + (it + 1) / nchunk, cn = ((it + 1) % nchunk) * W2CH;
+      prefetch(dzn, cn); stage_weights(dzn, cn, wnext);
+    }
     {
       const float* wl = &wcur[(8 * h * W2CH + half) * RW + cg * 32 + l31];
       const float* tl = &xt[(8 * h * W2CH + half) * NB + pg * 32 + l31];
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
             v[q] = (part[r][q] + ex_in[((r & 3) * 4 + q) * 64]) + bias;
             if (a.relu) v[q] = fmaxf(v[q], 0.f);
           }
-          float* o = a.y + ((size_t)b * a.cout + co) * plane + (size_t)y * a.W + x;
+          float* o = a.y + ((size_t)b * a.cout + co) * vol + (size_t)z * plane + (size_t)y * a.W + x;
           if (x + 1 < a.W) {
             *(float2*)o = make_float2(v[0], v[1]);
             if (y + 1 < a.H) *(float2*)(o + a.W) = make_float2(v[2], v[3]);
@@ -733,11 +745,13 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
 }
 
 // blob: (Cout,Cin,3x3) -> G g G^T as [16][Cin][Cout], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-__global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
-  const int n = cin * cout;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+// (3D: per z tap dz, [dz][16][Cin][Cout])
+__global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout, int kd) {
+  const int n = cin * cout * kd;
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < n; q0 += gridDim.x * blockDim.x) {
+    const int dz = q0 / (cin * cout), q = q0 - dz * cin * cout;
     const int co = q / cin, ci = q - co * cin;
-    const float* g = w + (size_t)q * 9;
+    const float* g = w + ((size_t)q * kd + dz) * 9;
     float t[4][3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -748,7 +762,7 @@ __global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __res
     for (int r = 0; r < 4; ++r) {
       const float u[4] = { t[r][0], 0.5f * ((t[r][0] + t[r][1]) + t[r][2]), 0.5f * ((t[r][0] - t[r][1]) + t[r][2]), t[r][2] };
 #pragma unroll
-      for (int s = 0; s < 4; ++s) pw[((size_t)(4 * r + s) * cin + ci) * cout + co] = u[s];
+      for (int s = 0; s < 4; ++s) pw[((size_t)(dz * 16 + 4 * r + s) * cin + ci) * cout + co] = u[s];
     }
   }
 }
@@ -952,18 +966,22 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
 }
 
 // Winograd F(2x2,3x3) for the 2D 3x3 MFMA layers, when the launch fills the chip (one workgroup per CU at a time)
-bool launch_conv_wino(const ConvArgs& a, const float* wt, hipStream_t s) {
+bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t s) {
   // FNX_CONV_WINO: 0 = off (direct implicit GEMM), 1 = conv3_wino_kernel, 2 (default) = conv3_wino2_kernel
   static const int mode = [] { const char* e = getenv("FNX_CONV_WINO"); return e ? atoi(e) : 2; }();
-  if (mode == 0 || a.D != 1 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
+  if (mode == 0 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
+  if (a.D != 1 && (mode != 2 || !is3d)) return false;
   if (mode == 2) {
     // 64 output channels per workgroup with 4-channel stages; the 32-channel layers: two pixel groups, 8-channel stages
     // (measured at 1024^2: 64->32 297 -> 274 us; 8-channel stages with 32 output channels per workgroup on the wider
     // layers: 918 -> 1065 us, the input tile is read and transformed once per 32 instead of 64 output channels)
     const int ncg = a.cout % 64 == 0 ? 2 : 1, npg = 2 / ncg;
-    const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * (a.cout / (32 * ncg)));
+    const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * a.D * (a.cout / (32 * ncg)));
     if ((long)grid.x * grid.y * grid.z < 1024) return false;
-    if (ncg == 2) conv3_wino2_kernel<2, 4><<<grid, 256, 0, s>>>(a, wt);
+    if (is3d) {
+      if (ncg == 2) conv3_wino2_kernel<2, 4, true><<<grid, 256, 0, s>>>(a, wt);
+      else conv3_wino2_kernel<1, 8, true><<<grid, 256, 0, s>>>(a, wt);
+    } else if (ncg == 2) conv3_wino2_kernel<2, 4><<<grid, 256, 0, s>>>(a, wt);
     else conv3_wino2_kernel<1, 8><<<grid, 256, 0, s>>>(a, wt);
     return true;
   }
@@ -983,7 +1001,7 @@ void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const Packe
   // most; beyond that -- 137 GB per 128-channel activation -- the direct kernel below still works)
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
-    if (wino_layer(L, is3d) && launch_conv_wino(a, packed + pl.w_off + layer_weight_floats(L, is3d), s)) return;
+    if (wino_layer(L, is3d) && launch_conv_wino(a, is3d, packed + pl.w_off + layer_weight_floats(L, is3d), s)) return;
     launch_conv_mfma(a, is3d, s);
     return;
   }
@@ -1079,7 +1097,7 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     if (mfma_layer(L)) {
       pack_layer_mfma_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 layer_taps(L, is3d));
-      if (wino_layer(L, is3d)) pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + nw, L.cin, L.cout);
+      if (wino_layer(L, is3d)) pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + nw, L.cin, L.cout, is3d ? 3 : 1);
     }
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
       pack_layer_pair_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,

@@ -250,25 +250,28 @@ def test_cnn_vs_oracle(dev, oracle, shape):
     assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352)])
+@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 16, 126, 130)])
 def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
     """Grids large enough for the full-resolution 3x3 layers to take the Winograd kernels (>= 1024 tiles; both the
     64-channel-group and the 32-channel instantiation), with partial tiles, an odd width and an odd height."""
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     B, D, H, W = shape
-    w = make_scalenet_weights(0)
+    is3d = D > 1
+    nd = 3 if is3d else 2
+    w = make_scalenet_weights(0, ndim=nd)
     mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
-                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False)
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d)
     net = FluidNet(mconf, w, dev)
     s = random_state(B, D, H, W, 0.5, seed=12)
     inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
     p, U = net(T(inp, dev))
-    po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, 2), inp)
+    po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, nd), inp)
     assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
-    # the MultiScaleNet alone, on inputs of O(1) magnitude
-    x = np.random.default_rng(3).standard_normal((B, 2, 1, H, W)).astype(np.float32)
-    assert_close(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 2e-5, "MultiScaleNet")
+    if not is3d:
+        # the MultiScaleNet alone, on inputs of O(1) magnitude
+        x = np.random.default_rng(3).standard_normal((B, 2, 1, H, W)).astype(np.float32)
+        assert_close(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 2e-5, "MultiScaleNet")
 
 
 def test_sim64_convnet_vs_reference(dev, golden):
