@@ -555,16 +555,19 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(ConvArgs a, const fl
 // ---------------------------------------------------------------------------------------------------
 // IS3D: a 3x3x3 convolution is the sum over its three z taps of 3x3 convolutions of the planes z-1, z, z+1 -- the same
 // 16 GEMMs with three times the contraction length (transformed weights [dz][16][Cin][Cout]); Winograd in x and y only.
-template <int NCG, int W2CH, bool IS3D = false>      // W2CH = input channels per stage
-__global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const float* __restrict__ wt) {
-  constexpr int NPG = 2 / NCG;
+// Workgroup = 2 position halves x NCG output-channel groups x NPG pixel groups (4 or 8 waves).  The weights of a stage are
+// streamed from L2 once per workgroup: with 32 blocks (128 pixels) per workgroup that stream, 4.3 GB for a 64->128 layer
+// at 1024^2, is what bounds the kernel (measured: 430 us of load/DMA time against 437 us of MFMA time); NPG = 2 halves it.
+template <int NCG, int NPG, int W2CH, bool IS3D = false>      // W2CH = input channels per stage
+__global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArgs a, const float* __restrict__ wt) {
+  constexpr int NWV = 2 * NCG * NPG, NT = 64 * NWV;          // waves, threads
   constexpr int ROWS = 4 * NPG + 2;
   constexpr int NB = 32 * NPG;
   constexpr int RW = 32 * NCG;
   constexpr int WROWS = 16 * W2CH;
   constexpr int LPR = RW / 4, RPI = 64 / LPR, NWI = WROWS / RPI;
-  constexpr int NEL = W2CH * ROWS * WCOLS, NLD = (NEL + 255) / 256;
-  constexpr int NPATCH = W2CH * NB, PPT = (NPATCH + 255) / 256;     // (channel, block) patches per stage / per thread
+  constexpr int NEL = W2CH * ROWS * WCOLS, NLD = (NEL + NT - 1) / NT;
+  constexpr int NPATCH = W2CH * NB, PPT = (NPATCH + NT - 1) / NT;     // (channel, block) patches per stage / per thread
   __shared__ __attribute__((aligned(16))) float raw[NEL];
   __shared__ __attribute__((aligned(16))) float xt[16 * W2CH * NB];
   __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];     // (separate arrays: see conv3_mfma_kernel)
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int h = wave & 1, g = wave >> 1;                // position half; output-channel or pixel group
-  const int cg = NCG == 2 ? g : 0, pg = NCG == 2 ? 0 : g;
+  const int cg = g % NCG, pg = g / NCG;
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * NPG);
   const int ngrp = a.cout / RW;
   int zb = blockIdx.z;
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   unsigned uoff[NLD];                                   // (out-of-image slots: out-of-range offset, the load returns 0)
 #pragma unroll
   for (int t = 0; t < NLD; ++t) {
-    const int idx = threadIdx.x + 256 * t;
+    const int idx = threadIdx.x + NT * t;
     const int cc = idx / (ROWS * WCOLS);
     const int rem = idx - cc * ROWS * WCOLS;
     const int row = rem / WCOLS, col = rem - row * WCOLS;
@@ -609,8 +612,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   };
   auto stage_weights = [&](int dz, int c0, float* wdst) {
 #pragma unroll
-    for (int q = 0; q < NWI / 4; ++q) {
-      const int wi = wave + 4 * q;
+    for (int q = 0; q < NWI / NWV; ++q) {
+      const int wi = wave + NWV * q;
       const int row = wi * RPI + lane / LPR;            // (p, ci)
       const int pp = row / W2CH, ci = row - pp * W2CH;
       const float* src = wt + ((size_t)(dz * 16 + pp) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
@@ -629,12 +632,12 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NLD; ++t)
-      if (threadIdx.x + 256 * t < NEL) raw[threadIdx.x + 256 * t] = stage[t];
+      if (threadIdx.x + NT * t < NEL) raw[threadIdx.x + NT * t] = stage[t];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PPT; ++i)
-    if (NPATCH % 256 == 0 || threadIdx.x + 256 * i < NPATCH) {        // B^T d B
-      const int q = threadIdx.x + 256 * i;
+    if (NPATCH % NT == 0 || threadIdx.x + NT * i < NPATCH) {        // B^T d B
+      const int q = threadIdx.x + NT * i;
       const int n = q % NB, c = q / NB;
       const int bx = n & 15, by = n >> 4;
       const float* d = &raw[c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx];
@@ -704,8 +707,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(ConvArgs a, const f
   const int bx = l31 & 15, byl = l31 >> 4;
   const int x = x0 + 2 * bx, y = y0 + 2 * (2 * pg + byl);
   // exchange buffer (per wave and round: 4 registers x 4 outputs x 64 lanes): xt itself when it is large enough
-  constexpr bool XT_BIG = 16 * W2CH * NB >= 4 * 16 * 64;
-  __shared__ __attribute__((aligned(16))) float exch_sep[XT_BIG ? 1 : 4 * 16 * 64];
+  constexpr bool XT_BIG = 16 * W2CH * NB >= NWV * 16 * 64;
+  __shared__ __attribute__((aligned(16))) float exch_sep[XT_BIG ? 1 : NWV * 16 * 64];
   float* exch = XT_BIG ? xt : exch_sep;
   float* ex_out = &exch[wave * 16 * 64 + lane];          // what this wave sends: registers of the other half
   const float* ex_in = &exch[(wave ^ 1) * 16 * 64 + lane];
@@ -975,14 +978,19 @@ bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t
     // 64 output channels per workgroup with 4-channel stages; the 32-channel layers: two pixel groups, 8-channel stages
     // (measured at 1024^2: 64->32 297 -> 274 us; 8-channel stages with 32 output channels per workgroup on the wider
     // layers: 918 -> 1065 us, the input tile is read and transformed once per 32 instead of 64 output channels)
-    const int ncg = a.cout % 64 == 0 ? 2 : 1, npg = 2 / ncg;
+    static const int v8 = [] { const char* e = getenv("FNX_WINO2_WAVES8"); return e ? atoi(e) : 1; }();   // A/B switch
+    const int ncg = a.cout % 64 == 0 ? 2 : 1;
+    int npg = 2 / ncg;
+    if (ncg == 2 && v8 && (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B * a.D * (a.cout / 64) >= 512) npg = 2;   // 8 waves
     const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * a.D * (a.cout / (32 * ncg)));
-    if ((long)grid.x * grid.y * grid.z < 1024) return false;
+    if ((long)grid.x * grid.y * grid.z < (npg * ncg == 4 ? 512 : 1024)) return false;
     if (is3d) {
-      if (ncg == 2) conv3_wino2_kernel<2, 4, true><<<grid, 256, 0, s>>>(a, wt);
-      else conv3_wino2_kernel<1, 8, true><<<grid, 256, 0, s>>>(a, wt);
-    } else if (ncg == 2) conv3_wino2_kernel<2, 4><<<grid, 256, 0, s>>>(a, wt);
-    else conv3_wino2_kernel<1, 8><<<grid, 256, 0, s>>>(a, wt);
+      if (ncg == 2 && npg == 2) conv3_wino2_kernel<2, 2, 4, true><<<grid, 512, 0, s>>>(a, wt);
+      else if (ncg == 2) conv3_wino2_kernel<2, 1, 4, true><<<grid, 256, 0, s>>>(a, wt);
+      else conv3_wino2_kernel<1, 2, 8, true><<<grid, 256, 0, s>>>(a, wt);
+    } else if (ncg == 2 && npg == 2) conv3_wino2_kernel<2, 2, 4><<<grid, 512, 0, s>>>(a, wt);
+    else if (ncg == 2) conv3_wino2_kernel<2, 1, 4><<<grid, 256, 0, s>>>(a, wt);
+    else conv3_wino2_kernel<1, 2, 8><<<grid, 256, 0, s>>>(a, wt);
     return true;
   }
   const int ncg = a.cout % 128 == 0 ? 4 : (a.cout % 64 == 0 ? 2 : 1), npg = 4 / ncg;
