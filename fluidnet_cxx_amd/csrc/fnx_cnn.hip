@@ -627,8 +627,10 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArg
   if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = 2; }
   const int niter = (dz_hi - dz_lo) * nchunk;
   if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, wbuf0); }
-  // (A prefetch distance of two stages -- three weight buffers, two register sets -- was tried and changes nothing: the
-  // workgroup-scope fence of every barrier waits for ALL outstanding LDS DMA, so the distance is one stage either way.)
+  // (A prefetch distance of two stages -- three weight buffers, two register sets -- was tried twice: with __syncthreads()
+  // it changes nothing, because the workgroup-scope fence of every barrier waits for ALL outstanding LDS DMA; with
+  // fence-free barriers (s_waitcnt lgkmcnt(0); s_barrier) and explicit vmcnt(K) waits it is correct and 4 % SLOWER,
+  // 947 vs 908 us for 64->128 at 1024^2: the transfers' latency is not what the stage waits for.)
   auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NLD; ++t)
