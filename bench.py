@@ -298,7 +298,8 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))   # fail, do not hang
     name = a.workload or "plume3d_slab_jacobi"
     out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev, a.schedule)
     if world == 1 and a.workload is None and not a.no_also:
