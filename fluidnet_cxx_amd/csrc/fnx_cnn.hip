@@ -806,7 +806,8 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
   constexpr int NTAP = KS * KW;                                       // k positions per plane (25, or 30 for PAIR)
   constexpr int NWI = (NTAP + TPI - 1) / TPI;                         // wave-instructions per stage
   __shared__ __attribute__((aligned(16))) float tile2[2][NEL];
-  __shared__ __attribute__((aligned(16))) float wbuf[2][NWI * 256];
+  __shared__ __attribute__((aligned(16))) float wbuf0[NWI * 256];       // (two separate arrays and out-of-range-zero buffer
+  __shared__ __attribute__((aligned(16))) float wbuf1[NWI * 256];       //  loads: see conv3_mfma_kernel)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg = lane & 15, kq = lane >> 4;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (4 * PR);
@@ -831,8 +832,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
   const float* xb = a.x + (size_t)b * a.cin * vol;
   // per-thread staging slots of the [CHS][ROWS][COLS] halo tile (offsets and predicates are stage-invariant: Cin is a
   // multiple of CHS, or smaller than CHS with a single chunk whose missing channels read as zero)
-  int goff[NLD];
-  unsigned valid = 0;
+  unsigned uoff[NLD];
 #pragma unroll
   for (int t = 0; t < NLD; ++t) {
     const int idx = threadIdx.x + 256 * t;
@@ -841,17 +841,17 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
     const int row = rem / COLS, col = rem - row * COLS;
     const int gx = x0 - PAD + col, gy = y0 - PAD + row;
     const bool ok = (idx < NEL) & (cc < a.cin) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    goff[t] = ok ? (int)((size_t)cc * vol + (size_t)gy * a.W + gx) : 0;
-    valid |= (unsigned)ok << t;
+    uoff[t] = ok ? (unsigned)(((size_t)cc * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
   }
+  const unsigned stage_bytes = (unsigned)((size_t)CHS * vol * 4 - 1) + 1u;
   float stage[NLD];
   auto prefetch = [&](int dz, int c0) {
     const int zz = IS3D ? z + dz - PAD : 0;
-    const float* src = xb + (size_t)c0 * vol + (size_t)zz * plane;
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
 #pragma unroll
-    for (int t = 0; t < NLD; ++t) stage[t] = src[goff[t]];
+    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
   };
-  auto stage_weights = [&](int dz, int c0, int buf) {
+  auto stage_weights = [&](int dz, int c0, float* wdst) {
 #pragma unroll
     for (int q = 0; q < (NWI + 3) / 4; ++q) {
       const int wi = wave + 4 * q;                        // wave-uniform
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
         if (tap > NTAP - 1) tap = NTAP - 1;               // the tail re-reads the last tap into slots nobody reads
         const float* src = a.w + ((size_t)(dz * NTAP + tap) * cin_pad + c0) * CO + (lane % LPT) * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(&wbuf[buf][wi * 256]), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
       }
     }
   };
@@ -868,18 +868,18 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
   int dz_lo = 0, dz_hi = IS3D ? KS : 1;
   if (IS3D) { dz_lo = PAD - z > 0 ? PAD - z : 0; dz_hi = a.D + PAD - z < KS ? a.D + PAD - z : KS; }
   const int niter = (dz_hi - dz_lo) * nchunk;
-  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, 0); }
-  for (int it = 0; it < niter; ++it) {
+  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, wbuf0); }
+  auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
     float* tile = tile2[it & 1];
 #pragma unroll
     for (int t = 0; t < NLD; ++t)
-      if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = ((valid >> t) & 1) ? stage[t] : 0.f;
+      if (threadIdx.x + 256 * t < NEL) tile[threadIdx.x + 256 * t] = stage[t];
     __syncthreads();                                     // tile stores + the stage's weight DMA visible to all
     if (it + 1 < niter) {
       prefetch(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CHS);
-      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CHS, (it + 1) & 1);
+      stage_weights(dz_lo + (it + 1) / nchunk, ((it + 1) % nchunk) * CHS, wnext);
     }
-    const float* wl = &wbuf[it & 1][kq * CO + seg];
+    const float* wl = &wcur[kq * CO + seg];
     const float* tl = &tile[kq * ROWS * COLS + (wave * PR) * COLS + XSTEP * seg];
     // (an explicit operand pipeline as in conv3_mfma_kernel measured slower here: 2.27 -> 2.74 ms at 128^3)
 #pragma unroll
@@ -905,6 +905,10 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
         }
       }
     }
+  };
+  for (int it = 0; it < niter; it += 2) {
+    stage_body(it, wbuf0, wbuf1);
+    if (it + 1 < niter) stage_body(it + 1, wbuf1, wbuf0);
   }
 #pragma unroll
   for (int pr = 0; pr < PR; ++pr) {
