@@ -366,14 +366,20 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   return FNX_OK;
 }
 
-int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
-                    int nsweeps, int k_begin, int k_end, void* ws, size_t ws_bytes, int reuse_mask, void* stream) {
+int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
+                     int nsweeps, int k_begin, int k_end, int k_begin2, void* ws, size_t ws_bytes, int reuse_mask,
+                     void* stream) {
   if (int rc = check_grid(g)) return rc;
   if (!flags || !div || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
   if (!g->is3D) return fail(FNX_EINVAL, "jacobi_pass: 3D only (2D uses fnx_jacobi_sweeps)");
   const bool from_zero = p_in == nullptr;                 // the first pass of a solve: p = 0 everywhere, nothing to read
   if (nsweeps != 1 && nsweeps != 2) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1 or 2");
   if (k_begin < 0 || k_end > g->D || (k_end != 0 && k_end <= k_begin)) return fail(FNX_EINVAL, "jacobi_pass: bad plane range");
+  if (k_begin2 >= 0) {
+    const int n = k_end - k_begin;
+    if (k_end == 0 || k_begin2 + n > g->D || (k_begin2 < k_end && k_begin < k_begin2 + n))
+      return fail(FNX_EINVAL, "jacobi_pass: bad or overlapping second plane range");
+  }
   hipStream_t s = (hipStream_t)stream;
   const GridDims d = dims(g);
   Carver c(ws, ws_bytes);
@@ -382,10 +388,18 @@ int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, cons
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_pass: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero);
-  else fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin, k_end);
+  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
+  else {
+    fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin, k_end);
+    if (k_begin2 >= 0) fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin2, k_begin2 + (k_end - k_begin));
+  }
   HIP_OK(hipGetLastError());
   return FNX_OK;
+}
+
+int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
+                    int nsweeps, int k_begin, int k_end, void* ws, size_t ws_bytes, int reuse_mask, void* stream) {
+  return fnx_jacobi_pass2(g, flags, div, p_in, p_out, nsweeps, k_begin, k_end, -1, ws, ws_bytes, reuse_mask, stream);
 }
 
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream) {

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
                                                                       const float* __restrict__ p_in,
                                                                       float* __restrict__ p_out,
                                                                       float* __restrict__ sumsq, int nxt, int nyt,
-                                                                      int zchunk, int kb, int ke) {
+                                                                      int zchunk, int kb, int ke, int kb2) {
   constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
   const int lane = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -448,8 +448,14 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int ntiles = nxt * nyt * g.B;
   int L0, L1;
+  int kbase = kb;                                        // kb2 >= 0: a second plane range [kb2, kb2 + np) in the same launch
   if (!SPLIT) {
-    const int zc = gid / ntiles, tl = gid - zc * ntiles;
+    int zc = gid / ntiles;
+    const int tl = gid - zc * ntiles;
+    if (kb2 >= 0) {                                      // chunks [0, nzc1) belong to the first range, [nzc1, 2 nzc1) to the second
+      const int nzc1 = (np + zchunk - 1) / zchunk;
+      if (zc >= nzc1) { zc -= nzc1; kbase = kb2; }
+    }
     L0 = tl * np + zc * zchunk;
     L1 = min(L0 + zchunk, (tl + 1) * np);
     if (zc * zchunk >= np) L1 = L0;                      // padding block
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   const int by = l1 % nyt, b = l1 / nyt;
   const int x = bx * 60 - 2 + lane;
   const int j0 = (by * Z2NW + w) * Z2R;
-  const int k_lo = kb + pk, k_hi = k_lo + seg;           // output planes [k_lo, k_hi) of this segment
+  const int k_lo = kbase + pk, k_hi = k_lo + seg;           // output planes [k_lo, k_hi) of this segment
   const bool xin = (x >= 0) & (x < g.W);
   const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
   const size_t base = (size_t)b * g.DHW;
@@ -758,8 +764,8 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 
 // two sweeps in one pass: p_in = p^n, p_out = p^{n+2}; sumsq receives ||p^{n+2} - p^{n+1}||^2
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero) {
-  if (ke <= kb) { kb = 0; ke = g.D; }
+                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero, int kb2) {
+  if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
   static const int slots = [] {                          // resident waves: Z2WPS per SIMD (<= 128 VGPRs each)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -777,15 +783,21 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   if (zchunk < 0) {
     // as many equal plane chunks per tile as fit one resident set
     int nzc = slots / ntiles;
+    if (kb2 >= 0) nzc /= 2;                              // two plane ranges share the resident set
     if (nzc < 1) nzc = 1;
     zchunk = (np + nzc - 1) / nzc;
     if (zchunk < zmin) zchunk = zmin;
     if (ntiles > slots) zchunk = 0;                      // more tiles than slots: even split of the (tile, plane) space
     if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
   }
+  if (kb2 >= 0 && (zchunk <= 0 || 2 * ntiles > slots)) {   // no room for both ranges at once: one after the other
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb, ke, from_zero, -1);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb2, kb2 + np, from_zero, -1);
+    return;
+  }
   long long G;
   if (zchunk > 0) {
-    G = (long long)ntiles * ((np + zchunk - 1) / zchunk);
+    G = (long long)ntiles * ((np + zchunk - 1) / zchunk) * (kb2 >= 0 ? 2 : 1);
     G = ((G + 7) / 8) * 8;
   } else {
     G = (long long)ntiles * np / 8;
@@ -794,7 +806,7 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
-#define J3D(R, Z, S) jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke)
+#define J3D(R, Z, S) jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2)
 #define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \
                        else { if (sumsq) J3D(true, false, S); else J3D(false, false, S); } } while (0)
   if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true);

@@ -67,7 +67,7 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                      bool from_zero, float* sumsq, hipStream_t s, int kb = 0, int ke = 0);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false);
+                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1);
 void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
 void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s);
 

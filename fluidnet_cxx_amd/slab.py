@@ -145,13 +145,16 @@ class NativeOps:
         self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid)
         self._mask_valid = True      # same flags for the rest of this step (begin_step resets)
 
-    def jacobi_pass(self, flags, div, p_in, p_out, n, k_begin, k_end):
+    two_ranges = True            # jacobi_pass takes a second plane range of the same length (one launch for both faces)
+
+    def jacobi_pass(self, flags, div, p_in, p_out, n, k_begin, k_end, k_begin2=-1):
         key = (tuple(flags.shape), flags.device)
         if self._ws is None or self._ws_key != key:
             B, _, D, H, W = flags.shape
             self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
             self._ws_key, self._mask_valid = key, False
-        self.ext.jacobi_pass_(flags, div, p_in, p_out, int(n), int(k_begin), int(k_end), self._ws, self._mask_valid)
+        self.ext.jacobi_pass_(flags, div, p_in, p_out, int(n), int(k_begin), int(k_end), self._ws, self._mask_valid,
+                              int(k_begin2))
         self._mask_valid = True
 
     def post_projection(self, st):
@@ -296,10 +299,13 @@ class SlabSimulator:
             for pi, n in enumerate(passes):
                 done += n
                 pin = None if (zero_in and pi == 0) else src
-                if has_lo:
-                    ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done)
-                if has_hi:
-                    ops.jacobi_pass(flags, div, pin, dst, n, top - 2 * w + done, top + w - done)
+                if has_lo and has_hi and getattr(ops, "two_ranges", False):       # both faces in one launch
+                    ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done, top - 2 * w + done)
+                else:
+                    if has_lo:
+                        ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done)
+                    if has_hi:
+                        ops.jacobi_pass(flags, div, pin, dst, n, top - 2 * w + done, top + w - done)
                 src, dst = dst, src
             fin = src
             yield "start", [fin], w

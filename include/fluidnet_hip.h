@@ -117,6 +117,11 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
  * fnx_jacobi_sweeps_ex (holds the neighbour mask). */
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                     int nsweeps, int k_begin, int k_end, void* ws, size_t ws_bytes, int reuse_mask, void* stream);
+/* The same for TWO disjoint plane ranges of equal length in one launch: [k_begin, k_end) and [k_begin2, k_begin2 +
+ * k_end - k_begin) (k_begin2 < 0: one range).  The slab driver's edge parts at the lower and the upper internal face. */
+int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
+                     int nsweeps, int k_begin, int k_end, int k_begin2, void* ws, size_t ws_bytes, int reuse_mask,
+                     void* stream);
 
 /* velocityUpdate (in place on U), lib/fluid/velocity_update.py:6-162 */
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream);

@@ -216,6 +216,28 @@ def test_generators_bitexact(fl, dev, golden):
     assert_close(N(bd["density"]), z["rt_density"], 1e-6, "Rayleigh-Taylor density")
 
 
+def test_jacobi_pass_two_ranges(dev, ext):
+    """fnx_jacobi_pass2: two disjoint plane ranges in one launch == the two single-range calls, bit for bit (1 and 2 sweeps,
+    from p and from zero)."""
+    B, D, H, W = 1, 40, 70, 130
+    rng = np.random.default_rng(4)
+    flags = T(make_flags(B, D, H, W, boxes=True), dev)
+    div = T(rng.standard_normal((B, 1, D, H, W)).astype(np.float32), dev)
+    p = T(rng.standard_normal((B, 1, D, H, W)).astype(np.float32), dev)
+    ws = torch.empty(ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=dev)
+    first = True
+    for n in (2, 1):
+        for pin in (p, None):
+            for (a, b, a2) in ((3, 17, 20), (2, 8, 30), (0, 5, 35)):
+                one = torch.full_like(p, 7.0); two = torch.full_like(p, 7.0)
+                ext.jacobi_pass_(flags, div, pin, one, n, a, b, ws, not first, a2); first = False
+                ext.jacobi_pass_(flags, div, pin, two, n, a, b, ws, True)
+                ext.jacobi_pass_(flags, div, pin, two, n, a2, a2 + b - a, ws, True)
+                assert torch.equal(one, two), (n, pin is None, a, b, a2)
+    with pytest.raises(RuntimeError, match="overlapping"):
+        ext.jacobi_pass_(flags, div, p, torch.empty_like(p), 2, 3, 17, ws, True, 10)
+
+
 # ---- CNN --------------------------------------------------------------------------------------------
 def test_cnn_vs_reference_golden(dev, golden):
     """MultiScaleNet / FluidNet.forward vs torch-2.10-CPU golden vectors: |d| <= 2e-5 * max(1,|ref|max)
