@@ -216,10 +216,12 @@ def test_generators_bitexact(fl, dev, golden):
     assert_close(N(bd["density"]), z["rt_density"], 1e-6, "Rayleigh-Taylor density")
 
 
-def test_jacobi_pass_two_ranges(dev, ext):
+@pytest.mark.parametrize("shape", [(1, 40, 70, 130), (1, 40, 1040, 1030)])
+def test_jacobi_pass_two_ranges(dev, ext, shape):
     """fnx_jacobi_pass2: two disjoint plane ranges in one launch == the two single-range calls, bit for bit (1 and 2 sweeps,
-    from p and from zero)."""
-    B, D, H, W = 1, 40, 70, 130
+    from p and from zero; the second shape has more tiles than resident waves: the launcher then runs the ranges one
+    after the other)."""
+    B, D, H, W = shape
     rng = np.random.default_rng(4)
     flags = T(make_flags(B, D, H, W, boxes=True), dev)
     div = T(rng.standard_normal((B, 1, D, H, W)).astype(np.float32), dev)
