@@ -199,7 +199,8 @@ def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule):
         simulate(CFG, bd, None, "jacobi")
     ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
     layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
-    sims = [SlabSimulator(l, CFG, sweeps_per_exchange=w, schedule=schedule) for l in layouts]
+    # (static_flags: the solver's neighbour mask of step 1 is reused in step 2, as bench.py runs it)
+    sims = [SlabSimulator(l, CFG, sweeps_per_exchange=w, schedule=schedule, static_flags=(w == 6)) for l in layouts]
     states = [local_state(gs, l, dev) for l in layouts]
     for n in range(2):
         lockstep_step(sims, states, defer=(n == 1))          # both orders an asynchronous transfer can take
