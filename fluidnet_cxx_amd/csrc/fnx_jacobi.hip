@@ -707,12 +707,14 @@ void launch_reg(const GridDims& g, const float* flags, const float* div, const f
   static const int forced = env_int("FNX_JACOBI_OY", 0);
   int oy = forced;
   if (!oy) {
-    // measured on MI355X (tools/ubench/jacobi_bench.cpp): <= 2 Mcells: 8-row tiles; up to 8 Mcells: 16; else 32
+    // measured on MI355X (tools/ubench/jacobi_bench.cpp, tools/jacobi2d_small_probe.py): <= 160 Kcells: 4-row tiles
+    // (28 sweeps at 128^2: 46 -> 39 us, at 384^2: 50 -> 48 us, at 512^2: 55 -> 63 us); <= 2 Mcells: 8; <= 8 Mcells: 16; else 32
     const long cells = (long)g.W * g.H * g.B;
-    oy = cells <= (2l << 20) ? 8 : (cells <= (8l << 20) ? 16 : 32);
+    oy = cells <= (160l << 10) ? 4 : (cells <= (2l << 20) ? 8 : (cells <= (8l << 20) ? 16 : 32));
   }
   if (oy == 32) launch_reg_oy<K, 32>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
   else if (oy == 16) launch_reg_oy<K, 16>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
+  else if (oy == 4) launch_reg_oy<K, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
   else launch_reg_oy<K, 8>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
 }
 
