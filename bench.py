@@ -232,10 +232,12 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
     torch.cuda.synchronize()
     times = {k: ext.profile_read(v) for k, v in PROF.items()}
     ext.profile_enable(False)
-    traffic = None
+    traffic = None           # HBM bytes per launch of the roofline kernel (PMC FETCH_SIZE/WRITE_SIZE passes, profiles/)
+    traffic_detail = None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(name)
+        traffic_detail = json.load(open(tfile)).get(name)
+        traffic = traffic_detail.get("bytes_per_launch") if traffic_detail else None
     if w["method"] == "convnet":
         tms, nl = times["conv_mfma"]
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
@@ -246,6 +248,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
                  "the MFMA peak")
         roof = dict(bound="mfma", kernel=kname, achieved=ach,
                     peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=traffic,
+                    traffic_detail=traffic_detail,
                     launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
                     algorithmic=f"{mfma_flops_per_cell(is3d):.0f} direct-convolution FLOP/cell in the MFMA conv launches x {cells} cells per step")
     else:
@@ -255,7 +258,8 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         kname = ("jacobi3d_march2_kernel (z-marching, 2 sweeps per pass)" if is3d
                  else "jacobi2d_reg_kernel (register/DPP temporal blocking)")
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=traffic, launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
+                    traffic=traffic, traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
+                    avg_launch_ms=tms / max(nl, 1),
                     algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} owned cells per step")
     if w["method"] == "jacobi":
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
