@@ -8,7 +8,9 @@ batch_dict, same mconf keys).  Two execution modes:
               parity tests use to compare stage by stage).
 `workspace` (a uint8 tensor of ext.step_workspace_bytes) avoids a per-step allocation; with it, `static_flags=True`
 promises that batch_dict['flags'] has not changed since the previous call on that workspace (3D Jacobi then reuses
-its obstacle mask).
+its obstacle mask).  `static_flags` may also be the C ABI's bit set (FnxStepParams.static_flags): 1 = flags unchanged,
+2 = the four BC arrays unchanged (the BC stages then go by a 1-byte class map kept in the workspace), 4 = that map was
+already built by an earlier call with bit 2 -- e.g. 0 for the first step, 3 for the second, 7 from the third on.
 """
 import torch
 
@@ -49,7 +51,7 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
                            float(maccormackStrength), bool(sampleOutsideFluid), float(buoyancyScale), gvec,
                            float(mconf.get("operatingDensity", 0.0)), float(mconf.get("pTol", 0.0)),
                            int(mconf.get("jacobiIter", 1)), sim_method,
-                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, bool(static_flags))
+                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, int(static_flags))
         if not has_density:
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return

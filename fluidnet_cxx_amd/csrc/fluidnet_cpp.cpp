@@ -292,7 +292,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
                     double maccormack_strength, bool sample_outside_fluid, double buoyancy_scale,
                     std::vector<double> gravity_vec, double operating_density, double p_tol, int jacobi_iter,
                     const std::string method, double normalize_threshold, c10::optional<Tensor> workspace,
-                    bool static_flags) {
+                    int static_flags) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
@@ -322,7 +322,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   if (given) ws = *workspace;
   else ws = at::empty({(int64_t)bytes}, flags.options().dtype(at::kByte));
   // the mask lives in the workspace: only a caller-owned workspace carries it from one step to the next
-  prm.static_flags = (static_flags && given) ? 1 : 0;
+  prm.static_flags = given ? static_flags : 0;      // (promises about the previous step need a caller-owned workspace)
   check_status(fnx_simulate_step(&g, &prm, &st, ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), cur_stream(U)));
 }
 
@@ -372,7 +372,35 @@ static FnxState make_state(const FnxGrid& g, Tensor& p, Tensor& U, Tensor& flags
   st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
   st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
   st.net = nullptr;
+  st.bc_class = nullptr;
   return st;
+}
+
+static const unsigned char* bc_class_ptr(c10::optional<Tensor>& t, const Tensor& flags) {
+  if (!t.has_value() || !t->defined()) return nullptr;
+  TORCH_CHECK(t->scalar_type() == at::kByte && t->is_contiguous() && t->numel() == flags.numel() && t->device() == flags.device(),
+              "bc_class: expected the uint8 tensor bc_classify returned for this grid");
+  return t->data_ptr<unsigned char>();
+}
+
+// class map of the (static) BC arrays for pre_projection_ / post_projection_ (FnxState.bc_class)
+Tensor bc_classify(Tensor flags, bool is3D, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
+                   c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask) {
+  FnxGrid g = grid_of(flags, is3D);
+  Tensor dummy;
+  c10::optional<Tensor> none;
+  FnxState st{};
+  auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> const float* {
+    if (!t.has_value() || !t->defined()) return nullptr;
+    if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
+    return t->data_ptr<float>();
+  };
+  st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
+  st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor cls = at::empty(flags.sizes(), flags.options().dtype(at::kByte));
+  check_status(fnx_bc_classify(&g, &st, cls.data_ptr<unsigned char>(), cur_stream(flags)));
+  return cls;
 }
 
 // simulate.py:96-133 (+ divergence): U_adv/rho_adv -> U, density (written), returns div
@@ -380,7 +408,7 @@ Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Te
                        c10::optional<Tensor> density, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
                        c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask, double dt,
                        double buoyancy_scale, std::vector<double> gravity_vec, double operating_density,
-                       bool jacobi_method) {
+                       bool jacobi_method, c10::optional<Tensor> bc_class) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
   check_vel(U, g, "U"); check_vel(U_adv, g, "U_adv"); check_scalar(p, g, "p");
@@ -391,6 +419,7 @@ Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Te
   FnxState st = make_state(g, p, U, flags, density, UBC, UBCInvMask, densityBC, densityBCInvMask);
   const float* ra = nullptr;
   if (rho_adv.has_value() && rho_adv->defined()) { check_scalar(*rho_adv, g, "rho_adv"); ra = rho_adv->data_ptr<float>(); }
+  st.bc_class = bc_class_ptr(bc_class, flags);
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor div = at::empty_like(flags);
   check_status(fnx_pre_projection(&g, &prm, &st, U_adv.data_ptr<float>(), ra, div.data_ptr<float>(), cur_stream(U)));
@@ -399,11 +428,12 @@ Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Te
 
 void post_projection_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> density, c10::optional<Tensor> UBC,
                       c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> densityBC,
-                      c10::optional<Tensor> densityBCInvMask) {
+                      c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> bc_class) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
   FnxState st = make_state(g, p, U, flags, density, UBC, UBCInvMask, densityBC, densityBCInvMask);
+  st.bc_class = bc_class_ptr(bc_class, flags);
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_post_projection(&g, &st, cur_stream(U)));
 }
@@ -444,15 +474,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("net"), py::arg("dt"),
         py::arg("maccormack_strength"), py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"),
         py::arg("operating_density"), py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("method"),
-        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = false);
+        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0);
   m.def("step_workspace_bytes", &step_workspace_bytes);
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
         py::arg("workspace") = py::none(), py::arg("reuse_mask") = false);
   m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
   m.def("jacobi_pass_", &jacobi_pass_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("nsweeps"),
         py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1);
-  m.def("pre_projection_", &pre_projection_);
-  m.def("post_projection_", &post_projection_);
+  m.def("pre_projection_", &pre_projection_, py::arg("U_adv"), py::arg("rho_adv"), py::arg("p"), py::arg("U"), py::arg("flags"),
+        py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"),
+        py::arg("dt"), py::arg("buoyancy_scale"), py::arg("gravity_vec"), py::arg("operating_density"),
+        py::arg("jacobi_method"), py::arg("bc_class") = py::none());
+  m.def("post_projection_", &post_projection_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),
+        py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("bc_class") = py::none());
+  m.def("bc_classify", &bc_classify, "uint8 class map of static BC arrays (FnxState.bc_class)");
   m.def("set_ref_quirks", [](bool on) { g_ref_quirks = on; }, "3D only: reproduce the reference's 3D defects bit-for-bit");
   m.def("get_ref_quirks", []() { return g_ref_quirks; });
   m.def("set_slab", [](int z_offset, int D_global) { g_z_offset = z_offset; g_D_global = D_global; },

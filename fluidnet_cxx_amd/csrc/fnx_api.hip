@@ -77,7 +77,8 @@ size_t ws_step(const FnxGrid* g) {
   size_t tail = adv > solve ? adv : solve;
   if (cnn > tail) tail = cnn;
   return al(ncell(g) * 4) /*rho2*/ + al(ncell(g) * 4 * nc) /*U2*/ + al(ncell(g) * 4) /*div*/ +
-         (g->is3D ? al(ncell(g)) : 0) /*Jacobi obstacle mask, kept between steps*/ + tail;
+         (g->is3D ? al(ncell(g)) : 0) /*Jacobi obstacle mask, kept between steps*/ +
+         al(ncell(g)) /*BC class map, kept between steps*/ + tail;
 }
 
 }  // namespace
@@ -514,7 +515,7 @@ int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxStat
   fnx::launch_pre_projection(ds, g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                              rbc ? st->densityBCInvMask : nullptr, st->U, st->density, (split && div) ? nullptr : div, buoy, sx, sy, sz,
-                             prm->operating_density, prm->method == 0, (hipStream_t)stream);
+                             prm->operating_density, prm->method == 0, (hipStream_t)stream, st->bc_class);
   if (split && div) fnx::launch_divergence(dims(g), g->is3D, st->U, st->flags, div, (hipStream_t)stream);
   HIP_OK(hipGetLastError());
   return FNX_OK;
@@ -527,7 +528,17 @@ int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream) {
   fnx::ProfScope ps(FNX_PROF_STAGE, (hipStream_t)stream);
   fnx::launch_post_projection(dims(g), g->is3D, st->p, st->U, st->density, st->flags, ubc ? st->UBC : nullptr,
                               ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
-                              rbc ? st->densityBCInvMask : nullptr, (hipStream_t)stream);
+                              rbc ? st->densityBCInvMask : nullptr, (hipStream_t)stream, st->bc_class);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_bc_classify(const FnxGrid* g, const FnxState* st, unsigned char* bc_class, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!st || !bc_class) return fail(FNX_EINVAL, "bc_classify: NULL argument");
+  const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  fnx::launch_bc_classify(dims(g), g->is3D, ubc ? st->UBC : nullptr, ubc ? st->UBCInvMask : nullptr,
+                          rbc ? st->densityBC : nullptr, rbc ? st->densityBCInvMask : nullptr, bc_class, (hipStream_t)stream);
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }
@@ -545,6 +556,7 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   float* U2 = (float*)c.take(n * 4 * nc);
   float* div = (float*)c.take(n * 4);
   unsigned char* kept_mask = g->is3D ? (unsigned char*)c.take(n) : nullptr;
+  unsigned char* kept_cls = (unsigned char*)c.take(n);
   void* tail = c.take(0);
   const size_t tail_bytes = ws_bytes > c.off ? ws_bytes - c.off : 0;
   if (!c.ok() || ws_bytes < ws_step(g)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small (%zu < %zu)", ws_bytes, ws_step(g));
@@ -563,13 +575,21 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
     if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
                                 prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   }
+  // static BC arrays (static_flags bit 1): the BC stages go by the class map kept in the workspace (built once, bit 2)
+  FnxState stc = *st;
+  stc.bc_class = nullptr;
+  if ((prm->static_flags & 2) && (st->UBC || st->densityBC)) {
+    if (!(prm->static_flags & 4)) { if (int rc = fnx_bc_classify(g, st, kept_cls, stream)) return rc; }
+    stc.bc_class = kept_cls;
+  }
+  st = &stc;
   // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, wall BCs, BCs, -div
   if (int rc = fnx_pre_projection(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream)) return rc;
   const GridDims d = dims(g);
   float* rho = has_rho ? st->density : nullptr;
   if (prm->method == 0) {
     // simulate.py:144-168
-    if (int rc = jacobi_solve(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, kept_mask, prm->static_flags != 0, stream)) return rc;
+    if (int rc = jacobi_solve(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, kept_mask, (prm->static_flags & 1) != 0, stream)) return rc;
     return fnx_post_projection(g, st, stream);
   } else {
     // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),

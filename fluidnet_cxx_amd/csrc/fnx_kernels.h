@@ -50,10 +50,13 @@ void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hi
 void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const float* U_adv, const float* rho_adv,
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
-                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s);
+                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s,
+                           const unsigned char* cls = nullptr);
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
                             const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
-                            hipStream_t s);
+                            hipStream_t s, const unsigned char* cls = nullptr);
+void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const float* UBCInvMask, const float* rhoBC,
+                        const float* rhoBCInvMask, unsigned char* cls, hipStream_t s);
 
 // Jacobi (fnx_jacobi.hip)
 // `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is

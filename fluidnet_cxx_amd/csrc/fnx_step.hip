@@ -20,6 +20,7 @@ struct StepPtrs {
   const float* UBC; const float* UBCInvMask;         // may be null
   const float* rhoBC; const float* rhoBCInvMask;     // may be null
   float* U; float* rho; float* div;
+  const unsigned char* cls;                          // optional BC class map (bit 0: velocity BCs are x*1+0, bit 1: density)
 };
 
 // velocity component `a` of cell (k,j,i) after setConstVals, addBuoyancy, setWallBcs, setConstVals
@@ -32,7 +33,10 @@ __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, 
   const bool ubc = P.UBC != nullptr;
   float u = P.U_adv[ou];
   float m = 1.f, c = 0.f;
-  if (ubc) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; const float t = u * m; u = t + c; }        // simulate.py:96
+  if (ubc) {                                                                                  // simulate.py:96
+    if (!(P.cls && (P.cls[os] & 1))) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; }                // (identity cells: no loads)
+    const float t = u * m; u = t + c;
+  }
   const float fc = P.flags[os];
   const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
   const int idx = a == 0 ? i : (a == 1 ? j : k);          // local index: guards the read
@@ -41,8 +45,11 @@ __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, 
     const bool rbc = P.rhoBC != nullptr;
     float r0 = P.rho_adv[os], r1 = P.rho_adv[os - off];
     if (rbc) {
-      float t = r0 * P.rhoBCInvMask[os]; r0 = t + P.rhoBC[os];
-      t = r1 * P.rhoBCInvMask[os - off]; r1 = t + P.rhoBC[os - off];
+      float m0 = 1.f, c0 = 0.f, m1 = 1.f, c1 = 0.f;
+      if (!(P.cls && (P.cls[os] & 2))) { m0 = P.rhoBCInvMask[os]; c0 = P.rhoBC[os]; }
+      if (!(P.cls && (P.cls[os - off] & 2))) { m1 = P.rhoBCInvMask[os - off]; c1 = P.rhoBC[os - off]; }
+      float t = r0 * m0; r0 = t + c0;
+      t = r1 * m1; r1 = t + c1;
     }
     if (a == 2 && QUIRKS) u = u + s_a * (0.5f * (r0 + (k + g.zoff <= 1 ? 0.f : r1)));
     else u = u + s_a * ((0.5f * (r0 + r1)) - rho_star);
@@ -75,7 +82,8 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
   if (P.rho_adv) {
     float r = P.rho_adv[os];
     if (P.rhoBC) {
-      const float m = P.rhoBCInvMask[os], c = P.rhoBC[os];
+      float m = 1.f, c = 0.f;
+      if (!(P.cls && (P.cls[os] & 2))) { m = P.rhoBCInvMask[os]; c = P.rhoBC[os]; }
       float t = r * m; r = t + c;       // simulate.py:96
       t = r * m; r = t + c;             // simulate.py:133
     }
@@ -111,7 +119,8 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
                                                                  const float* __restrict__ UBC,
                                                                  const float* __restrict__ UBCInvMask,
                                                                  const float* __restrict__ rhoBC,
-                                                                 const float* __restrict__ rhoBCInvMask) {
+                                                                 const float* __restrict__ rhoBCInvMask,
+                                                                 const unsigned char* __restrict__ cls) {
   const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
   const int b = IS3D ? bk / g.KN : bk, k = IS3D ? g.K0 + (bk - b * g.KN) : 0;
@@ -119,6 +128,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
   constexpr int NC = IS3D ? 3 : 2;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
   const float fc = flags[os], P = p[os];
+  const unsigned cl = cls ? cls[os] : 0u;
   const bool border = is_border<IS3D>(g, i, j, k);
 #pragma unroll
   for (int a = 0; a < NC; ++a) {
@@ -144,10 +154,40 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
         if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
       }
     }
-    if (UBC) { const float t = u * UBCInvMask[ou]; u = t + UBC[ou]; }
+    if (UBC) {
+      float m = 1.f, c = 0.f;
+      if (!(cl & 1)) { m = UBCInvMask[ou]; c = UBC[ou]; }
+      const float t = u * m; u = t + c;
+    }
     U[ou] = u;
   }
-  if (rho && rhoBC) { const float t = rho[os] * rhoBCInvMask[os]; rho[os] = t + rhoBC[os]; }
+  if (rho && rhoBC) {
+    float m = 1.f, c = 0.f;
+    if (!(cl & 2)) { m = rhoBCInvMask[os]; c = rhoBC[os]; }
+    const float t = rho[os] * m; rho[os] = t + c;
+  }
+}
+
+// bit 0: every velocity component has mask == 1 and bc == +0 (x*1 + 0 is then what setConstVals computes); bit 1: density
+__global__ __launch_bounds__(256) void bc_classify_kernel(size_t n, size_t dhw, int nc, const float* __restrict__ UBC,
+                                                          const float* __restrict__ UBCInvMask,
+                                                          const float* __restrict__ rhoBC,
+                                                          const float* __restrict__ rhoBCInvMask,
+                                                          unsigned char* __restrict__ cls) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const size_t b = q / dhw, o = q - b * dhw;
+    unsigned c = 0;
+    if (UBC && UBCInvMask) {
+      bool id = true;
+      for (int a = 0; a < nc; ++a) {
+        const size_t ou = (b * nc + a) * dhw + o;
+        id = id & (UBCInvMask[ou] == 1.f) & (__float_as_uint(UBC[ou]) == 0u);
+      }
+      c |= id ? 1u : 0u;
+    }
+    if (rhoBC && rhoBCInvMask) c |= ((rhoBCInvMask[q] == 1.f) & (__float_as_uint(rhoBC[q]) == 0u)) ? 2u : 0u;
+    cls[q] = (unsigned char)c;
+  }
 }
 
 inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
@@ -159,8 +199,8 @@ namespace fnx {
 void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const float* U_adv, const float* rho_adv,
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
-                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s) {
-  StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div};
+                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s, const unsigned char* cls) {
+  StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div, cls};
   const dim3 grid = cell_grid(g), block(BX, BY);
 #define PRE(A, Q, WL) pre_projection_kernel<A, Q, WL><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star)
   if (is3d) {
@@ -174,10 +214,18 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
 
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
                             const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
-                            hipStream_t s) {
+                            hipStream_t s, const unsigned char* cls) {
   const dim3 grid = cell_grid(g), block(BX, BY);
-  if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask);
-  else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask);
+  if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
+  else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
+}
+
+void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const float* UBCInvMask, const float* rhoBC,
+                        const float* rhoBCInvMask, unsigned char* cls, hipStream_t s) {
+  const size_t n = (size_t)g.B * g.DHW;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  bc_classify_kernel<<<(unsigned)blocks, 256, 0, s>>>(n, (size_t)g.DHW, is3d ? 3 : 2, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
 }
 
 }  // namespace fnx

@@ -107,9 +107,12 @@ class NativeOps:
         self._ws = None          # persistent Jacobi workspace: holds the 3D neighbour mask between sweep blocks
         self._ws_key = None
         self._mask_valid = False
+        self.static_bcs = False  # set by the driver from the second step on when the caller promises static flags / BCs
+        self._cls = None         # class map of the BC arrays (FnxState.bc_class), built once under that promise
 
     def begin_step(self):
         self._mask_valid = False
+        self._cls = None         # (new flags / BC arrays: the class map of the BC stages goes too)
 
     def set_slab(self, z_offset, D_global):
         self.ext.set_slab(int(z_offset), int(D_global))
@@ -128,13 +131,21 @@ class NativeOps:
         r, u = self.ext.advect_step(dt, rho, U, flags, bool(sample_outside), strength, out_rho, out_U)
         return r, u
 
+    def _bc_class(self, st):
+        if not self.static_bcs or (st.get("UBC") is None and st.get("densityBC") is None):
+            return None
+        if self._cls is None:
+            self._cls = self.ext.bc_classify(st["flags"], True, st.get("UBC"), st.get("UBCInvMask"), st.get("densityBC"),
+                                             st.get("densityBCInvMask"))
+        return self._cls
+
     def pre_projection(self, U_adv, rho_adv, st, cfg):
         gv = cfg["gravityVec"]
         return self.ext.pre_projection_(U_adv, rho_adv, st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"),
                                         st.get("UBCInvMask"), st.get("densityBC"), st.get("densityBCInvMask"),
                                         float(cfg["dt"]), float(cfg["buoyancyScale"]),
                                         [float(gv["x"]), float(gv["y"]), float(gv["z"])],
-                                        float(cfg.get("operatingDensity", 0.0)), True)
+                                        float(cfg.get("operatingDensity", 0.0)), True, self._bc_class(st))
 
     def jacobi_sweeps(self, flags, div, p, n):
         key = (tuple(flags.shape), flags.device)
@@ -159,7 +170,7 @@ class NativeOps:
 
     def post_projection(self, st):
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
-                                  st.get("densityBC"), st.get("densityBCInvMask"))
+                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st))
 
 
 class SlabSimulator:
@@ -169,7 +180,7 @@ class SlabSimulator:
                  static_flags=False):
         assert schedule in ("last_pass", "edge_first")
         self.schedule = schedule
-        self.static_flags = static_flags     # the caller promises that flags do not change between steps
+        self.static_flags = static_flags     # the caller promises that flags and BC arrays do not change between steps
         self._steps = 0
         self.l = layout
         self.cfg = mconf
@@ -199,7 +210,9 @@ class SlabSimulator:
         dt = float(cfg["dt"])
         w = self.w
         if hasattr(ops, "begin_step") and not (self.static_flags and self._steps > 0):
-            ops.begin_step()                 # (forget the solver's neighbour mask)
+            ops.begin_step()                 # (forget the solver's neighbour mask and the BC class map)
+        if hasattr(ops, "static_bcs"):
+            ops.static_bcs = bool(self.static_flags and self._steps > 0)
         self._steps += 1
         # advection reaches <= 2 planes beyond its inputs at CFL <= 1 and the BC/buoyancy/divergence stage one more:
         # 4 fresh ghost planes of U and density are enough (the arrays keep `halo` planes for the pressure solve)

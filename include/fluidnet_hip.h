@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 3
+#define FNX_ABI_VERSION 4
 
 enum {
   FNX_OK = 0,
@@ -171,9 +171,12 @@ typedef struct FnxStepParams {
   int   jacobi_iter;          /* mconf['jacobiIter'] */
   int   method;               /* 0 = 'jacobi', 1 = 'convnet' */
   float normalize_threshold;  /* mconf['normalizeInputThreshold'] (convnet) */
-  int   static_flags;         /* != 0: `flags` is unchanged since the previous fnx_simulate_step on this workspace,
-                                 so the 3D Jacobi solver reuses the obstacle mask it left there (no reference key;
-                                 every reference simulation keeps its flags fixed) */
+  int   static_flags;         /* promises about the previous fnx_simulate_step on this workspace (no reference key; every
+                                 reference simulation keeps its flags and BC arrays fixed):
+                                 bit 0: `flags` is unchanged -> the 3D Jacobi solver reuses the obstacle mask it left there;
+                                 bit 1: UBC / UBCInvMask / densityBC / densityBCInvMask are unchanged -> the BC stages use a
+                                        1-byte-per-cell class map kept in the workspace (see FnxState.bc_class);
+                                 bit 2: that class map was already built by an earlier call with bit 1 set */
 } FnxStepParams;
 
 typedef struct FnxState {
@@ -184,7 +187,14 @@ typedef struct FnxState {
   const float* UBC; const float* UBCInvMask;                 /* may be NULL */
   const float* densityBC; const float* densityBCInvMask;     /* may be NULL */
   const void*  net;  /* packed ScaleNet weights from fnx_scalenet_pack (method 1), else NULL */
+  /* Optional (B,1,D,H,W) bytes from fnx_bc_classify, or NULL: bit 0 = setConstVals is x*1+0 for every velocity component
+   * of the cell, bit 1 = the same for the density.  The BC stages then skip the 8 BC loads of such a cell (32 of its 64-68
+   * bytes) and apply t = x*1, t + 0 directly: same bits.  Only valid while the four BC arrays do not change. */
+  const unsigned char* bc_class;
 } FnxState;
+
+/* Classifies every cell for FnxState.bc_class (reads the four BC arrays once; st->bc_class itself is ignored). */
+int fnx_bc_classify(const FnxGrid* g, const FnxState* st, unsigned char* bc_class, void* stream);
 
 int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st,
                       void* ws, size_t ws_bytes, void* stream);

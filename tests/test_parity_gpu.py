@@ -320,18 +320,74 @@ def test_static_flags_reuses_mask_3d(dev, oracle, ext):
     from fluidnet_cxx_amd import simulate
     cfg = dict(PLUME_CFG, jacobiIter=7)
     runs = []
-    for static in (False, True):
+    for static in (False, True, "bcs"):
         bd = to_dev(plume_state(24, D=12), dev)
         ws = torch.empty(ext.step_workspace_bytes(1, 12, 24, 24, True), dtype=torch.uint8, device=dev)
-        for it in range(3):
-            simulate(cfg, bd, None, "jacobi", workspace=ws, static_flags=static and it > 0)
+        for it in range(4):
+            # "bcs": also the BC arrays are promised static -> class map built at step 2 (3), reused afterwards (7)
+            sf = (0, 3, 7, 7)[it] if static == "bcs" else (static and it > 0)
+            simulate(cfg, bd, None, "jacobi", workspace=ws, static_flags=sf)
         runs.append({k: N(bd[k]) for k in ("U", "density", "p")})
     st = plume_state(24, D=12)
-    for it in range(3):
+    for it in range(4):
         st = oracle.simulate_step(st, cfg, "jacobi")
     for k in ("U", "density", "p"):
         assert_bitexact(runs[0][k], st[k], f"{k} (mask rebuilt)")
         assert_bitexact(runs[1][k], st[k], f"{k} (mask reused)")
+        assert_bitexact(runs[2][k], st[k], f"{k} (mask and BC class map reused)")
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 40, 70), (1, 10, 20, 66)])
+@pytest.mark.parametrize("method", ["jacobi", "convnet"])
+def test_bc_class_map_same_bits(dev, ext, shape, method):
+    """The BC stages with the class map of static BC arrays (identity cells skip their 8 BC loads) give the same bits as
+    without, on random BC arrays: masks in {0, 1, 0.5}, values in {+0, -0, random} (a -0 value is NOT the identity:
+    x + -0 keeps a -0 that x + 0 turns into +0), through the fused step of both methods and the two stage entry points."""
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    B, D, H, W = shape
+    is3d = D > 1
+    rng = np.random.default_rng(8)
+    s = random_state(B, D, H, W, 1.0, seed=31)
+    nc = 3 if is3d else 2
+
+    def bc(shape_):
+        m = rng.choice(np.array([0.0, 1.0, 1.0, 1.0, 0.5], np.float32), size=shape_)
+        v = rng.choice(np.array([0.0, 0.0, 0.0, -0.0, 1.0], np.float32), size=shape_) * rng.standard_normal(shape_).astype(np.float32)
+        v[rng.random(shape_) < 0.5] = 0.0
+        v[rng.random(shape_) < 0.05] = -0.0
+        return m.astype(np.float32), v.astype(np.float32)
+    UM, UV = bc((B, nc, D, H, W)); RM, RV = bc((B, 1, D, H, W))
+    st0 = dict(p=np.zeros((B, 1, D, H, W), np.float32), U=s["U"] * 0.2, flags=s["flags"], density=s["rho"], UBC=UV, UBCInvMask=UM,
+               densityBC=RV, densityBCInvMask=RM)
+    cfg = dict(PLUME_CFG, jacobiIter=5, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False),
+               normalizeInput=True, normalizeInputChan="UDiv", is3D=is3d)
+    net = FluidNet(cfg, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if method == "convnet" else None
+    runs = []
+    for static in (False, True):
+        bd = to_dev(st0, dev)
+        ws = torch.empty(ext.step_workspace_bytes(B, D, H, W, is3d), dtype=torch.uint8, device=dev)
+        for it in range(3):
+            simulate(cfg, bd, net, method, workspace=ws, static_flags=(0, 3, 7)[it] if static else 0)
+        runs.append({k: bd[k].clone() for k in ("U", "density", "p")})
+    for k in ("U", "density", "p"):
+        assert torch.equal(runs[0][k].view(torch.int32), runs[1][k].view(torch.int32)), f"{method} {k}: bits differ with the class map"
+    # the stage entry points with an explicit class map
+    bd = to_dev(st0, dev)
+    cls = ext.bc_classify(bd["flags"], is3d, bd["UBC"], bd["UBCInvMask"], bd["densityBC"], bd["densityBCInvMask"])
+    assert 0.02 < float((cls & 1).float().mean()) < 0.9 and 0.1 < float(((cls >> 1) & 1).float().mean()) < 0.9   # both classes occur
+    Uadv, radv = T(s["U"] * 0.3, dev), T(s["rho"] * 0.7, dev)
+    outs = []
+    for c in (None, cls):
+        b2 = {k: v.clone() for k, v in bd.items()}
+        div = ext.pre_projection_(Uadv, radv, b2["p"], b2["U"], b2["flags"], b2["density"], b2["UBC"], b2["UBCInvMask"],
+                                  b2["densityBC"], b2["densityBCInvMask"], 0.1, 0.25, [0.0, -1.0, 0.2], 0.0, True, c)
+        b2["p"].copy_(torch.randn_like(b2["p"]).mul_(0).add_(div))       # any pressure field: use div itself
+        ext.post_projection_(b2["p"], b2["U"], b2["flags"], b2["density"], b2["UBC"], b2["UBCInvMask"], b2["densityBC"],
+                             b2["densityBCInvMask"], c)
+        outs.append((div, b2["U"], b2["density"]))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a.view(torch.int32), b_.view(torch.int32))
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 40, 70, 3.0), (1, 9, 20, 66, 2.0)])
