@@ -24,7 +24,8 @@ struct StepPtrs {
 };
 
 // velocity component `a` of cell (k,j,i) after setConstVals, addBuoyancy, setWallBcs, setConstVals
-template <bool IS3D, bool QUIRKS, bool WALL>
+// IDENT: every BC this evaluation touches is the identity x*1 + 0 (wave-uniform fast path: no BC or class loads at all)
+template <bool IS3D, bool QUIRKS, bool WALL, bool IDENT = false>
 __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, int b, int a, int k, int j, int i,
                                           bool buoy, float s_a, float rho_star) {
   constexpr int NC = IS3D ? 3 : 2;
@@ -34,7 +35,7 @@ __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, 
   float u = P.U_adv[ou];
   float m = 1.f, c = 0.f;
   if (ubc) {                                                                                  // simulate.py:96
-    if (!(P.cls && (P.cls[os] & 1))) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; }                // (identity cells: no loads)
+    if (!IDENT && !(P.cls && (P.cls[os] & 1))) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; }      // (identity cells: no loads)
     const float t = u * m; u = t + c;
   }
   const float fc = P.flags[os];
@@ -46,8 +47,8 @@ __device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, 
     float r0 = P.rho_adv[os], r1 = P.rho_adv[os - off];
     if (rbc) {
       float m0 = 1.f, c0 = 0.f, m1 = 1.f, c1 = 0.f;
-      if (!(P.cls && (P.cls[os] & 2))) { m0 = P.rhoBCInvMask[os]; c0 = P.rhoBC[os]; }
-      if (!(P.cls && (P.cls[os - off] & 2))) { m1 = P.rhoBCInvMask[os - off]; c1 = P.rhoBC[os - off]; }
+      if (!IDENT && !(P.cls && (P.cls[os] & 2))) { m0 = P.rhoBCInvMask[os]; c0 = P.rhoBC[os]; }
+      if (!IDENT && !(P.cls && (P.cls[os - off] & 2))) { m1 = P.rhoBCInvMask[os - off]; c1 = P.rhoBC[os - off]; }
       float t = r0 * m0; r0 = t + c0;
       t = r1 * m1; r1 = t + c1;
     }
@@ -74,16 +75,32 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
   constexpr int NC = IS3D ? 3 : 2;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
   const bool by = buoy != 0;
-  const float u0 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i, by, sx, rho_star);
-  const float u1 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j, i, by, sy, rho_star);
-  float u2 = 0.f;
-  if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k, j, i, by, sz, rho_star);
+  // staging pass without the fused divergence (3D): when every lane of the wave only touches identity cells -- its own
+  // and the -1 neighbours whose density the buoyancy term averages -- no BC array and no further class byte is read
+  bool ident = false;
+  if (P.cls && !P.div) {
+    bool mine = P.cls[os] == 3;
+    if (i > 0) mine = mine & ((P.cls[os - 1] & 2) != 0);
+    if (j > 0) mine = mine & ((P.cls[os - g.W] & 2) != 0);
+    if (IS3D && k > 0) mine = mine & ((P.cls[os - g.HW] & 2) != 0);
+    ident = __builtin_amdgcn_ballot_w64(!mine) == 0;
+  }
+  float u0, u1, u2 = 0.f;
+  if (ident) {
+    u0 = staged_u<IS3D, QUIRKS, WALL, true>(g, P, b, 0, k, j, i, by, sx, rho_star);
+    u1 = staged_u<IS3D, QUIRKS, WALL, true>(g, P, b, 1, k, j, i, by, sy, rho_star);
+    if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL, true>(g, P, b, 2, k, j, i, by, sz, rho_star);
+  } else {
+    u0 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i, by, sx, rho_star);
+    u1 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j, i, by, sy, rho_star);
+    if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k, j, i, by, sz, rho_star);
+  }
   float rnew = 0.f;
   if (P.rho_adv) {
     float r = P.rho_adv[os];
     if (P.rhoBC) {
       float m = 1.f, c = 0.f;
-      if (!(P.cls && (P.cls[os] & 2))) { m = P.rhoBCInvMask[os]; c = P.rhoBC[os]; }
+      if (!ident && !(P.cls && (P.cls[os] & 2))) { m = P.rhoBCInvMask[os]; c = P.rhoBC[os]; }
       float t = r * m; r = t + c;       // simulate.py:96
       t = r * m; r = t + c;             // simulate.py:133
     }
@@ -109,6 +126,83 @@ __global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, Step
   if (IS3D) P.U[((size_t)b * NC + 2) * g.DHW + o] = u2;
   if (P.rho_adv) P.rho[os] = rnew;
   if (P.div) P.div[os] = d;
+}
+
+// The 3D staging pass (pre_projection without the fused divergence) as straight-line code: every load of a cell -- its
+// three advected velocity components, the density and the flags of the cell and of its three -1 neighbours, and, unless
+// the whole wave is in identity BC cells, the BC arrays of those cells -- is issued unconditionally up front (a -1
+// neighbour that does not exist reads the cell itself) and the stage conditions become selects.  staged_u nests its
+// loads inside those conditions, which turned the kernel into a chain of load -> wait -> branch round trips (58 waits:
+// 257 us at 512x512x64 whether or not the BC loads were skipped).  Same operations in the same order: same bits.
+template <bool QUIRKS, bool WALL>
+__global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P, int buoy, float sx, float sy, float sz,
+                                                         float rho_star) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const int bk = blockIdx.z;
+  const int b = bk / g.KN, k = g.K0 + (bk - b * g.KN);
+  if (i >= g.W || j >= g.H) return;
+  const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
+  const int off[3] = { i > 0 ? 1 : 0, j > 0 ? g.W : 0, k > 0 ? g.HW : 0 };     // 0: "the cell itself" (staged_u: fm = fc)
+  const bool has_rho = P.rho_adv != nullptr, ubc = P.UBC != nullptr, rbc = P.rhoBC != nullptr;
+  bool ident = false;
+  if (P.cls) {
+    bool mine = P.cls[os] == 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mine = mine & ((P.cls[os - off[a]] & 2) != 0);
+    ident = __builtin_amdgcn_ballot_w64(!mine) == 0;
+  }
+  // ---- loads
+  const float fc = P.flags[os];
+  float fm[3], u[3], r1[3] = { 0.f, 0.f, 0.f }, r0 = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { fm[a] = P.flags[os - off[a]]; u[a] = P.U_adv[((size_t)b * 3 + a) * g.DHW + o]; }
+  if (has_rho) {
+    r0 = P.rho_adv[os];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r1[a] = P.rho_adv[os - off[a]];
+  }
+  float um[3] = { 1.f, 1.f, 1.f }, uc[3] = { 0.f, 0.f, 0.f }, rm0 = 1.f, rc0 = 0.f, rm1[3] = { 1.f, 1.f, 1.f }, rc1[3] = { 0.f, 0.f, 0.f };
+  if (!ident) {
+    if (ubc) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { um[a] = P.UBCInvMask[((size_t)b * 3 + a) * g.DHW + o]; uc[a] = P.UBC[((size_t)b * 3 + a) * g.DHW + o]; }
+    }
+    if (rbc && has_rho) {
+      rm0 = P.rhoBCInvMask[os]; rc0 = P.rhoBC[os];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { rm1[a] = P.rhoBCInvMask[os - off[a]]; rc1[a] = P.rhoBC[os - off[a]]; }
+    }
+  }
+  // ---- the stages of staged_u, per component
+  const bool border = is_border<true>(g, i, j, k);
+  const float sa[3] = { sx, sy, sz };
+  float un[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float v = u[a];
+    if (ubc) { const float t = v * um[a]; v = t + uc[a]; }                                   // simulate.py:96
+    if (buoy && has_rho && !border && fc == FNX_FLUID && fm[a] == FNX_FLUID) {                // source_terms.py
+      float q0 = r0, q1 = r1[a];
+      if (rbc) { float t = q0 * rm0; q0 = t + rc0; t = q1 * rm1[a]; q1 = t + rc1[a]; }
+      if (a == 2 && QUIRKS) v = v + sa[a] * (0.5f * (q0 + (k + g.zoff <= 1 ? 0.f : q1)));
+      else v = v + sa[a] * ((0.5f * (q0 + q1)) - rho_star);
+    }
+    if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {                                        // set_wall_bcs.py:45-84
+      if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
+        if (fm[a] == FNX_OBST || (fc == FNX_OBST && fm[a] == FNX_FLUID)) v = 0.f;
+      }
+    }
+    if (ubc) { const float t = v * um[a]; v = t + uc[a]; }                                   // simulate.py:133
+    un[a] = v;
+  }
+  float rnew = r0;
+  if (has_rho && rbc) {
+    float t = rnew * rm0; rnew = t + rc0;       // simulate.py:96
+    t = rnew * rm0; rnew = t + rc0;             // simulate.py:133
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) P.U[((size_t)b * 3 + a) * g.DHW + o] = un[a];
+  if (has_rho) P.rho[os] = rnew;
 }
 
 // velocityUpdate + setWallBcs + setConstVals (simulate.py:154-168), in place on U (and rho for the BC re-imposition)
@@ -203,6 +297,14 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
   StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div, cls};
   const dim3 grid = cell_grid(g), block(BX, BY);
 #define PRE(A, Q, WL) pre_projection_kernel<A, Q, WL><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star)
+  static const bool flat = [] { const char* e = getenv("FNX_STAGE3D_FLAT"); return !e || atoi(e) != 0; }();   // A/B switch
+  if (is3d && !div && flat) {
+    if (quirks) { if (wall_bcs) stage3d_kernel<true, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
+                  else stage3d_kernel<true, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
+    else        { if (wall_bcs) stage3d_kernel<false, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
+                  else stage3d_kernel<false, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
+    return;
+  }
   if (is3d) {
     if (quirks) { if (wall_bcs) PRE(true, true, true); else PRE(true, true, false); }
     else        { if (wall_bcs) PRE(true, false, true); else PRE(true, false, false); }
