@@ -414,6 +414,144 @@ __global__ __launch_bounds__(BX* BY) void sl_mac_bwd_clamp_kernel(GridDims g, fl
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Phase-ordered ("flat") velocity passes.  The per-component functions above interleave loads and their use: compiled,
+// the backward pass is ~60 dependent load -> wait round trips per thread (clusters of 1-13 loads).  Here all components
+// go through the same expressions phase by phase: (A) every load that depends on the cell only (own values, -1 flags,
+// the 9 face-velocity operands per component), (B) every gather that depends on the face velocities (8 trilinear
+// corners and 2 x 8 clamp corners per component) in one batch, (C) the arithmetic.  A non-fluid cell computes its
+// (unused) sample anyway -- addresses are clamped, so that is safe -- and takes the reference's pass-through by select.
+// Same operations in the same order per value: same bits.  Measured: 2D 1024^2 advection 39 -> 36 us; 3D unchanged
+// (1.06 ms at 512x512x64): there the scalar half with its line trace sets the pace.
+// ---------------------------------------------------------------------------------------------------
+template <bool IS3D>
+__device__ __forceinline__ void sl_mac_bwd_clamp_cell_flat(const GridDims& g, const CellId& c, float dt, float half_s,
+                                                           const float* __restrict__ orig,
+                                                           const float* __restrict__ fwd,
+                                                           const float* __restrict__ U,
+                                                           const float* __restrict__ flags,
+                                                           float* __restrict__ dst) {
+  constexpr int NC = IS3D ? 3 : 2, NK = IS3D ? 8 : 4;
+  const Field fo{orig + (size_t)c.b * NC * g.DHW}, fw{fwd + (size_t)c.b * NC * g.DHW},
+      fu{U + (size_t)c.b * NC * g.DHW}, ff{flags + (size_t)c.b * g.DHW};
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  float* d = dst + (size_t)c.b * NC * g.DHW + o;
+  if (is_border<IS3D>(g, c.i, c.j, c.k)) {
+#pragma unroll
+    for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = 0.f;
+    return;
+  }
+  const int i = c.i, j = c.j, k = c.k;
+  // ---- (A) loads that depend on the cell only
+  const float fcell = ff.p[o];
+  float f[NC], og[NC], fmn[NC], v[NC][3];
+  bool chk[NC];
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    f[a] = fw.p[(size_t)a * g.DHW + o];
+    og[a] = fo.p[(size_t)a * g.DHW + o];
+    const int idx = a == 0 ? i : (a == 1 ? j : k + g.zoff);
+    chk[a] = idx > 0 && !(a == 2 && k == 0);
+    fmn[a] = ff.p[o - (chk[a] ? (a == 0 ? 1 : (a == 1 ? g.W : g.HW)) : 0)];
+  }
+  get_at_mac<IS3D, false, 0>(g, fu, i, j, k, v[0]);
+  get_at_mac<IS3D, false, 1>(g, fu, i, j, k, v[1]);
+  if (IS3D) get_at_mac<IS3D, false, 2>(g, fu, i, j, k, v[2]);
+  // ---- (B) gathers that depend on the face velocities
+  float vd[NC][3];
+  Lerp L[NC];
+  float Iv[NC][NK], Cv[NC][2][NK];
+  const float pos[3] = { (float)i, (float)j, (float)(k + g.zoff) };
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) vd[a][q] = v[a][q] * dt;
+    L[a] = lerp_setup<IS3D>(g, ((float)i + 0.5f) + vd[a][0], ((float)j + 0.5f) + vd[a][1], ((float)(k + g.zoff) + 0.5f) + vd[a][2]);
+    const float* q = fw.p + (size_t)a * g.DHW + (size_t)L[a].z0 * g.HW + L[a].y0 * g.W + L[a].x0;
+    Iv[a][0] = q[0]; Iv[a][1] = q[g.W]; Iv[a][2] = q[1]; Iv[a][3] = q[g.W + 1];
+    if (IS3D) { const float* r = q + g.HW; Iv[a][4] = r[0]; Iv[a][5] = r[g.W]; Iv[a][6] = r[1]; Iv[a][7] = r[g.W + 1]; }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int qx = (int)(l == 0 ? pos[0] - vd[a][0] : pos[0] + vd[a][0]);
+      const int qy = (int)(l == 0 ? pos[1] - vd[a][1] : pos[1] + vd[a][1]);
+      const int qz = (int)(l == 0 ? pos[2] - vd[a][2] : pos[2] + vd[a][2]);
+      const int i0 = clampi(qx, 0, g.W - 2), j0 = clampi(qy, 0, g.H - 2);
+      const int k0 = IS3D ? clampi(clampi(qz, 0, g.Dglob - 2) - g.zoff, 0, g.D - 2) : 0;
+      const float* p = fo.p + (size_t)a * g.DHW + (size_t)k0 * g.HW + j0 * g.W + i0;
+      Cv[a][l][0] = p[0]; Cv[a][l][1] = p[1]; Cv[a][l][2] = p[g.W]; Cv[a][l][3] = p[g.W + 1];
+      if (IS3D) { const float* r = p + g.HW; Cv[a][l][4] = r[0]; Cv[a][l][5] = r[1]; Cv[a][l][6] = r[g.W]; Cv[a][l][7] = r[g.W + 1]; }
+    }
+  }
+  // ---- (C) arithmetic (mac_bwd_correct_clamp)
+  const bool fluid = fcell == FNX_FLUID;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const float lo = (Iv[a][0] * L[a].t0 + Iv[a][1] * L[a].t1) * L[a].s0 + (Iv[a][2] * L[a].t0 + Iv[a][3] * L[a].t1) * L[a].s1;
+    float smp = lo;
+    if (IS3D) {
+      const float hi = (Iv[a][4] * L[a].t0 + Iv[a][5] * L[a].t1) * L[a].s0 + (Iv[a][6] * L[a].t0 + Iv[a][7] * L[a].t1) * L[a].s1;
+      smp = lo * L[a].f0 + hi * L[a].f1;
+    }
+    const float bwd = fluid ? smp : (a == 0 ? f[1] : (a == 1 ? 0.f : f[a]));      // Q1 pass-through of SL(fwd)
+    const bool skip = !fluid | (chk[a] & (fmn[a] != FNX_FLUID));
+    const float corr = skip ? f[a] : f[a] + half_s * (og[a] - bwd);
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int q = 0; q < NK; ++q) { mn = fminf(mn, Cv[a][l][q]); mx = fmaxf(mx, Cv[a][l][q]); }
+    d[(size_t)a * g.DHW] = fmaxf(fminf(corr, mx), mn);
+  }
+}
+
+// forward pass (sl_mac_cell), the same way
+template <bool IS3D>
+__device__ __forceinline__ void sl_mac_cell_flat(const GridDims& g, const CellId& c, float dt, const float* __restrict__ src,
+                                                 const float* __restrict__ U, const float* __restrict__ flags,
+                                                 float* __restrict__ dst) {
+  constexpr int NC = IS3D ? 3 : 2, NK = IS3D ? 8 : 4;
+  const Field fs{src + (size_t)c.b * NC * g.DHW}, fu{U + (size_t)c.b * NC * g.DHW};
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  float* d = dst + (size_t)c.b * NC * g.DHW + o;
+  if (is_border<IS3D>(g, c.i, c.j, c.k)) {
+#pragma unroll
+    for (int a = 0; a < NC; ++a) d[(size_t)a * g.DHW] = 0.f;
+    return;
+  }
+  const int i = c.i, j = c.j, k = c.k;
+  const float fcell = flags[(size_t)c.b * g.DHW + o];
+  float own[NC], v[NC][3];
+#pragma unroll
+  for (int a = 0; a < NC; ++a) own[a] = fs.p[(size_t)a * g.DHW + o];
+  get_at_mac<IS3D, false, 0>(g, fu, i, j, k, v[0]);
+  get_at_mac<IS3D, false, 1>(g, fu, i, j, k, v[1]);
+  if (IS3D) get_at_mac<IS3D, false, 2>(g, fu, i, j, k, v[2]);
+  Lerp L[NC];
+  float Iv[NC][NK];
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const float px = ((float)i + 0.5f) + v[a][0] * (-dt);
+    const float py = ((float)j + 0.5f) + v[a][1] * (-dt);
+    const float pz = ((float)(k + g.zoff) + 0.5f) + v[a][2] * (-dt);
+    L[a] = lerp_setup<IS3D>(g, px, py, pz);
+    const float* q = fs.p + (size_t)a * g.DHW + (size_t)L[a].z0 * g.HW + L[a].y0 * g.W + L[a].x0;
+    Iv[a][0] = q[0]; Iv[a][1] = q[g.W]; Iv[a][2] = q[1]; Iv[a][3] = q[g.W + 1];
+    if (IS3D) { const float* r = q + g.HW; Iv[a][4] = r[0]; Iv[a][5] = r[g.W]; Iv[a][6] = r[1]; Iv[a][7] = r[g.W + 1]; }
+  }
+  const bool fluid = fcell == FNX_FLUID;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const float lo = (Iv[a][0] * L[a].t0 + Iv[a][1] * L[a].t1) * L[a].s0 + (Iv[a][2] * L[a].t0 + Iv[a][3] * L[a].t1) * L[a].s1;
+    float smp = lo;
+    if (IS3D) {
+      const float hi = (Iv[a][4] * L[a].t0 + Iv[a][5] * L[a].t1) * L[a].s0 + (Iv[a][6] * L[a].t0 + Iv[a][7] * L[a].t1) * L[a].s1;
+      smp = lo * L[a].f0 + hi * L[a].f1;
+    }
+    // non-fluid cell: the reference writes src channel 1 into channel 0, 0 into channel 1, src channel 2 into channel 2 (:413-416)
+    d[(size_t)a * g.DHW] = fluid ? smp : (a == 0 ? own[1] : (a == 1 ? 0.f : own[2]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The density and the velocity MacCormack advections of one time step in two launches instead of four (forward passes
 // together, backward/clamp passes together; 3D: the clamp-bounds pass in between).  In 2D at 128^2 .. 1024^2 each pass
 // is a 7-14 us launch that is mostly ramp-up; in 3D the two chains share their velocity loads (1.13 -> 1.06 ms at
@@ -428,7 +566,8 @@ __global__ __launch_bounds__(BX* BY) void advect_fwd_kernel(GridDims g, float dt
   const CellId c = cell_id<IS3D>(g);
   if (!c.valid) return;
   sl_scalar_cell<IS3D, QUIRKS, SAMPLE_OUTSIDE>(g, c, dt, rho, U, flags, rho_fwd, cell_out);
-  sl_mac_cell<IS3D, QUIRKS>(g, c, dt, U, U, flags, U_fwd);
+  if (QUIRKS) sl_mac_cell<IS3D, QUIRKS>(g, c, dt, U, U, flags, U_fwd);
+  else sl_mac_cell_flat<IS3D>(g, c, dt, U, U, flags, U_fwd);
 }
 
 template <bool IS3D, bool QUIRKS, bool SAMPLE_OUTSIDE>
@@ -444,7 +583,8 @@ __global__ __launch_bounds__(BX* BY) void advect_bwd_kernel(GridDims g, float dt
   const CellId c = cell_id<IS3D>(g);
   if (!c.valid) return;
   sl_scalar_bwd_clamp_cell<IS3D, QUIRKS, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, box, rho_dst);
-  sl_mac_bwd_clamp_cell<IS3D, QUIRKS>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
+  if (QUIRKS) sl_mac_bwd_clamp_cell<IS3D, QUIRKS>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
+  else sl_mac_bwd_clamp_cell_flat<IS3D>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
 }
 
 inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
