@@ -205,6 +205,88 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
   if (has_rho) P.rho[os] = rnew;
 }
 
+// The 2D fused stage (BCs, buoyancy, wall BCs, BCs and -div in one pass) the same way: the cell needs the staged
+// velocity of itself, of u_x at (i+1, j) and of u_y at (i, j+1); all the loads those four evaluations make -- flags and
+// density at the cell and its four neighbours, four advected velocity values and, unless the whole wave is in identity
+// BC cells, their BC entries -- are issued up front (clamped indices where a neighbour does not exist; such values are
+// never used) and staged_u's conditions become selects.  Same operations in the same order: same bits.
+template <bool WALL>
+__device__ __forceinline__ float stage_eval2d(int a, float u, bool ubc, float um, float uc, float fc, float fm, bool border,
+                                              bool buoy, float r0, float r1, bool rbc, float rm0, float rc0, float rm1,
+                                              float rc1, float s_a, float rho_star) {
+  if (ubc) { const float t = u * um; u = t + uc; }                                           // simulate.py:96
+  if (buoy && !border && fc == FNX_FLUID && fm == FNX_FLUID) {                               // source_terms.py
+    if (rbc) { float t = r0 * rm0; r0 = t + rc0; t = r1 * rm1; r1 = t + rc1; }
+    u = u + s_a * ((0.5f * (r0 + r1)) - rho_star);
+  }
+  if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {                                         // set_wall_bcs.py:45-84
+    if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
+  }
+  if (ubc) { const float t = u * um; u = t + uc; }                                           // simulate.py:133
+  (void)a;
+  return u;
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(BX* BY) void stage2d_div_kernel(GridDims g, StepPtrs P, int buoy_, float sx, float sy,
+                                                             float rho_star) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+  const int b = blockIdx.z;
+  if (i >= g.W || j >= g.H) return;
+  const size_t o = (size_t)j * g.W + i, os = (size_t)b * g.DHW + o;
+  const bool has_rho = P.rho_adv != nullptr, ubc = P.UBC != nullptr, rbc = P.rhoBC != nullptr && has_rho;
+  const bool buoy = buoy_ != 0 && has_rho;
+  // neighbour offsets; 0 where the neighbour does not exist (staged_u: fm = fc at index 0; the +1 values of a border
+  // cell are never used)
+  const int xm = i > 0 ? 1 : 0, ym = j > 0 ? g.W : 0, xp = i < g.W - 1 ? 1 : 0, yp = j < g.H - 1 ? g.W : 0;
+  bool ident = false;
+  if (P.cls) {
+    const bool mine = (P.cls[os] == 3) & ((P.cls[os - xm] & 2) != 0) & ((P.cls[os - ym] & 2) != 0) & (P.cls[os + xp] == 3) &
+                      (P.cls[os + yp] == 3);
+    ident = __builtin_amdgcn_ballot_w64(!mine) == 0;
+  }
+  // ---- loads
+  const float F00 = P.flags[os], Fm0 = P.flags[os - xm], F0m = P.flags[os - ym], Fp0 = P.flags[os + xp], F0p = P.flags[os + yp];
+  const size_t o0 = ((size_t)b * 2 + 0) * g.DHW + o, o1 = ((size_t)b * 2 + 1) * g.DHW + o;
+  const float u0 = P.U_adv[o0], u1 = P.U_adv[o1], u0p = P.U_adv[o0 + xp], u1p = P.U_adv[o1 + yp];
+  float R00 = 0.f, Rm0 = 0.f, R0m = 0.f, Rp0 = 0.f, R0p = 0.f;
+  if (has_rho) { R00 = P.rho_adv[os]; Rm0 = P.rho_adv[os - xm]; R0m = P.rho_adv[os - ym]; Rp0 = P.rho_adv[os + xp]; R0p = P.rho_adv[os + yp]; }
+  float m0 = 1.f, c0 = 0.f, m1 = 1.f, c1 = 0.f, m0p = 1.f, c0p = 0.f, m1p = 1.f, c1p = 0.f;
+  float rm00 = 1.f, rc00 = 0.f, rmm0 = 1.f, rcm0 = 0.f, rm0m = 1.f, rc0m = 0.f, rmp0 = 1.f, rcp0 = 0.f, rm0p = 1.f, rc0p = 0.f;
+  if (!ident) {
+    if (ubc) {
+      m0 = P.UBCInvMask[o0]; c0 = P.UBC[o0]; m1 = P.UBCInvMask[o1]; c1 = P.UBC[o1];
+      m0p = P.UBCInvMask[o0 + xp]; c0p = P.UBC[o0 + xp]; m1p = P.UBCInvMask[o1 + yp]; c1p = P.UBC[o1 + yp];
+    }
+    if (rbc) {
+      rm00 = P.rhoBCInvMask[os]; rc00 = P.rhoBC[os]; rmm0 = P.rhoBCInvMask[os - xm]; rcm0 = P.rhoBC[os - xm];
+      rm0m = P.rhoBCInvMask[os - ym]; rc0m = P.rhoBC[os - ym]; rmp0 = P.rhoBCInvMask[os + xp]; rcp0 = P.rhoBC[os + xp];
+      rm0p = P.rhoBCInvMask[os + yp]; rc0p = P.rhoBC[os + yp];
+    }
+  }
+  // ---- the four staged values
+  const bool border = is_border<false>(g, i, j, 0);
+  const float v0 = stage_eval2d<WALL>(0, u0, ubc, m0, c0, F00, Fm0, border, buoy, R00, Rm0, rbc, rm00, rc00, rmm0, rcm0, sx, rho_star);
+  const float v1 = stage_eval2d<WALL>(1, u1, ubc, m1, c1, F00, F0m, border, buoy, R00, R0m, rbc, rm00, rc00, rm0m, rc0m, sy, rho_star);
+  float rnew = R00;
+  if (rbc) { float t = rnew * rm00; rnew = t + rc00; t = rnew * rm00; rnew = t + rc00; }    // simulate.py:96, :133
+  float d = 0.f;
+  if (P.div) {
+    if (!border) {
+      const float v0p = stage_eval2d<WALL>(0, u0p, ubc, m0p, c0p, Fp0, F00, is_border<false>(g, i + 1, j, 0), buoy, Rp0, R00, rbc,
+                                           rmp0, rcp0, rm00, rc00, sx, rho_star);
+      const float v1p = stage_eval2d<WALL>(1, u1p, ubc, m1p, c1p, F0p, F00, is_border<false>(g, i, j + 1, 0), buoy, R0p, R00, rbc,
+                                           rm0p, rc0p, rm00, rc00, sy, rho_star);
+      d = ((v0 - v0p) + v1) - v1p;
+    }
+    if (F00 == FNX_OBST) d = 0.f;
+  }
+  P.U[o0] = v0;
+  P.U[o1] = v1;
+  if (has_rho) P.rho[os] = rnew;
+  if (P.div) P.div[os] = d;
+}
+
 // velocityUpdate + setWallBcs + setConstVals (simulate.py:154-168), in place on U (and rho for the BC re-imposition)
 template <bool IS3D>
 __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, const float* __restrict__ p,
@@ -298,6 +380,11 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
   const dim3 grid = cell_grid(g), block(BX, BY);
 #define PRE(A, Q, WL) pre_projection_kernel<A, Q, WL><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star)
   static const bool flat = [] { const char* e = getenv("FNX_STAGE3D_FLAT"); return !e || atoi(e) != 0; }();   // A/B switch
+  if (!is3d && flat) {
+    if (wall_bcs) stage2d_div_kernel<true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, rho_star);
+    else stage2d_div_kernel<false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, rho_star);
+    return;
+  }
   if (is3d && !div && flat) {
     if (quirks) { if (wall_bcs) stage3d_kernel<true, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
                   else stage3d_kernel<true, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
