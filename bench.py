@@ -177,7 +177,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         cells = w["res"] * w["res"] * layout.owned
     else:
         bd = build_state(w, dev)
-        net = FluidNet(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
+        net = FluidNet.from_weights(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
         ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
 
         seen = []                          # flags never change here: after the first step the solver keeps its mask

@@ -11,6 +11,8 @@ promises that batch_dict['flags'] has not changed since the previous call on tha
 its obstacle mask).  `static_flags` may also be the C ABI's bit set (FnxStepParams.static_flags): 1 = flags unchanged,
 2 = the four BC arrays unchanged (the BC stages then go by a 1-byte class map kept in the workspace), 4 = that map was
 already built by an earlier call with bit 2 -- e.g. 0 for the first step, 3 for the second, 7 from the third on.
+`geom` (an `ext.Geom`, 3D only) selects the reference-quirk mode / a z-slab view for this call; it is per call, the
+extension keeps no state.
 """
 import torch
 
@@ -27,7 +29,8 @@ def _gravity(mconf, scale):
     return [float(gv["x"]), float(gv["y"]), float(gv["z"])], float(scale)
 
 
-def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None, static_flags=False):
+def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None, static_flags=False,
+             geom=None):
     assert sim_method in ("convnet", "jacobi"), "Simulation method not supported. Choose either convnet or jacobi."
     dt = float(mconf["dt"])
     maccormackStrength = mconf["maccormackStrength"]
@@ -41,17 +44,20 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
 
     simple = (viscosity == 0 and gravityScale == 0 and not mconf.get("correctScalar", False)
               and "flags_stick" not in batch_dict and not output_div
-              and not ("periodic-x" in mconf and "periodic-y" in mconf))
+              and not ("periodic-x" in mconf and "periodic-y" in mconf)
+              # no 'density' key but a density BC: the reference applies setConstVals to its zeros (simulate.py:82-97)
+              and (has_density or not ("densityBC" in batch_dict and "densityBCInvMask" in batch_dict)))
     if fused and simple:
-        gvec, _ = _gravity(mconf, 1.0)
+        # gravityVec is only read when buoyancy is applied (simulate.py:99-105)
+        gvec = _gravity(mconf, 1.0)[0] if (has_density and buoyancyScale > 0) else [0.0, 0.0, 0.0]
         density = batch_dict["density"] if has_density else None
-        packed = net.packed if (sim_method == "convnet") else None
+        packed = net.packed_for(U.device) if (sim_method == "convnet") else None
         ext.simulate_step_(p, U, flags, density, batch_dict.get("UBC"), batch_dict.get("UBCInvMask"),
                            batch_dict.get("densityBC"), batch_dict.get("densityBCInvMask"), packed, dt,
                            float(maccormackStrength), bool(sampleOutsideFluid), float(buoyancyScale), gvec,
                            float(mconf.get("operatingDensity", 0.0)), float(mconf.get("pTol", 0.0)),
                            int(mconf.get("jacobiIter", 1)), sim_method,
-                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, int(static_flags))
+                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, int(static_flags), geom)
         if not has_density:
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return
@@ -65,23 +71,23 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
     if has_density:
         density = fluid.advectScalar(dt, batch_dict["density"], U, flags, method="maccormackFluidNet",
                                      boundary_width=1, sample_outside_fluid=sampleOutsideFluid,
-                                     maccormack_strength=maccormackStrength)
+                                     maccormack_strength=maccormackStrength, geom=geom)
         if mconf.get("correctScalar", False):
-            div = fluid.velocityDivergence(U, flags)
+            div = fluid.velocityDivergence(U, flags, geom=geom)
             fluid.correctScalar(dt, density, div, flags)
     else:
         density = torch.zeros_like(flags)
     U = fluid.advectVelocity(dt=dt, orig=orig, U=U, flags=flags, method="maccormackFluidNet", boundary_width=1,
-                             maccormack_strength=maccormackStrength)
+                             maccormack_strength=maccormackStrength, geom=geom)
     setConstVals(batch_dict, p, U, flags, density)
     if has_density and buoyancyScale > 0:
         gvec, _ = _gravity(mconf, 1.0)
         gravity = (torch.tensor(gvec, dtype=torch.float32) * (-buoyancyScale)).tolist()
-        U = fluid.addBuoyancy(U, flags, density, gravity, mconf["operatingDensity"], dt)
+        U = fluid.addBuoyancy(U, flags, density, gravity, mconf["operatingDensity"], dt, geom=geom)
     if has_density and gravityScale > 0:                        # simulate.py:107-114 (inside the density branch)
         gvec, _ = _gravity(mconf, 1.0)
         gravity = (torch.tensor(gvec, dtype=torch.float32) * (-gravityScale)).tolist()
-        U = fluid.addGravity(U, flags, gravity, dt)
+        U = fluid.addGravity(U, flags, gravity, dt, geom=geom)
     if output_div:
         return
     periodic = "periodic-x" in mconf and "periodic-y" in mconf
@@ -89,7 +95,7 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
     def wall_bcs(U):
         if periodic:
             U_temp = U.clone()
-        U = fluid.setWallBcs(U, flags)
+        U = fluid.setWallBcs(U, flags, geom=geom)
         if periodic:
             if mconf["periodic-x"]:
                 U[:, 1, :, :, 1] = U_temp[:, 1, :, :, U.size(4) - 1]
@@ -108,11 +114,11 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
         if stick:                                                # simulate.py:165-166
             fluid.setWallBcsStick(U, flags, batch_dict["flags_stick"])
     else:
-        div = fluid.velocityDivergence(U, flags)
+        div = fluid.velocityDivergence(U, flags, geom=geom)
         is3D = U.size(2) > 1
         p, residual = fluid.solveLinearSystemJacobi(flags=flags, div=div, is_3d=is3D, p_tol=mconf["pTol"],
-                                                    max_iter=mconf["jacobiIter"])
-        fluid.velocityUpdate(pressure=p, U=U, flags=flags)
+                                                    max_iter=mconf["jacobiIter"], geom=geom)
+        fluid.velocityUpdate(pressure=p, U=U, flags=flags, geom=geom)
         U = wall_bcs(U)
     setConstVals(batch_dict, p, U, flags, density)
     batch_dict["U"] = U

@@ -16,9 +16,14 @@ namespace {
 
 using at::Tensor;
 
-bool g_ref_quirks = false;
-int g_k_begin = 0, g_k_end = 0;       // compute window (set_window): plane-parallel operators produce planes [k_begin, k_end) only
-int g_z_offset = 0, g_D_global = 0;   // z-slab view (set_slab): arrays hold planes [z_offset, z_offset+D) of D_global
+// Per-call geometry options (no reference counterpart; the reference is single-device and has one 3D behaviour).  The
+// extension keeps NO mutable state: every 3D-capable entry point takes an optional `geom` and is re-entrant like the
+// reference's (SURVEY.md 8b "no globals").
+struct Geom {
+  bool ref_quirks = false;          // 3D only: reproduce the reference's 3D defects bit-for-bit (FnxGrid.ref_quirks)
+  int z_offset = 0, D_global = 0;   // z-slab view: the tensors hold planes [z_offset, z_offset + D) of a D_global-deep domain
+  int k_begin = 0, k_end = 0;       // compute window: plane-parallel operators produce local planes [k_begin, k_end) only
+};
 
 void check_status(int rc) {
   TORCH_CHECK(rc == FNX_OK, fnx_last_error());
@@ -31,15 +36,17 @@ void check_field(const Tensor& t, const char* name) {
   TORCH_CHECK(t.is_contiguous(), "Input is not contiguous");
 }
 
-FnxGrid grid_of(const Tensor& flags, bool is3D) {
+FnxGrid grid_of(const Tensor& flags, bool is3D, const Geom* geom) {
+  static const Geom none;
+  const Geom& go = geom ? *geom : none;
   check_field(flags, "flags");
   TORCH_CHECK(flags.size(1) == 1, "flags is not scalar");
   FnxGrid g{};
   g.B = (int)flags.size(0); g.D = (int)flags.size(2); g.H = (int)flags.size(3); g.W = (int)flags.size(4);
   g.is3D = is3D ? 1 : 0;
-  g.ref_quirks = g_ref_quirks ? 1 : 0;
-  g.z_offset = g_z_offset; g.D_global = is3D ? g_D_global : 0;
-  g.k_begin = is3D ? g_k_begin : 0; g.k_end = is3D ? g_k_end : 0;
+  g.ref_quirks = go.ref_quirks ? 1 : 0;
+  g.z_offset = is3D ? go.z_offset : 0; g.D_global = is3D ? go.D_global : 0;
+  g.k_begin = is3D ? go.k_begin : 0; g.k_end = is3D ? go.k_end : 0;
   if (!is3D) TORCH_CHECK(g.D == 1, "2D velocity field but zdepth > 1");
   return g;
 }
@@ -78,9 +85,10 @@ int method_of(const std::string& m) {
 // `out` (not in the reference): write into an existing tensor -- with a compute window (set_window) the z-slab driver
 // fills one advected field from several calls.
 Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::string method, int bnd,
-                     const bool sample_outside_fluid, const float maccormack_strength, c10::optional<Tensor> out) {
+                     const bool sample_outside_fluid, const float maccormack_strength, c10::optional<Tensor> out,
+                     const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(src, g, "src");
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor dst = (out.has_value() && out->defined()) ? *out : at::empty_like(src);
@@ -93,9 +101,9 @@ Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::st
 }
 
 Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::string method, int bnd,
-                  const float maccormack_strength, c10::optional<Tensor> out) {
+                  const float maccormack_strength, c10::optional<Tensor> out, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_vel(orig, g, "orig");
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor dst = (out.has_value() && out->defined()) ? *out : at::empty_like(U);
@@ -110,9 +118,9 @@ Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::stri
 // the two advections of one step fused (fnx_advect_step): returns {density_adv, U_adv}
 std::vector<Tensor> advect_step(float dt, Tensor density, Tensor U, Tensor flags, const bool sample_outside_fluid,
                                 const float maccormack_strength, c10::optional<Tensor> out_density,
-                                c10::optional<Tensor> out_U) {
+                                c10::optional<Tensor> out_U, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(density, g, "density");
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor rd = (out_density.has_value() && out_density->defined()) ? *out_density : at::empty_like(density);
@@ -126,8 +134,8 @@ std::vector<Tensor> advect_step(float dt, Tensor density, Tensor U, Tensor flags
 }
 
 std::vector<Tensor> solve_linear_system(Tensor flags, Tensor div, const bool is3D, const float p_tol,
-                                        const int max_iter, const bool verbose) {
-  FnxGrid g = grid_of(flags, is3D);
+                                        const int max_iter, const bool verbose, const Geom* geom) {
+  FnxGrid g = grid_of(flags, is3D, geom);
   check_scalar(div, g, "div");
   if (!is3D) TORCH_CHECK(g.D == 1, "d > 1 for a 2D domain");
   TORCH_CHECK(max_iter >= 1, "At least 1 iteration is needed (maxIter < 1)");
@@ -145,9 +153,9 @@ std::vector<Tensor> solve_linear_system(Tensor flags, Tensor div, const bool is3
 }
 
 // ---- operators the reference writes in Python -------------------------------------------------------
-Tensor velocity_divergence(Tensor U, Tensor flags) {
+Tensor velocity_divergence(Tensor U, Tensor flags, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U");
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor div = at::empty_like(flags);
@@ -155,17 +163,18 @@ Tensor velocity_divergence(Tensor U, Tensor flags) {
   return div;
 }
 
-void velocity_update_(Tensor pressure, Tensor U, Tensor flags) {
+void velocity_update_(Tensor pressure, Tensor U, Tensor flags, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(pressure, g, "pressure");
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_velocity_update(&g, pressure.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(U)));
 }
 
-void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> gravity, double rho_star, double dt) {
+void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> gravity, double rho_star, double dt,
+                   const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(density, g, "density");
   TORCH_CHECK(gravity.size() == 3, "Gravity must be a 3D vector (even in 2D)");
   const float gv[3] = {(float)gravity[0], (float)gravity[1], (float)gravity[2]};
@@ -174,9 +183,9 @@ void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> g
                                 (float)rho_star, (float)dt, cur_stream(U)));
 }
 
-void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt) {
+void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U");
   TORCH_CHECK(gravity.size() == 3, "Gravity must be a 3D vector (even in 2D)");
   const float gv[3] = {(float)gravity[0], (float)gravity[1], (float)gravity[2]};
@@ -186,7 +195,7 @@ void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt
 
 void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, nullptr);
   check_vel(U, g, "U");
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor old = U.clone();
@@ -197,7 +206,7 @@ void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
 // set_wall_bcs_stick.py:5-157 (2D; in place on U like the reference)
 void set_wall_bcs_stick_(Tensor U, Tensor flags, Tensor flags_stick) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, nullptr);
   check_vel(U, g, "U");
   check_scalar(flags_stick, g, "flags_stick");
   c10::hip::HIPGuard guard(flags.get_device());
@@ -206,9 +215,9 @@ void set_wall_bcs_stick_(Tensor U, Tensor flags, Tensor flags_stick) {
                                       flags_stick.data_ptr<float>(), cur_stream(U)));
 }
 
-void set_wall_bcs_(Tensor U, Tensor flags) {
+void set_wall_bcs_(Tensor U, Tensor flags, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U");
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_set_wall_bcs(&g, U.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(U)));
@@ -230,15 +239,15 @@ void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> 
 }
 
 Tensor flags_to_occupancy(Tensor flags) {
-  FnxGrid g = grid_of(flags, flags.size(2) > 1);
+  FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor occ = at::empty_like(flags);
   check_status(fnx_flags_to_occupancy(&g, flags.data_ptr<float>(), occ.data_ptr<float>(), cur_stream(flags)));
   return occ;
 }
 
-void empty_domain_(Tensor flags, int boundary_width) {
-  FnxGrid g = grid_of(flags, flags.size(2) > 1);
+void empty_domain_(Tensor flags, int boundary_width, const Geom* geom) {
+  FnxGrid g = grid_of(flags, flags.size(2) > 1, geom);
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_empty_domain(&g, flags.data_ptr<float>(), boundary_width, cur_stream(flags)));
 }
@@ -292,13 +301,13 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
                     double maccormack_strength, bool sample_outside_fluid, double buoyancy_scale,
                     std::vector<double> gravity_vec, double operating_density, double p_tol, int jacobi_iter,
                     const std::string method, double normalize_threshold, c10::optional<Tensor> workspace,
-                    int static_flags) {
+                    int static_flags, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
   TORCH_CHECK(method == "jacobi" || method == "convnet", "Simulation method not supported. Choose either convnet or jacobi.");
   TORCH_CHECK(gravity_vec.size() == 3, "gravityVec needs x, y, z");
-  FnxStepParams prm;
+  FnxStepParams prm{};
   prm.dt = (float)dt; prm.maccormack_strength = (float)maccormack_strength; prm.sample_outside_fluid = sample_outside_fluid;
   prm.buoyancy_scale = (float)buoyancy_scale;
   for (int a = 0; a < 3; ++a) prm.gravity_vec[a] = (float)gravity_vec[a];
@@ -309,7 +318,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
     if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
     return t->data_ptr<float>();
   };
-  FnxState st;
+  FnxState st{};
   st.p = p.data_ptr<float>(); st.U = U.data_ptr<float>(); st.flags = flags.data_ptr<float>();
   st.density = opt(density, false, "density");
   st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
@@ -328,8 +337,8 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
 
 // `nsweeps` more sweeps on an existing pressure field (in place) -- used by the z-slab driver
 void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, c10::optional<Tensor> workspace,
-                    bool reuse_mask) {
-  FnxGrid g = grid_of(flags, is3D);
+                    bool reuse_mask, const Geom* geom) {
+  FnxGrid g = grid_of(flags, is3D, geom);
   check_scalar(div, g, "div"); check_scalar(p, g, "p");
   c10::hip::HIPGuard guard(flags.get_device());
   const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_JACOBI);
@@ -342,8 +351,8 @@ void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, 
 
 // one pass (1|2 sweeps) p_in -> p_out on the output planes [k_begin, k_end) -- z-slab driver (overlap with exchange)
 void jacobi_pass_(Tensor flags, Tensor div, c10::optional<Tensor> p_in_opt, Tensor p_out, int nsweeps, int k_begin,
-                  int k_end, Tensor workspace, bool reuse_mask, int k_begin2) {
-  FnxGrid g = grid_of(flags, true);
+                  int k_end, Tensor workspace, bool reuse_mask, int k_begin2, const Geom* geom) {
+  FnxGrid g = grid_of(flags, true, geom);
   const bool zero = !(p_in_opt.has_value() && p_in_opt->defined());     // None: p = 0 (first pass of a solve)
   Tensor p_in = zero ? p_out : *p_in_opt;
   check_scalar(div, g, "div"); check_scalar(p_in, g, "p_in"); check_scalar(p_out, g, "p_out");
@@ -366,7 +375,7 @@ static FnxState make_state(const FnxGrid& g, Tensor& p, Tensor& U, Tensor& flags
     if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
     return t->data_ptr<float>();
   };
-  FnxState st;
+  FnxState st{};
   st.p = p.data_ptr<float>(); st.U = U.data_ptr<float>(); st.flags = flags.data_ptr<float>();
   st.density = opt(density, false, "density");
   st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
@@ -386,7 +395,7 @@ static const unsigned char* bc_class_ptr(c10::optional<Tensor>& t, const Tensor&
 // class map of the (static) BC arrays for pre_projection_ / post_projection_ (FnxState.bc_class)
 Tensor bc_classify(Tensor flags, bool is3D, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
                    c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask) {
-  FnxGrid g = grid_of(flags, is3D);
+  FnxGrid g = grid_of(flags, is3D, nullptr);
   Tensor dummy;
   c10::optional<Tensor> none;
   FnxState st{};
@@ -408,9 +417,9 @@ Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Te
                        c10::optional<Tensor> density, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
                        c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask, double dt,
                        double buoyancy_scale, std::vector<double> gravity_vec, double operating_density,
-                       bool jacobi_method, c10::optional<Tensor> bc_class) {
+                       bool jacobi_method, c10::optional<Tensor> bc_class, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_vel(U_adv, g, "U_adv"); check_scalar(p, g, "p");
   FnxStepParams prm{};
   prm.dt = (float)dt; prm.buoyancy_scale = (float)buoyancy_scale;
@@ -428,9 +437,9 @@ Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Te
 
 void post_projection_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> density, c10::optional<Tensor> UBC,
                       c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> densityBC,
-                      c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> bc_class) {
+                      c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> bc_class, const Geom* geom) {
   check_field(U, "U");
-  FnxGrid g = grid_of(flags, U.size(1) == 3);
+  FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
   FnxState st = make_state(g, p, U, flags, density, UBC, UBCInvMask, densityBC, densityBCInvMask);
   st.bc_class = bc_class_ptr(bc_class, flags);
@@ -446,54 +455,69 @@ int64_t step_workspace_bytes(int B, int D, int H, int W, bool is3D) {
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-  // reference entry points (fluids_init.cpp:1009-1014)
+  // Every compute entry point releases the GIL while it checks, allocates and enqueues: arguments are
+  // converted before the guard is taken and results after it is dropped; nothing inside touches Python objects.
+  using NoGil = py::call_guard<py::gil_scoped_release>;
+  const auto GEOM = py::arg("geom") = py::none();
+  py::class_<Geom>(m, "Geom", "per-call 3D geometry options: ref_quirks, z-slab view (z_offset, D_global), compute window [k_begin, k_end)")
+      .def(py::init([](bool ref_quirks, int z_offset, int D_global, int k_begin, int k_end) {
+             Geom g; g.ref_quirks = ref_quirks; g.z_offset = z_offset; g.D_global = D_global; g.k_begin = k_begin; g.k_end = k_end;
+             return g;
+           }),
+           py::arg("ref_quirks") = false, py::arg("z_offset") = 0, py::arg("D_global") = 0, py::arg("k_begin") = 0,
+           py::arg("k_end") = 0)
+      .def_readwrite("ref_quirks", &Geom::ref_quirks)
+      .def_readwrite("z_offset", &Geom::z_offset)
+      .def_readwrite("D_global", &Geom::D_global)
+      .def_readwrite("k_begin", &Geom::k_begin)
+      .def_readwrite("k_end", &Geom::k_end);
+  // reference entry points (fluids_init.cpp:1009-1014): same names, same positional arguments; `out` / `geom` are
+  // optional trailing extras
   m.def("advect_scalar", &advect_scalar, "Advect Scalar", py::arg("dt"), py::arg("src"), py::arg("U"), py::arg("flags"),
         py::arg("method"), py::arg("boundary_width"), py::arg("sample_outside_fluid"), py::arg("maccormack_strength"),
-        py::arg("out") = py::none());
+        py::arg("out") = py::none(), GEOM, NoGil());
   m.def("advect_step", &advect_step, py::arg("dt"), py::arg("density"), py::arg("U"), py::arg("flags"),
         py::arg("sample_outside_fluid"), py::arg("maccormack_strength"), py::arg("out_density") = py::none(),
-        py::arg("out_U") = py::none());
+        py::arg("out_U") = py::none(), GEOM, NoGil());
   m.def("advect_vel", &advect_vel, "Advect Velocity", py::arg("dt"), py::arg("orig"), py::arg("U"), py::arg("flags"),
-        py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none());
-  m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method");
+        py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none(), GEOM, NoGil());
+  m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method", py::arg("flags"),
+        py::arg("div"), py::arg("is3D"), py::arg("p_tol"), py::arg("max_iter"), py::arg("verbose"), GEOM, NoGil());
   // operators the reference implements in Python
-  m.def("velocity_divergence", &velocity_divergence);
-  m.def("velocity_update_", &velocity_update_);
-  m.def("add_buoyancy_", &add_buoyancy_);
-  m.def("add_gravity_", &add_gravity_);
-  m.def("add_viscosity_", &add_viscosity_);
-  m.def("set_wall_bcs_", &set_wall_bcs_);
-  m.def("set_wall_bcs_stick_", &set_wall_bcs_stick_);
-  m.def("set_const_vals_", &set_const_vals_);
-  m.def("flags_to_occupancy", &flags_to_occupancy);
-  m.def("empty_domain_", &empty_domain_);
-  m.def("scalenet_pack", &scalenet_pack);
-  m.def("multiscale_forward", &multiscale_forward);
-  m.def("fluidnet_forward", &fluidnet_forward);
+  m.def("velocity_divergence", &velocity_divergence, py::arg("U"), py::arg("flags"), GEOM, NoGil());
+  m.def("velocity_update_", &velocity_update_, py::arg("pressure"), py::arg("U"), py::arg("flags"), GEOM, NoGil());
+  m.def("add_buoyancy_", &add_buoyancy_, py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("gravity"),
+        py::arg("rho_star"), py::arg("dt"), GEOM, NoGil());
+  m.def("add_gravity_", &add_gravity_, py::arg("U"), py::arg("flags"), py::arg("gravity"), py::arg("dt"), GEOM, NoGil());
+  m.def("add_viscosity_", &add_viscosity_, NoGil());
+  m.def("set_wall_bcs_", &set_wall_bcs_, py::arg("U"), py::arg("flags"), GEOM, NoGil());
+  m.def("set_wall_bcs_stick_", &set_wall_bcs_stick_, NoGil());
+  m.def("set_const_vals_", &set_const_vals_, NoGil());
+  m.def("flags_to_occupancy", &flags_to_occupancy, NoGil());
+  m.def("empty_domain_", &empty_domain_, py::arg("flags"), py::arg("boundary_width"), GEOM, NoGil());
+  m.def("scalenet_pack", &scalenet_pack, NoGil());
+  m.def("multiscale_forward", &multiscale_forward, NoGil());
+  m.def("fluidnet_forward", &fluidnet_forward, NoGil());
   m.def("simulate_step_", &simulate_step_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),
         py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("net"), py::arg("dt"),
         py::arg("maccormack_strength"), py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"),
         py::arg("operating_density"), py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("method"),
-        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0);
+        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0, GEOM, NoGil());
   m.def("step_workspace_bytes", &step_workspace_bytes);
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
-        py::arg("workspace") = py::none(), py::arg("reuse_mask") = false);
+        py::arg("workspace") = py::none(), py::arg("reuse_mask") = false, GEOM, NoGil());
   m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
   m.def("jacobi_pass_", &jacobi_pass_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("nsweeps"),
-        py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1);
+        py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1, GEOM,
+        NoGil());
   m.def("pre_projection_", &pre_projection_, py::arg("U_adv"), py::arg("rho_adv"), py::arg("p"), py::arg("U"), py::arg("flags"),
         py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"),
         py::arg("dt"), py::arg("buoyancy_scale"), py::arg("gravity_vec"), py::arg("operating_density"),
-        py::arg("jacobi_method"), py::arg("bc_class") = py::none());
+        py::arg("jacobi_method"), py::arg("bc_class") = py::none(), GEOM, NoGil());
   m.def("post_projection_", &post_projection_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),
-        py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("bc_class") = py::none());
-  m.def("bc_classify", &bc_classify, "uint8 class map of static BC arrays (FnxState.bc_class)");
-  m.def("set_ref_quirks", [](bool on) { g_ref_quirks = on; }, "3D only: reproduce the reference's 3D defects bit-for-bit");
-  m.def("get_ref_quirks", []() { return g_ref_quirks; });
-  m.def("set_slab", [](int z_offset, int D_global) { g_z_offset = z_offset; g_D_global = D_global; },
-        "3D multi-GPU: subsequent calls treat their tensors as planes [z_offset, z_offset+D) of a D_global-deep domain (0,0 resets)");
-  m.def("set_window", [](int k_begin, int k_end) { g_k_begin = k_begin; g_k_end = k_end; },
-        "3D z-slab driver: subsequent plane-parallel operators only produce local planes [k_begin, k_end) (0,0 resets)");
+        py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("bc_class") = py::none(), GEOM,
+        NoGil());
+  m.def("bc_classify", &bc_classify, "uint8 class map of static BC arrays (FnxState.bc_class)", NoGil());
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
   m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });

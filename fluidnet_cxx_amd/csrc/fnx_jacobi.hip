@@ -240,14 +240,16 @@ __global__ __launch_bounds__(256) void jacobi3d_mask_kernel(GridDims g, const fl
   mask[o] = (unsigned char)m;
 }
 
-// first sweep from p = 0: ((((((0+0)+0)+0)+0)+0)+div)/6 == div/6 on 'cont' cells
-__global__ __launch_bounds__(256) void jacobi3d_first_kernel(size_t n, int B, size_t per, const float* __restrict__ div,
+// first sweep from p = 0: ((((((0+0)+0)+0)+0)+0)+div)/6 == div/6 on 'cont' cells.  Writes the planes [kb, ke) of every
+// sample only (`first` = kb*HW, `count` = (ke-kb)*HW cells per sample; `per` = cells per sample).
+__global__ __launch_bounds__(256) void jacobi3d_first_kernel(int B, size_t per, size_t first, size_t count,
+                                                             const float* __restrict__ div,
                                                              const unsigned char* __restrict__ mask,
                                                              float* __restrict__ p_out, float* __restrict__ sumsq) {
   for (int b = 0; b < B; ++b) {
     float local = 0.f;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < per; q += (size_t)gridDim.x * 256) {
-      const size_t o = (size_t)b * per + q;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) {
+      const size_t o = (size_t)b * per + first + q;
       float sum = 0.f + 0.f; sum = sum + 0.f; sum = sum + 0.f; sum = sum + 0.f; sum = sum + 0.f;
       const float v = (mask[o] & MZ_CONT) ? (sum + div[o]) / 6.f : 0.f;
       p_out[o] = v;
@@ -259,7 +261,6 @@ __global__ __launch_bounds__(256) void jacobi3d_first_kernel(size_t n, int B, si
       if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], local);
     }
   }
-  (void)n;
 }
 
 __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const unsigned char* __restrict__ mask,
@@ -820,9 +821,10 @@ void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* 
                      bool from_zero, float* sumsq, hipStream_t s, int kb, int ke) {
   if (ke <= kb) { kb = 0; ke = g.D; }
   if (from_zero) {
-    size_t nb = ((size_t)g.DHW + 256 * 4 - 1) / (256 * 4);
+    const size_t count = (size_t)(ke - kb) * g.HW;
+    size_t nb = (count + 256 * 4 - 1) / (256 * 4);
     if (nb > 4096) nb = 4096;
-    jacobi3d_first_kernel<<<(unsigned)nb, 256, 0, s>>>((size_t)g.B * g.DHW, g.B, (size_t)g.DHW, div, mask, p_out, sumsq);
+    jacobi3d_first_kernel<<<(unsigned)nb, 256, 0, s>>>(g.B, (size_t)g.DHW, (size_t)kb * g.HW, count, div, mask, p_out, sumsq);
     return;
   }
   const int nzc = (ke - kb + ZCHUNK - 1) / ZCHUNK;

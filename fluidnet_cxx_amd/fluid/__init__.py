@@ -12,12 +12,13 @@ from .._ext import ext as _ext
 # against the C ABI's FNX_TYPE_* constants in tests/test_abi.py.
 CellType = IntEnum("CellType", dict(TypeNone=0, TypeFluid=1, TypeObstacle=2, TypeEmpty=4, TypeInflow=8, TypeOutflow=16,
                                     TypeOpen=32, TypeStick=128, TypeReserved=256))
+Geom = _ext.Geom     # per-call 3D geometry options (ref_quirks, z-slab view, compute window); no reference counterpart
 from .ops import (advectScalar, advectVelocity, correctScalar, solveLinearSystemJacobi, velocityDivergence,
                   velocityUpdate, addBuoyancy, addGravity, addViscosity, setWallBcs, setWallBcsStick, flagsToOccupancy, setConstVals,
                   getDx)
 from .init_conditions import emptyDomain, createPlumeBCs, createRayleighTaylorBCs
 from .geometry_utils import createCylinder, createBox2D
 
-__all__ = ["CellType", "advectScalar", "advectVelocity", "correctScalar", "solveLinearSystemJacobi",
+__all__ = ["CellType", "Geom", "advectScalar", "advectVelocity", "correctScalar", "solveLinearSystemJacobi",
            "velocityDivergence", "velocityUpdate", "addBuoyancy", "addGravity", "addViscosity", "setWallBcs", "setWallBcsStick", "flagsToOccupancy", "setConstVals",
            "getDx", "emptyDomain", "createPlumeBCs", "createRayleighTaylorBCs", "createCylinder", "createBox2D"]

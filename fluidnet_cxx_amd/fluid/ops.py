@@ -2,6 +2,10 @@
 
 Each function cites the reference function it replaces; argument checks mirror the reference's asserts
 (AssertionError for shape errors raised on the Python side, RuntimeError from the native side).
+
+The 3D-capable operators take one extra keyword-only argument the reference does not have: `geom`, an
+`ext.Geom(ref_quirks=..., z_offset=..., D_global=..., k_begin=..., k_end=...)` (see `Geom` in `fluid/__init__.py`).
+It is per call -- the extension keeps no mutable state.
 """
 import torch
 
@@ -26,7 +30,7 @@ def getDx(self):
 
 
 def advectScalar(dt, src, U, flags, method="maccormackFluidNet", boundary_width=1, sample_outside_fluid=False,
-                 maccormack_strength=0.75):
+                 maccormack_strength=0.75, *, geom=None):
     """cpp/advection.py:14-66 -> pybind advect_scalar (cpp/fluids_init.cpp:265-382). 3D is supported here."""
     _check_advection_method(method)
     _check5(src, U, flags)
@@ -37,10 +41,11 @@ def advectScalar(dt, src, U, flags, method="maccormackFluidNet", boundary_width=
         assert U.size(1) == 2, "2D velocity field must have only 2 channels"
     assert U.size(0) == flags.size(0) and U.shape[2:] == flags.shape[2:], "Size mismatch"
     return ext.advect_scalar(float(dt), src, U, flags, method, int(boundary_width), bool(sample_outside_fluid),
-                             float(maccormack_strength))
+                             float(maccormack_strength), None, geom)
 
 
-def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_width=1, maccormack_strength=0.75):
+def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_width=1, maccormack_strength=0.75, *,
+                   geom=None):
     """cpp/advection.py:68-118 -> pybind advect_vel (cpp/fluids_init.cpp:656-807)."""
     _check_advection_method(method)
     _check5(orig, U, flags)
@@ -50,7 +55,7 @@ def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_wid
         assert flags.size(2) == 1, "2D velocity field but zdepth > 1"
         assert orig.size(1) == 2 and U.size(1) == 2, "2D velocity field must have only 2 channels"
     assert U.shape == orig.shape and U.size(0) == flags.size(0) and U.shape[2:] == flags.shape[2:], "Size mismatch"
-    return ext.advect_vel(float(dt), orig, U, flags, method, int(boundary_width), float(maccormack_strength))
+    return ext.advect_vel(float(dt), orig, U, flags, method, int(boundary_width), float(maccormack_strength), None, geom)
 
 
 def correctScalar(dt, src, div, flags):
@@ -59,48 +64,48 @@ def correctScalar(dt, src, div, flags):
     src.copy_(torch.where(maskFluid, src + dt * 0.5 * src * div, src))
 
 
-def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, verbose=False):
+def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, verbose=False, *, geom=None):
     """cpp/solve_linear_sys.py:4-40 -> pybind solve_linear_system (cpp/fluids_init.cpp:809-1004).
     Returns (p, residual) with residual a 0-dim tensor, like the reference."""
     _check5(div, flags)
     assert flags.size(1) == 1, "flags is not scalar"
     assert div.shape == flags.shape, "Size mismatch"
-    p, res = ext.solve_linear_system(flags, div, bool(is_3d), float(p_tol), int(max_iter), bool(verbose))
+    p, res = ext.solve_linear_system(flags, div, bool(is_3d), float(p_tol), int(max_iter), bool(verbose), geom)
     return p, res
 
 
-def velocityDivergence(U, flags):
+def velocityDivergence(U, flags, *, geom=None):
     """lib/fluid/velocity_divergence.py:4-74"""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
-    return ext.velocity_divergence(U, flags)
+    return ext.velocity_divergence(U, flags, geom)
 
 
-def velocityUpdate(pressure, U, flags):
+def velocityUpdate(pressure, U, flags, *, geom=None):
     """lib/fluid/velocity_update.py:6-162 -- in place on U, returns None."""
     _check5(pressure, U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
     assert pressure.shape == flags.shape, "size mismatch"
-    ext.velocity_update_(pressure, U, flags)
+    ext.velocity_update_(pressure, U, flags, geom)
 
 
-def addBuoyancy(U, flags, density, gravity, rho_star, dt):
+def addBuoyancy(U, flags, density, gravity, rho_star, dt, *, geom=None):
     """lib/fluid/source_terms.py:6-116 -- in place on U, returns U.  gravity: 3 floats (tensor or sequence)."""
     _check5(U, flags, density)
     assert flags.size(1) == 1, "flags is not scalar"
     g = gravity.detach().cpu().tolist() if torch.is_tensor(gravity) else [float(x) for x in gravity]
     assert len(g) == 3, "Gravity must be a 3D vector (even in 2D)"
-    ext.add_buoyancy_(U, flags, density, g, float(rho_star), float(dt))
+    ext.add_buoyancy_(U, flags, density, g, float(rho_star), float(dt), geom)
     return U
 
 
-def addGravity(U, flags, gravity, dt):
+def addGravity(U, flags, gravity, dt, *, geom=None):
     """lib/fluid/source_terms.py:122-219 -- in place on U, returns U."""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
     g = gravity.detach().cpu().tolist() if torch.is_tensor(gravity) else [float(x) for x in gravity]
     assert len(g) == 3, "Gravity must be a 3D vector (even in 2D)"
-    ext.add_gravity_(U, flags, g, float(dt))
+    ext.add_gravity_(U, flags, g, float(dt), geom)
     return U
 
 
@@ -112,11 +117,11 @@ def addViscosity(dt, U, flags, viscosity):
     ext.add_viscosity_(float(dt), U, flags, float(viscosity))
 
 
-def setWallBcs(U, flags):
+def setWallBcs(U, flags, *, geom=None):
     """lib/fluid/set_wall_bcs.py:4-86 -- in place on U, returns U."""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not a scalar"
-    ext.set_wall_bcs_(U, flags)
+    ext.set_wall_bcs_(U, flags, geom)
     return U
 
 

@@ -109,26 +109,36 @@ class NativeOps:
         self._mask_valid = False
         self.static_bcs = False  # set by the driver from the second step on when the caller promises static flags / BCs
         self._cls = None         # class map of the BC arrays (FnxState.bc_class), built once under that promise
+        # z-slab view and compute window of THIS operator set: turned into an ext.Geom that travels with every call
+        # (the extension itself keeps no state)
+        self._slab = (0, 0)
+        self._win = (0, 0)
 
     def begin_step(self):
         self._mask_valid = False
         self._cls = None         # (new flags / BC arrays: the class map of the BC stages goes too)
 
     def set_slab(self, z_offset, D_global):
-        self.ext.set_slab(int(z_offset), int(D_global))
+        self._slab = (int(z_offset), int(D_global))
 
     def set_window(self, k_begin, k_end):
-        self.ext.set_window(int(k_begin), int(k_end))
+        self._win = (int(k_begin), int(k_end))
+
+    def _geom(self, window=True):
+        """Geometry of the next call: the slab view, plus the compute window for the plane-parallel operators (the Jacobi
+        entry points take their own plane range and ignore it)."""
+        return self.ext.Geom(z_offset=self._slab[0], D_global=self._slab[1], k_begin=self._win[0] if window else 0,
+                             k_end=self._win[1] if window else 0)
 
     def advect_scalar(self, dt, rho, U, flags, strength, sample_outside, out=None):
-        return self.ext.advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, bool(sample_outside), strength, out)
+        return self.ext.advect_scalar(dt, rho, U, flags, "maccormackFluidNet", 1, bool(sample_outside), strength, out, self._geom())
 
     def advect_vel(self, dt, U, flags, strength, out=None):
-        return self.ext.advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, strength, out)
+        return self.ext.advect_vel(dt, U, U, flags, "maccormackFluidNet", 1, strength, out, self._geom())
 
     def advect_both(self, dt, rho, U, flags, strength, sample_outside, out_rho=None, out_U=None):
         """density and velocity advection of one step as the fused pair of launches (same bits as the two calls)"""
-        r, u = self.ext.advect_step(dt, rho, U, flags, bool(sample_outside), strength, out_rho, out_U)
+        r, u = self.ext.advect_step(dt, rho, U, flags, bool(sample_outside), strength, out_rho, out_U, self._geom())
         return r, u
 
     def _bc_class(self, st):
@@ -145,7 +155,7 @@ class NativeOps:
                                         st.get("UBCInvMask"), st.get("densityBC"), st.get("densityBCInvMask"),
                                         float(cfg["dt"]), float(cfg["buoyancyScale"]),
                                         [float(gv["x"]), float(gv["y"]), float(gv["z"])],
-                                        float(cfg.get("operatingDensity", 0.0)), True, self._bc_class(st))
+                                        float(cfg.get("operatingDensity", 0.0)), True, self._bc_class(st), self._geom())
 
     def jacobi_sweeps(self, flags, div, p, n):
         key = (tuple(flags.shape), flags.device)
@@ -153,7 +163,7 @@ class NativeOps:
             B, _, D, H, W = flags.shape
             self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
             self._ws_key, self._mask_valid = key, False
-        self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid)
+        self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid, self._geom(False))
         self._mask_valid = True      # same flags for the rest of this step (begin_step resets)
 
     two_ranges = True            # jacobi_pass takes a second plane range of the same length (one launch for both faces)
@@ -165,12 +175,12 @@ class NativeOps:
             self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
             self._ws_key, self._mask_valid = key, False
         self.ext.jacobi_pass_(flags, div, p_in, p_out, int(n), int(k_begin), int(k_end), self._ws, self._mask_valid,
-                              int(k_begin2))
+                              int(k_begin2), self._geom(False))
         self._mask_valid = True
 
     def post_projection(self, st):
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
-                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st))
+                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st), self._geom())
 
 
 class SlabSimulator:

@@ -12,10 +12,12 @@ def save_restart(path, batch_dict, it):
     torch.save({"batch_dict": cpu, "it": int(it)}, path)
 
 
-def load_restart(path, device):
+def load_restart(path, device, trusted=False):
     """Returns (batch_dict, it) with every tensor contiguous fp32 on `device`; accepts files written by the reference
-    (tensors pickled as CUDA tensors are mapped) and by save_restart."""
-    blob = torch.load(path, map_location="cpu", weights_only=False)
+    (tensors pickled as CUDA tensors are mapped) and by save_restart.  The payload is tensors plus an int, so the file
+    is read with `weights_only=True` (no arbitrary unpickling); `trusted=True` opts into the full unpickler for files
+    that carry other Python objects."""
+    blob = torch.load(path, map_location="cpu", weights_only=not trusted)
     assert isinstance(blob, dict) and "batch_dict" in blob and "it" in blob, "not a fluidnet restart file"
     bd = {}
     for k, v in blob["batch_dict"].items():

@@ -51,18 +51,27 @@ def test_extension_entry_points(built):
     for n in ("velocity_divergence", "velocity_update_", "add_buoyancy_", "set_wall_bcs_", "set_const_vals_",
               "flags_to_occupancy", "empty_domain_", "fluidnet_forward", "simulate_step_"):
         assert hasattr(ext, n)
+    # no mutable module state (the reference is re-entrant): quirk mode / slab view / window are per-call (ext.Geom)
+    for n in ("set_ref_quirks", "set_slab", "set_window"):
+        assert not hasattr(ext, n), n
+    g = ext.Geom(ref_quirks=True, z_offset=2, D_global=9, k_begin=1, k_end=3)
+    assert (g.ref_quirks, g.z_offset, g.D_global, g.k_begin, g.k_end) == (True, 2, 9, 1, 3)
 
 
 def test_python_surface_matches_reference(built):
     import inspect
     from fluidnet_cxx_amd import fluid
+    def positional(sig):          # the reference's parameters; `geom` is the one keyword-only extra (per-call 3D options)
+        extra = [n for n, p in sig.parameters.items() if p.kind is p.KEYWORD_ONLY]
+        assert extra in ([], ["geom"]), extra
+        return [n for n, p in sig.parameters.items() if p.kind is not p.KEYWORD_ONLY]
     sig = inspect.signature(fluid.advectScalar)
-    assert list(sig.parameters) == ["dt", "src", "U", "flags", "method", "boundary_width", "sample_outside_fluid", "maccormack_strength"]
+    assert positional(sig) == ["dt", "src", "U", "flags", "method", "boundary_width", "sample_outside_fluid", "maccormack_strength"]
     assert sig.parameters["maccormack_strength"].default == 0.75 and sig.parameters["method"].default == "maccormackFluidNet"
     sig = inspect.signature(fluid.advectVelocity)
-    assert list(sig.parameters) == ["dt", "orig", "U", "flags", "method", "boundary_width", "maccormack_strength"]
+    assert positional(sig) == ["dt", "orig", "U", "flags", "method", "boundary_width", "maccormack_strength"]
     sig = inspect.signature(fluid.solveLinearSystemJacobi)
-    assert list(sig.parameters) == ["flags", "div", "is_3d", "p_tol", "max_iter", "verbose"]
+    assert positional(sig) == ["flags", "div", "is_3d", "p_tol", "max_iter", "verbose"]
     assert sig.parameters["p_tol"].default == 1e-5 and sig.parameters["max_iter"].default == 1000
     assert int(fluid.CellType.TypeFluid) == 1 and int(fluid.CellType.TypeObstacle) == 2 and int(fluid.CellType.TypeEmpty) == 4
 
@@ -107,3 +116,41 @@ def test_restart_file_round_trip(tmp_path):
     torch.save({"batch_dict": {k: v.double() if k == "density" else v for k, v in st.items()}, "it": 3}, str(f))
     bd, it = load_restart(str(f), torch.device("cpu"))                # a foreign file: dtype normalised
     assert it == 3 and bd["density"].dtype == torch.float32 and bd["density"].is_contiguous()
+
+
+MCONF = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+             normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False, inputDim=2)
+
+
+def test_fluidnet_constructor_and_state_dict_like_reference(built):
+    """The reference drivers build the net as FluidNet(mconf, dropout=False), then .cuda(), .load_state_dict(state
+    ['state_dict']), .eval() (plume.py:119-123; model.py:45).  Host-side behaviour of that surface (no GPU needed: the
+    weights are only repacked on the first forward)."""
+    import inspect
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    sig = inspect.signature(FluidNet.__init__)
+    assert list(sig.parameters) == ["self", "mconf", "dropout"] and sig.parameters["dropout"].default is True
+    net = FluidNet(MCONF, dropout=False)
+    assert net.eval() is net and net.is3D is False
+    w = make_scalenet_weights(3)
+    # a reference checkpoint also carries the parameters of the layers its ScaleNet forward never reads
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    sd["conv1.weight"] = torch.zeros(16, 2, 3, 3); sd["conv1.bias"] = torch.zeros(16)
+    sd["convBank.encode.0.weight"] = torch.zeros(16, 16, 3, 3)
+    net.load_state_dict(sd)
+    out = net.state_dict()
+    assert set(out) == set(sd)
+    assert all(torch.equal(out[k], sd[k]) for k in sd)
+    bad = dict(sd); del bad["multiScale.final.bias"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        net.load_state_dict(bad)
+    bad = dict(sd); bad["somethingElse.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        net.load_state_dict(bad)
+    net.load_state_dict(bad, strict=False)
+    bad = dict(sd); bad["multiScale.final.weight"] = torch.zeros(2, 8, 1, 1)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        net.load_state_dict(bad)
+    with pytest.raises(AssertionError):
+        net.train()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import PLUME_CFG, assert_bitexact, assert_close, make_flags, plume_state, random_state
+from util import PLUME_CFG, assert_bitexact, assert_close, assert_close_rel, make_flags, plume_state, random_state
 
 pytestmark = pytest.mark.gpu
 
@@ -38,26 +38,26 @@ def N(t):
     return t.detach().cpu().numpy()
 
 
-def run_ops(fl, dev, flags, U, rho, p, dt, gravity, rho_star, is3d, orig=None, jac_iters=7):
+def run_ops(fl, dev, flags, U, rho, p, dt, gravity, rho_star, is3d, orig=None, jac_iters=7, geom=None):
     tf, tU, trho, tp = T(flags, dev), T(U, dev), T(rho, dev), T(p, dev)
     out = {}
     for meth in ("maccormackFluidNet", "eulerFluidNet"):
         for so in (0, 1):
-            out[f"advect_scalar_{meth}_{so}"] = N(fl.advectScalar(dt, trho, tU, tf, meth, 1, bool(so), 0.6))
-        out[f"advect_vel_{meth}"] = N(fl.advectVelocity(dt, tU, tU, tf, meth, 1, 0.6))
+            out[f"advect_scalar_{meth}_{so}"] = N(fl.advectScalar(dt, trho, tU, tf, meth, 1, bool(so), 0.6, geom=geom))
+        out[f"advect_vel_{meth}"] = N(fl.advectVelocity(dt, tU, tU, tf, meth, 1, 0.6, geom=geom))
     if orig is not None:
-        out["advect_vel_orig"] = N(fl.advectVelocity(dt, T(orig, dev), tU, tf, "maccormackFluidNet", 1, 0.75))
-    div = fl.velocityDivergence(tU, tf)
+        out["advect_vel_orig"] = N(fl.advectVelocity(dt, T(orig, dev), tU, tf, "maccormackFluidNet", 1, 0.75, geom=geom))
+    div = fl.velocityDivergence(tU, tf, geom=geom)
     out["divergence"] = N(div)
-    pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, jac_iters)
+    pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, jac_iters, geom=geom)
     out["jacobi_p"], out["jacobi_res"] = N(pj), float(res)
-    pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, 1)
+    pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, 0.0, 1, geom=geom)
     out["jacobi1_p"], out["jacobi1_res"] = N(pj), float(res)
-    Uu = tU.clone(); assert fl.velocityUpdate(tp, Uu, tf) is None; out["velocity_update"] = N(Uu)
-    Uw = tU.clone(); r = fl.setWallBcs(Uw, tf); assert r is Uw; out["set_wall_bcs"] = N(Uw)
-    Ub = tU.clone(); r = fl.addBuoyancy(Ub, tf, trho, gravity, rho_star, dt); assert r is Ub; out["add_buoyancy"] = N(Ub)
+    Uu = tU.clone(); assert fl.velocityUpdate(tp, Uu, tf, geom=geom) is None; out["velocity_update"] = N(Uu)
+    Uw = tU.clone(); r = fl.setWallBcs(Uw, tf, geom=geom); assert r is Uw; out["set_wall_bcs"] = N(Uw)
+    Ub = tU.clone(); r = fl.addBuoyancy(Ub, tf, trho, gravity, rho_star, dt, geom=geom); assert r is Ub; out["add_buoyancy"] = N(Ub)
     out["occupancy"] = N(fl.flagsToOccupancy(tf))
-    Ug = tU.clone(); r = fl.addGravity(Ug, tf, gravity, dt); assert r is Ug; out["add_gravity"] = N(Ug)
+    Ug = tU.clone(); r = fl.addGravity(Ug, tf, gravity, dt, geom=geom); assert r is Ug; out["add_gravity"] = N(Ug)
     if not is3d:
         Uv = tU.clone(); fl.addViscosity(dt, Uv, tf, 0.07); out["add_viscosity"] = N(Uv)
     # inputs untouched (reference: advect_* and solve_linear_system never write to inputs)
@@ -69,16 +69,13 @@ def run_ops(fl, dev, flags, U, rho, p, dt, gravity, rho_star, is3d, orig=None, j
 def test_ops_vs_reference_golden(fl, ext, dev, golden, case):
     z = golden(case)
     is3d = bool(z["is3d"])
-    ext.set_ref_quirks(is3d)          # 3D goldens are the reference's own (defective) 3D behaviour
-    try:
-        out = run_ops(fl, dev, z["flags"], z["U"], z["rho"], z["p"], float(z["dt"]), z["gravity"].tolist(), float(z["rho_star"]),
-                      is3d, z["orig"], int(z["jacobi_iters"]))
-        if "jacobi_tol" in z.files:
-            tf, div = T(z["flags"], dev), T(z["divergence"], dev)
-            pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, float(z["jacobi_tol"]), 50)
-            assert_bitexact(N(pj), z["jacobi_tol_p"], "jacobi p_tol early exit")
-    finally:
-        ext.set_ref_quirks(False)
+    geom = ext.Geom(ref_quirks=is3d)  # 3D goldens are the reference's own (defective) 3D behaviour
+    out = run_ops(fl, dev, z["flags"], z["U"], z["rho"], z["p"], float(z["dt"]), z["gravity"].tolist(), float(z["rho_star"]),
+                  is3d, z["orig"], int(z["jacobi_iters"]), geom=geom)
+    if "jacobi_tol" in z.files:
+        tf, div = T(z["flags"], dev), T(z["divergence"], dev)
+        pj, res = fl.solveLinearSystemJacobi(tf, div, is3d, float(z["jacobi_tol"]), 50, geom=geom)
+        assert_bitexact(N(pj), z["jacobi_tol_p"], "jacobi p_tol early exit")
     for k, v in out.items():
         if k.endswith("_res"):
             assert abs(v - float(z[k])) <= 1e-5 * max(1.0, float(z[k])), (k, v, float(z[k]))   # reduction order differs
@@ -104,11 +101,7 @@ def test_ops_vs_oracle(fl, ext, dev, oracle, shape, quirks):
     s = random_state(B, D, H, W, sigma, seed=B * 1000 + H, empties=empties)
     flags, U, rho, p = s["flags"], s["U"], s["rho"], s["p"]
     dt, grav, rstar = 0.17, [0.3, 0.25, -0.2], 0.05
-    ext.set_ref_quirks(quirks)
-    try:
-        out = run_ops(fl, dev, flags, U, rho, p, dt, grav, rstar, is3d, jac_iters=11)
-    finally:
-        ext.set_ref_quirks(False)
+    out = run_ops(fl, dev, flags, U, rho, p, dt, grav, rstar, is3d, jac_iters=11, geom=ext.Geom(ref_quirks=quirks))
     O = oracle
     for meth in ("maccormackFluidNet", "eulerFluidNet"):
         for so in (0, 1):
@@ -240,20 +233,64 @@ def test_jacobi_pass_two_ranges(dev, ext, shape):
         ext.jacobi_pass_(flags, div, p, torch.empty_like(p), 2, 3, 17, ws, True, 10)
 
 
+def test_jacobi_pass_from_zero_respects_plane_range(dev, ext, oracle):
+    """fnx_jacobi_pass with p_in = NULL ("p is 0 everywhere") and nsweeps 1 or 2 writes the planes [k_begin, k_end) only
+    (the header's contract; the single-sweep from-zero kernel used to write every plane, which clobbered planes in
+    flight in the slab driver's edge_first schedule with an odd sweep block)."""
+    B, D, H, W = 2, 20, 24, 70
+    rng = np.random.default_rng(9)
+    flags = make_flags(B, D, H, W, boxes=True)
+    div = rng.standard_normal((B, 1, D, H, W)).astype(np.float32)
+    tf, td = T(flags, dev), T(div, dev)
+    ws = torch.empty(ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=dev)
+    first = True
+    for n in (1, 2):
+        full = oracle.jacobi_sweeps(flags, div, np.zeros_like(div), True, n)
+        for (a, b, a2) in ((3, 9, -1), (0, 4, -1), (15, 20, -1), (2, 6, 12)):
+            out = torch.full((B, 1, D, H, W), 7.0, device=dev)
+            ext.jacobi_pass_(tf, td, None, out, n, a, b, ws, not first, a2); first = False
+            got = N(out)
+            want = np.full_like(got, 7.0)
+            want[:, :, a:b] = full[:, :, a:b]
+            if a2 >= 0:
+                want[:, :, a2:a2 + b - a] = full[:, :, a2:a2 + b - a]
+            assert_bitexact(got, want, f"from-zero pass n={n} planes [{a},{b}) + {a2}")
+
+
+def test_extension_is_stateless(fl, ext, dev, oracle):
+    """SURVEY 8b "no globals": quirk mode, slab view and compute window travel with the call (ext.Geom); a call with
+    them leaves nothing behind for the next call, and the module exports no setters."""
+    for name in ("set_ref_quirks", "set_slab", "set_window", "get_ref_quirks"):
+        assert not hasattr(ext, name), name
+    s = random_state(1, 10, 12, 20, 2.0, seed=5)
+    tf, tU, trho = T(s["flags"], dev), T(s["U"], dev), T(s["rho"], dev)
+    plain0 = N(fl.advectScalar(0.2, trho, tU, tf))
+    quirk = N(fl.advectScalar(0.2, trho, tU, tf, geom=ext.Geom(ref_quirks=True)))
+    win = torch.full_like(trho, 5.0)
+    ext.advect_scalar(0.2, trho, tU, tf, "maccormackFluidNet", 1, False, 0.75, win, ext.Geom(k_begin=3, k_end=6))
+    plain1 = N(fl.advectScalar(0.2, trho, tU, tf))
+    assert_bitexact(plain0, plain1, "a geom call changed a later plain call")
+    assert_bitexact(plain0, oracle.advect_scalar(0.2, s["rho"], s["U"], s["flags"], "maccormackFluidNet", 1, False, 0.75, False), "plain")
+    assert_bitexact(quirk, oracle.advect_scalar(0.2, s["rho"], s["U"], s["flags"], "maccormackFluidNet", 1, False, 0.75, True), "quirks")
+    w = N(win)
+    assert_bitexact(w[:, :, 3:6], plain0[:, :, 3:6], "window planes")
+    assert (w[:, :, :3] == 5.0).all() and (w[:, :, 6:] == 5.0).all(), "planes outside the window were written"
+
+
 # ---- CNN --------------------------------------------------------------------------------------------
 def test_cnn_vs_reference_golden(dev, golden):
-    """MultiScaleNet / FluidNet.forward vs torch-2.10-CPU golden vectors: |d| <= 2e-5 * max(1,|ref|max)
-    (fp32 conv with a different summation order; SURVEY.md noise floor)."""
+    """MultiScaleNet / FluidNet.forward vs torch-2.10-CPU golden vectors: |d| <= 1e-5 * |ref|max, relative to the
+    reference's own magnitude (fp32 convolutions with a different summation order)."""
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     c = golden("cnn")
     mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
                  normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False)
-    net = FluidNet(mconf, make_scalenet_weights(0), dev)
+    net = FluidNet.from_weights(mconf, make_scalenet_weights(0), dev)
     out = net.multiScale(T(c["x"], dev))
-    assert_close(N(out), c["multiscale"], 2e-5, "MultiScaleNet")
+    assert_close_rel(N(out), c["multiscale"], 1e-5, "MultiScaleNet")
     p, U = net(T(c["fluidnet_in"], dev))
-    assert_close(N(p), c["fluidnet_p"], 2e-5, "FluidNet p"); assert_close(N(U), c["fluidnet_U"], 2e-5, "FluidNet U")
+    assert_close_rel(N(p), c["fluidnet_p"], 1e-5, "FluidNet p"); assert_close_rel(N(U), c["fluidnet_U"], 1e-5, "FluidNet U")
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 36, 52), (2, 1, 64, 128), (1, 8, 12, 16), (1, 1, 44, 200), (1, 6, 20, 72)])
@@ -265,13 +302,13 @@ def test_cnn_vs_oracle(dev, oracle, shape):
     w = make_scalenet_weights(0, ndim=3 if is3d else 2)
     mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
                  normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d)
-    net = FluidNet(mconf, w, dev)
+    net = FluidNet.from_weights(mconf, w, dev)
     s = random_state(B, D, H, W, 0.5, seed=11)
     inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
     p, U = net(T(inp, dev))
     blob = oracle.pack_weights(w, 3 if is3d else 2)
     po, Uo = oracle.fluidnet_forward(blob, inp)
-    assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
+    assert_close_rel(N(p), po, 1e-5, "FluidNet p"); assert_close_rel(N(U), Uo, 1e-5, "FluidNet U")
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 16, 126, 130)])
@@ -286,16 +323,84 @@ def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
     w = make_scalenet_weights(0, ndim=nd)
     mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
                  normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d)
-    net = FluidNet(mconf, w, dev)
+    net = FluidNet.from_weights(mconf, w, dev)
     s = random_state(B, D, H, W, 0.5, seed=12)
     inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
     p, U = net(T(inp, dev))
     po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, nd), inp)
-    assert_close(N(p), po, 2e-5, "FluidNet p"); assert_close(N(U), Uo, 2e-5, "FluidNet U")
+    assert_close_rel(N(p), po, 1e-5, "FluidNet p"); assert_close_rel(N(U), Uo, 1e-5, "FluidNet U")
     if not is3d:
         # the MultiScaleNet alone, on inputs of O(1) magnitude
         x = np.random.default_rng(3).standard_normal((B, 2, 1, H, W)).astype(np.float32)
-        assert_close(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 2e-5, "MultiScaleNet")
+        assert_close_rel(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 1e-5, "MultiScaleNet")
+
+
+def test_fluidnet_built_like_the_reference_driver(dev, golden):
+    """plume.py:119-123 verbatim: FluidNet(mconf, dropout=False) -> .cuda() -> .load_state_dict(state['state_dict']) ->
+    forward; and a net moved / reloaded after its first forward repacks its weights."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    c = golden("cnn")
+    mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False, inputDim=2)
+    state = {"state_dict": {k: torch.from_numpy(v) for k, v in make_scalenet_weights(0).items()}}
+    net = FluidNet(mconf, dropout=False)
+    if torch.cuda.is_available():
+        net = net.cuda()
+    net.load_state_dict(state["state_dict"])
+    net.eval()
+    p, U = net(T(c["fluidnet_in"], dev))
+    assert_close_rel(N(p), c["fluidnet_p"], 1e-5, "FluidNet p"); assert_close_rel(N(U), c["fluidnet_U"], 1e-5, "FluidNet U")
+    assert all(v.is_cuda for v in net.state_dict().values())
+    other = {k: torch.from_numpy(v) for k, v in make_scalenet_weights(1).items()}
+    net.load_state_dict(other)
+    p2, _ = net(T(c["fluidnet_in"], dev))
+    assert not torch.equal(p, p2), "load_state_dict after a forward did not repack the weights"
+    net.load_state_dict(state["state_dict"])
+    p3, _ = net(T(c["fluidnet_in"], dev))
+    assert torch.equal(p, p3)
+
+
+def test_raw_c_abi_jacobi_through_ctypes(dev, oracle):
+    """The drop-in boundary without the torch shim: fnx_workspace_bytes + fnx_jacobi called through ctypes on raw device
+    pointers (tensor.data_ptr()) and the null stream, compared with the oracle bit for bit; plus the error convention
+    (status code + fnx_last_error)."""
+    import ctypes
+    from fluidnet_cxx_amd import build
+
+    class FnxGrid(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int) for n in ("B", "D", "H", "W", "is3D", "ref_quirks", "z_offset", "D_global", "k_begin", "k_end")]
+
+    lib = ctypes.CDLL(build.LIB)
+    lib.fnx_workspace_bytes.restype = ctypes.c_size_t
+    lib.fnx_workspace_bytes.argtypes = [ctypes.POINTER(FnxGrid), ctypes.c_int]
+    lib.fnx_last_error.restype = ctypes.c_char_p
+    lib.fnx_jacobi.restype = ctypes.c_int
+    lib.fnx_jacobi.argtypes = [ctypes.POINTER(FnxGrid)] + [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_int,
+                               ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    for (B, D, H, W) in ((2, 1, 50, 77), (1, 9, 20, 66)):
+        is3d = D > 1
+        s = random_state(B, D, H, W, 2.0, seed=21)
+        div = oracle.velocity_divergence(s["U"], s["flags"])
+        g = FnxGrid(B, D, H, W, int(is3d), 0, 0, 0, 0, 0)
+        nbytes = lib.fnx_workspace_bytes(ctypes.byref(g), 2)         # FNX_OP_JACOBI
+        assert nbytes > 0
+        tf, td = T(s["flags"], dev), T(div, dev)
+        p = torch.empty_like(tf); res = torch.zeros(1, device=dev); ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        iters = ctypes.c_int(0)
+        torch.cuda.synchronize()
+        rc = lib.fnx_jacobi(ctypes.byref(g), tf.data_ptr(), td.data_ptr(), p.data_ptr(), res.data_ptr(), 0.0, 13,
+                            ctypes.byref(iters), ws.data_ptr(), nbytes, None)
+        assert rc == 0, lib.fnx_last_error()
+        torch.cuda.synchronize()
+        po, ro, _ = oracle.jacobi(s["flags"], div, is3d, 0.0, 13)
+        assert iters.value == 13
+        assert_bitexact(N(p), po, f"raw C-ABI fnx_jacobi {(B, D, H, W)}")
+        assert abs(float(res) - ro) <= 1e-5 * max(1.0, ro)
+        rc = lib.fnx_jacobi(ctypes.byref(g), tf.data_ptr(), td.data_ptr(), p.data_ptr(), None, 0.0, 0, None, ws.data_ptr(), nbytes, None)
+        assert rc == 1 and b"At least 1 iteration" in lib.fnx_last_error()          # FNX_EINVAL
+        rc = lib.fnx_jacobi(ctypes.byref(g), tf.data_ptr(), td.data_ptr(), p.data_ptr(), None, 0.0, 3, None, ws.data_ptr(), 16, None)
+        assert rc == 3 and b"workspace too small" in lib.fnx_last_error()           # FNX_EWORKSPACE
 
 
 def test_sim64_convnet_vs_reference(dev, golden):
@@ -304,14 +409,14 @@ def test_sim64_convnet_vs_reference(dev, golden):
     s = golden("sim64")
     mconf = dict(PLUME_CFG, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
                  normalizeInputChan="UDiv", is3D=False)
-    net = FluidNet(mconf, make_scalenet_weights(0), dev)
+    net = FluidNet.from_weights(mconf, make_scalenet_weights(0), dev)
     for fused in (True, False):
         bd = to_dev(plume_state(64), dev)
         for it in range(1, 11):
             simulate(mconf, bd, net, "convnet", fused=fused)
             if it in (1, 3, 10):
                 for k in ("U", "density", "p"):
-                    assert_close(N(bd[k]), s[f"convnet_{k}_{it}"], 2e-5, f"convnet {k} after {it} (fused={fused})")
+                    assert_close_rel(N(bd[k]), s[f"convnet_{k}_{it}"], 1e-5, f"convnet {k} after {it} (fused={fused})")
 
 
 def test_static_flags_reuses_mask_3d(dev, oracle, ext):
@@ -362,7 +467,7 @@ def test_bc_class_map_same_bits(dev, ext, shape, method):
                densityBC=RV, densityBCInvMask=RM)
     cfg = dict(PLUME_CFG, jacobiIter=5, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False),
                normalizeInput=True, normalizeInputChan="UDiv", is3D=is3d)
-    net = FluidNet(cfg, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if method == "convnet" else None
+    net = FluidNet.from_weights(cfg, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if method == "convnet" else None
     runs = []
     for static in (False, True):
         bd = to_dev(st0, dev)
@@ -461,14 +566,14 @@ def test_sim64_stick_convnet_vs_reference(dev, golden):
     z = golden("stick")
     mconf = dict(PLUME_CFG, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
                  normalizeInputChan="UDiv", is3D=False)
-    net = FluidNet(mconf, make_scalenet_weights(0), dev)
+    net = FluidNet.from_weights(mconf, make_scalenet_weights(0), dev)
     st = plume_state(64)
     st["flags"] = z["sim_flags"]; st["flags_stick"] = z["sim_flags_stick"]
     bd = to_dev(st, dev)
     for it in range(1, 4):
         simulate(mconf, bd, net, "convnet")
         for k in ("U", "density", "p"):
-            assert_close(N(bd[k]), z[f"sim_{k}_{it}"], 2e-5, f"stick convnet {k} after {it}")
+            assert_close_rel(N(bd[k]), z[f"sim_{k}_{it}"], 1e-5, f"stick convnet {k} after {it}")
 
 
 # ---- properties at benchmark sizes ----------------------------------------------------------------------

@@ -58,13 +58,19 @@ def plume_state(res, D=1):
 
 
 def assert_bitexact(a, b, what=""):
+    """Same BITS: fp32 arrays are compared through their int32 views, so +0 / -0 differ and equal NaNs compare equal."""
     a = np.asarray(a); b = np.asarray(b)
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    bad = a != b
+    if a.dtype == np.float32 and b.dtype == np.float32:
+        bad = np.ascontiguousarray(a).view(np.int32) != np.ascontiguousarray(b).view(np.int32)
+    else:
+        bad = a != b
     if bad.any():
         idx = np.argwhere(bad)[:5]
-        raise AssertionError(f"{what}: {int(bad.sum())}/{a.size} cells differ, max |d| = "
-                             f"{np.abs(a.astype(np.float64) - b).max():.3e}, first at {idx.tolist()}")
+        with np.errstate(invalid="ignore"):
+            d = np.abs(a.astype(np.float64) - b)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{a.size} cells differ in bits, max |d| = "
+                             f"{np.nanmax(d):.3e}, first at {idx.tolist()}")
 
 
 def assert_close(a, b, rtol, what=""):
@@ -74,3 +80,13 @@ def assert_close(a, b, rtol, what=""):
     scale = max(1.0, float(np.abs(b).max()))
     d = np.abs(a - b).max()
     assert d <= rtol * scale, f"{what}: max |d| = {d:.3e} > {rtol:.1e} * {scale:.3e}"
+
+
+def assert_close_rel(a, b, rtol, what=""):
+    """|a-b| <= rtol * |b|max everywhere: relative to the reference's own magnitude, no floor at 1 (CNN outputs are
+    O(0.1) on random weights, where the max(1, .) form would be 10x looser than it reads)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = float(np.abs(b).max())
+    d = np.abs(a - b).max()
+    assert d <= rtol * scale, f"{what}: max |d| = {d:.3e} > {rtol:.1e} * |ref|max {scale:.3e} (relative {d / max(scale, 1e-300):.2e})"

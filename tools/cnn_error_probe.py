@@ -6,7 +6,7 @@ from fluidnet_cxx_amd.weights import make_scalenet_weights
 dev=torch.device('cuda:0')
 w=make_scalenet_weights(0)
 mconf=dict(model="ScaleNet", inputChannels=dict(div=True,pDiv=False,UDiv=False), normalizeInput=True, normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False)
-net=FluidNet(mconf,w,dev)
+net=FluidNet.from_weights(mconf,w,dev)
 x=np.random.default_rng(3).standard_normal((1,2,1,515,509)).astype(np.float32)
 out=net.multiScale(torch.from_numpy(x).to(dev)).cpu().numpy()
 ref=O.multiscale_forward(O.pack_weights(w,2),x)
