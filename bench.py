@@ -1,30 +1,47 @@
 #!/usr/bin/env python3
-"""Benchmark of the fluid time step (BASELINE.json metric: steps/s + Mcells/s).
+"""Benchmark of the fluid time step (BASELINE.json metric: steps/s + Mcells/s, 2D 1024^2 CNN plume & 3D Jacobi, 1-8 GPUs).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-graph] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-graph] [--no-cpu-baseline] [--no-also]
 
 A "step" is one pass of `simulate` over one synthetic plume state that is already resident in HBM.
 
-Default workload.  BASELINE.json's metric is quoted on two configurations ("2D 1024^2 CNN plume & 3D ... Jacobi, 1-8
-GPUs").  The 1->8 GPU series only means something if every N runs the SAME workload, and only the 3D Jacobi step
-shards (the CNN configs are single-GPU in BASELINE.json), so the default for every N is `plume3d_slab_jacobi`:
-512 x 512 x 64 cells per GPU, Jacobi-100 -- one z-slab of configs[4]; at N=8 it is exactly configs[4] (512^3).
-At N=1 the same JSON line carries configs[1] (2D 1024^2 CNN plume) under "also", measured in the same run.
+Launch.  With WORLD_SIZE in the environment (the driver's `python -m torch.distributed.run ... bench.py --gpus N`) this
+process is one rank.  Without it, `--gpus N` (N > 1) re-executes itself under `torch.distributed.run` with N ranks on
+127.0.0.1; `--gpus` that disagrees with WORLD_SIZE, or fewer visible devices than ranks, is an error.  `--dry-run`
+replaces the GPU work by a gloo rendezvous + all-reduce (proves the launcher on a box without GPUs).
 
-Workloads (BASELINE.json configs):
-  plume3d_slab_jacobi  configs[4]: 3D plume 512x512x(64 per GPU), Jacobi-100, z-slabs + P2P ghost exchange  [default]
-  plume2d_1024_cnn     configs[1]: 2D plume 1024^2, CNN pressure (ScaleNet, hash-seeded random-init weights)  [also, N=1]
-  plume2d_1024_jacobi  2D plume 1024^2, Jacobi-28 (the north star's "advection+Jacobi step at 1024^2")
+Headline workload (every N): `plume3d_slab_jacobi` -- 512 x 512 x 64 cells per GPU, Jacobi-100, one z-slab of
+configs[4] per rank (at N = 8 exactly configs[4], 512^3); the 1 -> 8 series is the SAME per-GPU work (weak scaling).
+At N = 1 the same JSON line carries, under "also", the other configurations the metric and the north star name:
+  plume3d_256_jacobi   3D plume 256^3, Jacobi-100               (the metric's "3D 256^3 Jacobi")
+  plume2d_1024_cnn     configs[1]: 2D plume 1024^2, CNN pressure (the metric's "2D 1024^2 CNN plume")
+  plume2d_1024_jacobi  2D plume 1024^2, Jacobi-28               (north star: >= 60 % HBM roofline on advection+Jacobi at 1024^2)
   rt2d_2048_jacobi     configs[2]: 2D Rayleigh-Taylor 2048^2, Jacobi-100
-  plume2d_128_jacobi   configs[0]: 2D plume 128^2, Jacobi-28
-  plume3d_256_jacobi   3D plume 256^3, Jacobi-100
-  plume3d_256_cnn      configs[3]: 3D plume 256^3, CNN pressure (Conv3d analogue of ScaleNet, MFMA implicit GEMM)
+  plume3d_256_cnn      configs[3]: 3D plume 256^3, CNN pressure (Conv3d analogue of ScaleNet on the MFMA)
+  plume3d_hbm_jacobi   3D plume 512 x 512 x 256, Jacobi-100: the solver's working set (1.3 GiB) exceeds the 256 MiB
+                       Infinity Cache, so its roofline numbers are against HBM proper
+Other names for --workload: plume2d_128_jacobi (configs[0]), plume3d_128_cnn.
+
+State.  Every workload is first advanced by >= 100 untimed steps (`config.developed_steps`) so that a plume exists
+(advection cost is data dependent: zero-velocity cells leave the line trace at once); the CNN workloads are developed with
+the Jacobi projection (a physical plume) and then timed with the CNN.  W more untimed warm-up steps follow the HIP-graph
+capture, then EXACTLY K timed steps between barrier + synchronize pairs, max over ranks.
+
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+  roofline.frac          SURVEY 8d model: algorithmic bytes (16 B/cell/sweep) / launch time / 8 TB/s.  The solvers run
+                         several sweeps per pass over HBM, so this can exceed 1; it is the contract's figure, not a
+                         utilisation.
+  roofline.frac_traffic  measured HBM-side bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json) / launch time / peak:
+                         the utilisation figure for the stencil kernels
+  roofline.mfma_util     (conv) multiply-add FLOPs actually issued to the matrix cores / time / 157.3 TF -- a Winograd
+                         launch issues 16/36 of the direct convolution's FLOPs, so `frac` (direct-equivalent) overstates it
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,15 +50,19 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "tests"))
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; 6.3 TB/s is what a plain copy reaches)
 MFMA_F32_PEAK_TF = 157.3     # exact-f32 MFMA peak (v_mfma_f32_32x32x2_f32)
+DEVELOP_STEPS = 100          # "warm-up 100 steps so a plume exists"
 
 # algorithmic bytes per cell, 2D / 3D
 STEP_BYTES = {False: lambda n: 340 + 16 * n, True: lambda n: 452 + 16 * n}
-CNN_FLOP_PER_CELL = {False: 484476, True: 1338929}
 PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4, conv_mfma16=5)
+
+# plumeConfig.yaml:29-76 with BASELINE.json's overrides (jacobiIter per workload, pTol 0)
+PLUME_CFG = dict(dt=0.1, maccormackStrength=0.6, sampleOutsideFluid=False, buoyancyScale=0.25, gravityScale=0,
+                 viscosity=0, correctScalar=False, gravityVec=dict(x=0.0, y=-1.0, z=0.0), operatingDensity=0.0,
+                 pTol=0.0, jacobiIter=28, normalizeInputThreshold=1e-5)
 
 WORKLOADS = {
     "plume2d_1024_cnn": dict(res=1024, D=1, method="convnet", iters=0, kind="plume"),
@@ -49,14 +70,18 @@ WORKLOADS = {
     "rt2d_2048_jacobi": dict(res=2048, D=1, method="jacobi", iters=100, kind="rt"),
     "plume2d_128_jacobi": dict(res=128, D=1, method="jacobi", iters=28, kind="plume"),
     "plume3d_256_jacobi": dict(res=256, D=256, method="jacobi", iters=100, kind="plume"),
+    "plume3d_hbm_jacobi": dict(res=512, D=256, method="jacobi", iters=100, kind="plume"),
     "plume3d_256_cnn": dict(res=256, D=256, method="convnet", iters=0, kind="plume"),      # configs[3]
     "plume3d_128_cnn": dict(res=128, D=128, method="convnet", iters=0, kind="plume"),
     "plume3d_slab_jacobi": dict(res=512, D=64, method="jacobi", iters=100, kind="plume", slab=True),
 }
+ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_cnn",
+        "plume3d_hbm_jacobi"]
 
 
 def mfma_flops_per_cell(is3d):
-    """FLOPs of the layers that run on the matrix cores (3x3 convs with 32/64/128 channels), per full-res cell."""
+    """Direct-convolution FLOPs of the layers that run on the matrix cores (3x3 convs with 32/64/128 channels), per
+    full-resolution cell."""
     taps = 27 if is3d else 9
     t1 = 2 * taps * (32 * 64 + 64 * 128 + 128 * 64 + 64 * 32)
     t4 = 2 * taps * (32 * 64 + 64 * 32)
@@ -66,7 +91,7 @@ def mfma_flops_per_cell(is3d):
 
 def plume_state_torch(res, D_local, dev, z_offset=0, D_global=None):
     """Plume initial state + BC masks (reference plume.py:131-163 / createPlumeBCs; 3D: inlet disc) for the planes
-    [z_offset, z_offset + D_local) of a D_global-deep domain, built on the device."""
+    [z_offset, z_offset + D_local) of a D_global-deep domain, built on `dev`."""
     import torch
     is3d = (D_global or D_local) > 1
     Dg = D_global or D_local
@@ -109,7 +134,6 @@ def build_state(w, dev):
 
 
 def mconf_for(w):
-    from util import PLUME_CFG
     m = dict(PLUME_CFG)
     if w["kind"] == "rt":
         m.update(dt=0.5, buoyancyScale=1.0, gravityVec=dict(x=0.0, y=1.0, z=0.0))
@@ -121,9 +145,10 @@ def mconf_for(w):
 
 def cpu_baseline(w, budget_s=12.0):
     """The oracle ("port": plain-C restatement of the reference, OpenMP) timed on this box's host cores on a bounded
-    sample of the same workload: the same step on a smaller grid of the same configuration, scaled per cell."""
+    sample of the same workload: the same step on a smaller grid of the same configuration, scaled per cell.  The only
+    place bench.py touches oracle/ -- as the thing compared WITH, outside every timed GPU region."""
+    import torch
     from oracle import oracle as O
-    from util import plume_state
     O.build()
     threads = min(os.cpu_count() or 1, 64)
     os.environ["OMP_NUM_THREADS"] = str(threads)
@@ -136,7 +161,7 @@ def cpu_baseline(w, budget_s=12.0):
         res, D = 128, 1
     else:
         res, D = (min(w["res"], 512), 1) if not is3d else (128, 64)
-    st = plume_state(res, D)
+    st = {k: v.numpy() for k, v in plume_state_torch(res, D, torch.device("cpu")).items()}
     st = O.simulate_step(st, m, w["method"], blob)      # warm-up
     t0 = time.time(); n = 0
     while True:
@@ -150,8 +175,8 @@ def cpu_baseline(w, budget_s=12.0):
 
 
 def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edge_first"):
-    """Warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then profile the dominant
-    kernel class with HIP events.  Returns the JSON-able result dict (without cpu_baseline)."""
+    """Develop the state, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then profile
+    the dominant kernel class with HIP events.  Returns the JSON-able result dict (without cpu_baseline)."""
     import torch
     import torch.distributed as dist
     from fluidnet_cxx_amd import FluidNet, simulate
@@ -163,6 +188,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
     m = mconf_for(w)
     graph_used = False
     layout = None
+    develop = max(DEVELOP_STEPS, warmup)
     if slab:
         # weak scaling: every GPU owns 64 planes of a 512 x 512 x (64*world) plume
         from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
@@ -172,30 +198,40 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         sim = SlabSimulator(layout, m, sweeps_per_exchange=6, schedule=schedule, static_flags=True)
         net = None
 
-        def eager_step():
+        def eager_step(method=None):
             sim.step(bd)
         cells = w["res"] * w["res"] * layout.owned
+        static_desc = "flags + BC arrays promised static from step 2 on (solver obstacle mask and BC class map reused)"
     else:
         bd = build_state(w, dev)
         net = FluidNet.from_weights(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
         ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
+        seen = []
 
-        seen = []                          # flags never change here: after the first step the solver keeps its mask
-
-        def eager_step():
-            # flags and BC arrays never change here: 0 for the first step, then 3 (solver keeps its mask, the BC stages build
-            # their class map), then 7 (and reuse it)
-            simulate(m, bd, net, w["method"], workspace=ws, static_flags=(0, 3, 7)[min(len(seen), 2)])
+        def eager_step(method=None):
+            # flags and BC arrays never change here: static_flags 0 for the first step, then 3 (solver keeps its mask, the
+            # BC stages build their class map), then 7 (and reuse it)
+            meth = method or w["method"]
+            simulate(m, bd, net if meth == "convnet" else None, meth, workspace=ws, static_flags=(0, 3, 7)[min(len(seen), 2)])
             seen.append(1)
         cells = w["res"] * w["res"] * w["D"]
+        static_desc = "static_flags 0, 3, then 7: flags + BC arrays promised static (solver obstacle mask and BC class map reused)"
     step = eager_step
 
-    for _ in range(warmup):
-        step()
+    # ---- develop the state (untimed): a physical plume via the Jacobi projection, whatever method is timed afterwards
+    timed_iters = m["jacobiIter"]
+    if w["method"] == "convnet":
+        m["jacobiIter"] = 28 if not is3d else 40
+    for _ in range(develop):
+        eager_step(None if slab else "jacobi")
+    m["jacobiIter"] = timed_iters
     torch.cuda.synchronize()
+    umax = float(bd["U"].abs().max()) * float(m["dt"])
     if not slab and use_graph:
         # the step is a fixed launch sequence on fixed buffers: capture it once, replay it per step
         try:
+            eager_step()                       # (first step of the timed method outside the capture: lazy packing etc.)
+            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 eager_step()
@@ -205,6 +241,8 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f"bench: graph capture failed ({e}); running eagerly\n")
             step = eager_step
+    for _ in range(warmup):
+        step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,6 +262,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         elapsed = float(t.item())
     ms = elapsed / steps * 1e3
     mcells = cells * world * steps / elapsed / 1e6
+    finite = bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all())
 
     # ---- dominant kernel: HIP events around every launch of its class, on the launch stream, over more steps of the
     # same workload (eager launches: events cannot be recorded inside a captured graph) ----
@@ -233,6 +272,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         eager_step()
     torch.cuda.synchronize()
     times = {k: ext.profile_read(v) for k, v in PROF.items()}
+    issued = {k: ext.profile_read_work(v) for k, v in PROF.items()}
     ext.profile_enable(False)
     traffic = None           # HBM bytes per launch of the roofline kernel (PMC FETCH_SIZE/WRITE_SIZE passes, profiles/)
     traffic_detail = None
@@ -244,24 +284,31 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         tms, nl = times["conv_mfma"]
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
         ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
+        util = issued["conv_mfma"] / (tms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if tms > 0 else 0.0
         kname = ("conv3_wino2_kernel (3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
-                 "instead of 36, v_mfma_f32_32x32x2_f32); achieved = DIRECT-convolution FLOPs / time, so it can exceed "
-                 "the MFMA peak")
+                 "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
+                 "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
+        avg_ms = tms / max(nl, 1)
         roof = dict(bound="mfma", kernel=kname, achieved=ach,
-                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=traffic,
+                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, mfma_util=util,
+                    issued_tflop_per_step=issued["conv_mfma"] / prof_steps / 1e12, traffic=traffic,
+                    frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                     traffic_detail=traffic_detail,
-                    launches_per_step=nl / prof_steps, avg_launch_ms=tms / max(nl, 1),
+                    launches_per_step=nl / prof_steps, avg_launch_ms=avg_ms,
                     algorithmic=f"{mfma_flops_per_cell(is3d):.0f} direct-convolution FLOP/cell in the MFMA conv launches x {cells} cells per step")
     else:
         tms, nl = times["jacobi"]
         byts = 16.0 * w["iters"] * cells * prof_steps
         ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-        kname = ("jacobi3d_march2_kernel (z-marching, 2 sweeps per pass)" if is3d
-                 else "jacobi2d_reg_kernel (register/DPP temporal blocking)")
+        kname = ("jacobi3d_march_kernel (z-marching, several sweeps per pass)" if is3d
+                 else "jacobi2d kernels (register/DPP temporal blocking)")
+        avg_ms = tms / max(nl, 1)
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=traffic, traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
-                    avg_launch_ms=tms / max(nl, 1),
+                    traffic=traffic,
+                    frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
+                    traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
+                    avg_launch_ms=avg_ms,
                     algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} owned cells per step")
     if w["method"] == "jacobi":
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
@@ -277,10 +324,48 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
                                          f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 6 sweeps per exchange, "
                                          f"schedule {schedule}"),
                             launch="hip-graph replay" if graph_used else "eager",
+                            developed_steps=develop,
+                            developed_with=("jacobi projection (physical plume), then timed with the CNN" if w["method"] == "convnet"
+                                            else "the timed step itself"),
+                            max_cfl_after_development=umax,
+                            static_flags=static_desc,
+                            state_finite_after_timing=finite,
                             weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
                 step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 kernel_ms_per_step={k: v[0] / prof_steps for k, v in times.items() if v[1] > 0},
                 roofline=roof)
+
+
+def self_spawn(a):
+    """`--gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"bench: --gpus {a.gpus} without WORLD_SIZE: launching {a.gpus} ranks under torch.distributed.run\n")
+    return subprocess.call(cmd)
+
+
+def dry_run(a, rank, world):
+    """Launcher check without GPUs: gloo rendezvous, an all-reduce over the ranks, one JSON line from rank 0."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    got = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        got = int(t.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=None,
+                              unit="Mcells/s", n_gpus=a.gpus, steps=a.steps, warmup=a.warmup, dry_run=True,
+                              world_size=dist.get_world_size() if world > 1 else 1, ranks_counted=got, backend="gloo",
+                              config=dict(workload=a.workload or "plume3d_slab_jacobi"))))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -293,25 +378,51 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", default="edge_first", choices=["edge_first", "last_pass"],
                     help="N > 1: how the slab driver orders a sweep block around its ghost exchange (slab.py)")
-    ap.add_argument("--no-also", action="store_true", help="skip the configs[1] line reported under 'also' at N=1")
+    ap.add_argument("--no-also", action="store_true", help="skip the other configurations reported under 'also' at N=1")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous, no GPU work")
     a = ap.parse_args()
+    assert a.gpus >= 1
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_spawn(a))
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        sys.exit(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a "
+                 f"launcher, which self-spawns)")
+    if a.dry_run:
+        return dry_run(a, rank, world)
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    ndev = torch.cuda.device_count()
+    if ndev < world or not torch.cuda.is_available():
+        sys.exit(f"bench: {world} rank(s) requested but {ndev} HIP device(s) visible -- the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))   # fail, do not hang
+        assert dist.get_world_size() == a.gpus
     name = a.workload or "plume3d_slab_jacobi"
+    if world > 1 and not WORKLOADS[name].get("slab"):
+        sys.exit(f"bench: workload {name} does not shard (single-GPU configuration); N > 1 runs plume3d_slab_jacobi")
     out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev, a.schedule)
+    out["config"]["world_size"] = dist.get_world_size() if world > 1 else 1
+    out["config"]["backend"] = "nccl (RCCL)" if world > 1 else None
     if world == 1 and a.workload is None and not a.no_also:
-        # configs[1], the other configuration the metric is quoted on (single-GPU by definition)
-        also = run_workload("plume2d_1024_cnn", min(a.steps, 20), min(a.warmup, 5), not a.no_graph, 1, 0, dev)
-        out["also"] = {k: also[k] for k in ("value", "unit", "steps_per_s", "ms_per_step", "config", "roofline", "kernel_ms_per_step")}
+        # the other configurations the metric / north star name (single-GPU by definition), measured in the same run
+        out["also"] = {}
+        for other in ALSO:
+            big = other in ("plume3d_256_cnn", "plume3d_hbm_jacobi")
+            try:
+                r = run_workload(other, min(a.steps, 5 if big else 20), min(a.warmup, 2 if big else 5), not a.no_graph, 1, 0, dev)
+                out["also"][other] = {k: r[k] for k in ("value", "unit", "steps_per_s", "ms_per_step", "step_hbm_frac", "steps",
+                                                        "config", "roofline", "kernel_ms_per_step")}
+            except Exception as e:  # noqa: BLE001  (an "also" line must not take the headline down)
+                out["also"][other] = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:       # the host baseline is reported with the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(WORKLOADS[name])

@@ -94,6 +94,7 @@ struct Prof {
   int tag[PROF_MAX];
   int created = 0;
   int open_idx[FNX_PROF_NTAGS];
+  double work[FNX_PROF_NTAGS];     // what the recorded launches of a class issued (MFMA FLOPs for the conv classes)
 } g_prof;
 }  // namespace
 
@@ -109,6 +110,10 @@ void prof_begin(int tag, hipStream_t s) {
   hipEventRecord(g_prof.ev[i][0], s);
 }
 
+void prof_add_work(int tag, double amount) {
+  if (g_prof.on && g_prof.open_idx[tag] >= 0) g_prof.work[tag] += amount;
+}
+
 void prof_end(int tag, hipStream_t s) {
   if (!g_prof.on) return;
   const int i = g_prof.open_idx[tag];
@@ -120,7 +125,13 @@ extern "C" {
 
 int fnx_profile_enable(int on) {
   fnx::g_prof.on = on != 0;
-  if (on) { fnx::g_prof.n = 0; for (int t = 0; t < FNX_PROF_NTAGS; ++t) fnx::g_prof.open_idx[t] = -1; }
+  if (on) { fnx::g_prof.n = 0; for (int t = 0; t < FNX_PROF_NTAGS; ++t) { fnx::g_prof.open_idx[t] = -1; fnx::g_prof.work[t] = 0.0; } }
+  return FNX_OK;
+}
+
+int fnx_profile_read_work(int tag, double* work) {
+  if (tag < 0 || tag >= FNX_PROF_NTAGS || !work) return fail(FNX_EINVAL, "profile_read_work: bad tag");
+  *work = fnx::g_prof.work[tag];
   return FNX_OK;
 }
 

@@ -1015,11 +1015,20 @@ void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const Packe
   // most; beyond that -- 137 GB per 128-channel activation -- the direct kernel below still works)
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
-    if (wino_layer(L, is3d) && launch_conv_wino(a, is3d, packed + pl.w_off + layer_weight_floats(L, is3d), s)) return;
+    const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
+    if (wino_layer(L, is3d) && launch_conv_wino(a, is3d, packed + pl.w_off + layer_weight_floats(L, is3d), s)) {
+      prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 4.0 * (is3d ? 3 : 1));   // 16 multiplies per 2x2 outputs (per z tap)
+      return;
+    }
     launch_conv_mfma(a, is3d, s);
+    prof_add_work(FNX_PROF_CONV_MFMA, px * mac * layer_taps(L, is3d));
     return;
   }
-  if (mfma16_layer(L)) { ProfScope ps(FNX_PROF_CONV_MFMA16, s); launch_conv_mfma16(a, is3d, s); return; }
+  if (mfma16_layer(L)) {
+    ProfScope ps(FNX_PROF_CONV_MFMA16, s); launch_conv_mfma16(a, is3d, s);
+    prof_add_work(FNX_PROF_CONV_MFMA16, (double)B * D * H * W * 2.0 * L.cin * L.cout * layer_taps(L, is3d));
+    return;
+  }
   ProfScope ps(FNX_PROF_CONV_DIRECT, s);
   if (is3d) {
     if (L.k == 3) launch_conv_k<3, true>(a, s);

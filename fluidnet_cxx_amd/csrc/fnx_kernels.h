@@ -8,6 +8,7 @@ namespace fnx {
 // event-pair timing of kernel classes (fnx_api.hip); no-ops unless fnx_profile_enable(1)
 void prof_begin(int tag, hipStream_t s);
 void prof_end(int tag, hipStream_t s);
+void prof_add_work(int tag, double amount);   // adds to the class's work counter while a recorded launch of it is open
 struct ProfScope {
   int tag; hipStream_t s;
   ProfScope(int t, hipStream_t st) : tag(t), s(st) { prof_begin(tag, s); }

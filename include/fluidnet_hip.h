@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 4
+#define FNX_ABI_VERSION 5
 
 enum {
   FNX_OK = 0,
@@ -229,6 +229,10 @@ enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PRO
        FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_NTAGS = 6 };
 int fnx_profile_enable(int on);
 int fnx_profile_read(int tag, double* total_ms, int* launches);
+/* What the recorded launches of a class ISSUED: for the conv classes the multiply-add FLOPs actually sent to the matrix
+ * cores (a Winograd F(2x2,3x3) launch issues 16/36 of the direct convolution's), so that issued / time / peak is the
+ * MFMA utilisation rather than a direct-convolution-equivalent rate.  0 for the other classes. */
+int fnx_profile_read_work(int tag, double* work);
 
 #ifdef __cplusplus
 }
