@@ -610,6 +610,263 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   }  // segments
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same march with its row loads going through the LDS-DMA path.
+//
+// What bounds the kernel above is not HBM and not the VALU but the texture addresser: a wave-level VMEM instruction
+// costs the CU's TA ~14 cycles whether it moves 64 B (a mask row), 256 B (a dword row) or more (measured,
+// tools/ubench/ta_bench.hip: dword rows 18.6 B/clk/CU, dwordx4 53 B/clk/CU), and a step issues 20 row loads + 4 row
+// stores = ~340 TA cycles for 4 x 60 cells, which IS the measured 51 us per pass at 16.8 M cells.  Here the rows of a
+// step arrive as buffer_load_dwordx4 ... lds: one instruction fetches FOUR 256-B rows (lane l: row l/16, columns
+// 4(l%16)..+3; ~31 TA cycles, i.e. 7.8 per row instead of 13.5) and drops them into the wave's private LDS stage as
+// [row][64 columns]; a ds_read_b32 per row then brings them into the lane <-> column register layout the sweeps use
+// (the transposition is free: it is the LDS address).  The six 64-B mask rows come in ONE instruction (lane l: row l/4).
+// No VGPRs are tied up by loads in flight, the stage is double buffered, and nothing synchronises between waves.
+// Per step: 5 DMA instructions instead of 20 loads.
+// ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
+template <bool RES, bool ZERO, bool SPLIT>
+__global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_dma_kernel(GridDims g, const unsigned char* __restrict__ mask,
+                                                                      const float* __restrict__ div,
+                                                                      const float* __restrict__ p_in,
+                                                                      float* __restrict__ p_out,
+                                                                      float* __restrict__ sumsq, int nxt, int nyt,
+                                                                      int zchunk, int kb, int ke, int kb2) {
+  constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
+  const int lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  // One resident set of waves.  !SPLIT: every tile is cut into the same plane chunks and a wave takes one
+  // (tile, chunk); all waves of a chunk start together and march the same planes at the same pace, so the halo
+  // columns/rows two neighbouring tiles both touch are fetched from HBM once and hit in L2 the second time.  Workgroup
+  // ids go round-robin over the 8 XCDs; renumbering gives XCD q the tiles [q*G/8, (q+1)*G/8), i.e. whole bands of
+  // neighbouring tiles.  SPLIT (more tiles than resident waves): the (tile, plane) space is cut into gridDim.x equal
+  // contiguous ranges instead.
+  const int G = gridDim.x, np = ke - kb;
+  const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int ntiles = nxt * nyt * g.B;
+  int L0, L1;
+  int kbase = kb;                                        // kb2 >= 0: a second plane range [kb2, kb2 + np) in the same launch
+  if (!SPLIT) {
+    int zc = gid / ntiles;
+    const int tl = gid - zc * ntiles;
+    if (kb2 >= 0) {                                      // chunks [0, nzc1) belong to the first range, [nzc1, 2 nzc1) to the second
+      const int nzc1 = (np + zchunk - 1) / zchunk;
+      if (zc >= nzc1) { zc -= nzc1; kbase = kb2; }
+    }
+    L0 = tl * np + zc * zchunk;
+    L1 = min(L0 + zchunk, (tl + 1) * np);
+    if (zc * zchunk >= np) L1 = L0;                      // padding block
+  } else {
+    const long long T = (long long)ntiles * np;
+    auto cut = [&](int q) {                              // range boundary, snapped away from 1-2 plane slivers at tile ends
+      int L = (int)(T * q / G);
+      const int pk = L % np;
+      if (pk < 3) L -= pk; else if (pk > np - 3) L += np - pk;
+      return L;
+    };
+    L0 = cut(gid); L1 = cut(gid + 1);
+  }
+  for (; L0 < L1;) {                                     // one pass unless SPLIT
+  const int tile = L0 / np, pk = L0 - tile * np;
+  const int seg = min(np - pk, L1 - L0);
+  L0 = SPLIT ? L0 + seg : L1;
+  const int bx = tile % nxt, l1 = tile / nxt;
+  const int by = l1 % nyt, b = l1 / nyt;
+  const int x = bx * 60 - 2 + lane;
+  const int j0 = (by * Z2NW + w) * Z2R;
+  const int k_lo = kbase + pk, k_hi = k_lo + seg;           // output planes [k_lo, k_hi) of this segment
+  const bool xin = (x >= 0) & (x < g.W);
+  const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
+  const size_t base = (size_t)b * g.DHW;
+
+  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
+  // Rows / planes / columns outside the grid are clamped onto the border, whose mask byte is 0 (border cells are
+  // never 'cont'), so no validity selects are needed: a clamped cell relaxes to 0 like the border cell it aliases.
+  unsigned rowb[R0];                                     // wave-uniform cell offset of row slot rr (j = j0-2+rr) in a plane
+#pragma unroll
+  for (int rr = 0; rr < R0; ++rr) {
+    const int j = j0 - 2 + rr;
+    rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
+  }
+  // buffer offsets are 32-bit: they are taken relative to the first plane this segment touches, so only the segment
+  // (<= a few dozen planes), not the whole field, has to stay below 4 GB
+  const int k0 = clampk(k_lo - 2);
+  auto planeoff = [&](int k) { return (unsigned)((clampk(k) - k0) * g.HW); };
+  // buffer addressing: per-lane voffset (the column) + wave-uniform soffset (plane/row), no 64-bit VALU address math
+  const unsigned xoff = (unsigned)xc * 4u;
+  const size_t seg0 = base + (size_t)k0 * g.HW;
+  const size_t left = (size_t)(g.D - k0) * g.HW;                       // cells from plane k0 to the end of the sample
+  const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
+  const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
+  const BufRsrc r_m = make_rsrc(mask + seg0, ncell), r_o = make_rsrc(p_out + seg0, ncell * 4u);
+  // ---- DMA addressing.  Columns are NOT clamped per lane (a 16-byte chunk is 4 columns): a chunk left of column 0 or
+  // right of column W-1 reads the neighbouring row's cells -- or, outside the sample, nothing (the buffer range check
+  // returns 0) -- and whatever arrives there only ever feeds border cells, whose mask byte is 0.  Rows and planes are
+  // clamped as before (wave-uniform).
+  const int x0 = bx * 60 - 2;
+  const int rs = lane >> 4, cq = lane & 15;              // row within a 4-row group, 16-byte chunk within the row
+  unsigned vrow_p[R0 / 4], vrow_a[2];                    // per-lane byte offset of "my" row of group q (+ my chunk)
+#pragma unroll
+  for (int q = 0; q < R0 / 4; ++q) {
+    unsigned ro = rowb[4 * q];
+    if (rs == 1) ro = rowb[4 * q + 1]; else if (rs == 2) ro = rowb[4 * q + 2]; else if (rs == 3) ro = rowb[4 * q + 3];
+    vrow_p[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {                          // div rows: slots 1..6 of the p^0 numbering (j0-1 .. j0+4)
+    unsigned ro = rowb[R0 - 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int slot = 1 + 4 * q + u; if (rs == u && slot < R0) ro = rowb[slot < R0 ? slot : R0 - 1]; }
+    vrow_a[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
+  }
+  // mask rows: one byte per cell.  A dwordx4 transfer needs a dword-aligned address, x0 = 60 bx - 2 is not one in bytes:
+  // the chunks start at column x0 - 2 (a multiple of 4) and a row is 5 chunks = 80 bytes, of which [2, 66) are the
+  // wave's columns.  Lane l fetches chunk l%5 of row slot 1 + l/5 (lanes 0 .. 5 R1 - 1): all six rows in ONE instruction.
+  constexpr int MROW = 80;
+  unsigned vrow_m;
+  {
+    const int mr = lane / 5, mc = lane - mr * 5;
+    unsigned ro = rowb[R0 - 1];
+#pragma unroll
+    for (int u = 0; u < R1; ++u) if (mr == u) ro = rowb[1 + u];
+    vrow_m = ro + (unsigned)(x0 - 2 + 16 * mc);
+  }
+  const bool m_lane = lane < 5 * R1;
+  // LDS stage: p^0 rows [R0][64] floats, aux rows [8][64] floats, mask rows [R1][64] bytes (padded to 1 KiB); two stages
+  constexpr int STAGE_F = R0 * 64 + 8 * 64 + 256;
+  __shared__ __attribute__((aligned(16))) float stage[2][STAGE_F];
+  typedef __attribute__((address_space(3))) void* LdsPtr;
+  auto dma_p = [&](int st, unsigned plane_cells) {         // p^0 rows of one plane -> stage st
+    if (ZERO) return;
+#pragma unroll
+    for (int q = 0; q < R0 / 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_p, (LdsPtr)&stage[st][q * 256], 16, vrow_p[q], plane_cells * 4u, 0, 0);
+  };
+  auto dma_a = [&](int st, unsigned plane_cells) {         // div + mask rows of one plane -> stage st
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_d, (LdsPtr)&stage[st][R0 * 64 + q * 256], 16, vrow_a[q], plane_cells * 4u, 0, 0);
+    if (m_lane)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_m, (LdsPtr)&stage[st][R0 * 64 + 8 * 64], 16, vrow_m, plane_cells, 0, 0);
+  };
+  auto lds_p = [&](int st, int rr) { return ZERO ? 0.f : stage[st][rr * 64 + lane]; };
+  auto lds_d = [&](int st, int rr) { return stage[st][R0 * 64 + rr * 64 + lane]; };          // rr: aux row slot (j = j0-1+rr)
+  auto lds_m = [&](int st, int rr) { return (unsigned)((const unsigned char*)&stage[st][R0 * 64 + 8 * 64])[rr * MROW + 2 + lane]; };
+  auto ldf = [&](const BufRsrc& r, unsigned cell) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
+  };
+  auto ldp = [&](unsigned cell) { return ZERO ? 0.f : ldf(r_p, cell); };
+  auto ldm = [&](unsigned cell) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, (unsigned)xc, cell, 0); };
+
+  float P0[4][R0];                                       // p^0 plane ring: slot (t+d)&3 for planes t-1..t+2
+  float P1[4][R1];                                       // p^1 plane ring (3 live)
+  float AD[4][R1]; unsigned AM[4][R1];                   // div / mask ring, row slot rr <-> j = j0-1+rr
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int rr = 0; rr < R1; ++rr) { P1[q][rr] = 0.f; AD[q][rr] = 0.f; AM[q][rr] = 0u; }
+#pragma unroll
+    for (int rr = 0; rr < R0; ++rr) P0[q][rr] = 0.f;
+  }
+  int t = k_lo - 1;
+  // prologue: planes t-1, t, t+1 of p^0 (slots 3, 0, 1) and the aux data of plane t (slot 0), all rows from memory
+  {
+    const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
+#pragma unroll
+    for (int rr = 0; rr < R0; ++rr) {
+      P0[3][rr] = ldp(pm + rowb[rr]); P0[0][rr] = ldp(pc + rowb[rr]); P0[1][rr] = ldp(pp + rowb[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < R1; ++rr) { AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]); AM[0][rr] = ldm(pc + rowb[rr + 1]); }
+    // the first step's "next" rows (p^0 plane t+2, aux plane t+1) already travel through the DMA path
+    dma_p(0, planeoff(t + 2)); dma_a(0, planeoff(t + 1));
+  }
+  float local = 0.f;
+  const bool lane_out = (lane >= 2) & (lane <= 61) & xin;
+  bool prev_free = false;
+
+  // one sweep over N rows: centre rows C[0..N), y-neighbours from the same plane, z-neighbours B / F
+  auto sweep = [&](auto nn, bool free, const unsigned* M, const float* Cm1, const float* B, const float* F,
+                   const float* DV, float* out) __attribute__((always_inline)) {
+    constexpr int N = decltype(nn)::value;
+    float xs[N];
+    bool bad = false;
+    if (free) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float c = Cm1[r + 1];
+        out[r] = relax3<true>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        bad |= __builtin_amdgcn_classf(out[r], 0x90);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float c = Cm1[r + 1];
+        out[r] = relax3<false>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        bad |= __builtin_amdgcn_classf(out[r], 0x90);
+      }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: scaled division
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+        if (__builtin_amdgcn_classf(out[r], 0x90)) out[r] = div6_tiny(xs[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)                            // cont ? v : 0
+      out[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[r]) & __builtin_amdgcn_sbfe((int)M[r], 0, 1));
+  };
+
+  auto step = [&](auto ph, int t) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph)::value;
+    constexpr int SM = (PH + 3) & 3, SC = PH, SP = (PH + 1) & 3, SN = (PH + 2) & 3, BUF = PH & 1;
+    // ---- p^0 plane t+2 and the aux data of plane t+1 (used one step later): they were sent to LDS stage `par` one step
+    // ago; pick them up, then start the DMA of the following planes into the other stage.  (The compiler does not track
+    // LDS-DMA: the waits are explicit.  vmcnt(0) also covers the row stores of the previous step.)
+    // lgkmcnt(0) too: the previous step's reads of the OTHER stage (long complete) must have left it before it is refilled
+    __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
+#pragma unroll
+    for (int rr = 0; rr < R0; ++rr) P0[SN][rr] = lds_p(BUF, rr);        // (steps alternate stages: BUF = PH & 1, the prologue filled 0)
+#pragma unroll
+    for (int rr = 0; rr < R1; ++rr) { AD[SP][rr] = lds_d(BUF, rr); AM[SP][rr] = lds_m(BUF, rr); }
+    if (t < k_hi) {                                      // (the last step of a segment has no successor to feed)
+      dma_p(BUF ^ 1, planeoff(t + 3)); dma_a(BUF ^ 1, planeoff(t + 2));
+    }
+    // ---- sweep 1 on plane t, rows j0-1 .. j0+4
+    unsigned ob = AM[SC][0];
+#pragma unroll
+    for (int rr = 1; rr < R1; ++rr) ob |= AM[SC][rr];
+    const bool free1 = __builtin_amdgcn_ballot_w64((ob & 0x7eu) != 0) == 0;     // no cell of these rows has an obstacle neighbour
+    sweep(IC<R1>{}, free1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
+    // ---- sweep 2 on plane t-1, rows j0 .. j0+3 (p^1 of planes t-2, t-1, t = slots SN, SM, SC)
+    if (t - 1 >= k_lo) {
+      float v[Z2R];
+      sweep(IC<Z2R>{}, prev_free, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
+      const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
+#pragma unroll
+      for (int r = 0; r < Z2R; ++r) {
+        if (lane_out && j0 + r < g.H) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
+          if (RES) { const float d = v[r] - P1[SM][r + 1]; local += d * d; }
+        }
+      }
+    }
+    prev_free = free1;
+  };
+
+  while (true) {
+    step(IC<0>{}, t); if (++t > k_hi) break;
+    step(IC<1>{}, t); if (++t > k_hi) break;
+    step(IC<2>{}, t); if (++t > k_hi) break;
+    step(IC<3>{}, t); if (++t > k_hi) break;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): no LDS-DMA may outlive the segment (or the wave)
+  if (RES) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) atomicAdd(&sumsq[b], local);
+  }
+  }  // segments
+}
+
 // Generic single sweep (3D, and any 2D shape): one thread per cell.
 constexpr int BX = 64, BY = 4;
 
@@ -809,7 +1066,9 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
-#define J3D(R, Z, S) jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2)
+  static const bool dma = [] { const char* e = getenv("FNX_JACOBI_DMA"); return e ? atoi(e) != 0 : true; }();   // A/B switch
+#define J3D(R, Z, S) do { if (dma) jacobi3d_march2_dma_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); \
+                          else jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
 #define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \
                        else { if (sumsq) J3D(true, false, S); else J3D(false, false, S); } } while (0)
   if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true);

@@ -318,15 +318,32 @@ def test_3d_default_semantics_axis_symmetry(fl, dev, perm):
         Uw = tU.clone(); fl.setWallBcs(Uw, tf); o["set_wall_bcs"] = N(Uw)
         return o
     a, b = run(s, grav), run(sp, gravp)
+    # Where the reference's rules are anisotropic BY CONSTRUCTION the exchange cannot hold and the cells are left out:
+    #  * the fluid-aware interpolation of advectScalar pairs the corners y first, then x, then z (grid.cpp:118-269) and falls
+    #    back corner by corner next to non-fluid cells, the line trace backs off along an axis-ordered box test, and a
+    #    non-fluid cell of advectVel receives the reference's channel shuffle (fluids_init.cpp:413-416): the advection
+    #    operators are compared on the cells whose 5x5x5 neighbourhood is fluid (CFL < 1 here);
+    #  * setWallBcs at index 0: the x / y neighbour clamps to the cell itself, the z rule needs k > 0.
+    fl3 = back(s["flags"]) == 1.0
+    deep = fl3.copy()
+    for ax in (2, 3, 4):                                  # separable erosion: the full 5x5x5 cube, diagonals included
+        cur = deep.copy()
+        for sh in (-2, -1, 1, 2):
+            deep &= np.roll(cur, sh, axis=ax)
+    deep[:, :, :2] = False; deep[:, :, -2:] = False; deep[:, :, :, :2] = False; deep[:, :, :, -2:] = False
+    deep[..., :2] = False; deep[..., -2:] = False
+    assert deep.mean() > 0.1
     for k in a:
         want, got = back(a[k]), b[k]                      # operator(exchanged state) vs exchanged(operator(state))
+        sel = np.ones(want.shape, bool)
+        if k.startswith("advect"):
+            sel = np.broadcast_to(deep, want.shape)
         if k == "set_wall_bcs":
-            # the one documented asymmetry: at index 0 the x / y neighbour clamps to the cell itself, the z rule needs k > 0
-            want, got = want[:, :, 1:, 1:, 1:], got[:, :, 1:, 1:, 1:]
+            sel = sel.copy(); sel[:, :, 0] = False; sel[:, :, :, 0] = False; sel[..., 0] = False
         scale = max(float(np.abs(want).max()), 1e-30)
-        d = np.abs(want.astype(np.float64) - got)
+        d = np.abs(want.astype(np.float64) - got)[sel]
         frac_bad = float((d > 2e-6 * scale).mean())
-        assert frac_bad <= 1e-3, f"{k} under {perm} exchange: {frac_bad:.2%} of the cells differ by more than rounding (max {d.max():.3e}, scale {scale:.3e})"
+        assert frac_bad <= 1e-3, f"{k} under {perm} exchange: {frac_bad:.2%} of the compared cells differ by more than rounding (max {d.max():.3e}, scale {scale:.3e})"
 
 
 # ---- CNN --------------------------------------------------------------------------------------------
