@@ -587,6 +587,8 @@ __global__ __launch_bounds__(BX* BY) void advect_bwd_kernel(GridDims g, float dt
   else sl_mac_bwd_clamp_cell_flat<IS3D>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
 }
 
+#include "fnx_advect_march.h"
+
 inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
 
 }  // namespace
@@ -642,13 +644,44 @@ void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const fl
   DISPATCH2(is3d, quirks, sl_mac_kernel, <<<grid, block, 0, s>>>(g, dt, src, U, flags, dst));
 }
 
+// z-marching tile kernels (fnx_advect_march.h): the planes of the compute window are cut into chunks so that the
+// launch is a whole number of rounds of resident workgroups (3 per CU); a chunk re-reads 2 lead-in planes.
+static void tile_launch_geometry(const GridDims& g, int& ntx, int& nty, int& zchunk, unsigned& G) {
+  static const int slots = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 3 * cus;
+  }();
+  ntx = (g.W + 63) / 64; nty = (g.H + ATR - 1) / ATR;
+  const long ntiles = (long)ntx * nty * g.B;
+  long nzc = (2l * slots + ntiles - 1) / ntiles;          // two rounds of workgroups
+  if (nzc < 1) nzc = 1;
+  zchunk = (int)((g.KN + nzc - 1) / nzc);
+  if (zchunk < 8) zchunk = g.KN < 8 ? g.KN : 8;
+  nzc = (g.KN + zchunk - 1) / zchunk;
+  long n = ntiles * nzc;
+  G = (unsigned)(((n + 7) / 8) * 8);
+}
+
+static void launch_fwd_tile(const GridDims& g, bool sample_outside, float dt, const float* rho, const float* U,
+                            const float* flags, float* rho_fwd, int* cell, float* U_fwd, hipStream_t s) {
+  int ntx, nty, zchunk; unsigned G;
+  tile_launch_geometry(g, ntx, nty, zchunk, G);
+  if (sample_outside) advect3d_fwd_tile_kernel<true><<<dim3(G), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ntx, nty, zchunk);
+  else advect3d_fwd_tile_kernel<false><<<dim3(G), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ntx, nty, zchunk);
+}
+
 // MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches
 void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, bool sample_outside, float dt,
                          float half_s, const float* rho, const float* U, const float* flags, float* rho_fwd, int* cell,
                          float* U_fwd, float* box, float* rho_dst, float* U_dst, hipStream_t s) {
   const dim3 block(BX, BY);
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
-  DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
+  static const int march = [] { const char* e = getenv("FNX_ADVECT_MARCH"); return e ? atoi(e) : 1; }();   // A/B switch
+  if (is3d && !quirks && (march & 1) && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu)
+    launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, s);
+  else
+    DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
   if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
   DISPATCH3(is3d, quirks, sample_outside, advect_bwd_kernel,
             <<<cell_grid(g), block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst));

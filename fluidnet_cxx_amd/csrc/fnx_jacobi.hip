@@ -1066,7 +1066,7 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
-  static const bool dma = [] { const char* e = getenv("FNX_JACOBI_DMA"); return e ? atoi(e) != 0 : true; }();   // A/B switch
+  static const bool dma = [] { const char* e = getenv("FNX_JACOBI_DMA"); return e ? atoi(e) != 0 : false; }();   // A/B switch (same bits, same speed: see the kernel comment)
 #define J3D(R, Z, S) do { if (dma) jacobi3d_march2_dma_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); \
                           else jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
 #define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \

@@ -614,16 +614,38 @@ def test_bc_class_map_same_bits(dev, ext, shape, method):
         assert torch.equal(a.view(torch.int32), b_.view(torch.int32))
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 40, 70, 3.0), (1, 9, 20, 66, 2.0)])
+@pytest.mark.parametrize("shape", [(2, 1, 40, 70, 3.0), (1, 9, 20, 66, 2.0), (2, 12, 21, 130, 0.8), (1, 16, 33, 70, 6.0),
+                                   (1, 7, 9, 11, 1.5), (1, 20, 64, 200, 0.3), (1, 10, 30, 63, 0.0)])
 def test_advect_step_equals_the_two_advections(fl, ext, dev, shape):
-    """fnx_advect_step (fused forward / backward launches) == advectScalar + advectVelocity, bit for bit."""
+    """fnx_advect_step (the step's fused advection; in 3D the z-marching stencil kernels with their in-register fast path
+    and per-cell fallback lanes) == advectScalar + advectVelocity (the per-cell kernels, themselves pinned to the goldens
+    and the oracle), bit for bit: CFL from 0 (sigma 0: every trace stays) over the all-fast-path range to mostly-fallback
+    (sigma 6), obstacles and Empty cells, several x tiles, odd sizes, batch 2, and a compute window."""
     B, D, H, W, sigma = shape
     s = random_state(B, D, H, W, sigma, seed=21, empties=True)
     tf, tU, trho = T(s["flags"], dev), T(s["U"], dev), T(s["rho"], dev)
     for so in (False, True):
         r, u = ext.advect_step(0.13, trho, tU, tf, so, 0.7)
-        assert_bitexact(N(r), N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7)), f"density so={so}")
-        assert_bitexact(N(u), N(fl.advectVelocity(0.13, tU, tU, tf, "maccormackFluidNet", 1, 0.7)), f"U so={so}")
+        want_r = N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7))
+        want_u = N(fl.advectVelocity(0.13, tU, tU, tf, "maccormackFluidNet", 1, 0.7))
+        assert_bitexact(N(r), want_r, f"density so={so}")
+        assert_bitexact(N(u), want_u, f"U so={so}")
+        if D >= 9 and sigma * 0.13 * 5 < 1.0:
+            # compute window (valid for CFL < 1: the forward pass covers the window widened by 2 planes): planes [3, D-3) only,
+            # the rest of the output untouched
+            ro, uo = torch.full_like(trho, 9.0), torch.full_like(tU, 9.0)
+            ext.advect_step(0.13, trho, tU, tf, so, 0.7, ro, uo, ext.Geom(k_begin=3, k_end=D - 3))
+            assert_bitexact(N(ro)[:, :, 3:D - 3], want_r[:, :, 3:D - 3], "window density")
+            assert_bitexact(N(uo)[:, :, 3:D - 3], want_u[:, :, 3:D - 3], "window U")
+            assert (N(ro)[:, :, :3] == 9.0).all() and (N(ro)[:, :, D - 3:] == 9.0).all() and (N(uo)[:, :, :3] == 9.0).all()
+    if D > 1:
+        # every trace towards +x,+y,+z (and then towards -x,-y,-z): the last (first) interior cell samples the far (near)
+        # corner cell of the arrays, where the tile loader's 16-byte chunks hang over the end (start) of the tensors
+        for sign in (-1.0, 1.0):
+            tUn = (tU.abs() * sign).contiguous()
+            r, u = ext.advect_step(0.13, trho, tUn, tf, False, 0.7)
+            assert_bitexact(N(r), N(fl.advectScalar(0.13, trho, tUn, tf, "maccormackFluidNet", 1, False, 0.7)), f"density, U sign {sign}")
+            assert_bitexact(N(u), N(fl.advectVelocity(0.13, tUn, tUn, tf, "maccormackFluidNet", 1, 0.7)), f"U, U sign {sign}")
 
 
 def test_rollout_batch_of_two(dev, oracle):
