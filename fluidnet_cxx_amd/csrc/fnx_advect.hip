@@ -677,12 +677,20 @@ void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, boo
                          float* U_fwd, float* box, float* rho_dst, float* U_dst, hipStream_t s) {
   const dim3 block(BX, BY);
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
-  static const int march = [] { const char* e = getenv("FNX_ADVECT_MARCH"); return e ? atoi(e) : 1; }();   // A/B switch
+  static const int march = [] { const char* e = getenv("FNX_ADVECT_MARCH"); return e ? atoi(e) : 3; }();   // A/B switch: bit 0 forward, bit 1 backward tile kernels
   if (is3d && !quirks && (march & 1) && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu)
     launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, s);
   else
     DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
   if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
+  if (is3d && !quirks && (march & 2) && (size_t)(g.KN + 2) * g.HW < 0x3fffffffu) {
+    int ntx, nty, zchunk; unsigned G;
+    tile_launch_geometry(g, ntx, nty, zchunk, G);
+    if (sample_outside) advect3d_bwd_scalar_tile_kernel<true><<<dim3(G), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, ntx, nty, zchunk);
+    else advect3d_bwd_scalar_tile_kernel<false><<<dim3(G), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, ntx, nty, zchunk);
+    advect3d_bwd_vel_tile_kernel<<<dim3(G), 256, 0, s>>>(g, dt, half_s, U, U_fwd, flags, U_dst, ntx, nty, zchunk);
+    return;
+  }
   DISPATCH3(is3d, quirks, sample_outside, advect_bwd_kernel,
             <<<cell_grid(g), block, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst));
 }

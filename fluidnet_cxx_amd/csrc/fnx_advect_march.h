@@ -371,3 +371,330 @@ __global__ __launch_bounds__(256, 3) void advect3d_fwd_tile_kernel(GridDims g, f
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                     // no LDS-DMA may outlive the wave
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Backward pass, density: sl_scalar_bwd_clamp_cell<true, false, SO> for the planes [K0, K0+KN).
+// Ring fields: rho_fwd, Ux, Uy, Uz.  rho, the traced cell and its clamp bounds are per-cell global loads.
+// ---------------------------------------------------------------------------------------------------
+template <bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(256, 3) void advect3d_bwd_scalar_tile_kernel(GridDims g, float dt, float half_s,
+                                                                          const float* __restrict__ rho,
+                                                                          const float* __restrict__ rho_fwd,
+                                                                          const int* __restrict__ cell_in,
+                                                                          const float* __restrict__ U,
+                                                                          const float* __restrict__ flags,
+                                                                          const float2* __restrict__ box,
+                                                                          float* __restrict__ rho_dst, int ntx, int nty, int zchunk) {
+  constexpr int NF = 4;
+  constexpr int FSZ = ATRR * ATP;
+  __shared__ __attribute__((aligned(16))) float ring[4][NF][FSZ];
+  __shared__ __attribute__((aligned(16))) float fstage[2][FSZ];
+  ATile m;
+  if (!atile_setup(m, g, ntx, nty, zchunk)) return;
+  const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
+  const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
+  const ABuf rs_r = atile_rsrc(m, g, rho_fwd + sb1, after1), rs_x = atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
+             rs_y = atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), rs_z = atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3),
+             rs_f = atile_rsrc(m, g, flags + sb1, after1);
+  const int lane = m.lane, w = m.w;
+  auto dma_plane = [&](int slot, int fs, int k) {
+    const unsigned pb = m.planeoff(g, k);
+    atile_dma(m, rs_r, ring[slot][0], pb, 0);
+    atile_dma(m, rs_x, ring[slot][1], pb, 1);
+    atile_dma(m, rs_y, ring[slot][2], pb, 2);
+    atile_dma(m, rs_z, ring[slot][3], pb, 3);
+    atile_dma(m, rs_f, fstage[fs], pb, 0);
+  };
+  const int hr0 = 2 * w + 1;
+  const int col = lane + m.xs;
+  auto fluid_bits = [&](int fs) {
+    unsigned c = 0;
+    const float* f = &fstage[fs][(hr0 - 1) * ATP + col - 1];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) c |= (f[rr * ATP + dx] == FNX_FLUID ? 1u : 0u) << (3 * rr + dx);
+    }
+    return c;
+  };
+  const int i = m.x;
+  const bool xin = i < g.W;
+  unsigned FB[3];
+
+  auto step = [&](auto rsl, int k, unsigned fbm, unsigned fbc, unsigned fbp) __attribute__((always_inline)) {
+    constexpr int SC = decltype(rsl)::value, SM = (SC + 3) % 4, SP = (SC + 1) % 4;
+    const int kg = k + g.zoff;
+    const float ctrz = (float)kg + 0.5f;
+    const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
+    bool slow[2];
+    bool any_slow = false;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = m.j0 + 2 * w + r;
+      const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
+      const bool live = xin & (j < g.H);
+      const float ctrx = (float)i + 0.5f, ctry = (float)j + 0.5f;
+      auto at = [&](int f, int s, int dy, int dx) { return ring[s][f][(hr0 + r + dy) * ATP + col + dx]; };
+      const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
+      const unsigned nb = ((fbm >> (3 * r)) & 0x1ffu) | (((fbc >> (3 * r)) & 0x1ffu) << 9) | (((fbp >> (3 * r)) & 0x1ffu) << 18);
+      // per-cell global operands, issued first (clamped addresses for the lanes that store nothing)
+      const size_t o = (size_t)k * g.HW + (size_t)(j < g.H ? j : g.H - 1) * g.W + (xin ? i : g.W - 1);
+      const float src = rho[sb1 + o];
+      const int cell = cell_in[sb1 + o];
+      const bool inslab = (cell >= g.HW) & (cell < g.HW + g.DHW);
+      const float2 bb = box[sb1 + (size_t)(inslab ? cell - g.HW : 0)];
+
+      const float f = at(0, SC, 0, 0);
+      const float x_c = at(1, SC, 0, 0), y_c = at(2, SC, 0, 0), z_c = at(3, SC, 0, 0);
+      const float cen0 = 0.5f * (x_c + at(1, SC, 0, 1));
+      const float cen1 = 0.5f * (y_c + at(2, SC, 1, 0));
+      const float cen2 = 0.5f * (z_c + at(3, SP, 0, 0));
+      const float d0 = dt * cen0, d1 = dt * cen1, d2 = dt * cen2;           // (-ndt) * cen with ndt = -dt
+      const float length = sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+      const bool stay = (length <= FNX_EPSILON) | (0.f >= length - FNX_HIT_MARGIN);
+      const float dir0 = d0 / length, dir1 = d1 / length, dir2 = d2 / length;
+      const float stp = fminf(length - 0.f, 1.f);
+      const float n0 = ctrx + dir0 * stp, n1 = ctry + dir1 * stp, n2 = ctrz + dir2 * stp;
+      const bool ends = stp >= length - FNX_HIT_MARGIN;
+      const int c0 = (int)n0 - i, c1 = (int)n1 - j, c2 = (int)n2 - kg;
+      const bool near = ((unsigned)(c0 + 1) <= 2u) & ((unsigned)(c1 + 1) <= 2u) & ((unsigned)(c2 + 1) <= 2u);
+      const bool tfluid = (nb >> ((9 * (c2 + 1) + 3 * (c1 + 1) + (c0 + 1)) & 31)) & 1u;
+      const bool moved_ok = ends & near & tfluid;
+      const float p0 = stay ? ctrx : n0, p1 = stay ? ctry : n1, p2 = stay ? ctrz : n2;
+      const ALerp Ls = alerp(p0, p1, p2, i, j, kg);
+      float cs[8];
+      {
+        const int rowcol = (hr0 + r - (Ls.ny ? 1 : 0)) * ATP + col - (Ls.nx ? 1 : 0);
+        const float* z0 = (Ls.nz ? &ring[SM][0][0] : &ring[SC][0][0]) + rowcol;
+        const float* z1 = (Ls.nz ? &ring[SC][0][0] : &ring[SP][0][0]) + rowcol;
+        cs[0] = z0[0]; cs[1] = z0[1]; cs[2] = z0[ATP]; cs[3] = z0[ATP + 1];
+        cs[4] = z1[0]; cs[5] = z1[1]; cs[6] = z1[ATP]; cs[7] = z1[ATP + 1];
+      }
+      float smp;
+      if (SAMPLE_OUTSIDE) {
+        smp = atrilin(cs, Ls);
+      } else {
+        const unsigned sh = (Ls.nz ? 0u : 9u) + (Ls.ny ? 0u : 3u) + (Ls.nx ? 0u : 1u);
+        const unsigned q = nb >> sh;
+        const unsigned fb = (q & 1u) | ((q >> 1) & 1u) << 1 | ((q >> 3) & 1u) << 2 | ((q >> 4) & 1u) << 3 | ((q >> 9) & 1u) << 4 |
+                            ((q >> 10) & 1u) << 5 | ((q >> 12) & 1u) << 6 | ((q >> 13) & 1u) << 7;
+        smp = atrilin_fluid(cs, fb, Ls);
+      }
+      const float bwd = border ? 0.f : (fluid ? smp : f);
+      float d = f;
+      if (fluid) d = f + half_s * (src - bwd);             // applied on border cells too (reference :371)
+      const float mn = bb.x, mx = bb.y;
+      const bool any = !(mn != mn);
+      const float dc = any ? fmaxf(mn, fminf(mx, d)) : f;
+      if (!border) d = dc;
+      slow[r] = live & !border & ((fluid & (!(stay | moved_ok) | !Ls.ok)) | !inslab);
+      if (live) rho_dst[sb1 + o] = d;
+      any_slow |= slow[r];
+    }
+    if (__builtin_amdgcn_ballot_w64(any_slow) != 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        CellId c; c.b = m.b; c.k = k; c.j = m.j0 + 2 * w + r; c.i = i; c.valid = true;
+        if (slow[r]) sl_scalar_bwd_clamp_cell<true, false, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, box, rho_dst);
+      }
+    }
+  };
+
+  int k = m.k_lo;
+  dma_plane(0, 0, k - 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  FB[0] = fluid_bits(0);
+  dma_plane(1, 1, k);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  FB[1] = fluid_bits(1);
+  dma_plane(2, 0, k + 1);
+  int fs = 0;
+  auto one = [&](auto rsl) __attribute__((always_inline)) {
+    constexpr int SC = decltype(rsl)::value;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    FB[2] = fluid_bits(fs);
+    if (k + 1 < m.k_hi) dma_plane((SC + 2) % 4, fs ^ 1, k + 2);
+    fs ^= 1;
+    step(rsl, k, FB[0], FB[1], FB[2]);
+    FB[0] = FB[1]; FB[1] = FB[2];
+  };
+  while (true) {
+    one(AIC<1>{}); if (++k >= m.k_hi) break;
+    one(AIC<2>{}); if (++k >= m.k_hi) break;
+    one(AIC<3>{}); if (++k >= m.k_hi) break;
+    one(AIC<0>{}); if (++k >= m.k_hi) break;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward pass, velocity: sl_mac_bwd_clamp_cell_flat<true> (self-advection: orig == U) for the planes [K0, K0+KN).
+// Ring fields: U_fwd x,y,z (sampled), U x,y,z (face velocities, clamp boxes).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void advect3d_bwd_vel_tile_kernel(GridDims g, float dt, float half_s,
+                                                                       const float* __restrict__ U,
+                                                                       const float* __restrict__ U_fwd,
+                                                                       const float* __restrict__ flags,
+                                                                       float* __restrict__ U_dst, int ntx, int nty, int zchunk) {
+  constexpr int NF = 6;
+  constexpr int FSZ = ATRR * ATP;
+  __shared__ __attribute__((aligned(16))) float ring[4][NF][FSZ];
+  __shared__ __attribute__((aligned(16))) float fstage[2][FSZ];
+  ATile m;
+  if (!atile_setup(m, g, ntx, nty, zchunk)) return;
+  const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
+  const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
+  ABuf rs[NF];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    rs[a] = atile_rsrc(m, g, U_fwd + sb3 + (size_t)a * g.DHW, after3 + (size_t)(2 - a) * g.DHW);
+    rs[3 + a] = atile_rsrc(m, g, U + sb3 + (size_t)a * g.DHW, after3 + (size_t)(2 - a) * g.DHW);
+  }
+  const ABuf rs_f = atile_rsrc(m, g, flags + sb1, after1);
+  const int lane = m.lane, w = m.w;
+  auto dma_plane = [&](int slot, int fs, int k) {
+    const unsigned pb = m.planeoff(g, k);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) atile_dma(m, rs[f], ring[slot][f], pb, f);
+    atile_dma(m, rs_f, fstage[fs], pb, 2);
+  };
+  const int hr0 = 2 * w + 1;
+  const int col = lane + m.xs;
+  auto fluid_bits = [&](int fs) {
+    unsigned c = 0;
+    const float* f = &fstage[fs][(hr0 - 1) * ATP + col - 1];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) c |= (f[rr * ATP + dx] == FNX_FLUID ? 1u : 0u) << (3 * rr + dx);
+    }
+    return c;
+  };
+  const int i = m.x;
+  const bool xin = i < g.W;
+  unsigned FB[3];
+
+  auto step = [&](auto rsl, int k, unsigned fbm, unsigned fbc) __attribute__((always_inline)) {
+    constexpr int SC = decltype(rsl)::value, SM = (SC + 3) % 4, SP = (SC + 1) % 4;
+    const int kg = k + g.zoff;
+    const float ctrz = (float)kg + 0.5f, posz = (float)kg;
+    const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
+    bool slow[2];
+    bool any_slow = false;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = m.j0 + 2 * w + r;
+      const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
+      const bool live = xin & (j < g.H);
+      const float ctrx = (float)i + 0.5f, ctry = (float)j + 0.5f, posx = (float)i, posy = (float)j;
+      auto at = [&](int f, int s, int dy, int dx) { return ring[s][f][(hr0 + r + dy) * ATP + col + dx]; };
+      const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
+      // flags of the -1 neighbours along x, y, z (chk[a] is true for every non-border cell)
+      const bool fmx = (fbc >> (3 * (r + 1) + 0)) & 1u, fmy = (fbc >> (3 * r + 1)) & 1u, fmz = (fbm >> (3 * (r + 1) + 1)) & 1u;
+      // get_at_mac<true, false, 0/1/2> on U (ring fields 3, 4, 5), operand for operand
+      const float x_c = at(3, SC, 0, 0), y_c = at(4, SC, 0, 0), z_c = at(5, SC, 0, 0);
+      const float x_r = at(3, SC, 0, 1), y_u = at(4, SC, 1, 0), z_f = at(5, SP, 0, 0);
+      float v[3][3];
+      v[0][0] = x_c;
+      v[0][1] = 0.25f * (((y_c + at(4, SC, 0, -1)) + y_u) + at(4, SC, 1, -1));
+      v[0][2] = 0.25f * (((z_c + at(5, SC, 0, -1)) + z_f) + at(5, SP, 0, -1));
+      v[1][0] = 0.25f * (((x_c + at(3, SC, -1, 0)) + x_r) + at(3, SC, -1, 1));
+      v[1][1] = y_c;
+      v[1][2] = 0.25f * (((z_c + at(5, SC, -1, 0)) + z_f) + at(5, SP, -1, 0));
+      v[2][0] = 0.25f * (((x_c + at(3, SM, 0, 0)) + x_r) + at(3, SM, 0, 1));
+      v[2][1] = 0.25f * (((y_c + at(4, SM, 0, 0)) + y_u) + at(4, SM, 1, 0));
+      v[2][2] = z_c;
+      const float fwd0 = at(0, SC, 0, 0), fwd1 = at(1, SC, 0, 0), fwd2 = at(2, SC, 0, 0);
+      float out[3];
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float vd0 = v[a][0] * dt, vd1 = v[a][1] * dt, vd2 = v[a][2] * dt;
+        const ALerp L = alerp(ctrx + vd0, ctry + vd1, ctrz + vd2, i, j, kg);
+        float c[8];
+        {
+          const int rowcol = (hr0 + r - (L.ny ? 1 : 0)) * ATP + col - (L.nx ? 1 : 0);
+          const float* z0 = (L.nz ? &ring[SM][a][0] : &ring[SC][a][0]) + rowcol;
+          const float* z1 = (L.nz ? &ring[SC][a][0] : &ring[SP][a][0]) + rowcol;
+          c[0] = z0[0]; c[1] = z0[1]; c[2] = z0[ATP]; c[3] = z0[ATP + 1];
+          c[4] = z1[0]; c[5] = z1[1]; c[6] = z1[ATP]; c[7] = z1[ATP + 1];
+        }
+        const float smp = atrilin(c, L);
+        float mn = INFINITY, mx = -INFINITY;
+        bool okc = true;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {                      // doClampComponentMAC: the boxes at trunc(pos -/+ vd)
+          const int qx = (int)(l == 0 ? posx - vd0 : posx + vd0);
+          const int qy = (int)(l == 0 ? posy - vd1 : posy + vd1);
+          const int qz = (int)(l == 0 ? posz - vd2 : posz + vd2);
+          const int rx = qx - i, ry = qy - j, rz = qz - kg;
+          okc &= ((unsigned)(rx + 1) <= 1u) & ((unsigned)(ry + 1) <= 1u) & ((unsigned)(rz + 1) <= 1u);
+          const int rowcol = (hr0 + r + (ry == -1 ? -1 : 0)) * ATP + col + (rx == -1 ? -1 : 0);
+          const float* z0 = (rz == -1 ? &ring[SM][3 + a][0] : &ring[SC][3 + a][0]) + rowcol;
+          const float* z1 = (rz == -1 ? &ring[SC][3 + a][0] : &ring[SP][3 + a][0]) + rowcol;
+          const float e0 = z0[0], e1 = z0[1], e2 = z0[ATP], e3 = z0[ATP + 1], e4 = z1[0], e5 = z1[1], e6 = z1[ATP], e7 = z1[ATP + 1];
+          mn = fminf(mn, e0); mx = fmaxf(mx, e0); mn = fminf(mn, e1); mx = fmaxf(mx, e1);
+          mn = fminf(mn, e2); mx = fmaxf(mx, e2); mn = fminf(mn, e3); mx = fmaxf(mx, e3);
+          mn = fminf(mn, e4); mx = fmaxf(mx, e4); mn = fminf(mn, e5); mx = fmaxf(mx, e5);
+          mn = fminf(mn, e6); mx = fmaxf(mx, e6); mn = fminf(mn, e7); mx = fmaxf(mx, e7);
+        }
+        const float fa = a == 0 ? fwd0 : (a == 1 ? fwd1 : fwd2);
+        const float og = a == 0 ? x_c : (a == 1 ? y_c : z_c);
+        const float bwd = fluid ? smp : (a == 0 ? fwd1 : (a == 1 ? 0.f : fa));     // Q1 pass-through of SL(fwd)
+        const bool fm = a == 0 ? fmx : (a == 1 ? fmy : fmz);
+        const bool skip = !fluid | !fm;
+        const float corr = skip ? fa : fa + half_s * (og - bwd);
+        out[a] = fmaxf(fminf(corr, mx), mn);
+        ok &= okc & (L.ok | !fluid);
+      }
+      if (border) { out[0] = 0.f; out[1] = 0.f; out[2] = 0.f; }
+      slow[r] = live & !border & !ok;
+      if (live) {
+        const size_t o = (size_t)k * g.HW + (size_t)j * g.W + i;
+        U_dst[sb3 + o] = out[0];
+        U_dst[sb3 + g.DHW + o] = out[1];
+        U_dst[sb3 + 2 * (size_t)g.DHW + o] = out[2];
+      }
+      any_slow |= slow[r];
+    }
+    if (__builtin_amdgcn_ballot_w64(any_slow) != 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        CellId c; c.b = m.b; c.k = k; c.j = m.j0 + 2 * w + r; c.i = i; c.valid = true;
+        if (slow[r]) sl_mac_bwd_clamp_cell_flat<true>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
+      }
+    }
+  };
+
+  int k = m.k_lo;
+  dma_plane(0, 0, k - 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  FB[0] = fluid_bits(0);
+  dma_plane(1, 1, k);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  FB[1] = fluid_bits(1);
+  dma_plane(2, 0, k + 1);
+  int fs = 0;
+  auto one = [&](auto rsl) __attribute__((always_inline)) {
+    constexpr int SC = decltype(rsl)::value;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    FB[2] = fluid_bits(fs);
+    if (k + 1 < m.k_hi) dma_plane((SC + 2) % 4, fs ^ 1, k + 2);
+    fs ^= 1;
+    step(rsl, k, FB[0], FB[1]);
+    FB[0] = FB[1]; FB[1] = FB[2];
+  };
+  while (true) {
+    one(AIC<1>{}); if (++k >= m.k_hi) break;
+    one(AIC<2>{}); if (++k >= m.k_hi) break;
+    one(AIC<3>{}); if (++k >= m.k_hi) break;
+    one(AIC<0>{}); if (++k >= m.k_hi) break;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
