@@ -595,6 +595,8 @@ inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H
 
 namespace fnx {
 
+size_t advect_fix_words(const GridDims& g) { return (size_t)g.B * g.D * g.H * ((g.W + 63) / 64); }
+
 #define DISPATCH3(IS3D, Q, SO, KERNEL, ...)                                                   \
   do {                                                                                        \
     if (IS3D) {                                                                               \
@@ -664,31 +666,46 @@ static void tile_launch_geometry(const GridDims& g, int& ntx, int& nty, int& zch
 }
 
 static void launch_fwd_tile(const GridDims& g, bool sample_outside, float dt, const float* rho, const float* U,
-                            const float* flags, float* rho_fwd, int* cell, float* U_fwd, hipStream_t s) {
+                            const float* flags, float* rho_fwd, int* cell, float* U_fwd, unsigned long long* fix_s,
+                            unsigned long long* fix_v, hipStream_t s) {
   int ntx, nty, zchunk; unsigned G;
   tile_launch_geometry(g, ntx, nty, zchunk, G);
-  if (sample_outside) advect3d_fwd_tile_kernel<true><<<dim3(G), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ntx, nty, zchunk);
-  else advect3d_fwd_tile_kernel<false><<<dim3(G), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ntx, nty, zchunk);
+  const unsigned nfix = (unsigned)(((size_t)g.B * g.KN * g.H * ntx + 255) / 256);
+  if (sample_outside) {
+    advect3d_fwd_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx, nty, zchunk);
+    advect3d_fwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
+  } else {
+    advect3d_fwd_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx, nty, zchunk);
+    advect3d_fwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
+  }
 }
 
 // MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches
 void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, bool sample_outside, float dt,
                          float half_s, const float* rho, const float* U, const float* flags, float* rho_fwd, int* cell,
-                         float* U_fwd, float* box, float* rho_dst, float* U_dst, hipStream_t s) {
+                         float* U_fwd, float* box, float* rho_dst, float* U_dst, unsigned long long* fix, hipStream_t s) {
+  // fix-up bitmaps of the tile kernels: 4 x (one 64-bit word per 64-cell row segment): fwd density, fwd velocity,
+  // bwd density, bwd velocity
+  const size_t nwords = advect_fix_words(g);
   const dim3 block(BX, BY);
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
   static const int march = [] { const char* e = getenv("FNX_ADVECT_MARCH"); return e ? atoi(e) : 3; }();   // A/B switch: bit 0 forward, bit 1 backward tile kernels
   if (is3d && !quirks && (march & 1) && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu)
-    launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, s);
+    launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix, fix + nwords, s);
   else
     DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
   if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
   if (is3d && !quirks && (march & 2) && (size_t)(g.KN + 2) * g.HW < 0x3fffffffu) {
     int ntx, nty, zchunk; unsigned G;
     tile_launch_geometry(g, ntx, nty, zchunk, G);
-    if (sample_outside) advect3d_bwd_scalar_tile_kernel<true><<<dim3(G), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, ntx, nty, zchunk);
-    else advect3d_bwd_scalar_tile_kernel<false><<<dim3(G), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, ntx, nty, zchunk);
-    advect3d_bwd_vel_tile_kernel<<<dim3(G), 256, 0, s>>>(g, dt, half_s, U, U_fwd, flags, U_dst, ntx, nty, zchunk);
+    unsigned long long* fb_s = fix + 2 * nwords;
+    unsigned long long* fb_v = fix + 3 * nwords;
+    if (sample_outside) advect3d_bwd_scalar_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
+    else advect3d_bwd_scalar_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
+    advect3d_bwd_vel_tile_kernel<<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, U, U_fwd, flags, U_dst, fb_v, ntx, nty, zchunk);
+    const unsigned nfix = (unsigned)(((size_t)g.B * g.KN * g.H * ntx + 255) / 256);
+    if (sample_outside) advect3d_bwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx);
+    else advect3d_bwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx);
     return;
   }
   DISPATCH3(is3d, quirks, sample_outside, advect_bwd_kernel,

@@ -17,15 +17,29 @@
 //     the fixed-offset neighbours (face velocities) are ds_reads at immediate offsets;
 //   * the flags become 3 bits x 4 rows per plane (fluid?) in registers, so the fluid-aware interpolation and the "is the
 //     traced cell blocked" test never touch memory.
-// A lane whose displacement is not below one cell, or whose trace ends in a non-fluid cell, takes the per-cell function
-// above under its exec mask (same arithmetic, global gathers): the kernels are bit-identical to the per-cell ones for
-// EVERY input, the fast path only has to be the common case.  Every expression below is the per-cell function's own,
-// operand for operand (fnx_device.h); only where the operands come from differs.
+// A lane whose displacement is not below one cell, or whose trace ends in a non-fluid cell, is not computed here: the
+// kernel records it in a bitmap (one 64-bit word per 64-cell row segment, written by every wave) and a fix-up launch of
+// the per-cell function above redoes exactly those cells from memory (one thread per word: a few us when nothing is
+// flagged).  The result is bit-identical to the per-cell kernels for EVERY input; the tile path only has
+// to be the common case.  Every expression below is the per-cell function's own, operand for operand (fnx_device.h);
+// only where the operands come from differs.  (Inlining the fallback into the tile kernels cost 40-280 bytes of scratch
+// per lane and a third of the instruction cache.)
 // (A first version kept the planes in registers and picked the corners with v_cndmask networks -- 38 selects + 18 DPP
 // moves per sample: 1540 VALU per two rows, slower than the gather kernel it replaced; the LDS does that selection for
 // the price of an address.)
 
-constexpr int ATR = 8;               // tile rows (2 per wave)
+constexpr int ATR = 8;               // tile rows
+#ifndef FNX_ATRPW
+#define FNX_ATRPW 2
+#endif
+constexpr int ATRPW = FNX_ATRPW;     // rows per wave (1: 8 waves per workgroup, 2: 4 waves)
+constexpr int ATNW = ATR / ATRPW;    // waves per workgroup
+// waves per SIMD the register budgets are sized for (workgroups per CU x ATNW / 4)
+#ifndef FNX_AT_WPS_FWD
+#define FNX_AT_WPS_FWD (ATRPW == 1 ? 4 : 3)
+#define FNX_AT_WPS_BS (ATRPW == 1 ? 6 : 3)
+#define FNX_AT_WPS_BV (ATRPW == 1 ? 4 : 2)
+#endif
 constexpr int ATRR = ATR + 2;        // rows held: j0-1 .. j0+8
 constexpr int ATP = 68;              // row pitch in floats: columns x0-1 .. x0+66 = 17 chunks of 16 bytes
 constexpr int ATNQ = (ATRR + 2) / 3; // DMA instructions per field-plane (3 rows each): 4
@@ -37,21 +51,19 @@ __device__ __forceinline__ ABuf amake_rsrc(const void* p, unsigned bytes) {
 }
 template <int N> struct AIC { static constexpr int value = N; };
 
-// lerp_setup (fnx_device.h) for a position whose base cell lands on {c-1, c} per axis.  The weights are lerp_setup's own
-// expressions minus its clamps: for a non-negative coordinate s1 = p - trunc(p) is in [0, 1) and s0 = 1 - s1 in (0, 1], and
-// clamp01 returns such a value unchanged (bit for bit).  n? = the base is c-1; ok = all three bases are in {c-1, c} (the
-// only case the tile path covers; then the coordinates are positive and lerp_setup's index clamps are no-ops too).
+// lerp_setup (fnx_device.h) for a position whose base cell lands on {c-1, c} per axis, c = (i, j, kg) given as floats.
+// With p' = p - 0.5 >= 0:  s1 = p' - (float)(int)p' is exactly fract(p') (the subtraction is exact, and so is v_fract for a
+// non-negative argument), s0 = 1 - s1, and lerp_setup's clamp01 returns values in [0, 1] unchanged, bit for bit; the base is
+// c-1 iff p' < c, and it is in {c-1, c} iff c-1 <= p' < c+1 (for a non-border cell c >= 1, so p' >= 0 follows and
+// lerp_setup's index clamps are no-ops too).  ok = all three hold: the only case the tile path covers.
 struct ALerp { float s0, s1, t0, t1, f0, f1; bool nx, ny, nz, ok; };
-__device__ __forceinline__ ALerp alerp(float px, float py, float pz, int i, int j, int kg) {
+__device__ __forceinline__ ALerp alerp(float px, float py, float pz, float fi, float fj, float fk) {
   ALerp L;
   px = px - 0.5f; py = py - 0.5f; pz = pz - 0.5f;
-  const int qx = (int)px, qy = (int)py, qz = (int)pz;
-  L.s1 = px - (float)qx; L.t1 = py - (float)qy; L.f1 = pz - (float)qz;
+  L.s1 = __builtin_amdgcn_fractf(px); L.t1 = __builtin_amdgcn_fractf(py); L.f1 = __builtin_amdgcn_fractf(pz);
   L.s0 = 1.f - L.s1; L.t0 = 1.f - L.t1; L.f0 = 1.f - L.f1;
-  const int rx = qx - i, ry = qy - j, rz = qz - kg;
-  L.nx = rx == -1; L.ny = ry == -1; L.nz = rz == -1;
-  // (a coordinate in (-1, 0) also truncates to 0 = c-1 for c = 1, but lerp_setup then clamps its negative weight: not this path)
-  L.ok = ((unsigned)(rx + 1) <= 1u) & ((unsigned)(ry + 1) <= 1u) & ((unsigned)(rz + 1) <= 1u) & (px >= 0.f) & (py >= 0.f) & (pz >= 0.f);
+  L.nx = px < fi; L.ny = py < fj; L.nz = pz < fk;
+  L.ok = (px >= fi - 1.f) & (px < fi + 1.f) & (py >= fj - 1.f) & (py < fj + 1.f) & (pz >= fk - 1.f) & (pz < fk + 1.f);
   return L;
 }
 
@@ -98,6 +110,9 @@ struct ATile {
   unsigned voff[ATNQ];           // per-lane byte offset of "my" row + chunk inside a plane, per DMA instruction
   bool dma_lane[ATNQ];
   unsigned hw;
+  int bx, ntx;
+  // fix-up bitmap word of my 64-cell row segment in plane k, row j
+  __device__ __forceinline__ size_t word(const GridDims& g, int k, int j) const { return (((size_t)b * g.D + k) * g.H + j) * ntx + bx; }
   __device__ __forceinline__ unsigned planeoff(const GridDims& g, int k) const {   // bytes, relative to plane k0
     const int kc = k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k);
     return (unsigned)(kc - k0) * hw * 4u;
@@ -117,6 +132,7 @@ __device__ __forceinline__ bool atile_setup(ATile& m, const GridDims& g, int ntx
   const int by = l1 % nty;
   m.b = l1 / nty;
   m.x = bx * 64 + m.lane;
+  m.bx = bx; m.ntx = ntx;
   m.j0 = by * ATR;
   m.k_lo = g.K0 + zc * zchunk;
   m.k_hi = min(m.k_lo + zchunk, g.K0 + g.KN);
@@ -150,12 +166,12 @@ __device__ __forceinline__ ABuf atile_rsrc(const ATile& m, const GridDims& g, co
   return amake_rsrc(chan + (size_t)m.k0 * g.HW, ncell * 4u);
 }
 
-// one field-plane (ATRR rows) -> LDS at `dst` ([ATRR][ATP] floats); the ATNQ instructions are dealt round-robin to
-// the four waves starting with wave `first`
+// field-plane number `first` of a plane (ATRR rows) -> LDS at `dst` ([ATRR][ATP] floats); a plane's instructions are dealt
+// round-robin to the workgroup's waves
 __device__ __forceinline__ void atile_dma(const ATile& m, const ABuf& rs, float* dst, unsigned plane_bytes, int first) {
 #pragma unroll
   for (int q = 0; q < ATNQ; ++q) {
-    if (((first + q) & 3) == m.w) {                       // wave-uniform
+    if (((first * ATNQ + q) % ATNW) == m.w) {             // wave-uniform: instruction n of the plane goes to wave n mod ATNW
       if (m.dma_lane[q])
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ALds)(dst + 3 * q * ATP), 16, m.voff[q] + plane_bytes, 0, 0, 0);
     }
@@ -163,213 +179,243 @@ __device__ __forceinline__ void atile_dma(const ATile& m, const ABuf& rs, float*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The march itself, shared by the three kernels.
+//
+// LDS: four ring slots (planes k-1, k, k+1 and the one in flight) of NF fields, plus two stages for the flags of the
+// plane that has just landed / is in flight.  They are SEPARATE __shared__ arrays, selected by compile-time phase: the
+// compiler cannot tell an LDS-DMA into one ring slot from the ds_reads of the others when they are one array, and then
+// parks an s_waitcnt vmcnt(0) between a step's DMA issue and its first read -- the whole transfer latency, every step.
+//
+// Synchronisation per step (one plane): s_barrier (everybody has left step k-1 and everybody's share of plane k+1 has
+// landed) -> fluid bits of plane k+1 -> issue the DMA of plane k+2 into the slot plane k-2 left -> compute plane k from
+// LDS into registers -> s_waitcnt vmcnt(0): my share of plane k+2 (issued a whole step's compute ago) -> store.  The row
+// stores of a step are thus never waited for before the NEXT step's wait, one step's compute later (a plain
+// __syncthreads() would fence them right away: vmcnt counts stores too).
+// ---------------------------------------------------------------------------------------------------
+constexpr int AFSZ = ATRR * ATP;                         // floats per field-plane
+
+#define ATILE_LDS(NF)                                                          \
+  __shared__ __attribute__((aligned(16))) float ring0[NF][AFSZ];               \
+  __shared__ __attribute__((aligned(16))) float ring1[NF][AFSZ];               \
+  __shared__ __attribute__((aligned(16))) float ring2[NF][AFSZ];               \
+  __shared__ __attribute__((aligned(16))) float ring3[NF][AFSZ];               \
+  __shared__ __attribute__((aligned(16))) float fst0[AFSZ];                    \
+  __shared__ __attribute__((aligned(16))) float fst1[AFSZ]
+
+__device__ __forceinline__ void atile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void atile_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// fluid bits of a plane for the rows hr0-1 .. hr0+ATRPW around my rows: bit 3*rr + (dx+1)
+__device__ __forceinline__ unsigned atile_fluid_bits(const float* fst, int hr0, int col) {
+  unsigned c = 0;
+  const float* f = fst + (hr0 - 1) * ATP + col - 1;
+#pragma unroll
+  for (int rr = 0; rr < ATRPW + 2; ++rr) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) c |= (f[rr * ATP + dx] == FNX_FLUID ? 1u : 0u) << (3 * rr + dx);
+  }
+  return c;
+}
+
+// body(k, fbm, fbc, fbp, ringM, ringC, ringP, pre_store): compute plane k from the three ring slots, call pre_store(), store.
+template <int NF, class Body>
+__device__ __forceinline__ void atile_march(const GridDims& g, const ATile& m, const ABuf (&rs)[NF], const ABuf& rs_f,
+                                            float (&ring0)[NF][AFSZ], float (&ring1)[NF][AFSZ], float (&ring2)[NF][AFSZ],
+                                            float (&ring3)[NF][AFSZ], float (&fst0)[AFSZ], float (&fst1)[AFSZ], Body body) {
+  const int hr0 = ATRPW * m.w + 1, col = m.lane + m.xs;
+  auto dma_plane = [&](float (&ring)[NF][AFSZ], float (&fst)[AFSZ], int k) {
+    const unsigned pb = m.planeoff(g, k);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) atile_dma(m, rs[f], ring[f], pb, f);
+    atile_dma(m, rs_f, fst, pb, NF);
+  };
+  unsigned FB0, FB1;
+  int k = m.k_lo;
+  // prologue: ring slot of plane p is (p - k_lo + 1) mod 4, its flags stage (p - k_lo + 1) mod 2
+  dma_plane(ring0, fst0, k - 1);
+  dma_plane(ring1, fst1, k);
+  atile_wait_vm();
+  atile_barrier();
+  FB0 = atile_fluid_bits(fst0, hr0, col);
+  FB1 = atile_fluid_bits(fst1, hr0, col);
+  atile_barrier();                                        // everybody has read fst0 before plane k+1's flags land in it
+  dma_plane(ring2, fst0, k + 1);
+  atile_wait_vm();
+  auto pre_store = [&]() { atile_wait_vm(); };
+#define ATILE_STEP(RM, RC, RP, RN, FP, FN)                                             \
+  {                                                                                     \
+    atile_barrier();                                                                    \
+    const unsigned FB2 = atile_fluid_bits(FP, hr0, col);                                \
+    if (k + 1 < m.k_hi) dma_plane(RN, FN, k + 2);                                       \
+    body(k, FB0, FB1, FB2, RM, RC, RP, pre_store);                                      \
+    FB0 = FB1; FB1 = FB2;                                                               \
+    if (++k >= m.k_hi) break;                                                           \
+  }
+  while (true) {
+    ATILE_STEP(ring0, ring1, ring2, ring3, fst0, fst1)
+    ATILE_STEP(ring1, ring2, ring3, ring0, fst1, fst0)
+    ATILE_STEP(ring2, ring3, ring0, ring1, fst0, fst1)
+    ATILE_STEP(ring3, ring0, ring1, ring2, fst1, fst0)
+  }
+#undef ATILE_STEP
+  atile_wait_vm();                                        // no LDS-DMA may outlive the wave
+}
+
+// the 8 corners of a sample of ring field f at the per-lane base cell (b = -1 where n? is set)
+template <int NF>
+__device__ __forceinline__ void atile_corners(const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ], const float (&rP)[NF][AFSZ],
+                                              int f, int rowcol0, bool nx, bool ny, bool nz, float (&c)[8]) {
+  const int rowcol = rowcol0 - (ny ? ATP : 0) - (nx ? 1 : 0);
+  const float* z0 = (nz ? &rM[f][0] : &rC[f][0]) + rowcol;
+  const float* z1 = (nz ? &rC[f][0] : &rP[f][0]) + rowcol;
+  c[0] = z0[0]; c[1] = z0[1]; c[2] = z0[ATP]; c[3] = z0[ATP + 1];
+  c[4] = z1[0]; c[5] = z1[1]; c[6] = z1[ATP]; c[7] = z1[ATP + 1];
+}
+
+// fluid bits of the 8 corners out of the 27 neighbourhood bits: base bit 9*(bz+1) + 3*(by+1) + (bx+1), offsets 0,1,3,4,9,10,12,13
+__device__ __forceinline__ unsigned atile_corner_bits(unsigned nb, const ALerp& L) {
+  const unsigned sh = (L.nz ? 0u : 9u) + (L.ny ? 0u : 3u) + (L.nx ? 0u : 1u);
+  const unsigned q = nb >> sh;
+  return (q & 1u) | ((q >> 1) & 1u) << 1 | ((q >> 3) & 1u) << 2 | ((q >> 4) & 1u) << 3 | ((q >> 9) & 1u) << 4 |
+         ((q >> 10) & 1u) << 5 | ((q >> 12) & 1u) << 6 | ((q >> 13) & 1u) << 7;
+}
+
+// line_trace from the centre of a non-border FLUID cell with displacement d (fnx_device.h): either it stays (length <= eps
+// / <= margin) or it is ONE step of length min(|d|, 1) that must end the loop and land in a fluid cell of the
+// neighbourhood (bits nb).  Returns the end point and whether this path covers the trace.
+__device__ __forceinline__ bool atile_trace(float d0, float d1, float d2, float ctrx, float ctry, float ctrz, int i, int j, int kg,
+                                            unsigned nb, float& p0, float& p1, float& p2) {
+  const float length = sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+  const bool stay = (length <= FNX_EPSILON) | (0.f >= length - FNX_HIT_MARGIN);
+  const float dir0 = d0 / length, dir1 = d1 / length, dir2 = d2 / length;
+  const float stp = fminf(length - 0.f, 1.f);
+  const float n0 = ctrx + dir0 * stp, n1 = ctry + dir1 * stp, n2 = ctrz + dir2 * stp;
+  const bool ends = stp >= length - FNX_HIT_MARGIN;                            // the second iteration's exit test
+  const int c0 = (int)n0 - i, c1 = (int)n1 - j, c2 = (int)n2 - kg;              // traced cell relative to this one
+  const bool near = ((unsigned)(c0 + 1) <= 2u) & ((unsigned)(c1 + 1) <= 2u) & ((unsigned)(c2 + 1) <= 2u);
+  const bool tfluid = (nb >> ((9 * (c2 + 1) + 3 * (c1 + 1) + (c0 + 1)) & 31)) & 1u;
+  p0 = stay ? ctrx : n0; p1 = stay ? ctry : n1; p2 = stay ? ctrz : n2;
+  return stay | (ends & near & tfluid);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Forward pass: sl_scalar_cell (density) + sl_mac_cell_flat (velocity) for the planes [K0, K0+KN).
+// Ring fields: rho, Ux, Uy, Uz.
 // ---------------------------------------------------------------------------------------------------
 template <bool SAMPLE_OUTSIDE>
-__global__ __launch_bounds__(256, 3) void advect3d_fwd_tile_kernel(GridDims g, float dt, const float* __restrict__ rho,
+__global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_kernel(GridDims g, float dt, const float* __restrict__ rho,
                                                                    const float* __restrict__ U,
                                                                    const float* __restrict__ flags,
                                                                    float* __restrict__ rho_fwd, int* __restrict__ cell_out,
-                                                                   float* __restrict__ U_fwd, int ntx, int nty, int zchunk) {
-  constexpr int NF = 4;                                   // ring fields: rho, Ux, Uy, Uz
-  constexpr int FSZ = ATRR * ATP;                         // floats per field-plane
-  __shared__ __attribute__((aligned(16))) float ring[4][NF][FSZ];
-  __shared__ __attribute__((aligned(16))) float fstage[2][FSZ];      // flags of the plane in flight / just landed
+                                                                   float* __restrict__ U_fwd,
+                                                                   unsigned long long* __restrict__ fix_s,
+                                                                   unsigned long long* __restrict__ fix_v, int ntx, int nty,
+                                                                   int zchunk) {
+  constexpr int NF = 4;
+  ATILE_LDS(NF);
   ATile m;
   if (!atile_setup(m, g, ntx, nty, zchunk)) return;
   const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
   const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
-  const ABuf rs_r = atile_rsrc(m, g, rho + sb1, after1), rs_x = atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
-             rs_y = atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), rs_z = atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3),
-             rs_f = atile_rsrc(m, g, flags + sb1, after1);
-  const int lane = m.lane, w = m.w;
-  auto dma_plane = [&](int slot, int fs, int k) {          // plane k -> ring slot `slot`, flags -> fstage[fs]
-    const unsigned pb = m.planeoff(g, k);
-    atile_dma(m, rs_r, ring[slot][0], pb, 0);
-    atile_dma(m, rs_x, ring[slot][1], pb, 1);
-    atile_dma(m, rs_y, ring[slot][2], pb, 2);
-    atile_dma(m, rs_z, ring[slot][3], pb, 3);
-    atile_dma(m, rs_f, fstage[fs], pb, 0);
-  };
-  // my two rows: held rows hr0 = 2w+1, 2w+2 (tile rows 2w, 2w+1); my LDS column: lane + xs
-  const int hr0 = 2 * w + 1;
-  const int col = lane + m.xs;
-  // fluid bits of a plane for my rows hr0-1 .. hr0+2: bit 3*rr + (dx+1)
-  auto fluid_bits = [&](int fs) {
-    unsigned c = 0;
-    const float* f = &fstage[fs][(hr0 - 1) * ATP + col - 1];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) c |= (f[rr * ATP + dx] == FNX_FLUID ? 1u : 0u) << (3 * rr + dx);
-    }
-    return c;
-  };
-
-  const int i = m.x;
+  const ABuf rs[NF] = { atile_rsrc(m, g, rho + sb1, after1), atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
+                        atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3) };
+  const ABuf rs_f = atile_rsrc(m, g, flags + sb1, after1);
+  const int lane = m.lane, w = m.w, i = m.x, hr0 = ATRPW * w + 1, col = lane + m.xs;
   const bool xin = i < g.W;
   const float ndt = -dt;
-  unsigned FB[3];                                         // fluid bits of planes k-1, k, k+1 (rotated by hand below)
 
-  // one output plane k.  SC = ring slot of plane k; planes k-1 / k+1 sit in slots (SC+3)%4 / (SC+1)%4.
-  auto step = [&](auto rsl, int k, unsigned fbm, unsigned fbc, unsigned fbp) __attribute__((always_inline)) {
-    constexpr int SC = decltype(rsl)::value, SM = (SC + 3) % 4, SP = (SC + 1) % 4;
+  auto body = [&](int k, unsigned fbm, unsigned fbc, unsigned fbp, const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ],
+                  const float (&rP)[NF][AFSZ], auto pre_store) __attribute__((always_inline)) {
     const int kg = k + g.zoff;
     const float ctrz = (float)kg + 0.5f;
     const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
-    bool slow_s[2], slow_v[2];
-    bool any_slow = false;
+    float o_rho[ATRPW], o_u[ATRPW][3]; int o_cell[ATRPW];
+    unsigned long long ws[ATRPW], wv[ATRPW];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = m.j0 + 2 * w + r;
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
       const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
-      const float ctrx = (float)i + 0.5f, ctry = (float)j + 0.5f;
-      // LDS word of field f, plane slot s, at my cell + (dy, dx)
-      auto at = [&](int f, int s, int dy, int dx) { return ring[s][f][(hr0 + r + dy) * ATP + col + dx]; };
+      const float fi = (float)i, fj = (float)j, fk = (float)kg;
+      const float ctrx = fi + 0.5f, ctry = fj + 0.5f;
+      const int rc0 = (hr0 + r) * ATP + col;                          // my cell in a field-plane
       const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
       // 27 fluid bits of the neighbourhood: bit 9*(dz+1) + 3*(dy+1) + (dx+1)
       const unsigned nb = ((fbm >> (3 * r)) & 0x1ffu) | (((fbc >> (3 * r)) & 0x1ffu) << 9) | (((fbp >> (3 * r)) & 0x1ffu) << 18);
-      // the 8 corners of a sample of field f: per-lane LDS offsets of the base cell on the two z levels
-      auto corners = [&](int f, const ALerp& L, float (&c)[8]) {
-        const int rowcol = (hr0 + r - (L.ny ? 1 : 0)) * ATP + col - (L.nx ? 1 : 0);
-        const float* z0 = (L.nz ? &ring[SM][f][0] : &ring[SC][f][0]) + rowcol;
-        const float* z1 = (L.nz ? &ring[SC][f][0] : &ring[SP][f][0]) + rowcol;
-        c[0] = z0[0]; c[1] = z0[1]; c[2] = z0[ATP]; c[3] = z0[ATP + 1];
-        c[4] = z1[0]; c[5] = z1[1]; c[6] = z1[ATP]; c[7] = z1[ATP + 1];
-      };
 
       // ================= density: sl_scalar_cell =================
-      const float x_c = at(1, SC, 0, 0), y_c = at(2, SC, 0, 0), z_c = at(3, SC, 0, 0);
-      const float x_r = at(1, SC, 0, 1), y_u = at(2, SC, 1, 0), z_f = at(3, SP, 0, 0);
-      const float cen0 = 0.5f * (x_c + x_r);                                    // get_centered
-      const float cen1 = 0.5f * (y_c + y_u);
-      const float cen2 = 0.5f * (z_c + z_f);
-      const float d0 = ndt * cen0, d1 = ndt * cen1, d2 = ndt * cen2;
-      // line_trace from the centre of a fluid cell (fnx_device.h): either it stays (length <= eps / <= margin) or it is ONE
-      // step of length min(|d|, 1) that must end the loop and land in a fluid cell of the neighbourhood
-      const float length = sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
-      const bool stay = (length <= FNX_EPSILON) | (0.f >= length - FNX_HIT_MARGIN);
-      const float dir0 = d0 / length, dir1 = d1 / length, dir2 = d2 / length;
-      const float stp = fminf(length - 0.f, 1.f);
-      const float n0 = ctrx + dir0 * stp, n1 = ctry + dir1 * stp, n2 = ctrz + dir2 * stp;
-      const bool ends = stp >= length - FNX_HIT_MARGIN;                        // the second iteration's exit test
-      const int c0 = (int)n0 - i, c1 = (int)n1 - j, c2 = (int)n2 - kg;          // traced cell relative to this one
-      const bool near = ((unsigned)(c0 + 1) <= 2u) & ((unsigned)(c1 + 1) <= 2u) & ((unsigned)(c2 + 1) <= 2u);
-      const bool tfluid = (nb >> ((9 * (c2 + 1) + 3 * (c1 + 1) + (c0 + 1)) & 31)) & 1u;
-      const bool moved_ok = ends & near & tfluid;
-      const float p0 = stay ? ctrx : n0, p1 = stay ? ctry : n1, p2 = stay ? ctrz : n2;
-      const ALerp Ls = alerp(p0, p1, p2, i, j, kg);
+      const float x_c = rC[1][rc0], y_c = rC[2][rc0], z_c = rC[3][rc0];
+      const float x_r = rC[1][rc0 + 1], y_u = rC[2][rc0 + ATP], z_f = rP[3][rc0];
+      const float cen0 = 0.5f * (x_c + x_r), cen1 = 0.5f * (y_c + y_u), cen2 = 0.5f * (z_c + z_f);   // get_centered
+      float p0, p1, p2;
+      const bool traced = atile_trace(ndt * cen0, ndt * cen1, ndt * cen2, ctrx, ctry, ctrz, i, j, kg, nb, p0, p1, p2);
+      const ALerp Ls = alerp(p0, p1, p2, fi, fj, fk);
       float cs[8];
-      corners(0, Ls, cs);
-      float smp;
-      if (SAMPLE_OUTSIDE) {
-        smp = atrilin(cs, Ls);
-      } else {
-        // fluid bits of the 8 corners: base bit 9*(bz+1) + 3*(by+1) + (bx+1), corner offsets 0,1,3,4,9,10,12,13
-        const unsigned sh = (Ls.nz ? 0u : 9u) + (Ls.ny ? 0u : 3u) + (Ls.nx ? 0u : 1u);
-        const unsigned q = nb >> sh;
-        const unsigned fb = (q & 1u) | ((q >> 1) & 1u) << 1 | ((q >> 3) & 1u) << 2 | ((q >> 4) & 1u) << 3 | ((q >> 9) & 1u) << 4 |
-                            ((q >> 10) & 1u) << 5 | ((q >> 12) & 1u) << 6 | ((q >> 13) & 1u) << 7;
-        smp = atrilin_fluid(cs, fb, Ls);
-      }
-      const float rho_c = at(0, SC, 0, 0);
-      const float val = border ? 0.f : (fluid ? smp : rho_c);
+      atile_corners<NF>(rM, rC, rP, 0, rc0, Ls.nx, Ls.ny, Ls.nz, cs);
+      // wave-uniform shortcut: when every lane that uses its sample has an all-fluid neighbourhood, interpol_with_fluid IS the
+      // plain trilinear expression (every lerp1d_fluid takes its a*ta + b*tb branch): same bits, a third of the work
+      const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb != 0x7ffffffu)) == 0;
+      const float smp = allfluid ? atrilin(cs, Ls) : atrilin_fluid(cs, atile_corner_bits(nb, Ls), Ls);
+      const float rho_c = rC[0][rc0];
+      o_rho[r] = border ? 0.f : (fluid ? smp : rho_c);
       const bool keep = border | !fluid;                   // p = ctr
       const float q0 = keep ? ctrx : p0, q1 = keep ? ctry : p1, q2 = keep ? ctrz : p2;
       const int ci = clampi((int)q0, 0, g.W - 1), cj = clampi((int)q1, 0, g.H - 1);
       const int ck = clampi((int)q2, 0, g.Dglob - 1) - g.zoff;
-      const int cell = (ck + 1) * g.HW + cj * g.W + ci;
-      slow_s[r] = !keep & (!(stay | moved_ok) | !Ls.ok);
+      o_cell[r] = (ck + 1) * g.HW + cj * g.W + ci;
+      const bool live = xin & (j < g.H);
+      ws[r] = __builtin_amdgcn_ballot_w64(live & !keep & (!traced | !Ls.ok));
 
       // ================= velocity: sl_mac_cell_flat =================
       // get_at_mac<true, false, 0/1/2> (fnx_device.h), operand for operand
       float v0[3], v1[3], v2[3];
       v0[0] = x_c;
-      v0[1] = 0.25f * (((y_c + at(2, SC, 0, -1)) + y_u) + at(2, SC, 1, -1));
-      v0[2] = 0.25f * (((z_c + at(3, SC, 0, -1)) + z_f) + at(3, SP, 0, -1));
-      v1[0] = 0.25f * (((x_c + at(1, SC, -1, 0)) + x_r) + at(1, SC, -1, 1));
+      v0[1] = 0.25f * (((y_c + rC[2][rc0 - 1]) + y_u) + rC[2][rc0 + ATP - 1]);
+      v0[2] = 0.25f * (((z_c + rC[3][rc0 - 1]) + z_f) + rP[3][rc0 - 1]);
+      v1[0] = 0.25f * (((x_c + rC[1][rc0 - ATP]) + x_r) + rC[1][rc0 - ATP + 1]);
       v1[1] = y_c;
-      v1[2] = 0.25f * (((z_c + at(3, SC, -1, 0)) + z_f) + at(3, SP, -1, 0));
-      v2[0] = 0.25f * (((x_c + at(1, SM, 0, 0)) + x_r) + at(1, SM, 0, 1));
-      v2[1] = 0.25f * (((y_c + at(2, SM, 0, 0)) + y_u) + at(2, SM, 1, 0));
+      v1[2] = 0.25f * (((z_c + rC[3][rc0 - ATP]) + z_f) + rP[3][rc0 - ATP]);
+      v2[0] = 0.25f * (((x_c + rM[1][rc0]) + x_r) + rM[1][rc0 + 1]);
+      v2[1] = 0.25f * (((y_c + rM[2][rc0]) + y_u) + rM[2][rc0 + ATP]);
       v2[2] = z_c;
-      float uo[3];
       bool okv = true;
       {
-        const ALerp L = alerp(ctrx + v0[0] * ndt, ctry + v0[1] * ndt, ctrz + v0[2] * ndt, i, j, kg);
-        float c[8]; corners(1, L, c);
-        uo[0] = fluid ? atrilin(c, L) : y_c;              // non-fluid cell: channel 1 into channel 0 (:413-416)
+        const ALerp L = alerp(ctrx + v0[0] * ndt, ctry + v0[1] * ndt, ctrz + v0[2] * ndt, fi, fj, fk);
+        float c[8]; atile_corners<NF>(rM, rC, rP, 1, rc0, L.nx, L.ny, L.nz, c);
+        o_u[r][0] = fluid ? atrilin(c, L) : y_c;            // non-fluid cell: channel 1 into channel 0 (:413-416)
         okv &= L.ok;
       }
       {
-        const ALerp L = alerp(ctrx + v1[0] * ndt, ctry + v1[1] * ndt, ctrz + v1[2] * ndt, i, j, kg);
-        float c[8]; corners(2, L, c);
-        uo[1] = fluid ? atrilin(c, L) : 0.f;
+        const ALerp L = alerp(ctrx + v1[0] * ndt, ctry + v1[1] * ndt, ctrz + v1[2] * ndt, fi, fj, fk);
+        float c[8]; atile_corners<NF>(rM, rC, rP, 2, rc0, L.nx, L.ny, L.nz, c);
+        o_u[r][1] = fluid ? atrilin(c, L) : 0.f;
         okv &= L.ok;
       }
       {
-        const ALerp L = alerp(ctrx + v2[0] * ndt, ctry + v2[1] * ndt, ctrz + v2[2] * ndt, i, j, kg);
-        float c[8]; corners(3, L, c);
-        uo[2] = fluid ? atrilin(c, L) : z_c;
+        const ALerp L = alerp(ctrx + v2[0] * ndt, ctry + v2[1] * ndt, ctrz + v2[2] * ndt, fi, fj, fk);
+        float c[8]; atile_corners<NF>(rM, rC, rP, 3, rc0, L.nx, L.ny, L.nz, c);
+        o_u[r][2] = fluid ? atrilin(c, L) : z_c;
         okv &= L.ok;
       }
-      slow_v[r] = !border & fluid & !okv;
-      if (border) { uo[0] = 0.f; uo[1] = 0.f; uo[2] = 0.f; }
-
+      wv[r] = __builtin_amdgcn_ballot_w64(live & !border & fluid & !okv);
+      if (border) { o_u[r][0] = 0.f; o_u[r][1] = 0.f; o_u[r][2] = 0.f; }
+    }
+    pre_store();
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
       if (xin && j < g.H) {
         const size_t o = (size_t)k * g.HW + (size_t)j * g.W + i;
-        rho_fwd[sb1 + o] = val;
-        cell_out[sb1 + o] = cell;
-        U_fwd[sb3 + o] = uo[0];
-        U_fwd[sb3 + g.DHW + o] = uo[1];
-        U_fwd[sb3 + 2 * (size_t)g.DHW + o] = uo[2];
-      } else {
-        slow_s[r] = false; slow_v[r] = false;
+        rho_fwd[sb1 + o] = o_rho[r];
+        cell_out[sb1 + o] = o_cell[r];
+        U_fwd[sb3 + o] = o_u[r][0];
+        U_fwd[sb3 + g.DHW + o] = o_u[r][1];
+        U_fwd[sb3 + 2 * (size_t)g.DHW + o] = o_u[r][2];
       }
-      any_slow |= slow_s[r] | slow_v[r];
-    }
-    // lanes the neighbourhood path does not cover (|displacement| >= 1 cell, trace into a non-fluid cell): the per-cell
-    // function redoes them from memory
-    if (__builtin_amdgcn_ballot_w64(any_slow) != 0) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        CellId c; c.b = m.b; c.k = k; c.j = m.j0 + 2 * w + r; c.i = i; c.valid = true;
-        if (slow_s[r]) sl_scalar_cell<true, false, SAMPLE_OUTSIDE>(g, c, dt, rho, U, flags, rho_fwd, cell_out);
-        if (slow_v[r]) sl_mac_cell_flat<true>(g, c, dt, U, U, flags, U_fwd);
-      }
+      // lanes the neighbourhood path does not cover (|displacement| >= 1 cell, trace into a non-fluid cell) go to the fix-up
+      if (lane == 0 && j < g.H) { const size_t wi = m.word(g, k, j); fix_s[wi] = ws[r]; fix_v[wi] = wv[r]; }
     }
   };
-
-  // ---- prologue.  Ring slot of plane k: (k - k_lo + 1) mod 4, so the march always enters at the same phase.
-  int k = m.k_lo;
-  dma_plane(0, 0, k - 1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): my share of the plane has landed
-  __syncthreads();                                        // ... and everybody else's
-  FB[0] = fluid_bits(0);
-  dma_plane(1, 1, k);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  FB[1] = fluid_bits(1);
-  dma_plane(2, 0, k + 1);                                 // (everybody read fstage[0] before the barrier above)
-  int fs = 0;                                             // fstage holding the flags of plane k+1
-  // one step: plane k+1 lands (slot SC+1), plane k+2 is requested (slot SC+2, the slot plane k-2 left), plane k is computed
-  auto one = [&](auto rsl) __attribute__((always_inline)) {
-    constexpr int SC = decltype(rsl)::value;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // my DMA share of plane k+1
-    __syncthreads();                                      // all of plane k+1 is in LDS; everybody has left step k-1
-    FB[2] = fluid_bits(fs);
-    if (k + 1 < m.k_hi) dma_plane((SC + 2) % 4, fs ^ 1, k + 2);
-    fs ^= 1;
-    step(rsl, k, FB[0], FB[1], FB[2]);
-    FB[0] = FB[1]; FB[1] = FB[2];
-  };
-  while (true) {
-    one(AIC<1>{}); if (++k >= m.k_hi) break;
-    one(AIC<2>{}); if (++k >= m.k_hi) break;
-    one(AIC<3>{}); if (++k >= m.k_hi) break;
-    one(AIC<0>{}); if (++k >= m.k_hi) break;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);                     // no LDS-DMA may outlive the wave
+  atile_march<NF>(g, m, rs, rs_f, ring0, ring1, ring2, ring3, fst0, fst1, body);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -377,251 +423,155 @@ __global__ __launch_bounds__(256, 3) void advect3d_fwd_tile_kernel(GridDims g, f
 // Ring fields: rho_fwd, Ux, Uy, Uz.  rho, the traced cell and its clamp bounds are per-cell global loads.
 // ---------------------------------------------------------------------------------------------------
 template <bool SAMPLE_OUTSIDE>
-__global__ __launch_bounds__(256, 3) void advect3d_bwd_scalar_tile_kernel(GridDims g, float dt, float half_s,
+__global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_BS) void advect3d_bwd_scalar_tile_kernel(GridDims g, float dt, float half_s,
                                                                           const float* __restrict__ rho,
                                                                           const float* __restrict__ rho_fwd,
                                                                           const int* __restrict__ cell_in,
                                                                           const float* __restrict__ U,
                                                                           const float* __restrict__ flags,
                                                                           const float2* __restrict__ box,
-                                                                          float* __restrict__ rho_dst, int ntx, int nty, int zchunk) {
+                                                                          float* __restrict__ rho_dst,
+                                                                          unsigned long long* __restrict__ fix, int ntx, int nty,
+                                                                          int zchunk) {
   constexpr int NF = 4;
-  constexpr int FSZ = ATRR * ATP;
-  __shared__ __attribute__((aligned(16))) float ring[4][NF][FSZ];
-  __shared__ __attribute__((aligned(16))) float fstage[2][FSZ];
+  ATILE_LDS(NF);
   ATile m;
   if (!atile_setup(m, g, ntx, nty, zchunk)) return;
   const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
   const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
-  const ABuf rs_r = atile_rsrc(m, g, rho_fwd + sb1, after1), rs_x = atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
-             rs_y = atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), rs_z = atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3),
-             rs_f = atile_rsrc(m, g, flags + sb1, after1);
-  const int lane = m.lane, w = m.w;
-  auto dma_plane = [&](int slot, int fs, int k) {
-    const unsigned pb = m.planeoff(g, k);
-    atile_dma(m, rs_r, ring[slot][0], pb, 0);
-    atile_dma(m, rs_x, ring[slot][1], pb, 1);
-    atile_dma(m, rs_y, ring[slot][2], pb, 2);
-    atile_dma(m, rs_z, ring[slot][3], pb, 3);
-    atile_dma(m, rs_f, fstage[fs], pb, 0);
-  };
-  const int hr0 = 2 * w + 1;
-  const int col = lane + m.xs;
-  auto fluid_bits = [&](int fs) {
-    unsigned c = 0;
-    const float* f = &fstage[fs][(hr0 - 1) * ATP + col - 1];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) c |= (f[rr * ATP + dx] == FNX_FLUID ? 1u : 0u) << (3 * rr + dx);
-    }
-    return c;
-  };
-  const int i = m.x;
+  const ABuf rs[NF] = { atile_rsrc(m, g, rho_fwd + sb1, after1), atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
+                        atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3) };
+  const ABuf rs_f = atile_rsrc(m, g, flags + sb1, after1);
+  const int lane = m.lane, w = m.w, i = m.x, hr0 = ATRPW * w + 1, col = lane + m.xs;
   const bool xin = i < g.W;
-  unsigned FB[3];
 
-  auto step = [&](auto rsl, int k, unsigned fbm, unsigned fbc, unsigned fbp) __attribute__((always_inline)) {
-    constexpr int SC = decltype(rsl)::value, SM = (SC + 3) % 4, SP = (SC + 1) % 4;
+  auto body = [&](int k, unsigned fbm, unsigned fbc, unsigned fbp, const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ],
+                  const float (&rP)[NF][AFSZ], auto pre_store) __attribute__((always_inline)) {
     const int kg = k + g.zoff;
     const float ctrz = (float)kg + 0.5f;
     const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
-    bool slow[2];
-    bool any_slow = false;
+    // per-cell global operands of both rows first (clamped addresses for the lanes that store nothing); the clamp bounds
+    // hang off the traced cell
+    float src[ATRPW]; int cell[ATRPW]; float2 bb[ATRPW]; bool inslab[ATRPW]; size_t oo[ATRPW];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = m.j0 + 2 * w + r;
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
+      oo[r] = (size_t)k * g.HW + (size_t)(j < g.H ? j : g.H - 1) * g.W + (xin ? i : g.W - 1);
+      src[r] = rho[sb1 + oo[r]];
+      cell[r] = cell_in[sb1 + oo[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      inslab[r] = (cell[r] >= g.HW) & (cell[r] < g.HW + g.DHW);
+      bb[r] = box[sb1 + (size_t)(inslab[r] ? cell[r] - g.HW : 0)];
+    }
+    float o_d[ATRPW]; unsigned long long ws[ATRPW];
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
       const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
       const bool live = xin & (j < g.H);
-      const float ctrx = (float)i + 0.5f, ctry = (float)j + 0.5f;
-      auto at = [&](int f, int s, int dy, int dx) { return ring[s][f][(hr0 + r + dy) * ATP + col + dx]; };
+      const float fi = (float)i, fj = (float)j, fk = (float)kg;
+      const float ctrx = fi + 0.5f, ctry = fj + 0.5f;
+      const int rc0 = (hr0 + r) * ATP + col;
       const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
       const unsigned nb = ((fbm >> (3 * r)) & 0x1ffu) | (((fbc >> (3 * r)) & 0x1ffu) << 9) | (((fbp >> (3 * r)) & 0x1ffu) << 18);
-      // per-cell global operands, issued first (clamped addresses for the lanes that store nothing)
-      const size_t o = (size_t)k * g.HW + (size_t)(j < g.H ? j : g.H - 1) * g.W + (xin ? i : g.W - 1);
-      const float src = rho[sb1 + o];
-      const int cell = cell_in[sb1 + o];
-      const bool inslab = (cell >= g.HW) & (cell < g.HW + g.DHW);
-      const float2 bb = box[sb1 + (size_t)(inslab ? cell - g.HW : 0)];
-
-      const float f = at(0, SC, 0, 0);
-      const float x_c = at(1, SC, 0, 0), y_c = at(2, SC, 0, 0), z_c = at(3, SC, 0, 0);
-      const float cen0 = 0.5f * (x_c + at(1, SC, 0, 1));
-      const float cen1 = 0.5f * (y_c + at(2, SC, 1, 0));
-      const float cen2 = 0.5f * (z_c + at(3, SP, 0, 0));
-      const float d0 = dt * cen0, d1 = dt * cen1, d2 = dt * cen2;           // (-ndt) * cen with ndt = -dt
-      const float length = sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
-      const bool stay = (length <= FNX_EPSILON) | (0.f >= length - FNX_HIT_MARGIN);
-      const float dir0 = d0 / length, dir1 = d1 / length, dir2 = d2 / length;
-      const float stp = fminf(length - 0.f, 1.f);
-      const float n0 = ctrx + dir0 * stp, n1 = ctry + dir1 * stp, n2 = ctrz + dir2 * stp;
-      const bool ends = stp >= length - FNX_HIT_MARGIN;
-      const int c0 = (int)n0 - i, c1 = (int)n1 - j, c2 = (int)n2 - kg;
-      const bool near = ((unsigned)(c0 + 1) <= 2u) & ((unsigned)(c1 + 1) <= 2u) & ((unsigned)(c2 + 1) <= 2u);
-      const bool tfluid = (nb >> ((9 * (c2 + 1) + 3 * (c1 + 1) + (c0 + 1)) & 31)) & 1u;
-      const bool moved_ok = ends & near & tfluid;
-      const float p0 = stay ? ctrx : n0, p1 = stay ? ctry : n1, p2 = stay ? ctrz : n2;
-      const ALerp Ls = alerp(p0, p1, p2, i, j, kg);
+      const float f = rC[0][rc0];
+      const float cen0 = 0.5f * (rC[1][rc0] + rC[1][rc0 + 1]);
+      const float cen1 = 0.5f * (rC[2][rc0] + rC[2][rc0 + ATP]);
+      const float cen2 = 0.5f * (rC[3][rc0] + rP[3][rc0]);
+      float p0, p1, p2;                                               // displacement (-ndt) * cen with ndt = -dt
+      const bool traced = atile_trace(dt * cen0, dt * cen1, dt * cen2, ctrx, ctry, ctrz, i, j, kg, nb, p0, p1, p2);
+      const ALerp Ls = alerp(p0, p1, p2, fi, fj, fk);
       float cs[8];
-      {
-        const int rowcol = (hr0 + r - (Ls.ny ? 1 : 0)) * ATP + col - (Ls.nx ? 1 : 0);
-        const float* z0 = (Ls.nz ? &ring[SM][0][0] : &ring[SC][0][0]) + rowcol;
-        const float* z1 = (Ls.nz ? &ring[SC][0][0] : &ring[SP][0][0]) + rowcol;
-        cs[0] = z0[0]; cs[1] = z0[1]; cs[2] = z0[ATP]; cs[3] = z0[ATP + 1];
-        cs[4] = z1[0]; cs[5] = z1[1]; cs[6] = z1[ATP]; cs[7] = z1[ATP + 1];
-      }
-      float smp;
-      if (SAMPLE_OUTSIDE) {
-        smp = atrilin(cs, Ls);
-      } else {
-        const unsigned sh = (Ls.nz ? 0u : 9u) + (Ls.ny ? 0u : 3u) + (Ls.nx ? 0u : 1u);
-        const unsigned q = nb >> sh;
-        const unsigned fb = (q & 1u) | ((q >> 1) & 1u) << 1 | ((q >> 3) & 1u) << 2 | ((q >> 4) & 1u) << 3 | ((q >> 9) & 1u) << 4 |
-                            ((q >> 10) & 1u) << 5 | ((q >> 12) & 1u) << 6 | ((q >> 13) & 1u) << 7;
-        smp = atrilin_fluid(cs, fb, Ls);
-      }
+      atile_corners<NF>(rM, rC, rP, 0, rc0, Ls.nx, Ls.ny, Ls.nz, cs);
+      const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb != 0x7ffffffu)) == 0;   // (see the forward kernel)
+      const float smp = allfluid ? atrilin(cs, Ls) : atrilin_fluid(cs, atile_corner_bits(nb, Ls), Ls);
       const float bwd = border ? 0.f : (fluid ? smp : f);
       float d = f;
-      if (fluid) d = f + half_s * (src - bwd);             // applied on border cells too (reference :371)
-      const float mn = bb.x, mx = bb.y;
+      if (fluid) d = f + half_s * (src[r] - bwd);          // applied on border cells too (reference :371)
+      const float mn = bb[r].x, mx = bb[r].y;
       const bool any = !(mn != mn);
       const float dc = any ? fmaxf(mn, fminf(mx, d)) : f;
-      if (!border) d = dc;
-      slow[r] = live & !border & ((fluid & (!(stay | moved_ok) | !Ls.ok)) | !inslab);
-      if (live) rho_dst[sb1 + o] = d;
-      any_slow |= slow[r];
+      o_d[r] = border ? d : dc;
+      ws[r] = __builtin_amdgcn_ballot_w64(live & !border & ((fluid & (!traced | !Ls.ok)) | !inslab[r]));
     }
-    if (__builtin_amdgcn_ballot_w64(any_slow) != 0) {
+    pre_store();
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        CellId c; c.b = m.b; c.k = k; c.j = m.j0 + 2 * w + r; c.i = i; c.valid = true;
-        if (slow[r]) sl_scalar_bwd_clamp_cell<true, false, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, box, rho_dst);
-      }
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
+      if (xin && j < g.H) rho_dst[sb1 + oo[r]] = o_d[r];
+      if (lane == 0 && j < g.H) fix[m.word(g, k, j)] = ws[r];
     }
   };
-
-  int k = m.k_lo;
-  dma_plane(0, 0, k - 1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  FB[0] = fluid_bits(0);
-  dma_plane(1, 1, k);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  FB[1] = fluid_bits(1);
-  dma_plane(2, 0, k + 1);
-  int fs = 0;
-  auto one = [&](auto rsl) __attribute__((always_inline)) {
-    constexpr int SC = decltype(rsl)::value;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    FB[2] = fluid_bits(fs);
-    if (k + 1 < m.k_hi) dma_plane((SC + 2) % 4, fs ^ 1, k + 2);
-    fs ^= 1;
-    step(rsl, k, FB[0], FB[1], FB[2]);
-    FB[0] = FB[1]; FB[1] = FB[2];
-  };
-  while (true) {
-    one(AIC<1>{}); if (++k >= m.k_hi) break;
-    one(AIC<2>{}); if (++k >= m.k_hi) break;
-    one(AIC<3>{}); if (++k >= m.k_hi) break;
-    one(AIC<0>{}); if (++k >= m.k_hi) break;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  atile_march<NF>(g, m, rs, rs_f, ring0, ring1, ring2, ring3, fst0, fst1, body);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Backward pass, velocity: sl_mac_bwd_clamp_cell_flat<true> (self-advection: orig == U) for the planes [K0, K0+KN).
-// Ring fields: U_fwd x,y,z (sampled), U x,y,z (face velocities, clamp boxes).
+// Ring fields: U_fwd x,y,z (sampled), U x,y,z (face velocities, clamp boxes): 71 KB of LDS, two workgroups per CU.
+// (One component per workgroup with four ring fields and three workgroups per CU was measured: 3 x 138 us against 325 us,
+// the per-plane overheads do not shrink with the work.)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void advect3d_bwd_vel_tile_kernel(GridDims g, float dt, float half_s,
+__global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_BV) void advect3d_bwd_vel_tile_kernel(GridDims g, float dt, float half_s,
                                                                        const float* __restrict__ U,
                                                                        const float* __restrict__ U_fwd,
                                                                        const float* __restrict__ flags,
-                                                                       float* __restrict__ U_dst, int ntx, int nty, int zchunk) {
+                                                                       float* __restrict__ U_dst,
+                                                                       unsigned long long* __restrict__ fix, int ntx, int nty,
+                                                                       int zchunk) {
   constexpr int NF = 6;
-  constexpr int FSZ = ATRR * ATP;
-  __shared__ __attribute__((aligned(16))) float ring[4][NF][FSZ];
-  __shared__ __attribute__((aligned(16))) float fstage[2][FSZ];
+  ATILE_LDS(NF);
   ATile m;
   if (!atile_setup(m, g, ntx, nty, zchunk)) return;
   const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
   const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
-  ABuf rs[NF];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    rs[a] = atile_rsrc(m, g, U_fwd + sb3 + (size_t)a * g.DHW, after3 + (size_t)(2 - a) * g.DHW);
-    rs[3 + a] = atile_rsrc(m, g, U + sb3 + (size_t)a * g.DHW, after3 + (size_t)(2 - a) * g.DHW);
-  }
+  const ABuf rs[NF] = { atile_rsrc(m, g, U_fwd + sb3, after3 + 2 * (size_t)g.DHW), atile_rsrc(m, g, U_fwd + sb3 + g.DHW, after3 + g.DHW),
+                        atile_rsrc(m, g, U_fwd + sb3 + 2 * (size_t)g.DHW, after3), atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
+                        atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3) };
   const ABuf rs_f = atile_rsrc(m, g, flags + sb1, after1);
-  const int lane = m.lane, w = m.w;
-  auto dma_plane = [&](int slot, int fs, int k) {
-    const unsigned pb = m.planeoff(g, k);
-#pragma unroll
-    for (int f = 0; f < NF; ++f) atile_dma(m, rs[f], ring[slot][f], pb, f);
-    atile_dma(m, rs_f, fstage[fs], pb, 2);
-  };
-  const int hr0 = 2 * w + 1;
-  const int col = lane + m.xs;
-  auto fluid_bits = [&](int fs) {
-    unsigned c = 0;
-    const float* f = &fstage[fs][(hr0 - 1) * ATP + col - 1];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) c |= (f[rr * ATP + dx] == FNX_FLUID ? 1u : 0u) << (3 * rr + dx);
-    }
-    return c;
-  };
-  const int i = m.x;
+  const int lane = m.lane, w = m.w, i = m.x, hr0 = ATRPW * w + 1, col = lane + m.xs;
   const bool xin = i < g.W;
-  unsigned FB[3];
 
-  auto step = [&](auto rsl, int k, unsigned fbm, unsigned fbc) __attribute__((always_inline)) {
-    constexpr int SC = decltype(rsl)::value, SM = (SC + 3) % 4, SP = (SC + 1) % 4;
+  auto body = [&](int k, unsigned fbm, unsigned fbc, unsigned fbp, const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ],
+                  const float (&rP)[NF][AFSZ], auto pre_store) __attribute__((always_inline)) {
+    (void)fbp;
     const int kg = k + g.zoff;
     const float ctrz = (float)kg + 0.5f, posz = (float)kg;
     const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
-    bool slow[2];
-    bool any_slow = false;
+    float o_u[ATRPW][3]; unsigned long long ws[ATRPW];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = m.j0 + 2 * w + r;
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
       const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
       const bool live = xin & (j < g.H);
-      const float ctrx = (float)i + 0.5f, ctry = (float)j + 0.5f, posx = (float)i, posy = (float)j;
-      auto at = [&](int f, int s, int dy, int dx) { return ring[s][f][(hr0 + r + dy) * ATP + col + dx]; };
+      const float fi = (float)i, fj = (float)j, fk = (float)kg;
+      const float ctrx = fi + 0.5f, ctry = fj + 0.5f, posx = fi, posy = fj;
+      const int rc0 = (hr0 + r) * ATP + col;
       const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
       // flags of the -1 neighbours along x, y, z (chk[a] is true for every non-border cell)
       const bool fmx = (fbc >> (3 * (r + 1) + 0)) & 1u, fmy = (fbc >> (3 * r + 1)) & 1u, fmz = (fbm >> (3 * (r + 1) + 1)) & 1u;
       // get_at_mac<true, false, 0/1/2> on U (ring fields 3, 4, 5), operand for operand
-      const float x_c = at(3, SC, 0, 0), y_c = at(4, SC, 0, 0), z_c = at(5, SC, 0, 0);
-      const float x_r = at(3, SC, 0, 1), y_u = at(4, SC, 1, 0), z_f = at(5, SP, 0, 0);
+      const float x_c = rC[3][rc0], y_c = rC[4][rc0], z_c = rC[5][rc0];
+      const float x_r = rC[3][rc0 + 1], y_u = rC[4][rc0 + ATP], z_f = rP[5][rc0];
       float v[3][3];
       v[0][0] = x_c;
-      v[0][1] = 0.25f * (((y_c + at(4, SC, 0, -1)) + y_u) + at(4, SC, 1, -1));
-      v[0][2] = 0.25f * (((z_c + at(5, SC, 0, -1)) + z_f) + at(5, SP, 0, -1));
-      v[1][0] = 0.25f * (((x_c + at(3, SC, -1, 0)) + x_r) + at(3, SC, -1, 1));
+      v[0][1] = 0.25f * (((y_c + rC[4][rc0 - 1]) + y_u) + rC[4][rc0 + ATP - 1]);
+      v[0][2] = 0.25f * (((z_c + rC[5][rc0 - 1]) + z_f) + rP[5][rc0 - 1]);
+      v[1][0] = 0.25f * (((x_c + rC[3][rc0 - ATP]) + x_r) + rC[3][rc0 - ATP + 1]);
       v[1][1] = y_c;
-      v[1][2] = 0.25f * (((z_c + at(5, SC, -1, 0)) + z_f) + at(5, SP, -1, 0));
-      v[2][0] = 0.25f * (((x_c + at(3, SM, 0, 0)) + x_r) + at(3, SM, 0, 1));
-      v[2][1] = 0.25f * (((y_c + at(4, SM, 0, 0)) + y_u) + at(4, SM, 1, 0));
+      v[1][2] = 0.25f * (((z_c + rC[5][rc0 - ATP]) + z_f) + rP[5][rc0 - ATP]);
+      v[2][0] = 0.25f * (((x_c + rM[3][rc0]) + x_r) + rM[3][rc0 + 1]);
+      v[2][1] = 0.25f * (((y_c + rM[4][rc0]) + y_u) + rM[4][rc0 + ATP]);
       v[2][2] = z_c;
-      const float fwd0 = at(0, SC, 0, 0), fwd1 = at(1, SC, 0, 0), fwd2 = at(2, SC, 0, 0);
-      float out[3];
+      const float fwd0 = rC[0][rc0], fwd1 = rC[1][rc0], fwd2 = rC[2][rc0];
       bool ok = true;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float vd0 = v[a][0] * dt, vd1 = v[a][1] * dt, vd2 = v[a][2] * dt;
-        const ALerp L = alerp(ctrx + vd0, ctry + vd1, ctrz + vd2, i, j, kg);
+        const ALerp L = alerp(ctrx + vd0, ctry + vd1, ctrz + vd2, fi, fj, fk);
         float c[8];
-        {
-          const int rowcol = (hr0 + r - (L.ny ? 1 : 0)) * ATP + col - (L.nx ? 1 : 0);
-          const float* z0 = (L.nz ? &ring[SM][a][0] : &ring[SC][a][0]) + rowcol;
-          const float* z1 = (L.nz ? &ring[SC][a][0] : &ring[SP][a][0]) + rowcol;
-          c[0] = z0[0]; c[1] = z0[1]; c[2] = z0[ATP]; c[3] = z0[ATP + 1];
-          c[4] = z1[0]; c[5] = z1[1]; c[6] = z1[ATP]; c[7] = z1[ATP + 1];
-        }
+        atile_corners<NF>(rM, rC, rP, a, rc0, L.nx, L.ny, L.nz, c);
         const float smp = atrilin(c, L);
         float mn = INFINITY, mx = -INFINITY;
         bool okc = true;
@@ -632,14 +582,10 @@ __global__ __launch_bounds__(256, 2) void advect3d_bwd_vel_tile_kernel(GridDims 
           const int qz = (int)(l == 0 ? posz - vd2 : posz + vd2);
           const int rx = qx - i, ry = qy - j, rz = qz - kg;
           okc &= ((unsigned)(rx + 1) <= 1u) & ((unsigned)(ry + 1) <= 1u) & ((unsigned)(rz + 1) <= 1u);
-          const int rowcol = (hr0 + r + (ry == -1 ? -1 : 0)) * ATP + col + (rx == -1 ? -1 : 0);
-          const float* z0 = (rz == -1 ? &ring[SM][3 + a][0] : &ring[SC][3 + a][0]) + rowcol;
-          const float* z1 = (rz == -1 ? &ring[SC][3 + a][0] : &ring[SP][3 + a][0]) + rowcol;
-          const float e0 = z0[0], e1 = z0[1], e2 = z0[ATP], e3 = z0[ATP + 1], e4 = z1[0], e5 = z1[1], e6 = z1[ATP], e7 = z1[ATP + 1];
-          mn = fminf(mn, e0); mx = fmaxf(mx, e0); mn = fminf(mn, e1); mx = fmaxf(mx, e1);
-          mn = fminf(mn, e2); mx = fmaxf(mx, e2); mn = fminf(mn, e3); mx = fmaxf(mx, e3);
-          mn = fminf(mn, e4); mx = fmaxf(mx, e4); mn = fminf(mn, e5); mx = fmaxf(mx, e5);
-          mn = fminf(mn, e6); mx = fmaxf(mx, e6); mn = fminf(mn, e7); mx = fmaxf(mx, e7);
+          float e[8];
+          atile_corners<NF>(rM, rC, rP, 3 + a, rc0, rx == -1, ry == -1, rz == -1, e);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { mn = fminf(mn, e[q]); mx = fmaxf(mx, e[q]); }
         }
         const float fa = a == 0 ? fwd0 : (a == 1 ? fwd1 : fwd2);
         const float og = a == 0 ? x_c : (a == 1 ? y_c : z_c);
@@ -647,54 +593,77 @@ __global__ __launch_bounds__(256, 2) void advect3d_bwd_vel_tile_kernel(GridDims 
         const bool fm = a == 0 ? fmx : (a == 1 ? fmy : fmz);
         const bool skip = !fluid | !fm;
         const float corr = skip ? fa : fa + half_s * (og - bwd);
-        out[a] = fmaxf(fminf(corr, mx), mn);
+        o_u[r][a] = border ? 0.f : fmaxf(fminf(corr, mx), mn);
         ok &= okc & (L.ok | !fluid);
       }
-      if (border) { out[0] = 0.f; out[1] = 0.f; out[2] = 0.f; }
-      slow[r] = live & !border & !ok;
-      if (live) {
-        const size_t o = (size_t)k * g.HW + (size_t)j * g.W + i;
-        U_dst[sb3 + o] = out[0];
-        U_dst[sb3 + g.DHW + o] = out[1];
-        U_dst[sb3 + 2 * (size_t)g.DHW + o] = out[2];
-      }
-      any_slow |= slow[r];
+      ws[r] = __builtin_amdgcn_ballot_w64(live & !border & !ok);
     }
-    if (__builtin_amdgcn_ballot_w64(any_slow) != 0) {
+    pre_store();
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        CellId c; c.b = m.b; c.k = k; c.j = m.j0 + 2 * w + r; c.i = i; c.valid = true;
-        if (slow[r]) sl_mac_bwd_clamp_cell_flat<true>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
+      if (xin && j < g.H) {
+        const size_t o = (size_t)k * g.HW + (size_t)j * g.W + i;
+        U_dst[sb3 + o] = o_u[r][0];
+        U_dst[sb3 + g.DHW + o] = o_u[r][1];
+        U_dst[sb3 + 2 * (size_t)g.DHW + o] = o_u[r][2];
       }
+      if (lane == 0 && j < g.H) fix[m.word(g, k, j)] = ws[r];
     }
   };
+  atile_march<NF>(g, m, rs, rs_f, ring0, ring1, ring2, ring3, fst0, fst1, body);
+}
 
-  int k = m.k_lo;
-  dma_plane(0, 0, k - 1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  FB[0] = fluid_bits(0);
-  dma_plane(1, 1, k);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  FB[1] = fluid_bits(1);
-  dma_plane(2, 0, k + 1);
-  int fs = 0;
-  auto one = [&](auto rsl) __attribute__((always_inline)) {
-    constexpr int SC = decltype(rsl)::value;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    FB[2] = fluid_bits(fs);
-    if (k + 1 < m.k_hi) dma_plane((SC + 2) % 4, fs ^ 1, k + 2);
-    fs ^= 1;
-    step(rsl, k, FB[0], FB[1]);
-    FB[0] = FB[1]; FB[1] = FB[2];
-  };
-  while (true) {
-    one(AIC<1>{}); if (++k >= m.k_hi) break;
-    one(AIC<2>{}); if (++k >= m.k_hi) break;
-    one(AIC<3>{}); if (++k >= m.k_hi) break;
-    one(AIC<0>{}); if (++k >= m.k_hi) break;
+// ---------------------------------------------------------------------------------------------------
+// Fix-up launches: the per-cell functions on the cells the tile kernels flagged.  One thread per bitmap word (a 64-cell row
+// segment of the compute window): nothing flagged = one 8-byte load per thread.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool afix_decode(const GridDims& g, int ntx, size_t t, CellId& c, size_t& wi) {
+  const size_t nrow = (size_t)g.B * g.KN * g.H;
+  if (t >= nrow * ntx) return false;
+  const int bx = (int)(t % ntx); size_t q = t / ntx;
+  c.j = (int)(q % g.H); q /= g.H;
+  c.k = g.K0 + (int)(q % g.KN); c.b = (int)(q / g.KN);
+  c.i = bx * 64; c.valid = true;
+  wi = (((size_t)c.b * g.D + c.k) * g.H + c.j) * ntx + bx;
+  return true;
+}
+
+template <bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(256) void advect3d_fwd_fix_kernel(GridDims g, float dt, const float* __restrict__ rho,
+                                                               const float* __restrict__ U, const float* __restrict__ flags,
+                                                               float* __restrict__ rho_fwd, int* __restrict__ cell_out,
+                                                               float* __restrict__ U_fwd,
+                                                               const unsigned long long* __restrict__ fix_s,
+                                                               const unsigned long long* __restrict__ fix_v, int ntx) {
+  CellId c; size_t wi;
+  if (!afix_decode(g, ntx, (size_t)blockIdx.x * 256 + threadIdx.x, c, wi)) return;
+  unsigned long long ws = fix_s[wi], wv = fix_v[wi];
+  const int i0 = c.i;
+  for (unsigned long long a = ws | wv; a != 0; a &= a - 1) {
+    const int bit = __builtin_ctzll(a);
+    c.i = i0 + bit;
+    if ((ws >> bit) & 1ull) sl_scalar_cell<true, false, SAMPLE_OUTSIDE>(g, c, dt, rho, U, flags, rho_fwd, cell_out);
+    if ((wv >> bit) & 1ull) sl_mac_cell_flat<true>(g, c, dt, U, U, flags, U_fwd);
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+template <bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(256) void advect3d_bwd_fix_kernel(GridDims g, float dt, float half_s, const float* __restrict__ rho,
+                                                               const float* __restrict__ rho_fwd, const int* __restrict__ cell_in,
+                                                               const float* __restrict__ U, const float* __restrict__ U_fwd,
+                                                               const float* __restrict__ flags, const float2* __restrict__ box,
+                                                               float* __restrict__ rho_dst, float* __restrict__ U_dst,
+                                                               const unsigned long long* __restrict__ fix_s,
+                                                               const unsigned long long* __restrict__ fix_v, int ntx) {
+  CellId c; size_t wi;
+  if (!afix_decode(g, ntx, (size_t)blockIdx.x * 256 + threadIdx.x, c, wi)) return;
+  unsigned long long ws = fix_s[wi], wv = fix_v[wi];
+  const int i0 = c.i;
+  for (unsigned long long a = ws | wv; a != 0; a &= a - 1) {
+    const int bit = __builtin_ctzll(a);
+    c.i = i0 + bit;
+    if ((ws >> bit) & 1ull) sl_scalar_bwd_clamp_cell<true, false, SAMPLE_OUTSIDE>(g, c, dt, half_s, rho, rho_fwd, cell_in, U, flags, box, rho_dst);
+    if ((wv >> bit) & 1ull) sl_mac_bwd_clamp_cell_flat<true>(g, c, dt, half_s, U, U_fwd, U, flags, U_dst);
+  }
 }

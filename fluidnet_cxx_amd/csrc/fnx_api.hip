@@ -67,11 +67,13 @@ struct Carver {
 
 size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4) + (g->is3D ? al(ncell(g) * 8) : 0); }   // fwd, traced cell, 3D clamp bounds
 size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
+// fix-up bitmaps of the 3D tile advection kernels (fnx_advect_march.h): 4 x one 64-bit word per 64-cell row segment
+size_t ws_advect_fix(const FnxGrid* g) { return g->is3D ? al(4 * 8 * (size_t)g->B * g->D * g->H * ((g->W + 63) / 64)) : 0; }
 size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + (g->is3D ? al(ncell(g)) : 0); }
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   // 2D: the fused advection launches keep both forward fields at once
-  size_t adv = ws_advect_scalar(g) + ws_advect_vel(g);
+  size_t adv = ws_advect_scalar(g) + ws_advect_vel(g) + ws_advect_fix(g);
   size_t solve = ws_jacobi(g);
   size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D);
   size_t tail = adv > solve ? adv : solve;
@@ -169,7 +171,7 @@ size_t fnx_workspace_bytes(const FnxGrid* g, int op) {
     case FNX_OP_JACOBI: return ws_jacobi(g);
     case FNX_OP_STEP: return ws_step(g);
     case FNX_OP_FLUIDNET: return fnx::fluidnet_ws_bytes(dims(g), g->is3D);
-    case FNX_OP_ADVECT_STEP: return ws_advect_scalar(g) + ws_advect_vel(g);
+    case FNX_OP_ADVECT_STEP: return ws_advect_scalar(g) + ws_advect_vel(g) + ws_advect_fix(g);
   }
   fail(FNX_EINVAL, "unknown op %d", op);
   return 0;
@@ -241,11 +243,12 @@ int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const floa
   int* cell = (int*)c.take(n * 4);
   float* box = g->is3D ? (float*)c.take(n * 8) : nullptr;
   float* U_fwd = (float*)c.take(n * 4 * nc);
+  unsigned long long* fix = g->is3D ? (unsigned long long*)c.take(ws_advect_fix(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_step: workspace too small (%zu < %zu)", ws_bytes, c.off);
   const GridDims d = dims(g);
   fnx::ProfScope ps(FNX_PROF_ADVECT, s);
   fnx::launch_advect_fused(d, widened(d, 2), g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, density, U, flags,
-                           rho_fwd, cell, U_fwd, box, density_dst, U_dst, s);
+                           rho_fwd, cell, U_fwd, box, density_dst, U_dst, fix, s);
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }
