@@ -507,6 +507,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
         py::arg("workspace") = py::none(), py::arg("reuse_mask") = false, GEOM, NoGil());
   m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
+  m.def("jacobi_max_pass_sweeps", [](int B, int D, int H, int W, int nplanes, int nranges) {
+    FnxGrid g{B, D, H, W, 1, 0, 0, 0};
+    return fnx_jacobi_max_pass_sweeps(&g, nplanes, nranges);
+  });
   m.def("jacobi_pass_", &jacobi_pass_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("nsweeps"),
         py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1, GEOM,
         NoGil());

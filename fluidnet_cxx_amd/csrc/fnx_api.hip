@@ -291,7 +291,8 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
   auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss) {
     fnx::ProfScope ps(FNX_PROF_JACOBI, s);
     if (g->is3D) {
-      if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, ss, s, 0, 0, from_zero);
+      if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, ss, s, 0, 0, from_zero);
+      else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, ss, s, 0, 0, from_zero);
       else fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
     } else {
       fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
@@ -300,8 +301,14 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
   if (!(p_tol > 0.f)) {
     // sweeps per launch: 2D up to kmax (register temporal blocking); 3D pairs (the first one knows p = 0)
     int plan[1024]; int nl = 0, left = max_iter;
-    const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
-    while (left > 0 && nl < 1023) { const int k = left < kmax ? left : kmax; plan[nl++] = k; left -= k; }
+    // sweeps per launch: 2D up to kmax (register temporal blocking); 3D three per pass where the grid allows it (a
+    // remainder of 1 is split 2 + 2 rather than 3 + 1: the single-sweep kernel is the slowest per sweep)
+    const int kmax = g->is3D ? (fnx::jacobi3d_x3_available(d, g->D, 1) ? 3 : 2) : fnx::jacobi_max_sweeps_per_launch(d, false);
+    while (left > 0 && nl < 1023) {
+      int k = left < kmax ? left : kmax;
+      if (g->is3D && kmax == 3 && left == 4) k = 2;
+      plan[nl++] = k; left -= k;
+    }
     if (left > 0) return fail(FNX_EINVAL, "solve_linear_system: max_iter too large for one call (%d)", max_iter);
     if (residual) HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
     const float* in = nullptr;
@@ -359,17 +366,18 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (g->is3D && !reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
-  const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
-  const int nl = (nsweeps + kmax - 1) / kmax;
+  const int kmax = g->is3D ? (fnx::jacobi3d_x3_available(d, g->D, 1) ? 3 : 2) : fnx::jacobi_max_sweeps_per_launch(d, false);
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
   const float* in = p;
   int done = 0;
-  for (int l = 0; l < nl; ++l) {
-    const int k = nsweeps - done < kmax ? nsweeps - done : kmax;
+  for (int l = 0; done < nsweeps; ++l) {
+    int k = nsweeps - done < kmax ? nsweeps - done : kmax;
+    if (g->is3D && kmax == 3 && nsweeps - done == 4) k = 2;
     float* out = (l % 2 == 0) ? tmp : p;
     { fnx::ProfScope ps(FNX_PROF_JACOBI, s);
       if (g->is3D) {
-        if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s);
+        if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, nullptr, s);
+        else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s);
         else fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
       } else {
         fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s);
@@ -388,7 +396,9 @@ int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, con
   if (!flags || !div || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
   if (!g->is3D) return fail(FNX_EINVAL, "jacobi_pass: 3D only (2D uses fnx_jacobi_sweeps)");
   const bool from_zero = p_in == nullptr;                 // the first pass of a solve: p = 0 everywhere, nothing to read
-  if (nsweeps != 1 && nsweeps != 2) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1 or 2");
+  if (nsweeps < 1 || nsweeps > 3) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1, 2 or 3");
+  if (nsweeps == 3 && !fnx::jacobi3d_x3_available(dims(g), k_end > k_begin ? k_end - k_begin : g->D, k_begin2 >= 0 ? 2 : 1))
+    return fail(FNX_EINVAL, "jacobi_pass: a 3-sweep pass is not available for this grid (fnx_jacobi_max_pass_sweeps)");
   if (k_begin < 0 || k_end > g->D || (k_end != 0 && k_end <= k_begin)) return fail(FNX_EINVAL, "jacobi_pass: bad plane range");
   if (k_begin2 >= 0) {
     const int n = k_end - k_begin;
@@ -403,13 +413,19 @@ int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, con
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_pass: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
+  if (nsweeps == 3) fnx::launch_jacobi3d_x3(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
+  else if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
   else {
     fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin, k_end);
     if (k_begin2 >= 0) fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin2, k_begin2 + (k_end - k_begin));
   }
   HIP_OK(hipGetLastError());
   return FNX_OK;
+}
+
+int fnx_jacobi_max_pass_sweeps(const FnxGrid* g, int nplanes, int nranges) {
+  if (check_grid(g) != FNX_OK || !g->is3D) return 0;
+  return fnx::jacobi3d_x3_available(dims(g), nplanes, nranges < 1 ? 1 : nranges) ? 3 : 2;
 }
 
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,

@@ -867,6 +867,290 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_dma_kernel(G
   }  // segments
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3D, THREE sweeps per pass.
+//
+// At 16.8 M cells a 2-sweep pass moves 250 MB in 49 us = 5.1 TB/s, which is what this memory system gives a mixed
+// read/write stream whose footprint sits at the edge of the 256 MiB Infinity Cache (tools/ubench/bw_bench.hip: copy 7.4
+// TB/s at 192 MiB, 5.0 TB/s from 512 MiB on); the LDS-DMA loader above changed nothing, so the texture addresser is not
+// the limit either.  What is left is moving fewer bytes per sweep: the same march with a third register level.  A wave owns
+// 58 columns x 4 rows; per step t it builds p^1(plane t) on 8 rows, p^2(plane t-1) on 6 and the finished p^3(plane t-2)
+// on its 4, each from the three planes of the level below held in a 3-slot register ring (10 / 8 / 6 rows).  The row
+// loads go through the LDS-DMA path (which costs no VGPRs for loads in flight -- what makes the third level fit): at the
+// END of a step the rows of p^0(plane t+2) and the div / mask rows of plane t+1 are picked up from the LDS stage into the
+// ring slots the step has just freed, and the DMA of the following plane is issued into the other stage.  The mask bytes
+// of a plane's 8 rows are packed four to a register.  Redundancy: 18 row updates per 12 finished, 58 of 64 lanes, and 4
+// lead-in steps per z chunk instead of 2 -- 1.25x the VALU work per sweep of the 2-sweep kernel for 2/3 of its traffic.
+// ---------------------------------------------------------------------------------------------------
+constexpr int Z3K = 3, Z3R = 4, Z3RW = Z3R + 2 * Z3K, Z3C = 64 - 2 * Z3K;     // sweeps, output rows, row slots, output columns
+constexpr int Z3WPS = 3;                                                     // waves per SIMD the register budget is sized for
+
+template <bool FREE, int SH>
+__device__ __forceinline__ float relax3p(int mp, float c, float xl, float xr, float yd, float yu, float zb, float zf, float dv,
+                                         float& num) {
+  if (!FREE) {                                          // Neumann: an obstacle neighbour is replaced by the centre
+    xl = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 1, 1), c, xl);
+    xr = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 2, 1), c, xr);
+    yd = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 3, 1), c, yd);
+    yu = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 4, 1), c, yu);
+    zb = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 5, 1), c, zb);
+    zf = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 6, 1), c, zf);
+  }
+  float sum = xl + xr;
+  sum = sum + yd;
+  sum = sum + yu;
+  sum = sum + zb;
+  sum = sum + zf;
+  num = sum + dv;
+  return div6_fast(num);
+}
+
+template <bool RES, bool ZERO>
+__global__ __launch_bounds__(64, Z3WPS) void jacobi3d_march3_kernel(GridDims g, const unsigned char* __restrict__ mask,
+                                                                   const float* __restrict__ div,
+                                                                   const float* __restrict__ p_in, float* __restrict__ p_out,
+                                                                   float* __restrict__ sumsq, int nxt, int nyt, int zchunk,
+                                                                   int kb, int ke, int kb2) {
+  constexpr int K = Z3K, R = Z3R, RW = Z3RW, NA = RW - 2;             // NA: aux (div / mask) rows = row slots 1 .. RW-2
+  constexpr int NPQ = (RW + 3) / 4, NAQ = (NA + 3) / 4;               // DMA instructions per plane: p^0 rows, div rows
+  constexpr int MROW = 80;                                            // bytes per mask row in LDS (5 chunks)
+  constexpr int STAGE_F = NPQ * 256 + NAQ * 256 + (NA * MROW + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float stage0[STAGE_F];
+  __shared__ __attribute__((aligned(16))) float stage1[STAGE_F];
+  const int lane = threadIdx.x;
+  const int G = gridDim.x, np = ke - kb;
+  const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int ntiles = nxt * nyt * g.B;
+  int zc = gid / ntiles;
+  const int tile = gid - zc * ntiles;
+  int kbase = kb;
+  if (kb2 >= 0) {                                        // chunks [0, nzc1) belong to the first range, the rest to the second
+    const int nzc1 = (np + zchunk - 1) / zchunk;
+    if (zc >= nzc1) { zc -= nzc1; kbase = kb2; }
+  }
+  if (zc * zchunk >= np) return;                         // padding block
+  const int bx = tile % nxt, l1 = tile / nxt;
+  const int by = l1 % nyt, b = l1 / nyt;
+  const int k_lo = kbase + zc * zchunk, k_hi = kbase + min((zc + 1) * zchunk, np);     // output planes [k_lo, k_hi)
+  // Columns.  Tile bx finishes columns [bx*58, bx*58 + 58); its lanes start K columns to the left -- except the first tile,
+  // which starts AT column 0: a DMA chunk must not start before the row (the buffer range check then drops all 16 bytes,
+  // real columns included), and column 0, a border column, needs no left neighbour.
+  const int lane_lo = bx == 0 ? 0 : K;
+  const int x0 = bx * Z3C - lane_lo;
+  const int x = x0 + lane;
+  const int j0 = by * R;
+  const bool xin = x < g.W;
+  const size_t base = (size_t)b * g.DHW;
+  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
+  unsigned rowb[RW];                                     // wave-uniform cell offset of row slot rr (j = j0-K+rr) in a plane
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const int j = j0 - K + rr;
+    rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
+  }
+  const int k0 = clampk(k_lo - K);
+  auto planeoff = [&](int k) { return (unsigned)((clampk(k) - k0) * g.HW); };
+  // buffer resources: from plane k0 to the END OF THE TENSOR (a chunk hanging over the sample's end reads the next
+  // sample, or 0 past the last one); the plane offset travels in the VGPR offset (the range check ignores an SGPR offset)
+  const size_t seg0 = base + (size_t)k0 * g.HW;
+  const size_t left = (size_t)(g.D - k0) * g.HW + (size_t)(g.B - 1 - b) * g.DHW;
+  const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
+  const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
+  const BufRsrc r_m = make_rsrc(mask + seg0, ncell), r_o = make_rsrc(p_out + seg0, ncell * 4u);
+  // DMA: one instruction = 4 rows of 256 B (lane l: row l/16, chunk l%16); mask: one instruction = NA rows of 5 chunks
+  const int rs = lane >> 4, cq = lane & 15;
+  unsigned vrow_p[NPQ], vrow_a[NAQ];
+#pragma unroll
+  for (int q = 0; q < NPQ; ++q) {
+    unsigned ro = rowb[RW - 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int slot = 4 * q + u; if (rs == u && slot < RW) ro = rowb[slot < RW ? slot : RW - 1]; }
+    vrow_p[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
+  }
+#pragma unroll
+  for (int q = 0; q < NAQ; ++q) {
+    unsigned ro = rowb[RW - 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int slot = 1 + 4 * q + u; if (rs == u && slot < RW - 1) ro = rowb[slot < RW ? slot : RW - 1]; }
+    vrow_a[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
+  }
+  // mask bytes: chunks start at the multiple of 4 at or below x0 (a dwordx4 needs a dword-aligned address); my byte sits
+  // `moff` bytes into the row's 80
+  const int xm0 = x0 & ~3, moff = x0 - xm0;
+  unsigned vrow_m;
+  {
+    const int mr = lane / 5, mc = lane - mr * 5;
+    unsigned ro = rowb[RW - 1];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) if (mr == u) ro = rowb[1 + u];
+    vrow_m = ro + (unsigned)(xm0 + 16 * mc);
+  }
+  const bool m_lane = lane < 5 * NA;
+  typedef __attribute__((address_space(3))) void* LdsPtr;
+  auto dma = [&](float* st, int kp, int ka) {            // p^0 rows of plane kp, div + mask rows of plane ka -> stage st
+    const unsigned pp = planeoff(kp) * 4u, pa = planeoff(ka);
+    if (!ZERO) {
+#pragma unroll
+      for (int q = 0; q < NPQ; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_p, (LdsPtr)(st + q * 256), 16, vrow_p[q] + pp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NAQ; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_d, (LdsPtr)(st + NPQ * 256 + q * 256), 16, vrow_a[q] + pa * 4u, 0, 0, 0);
+    if (m_lane) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_m, (LdsPtr)(st + (NPQ + NAQ) * 256), 16, vrow_m + pa, 0, 0, 0);
+  };
+  // rings: level-s planes in slot (plane - k_lo + 3K) mod 3
+  float P0[3][RW], P1[3][RW], P2[3][RW], AD[3][NA];
+  int AM[3][(NA + 3) / 4];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) { P0[q][rr] = 0.f; P1[q][rr] = 0.f; P2[q][rr] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < NA; ++rr) AD[q][rr] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < (NA + 3) / 4; ++rr) AM[q][rr] = 0;
+  }
+  auto pick_p = [&](auto sl, const float* st) {          // LDS stage -> P0 slot
+    constexpr int S = decltype(sl)::value;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) P0[S][rr] = ZERO ? 0.f : st[rr * 64 + lane];
+  };
+  auto pick_a = [&](auto sl, const float* st) {          // LDS stage -> AD / AM slot (mask bytes packed 4 rows to a register)
+    constexpr int S = decltype(sl)::value;
+#pragma unroll
+    for (int rr = 0; rr < NA; ++rr) AD[S][rr] = st[NPQ * 256 + rr * 64 + lane];
+    const unsigned char* mb = (const unsigned char*)(st + (NPQ + NAQ) * 256) + moff + lane;
+#pragma unroll
+    for (int q4 = 0; q4 < (NA + 3) / 4; ++q4) {
+      unsigned v = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (4 * q4 + u < NA) v |= (unsigned)mb[(4 * q4 + u) * MROW] << (8 * u);
+      AM[S][q4] = (int)v;
+    }
+  };
+  float local = 0.f;
+  const bool lane_out = (lane >= lane_lo) & (lane < lane_lo + Z3C) & xin;
+
+  // one sweep: level L-1 planes (slots SB, SCc, SF = back, centre, front) -> rows [L, RW-L) of `out`
+  auto sweep = [&](auto lvl, bool free, const int (&M)[(NA + 3) / 4], const float (&C)[RW], const float (&Bk)[RW], const float (&Fr)[RW],
+                   const float (&DV)[NA], float (&out)[RW]) __attribute__((always_inline)) {
+    constexpr int L = decltype(lvl)::value;
+    float xs[RW];
+    bool bad = false;
+#pragma unroll
+    for (int rr = L; rr < RW - L; ++rr) {
+      const float c = C[rr];
+      const int mp = M[(rr - 1) >> 2];
+      // (the shift of row rr's byte is a compile-time constant per unrolled iteration)
+      float v;
+      switch ((rr - 1) & 3) {
+        case 0: v = free ? relax3p<true, 0>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
+                         : relax3p<false, 0>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
+        case 1: v = free ? relax3p<true, 8>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
+                         : relax3p<false, 8>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
+        case 2: v = free ? relax3p<true, 16>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
+                         : relax3p<false, 16>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
+        default: v = free ? relax3p<true, 24>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
+                          : relax3p<false, 24>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
+      }
+      out[rr] = v;
+      bad |= __builtin_amdgcn_classf(v, 0x90);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: scaled division
+#pragma unroll
+      for (int rr = L; rr < RW - L; ++rr)
+        if (__builtin_amdgcn_classf(out[rr], 0x90)) out[rr] = div6_tiny(xs[rr]);
+    }
+#pragma unroll
+    for (int rr = L; rr < RW - L; ++rr)                    // cont ? v : 0
+      out[rr] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[rr]) & __builtin_amdgcn_sbfe(M[(rr - 1) >> 2], 8 * ((rr - 1) & 3), 1));
+  };
+
+  bool fr_c = false, fr_m = false;                       // "no obstacle neighbour on any row" of planes t-1, t-2 (wave-uniform)
+  // one step.  PH = ring slot of plane t; planes t-1 / t-2 / t+1 sit in (PH+2)%3 / (PH+1)%3 / (PH+1)%3 (t+1 replaces t-2).
+  auto step = [&](auto ph, int t, const float* st_cur, float* st_nxt) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(ph)::value, S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;     // slots of planes t, t-1, t-2
+    constexpr int SN = S2;                                                            // plane t+1 (p^0) shares the slot of t-2
+    // ---- sweep 1: p^1(plane t) from p^0 planes t-1, t, t+1
+    int ob = AM[S0][0];
+#pragma unroll
+    for (int q4 = 1; q4 < (NA + 3) / 4; ++q4) ob |= AM[S0][q4];
+    const bool fr_t = __builtin_amdgcn_ballot_w64((ob & 0x7e7e7e7e) != 0) == 0;
+    sweep(IC<1>{}, fr_t, AM[S0], P0[S0], P0[S1], P0[SN], AD[S0], P1[S0]);
+    // ---- sweep 2: p^2(plane t-1) from p^1 planes t-2, t-1, t
+    if (t - 1 >= k_lo - 1) sweep(IC<2>{}, fr_c, AM[S1], P1[S1], P1[S2], P1[S0], AD[S1], P2[S1]);
+    // ---- sweep 3: finished p^3(plane t-2) from p^2 planes t-3, t-2, t-1 (p^2(t-3) sits in slot S0: not yet overwritten)
+    float v[RW];
+    const bool fin = t - 2 >= k_lo;
+    if (fin) sweep(IC<3>{}, fr_m, AM[S2], P2[S2], P2[S0], P2[S1], AD[S2], v);
+    // ---- next planes: p^0(t+2) replaces p^0(t-1) (slot S1), the aux rows of plane t+1 replace those of plane t-2 (slot S2).
+    // That pair was requested two steps ago; the pair requested one step ago (the youngest NDMA VMEM instructions: this
+    // step's stores are issued BEFORE its DMA, so nothing younger follows them) may stay in flight -- a plain vmcnt(0)
+    // would wait for it too and halve the prefetch distance.  vmcnt(NDMA) also covers the previous step's stores.
+    constexpr int NDMA = (ZERO ? 0 : NPQ) + NAQ + 1;
+    if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    pick_p(IC<S1>{}, st_cur);
+    pick_a(IC<S2>{}, st_cur);
+    if (fin) {
+      const unsigned ok = (unsigned)((t - 2 - k0) * g.HW + j0 * g.W) * 4u + (unsigned)x0 * 4u + (unsigned)lane * 4u;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (lane_out && j0 + r < g.H) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[K + r]), r_o, ok + (unsigned)(r * g.W) * 4u, 0, 0);
+          if (RES) { const float d = v[K + r] - P2[S2][K + r]; local += d * d; }
+        }
+      }
+    }
+    // the following pair goes into the stage just read; a pair nobody will pick is still requested (the instruction count
+    // per step must not vary for the counted wait) -- it reads clamped planes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the reads above have left the stage
+    dma(st_nxt, t + 4, t + 3);
+    fr_m = fr_c; fr_c = fr_t;
+  };
+
+  // ---- prologue: p^0 planes t-1, t, t+1 and the aux rows of plane t straight from memory (t = k_lo - 2); then the
+  // stages take over: p^0(t+2) + aux(t+1) -> stage0 (picked at the end of the first step), p^0(t+3) + aux(t+2) -> stage1
+  int t = k_lo - (K - 1);
+  {
+    const unsigned xoff = (unsigned)(x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x)) * 4u;
+    auto ldf = [&](const BufRsrc& r, unsigned cell) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0)); };
+    const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      if (!ZERO) { P0[2][rr] = ldf(r_p, pm + rowb[rr]); P0[0][rr] = ldf(r_p, pc + rowb[rr]); P0[1][rr] = ldf(r_p, pp + rowb[rr]); }
+    }
+    unsigned mb[NA];
+#pragma unroll
+    for (int rr = 0; rr < NA; ++rr) {
+      AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]);
+      mb[rr] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, xoff >> 2, pc + rowb[rr + 1], 0);
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < (NA + 3) / 4; ++q4) {
+      unsigned vv = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (4 * q4 + u < NA) vv |= mb[4 * q4 + u] << (8 * u);
+      AM[0][q4] = (int)vv;
+    }
+    dma(stage0, t + 2, t + 1);
+    dma(stage1, t + 3, t + 2);
+  }
+  // The first step's plane t sits in slot 0 and reads stage0; slots advance by one and stages alternate per step.
+  while (true) {
+    step(IC<0>{}, t, stage0, stage0); if (++t > k_hi + 1) break;
+    step(IC<1>{}, t, stage1, stage1); if (++t > k_hi + 1) break;
+    step(IC<2>{}, t, stage0, stage0); if (++t > k_hi + 1) break;
+    step(IC<0>{}, t, stage1, stage1); if (++t > k_hi + 1) break;
+    step(IC<1>{}, t, stage0, stage0); if (++t > k_hi + 1) break;
+    step(IC<2>{}, t, stage1, stage1); if (++t > k_hi + 1) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the wave
+  if (RES) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) atomicAdd(&sumsq[b], local);
+  }
+}
+
 // Generic single sweep (3D, and any 2D shape): one thread per cell.
 constexpr int BX = 64, BY = 4;
 
@@ -1074,6 +1358,56 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true);
 #undef J3D_RZ
 #undef J3D
+}
+
+// three sweeps in one pass: p_in = p^n, p_out = p^{n+3}; returns false (nothing launched) when the grid has more tiles than
+// resident waves -- the caller then uses the 2-sweep / 1-sweep launches
+static int jacobi3d_x3_slots() {
+  static const int slots = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return Z3WPS * 4 * cus;
+  }();
+  return slots;
+}
+
+// can a pass over `np` planes (x `nranges` plane ranges) of this grid run as a 3-sweep launch?
+bool jacobi3d_x3_available(const GridDims& g, int np, int nranges) {
+  // Opt-in (FNX_JACOBI_X3=1).  Measured at 16.8 M cells: 103 us per 3-sweep pass = 68 us per two sweeps against 49 us for
+  // the 2-sweep kernel; at 67 M cells 279 against 256.  Same bits (the whole Jacobi test set passes with it on).  The
+  // counters say why: 53 % of the wave time sits in s_waitcnt -- at 147-168 VGPRs only 2.25 waves per SIMD are resident and
+  // each runs one DMA pair ahead, too little in flight to cover the memory latency -- and its L2-side traffic per pass is
+  // 295 MB against 250 MB (10-row reads, 4 lead-in planes per chunk), so the byte saving per sweep is 21 %, not 33 %.
+  static const bool on = [] { const char* e = getenv("FNX_JACOBI_X3"); return e && atoi(e) != 0; }();
+  if (!on) return false;
+  if (np <= 0) np = g.D;
+  const int ntiles = ((g.W + Z3C - 1) / Z3C) * ((g.H + Z3R - 1) / Z3R) * g.B;
+  return (long)ntiles * nranges <= jacobi3d_x3_slots() && (size_t)(np + 2 * Z3K + 2) * g.HW < 0x3fffffffu;
+}
+
+bool launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
+                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero, int kb2) {
+  if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
+  const int slots = jacobi3d_x3_slots();
+  const int nxt = (g.W + Z3C - 1) / Z3C, nyt = (g.H + Z3R - 1) / Z3R;
+  const int np = ke - kb, ntiles = nxt * nyt * g.B;
+  const int nr = kb2 >= 0 ? 2 : 1;
+  if (!jacobi3d_x3_available(g, np, nr)) return false;
+  int nzc = slots / (ntiles * nr);
+  if (nzc < 1) nzc = 1;
+  int zchunk = (np + nzc - 1) / nzc;
+  if (zchunk < 4) zchunk = np < 4 ? np : 4;
+  long long G = (long long)ntiles * ((np + zchunk - 1) / zchunk) * nr;
+  G = ((G + 7) / 8) * 8;
+  const dim3 grid((unsigned)G), block(64);
+  if (from_zero) {
+    if (sumsq) jacobi3d_march3_kernel<true, true><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
+    else jacobi3d_march3_kernel<false, true><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
+  } else {
+    if (sumsq) jacobi3d_march3_kernel<true, false><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
+    else jacobi3d_march3_kernel<false, false><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
+  }
+  return true;
 }
 
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,

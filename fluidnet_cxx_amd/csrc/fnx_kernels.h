@@ -74,6 +74,9 @@ void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* 
                      bool from_zero, float* sumsq, hipStream_t s, int kb = 0, int ke = 0);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                         float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1);
+bool jacobi3d_x3_available(const GridDims& g, int np, int nranges);
+bool launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
+                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1);
 void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
 void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s);
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 5
+#define FNX_ABI_VERSION 6
 
 enum {
   FNX_OK = 0,
@@ -111,7 +111,11 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
 int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
                          void* ws, size_t ws_bytes, int reuse_mask, void* stream);
 
-/* One pass of 1 or 2 sweeps (3D) from p_in into p_out restricted to the output planes [k_begin, k_end)
+/* How many sweeps one fnx_jacobi_pass launch can run for passes over `nplanes` planes (0 = all) in `nranges` (1 or 2)
+ * plane ranges of this 3D grid: 3 where the 3-sweep kernel applies, else 2. */
+int fnx_jacobi_max_pass_sweeps(const FnxGrid* g, int nplanes, int nranges);
+
+/* One pass of 1, 2 or 3 sweeps (3D) from p_in into p_out restricted to the output planes [k_begin, k_end)
  * (0,0 = all); explicit buffers, no ping-pong.  p_in == NULL: the pressure is 0 everywhere (first pass of a solve).  Lets the z-slab driver compute the planes its neighbours need
  * first, start the ghost exchange, and compute the interior while the exchange is in flight.  `ws` as for
  * fnx_jacobi_sweeps_ex (holds the neighbour mask). */

@@ -151,6 +151,28 @@ def test_jacobi_denormal_front(fl, dev, oracle, shape):
     assert_bitexact(N(pg), po, "jacobi through the denormal range")
 
 
+def test_jacobi_three_sweep_kernel_opt_in(oracle, tmp_path):
+    """The 3-sweep-per-pass 3D kernel (FNX_JACOBI_X3=1, off by default: it is slower, see fnx_jacobi.hip) gives the same bits
+    as the oracle; the switch is read once per process, hence the subprocess."""
+    import os as _os, subprocess, sys as _sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from util import random_state\n"
+        "from fluidnet_cxx_amd import fluid as fl\n"
+        "from oracle import oracle as O\n"
+        "for (B, D, H, W, n) in ((1, 20, 21, 130, 7), (2, 9, 12, 33, 3), (1, 40, 64, 200, 10)):\n"
+        "    s = random_state(B, D, H, W, 2.0, seed=D)\n"
+        "    div = O.velocity_divergence(s['U'], s['flags'])\n"
+        "    p, _ = fl.solveLinearSystemJacobi(torch.from_numpy(s['flags']).cuda(), torch.from_numpy(div).cuda(), True, 0.0, n)\n"
+        "    po, _, _ = O.jacobi(s['flags'], div, True, 0.0, n)\n"
+        "    assert np.array_equal(p.cpu().numpy().view(np.int32), po.view(np.int32)), (B, D, H, W, n)\n"
+        "print('x3 ok')\n")
+    r = subprocess.run([_sys.executable, "-c", code], env=dict(_os.environ, FNX_JACOBI_X3="1"), capture_output=True, text=True,
+                       timeout=600, cwd=_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    assert r.returncode == 0 and "x3 ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_jacobi_tolerance_exit(fl, dev, oracle):
     s = random_state(1, 1, 48, 80, 2.0, seed=3)
     div = oracle.velocity_divergence(s["U"], s["flags"])
