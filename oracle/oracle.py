@@ -206,10 +206,12 @@ def pack_weights(wdict, ndim=2):
     return blob
 
 
-def multiscale_forward(blob, x, is3d=False):
-    """x: (B,2,H,W) or (B,2,D,H,W) -> (B,1,...)"""
+def multiscale_forward(blob, x, is3d=None):
+    """x: (B,2,H,W) or (B,2,D,H,W) -> (B,1,...); is3d defaults to "x has more than one z plane" """
     x5 = x if x.ndim == 5 else x[:, :, None]
     B, _, D, H, W = x5.shape
+    if is3d is None:
+        is3d = D > 1
     g = OraGrid(B, D, H, W, int(is3d), 0, 0)
     x5, px = _f(x5); blob, pb = _f(blob)
     p = np.empty((B, 1, D, H, W), np.float32)
