@@ -238,6 +238,16 @@ void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> 
                                   ptr(densityBC, false), ptr(densityBCInvMask, false), cur_stream(U)));
 }
 
+// max |x| of a 5-D field as a 0-dim device tensor (no host sync) -- CFL guard of the z-slab driver
+Tensor max_abs(Tensor x) {
+  check_field(x, "x");
+  FnxGrid g{}; g.B = (int)x.size(0); g.D = (int)x.size(2); g.H = (int)x.size(3); g.W = (int)x.size(4); g.is3D = g.D > 1;
+  c10::hip::HIPGuard guard(x.get_device());
+  Tensor out = at::empty({}, x.options());
+  check_status(fnx_max_abs(&g, x.data_ptr<float>(), (int)x.size(1), out.data_ptr<float>(), cur_stream(x)));
+  return out;
+}
+
 Tensor flags_to_occupancy(Tensor flags) {
   FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
   c10::hip::HIPGuard guard(flags.get_device());
@@ -494,6 +504,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_wall_bcs_stick_", &set_wall_bcs_stick_, NoGil());
   m.def("set_const_vals_", &set_const_vals_, NoGil());
   m.def("flags_to_occupancy", &flags_to_occupancy, NoGil());
+  m.def("max_abs", &max_abs, NoGil());
   m.def("empty_domain_", &empty_domain_, py::arg("flags"), py::arg("boundary_width"), GEOM, NoGil());
   m.def("scalenet_pack", &scalenet_pack, NoGil());
   m.def("multiscale_forward", &multiscale_forward, NoGil());

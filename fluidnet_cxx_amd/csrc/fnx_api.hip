@@ -510,6 +510,17 @@ int fnx_flags_to_occupancy(const FnxGrid* g, const float* flags, float* occupanc
   return FNX_OK;
 }
 
+int fnx_max_abs(const FnxGrid* g, const float* x, int channels, float* out_max, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!x || !out_max || channels < 1) return fail(FNX_EINVAL, "max_abs: NULL tensor or channels < 1");
+  if (((size_t)x & 15) != 0) return fail(FNX_EINVAL, "max_abs: the field must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_OK(hipMemsetAsync(out_max, 0, 4, s));
+  fnx::launch_max_abs(ncell(g) * (size_t)channels, x, out_max, s);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* stream) {
   if (int rc = check_grid(g)) return rc;
   if (!flags) return fail(FNX_EINVAL, "empty_domain: NULL tensor");

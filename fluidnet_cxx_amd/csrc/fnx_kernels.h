@@ -47,6 +47,7 @@ void launch_set_wall_bcs_stick(const GridDims& g, const float* Uin, float* Uout,
                                hipStream_t s);
 void launch_set_const_vals(size_t n, float* x, const float* bc, const float* inv_mask, hipStream_t s);
 void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStream_t s);
+void launch_max_abs(size_t n, const float* x, float* out, hipStream_t s);
 void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s);
 
 // fused step stages (fnx_step.hip)

@@ -327,6 +327,28 @@ void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStre
   occupancy_kernel<<<stream_blocks(n), 256, 0, s>>>(n, flags, occ);
 }
 
+// max |x| over n floats into *out (a non-negative float; its bit pattern orders like an unsigned integer).  The caller
+// zeroes *out.  NaNs are ignored (v_max semantics).
+__global__ __launch_bounds__(256) void max_abs_kernel(size_t n4, size_t n, const float* __restrict__ x, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const float4* x4 = (const float4*)x;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+    const float4 v = x4[q];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+void launch_max_abs(size_t n, const float* x, float* out, hipStream_t s) {
+  size_t nb = (n / 4 + 256 * 8 - 1) / (256 * 8);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  max_abs_kernel<<<(unsigned)nb, 256, 0, s>>>(n / 4, n, x, (unsigned*)out);
+}
+
 void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s) {
   if (is3d) empty_domain_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, bnd);
   else empty_domain_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, bnd);

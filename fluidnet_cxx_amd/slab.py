@@ -178,6 +178,10 @@ class NativeOps:
                               int(k_begin2), self._geom(False))
         self._mask_valid = True
 
+    def max_abs(self, x):
+        """max |x| as a 0-dim tensor on x's device (no host sync)"""
+        return self.ext.max_abs(x)
+
     def post_projection(self, st):
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
                                   st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st), self._geom())
@@ -187,8 +191,13 @@ class SlabSimulator:
     """`simulate(mconf, batch_dict, None, 'jacobi')` for one rank's slab of a 3D domain (in place on `state`)."""
 
     def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4, schedule="edge_first",
-                 static_flags=False):
+                 static_flags=False, cfl_check_every=8):
+        """cfl_check_every: every that many steps (0 = never) the step starts by reducing max |U| dt over all ranks and
+        raises RuntimeError on EVERY rank when it exceeds 1 cell -- the bound the ghost widths, the advection windows and the
+        overlapped U / density exchange rest on (a violation would otherwise read stale ghost planes silently).  Costs one
+        pass over U and one 4-byte all-reduce(MAX) on the control path."""
         assert schedule in ("last_pass", "edge_first")
+        self.cfl_check_every = int(cfl_check_every)
         self.schedule = schedule
         self.static_flags = static_flags     # the caller promises that flags and BC arrays do not change between steps
         self._steps = 0
@@ -200,6 +209,7 @@ class SlabSimulator:
         self._pbuf = None
         assert layout.world == 1 or layout.owned >= 2 * self.w, "slab too thin for the sweep block"
         assert layout.world == 1 or layout.halo >= 5, "advection + projection need 5 valid ghost planes (CFL <= 1)"
+        assert float(mconf.get("pTol", 0.0)) >= 0.0
 
     def _side_stream(self, t):
         """A second HIP stream for work that may run next to the main stream's (device tensors with the native
@@ -219,6 +229,15 @@ class SlabSimulator:
         l, cfg, ops = self.l, self.cfg, self.ops
         dt = float(cfg["dt"])
         w = self.w
+        assert "density" in st, "the z-slab driver advects a density field (simulate() without one is single-domain only)"
+        if self.cfl_check_every > 0 and self._steps % self.cfl_check_every == 0 and hasattr(ops, "max_abs"):
+            # CFL guard: max |U| dt over the whole domain (every rank gets the same number and raises or not together)
+            m = ops.max_abs(st["U"]).reshape(1).clone()
+            yield "allmax", m
+            cfl = float(m.item()) * abs(dt)
+            if cfl > 1.0:
+                raise RuntimeError(f"z-slab step: max |U| dt = {cfl:.3f} cells > 1 -- the slab decomposition (ghost widths, advection "
+                                   f"windows) is only valid for CFL <= 1; reduce dt or run the single-domain simulate()")
         if hasattr(ops, "begin_step") and not (self.static_flags and self._steps > 0):
             ops.begin_step()                 # (forget the solver's neighbour mask and the BC class map)
         if hasattr(ops, "static_bcs"):
@@ -267,7 +286,9 @@ class SlabSimulator:
         yield "xchg", [div], max(w - 1, 1)
 
         ops.set_slab(l.z_offset, l.D_global)
-        if self.schedule == "edge_first" and l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w:
+        if float(cfg.get("pTol", 0.0)) > 0.0:
+            cur = yield from self._jacobi_ptol(st, div)
+        elif self.schedule == "edge_first" and l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w:
             cur = yield from self._jacobi_edge_first(st, div)
         else:
             cur = yield from self._jacobi_last_pass(st, div)
@@ -281,6 +302,35 @@ class SlabSimulator:
         if window:
             window(0, 0)
         ops.set_slab(0, 0)
+
+    def _jacobi_ptol(self, st, div):
+        """pTol > 0: the reference's convergence test (fluids_init.cpp:961-979) -- after EVERY sweep the residual
+        max_b ||p_new - p_old||_2 over the whole domain is compared with pTol on the host.  Decomposed: one sweep per ghost
+        exchange, the squared differences summed over the owned planes and all-reduced (a B-float collective per sweep; the
+        single-domain solver pays a host sync per sweep here too).  Temporal blocking does not apply: the exit test needs
+        every sweep's result."""
+        l, cfg, ops = self.l, self.cfg, self.ops
+        if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
+            self._pbuf = torch.zeros_like(st["p"])
+        cur, nxt = st["p"], self._pbuf
+        cur.zero_()
+        lo, top = l.lo, l.lo + l.owned
+        a = lo if l.rank > 0 else 0
+        b = top if l.rank < l.world - 1 else l.D_local
+        tol = float(cfg["pTol"])
+        for it in range(int(cfg["jacobiIter"])):
+            if it > 0:
+                yield "xchg", [cur], 1
+                ops.set_slab(l.z_offset, l.D_global)
+            ops.jacobi_pass(st["flags"], div, cur, nxt, 1, a, b)
+            d = (nxt[:, :, lo:top] - cur[:, :, lo:top]).double()
+            ss = (d * d).sum(dim=(1, 2, 3, 4))
+            yield "allsum", ss
+            ops.set_slab(l.z_offset, l.D_global)
+            cur, nxt = nxt, cur
+            if float(ss.sqrt().max().item()) < tol:
+                break
+        return cur
 
     def _jacobi_edge_first(self, st, div):
         """Jacobi schedule "edge_first": the same blocks of w sweeps and the same shrinking plane ranges as "last_pass"
@@ -427,6 +477,9 @@ class SlabSimulator:
             for req in self.phases(st):
                 if req[0] == "xchg":
                     self.comm.exchange(req[1], req[2])
+                elif req[0] in ("allmax", "allsum"):
+                    if self.l.world > 1:
+                        dist.all_reduce(req[1], op=dist.ReduceOp.MAX if req[0] == "allmax" else dist.ReduceOp.SUM, group=self.comm.group)
                 elif req[0] == "start":
                     handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None)
                 else:
@@ -467,6 +520,13 @@ def lockstep_step(sims, states, defer=False):
         if all(r is None for r in reqs):
             break
         assert all(r is not None for r in reqs) and len({r[0] for r in reqs}) == 1, "ranks fell out of step"
+        if reqs[0][0] in ("allmax", "allsum"):
+            ts = [r[1] for r in reqs]
+            red = torch.stack([t.to(ts[0].device) for t in ts])
+            red = red.max(0).values if reqs[0][0] == "allmax" else red.sum(0)
+            for t in ts:
+                t.copy_(red)
+            continue
         if reqs[0][0] == "wait":
             if posted is not None:
                 serve(posted)

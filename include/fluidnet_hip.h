@@ -160,6 +160,11 @@ int fnx_set_const_vals(const FnxGrid* g, float* U, const float* UBC, const float
 /* flagsToOccupancy, lib/fluid/flags_to_occupancy.py:6-19 */
 int fnx_flags_to_occupancy(const FnxGrid* g, const float* flags, float* occupancy, void* stream);
 
+/* max |x| over a (B,channels,D,H,W) field into *out_max (DEVICE float; overwritten).  No reference counterpart: the
+ * z-slab driver's CFL guard (max |U| dt <= 1 is what its ghost widths rest on) and any caller that wants the CFL number
+ * without a host-side reduction.  NaNs are ignored. */
+int fnx_max_abs(const FnxGrid* g, const float* x, int channels, float* out_max, void* stream);
+
 /* emptyDomain (writes flags), lib/fluid/util.py:5-47 */
 int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* stream);
 

@@ -88,6 +88,9 @@ class OracleOps:
         else:
             p_out[:, :, k_begin:k_end].copy_(full[:, :, k_begin:k_end])
 
+    def max_abs(self, x):
+        return x.abs().max()
+
     def post_projection(self, st):
         O = self.O
         n = {k: v.numpy() for k, v in st.items()}
@@ -137,6 +140,51 @@ def test_lockstep_slabs_match_single_domain_cpu(world, halo, w, schedule):
         check_owned(st, ref, l, f"lockstep world={world}")
 
 
+def test_cfl_guard_raises_on_every_rank():
+    """max |U| dt > 1 breaks the assumption the ghost widths rest on: the step must refuse loudly (on all ranks: the
+    number is all-reduced), not read stale ghost planes."""
+    from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
+    D, H, W, world = 24, 12, 16, 2
+    gs = global_state(D, H, W)
+    gs["U"] = gs["U"] * 20.0                           # CFL ~ 20 * 1.5 * 4 sigma * dt
+    layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
+    sims = [SlabSimulator(l, CFG, ops=OracleOps(), sweeps_per_exchange=4, schedule="last_pass") for l in layouts]
+    states = [local_state(gs, l) for l in layouts]
+    with pytest.raises(RuntimeError, match="CFL <= 1"):
+        lockstep_step(sims, states)
+    # the guard is periodic: with cfl_check_every=0 nothing is checked (and nothing promised)
+    sims = [SlabSimulator(l, CFG, ops=OracleOps(), sweeps_per_exchange=4, schedule="last_pass", cfl_check_every=0) for l in layouts]
+    lockstep_step(sims, [local_state(gs, l) for l in layouts])
+
+
+@pytest.mark.parametrize("tol", [1e9, 1e-30, "mid"])
+def test_ptol_exit_matches_single_domain(tol):
+    """pTol > 0 (the reference's per-sweep convergence test): the decomposed solve takes the same number of sweeps as the
+    single-domain one -- the residual is all-reduced over the ranks -- and gives the same bits."""
+    from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
+    from oracle import oracle as O
+    D, H, W, world = 24, 12, 16, 3
+    gs = global_state(D, H, W)
+    if tol == "mid":
+        # a tolerance that stops the solve part-way: the first of a log grid whose result differs from both extremes
+        lo = O.simulate_step(dict(gs), dict(CFG, pTol=1e9), "jacobi")["p"]
+        hi = O.simulate_step(dict(gs), dict(CFG, pTol=1e-30), "jacobi")["p"]
+        for cand in (3.0, 1.0, 0.3, 0.1, 0.03, 0.01, 3e-3, 1e-3):
+            mid = O.simulate_step(dict(gs), dict(CFG, pTol=cand), "jacobi")["p"]
+            if not np.array_equal(mid, lo) and not np.array_equal(mid, hi):
+                tol = cand
+                break
+        assert tol != "mid", "no tolerance of the grid stops the solve part-way"
+    cfg = dict(CFG, pTol=tol)
+    ref = O.simulate_step(dict(gs), cfg, "jacobi")
+    layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
+    sims = [SlabSimulator(l, cfg, ops=OracleOps(), sweeps_per_exchange=4, schedule="edge_first") for l in layouts]
+    states = [local_state(gs, l) for l in layouts]
+    lockstep_step(sims, states)
+    for l, st in zip(layouts, states):
+        check_owned(st, ref, l, f"pTol={tol}")
+
+
 def _dist_worker(rank, world, port, D, H, W, halo, w, schedule, out_dir):
     sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
     import torch.distributed as dist
@@ -148,7 +196,8 @@ def _dist_worker(rank, world, port, D, H, W, halo, w, schedule, out_dir):
         gs = global_state(D, H, W)
         layout = SlabLayout(D, world, rank, halo)
         ops = OracleOps(); ops.windows = True
-        sim = SlabSimulator(layout, CFG, ops=ops, sweeps_per_exchange=w, schedule=schedule)
+        cfg = dict(CFG, pTol=0.05) if schedule == "ptol" else CFG
+        sim = SlabSimulator(layout, cfg, ops=ops, sweeps_per_exchange=w, schedule="edge_first" if schedule == "ptol" else schedule)
         st = local_state(gs, layout)
         for _ in range(2):
             sim.step(st)
@@ -157,9 +206,10 @@ def _dist_worker(rank, world, port, D, H, W, halo, w, schedule, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("schedule", ["last_pass", "edge_first"])
+@pytest.mark.parametrize("schedule", ["last_pass", "edge_first", "ptol"])
 def test_gloo_two_ranks_match_single_domain(tmp_path, schedule):
-    """world_size 2 over gloo: real send/recv between two processes."""
+    """world_size 2 over gloo: real send/recv between two processes ("ptol": the per-sweep residual all-reduce of the
+    pTol > 0 solve; every variant also runs the CFL guard's all-reduce)."""
     import torch.multiprocessing as mp
     from fluidnet_cxx_amd.slab import SlabLayout
     D, H, W, halo, w, world = (32 if schedule == "edge_first" else 24), 12, 16, 6, 4, 2
@@ -167,7 +217,13 @@ def test_gloo_two_ranks_match_single_domain(tmp_path, schedule):
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     os.environ.setdefault("OMP_NUM_THREADS", "2")
     mp.spawn(_dist_worker, args=(world, port, D, H, W, halo, w, schedule, str(tmp_path)), nprocs=world, join=True)
-    ref = reference_steps(global_state(D, H, W), 2)
+    if schedule == "ptol":
+        from oracle import oracle as O
+        ref = dict(global_state(D, H, W))
+        for _ in range(2):
+            ref = O.simulate_step(ref, dict(CFG, pTol=0.05), "jacobi")
+    else:
+        ref = reference_steps(global_state(D, H, W), 2)
     for r in range(world):
         l = SlabLayout(D, world, r, halo)
         z = np.load(tmp_path / f"rank{r}.npz")
