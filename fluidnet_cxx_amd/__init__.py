@@ -14,6 +14,8 @@ def __getattr__(name):
         return importlib.import_module("._simulate", __name__).simulate
     if name in ("save_restart", "load_restart", "rollout"):
         return getattr(importlib.import_module(".state_io", __name__), name)
+    if name == "output":
+        return importlib.import_module(".output", __name__)
     if name in ("FluidNet", "MultiScaleNet"):
         return getattr(importlib.import_module(".model", __name__), name)
     raise AttributeError(name)

@@ -262,6 +262,31 @@ void empty_domain_(Tensor flags, int boundary_width, const Geom* geom) {
   check_status(fnx_empty_domain(&g, flags.data_ptr<float>(), boundary_width, cur_stream(flags)));
 }
 
+// geometry written into flags (all z planes), lib/fluid/geometry_utils.py:4-63
+void create_cylinder_(Tensor flags, double center_x, double center_y, double radius) {
+  FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_create_cylinder(&g, flags.data_ptr<float>(), center_x, center_y, radius, cur_stream(flags)));
+}
+
+void create_box2d_(Tensor flags, double x0, double x1, double y0, double y1) {
+  FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_create_box2d(&g, flags.data_ptr<float>(), (float)x0, (float)x1, (float)y0, (float)y1, cur_stream(flags)));
+}
+
+// lib/fluid/grid.py:7-32
+Tensor get_centered(Tensor U) {
+  check_field(U, "U");
+  TORCH_CHECK(U.size(1) == 2 || U.size(1) == 3, "velocity field must have 2 or 3 channels");
+  FnxGrid g{}; g.B = (int)U.size(0); g.D = (int)U.size(2); g.H = (int)U.size(3); g.W = (int)U.size(4); g.is3D = U.size(1) == 3;
+  TORCH_CHECK(g.is3D || g.D == 1, "2D velocity field but zdepth > 1");
+  c10::hip::HIPGuard guard(U.get_device());
+  Tensor out = at::empty({U.size(0), 3, U.size(2), U.size(3), U.size(4)}, U.options());
+  check_status(fnx_get_centered(&g, U.data_ptr<float>(), out.data_ptr<float>(), cur_stream(U)));
+  return out;
+}
+
 // ---- CNN pressure projection --------------------------------------------------------------------------
 Tensor scalenet_pack(Tensor blob, bool is3D) {
   TORCH_CHECK(blob.is_cuda() && blob.scalar_type() == at::kFloat && blob.is_contiguous(), "weights blob must be a contiguous float32 GPU tensor");
@@ -506,6 +531,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("flags_to_occupancy", &flags_to_occupancy, NoGil());
   m.def("max_abs", &max_abs, NoGil());
   m.def("empty_domain_", &empty_domain_, py::arg("flags"), py::arg("boundary_width"), GEOM, NoGil());
+  m.def("create_cylinder_", &create_cylinder_, NoGil());
+  m.def("create_box2d_", &create_box2d_, NoGil());
+  m.def("get_centered", &get_centered, NoGil());
   m.def("scalenet_pack", &scalenet_pack, NoGil());
   m.def("multiscale_forward", &multiscale_forward, NoGil());
   m.def("fluidnet_forward", &fluidnet_forward, NoGil());

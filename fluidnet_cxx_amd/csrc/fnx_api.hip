@@ -530,6 +530,39 @@ int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* s
   return FNX_OK;
 }
 
+int fnx_create_cylinder(const FnxGrid* g, float* flags, double center_x, double center_y, double radius, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!flags) return fail(FNX_EINVAL, "create_cylinder: NULL tensor");
+  // the reference squares the radius as a python double and the comparison casts it to fp32 (geometry_utils.py:31)
+  const float r2 = (float)(radius * radius);
+  fnx::launch_create_cylinder(dims(g), flags, (float)center_x, (float)center_y, r2, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_create_box2d(const FnxGrid* g, float* flags, float x0, float x1, float y0, float y1, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!flags) return fail(FNX_EINVAL, "create_box2d: NULL tensor");
+  fnx::launch_create_box2d(dims(g), flags, x0, x1, y0, y1, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_get_centered(const FnxGrid* g, const float* U, float* centered, void* stream) {
+  // a pure per-cell average: any block of a field is a valid input (the drivers pass interior blocks, plume.py:351), so
+  // only the launch limits are checked, not the operators' minimum domain size
+  if (!g) return fail(FNX_EINVAL, "grid descriptor is NULL");
+  if (g->B < 1 || g->D < 1 || g->H < 1 || g->W < 1) return fail(FNX_EINVAL, "Dimension mismatch: B=%d D=%d H=%d W=%d", g->B, g->D, g->H, g->W);
+  if (!g->is3D && g->D != 1) return fail(FNX_EINVAL, "2D velocity field but zdepth > 1");
+  if ((long long)g->D * g->H * g->W >= (1ll << 31)) return fail(FNX_EINVAL, "more than 2^31 cells per sample");
+  if ((long long)g->B * g->D > 65535 || (g->H + 3) / 4 > 65535) return fail(FNX_EINVAL, "B*D or H/4 > 65535 not supported");
+  if (!U || !centered) return fail(FNX_EINVAL, "get_centered: NULL tensor");
+  if ((const float*)centered == U) return fail(FNX_EINVAL, "get_centered: the output must not alias U");
+  fnx::launch_get_centered(make_dims(g->B, g->D, g->H, g->W), g->is3D, U, centered, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
                        const float* rho_adv, float* div, void* stream) {
   if (int rc = check_grid(g)) return rc;

@@ -269,6 +269,44 @@ __global__ __launch_bounds__(BX* BY) void empty_domain_kernel(GridDims g, float*
   flags[(size_t)c.b * g.DHW + (size_t)c.k * g.HW + c.j * g.W + c.i] = border ? FNX_OBST : FNX_FLUID;
 }
 
+// createCylinder / createBox2D, lib/fluid/geometry_utils.py:4-34, 36-63: obstacle cells written into flags on every z plane.
+// Cylinder: the reference evaluates (X - cx)^2 + (Y - cy)^2 <= r*r on int64 index grids promoted to fp32 (the python
+// scalars are cast to fp32 by the tensor iterator): float(i) - cx, squared, summed, compared with float(r*r).
+template <bool BOX>
+__global__ __launch_bounds__(BX* BY) void geometry_kernel(GridDims g, float* __restrict__ flags, float a0, float a1,
+                                                          float a2, float a3) {
+  const CellId c = cell_id<true>(g);
+  if (!c.valid) return;
+  bool inside;
+  if (BOX) {
+    // a0 <= x < a1, a2 <= y < a3 (the box the reference's docstring describes; its own body cannot run, :59-62)
+    const float x = (float)c.i, y = (float)c.j;
+    inside = (x >= a0) & (x < a1) & (y >= a2) & (y < a3);
+  } else {
+    const float dx = (float)c.i - a0, dy = (float)c.j - a1;
+    inside = dx * dx + dy * dy <= a2;
+  }
+  if (inside) flags[(size_t)c.b * g.DHW + (size_t)c.k * g.HW + c.j * g.W + c.i] = FNX_OBST;
+}
+
+// getCentered, lib/fluid/grid.py:7-32: cell-centred velocity 0.5 (u_c + u_c(+1)) per component, 0 on the last
+// column / row / plane; always 3 output channels (the z channel is 0 in 2D).
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void get_centered_kernel(GridDims g, const float* __restrict__ U,
+                                                              float* __restrict__ out) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* u = U + (size_t)c.b * NC * g.DHW + o;
+  float* r = out + (size_t)c.b * 3 * g.DHW + o;
+  r[0] = c.i < g.W - 1 ? 0.5f * (u[0] + u[1]) : 0.f;
+  r[g.DHW] = c.j < g.H - 1 ? 0.5f * (u[g.DHW] + u[(size_t)g.DHW + g.W]) : 0.f;
+  float z = 0.f;
+  if (IS3D) z = c.k < g.D - 1 ? 0.5f * (u[(size_t)2 * g.DHW] + u[(size_t)2 * g.DHW + g.HW]) : 0.f;
+  r[(size_t)2 * g.DHW] = z;
+}
+
 inline int stream_blocks(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b < 2048 ? (b ? b : 1) : 2048);
@@ -352,6 +390,19 @@ void launch_max_abs(size_t n, const float* x, float* out, hipStream_t s) {
 void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hipStream_t s) {
   if (is3d) empty_domain_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, bnd);
   else empty_domain_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, bnd);
+}
+
+void launch_create_cylinder(const GridDims& g, float* flags, float cx, float cy, float r2, hipStream_t s) {
+  geometry_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, cx, cy, r2, 0.f);
+}
+
+void launch_create_box2d(const GridDims& g, float* flags, float x0, float x1, float y0, float y1, hipStream_t s) {
+  geometry_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, flags, x0, x1, y0, y1);
+}
+
+void launch_get_centered(const GridDims& g, bool is3d, const float* U, float* out, hipStream_t s) {
+  if (is3d) get_centered_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, out);
+  else get_centered_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, out);
 }
 
 }  // namespace fnx

@@ -15,10 +15,10 @@ CellType = IntEnum("CellType", dict(TypeNone=0, TypeFluid=1, TypeObstacle=2, Typ
 Geom = _ext.Geom     # per-call 3D geometry options (ref_quirks, z-slab view, compute window); no reference counterpart
 from .ops import (advectScalar, advectVelocity, correctScalar, solveLinearSystemJacobi, velocityDivergence,
                   velocityUpdate, addBuoyancy, addGravity, addViscosity, setWallBcs, setWallBcsStick, flagsToOccupancy, setConstVals,
-                  getDx)
+                  getDx, getCentered)
 from .init_conditions import emptyDomain, createPlumeBCs, createRayleighTaylorBCs
 from .geometry_utils import createCylinder, createBox2D
 
 __all__ = ["CellType", "Geom", "advectScalar", "advectVelocity", "correctScalar", "solveLinearSystemJacobi",
            "velocityDivergence", "velocityUpdate", "addBuoyancy", "addGravity", "addViscosity", "setWallBcs", "setWallBcsStick", "flagsToOccupancy", "setConstVals",
-           "getDx", "emptyDomain", "createPlumeBCs", "createRayleighTaylorBCs", "createCylinder", "createBox2D"]
+           "getDx", "getCentered", "emptyDomain", "createPlumeBCs", "createRayleighTaylorBCs", "createCylinder", "createBox2D"]

@@ -29,6 +29,12 @@ def getDx(self):
     return 1.0 / max(self.size(2), self.size(3), self.size(4))
 
 
+def getCentered(self):
+    """lib/fluid/grid.py:7-32: MAC velocity (B,2|3,D,H,W) -> cell-centred (B,3,D,H,W), 0 on the last column/row/plane."""
+    assert self.dim() == 5, "Dimension mismatch"
+    return ext.get_centered(self.contiguous())
+
+
 def advectScalar(dt, src, U, flags, method="maccormackFluidNet", boundary_width=1, sample_outside_fluid=False,
                  maccormack_strength=0.75, *, geom=None):
     """cpp/advection.py:14-66 -> pybind advect_scalar (cpp/fluids_init.cpp:265-382). 3D is supported here."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 6
+#define FNX_ABI_VERSION 7
 
 enum {
   FNX_OK = 0,
@@ -167,6 +167,19 @@ int fnx_max_abs(const FnxGrid* g, const float* x, int channels, float* out_max, 
 
 /* emptyDomain (writes flags), lib/fluid/util.py:5-47 */
 int fnx_empty_domain(const FnxGrid* g, float* flags, int boundary_width, void* stream);
+
+/* createCylinder, lib/fluid/geometry_utils.py:4-34: cells with (x - center_x)^2 + (y - center_y)^2 <= radius^2 (integer
+ * cell indices against the float centre, fp32 arithmetic as the reference's tensor expression evaluates it) become
+ * obstacles on every z plane.  The scalars are doubles like the python floats the reference takes: radius is squared in
+ * double and then rounded to fp32, the centre is rounded to fp32 (what the tensor iterator does).  In place on flags. */
+int fnx_create_cylinder(const FnxGrid* g, float* flags, double center_x, double center_y, double radius, void* stream);
+/* createBox2D, lib/fluid/geometry_utils.py:36-63: cells with x0 <= x < x1 and y0 <= y < y1 become obstacles.  The
+ * reference's body cannot run (it tests Y against y1 twice and names an undefined mask, :59-62); this is the box its
+ * docstring describes.  In place on flags. */
+int fnx_create_box2d(const FnxGrid* g, float* flags, float x0, float x1, float y0, float y1, void* stream);
+/* getCentered, lib/fluid/grid.py:7-32: (B,2|3,D,H,W) MAC velocity -> (B,3,D,H,W) cell-centred velocity (the z channel
+ * is 0 in 2D); what the drivers' field dumps plot (plume.py:243,336). */
+int fnx_get_centered(const FnxGrid* g, const float* U, float* centered, void* stream);
 
 /* One whole time step, lib/simulate.py:28-171 (the keys simulate() reads from mconf). */
 typedef struct FnxStepParams {

@@ -802,3 +802,43 @@ int ora_empty_domain(const OraGrid* g, float* flags, int bnd) {
         for (int i = 0; i < g->W; ++i) flags[IDX(g, 1, b, 0, k, j, i)] = is_border(g, i, j, k, bnd) ? T_OBST : T_FLUID;
   return 0;
 }
+
+/* createCylinder (geometry_utils.py:26-33): (X - cx)^2 + (Y - cy)^2 <= r*r with int64 index grids promoted to fp32 and
+ * the python scalars rounded to fp32 (r*r is squared in double first); every z plane. */
+int ora_create_cylinder(const OraGrid* g, float* flags, double cx, double cy, double radius) {
+  const float fcx = (float)cx, fcy = (float)cy, r2 = (float)(radius * radius);
+  for (int b = 0; b < g->B; ++b)
+    for (int k = 0; k < g->D; ++k)
+      for (int j = 0; j < g->H; ++j)
+        for (int i = 0; i < g->W; ++i) {
+          const float dx = (float)i - fcx, dy = (float)j - fcy;
+          const float a = dx * dx, c = dy * dy;
+          if (a + c <= r2) flags[IDX(g, 1, b, 0, k, j, i)] = T_OBST;
+        }
+  return 0;
+}
+
+/* createBox2D as its docstring describes it (geometry_utils.py:36-46; the body :59-62 cannot run): x0 <= x < x1, y0 <= y < y1 */
+int ora_create_box2d(const OraGrid* g, float* flags, double x0, double x1, double y0, double y1) {
+  for (int b = 0; b < g->B; ++b)
+    for (int k = 0; k < g->D; ++k)
+      for (int j = 0; j < g->H; ++j)
+        for (int i = 0; i < g->W; ++i)
+          if ((float)i >= (float)x0 && (float)i < (float)x1 && (float)j >= (float)y0 && (float)j < (float)y1)
+            flags[IDX(g, 1, b, 0, k, j, i)] = T_OBST;
+  return 0;
+}
+
+/* getCentered (grid.py:7-32): U (B,2|3,D,H,W) -> (B,3,D,H,W) */
+int ora_get_centered(const OraGrid* g, const float* U, float* out) {
+  const int nc = g->is3D ? 3 : 2;
+  for (int b = 0; b < g->B; ++b)
+    for (int k = 0; k < g->D; ++k)
+      for (int j = 0; j < g->H; ++j)
+        for (int i = 0; i < g->W; ++i) {
+          out[IDX(g, 3, b, 0, k, j, i)] = i < g->W - 1 ? 0.5f * (U[IDX(g, nc, b, 0, k, j, i)] + U[IDX(g, nc, b, 0, k, j, i + 1)]) : 0.f;
+          out[IDX(g, 3, b, 1, k, j, i)] = j < g->H - 1 ? 0.5f * (U[IDX(g, nc, b, 1, k, j, i)] + U[IDX(g, nc, b, 1, k, j + 1, i)]) : 0.f;
+          out[IDX(g, 3, b, 2, k, j, i)] = (g->is3D && k < g->D - 1) ? 0.5f * (U[IDX(g, nc, b, 2, k, j, i)] + U[IDX(g, nc, b, 2, k + 1, j, i)]) : 0.f;
+        }
+  return 0;
+}

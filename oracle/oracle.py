@@ -194,6 +194,31 @@ def empty_domain(B, D, H, W, bnd=1):
     return flags
 
 
+def create_cylinder(flags, cx, cy, radius):
+    """geometry_utils.py:4-34; returns a new flags array"""
+    f, pf = _f(flags.copy())
+    g = _grid(f)
+    lib().ora_create_cylinder(ctypes.byref(g), pf, ctypes.c_double(cx), ctypes.c_double(cy), ctypes.c_double(radius))
+    return f
+
+
+def create_box2d(flags, x0, x1, y0, y1):
+    f, pf = _f(flags.copy())
+    g = _grid(f)
+    lib().ora_create_box2d(ctypes.byref(g), pf, ctypes.c_double(x0), ctypes.c_double(x1), ctypes.c_double(y0), ctypes.c_double(y1))
+    return f
+
+
+def get_centered(U):
+    """grid.py:7-32"""
+    u, pu = _f(U)
+    B, nc, D, H, W = u.shape
+    g = OraGrid(B, D, H, W, int(nc == 3), 0, 0)
+    out = np.empty((B, 3, D, H, W), np.float32)
+    lib().ora_get_centered(ctypes.byref(g), pu, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
 def pack_weights(wdict, ndim=2):
     """Flatten a torch-named weight dict into the canonical blob (see cnn_oracle.c header)."""
     from fluidnet_cxx_amd.weights import scalenet_layers

@@ -49,7 +49,8 @@ def test_extension_entry_points(built):
     for n in ("advect_scalar", "advect_vel", "solve_linear_system"):
         assert hasattr(ext, n)
     for n in ("velocity_divergence", "velocity_update_", "add_buoyancy_", "set_wall_bcs_", "set_const_vals_",
-              "flags_to_occupancy", "empty_domain_", "fluidnet_forward", "simulate_step_"):
+              "flags_to_occupancy", "empty_domain_", "fluidnet_forward", "simulate_step_", "create_cylinder_", "create_box2d_",
+              "get_centered"):
         assert hasattr(ext, n)
     # no mutable module state (the reference is re-entrant): quirk mode / slab view / window are per-call (ext.Geom)
     for n in ("set_ref_quirks", "set_slab", "set_window"):
@@ -73,6 +74,12 @@ def test_python_surface_matches_reference(built):
     sig = inspect.signature(fluid.solveLinearSystemJacobi)
     assert positional(sig) == ["flags", "div", "is_3d", "p_tol", "max_iter", "verbose"]
     assert sig.parameters["p_tol"].default == 1e-5 and sig.parameters["max_iter"].default == 1000
+    # every name the reference's lib/fluid/__init__.py:1-14 re-exports is there
+    for n in ("CellType", "getDx", "getCentered", "setWallBcs", "setWallBcsStick", "flagsToOccupancy", "velocityDivergence",
+              "velocityUpdate", "addBuoyancy", "addGravity", "addViscosity", "createCylinder", "createBox2D", "emptyDomain",
+              "createPlumeBCs", "createRayleighTaylorBCs", "correctScalar", "advectScalar", "advectVelocity",
+              "solveLinearSystemJacobi"):
+        assert hasattr(fluid, n), n
     assert int(fluid.CellType.TypeFluid) == 1 and int(fluid.CellType.TypeObstacle) == 2 and int(fluid.CellType.TypeEmpty) == 4
 
 

@@ -75,21 +75,20 @@ def test_generators(oracle, golden):
             assert_bitexact(st[k], z[f"plume{res}_{k}"], k)
 
 
-def test_geometry_generators(golden):
+def test_geometry_generators(oracle, golden):
     """createCylinder against the reference's flags (2D and 3D); createBox2D (the reference's cannot run) against its
-    documented meaning.  Host logic: plain torch on whatever device the flags live on."""
-    import torch
-    from fluidnet_cxx_amd.fluid import geometry_utils as G
+    documented meaning; getCentered against the reference's output."""
     from util import make_flags
     z = golden("generators")
     for tag, shape in (("cyl2d", (1, 1, 40, 32)), ("cyl3d", (1, 5, 24, 28))):
-        bd = dict(flags=torch.from_numpy(make_flags(*shape, boxes=False)))
-        G.createCylinder(bd, 15.5, 20.0, 6.3)
-        assert_bitexact(bd["flags"].numpy(), z[tag + "_flags"], tag)
-    bd = dict(flags=torch.from_numpy(make_flags(1, 1, 20, 30, boxes=False)))
-    G.createBox2D(bd, 5, 9, 3, 6)
+        got = oracle.create_cylinder(make_flags(*shape, boxes=False), 15.5, 20.0, 6.3)
+        assert_bitexact(got, z[tag + "_flags"], tag)
+    got = oracle.create_box2d(make_flags(1, 1, 20, 30, boxes=False), 5, 9, 3, 6)
     want = make_flags(1, 1, 20, 30, boxes=False); want[0, 0, 0, 3:6, 5:9] = 2
-    assert_bitexact(bd["flags"].numpy(), want, "box2d")
+    assert_bitexact(got, want, "box2d")
+    zg = golden("grid")
+    for tag in ("2d", "3d"):
+        assert_bitexact(oracle.get_centered(zg[f"U_{tag}"]), zg[f"centered_{tag}"], f"getCentered {tag}")
 
 
 def test_cnn_tolerance(oracle, golden):

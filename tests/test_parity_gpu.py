@@ -231,6 +231,34 @@ def test_generators_bitexact(fl, dev, golden):
     assert_close(N(bd["density"]), z["rt_density"], 1e-6, "Rayleigh-Taylor density")
 
 
+def test_geometry_and_centered_bitexact(fl, dev, golden, oracle):
+    """createCylinder / createBox2D / getCentered as native kernels: the reference's flags and centred velocities (goldens),
+    and the oracle on a larger 3D grid with off-grid centres and radii that are not fp32 numbers."""
+    z = golden("generators")
+    for tag, shape in (("cyl2d", (1, 1, 40, 32)), ("cyl3d", (1, 5, 24, 28))):
+        bd = dict(flags=T(make_flags(*shape, boxes=False), dev))
+        fl.createCylinder(bd, 15.5, 20.0, 6.3)
+        assert_bitexact(N(bd["flags"]), z[tag + "_flags"], tag)
+    bd = dict(flags=T(make_flags(1, 1, 20, 30, boxes=False), dev))
+    fl.createBox2D(bd, 5, 9, 3, 6)
+    want = make_flags(1, 1, 20, 30, boxes=False); want[0, 0, 0, 3:6, 5:9] = 2
+    assert_bitexact(N(bd["flags"]), want, "box2d")
+    f0 = make_flags(1, 7, 150, 131, boxes=True)
+    for (cx, cy, r) in ((0.5 * 131, 0.5 * 150, 50), (40.3, 77.7, 12.1), (-3.0, 10.0, 9.9), (130.0, 149.0, 0.0)):
+        bd = dict(flags=T(f0, dev)); fl.createCylinder(bd, cx, cy, r)
+        assert_bitexact(N(bd["flags"]), oracle.create_cylinder(f0, cx, cy, r), f"cylinder {cx},{cy},{r}")
+    for box in ((0.5 * 131, 0.7 * 131, 0.2 * 150, 0.7 * 150), (-5, 3.5, 140.2, 1000), (10, 10, 3, 9)):
+        bd = dict(flags=T(f0, dev)); fl.createBox2D(bd, *box)
+        assert_bitexact(N(bd["flags"]), oracle.create_box2d(f0, *box), f"box {box}")
+    zg = golden("grid")
+    for tag in ("2d", "3d"):
+        assert_bitexact(N(fl.getCentered(T(zg[f"U_{tag}"], dev))), zg[f"centered_{tag}"], f"getCentered {tag}")
+    rng = np.random.default_rng(5)
+    for shape in ((2, 2, 1, 67, 130), (1, 3, 9, 33, 70)):
+        U = rng.standard_normal(shape).astype(np.float32)
+        assert_bitexact(N(fl.getCentered(T(U, dev))), oracle.get_centered(U), f"getCentered {shape}")
+
+
 @pytest.mark.parametrize("shape", [(1, 40, 70, 130), (1, 40, 1040, 1030)])
 def test_jacobi_pass_two_ranges(dev, ext, shape):
     """fnx_jacobi_pass2: two disjoint plane ranges in one launch == the two single-range calls, bit for bit (1 and 2 sweeps,

@@ -11,7 +11,7 @@ Runs only in the build container (needs /root/reference, no GPU).  It
   3. runs every hot-path operator on seeded inputs and stores inputs + outputs as .npz.
 
 The fixtures are data only (inputs and expected outputs).  Usage:
-    python tools/make_golden.py [--only ops2d,ops3d,plume,sim,cnn]
+    python tools/make_golden.py [--only ops2d,ops3d,plume,sim,cnn,gen,stick,grid,dump]
 """
 import argparse
 import importlib.util
@@ -315,6 +315,43 @@ def gen_generators(torch, lib, ext):
     print("  wrote generators.npz")
 
 
+def gen_grid(torch, lib, ext):
+    """getCentered (grid.py:7-32) on seeded MAC velocities, 2D (B=2) and 3D."""
+    out = {}
+    rng = np.random.default_rng(11)
+    for tag, shape in (("2d", (2, 2, 1, 12, 17)), ("3d", (1, 3, 5, 6, 9))):
+        U = rng.standard_normal(shape).astype(np.float32)
+        out[f"U_{tag}"] = U
+        out[f"centered_{tag}"] = lib.fluid.getCentered(torch.from_numpy(U.copy())).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "grid.npz"), **out)
+    print("  wrote grid.npz")
+
+
+def gen_dump(torch, lib, ext):
+    """The arrays the reference driver hands to pyevtk.gridToVTK (plume.py:317-408) for a seeded 2D state with
+    obstacles, on a window smaller than the domain.  The driver has no function for this: the statements are inline in
+    its main loop, so they are executed here from the reference file itself (by line range) in a namespace that holds
+    the state."""
+    import textwrap
+    import numpy.ma as ma
+    rng = np.random.default_rng(21)
+    H, W = 24, 38
+    flags = make_flags(rng, 1, 1, H, W, boxes=True)
+    bd = dict(U=rng.standard_normal((1, 2, 1, H, W)).astype(np.float32), p=rng.standard_normal((1, 1, 1, H, W)).astype(np.float32),
+              density=rng.random((1, 1, 1, H, W)).astype(np.float32), flags=flags)
+    out = {f"in_{k}": v for k, v in bd.items()}
+    win = dict(minX=2, maxX=35, minY=1, maxY=20, maxX_win=33, maxY_win=19)
+    out["window"] = np.array([win["minX"], win["maxX"], win["minY"], win["maxY"]], np.int32)
+    lines = open(os.path.join(REF, "pytorch/plume.py")).read().splitlines()
+    ns = dict(torch=torch, np=np, ma=ma, fluid=lib.fluid, batch_dict={k: torch.from_numpy(v.copy()) for k, v in bd.items()}, **win)
+    exec(textwrap.dedent("\n".join(lines[316:329])), ns)      # plume.py:317-329  nx, ny, dx, dy, x, y, z
+    exec(textwrap.dedent("\n".join(lines[330:408])), ns)      # plume.py:331-408  the cell arrays
+    for k in ("x", "y", "z", "divergence", "rho", "p", "velx", "vely", "gradRhox", "gradRhoy", "gradPx", "gradPy"):
+        out[f"vtk_{k}"] = np.asarray(ns[k]).copy()
+    np.savez_compressed(os.path.join(OUT, "dump.npz"), **out)
+    print("  wrote dump.npz")
+
+
 def stick_flags(flags):
     """flags_stick as cylinder.py:76 builds it: a copy of flags with the no-slip cells set to TypeStick (128).  Marked
     here: the obstacle box (thick), the single obstacle cell, the 1-cell bar (fluid on both sides) and a stretch of the
@@ -371,7 +408,7 @@ def gen_stick(torch, lib, ext):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops2d,ops3d,plume,sim,cnn,gen,stick")
+    ap.add_argument("--only", default="ops2d,ops3d,plume,sim,cnn,gen,stick,grid,dump")
     a = ap.parse_args()
     only = set(a.only.split(","))
     os.makedirs(OUT, exist_ok=True)
@@ -395,6 +432,10 @@ def main():
         gen_generators(torch, lib, ext)
     if "stick" in only:
         gen_stick(torch, lib, ext)
+    if "grid" in only:
+        gen_grid(torch, lib, ext)
+    if "dump" in only:
+        gen_dump(torch, lib, ext)
 
 
 if __name__ == "__main__":
