@@ -52,7 +52,7 @@ def build_lib(force=False, verbose=False):
         obj = os.path.join(HERE, "build", unit.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs + [__file__]):
-            cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + COMMON + extra + os.environ.get("FNX_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((unit, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

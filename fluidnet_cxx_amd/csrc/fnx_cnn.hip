@@ -5,7 +5,9 @@
 // the remaining thin layers (2->32 and 32->1 3x3, the final 1x1) are bandwidth-shaped and use a direct kernel
 // (a strip of output pixels x CO_T output channels per thread, weights through the scalar cache).
 #include "fnx_cnn.h"
+#include <assert.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "fnx_kernels.h"
 #include "../../include/fluidnet_hip.h"
 
@@ -35,7 +37,7 @@ inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 
 // ([16][Cin][Cout]) follow the [tap][Cin][Cout] image in the packed buffer
 inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_layer(L); }
 inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
-  if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
+  if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + 2 * (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
   if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
@@ -203,6 +205,7 @@ void launch_conv_k(const ConvArgs& a, hipStream_t s) {
 // outer loop over the three input planes.
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int MF_CHUNK = 8;       // input channels per LDS stage
 constexpr int MF_COLS = 34;       // 32 + halo
 
@@ -749,6 +752,357 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Third Winograd kernel: conv3_wino2_kernel's decomposition (two position halves x NCG output-channel groups x NPG pixel
+// groups; the same transforms, the same MFMA order per accumulator, the same epilogue arithmetic: SAME BITS) as a
+// PERSISTENT software pipeline.  wino2 serialises every stage -- halo tile -> LDS, barrier, transform, barrier, operand
+// reads, MFMAs -- and pays a full prologue (two dependent global round trips) and epilogue per 256-pixel tile with nothing
+// to overlap them: one 8-wave workgroup fills a CU's registers.  Measured on it at 1024^2: time = rounds x (5.5 us + stages
+// x 1.31 us) against 0.91 us of MFMA work per stage, 47 % of the MFMA peak.  Here:
+//  * every LDS image has two copies and a phase has ONE barrier.  Between two barriers a wave issues
+//      global -> registers   halo tile of stage s+2          (first; lands during the MFMAs)
+//      global -> LDS (DMA)   transformed weights of stage s+1
+//      LDS -> LDS            input transform of stage s+1 (halo tile s+1 -> xt[s+1]) in the gaps of the MFMA stream
+//      16 MFMAs              second k-step of stage s-1, then first k-step of stage s: the stream is rotated by half a
+//                            stage against the barriers and each k-step's operands are read half a phase before its
+//                            MFMAs, so a wave leaves a barrier with its next 8 MFMAs' operands already in registers
+//      registers -> LDS      halo tile of stage s+2 (into the copy the transform of stage s read one phase ago)
+//  * a workgroup walks over tiles (tile = blockIdx.x, += gridDim.x) and the three streams -- halo fetch (two stages ahead),
+//    weights + transform (one ahead), MFMAs -- each carry their own tile: the fetches run on into the next tile while the
+//    MFMAs finish the current one, so only the first tile of a workgroup pays a prologue.  Between tiles: the last
+//    k-step, the output transform + half-exchange (its own LDS buffer: the xt copies already hold the next tile), stores.
+//  * the transform work is dealt out in half patches (two of the four rows of B^T d B: 4 ds_read2_b64, 4 xor, 16 adds,
+//    4 ds_write2) so that all threads carry the same share, with no per-lane selects.
+//  * the transformed weights a workgroup DMAs per stage are one contiguous 16*4*RW-float block (repack_wino3_kernel).
+// ---------------------------------------------------------------------------------------------------
+#ifndef W3_RAW_SLOT
+#define W3_RAW_SLOT 13
+#endif
+constexpr int W3C = 4;                                 // input channels per stage of conv3_wino3_kernel
+inline int wino3_rw(int cout) { return cout % 64 == 0 ? 64 : 32; }   // its output channels per workgroup
+template <int NCG, int NPG, bool IS3D = false>
+__global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArgs a, const float* __restrict__ wt, int ntx,
+                                                                         int nty, int ntiles) {
+  constexpr int C = W3C;
+  constexpr int NWV = 2 * NCG * NPG, NT = 64 * NWV;
+  constexpr int ROWS = 4 * NPG + 2;
+  constexpr int NB = 32 * NPG;
+  constexpr int RW = 32 * NCG;
+  constexpr int WROWS = 16 * C;
+  constexpr int NWI = WROWS * RW / 256, NDMA = NWI / NWV;       // 1-KiB DMA instructions per stage / per wave
+  constexpr int NEL = C * ROWS * WCOLS, NLD = (NEL + NT - 1) / NT;
+  constexpr int NUNIT = 2 * C * NB, UPT = NUNIT / NT;          // half patches per stage / per thread
+  static_assert(NUNIT % NT == 0 && (C * NB) % 64 == 0, "half patches must deal out evenly, wave-uniform in the half");
+  static_assert(NWI % NWV == 0 && UPT <= 4, "stage shape");
+  __shared__ __attribute__((aligned(16))) float raw0[NEL];
+  __shared__ __attribute__((aligned(16))) float raw1[NEL];
+  __shared__ __attribute__((aligned(16))) float xt0[16 * C * NB];
+  __shared__ __attribute__((aligned(16))) float xt1[16 * C * NB];
+  __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];
+  __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
+  __shared__ __attribute__((aligned(16))) float exch[NWV * 16 * 64];   // epilogue: 4 registers x 4 outputs x 64 lanes per wave
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int h = wave & 1, g = wave >> 1;
+  const int cg = g % NCG, pg = g / NCG;
+  const int ngrp = a.cout / RW, nchunk = a.cin / C;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
+  const unsigned stage_bytes = (unsigned)((size_t)C * vol * 4 - 1) + 1u;
+  const int tstep = gridDim.x;
+
+  // Tiles are numbered x fastest, then y, output-channel group, z, sample.  A workgroup's tiles are blockIdx.x + k*gridDim.x:
+  // the tile's digits are advanced by the digits of the step with carries (one integer division chain per workgroup, not
+  // three per tile: scalar division is a ~30-instruction dependent chain).
+  struct Tile { int tx, ty, grp, z, b; };
+  auto decode = [&](int t) __attribute__((always_inline)) {
+    Tile T;
+    T.tx = t % ntx; t /= ntx;
+    T.ty = t % nty; t /= nty;
+    T.grp = t % ngrp; t /= ngrp;
+    T.z = t % a.D; T.b = t / a.D;
+    return T;
+  };
+  const Tile T0 = decode(blockIdx.x), TS = decode(tstep);
+  auto next_tile = [&](Tile T) __attribute__((always_inline)) {
+    int c;
+    T.tx += TS.tx;        c = T.tx >= ntx;   T.tx -= c ? ntx : 0;
+    T.ty += TS.ty + c;    c = T.ty >= nty;   T.ty -= c ? nty : 0;
+    T.grp += TS.grp + c;  c = T.grp >= ngrp; T.grp -= c ? ngrp : 0;
+    T.z += TS.z + c;      c = T.z >= a.D;    T.z -= c ? a.D : 0;
+    T.b += TS.b + c;
+    return T;
+  };
+  auto dz_lo_of = [&](const Tile& T) __attribute__((always_inline)) { return IS3D && T.z == 0 ? 1 : 0; };
+  auto dz_hi_of = [&](const Tile& T) __attribute__((always_inline)) { return IS3D ? (T.z == a.D - 1 ? 2 : 3) : 1; };
+
+  // ---- halo-fetch stream (two stages ahead of the MFMAs): its tile is (xR, rz), cursor (rdz, rc0) ----
+  const float* xR;                                      // sample base of the stream's tile
+  int rz, rdz, rc0 = 0;
+  // per-thread slots of the [C][ROWS][34] halo tile: the tile-independent part of the byte offset and (row, col); a slot
+  // outside the image gets an out-of-range offset (the buffer load then returns 0)
+  unsigned uoff[NLD], ubase[NLD], urc[NLD];
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = threadIdx.x + NT * t;
+    const int cc = idx / (ROWS * WCOLS);
+    const int rem = idx - cc * ROWS * WCOLS;
+    const int row = rem / WCOLS, col = rem - row * WCOLS;
+    ubase[t] = (unsigned)(((size_t)cc * vol + (size_t)row * a.W + col) * 4);
+    urc[t] = idx < NEL ? (unsigned)(row << 16 | col) : 0xffffffffu;
+  }
+  auto enter_R = [&](const Tile& T) __attribute__((always_inline)) {
+    xR = a.x + (size_t)T.b * a.cin * vol; rz = T.z; rdz = dz_lo_of(T); rc0 = 0;
+    const int tx0 = T.tx * 32, ty0 = T.ty * (4 * NPG);
+    const unsigned toff = (unsigned)(((size_t)(ty0 - 1) * a.W + (tx0 - 1)) * 4);      // (wraps for the first row/column: those slots are out of the image)
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+      const int gx = tx0 - 1 + (int)(urc[t] & 0xffff), gy = ty0 - 1 + (int)(urc[t] >> 16);
+      const bool ok = (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
+      uoff[t] = ok ? ubase[t] + toff : 0xfffffff0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  enter_R(T0);
+  float stage[NLD];
+  auto prefetch = [&]() __attribute__((always_inline)) {
+    const int zz = IS3D ? rz + rdz - 1 : 0;
+    const BufRsrcC r = make_rsrc_c(xR + (size_t)rc0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
+    rc0 += C;
+    if (rc0 >= a.cin) { rc0 = 0; ++rdz; }
+  };
+  auto store_raw = [&](float* rawdst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NLD; ++t)
+      if (threadIdx.x + NT * t < NEL) rawdst[threadIdx.x + NT * t] = stage[t];
+  };
+  // ---- weight stream (one stage ahead): the stage's [16][C][RW] image is one contiguous block of the packed weights
+  // ([dz][Cin/C][Cout/RW] blocks); DMA instruction q of this wave moves its floats [wi*256, (wi+1)*256), wi = wave + NWV*q
+  const float* wW;                                      // block (dz 0, chunk 0) of the stream's output-channel group
+  int wblk;                                             // (dz, chunk) block index of the cursor
+  const size_t wstep = (size_t)ngrp * (16 * C * RW);
+  auto enter_W = [&](const Tile& T) __attribute__((always_inline)) {
+    wW = wt + (size_t)T.grp * (16 * C * RW) + (size_t)wave * 256 + lane * 4; wblk = dz_lo_of(T) * nchunk;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  enter_W(T0);
+  auto stage_weights = [&](float* wdst) __attribute__((always_inline)) {
+    const float* sb = wW + (size_t)wblk * wstep;
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (size_t)NWV * 256 * q),
+                                       (__attribute__((address_space(3))) void*)(&wdst[(wave + NWV * q) * 256]), 16, 0, 0);
+    ++wblk;
+  };
+  // ---- input transform.  Half patch u = threadIdx.x + NT*i: block n = u % NB, channel c = (u / NB) % C, row half
+  // hp = u / (NB*C) (wave-uniform).
+  //   hp 0 -> rows 0,1 of B^T d B:  t0 = d0 - d2, t1 = d1 + d2        hp 1 -> rows 2,3:  t2 = d2 - d1, t3 = d1 - d3
+  // as ONE instruction stream: t_a = P - Q, t_b = R + (S ^ sign) with (P,Q,R,S) = (d0,d2,d1,d2) or (d2,d1,d1,d3) and
+  // sign = 0 or the sign bit (x + (-y) == x - y bit for bit).
+  int rd_off[UPT][4], wr_off[UPT];
+  unsigned sgn[UPT];
+#pragma unroll
+  for (int i = 0; i < UPT; ++i) {
+    const int u = threadIdx.x + NT * i;
+    const int n = u % NB, c = (u / NB) % C, hp = u / (NB * C);
+    const int bx = n & 15, by = n >> 4;
+    const int d = c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx;
+    rd_off[i][0] = d + (hp ? 2 : 0) * WCOLS; rd_off[i][1] = d + (hp ? 1 : 2) * WCOLS;
+    rd_off[i][2] = d + 1 * WCOLS;            rd_off[i][3] = d + (hp ? 3 : 2) * WCOLS;
+    wr_off[i] = (8 * hp) * C * NB + c * NB + n;
+    sgn[i] = hp ? 0x80000000u : 0u;
+  }
+  float2 e[4][2];
+  float tc[2][4];
+  auto xf_load = [&](int i, const float* rawsrc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      e[j][0] = *(const float2*)(rawsrc + rd_off[i][j]); e[j][1] = *(const float2*)(rawsrc + rd_off[i][j] + 2);
+    }
+  };
+  auto xf_cols = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float P = s & 1 ? e[0][s >> 1].y : e[0][s >> 1].x, Q = s & 1 ? e[1][s >> 1].y : e[1][s >> 1].x;
+      const float R = s & 1 ? e[2][s >> 1].y : e[2][s >> 1].x, S = s & 1 ? e[3][s >> 1].y : e[3][s >> 1].x;
+      tc[0][s] = P - Q;
+      tc[1][s] = R + __builtin_bit_cast(float, __builtin_bit_cast(unsigned, S) ^ sgn[i]);
+    }
+  };
+  auto xf_rows_store = [&](int i, float* xtdst) __attribute__((always_inline)) {
+    float* o = xtdst + wr_off[i];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      o[(4 * rr + 0) * C * NB] = tc[rr][0] - tc[rr][2];
+      o[(4 * rr + 1) * C * NB] = tc[rr][1] + tc[rr][2];
+      o[(4 * rr + 2) * C * NB] = tc[rr][2] - tc[rr][1];
+      o[(4 * rr + 3) * C * NB] = tc[rr][1] - tc[rr][3];
+    }
+  };
+
+  // ---- prologue (first tile of the workgroup only): halo tiles of stages 0 and 1, weights of stage 0, transform of stage 0
+  prefetch();
+  stage_weights(wbuf0);
+  store_raw(raw0);
+  prefetch();
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < UPT; ++i) { xf_load(i, raw0); xf_cols(i); xf_rows_store(i, xt0); }
+  store_raw(raw1);
+  __syncthreads();
+
+  // ---- MFMA stream ----
+  f32x16 acc[8];
+  const int wlo = (8 * h * C + half) * RW + cg * 32 + l31, tlo = (8 * h * C + half) * NB + pg * 32 + l31;
+  float av[2][8], bv[2][8];
+  auto load_k = [&](int ks, const float* wcur, const float* xcur) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { av[ks][p] = wcur[wlo + (p * C + 2 * ks) * RW]; bv[ks][p] = xcur[tlo + (p * C + 2 * ks) * NB]; }
+  };
+  // One phase (between two barriers), stage s of the MFMA stream's tile.  M0: a stage s-1 exists in this tile (its second
+  // k-step is issued first; without it the accumulators start from zero).  The weight/transform stream (stage s+1) and the
+  // halo stream (stage s+2) are always live: behind a workgroup's last tile they run on a stand-in tile whose results
+  // nobody reads, which keeps every phase the same straight-line code.
+  auto phase = [&](auto m0, const float* wcur, float* wnext, const float* xcur, float* xnext, const float* rawnext,
+                   float* rawfree) __attribute__((always_inline)) {
+    constexpr bool M0 = decltype(m0)::value;
+    // (the fetches of the phase are issued BEHIND its first MFMAs, whose operands are already in registers: the matrix
+    // pipe restarts right behind the barrier instead of idling through ~40 address/VMEM/LDS instructions per wave)
+#pragma unroll
+    for (int slot = 0; slot < 16; ++slot) {
+      const int ks = slot < 8 ? 1 : 0, p = slot & 7;
+      if (slot >= 8 || M0) {
+        if (slot >= 8 && !M0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][p], bv[ks][p], zero, 0, 0, 0);
+        } else {
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][p], bv[ks][p], acc[p], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (slot == 0) { prefetch(); xf_load(0, rawnext); }
+      if (slot == 1) stage_weights(wnext);
+      if (slot == 2) load_k(0, wcur, xcur);
+      // half patch i: loaded at slot 4i (i > 0), columns at 4i+3, rows + stores at 4i+4
+      const int ui = slot / 4, us = slot % 4;
+      if (us == 0 && ui > 0 && ui < UPT) xf_load(ui, rawnext);
+      if (us == 3 && ui < UPT) xf_cols(ui);
+      if (us == 0 && ui > 0 && ui - 1 < UPT) xf_rows_store(ui - 1, xnext);
+      if (slot == 7) load_k(1, wcur, xcur);                // the registers of k-step 1 are free: its MFMAs have all been issued
+      if (slot == W3_RAW_SLOT) store_raw(rawfree);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  int tM = blockIdx.x;
+  Tile TM = T0;
+  for (;;) {
+    const int niter = (dz_hi_of(TM) - dz_lo_of(TM)) * nchunk;   // even, >= 4 (the host checks Cin % (4 C))
+    const bool more = tM + tstep < ntiles;
+    const Tile TN = more ? next_tile(TM) : TM;          // the streams' next tile (stand-in behind the last one: this tile again)
+    phase(F_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);    // stage 0
+    for (int it = 1; it + 1 < niter; it += 2) {
+      phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);  // stage it (odd)
+      if (it + 3 == niter) enter_R(TN);         // stage niter-2 fetches the halo tile of the next tile's stage 0
+      phase(T_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);  // stage it+1 (even)
+    }
+    enter_W(TN);                                        // stage niter-1 fetches the weights of the next tile's stage 0
+    phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);
+    // the second k-step of the last stage
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][p], bv[1][p], acc[p], 0, 0, 0);
+
+    // Output transform A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]); this wave holds rows 2h, 2h+1 of M (acc[4*(row-2h) + s]):
+    //   h = 0:  t0 = M0 + M1, t1 = M1          h = 1:  t0 = M2, t1 = -M2 - M3
+    // Register r belongs to half (r >> 3): the partial outputs of the other half's registers go through LDS to the
+    // partner wave, the own ones are completed with the partner's, then bias, ReLU, store.  All of it on register PAIRS
+    // (r, r+1) as packed fp32 (v_pk_add_f32: the same IEEE additions, two per instruction); the barriers of the
+    // exchange wait for LDS only (a __syncthreads() would also wait for the stores of the round before to be acknowledged).
+    {
+      const int bx = l31 & 15, byl = l31 >> 4;
+      const int tx0 = TM.tx * 32, ty0 = TM.ty * (4 * NPG);
+      const int x = tx0 + 2 * bx, y = ty0 + 2 * (2 * pg + byl);
+      // channel of register r = 8 hh + 4 round + 2 j (+1):  cg*32 + 2 j + 8 (2 hh + round) + 4 half
+      const int co_own = TM.grp * RW + cg * 32 + 16 * h + 4 * half;
+      f32x2 bias2[2][2];
+#pragma unroll
+      for (int round = 0; round < 2; ++round)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias2[round][j] = *(const f32x2*)&a.bias[co_own + 8 * round + 2 * j];
+      float* obase = a.y + ((size_t)TM.b * a.cout + co_own) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x;
+      const bool inx = x < a.W, iny = y < a.H, inx1 = x + 1 < a.W, iny1 = y + 1 < a.H;
+      const bool full = (tx0 + 32 <= a.W) & (ty0 + 4 * NPG <= a.H);       // (wave-uniform) no clipped pixel in the tile
+      f32x2* ex_out = (f32x2*)&exch[wave * 16 * 64] + lane;
+      const f32x2* ex_in = (const f32x2*)&exch[(wave ^ 1) * 16 * 64] + lane;
+      auto out_part = [&](auto hh_, int r, f32x2 (&pt)[4]) __attribute__((always_inline)) {
+        constexpr int HH = decltype(hh_)::value;           // this wave's position half
+        f32x2 t0[4], t1[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const f32x2 a0 = {acc[s][r], acc[s][r + 1]}, a1 = {acc[4 + s][r], acc[4 + s][r + 1]};
+          if (HH == 0) { t0[s] = a0 + a1; t1[s] = a1; }
+          else { t0[s] = a0; t1[s] = (-a0) - a1; }
+        }
+        pt[0] = (t0[0] + t0[1]) + t0[2]; pt[1] = (t0[1] - t0[2]) - t0[3];
+        pt[2] = (t1[0] + t1[1]) + t1[2]; pt[3] = (t1[1] - t1[2]) - t1[3];
+      };
+      auto send = [&](auto hh_, int round) __attribute__((always_inline)) {
+        constexpr int HH = decltype(hh_)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x2 pt[4];
+          out_part(hh_, 8 * (1 - HH) + 4 * round + 2 * j, pt);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ex_out[(j * 4 + q) * 64] = pt[q];
+        }
+      };
+      auto finish = [&](auto hh_, int round) __attribute__((always_inline)) {
+        constexpr int HH = decltype(hh_)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x2 pt[4], v[4];
+          out_part(hh_, 8 * HH + 4 * round + 2 * j, pt);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[q] = (pt[q] + ex_in[(j * 4 + q) * 64]) + bias2[round][j];
+            if (a.relu) v[q] = __builtin_elementwise_max(v[q], (f32x2){0.f, 0.f});
+          }
+          float* o0 = obase + (size_t)(8 * round + 2 * j) * vol;
+          float* o1 = o0 + vol;
+          if (full) {
+            *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x);
+            *(float2*)o1 = make_float2(v[0].y, v[1].y); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y);
+          } else if (inx & iny) {
+            if (inx1) {
+              *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)o1 = make_float2(v[0].y, v[1].y);
+              if (iny1) { *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y); }
+            } else {
+              o0[0] = v[0].x; o1[0] = v[0].y;
+              if (iny1) { o0[a.W] = v[2].x; o1[a.W] = v[2].y; }
+            }
+          }
+        }
+      };
+      using H0 = std::integral_constant<int, 0>;
+      using H1 = std::integral_constant<int, 1>;
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {            // 4 of a half's 8 registers per round (16 values each way)
+        // (round 0: the previous tile's reads of the exchange buffer are many barriers back)
+        if (round) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); }       // lgkmcnt(0) only
+        if (h == 0) send(H0{}, round); else send(H1{}, round);
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+        if (h == 0) finish(H0{}, round); else finish(H1{}, round);
+      }
+    }
+    if (!more) break;
+    tM += tstep; TM = TN;
+  }
+}
+
 // blob: (Cout,Cin,3x3) -> G g G^T as [16][Cin][Cout], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 // (3D: per z tap dz, [dz][16][Cin][Cout])
 __global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout, int kd) {
@@ -769,6 +1123,23 @@ __global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __res
 #pragma unroll
       for (int s = 0; s < 4; ++s) pw[((size_t)(dz * 16 + 4 * r + s) * cin + ci) * cout + co] = u[s];
     }
+  }
+}
+
+// The same G g G^T values re-ordered for conv3_wino3_kernel: [dz][Cin/4][Cout/RW][16][4][RW] -- the 16*4*RW floats one
+// workgroup DMAs per stage are ONE contiguous block (every workgroup of the launch reads the same blocks at about the
+// same time: 64 rows of RW floats strided over the [16][Cin][Cout] image land on half of an XCD's L2 channels, the
+// contiguous block on all of them).  RW = 64 where Cout % 64 == 0, else 32 (the kernel's output channels per workgroup).
+__global__ void repack_wino3_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int kd, int rw) {
+  const size_t n = (size_t)kd * 16 * cin * cout;
+  const int nchunk = cin / W3C, ngrp = cout / rw;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(q % cout);
+    size_t r = q / cout;
+    const int ci = (int)(r % cin); r /= cin;
+    const int pp = (int)(r % 16), dz = (int)(r / 16);
+    const size_t o = ((((((size_t)dz * nchunk + ci / W3C) * ngrp + co / rw) * 16 + pp) * W3C + ci % W3C) * rw) + co % rw;
+    dst[o] = src[q];
   }
 }
 
@@ -977,10 +1348,10 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
 // Winograd F(2x2,3x3) for the 2D 3x3 MFMA layers, when the launch fills the chip (one workgroup per CU at a time)
 bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t s) {
   // FNX_CONV_WINO: 0 = off (direct implicit GEMM), 1 = conv3_wino_kernel, 2 (default) = conv3_wino2_kernel
-  static const int mode = [] { const char* e = getenv("FNX_CONV_WINO"); return e ? atoi(e) : 2; }();
+  static const int mode = [] { const char* e = getenv("FNX_CONV_WINO"); return e ? atoi(e) : 3; }();
   if (mode == 0 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
-  if (a.D != 1 && (mode != 2 || !is3d)) return false;
-  if (mode == 2) {
+  if (a.D != 1 && (mode < 2 || !is3d)) return false;
+  if (mode == 2 || mode == 3) {
     // 64 output channels per workgroup with 4-channel stages; the 32-channel layers: two pixel groups, 8-channel stages
     // (measured at 1024^2: 64->32 297 -> 274 us; 8-channel stages with 32 output channels per workgroup on the wider
     // layers: 918 -> 1065 us, the input tile is read and transformed once per 32 instead of 64 output channels)
@@ -990,6 +1361,27 @@ bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t
     if (ncg == 2 && v8 && (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B * a.D * (a.cout / 64) >= 512) npg = 2;   // 8 waves
     const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * a.D * (a.cout / (32 * ncg)));
     if ((long)grid.x * grid.y * grid.z < (npg * ncg == 4 ? 512 : 1024)) return false;
+    if (mode == 3 && a.cin % (4 * W3C) == 0) {
+      // persistent: one workgroup per CU slot (8-wave workgroups fill a CU's registers; two 4-wave ones fit), walking
+      // over the tiles x fastest
+      assert(wino3_rw(a.cout) == 32 * ncg);
+      if (ncg == 1) npg = 2;
+      const float* w3 = wt + (size_t)16 * (is3d ? 3 : 1) * a.cin * a.cout;   // the stage-contiguous image follows [16][Cin][Cout]
+      const int ntx = (a.W + 31) / 32, nty = (a.H + 4 * npg - 1) / (4 * npg);
+      const long nt = (long)ntx * nty * a.B * a.D * (a.cout / (32 * ncg));
+      static const int ncu = [] { int d = 0; hipDeviceProp_t pr; hipGetDevice(&d); hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
+      const int slots = ncu * (ncg * npg == 4 ? 1 : 2);
+      if (nt < (npg * ncg == 4 ? 512 : 1024) || nt > 0x7fffffffl) return false;
+      const int nwg = (int)(nt < slots ? nt : slots);
+      if (is3d) {
+        if (ncg == 2 && npg == 2) conv3_wino3_kernel<2, 2, true><<<nwg, 512, 0, s>>>(a, w3, ntx, nty, (int)nt);
+        else if (ncg == 2) conv3_wino3_kernel<2, 1, true><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+        else conv3_wino3_kernel<1, 2, true><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+      } else if (ncg == 2 && npg == 2) conv3_wino3_kernel<2, 2><<<nwg, 512, 0, s>>>(a, w3, ntx, nty, (int)nt);
+      else if (ncg == 2) conv3_wino3_kernel<2, 1><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+      else conv3_wino3_kernel<1, 2><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+      return true;
+    }
     if (is3d) {
       if (ncg == 2 && npg == 2) conv3_wino2_kernel<2, 2, 4, true><<<grid, 512, 0, s>>>(a, wt);
       else if (ncg == 2) conv3_wino2_kernel<2, 1, 4, true><<<grid, 256, 0, s>>>(a, wt);
@@ -1120,7 +1512,13 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     if (mfma_layer(L)) {
       pack_layer_mfma_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 layer_taps(L, is3d));
-      if (wino_layer(L, is3d)) pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + nw, L.cin, L.cout, is3d ? 3 : 1);
+      if (wino_layer(L, is3d)) {
+        const int kd = is3d ? 3 : 1;
+        float* w2 = pk + pl.w_off + nw;                         // [dz][16][Cin][Cout]  (conv3_wino_kernel, conv3_wino2_kernel)
+        float* w3 = w2 + (size_t)16 * kd * L.cin * L.cout;      // stage-contiguous     (conv3_wino3_kernel)
+        pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, w2, L.cin, L.cout, kd);
+        repack_wino3_kernel<<<64, 256, 0, s>>>(w2, w3, L.cin, L.cout, kd, wino3_rw(L.cout));
+      }
     }
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
       pack_layer_pair_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
