@@ -775,9 +775,6 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArg
 //    4 ds_write2) so that all threads carry the same share, with no per-lane selects.
 //  * the transformed weights a workgroup DMAs per stage are one contiguous 16*4*RW-float block (repack_wino3_kernel).
 // ---------------------------------------------------------------------------------------------------
-#ifndef W3_RAW_SLOT
-#define W3_RAW_SLOT 13
-#endif
 constexpr int W3C = 4;                                 // input channels per stage of conv3_wino3_kernel
 inline int wino3_rw(int cout) { return cout % 64 == 0 ? 64 : 32; }   // its output channels per workgroup
 template <int NCG, int NPG, bool IS3D = false>
@@ -910,7 +907,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
     const int d = c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx;
     rd_off[i][0] = d + (hp ? 2 : 0) * WCOLS; rd_off[i][1] = d + (hp ? 1 : 2) * WCOLS;
     rd_off[i][2] = d + 1 * WCOLS;            rd_off[i][3] = d + (hp ? 3 : 2) * WCOLS;
-    wr_off[i] = (8 * hp) * C * NB + c * NB + n;
+    wr_off[i] = 2 * ((4 * hp) * C * NB + c * NB + n);   // xt is [position pair][channel][block][2]
     sgn[i] = hp ? 0x80000000u : 0u;
   }
   float2 e[4][2];
@@ -933,11 +930,9 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   auto xf_rows_store = [&](int i, float* xtdst) __attribute__((always_inline)) {
     float* o = xtdst + wr_off[i];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      o[(4 * rr + 0) * C * NB] = tc[rr][0] - tc[rr][2];
-      o[(4 * rr + 1) * C * NB] = tc[rr][1] + tc[rr][2];
-      o[(4 * rr + 2) * C * NB] = tc[rr][2] - tc[rr][1];
-      o[(4 * rr + 3) * C * NB] = tc[rr][1] - tc[rr][3];
+    for (int rr = 0; rr < 2; ++rr) {                      // row 2 hp + rr of B^T d B: positions 4 row + 0..3 = pairs 2 row, 2 row + 1
+      *(float2*)(o + (2 * rr + 0) * 2 * C * NB) = make_float2(tc[rr][0] - tc[rr][2], tc[rr][1] + tc[rr][2]);
+      *(float2*)(o + (2 * rr + 1) * 2 * C * NB) = make_float2(tc[rr][2] - tc[rr][1], tc[rr][1] - tc[rr][3]);
     }
   };
 
@@ -954,11 +949,16 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
 
   // ---- MFMA stream ----
   f32x16 acc[8];
-  const int wlo = (8 * h * C + half) * RW + cg * 32 + l31, tlo = (8 * h * C + half) * NB + pg * 32 + l31;
+  // both LDS images keep the two positions of a pair next to each other ([pair][channel][RW or NB][2]): one ds_read_b64
+  // per operand and position PAIR (half the LDS time of two 4-byte reads)
+  const int wlo = 2 * ((4 * h * C + half) * RW + cg * 32 + l31), tlo = 2 * ((4 * h * C + half) * NB + pg * 32 + l31);
   float av[2][8], bv[2][8];
   auto load_k = [&](int ks, const float* wcur, const float* xcur) __attribute__((always_inline)) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) { av[ks][p] = wcur[wlo + (p * C + 2 * ks) * RW]; bv[ks][p] = xcur[tlo + (p * C + 2 * ks) * NB]; }
+    for (int p2 = 0; p2 < 4; ++p2) {
+      const float2 wa = *(const float2*)(wcur + wlo + 2 * (p2 * C + 2 * ks) * RW), xb = *(const float2*)(xcur + tlo + 2 * (p2 * C + 2 * ks) * NB);
+      av[ks][2 * p2] = wa.x; av[ks][2 * p2 + 1] = wa.y; bv[ks][2 * p2] = xb.x; bv[ks][2 * p2 + 1] = xb.y;
+    }
   };
   // One phase (between two barriers), stage s of the MFMA stream's tile.  M0: a stage s-1 exists in this tile (its second
   // k-step is issued first; without it the accumulators start from zero).  The weight/transform stream (stage s+1) and the
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
       if (us == 3 && ui < UPT) xf_cols(ui);
       if (us == 0 && ui > 0 && ui - 1 < UPT) xf_rows_store(ui - 1, xnext);
       if (slot == 7) load_k(1, wcur, xcur);                // the registers of k-step 1 are free: its MFMAs have all been issued
-      if (slot == W3_RAW_SLOT) store_raw(rawfree);
+      if (slot == 13) store_raw(rawfree);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -1126,7 +1126,7 @@ __global__ void pack_layer_wino_kernel(const float* __restrict__ w, float* __res
   }
 }
 
-// The same G g G^T values re-ordered for conv3_wino3_kernel: [dz][Cin/4][Cout/RW][16][4][RW] -- the 16*4*RW floats one
+// The same G g G^T values re-ordered for conv3_wino3_kernel: [dz][Cin/4][Cout/RW][8 position pairs][4][RW][2] -- the 16*4*RW floats one
 // workgroup DMAs per stage are ONE contiguous block (every workgroup of the launch reads the same blocks at about the
 // same time: 64 rows of RW floats strided over the [16][Cin][Cout] image land on half of an XCD's L2 channels, the
 // contiguous block on all of them).  RW = 64 where Cout % 64 == 0, else 32 (the kernel's output channels per workgroup).
@@ -1138,7 +1138,7 @@ __global__ void repack_wino3_kernel(const float* __restrict__ src, float* __rest
     size_t r = q / cout;
     const int ci = (int)(r % cin); r /= cin;
     const int pp = (int)(r % 16), dz = (int)(r / 16);
-    const size_t o = ((((((size_t)dz * nchunk + ci / W3C) * ngrp + co / rw) * 16 + pp) * W3C + ci % W3C) * rw) + co % rw;
+    const size_t o = (((((((size_t)dz * nchunk + ci / W3C) * ngrp + co / rw) * 8 + pp / 2) * W3C + ci % W3C) * rw) + co % rw) * 2 + pp % 2;
     dst[o] = src[q];
   }
 }
