@@ -314,6 +314,8 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
     else:
         step_bytes = (STEP_BYTES[is3d](0) - (44 if not is3d else 60) + 104) * cells   # advection + CNN glue
+    if slab:
+        run_workload.slab_state = (bd, m)
     return dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
                 unit="Mcells/s", steps_per_s=steps / elapsed, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=ms,
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -334,6 +336,41 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
                 step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 kernel_ms_per_step={k: v[0] / prof_steps for k, v in times.items() if v[1] > 0},
                 roofline=roof)
+
+
+def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D):
+    """The SAME per-GPU slab step through the C++ z-slab driver (fnx_slab_step: launches, RCCL ncclSend/ncclRecv and their
+    overlap issued from C++, csrc/fnx_slab.hip), continuing from the state the headline run developed.  Reported next to the
+    headline as `native_driver`; same bits as the Python driver (tests/test_slab.py)."""
+    import torch
+    import torch.distributed as dist
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout, rccl_comm
+    layout = SlabLayout(D * world, world, rank, halo=6)
+    comm = rccl_comm(rank, world) if world > 1 else None
+    sim = NativeSlabSimulator(layout, m, comm=comm, sweeps_per_exchange=6, static_flags=True, cfl_check_every=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 3)):
+        sim.step(bd)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step(bd)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cells = res * res * layout.owned * world
+    return dict(ms_per_step=elapsed / steps * 1e3, value=cells * steps / elapsed / 1e6, unit="Mcells/s", steps=steps,
+                transport="RCCL ncclSend/ncclRecv issued from C++ (librccl resolved at run time)" if world > 1 else None,
+                state_finite=bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all()))
 
 
 def self_spawn(a):
@@ -380,6 +417,7 @@ def main():
                     help="N > 1: how the slab driver orders a sweep block around its ghost exchange (slab.py)")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations reported under 'also' at N=1")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous, no GPU work")
+    ap.add_argument("--no-native", action="store_true", help="skip the C++ z-slab driver leg reported as 'native_driver'")
     a = ap.parse_args()
     assert a.gpus >= 1
 
@@ -423,10 +461,34 @@ def main():
             except Exception as e:  # noqa: BLE001  (an "also" line must not take the headline down)
                 out["also"][other] = dict(error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()
-    if rank == 0:
-        if not a.no_cpu_baseline and world == 1:       # the host baseline is reported with the single-GPU line only
-            out["cpu_baseline"] = cpu_baseline(WORKLOADS[name])
-        print(json.dumps(out))
+    if rank == 0 and not a.no_cpu_baseline and world == 1:       # the host baseline is reported with the single-GPU line only
+        out["cpu_baseline"] = cpu_baseline(WORKLOADS[name])
+    done = []
+
+    def emit():
+        if rank == 0 and not done:
+            done.append(1)
+            print(json.dumps(out), flush=True)
+
+    if WORKLOADS[name].get("slab") and not a.no_native:
+        # the same step through the C++ driver.  It has never met more than one GPU before the driver's multi-GPU run, so
+        # it runs under a watchdog: if it is not through in time the headline line is printed without it and the job ends
+        import threading
+
+        def bail():
+            out["native_driver"] = dict(error="the native-driver leg did not finish within its time limit")
+            emit()
+            os._exit(0)
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            bd_s, m_s = run_workload.slab_state
+            out["native_driver"] = run_native_slab(a.steps, a.warmup, world, rank, dev, bd_s, m_s, WORKLOADS[name]["res"], WORKLOADS[name]["D"])
+        except Exception as e:  # noqa: BLE001
+            out["native_driver"] = dict(error=f"{type(e).__name__}: {e}")
+        dog.cancel()
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

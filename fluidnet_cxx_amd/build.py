@@ -25,6 +25,7 @@ HIP_UNITS = {
     "fnx_step.hip": ["-ffp-contract=off"],
     "fnx_api.hip": ["-ffp-contract=off"],
     "fnx_cnn.hip": [],
+    "fnx_slab.hip": [],
 }
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 adds into v_pk_add_f32 + v_pk_mov shuffles, measured
 # 1.6x slower per op than plain VALU on gfx950 (tools/ubench/dpp_bench.hip).

@@ -1,3 +1,4 @@
+#include <memory>
 // torch cpp-extension `fluidnet_cpp` for MI355X: the reference's three pybind entry points
 // (pytorch/lib/fluid/cpp/fluids_init.cpp:1009-1014) with identical names and positional signatures, bound
 // to the C ABI of libfluidnet_hip.so, plus the operators the reference implements in Python
@@ -370,6 +371,84 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   check_status(fnx_simulate_step(&g, &prm, &st, ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), cur_stream(U)));
 }
 
+// ---- native z-slab driver (fnx_slab_*): communicators and the per-rank driver object ---------------------------
+struct PyLoopbackGroup {
+  void* g = nullptr; int nranks;
+  explicit PyLoopbackGroup(int n) : nranks(n) { check_status(fnx_slab_loopback_group(&g, n)); }
+  ~PyLoopbackGroup() { fnx_slab_loopback_group_free(g); }
+};
+struct PySlabComm {
+  FnxSlabComm c{};
+  std::shared_ptr<PyLoopbackGroup> keep;      // a loopback comm keeps its group alive
+  ~PySlabComm() { fnx_slab_comm_free(&c); }
+};
+py::bytes slab_rccl_unique_id() {
+  char id[128];
+  check_status(fnx_slab_rccl_unique_id(id));
+  return py::bytes(id, 128);
+}
+std::shared_ptr<PySlabComm> slab_comm_rccl(int rank, int nranks, const std::string& unique_id) {
+  TORCH_CHECK(unique_id.size() == 128, "the RCCL unique id has 128 bytes");
+  auto c = std::make_shared<PySlabComm>();
+  py::gil_scoped_release nogil;               // ncclCommInitRank blocks until every rank has arrived
+  check_status(fnx_slab_comm_rccl(&c->c, rank, nranks, unique_id.data()));
+  return c;
+}
+std::shared_ptr<PySlabComm> slab_comm_loopback(std::shared_ptr<PyLoopbackGroup> group, int rank) {
+  auto c = std::make_shared<PySlabComm>();
+  check_status(fnx_slab_comm_loopback(&c->c, group->g, rank));
+  c->keep = group;
+  return c;
+}
+struct PySlab {
+  FnxSlab* s = nullptr;
+  FnxSlabConfig cfg{};
+  std::shared_ptr<PySlabComm> comm;
+  PySlab(int B, int H, int W, int D_global, int rank, int nranks, int halo, int sweeps_per_exchange, bool static_flags,
+         int cfl_check_every, std::shared_ptr<PySlabComm> comm_) : comm(comm_) {
+    cfg.B = B; cfg.H = H; cfg.W = W; cfg.D_global = D_global; cfg.rank = rank; cfg.nranks = nranks; cfg.halo = halo;
+    cfg.sweeps_per_exchange = sweeps_per_exchange; cfg.static_flags = static_flags ? 1 : 0; cfg.cfl_check_every = cfl_check_every;
+    check_status(fnx_slab_create(&s, &cfg, comm ? &comm->c : nullptr));
+  }
+  ~PySlab() { fnx_slab_destroy(s); }
+  std::vector<int> layout() const {
+    int o, l, h, z;
+    check_status(fnx_slab_layout(&cfg, &o, &l, &h, &z));
+    return {o, l, h, z};
+  }
+  int64_t workspace_bytes() const { return (int64_t)fnx_slab_workspace_bytes(&cfg); }
+  void step(Tensor p, Tensor U, Tensor flags, Tensor density, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
+            c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask, double dt, double maccormack_strength,
+            bool sample_outside_fluid, double buoyancy_scale, std::vector<double> gravity_vec, double operating_density,
+            double p_tol, int jacobi_iter, Tensor workspace) {
+    check_field(U, "U");
+    Geom none;
+    FnxGrid g = grid_of(flags, true, &none);
+    check_vel(U, g, "U"); check_scalar(p, g, "p"); check_scalar(density, g, "density");
+    const std::vector<int> l = layout();
+    TORCH_CHECK(g.B == cfg.B && g.H == cfg.H && g.W == cfg.W && g.D == l[0] + l[1] + l[2], "the tensors are not this rank's slab (",
+                cfg.B, " x ", l[0] + l[1] + l[2], " x ", cfg.H, " x ", cfg.W, " with ghost planes)");
+    TORCH_CHECK(gravity_vec.size() == 3, "gravityVec needs x, y, z");
+    TORCH_CHECK(workspace.is_cuda() && workspace.is_contiguous(), "workspace must be a contiguous GPU tensor");
+    FnxStepParams prm{};
+    prm.dt = (float)dt; prm.maccormack_strength = (float)maccormack_strength; prm.sample_outside_fluid = sample_outside_fluid;
+    prm.buoyancy_scale = (float)buoyancy_scale;
+    for (int a = 0; a < 3; ++a) prm.gravity_vec[a] = (float)gravity_vec[a];
+    prm.operating_density = (float)operating_density; prm.p_tol = (float)p_tol; prm.jacobi_iter = jacobi_iter; prm.method = 0;
+    auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> float* {
+      if (!t.has_value() || !t->defined()) return nullptr;
+      if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
+      return t->data_ptr<float>();
+    };
+    FnxState st{};
+    st.p = p.data_ptr<float>(); st.U = U.data_ptr<float>(); st.flags = flags.data_ptr<float>(); st.density = density.data_ptr<float>();
+    st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
+    st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
+    c10::hip::HIPGuard guard(flags.get_device());
+    check_status(fnx_slab_step(s, &prm, &st, workspace.data_ptr(), (size_t)workspace.numel() * workspace.element_size(), cur_stream(U)));
+  }
+};
+
 // `nsweeps` more sweeps on an existing pressure field (in place) -- used by the z-slab driver
 void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, c10::optional<Tensor> workspace,
                     bool reuse_mask, const Geom* geom) {
@@ -561,6 +640,22 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("bc_class") = py::none(), GEOM,
         NoGil());
   m.def("bc_classify", &bc_classify, "uint8 class map of static BC arrays (FnxState.bc_class)", NoGil());
+  py::class_<PyLoopbackGroup, std::shared_ptr<PyLoopbackGroup>>(m, "SlabLoopbackGroup", "in-process communicator group: n slabs driven by n host threads")
+      .def(py::init<int>(), py::arg("nranks"));
+  py::class_<PySlabComm, std::shared_ptr<PySlabComm>>(m, "SlabComm", "ghost-plane communicator of the native z-slab driver (FnxSlabComm)");
+  m.def("slab_rccl_unique_id", &slab_rccl_unique_id);
+  m.def("slab_comm_rccl", &slab_comm_rccl, py::arg("rank"), py::arg("nranks"), py::arg("unique_id"));
+  m.def("slab_comm_loopback", &slab_comm_loopback, py::arg("group"), py::arg("rank"));
+  py::class_<PySlab>(m, "SlabDriver", "native z-slab driver of the 3D Jacobi step (fnx_slab_create / fnx_slab_step)")
+      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>>(), py::arg("B"), py::arg("H"),
+           py::arg("W"), py::arg("D_global"), py::arg("rank"), py::arg("nranks"), py::arg("halo"), py::arg("sweeps_per_exchange"),
+           py::arg("static_flags") = false, py::arg("cfl_check_every") = 0, py::arg("comm") = nullptr)
+      .def("layout", &PySlab::layout, "(owned planes, ghost planes below, above, global plane of local plane 0)")
+      .def("workspace_bytes", &PySlab::workspace_bytes)
+      .def("step", &PySlab::step, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"),
+           py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("dt"), py::arg("maccormack_strength"),
+           py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"), py::arg("operating_density"),
+           py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("workspace"), NoGil());
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
   m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });

@@ -85,6 +85,16 @@ size_t ws_step(const FnxGrid* g) {
 
 }  // namespace
 
+namespace fnx {
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace fnx
+
 // ---- event-pair profiler ----------------------------------------------------------------------------
 namespace fnx {
 namespace {

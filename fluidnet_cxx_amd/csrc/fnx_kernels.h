@@ -5,6 +5,9 @@
 
 namespace fnx {
 
+// sets the calling thread's fnx_last_error() message and returns `code` (fnx_api.hip)
+int set_error(int code, const char* fmt, ...);
+
 // event-pair timing of kernel classes (fnx_api.hip); no-ops unless fnx_profile_enable(1)
 void prof_begin(int tag, hipStream_t s);
 void prof_end(int tag, hipStream_t s);

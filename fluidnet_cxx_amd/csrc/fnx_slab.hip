@@ -1,0 +1,602 @@
+// z-slab driver of the 3D Jacobi time step (include/fluidnet_hip.h, "z-slab decomposition"): host code only, written on
+// top of the library's own C ABI -- fnx_advect_step / fnx_pre_projection / fnx_jacobi_pass[2] / fnx_post_projection with
+// FnxGrid's slab view (z_offset, D_global) and compute windows (k_begin, k_end) -- plus two communicators: RCCL
+// (ncclSend/ncclRecv between z-neighbours, loaded with dlopen) and an in-process one (several slabs of a domain driven by
+// host threads of one process; the lock-step tests and single-process multi-device runs).
+//
+// The schedule is the one fluidnet_cxx_amd/slab.py documents ("edge_first"): per step
+//   1. ghost exchange of U, density (4 planes) posted; the planes whose advection reads no ghost plane are advected
+//      meanwhile, the two 4-plane edge windows after it has landed
+//   2. BC / buoyancy / wall stage + divergence on the owned planes; blocking exchange of div (w-1 planes)
+//   3. blocks of w Jacobi sweeps: the edge parts of all passes of a block first (a closed chain that ends in the w owned
+//      planes each neighbour needs), their exchange posted, the interior parts while it is in flight
+//   4. exchange of p (1 plane), velocity update + wall BCs + BCs on the owned planes
+// Every owned cell goes through the arithmetic of the single-domain step: same bits (tests/test_slab.py).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/fluidnet_hip.h"
+#include "fnx_kernels.h"
+
+namespace {
+
+#define SLAB_HIP(expr)                                                                                     \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess) return fnx::set_error(FNX_EHIP, "HIP error: %s (%s)", hipGetErrorString(e_), #expr); \
+  } while (0)
+#define SLAB_OK(expr)            \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != FNX_OK) return rc_; \
+  } while (0)
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// RCCL communicator.  librccl is resolved at run time: libfluidnet_hip.so has no link-time dependency on it, and a
+// process that already carries an RCCL (torch's) gets that one.
+// ---------------------------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } NcclUniqueId;
+typedef void* NcclComm;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt8 = 0, kNcclFloat32 = 7, kNcclMax = 2;      // ncclDataType_t / ncclRedOp_t values of nccl.h
+
+int rccl_api(RcclApi** out) {
+  static RcclApi api;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!api.lib) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return fnx::set_error(FNX_ECOMM, "librccl.so could not be loaded: %s", dlerror());
+    auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+    api.GetUniqueId = (int (*)(NcclUniqueId*))sym("ncclGetUniqueId");
+    api.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))sym("ncclCommInitRank");
+    api.CommDestroy = (int (*)(NcclComm))sym("ncclCommDestroy");
+    api.GroupStart = (int (*)())sym("ncclGroupStart");
+    api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    api.Send = (int (*)(const void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclSend");
+    api.Recv = (int (*)(void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclRecv");
+    api.AllReduce = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclAllReduce");
+    api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send ||
+        !api.Recv || !api.AllReduce) {
+      api.lib = nullptr;
+      return fnx::set_error(FNX_ECOMM, "librccl.so lacks an expected nccl* symbol");
+    }
+  }
+  *out = &api;
+  return FNX_OK;
+}
+
+struct RcclCtx { RcclApi* api; NcclComm comm; int rank, nranks; };
+#define NCCL_OK(ctx, expr)                                                                                         \
+  do {                                                                                                             \
+    int r_ = (expr);                                                                                               \
+    if (r_ != 0) return fnx::set_error(FNX_ECOMM, "RCCL error %d (%s) in %s", r_,                                  \
+                                       (ctx)->api->GetErrorString ? (ctx)->api->GetErrorString(r_) : "?", #expr);  \
+  } while (0)
+
+int rccl_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
+  RcclCtx* c = (RcclCtx*)vctx;
+  hipStream_t s = (hipStream_t)stream;
+  NCCL_OK(c, c->api->GroupStart());
+  for (int i = 0; i < nsegs; ++i) {
+    const FnxSlabSeg& g = segs[i];
+    if (c->rank > 0 && g.send_lo) NCCL_OK(c, c->api->Send(g.send_lo, g.bytes, kNcclInt8, c->rank - 1, c->comm, s));
+    if (c->rank > 0 && g.recv_lo) NCCL_OK(c, c->api->Recv(g.recv_lo, g.bytes, kNcclInt8, c->rank - 1, c->comm, s));
+    if (c->rank < c->nranks - 1 && g.send_hi) NCCL_OK(c, c->api->Send(g.send_hi, g.bytes, kNcclInt8, c->rank + 1, c->comm, s));
+    if (c->rank < c->nranks - 1 && g.recv_hi) NCCL_OK(c, c->api->Recv(g.recv_hi, g.bytes, kNcclInt8, c->rank + 1, c->comm, s));
+  }
+  NCCL_OK(c, c->api->GroupEnd());
+  return FNX_OK;
+}
+int rccl_allreduce_max(void* vctx, float* x, int n, void* stream) {
+  RcclCtx* c = (RcclCtx*)vctx;
+  NCCL_OK(c, c->api->AllReduce(x, x, (size_t)n, kNcclFloat32, kNcclMax, c->comm, (hipStream_t)stream));
+  return FNX_OK;
+}
+void rccl_destroy(void* vctx) {
+  RcclCtx* c = (RcclCtx*)vctx;
+  if (c->comm) c->api->CommDestroy(c->comm);
+  delete c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// In-process communicator: rank r and r+1 meet in a mailbox per pair and exchange call.  The first to arrive leaves its
+// pointers and an event recorded on its stream; the second enqueues both copies on ITS stream behind that event, records
+// a completion event and wakes the first, whose stream then waits for it.  Every rank serves its lower pair before its
+// upper pair, so the pairs are visited in ascending order everywhere and nobody waits in a cycle.
+// ---------------------------------------------------------------------------------------------------------------
+struct LoopPair {
+  std::mutex mu;
+  std::condition_variable cv;
+  int phase = 0;                 // 0: empty, 1: first party posted, 2: copies enqueued (first party may pick up)
+  std::vector<FnxSlabSeg> segs;  // the first party's segments
+  bool first_is_lower = false;
+  hipEvent_t ev_first = nullptr, ev_done = nullptr;
+  int rc = FNX_OK;
+};
+struct LoopGroup {
+  int nranks;
+  std::vector<LoopPair> pairs;   // pair i: ranks i, i+1
+  std::mutex mu; std::condition_variable cv;
+  int red_count = 0, red_gen = 0; float red_val[64]; int red_n = 0;
+  explicit LoopGroup(int n) : nranks(n), pairs(n > 1 ? n - 1 : 0) {}
+};
+struct LoopCtx { LoopGroup* g; int rank; };
+
+// one side of pair `pi`; lower = this rank is the lower one of the pair (it sends its *_hi pointers)
+int loop_meet(LoopGroup* g, int pi, bool lower, const FnxSlabSeg* segs, int nsegs, hipStream_t s) {
+  LoopPair& P = g->pairs[pi];
+  std::unique_lock<std::mutex> lk(P.mu);
+  P.cv.wait(lk, [&] { return P.phase == 0 || (P.phase == 1 && P.first_is_lower != lower); });
+  if (P.phase == 0) {                       // first to arrive
+    P.segs.assign(segs, segs + nsegs);
+    P.first_is_lower = lower;
+    P.rc = FNX_OK;
+    if (!P.ev_first) { SLAB_HIP(hipEventCreateWithFlags(&P.ev_first, hipEventDisableTiming)); SLAB_HIP(hipEventCreateWithFlags(&P.ev_done, hipEventDisableTiming)); }
+    SLAB_HIP(hipEventRecord(P.ev_first, s));
+    P.phase = 1;
+    P.cv.notify_all();
+    P.cv.wait(lk, [&] { return P.phase == 2; });
+    const int rc = P.rc;
+    hipError_t e = hipStreamWaitEvent(s, P.ev_done, 0);
+    P.phase = 0;
+    P.cv.notify_all();
+    if (rc != FNX_OK) return rc;
+    SLAB_HIP(e);
+    return FNX_OK;
+  }
+  // second to arrive: both parties' buffers are known
+  int rc = FNX_OK;
+  if ((int)P.segs.size() != nsegs) rc = fnx::set_error(FNX_ECOMM, "loopback exchange: the two ranks of a pair posted %zu and %d segments", P.segs.size(), nsegs);
+  if (rc == FNX_OK && hipStreamWaitEvent(s, P.ev_first, 0) != hipSuccess) rc = fnx::set_error(FNX_EHIP, "hipStreamWaitEvent failed");
+  for (int i = 0; i < nsegs && rc == FNX_OK; ++i) {
+    const FnxSlabSeg& lo = lower ? segs[i] : P.segs[i];     // the lower rank's segment: its hi side faces the pair
+    const FnxSlabSeg& hi = lower ? P.segs[i] : segs[i];
+    if (lo.bytes != hi.bytes) { rc = fnx::set_error(FNX_ECOMM, "loopback exchange: segment %d has %zu and %zu bytes", i, lo.bytes, hi.bytes); break; }
+    if (hi.recv_lo && lo.send_hi && hipMemcpyAsync(hi.recv_lo, lo.send_hi, lo.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      rc = fnx::set_error(FNX_EHIP, "hipMemcpyAsync failed");
+    if (lo.recv_hi && hi.send_lo && hipMemcpyAsync(lo.recv_hi, hi.send_lo, lo.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      rc = fnx::set_error(FNX_EHIP, "hipMemcpyAsync failed");
+  }
+  if (hipEventRecord(P.ev_done, s) != hipSuccess && rc == FNX_OK) rc = fnx::set_error(FNX_EHIP, "hipEventRecord failed");
+  P.rc = rc;
+  P.phase = 2;
+  P.cv.notify_all();
+  return rc;
+}
+int loop_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
+  LoopCtx* c = (LoopCtx*)vctx;
+  if (c->rank > 0) SLAB_OK(loop_meet(c->g, c->rank - 1, false, segs, nsegs, (hipStream_t)stream));
+  if (c->rank < c->g->nranks - 1) SLAB_OK(loop_meet(c->g, c->rank, true, segs, nsegs, (hipStream_t)stream));
+  return FNX_OK;
+}
+int loop_allreduce_max(void* vctx, float* x, int n, void* stream) {
+  LoopCtx* c = (LoopCtx*)vctx;
+  LoopGroup* g = c->g;
+  if (n > 64) return fnx::set_error(FNX_EINVAL, "loopback allreduce: n > 64");
+  float h[64];
+  SLAB_HIP(hipMemcpyAsync(h, x, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SLAB_HIP(hipStreamSynchronize((hipStream_t)stream));
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    const int gen = g->red_gen;
+    if (g->red_count == 0) { g->red_n = n; for (int i = 0; i < n; ++i) g->red_val[i] = h[i]; }
+    else for (int i = 0; i < n; ++i) g->red_val[i] = h[i] > g->red_val[i] ? h[i] : g->red_val[i];
+    if (++g->red_count == g->nranks) { g->red_count = 0; ++g->red_gen; g->cv.notify_all(); }
+    else g->cv.wait(lk, [&] { return g->red_gen != gen; });
+    for (int i = 0; i < n; ++i) h[i] = g->red_val[i];
+  }
+  SLAB_HIP(hipMemcpyAsync(x, h, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  SLAB_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return FNX_OK;
+}
+void loop_destroy(void* vctx) { delete (LoopCtx*)vctx; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+struct FnxSlab {
+  FnxSlabConfig cfg;
+  FnxSlabComm comm;          // copy of the caller's table (ctx borrowed); exchange == nullptr when nranks == 1
+  int owned, lo, hi, z_offset, D_local, w;
+  long steps = 0;
+  bool mask_valid = false, cls_valid = false;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_post = nullptr, ev_done = nullptr;
+  bool pending = false;
+  float* h_cfl = nullptr;    // pinned host float
+};
+
+namespace {
+
+int layout_of(const FnxSlabConfig* c, int* owned, int* lo, int* hi, int* zoff) {
+  if (!c) return fnx::set_error(FNX_EINVAL, "slab config is NULL");
+  if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) return fnx::set_error(FNX_EINVAL, "slab: rank %d of %d", c->rank, c->nranks);
+  if (c->B < 1 || c->H < 3 || c->W < 3 || c->D_global < 3) return fnx::set_error(FNX_EINVAL, "slab: bad domain %dx%dx%dx%d", c->B, c->D_global, c->H, c->W);
+  if (c->D_global % c->nranks) return fnx::set_error(FNX_EINVAL, "slab: D must divide evenly across ranks");
+  const int ow = c->D_global / c->nranks;
+  if (c->nranks > 1 && c->halo < 5) return fnx::set_error(FNX_EINVAL, "slab: advection + projection need 5 valid ghost planes (CFL <= 1)");
+  if (c->nranks > 1 && ow < c->halo) return fnx::set_error(FNX_EINVAL, "slab thinner than its halo");
+  *owned = ow;
+  *lo = c->rank > 0 ? c->halo : 0;
+  *hi = c->rank < c->nranks - 1 ? c->halo : 0;
+  *zoff = c->rank * ow - *lo;
+  return FNX_OK;
+}
+
+FnxGrid grid_of(const FnxSlab* s, int kb = 0, int ke = 0) {
+  FnxGrid g{};
+  g.B = s->cfg.B; g.D = s->D_local; g.H = s->cfg.H; g.W = s->cfg.W; g.is3D = 1; g.ref_quirks = 0;
+  g.z_offset = s->z_offset; g.D_global = s->cfg.D_global; g.k_begin = kb; g.k_end = ke;
+  return g;
+}
+
+struct Work {                      // the step's scratch, carved from the caller's workspace
+  float *rho_adv, *U_adv, *div, *pbuf, *cfl;
+  unsigned char* cls;
+  void *jac, *adv;
+  size_t jac_bytes, adv_bytes;
+};
+size_t carve(const FnxSlab* s, void* ws, Work* w) {
+  const FnxGrid g = grid_of(s);
+  const size_t n1 = (size_t)g.B * g.D * g.H * g.W;
+  char* base = (char*)ws;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* r = base ? base + off : nullptr; off += al(bytes); return r; };
+  Work t;
+  t.rho_adv = (float*)take(n1 * 4); t.U_adv = (float*)take(n1 * 12); t.div = (float*)take(n1 * 4); t.pbuf = (float*)take(n1 * 4);
+  t.cfl = (float*)take(256); t.cls = (unsigned char*)take(n1);
+  t.jac_bytes = fnx_workspace_bytes(&g, FNX_OP_JACOBI); t.jac = take(t.jac_bytes);
+  t.adv_bytes = fnx_workspace_bytes(&g, FNX_OP_ADVECT_STEP); t.adv = take(t.adv_bytes);
+  if (w) *w = t;
+  return off;
+}
+
+// ghost exchange of `width` planes of `nf` fields (channels[i] channels each; B samples) with both neighbours
+int build_segs(const FnxSlab* s, float* const* fields, float* const* sources, const int* channels, int nf, int width,
+               std::vector<FnxSlabSeg>& segs) {
+  const size_t plane = (size_t)s->cfg.H * s->cfg.W, vol = plane * s->D_local;
+  const int lo = s->lo, top = s->lo + s->owned;
+  segs.clear();
+  for (int f = 0; f < nf; ++f)
+    for (int b = 0; b < s->cfg.B; ++b)
+      for (int c = 0; c < channels[f]; ++c) {
+        float* dst = fields[f] + ((size_t)b * channels[f] + c) * vol;
+        const float* src = (sources ? sources[f] : fields[f]) + ((size_t)b * channels[f] + c) * vol;
+        FnxSlabSeg g{};
+        g.bytes = (size_t)width * plane * 4;
+        if (s->cfg.rank > 0) { g.send_lo = src + (size_t)lo * plane; g.recv_lo = dst + (size_t)(lo - width) * plane; }
+        if (s->cfg.rank < s->cfg.nranks - 1) { g.send_hi = src + (size_t)(top - width) * plane; g.recv_hi = dst + (size_t)top * plane; }
+        segs.push_back(g);
+      }
+  return FNX_OK;
+}
+// post on the communication stream behind everything `stream` has been given so far
+int post(FnxSlab* s, float* const* fields, float* const* sources, const int* channels, int nf, int width, hipStream_t stream) {
+  if (s->cfg.nranks == 1) return FNX_OK;
+  if (width > s->cfg.halo) return fnx::set_error(FNX_EINVAL, "slab: exchange wider than the halo");
+  if (s->pending) return fnx::set_error(FNX_EINVAL, "slab: two exchanges in flight");
+  std::vector<FnxSlabSeg> segs;
+  build_segs(s, fields, sources, channels, nf, width, segs);
+  SLAB_HIP(hipEventRecord(s->ev_post, stream));
+  SLAB_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_post, 0));
+  SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), s->comm_stream));
+  SLAB_HIP(hipEventRecord(s->ev_done, s->comm_stream));
+  s->pending = true;
+  return FNX_OK;
+}
+int wait(FnxSlab* s, hipStream_t stream) {
+  if (!s->pending) return FNX_OK;
+  SLAB_HIP(hipStreamWaitEvent(stream, s->ev_done, 0));
+  s->pending = false;
+  return FNX_OK;
+}
+int xchg(FnxSlab* s, float* const* fields, const int* channels, int nf, int width, hipStream_t stream) {
+  SLAB_OK(post(s, fields, nullptr, channels, nf, width, stream));
+  return wait(s, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnx_slab_rccl_unique_id(void* out128) {
+  if (!out128) return fnx::set_error(FNX_EINVAL, "unique id buffer is NULL");
+  RcclApi* api;
+  SLAB_OK(rccl_api(&api));
+  NcclUniqueId id;
+  const int r = api->GetUniqueId(&id);
+  if (r != 0) return fnx::set_error(FNX_ECOMM, "ncclGetUniqueId failed (%d)", r);
+  memcpy(out128, &id, sizeof(id));
+  return FNX_OK;
+}
+
+int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* unique_id128) {
+  if (!out || !unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) return fnx::set_error(FNX_EINVAL, "slab_comm_rccl: bad arguments");
+  RcclApi* api;
+  SLAB_OK(rccl_api(&api));
+  RcclCtx* c = new (std::nothrow) RcclCtx{api, nullptr, rank, nranks};
+  if (!c) return fnx::set_error(FNX_EINVAL, "out of host memory");
+  NcclUniqueId id;
+  memcpy(&id, unique_id128, sizeof(id));
+  const int r = api->CommInitRank(&c->comm, nranks, id, rank);
+  if (r != 0) { delete c; return fnx::set_error(FNX_ECOMM, "ncclCommInitRank failed (%d: %s)", r, api->GetErrorString ? api->GetErrorString(r) : "?"); }
+  out->ctx = c; out->exchange = rccl_exchange; out->allreduce_max = rccl_allreduce_max; out->destroy = rccl_destroy;
+  return FNX_OK;
+}
+
+int fnx_slab_loopback_group(void** group, int nranks) {
+  if (!group || nranks < 1) return fnx::set_error(FNX_EINVAL, "loopback group: bad arguments");
+  *group = new (std::nothrow) LoopGroup(nranks);
+  return *group ? FNX_OK : fnx::set_error(FNX_EINVAL, "out of host memory");
+}
+int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank) {
+  LoopGroup* g = (LoopGroup*)group;
+  if (!out || !g || rank < 0 || rank >= g->nranks) return fnx::set_error(FNX_EINVAL, "loopback comm: bad arguments");
+  out->ctx = new LoopCtx{g, rank}; out->exchange = loop_exchange; out->allreduce_max = loop_allreduce_max; out->destroy = loop_destroy;
+  return FNX_OK;
+}
+void fnx_slab_loopback_group_free(void* group) {
+  LoopGroup* g = (LoopGroup*)group;
+  if (!g) return;
+  for (LoopPair& p : g->pairs) { if (p.ev_first) (void)hipEventDestroy(p.ev_first); if (p.ev_done) (void)hipEventDestroy(p.ev_done); }
+  delete g;
+}
+void fnx_slab_comm_free(FnxSlabComm* comm) {
+  if (comm && comm->destroy && comm->ctx) comm->destroy(comm->ctx);
+  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->destroy = nullptr; }
+}
+
+int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset) {
+  int o, l, h, z;
+  SLAB_OK(layout_of(cfg, &o, &l, &h, &z));
+  if (owned) *owned = o;
+  if (ghost_lo) *ghost_lo = l;
+  if (ghost_hi) *ghost_hi = h;
+  if (z_offset) *z_offset = z;
+  return FNX_OK;
+}
+
+size_t fnx_slab_workspace_bytes(const FnxSlabConfig* cfg) {
+  FnxSlab t{};
+  if (layout_of(cfg, &t.owned, &t.lo, &t.hi, &t.z_offset) != FNX_OK) return 0;
+  t.cfg = *cfg; t.D_local = t.owned + t.lo + t.hi;
+  return carve(&t, nullptr, nullptr);
+}
+
+int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* comm) {
+  if (!out) return fnx::set_error(FNX_EINVAL, "slab_create: out is NULL");
+  FnxSlab* s = new (std::nothrow) FnxSlab();
+  if (!s) return fnx::set_error(FNX_EINVAL, "out of host memory");
+  int rc = layout_of(cfg, &s->owned, &s->lo, &s->hi, &s->z_offset);
+  if (rc != FNX_OK) { delete s; return rc; }
+  s->cfg = *cfg;
+  s->D_local = s->owned + s->lo + s->hi;
+  s->w = cfg->sweeps_per_exchange < cfg->halo ? cfg->sweeps_per_exchange : cfg->halo;
+  if (s->w < 1) s->w = 1;
+  if (cfg->nranks > 1) {
+    if (!comm || !comm->exchange || !comm->allreduce_max) { delete s; return fnx::set_error(FNX_EINVAL, "slab_create: nranks > 1 needs a communicator"); }
+    if (s->owned < 2 * s->w) { delete s; return fnx::set_error(FNX_EINVAL, "slab too thin for the sweep block"); }
+    s->comm = *comm;
+    if (hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_post, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming) != hipSuccess) {
+      fnx_slab_destroy(s);
+      return fnx::set_error(FNX_EHIP, "slab_create: stream / event creation failed");
+    }
+  } else {
+    s->comm = FnxSlabComm{};
+  }
+  if (cfg->cfl_check_every > 0 && hipHostMalloc((void**)&s->h_cfl, sizeof(float)) != hipSuccess) {
+    fnx_slab_destroy(s);
+    return fnx::set_error(FNX_EHIP, "slab_create: pinned host allocation failed");
+  }
+  *out = s;
+  return FNX_OK;
+}
+
+void fnx_slab_destroy(FnxSlab* s) {
+  if (!s) return;
+  if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+  if (s->ev_post) (void)hipEventDestroy(s->ev_post);
+  if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+  if (s->h_cfl) (void)hipHostFree(s->h_cfl);
+  delete s;
+}
+
+int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* vstream) {
+  if (!s || !prm || !st) return fnx::set_error(FNX_EINVAL, "slab_step: NULL argument");
+  if (!st->p || !st->U || !st->flags || !st->density) return fnx::set_error(FNX_EINVAL, "slab_step: the z-slab driver needs p, U, flags and a density field");
+  if (prm->method != 0) return fnx::set_error(FNX_EINVAL, "slab_step: only the Jacobi projection shards (the CNN configurations are single-GPU)");
+  if (prm->p_tol > 0.f) return fnx::set_error(FNX_EINVAL, "slab_step: pTol > 0 needs the host-driven per-sweep test (fluidnet_cxx_amd/slab.py)");
+  if (prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
+  Work W;
+  if (!ws || carve(s, ws, &W) > ws_bytes) return fnx::set_error(FNX_EWORKSPACE, "slab_step: workspace too small (%zu < %zu)", ws_bytes, carve(s, nullptr, nullptr));
+  hipStream_t stream = (hipStream_t)vstream;
+  const int world = s->cfg.nranks, rank = s->cfg.rank, w = s->w;
+  const int lo = s->lo, top = s->lo + s->owned, DL = s->D_local;
+  const bool has_lo = rank > 0, has_hi = rank < world - 1;
+  const float dt = prm->dt;
+  const bool keep = s->cfg.static_flags && s->steps > 0;      // flags / BC arrays promised unchanged since the last step
+
+  // CFL guard (control path): max |U| dt over all ranks
+  if (s->cfg.cfl_check_every > 0 && s->steps % s->cfg.cfl_check_every == 0) {
+    const FnxGrid g = grid_of(s);
+    SLAB_OK(fnx_max_abs(&g, st->U, 3, W.cfl, stream));
+    if (world > 1) SLAB_OK(s->comm.allreduce_max(s->comm.ctx, W.cfl, 1, stream));
+    SLAB_HIP(hipMemcpyAsync(s->h_cfl, W.cfl, sizeof(float), hipMemcpyDeviceToHost, stream));
+    SLAB_HIP(hipStreamSynchronize(stream));
+    const float cfl = *s->h_cfl * (dt < 0 ? -dt : dt);
+    if (cfl > 1.0f)
+      return fnx::set_error(FNX_ECFL, "z-slab step: max |U| dt = %.3f cells > 1 -- the slab decomposition (ghost widths, advection "
+                            "windows) is only valid for CFL <= 1; reduce dt or run the single-domain step", cfl);
+  }
+  if (!keep) { s->mask_valid = false; s->cls_valid = false; }
+  ++s->steps;
+
+  FnxState state = *st;
+  state.net = nullptr;
+  state.bc_class = nullptr;
+  const bool has_bc = (st->UBC && st->UBCInvMask) || (st->densityBC && st->densityBCInvMask);
+  if (keep && has_bc) {                    // class map of the BC arrays: built on the first step under the promise, then reused
+    if (!s->cls_valid) { const FnxGrid g = grid_of(s); SLAB_OK(fnx_bc_classify(&g, st, W.cls, stream)); s->cls_valid = true; }
+    state.bc_class = W.cls;
+  }
+
+  // ---- 1. advection: the U / density ghost exchange is in flight while the ghost-free planes are advected
+  const int a_ = lo - 1 > 0 ? lo - 1 : 0, b_ = top + 1 < DL ? top + 1 : DL;
+  const int ia_ = has_lo ? lo + 3 : a_, ib_ = has_hi ? top - 3 : b_;
+  float* f2[2] = {st->U, st->density};
+  const int c2[2] = {3, 1};
+  const int gw = s->cfg.halo < 4 ? s->cfg.halo : 4;
+  auto advect = [&](int kb, int ke) {
+    const FnxGrid g = grid_of(s, kb, ke);
+    return fnx_advect_step(&g, dt, st->density, st->U, st->flags, W.rho_adv, W.U_adv, prm->sample_outside_fluid,
+                           prm->maccormack_strength, W.adv, W.adv_bytes, stream);
+  };
+  if (world > 1 && s->owned - 6 >= 8) {
+    SLAB_OK(post(s, f2, nullptr, c2, 2, gw, stream));
+    SLAB_OK(advect(ia_, ib_));
+    SLAB_OK(wait(s, stream));
+    if (ia_ > a_) SLAB_OK(advect(a_, ia_));
+    if (b_ > ib_) SLAB_OK(advect(ib_, b_));
+  } else {
+    SLAB_OK(xchg(s, f2, c2, 2, gw, stream));
+    if (world > 1) SLAB_OK(advect(a_, b_)); else SLAB_OK(advect(0, 0));
+  }
+  // ---- 2. BC / buoyancy / wall stage + divergence on the owned planes
+  {
+    const FnxGrid g = world > 1 ? grid_of(s, lo, top) : grid_of(s);
+    SLAB_OK(fnx_pre_projection(&g, prm, &state, W.U_adv, W.rho_adv, W.div, stream));
+  }
+  float* fd[1] = {W.div};
+  const int c1[1] = {1};
+  SLAB_OK(xchg(s, fd, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
+
+  // ---- 3. Jacobi: blocks of w sweeps between ghost exchanges of p
+  const FnxGrid gj = grid_of(s);
+  auto pass = [&](const float* pin, float* pout, int n, int kb, int ke, int kb2 = -1) {
+    const int rc = kb2 >= 0 ? fnx_jacobi_pass2(&gj, st->flags, W.div, pin, pout, n, kb, ke, kb2, W.jac, W.jac_bytes, s->mask_valid ? 1 : 0, stream)
+                            : fnx_jacobi_pass(&gj, st->flags, W.div, pin, pout, n, kb, ke, W.jac, W.jac_bytes, s->mask_valid ? 1 : 0, stream);
+    s->mask_valid = true;
+    return rc;
+  };
+  float *cur = st->p, *nxt = W.pbuf;
+  int remaining = prm->jacobi_iter;
+  bool zero_in = true;                       // the solve starts from p = 0 everywhere: the first pass reads nothing
+  if (world > 1 && s->owned >= 4 * w && remaining > w) {
+    // "edge_first" (slab.py:_jacobi_edge_first)
+    int npass = 0, passes[64];
+    if (w % 2) passes[npass++] = 1;
+    for (int i = 0; i < w / 2; ++i) passes[npass++] = 2;
+    int block = 0;
+    while (remaining > w) {
+      remaining -= w;
+      if (++block > 1) SLAB_OK(wait(s, stream));
+      float *src = cur, *dst = nxt;
+      int done = 0;
+      for (int pi = 0; pi < npass; ++pi) {
+        const int n = passes[pi];
+        done += n;
+        const float* pin = (zero_in && pi == 0) ? nullptr : src;
+        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + 2 * w - done, top - 2 * w + done));
+        else {
+          if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + 2 * w - done));
+          if (has_hi) SLAB_OK(pass(pin, dst, n, top - 2 * w + done, top + w - done));
+        }
+        float* t = src; src = dst; dst = t;
+      }
+      float* fin = src;
+      float* ff[1] = {fin};
+      SLAB_OK(post(s, ff, nullptr, c1, 1, w, stream));
+      src = cur; dst = nxt; done = 0;
+      for (int pi = 0; pi < npass; ++pi) {
+        const int n = passes[pi];
+        done += n;
+        SLAB_OK(pass((zero_in && pi == 0) ? nullptr : src, dst, n, has_lo ? lo + 2 * w - done : 0, has_hi ? top - 2 * w + done : DL));
+        float* t = src; src = dst; dst = t;
+      }
+      if (fin != cur) { float* t = cur; cur = nxt; nxt = t; }
+      zero_in = false;
+    }
+    SLAB_OK(wait(s, stream));
+    int done = 0;
+    for (int left = remaining; left > 0;) {
+      const int n = left >= 2 ? 2 : 1;
+      left -= n; done += n;
+      const int g = w - done > 0 ? w - done : 0;
+      SLAB_OK(pass(cur, nxt, n, has_lo ? lo - g : 0, has_hi ? top + g : DL));
+      float* t = cur; cur = nxt; nxt = t;
+    }
+  } else {
+    // "last_pass" (slab.py:_jacobi_last_pass): thin slabs, short solves, and the single-rank case
+    bool pending = false, first = true;
+    while (remaining > 0) {
+      const int k = w < remaining ? w : remaining;
+      remaining -= k;
+      if (pending) { SLAB_OK(wait(s, stream)); pending = false; }
+      int done = 0;
+      for (int left = k; left > 0;) {
+        const int n = left >= 2 ? 2 : 1;
+        left -= n; done += n;
+        const float* pin = first ? nullptr : cur;
+        first = false;
+        const int g = w - done > 0 ? w - done : 0;
+        const int a = has_lo ? lo - g : 0, b = has_hi ? top + g : DL;
+        if (left == 0 && remaining > 0 && world > 1) {
+          const int ia = has_lo ? lo + w : a, ib = has_hi ? top - w : b;
+          if (has_lo) SLAB_OK(pass(pin, nxt, n, lo, lo + w));
+          if (has_hi) SLAB_OK(pass(pin, nxt, n, top - w, top));
+          float* ff[1] = {nxt};
+          SLAB_OK(post(s, ff, nullptr, c1, 1, w, stream));
+          pending = true;
+          if (ib > ia) SLAB_OK(pass(pin, nxt, n, ia, ib));
+        } else if (world > 1) {
+          SLAB_OK(pass(pin, nxt, n, a, b));
+        } else {
+          SLAB_OK(pass(pin, nxt, n, 0, 0));
+        }
+        float* t = cur; cur = nxt; nxt = t;
+      }
+    }
+    if (pending) SLAB_OK(wait(s, stream));
+  }
+  if (cur != st->p) {
+    const FnxGrid g = grid_of(s);
+    SLAB_HIP(hipMemcpyAsync(st->p, cur, (size_t)g.B * g.D * g.H * g.W * 4, hipMemcpyDeviceToDevice, stream));
+  }
+  // ---- 4. velocity update on the owned planes
+  float* fp[1] = {st->p};
+  SLAB_OK(xchg(s, fp, c1, 1, 1, stream));
+  {
+    const FnxGrid g = world > 1 ? grid_of(s, lo, top) : grid_of(s);
+    SLAB_OK(fnx_post_projection(&g, &state, stream));
+  }
+  return FNX_OK;
+}
+
+}  // extern "C"

@@ -491,6 +491,54 @@ class SlabSimulator:
                 self.ops.set_window(0, 0)
 
 
+class NativeSlabSimulator:
+    """The same step through the C++ z-slab driver of the C ABI (`fnx_slab_create` / `fnx_slab_step`,
+    csrc/fnx_slab.hip): the launch sequence, the ghost exchanges (RCCL ncclSend/ncclRecv called directly from C++, or the
+    in-process communicator) and their overlap with the interior work are all native; Python only hands over the
+    tensors.  pTol must be 0 (the per-sweep convergence test is host-driven: SlabSimulator has it).
+
+    comm: an `ext.SlabComm` (`rccl_comm(...)` below, or `ext.slab_comm_loopback(group, rank)`); None for one rank."""
+
+    def __init__(self, layout, mconf, comm=None, sweeps_per_exchange=4, static_flags=False, cfl_check_every=8, batch=1,
+                 H=None, W=None):
+        from ._ext import ext
+        self.ext, self.l, self.cfg, self.comm = ext, layout, mconf, comm
+        self._args = (int(sweeps_per_exchange), bool(static_flags), int(cfl_check_every))
+        self._drv = None
+        self._ws = None
+        assert float(mconf.get("pTol", 0.0)) == 0.0, "the native z-slab driver runs fixed sweep counts (pTol == 0)"
+
+    def _driver(self, st):
+        if self._drv is None:
+            B, _, D, H, W = st["flags"].shape
+            l = self.l
+            self._drv = self.ext.SlabDriver(B, H, W, l.D_global, l.rank, l.world, l.halo, self._args[0], self._args[1],
+                                            self._args[2], self.comm)
+            assert self._drv.layout() == [l.owned, l.lo, l.hi, l.z_offset] and D == l.D_local
+            self._ws = torch.empty(self._drv.workspace_bytes(), dtype=torch.uint8, device=st["flags"].device)
+        return self._drv
+
+    def step(self, st):
+        assert "density" in st, "the z-slab driver advects a density field (simulate() without one is single-domain only)"
+        cfg = self.cfg
+        gv = cfg["gravityVec"]
+        self._driver(st).step(st["p"], st["U"], st["flags"], st["density"], st.get("UBC"), st.get("UBCInvMask"), st.get("densityBC"),
+                              st.get("densityBCInvMask"), float(cfg["dt"]), float(cfg["maccormackStrength"]),
+                              bool(cfg.get("sampleOutsideFluid", False)), float(cfg["buoyancyScale"]),
+                              [float(gv["x"]), float(gv["y"]), float(gv["z"])], float(cfg.get("operatingDensity", 0.0)),
+                              float(cfg.get("pTol", 0.0)), int(cfg["jacobiIter"]), self._ws)
+
+
+def rccl_comm(rank, world, group=None):
+    """An RCCL communicator for the native driver: rank 0 draws the unique id, `torch.distributed` (any backend) carries
+    its 128 bytes to the other ranks, every rank then joins with ncclCommInitRank from C++."""
+    from ._ext import ext
+    box = [ext.slab_rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return ext.slab_comm_rccl(rank, world, box[0])
+
+
 def lockstep_step(sims, states, defer=False):
     """Single-process stand-in for n ranks: advances all slabs phase by phase and serves their ghost exchanges with
     direct copies.  Used to validate the decomposition on ONE device (tests); production uses SlabSimulator.step.

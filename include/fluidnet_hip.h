@@ -29,14 +29,16 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 7
+#define FNX_ABI_VERSION 8
 
 enum {
   FNX_OK = 0,
   FNX_EINVAL = 1,    /* bad argument (shape, bnd != 1, null pointer, max_iter < 1 ...) */
   FNX_EMETHOD = 2,   /* "Advection method not supported" (cpp/advect_type.cpp:14) */
   FNX_EWORKSPACE = 3,/* workspace too small */
-  FNX_EHIP = 4       /* HIP runtime error / no device */
+  FNX_EHIP = 4,      /* HIP runtime error / no device */
+  FNX_ECFL = 5,      /* z-slab step: max |U| dt > 1 cell (the decomposition's ghost widths rest on CFL <= 1) */
+  FNX_ECOMM = 6      /* communicator error (RCCL call failed, librccl not loadable, peer missing) */
 };
 
 /* Cell types, cpp/cell_type.h:7-18 and lib/fluid/cell_type.py:5-14 */
@@ -228,6 +230,58 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
 int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
                        const float* rho_adv, float* div, void* stream);
 int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream);
+
+/* ---- z-slab decomposition of the 3D Jacobi step over the GPUs of one node (the reference is single
+ * device, plume.py:131-135).  Rank r owns D_global / nranks planes and keeps `halo` ghost planes towards each
+ * z-neighbour; its arrays hold local planes [0, owned + ghosts) = global planes [z_offset, ...).  One fnx_slab_step is
+ * lib/simulate.py:28-171 (method 'jacobi', pTol 0) for the rank's owned planes, bit for bit what the single-domain
+ * fnx_simulate_step computes there; ghost planes travel through an FnxSlabComm (neighbour exchange only, no collective on
+ * the data path).  The driver enqueues on `stream` and on one internal communication stream joined back with events
+ * (the whole step is capturable in a HIP graph); nothing synchronises except the optional CFL check. ---- */
+typedef struct FnxSlabSeg {           /* one contiguous block of ghost planes of one field and channel */
+  const void* send_lo; void* recv_lo;  /* to / from rank - 1 (NULL on rank 0) */
+  const void* send_hi; void* recv_hi;  /* to / from rank + 1 (NULL on the last rank) */
+  size_t bytes;
+} FnxSlabSeg;
+typedef struct FnxSlabComm {
+  void* ctx;
+  /* Stream-ordered exchange of all segments with both neighbours (RCCL: one ncclGroupStart/Send/Recv/GroupEnd). */
+  int (*exchange)(void* ctx, const FnxSlabSeg* segs, int nsegs, void* stream);
+  /* In-place max over all ranks of n DEVICE floats (CFL guard; control path only). */
+  int (*allreduce_max)(void* ctx, float* x, int n, void* stream);
+  void (*destroy)(void* ctx);
+} FnxSlabComm;
+/* RCCL communicator (librccl is loaded on first use; no link-time dependency).  unique_id: the 128 bytes of
+ * fnx_slab_rccl_unique_id() from rank 0, distributed by the caller (MPI, torch.distributed, a file ...). */
+int fnx_slab_rccl_unique_id(void* out128);
+int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* unique_id128);
+/* In-process communicator for `nranks` slabs driven by `nranks` host threads of one process (one device, or several
+ * with peer access): device-to-device copies ordered by events.  Create the group once, then one comm per rank. */
+int fnx_slab_loopback_group(void** group, int nranks);
+int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank);
+void fnx_slab_loopback_group_free(void* group);
+void fnx_slab_comm_free(FnxSlabComm* comm);
+
+typedef struct FnxSlabConfig {
+  int B, H, W, D_global;    /* the whole domain */
+  int rank, nranks;         /* D_global % nranks == 0 */
+  int halo;                 /* ghost planes per internal face (>= 5; the pressure solve uses all of them) */
+  int sweeps_per_exchange;  /* Jacobi sweeps per ghost exchange of p (temporal blocking in z), clipped to halo */
+  int static_flags;         /* 1: flags and BC arrays never change between steps (solver mask and BC class map are kept) */
+  int cfl_check_every;      /* every that many steps the step begins with max |U| dt over all ranks (one host sync);
+                               > 1 cell returns FNX_ECFL on every rank.  0 = never */
+} FnxSlabConfig;
+typedef struct FnxSlab FnxSlab;
+/* Local geometry of a rank (what to allocate): planes it owns, ghosts below / above, global plane of local plane 0. */
+int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset);
+size_t fnx_slab_workspace_bytes(const FnxSlabConfig* cfg);
+/* comm is borrowed (must outlive the slab).  nranks == 1 needs no communicator (comm may be NULL). */
+int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* comm);
+void fnx_slab_destroy(FnxSlab* s);
+/* One time step.  st: the rank's local arrays (with ghost planes), st->density required, st->net unused; prm->method
+ * must be 0 and prm->p_tol 0 (the per-sweep convergence test is host-driven: fluidnet_cxx_amd/slab.py has it);
+ * prm->static_flags is ignored (FnxSlabConfig.static_flags).  ws: fnx_slab_workspace_bytes, kept between steps. */
+int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* stream);
 
 /* MultiScaleNet / FluidNet.forward, lib/multi_scale_net.py:118-127 and lib/model.py:76-227 (ScaleNet variant).
  * weights_blob: 17 convs in the order convN_4[0..3], convN_2[0..5], convN_1[0..5], final; for each conv the

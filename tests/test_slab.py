@@ -267,3 +267,93 @@ def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule):
     oref = reference_steps(gs, 2)
     for k in ("U", "density", "p"):
         assert np.array_equal(ref[k], oref[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,halo,w,static", [(2, 6, 4, False), (4, 6, 3, False), (2, 6, 6, True), (3, 6, 5, True), (2, 5, 5, False),
+                                                 (2, 6, 4, "thin"), (1, 6, 6, True)])
+def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static):
+    """The C++ z-slab driver (fnx_slab_step) on `world` slabs of one domain, each driven by its own host thread and HIP
+    stream on one device, ghost planes through the in-process communicator (event-ordered device copies): every owned
+    plane bit-identical to the single-domain step, 3 steps (the third reuses the solver mask and the BC class map under
+    the static promise).  "thin": slabs too thin for the edge-first schedule (the last-pass schedule of the driver)."""
+    import threading
+    from fluidnet_cxx_amd import simulate
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    dev = torch.device("cuda:0")
+    thin = static == "thin"
+    D = (2 * w * world if thin else 4 * w * world) if world > 1 else 24
+    H, W = 20, 70
+    gs = global_state(D, H, W, seed=5)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    nsteps = 3
+    for _ in range(nsteps):
+        simulate(CFG, bd, None, "jacobi")
+    ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
+    layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
+    states = [local_state(gs, l, dev) for l in layouts]
+    group = ext.SlabLoopbackGroup(world)
+    sims = [NativeSlabSimulator(l, CFG, comm=ext.slab_comm_loopback(group, l.rank) if world > 1 else None, sweeps_per_exchange=w,
+                                static_flags=bool(static) and not thin, cfl_check_every=2) for l in layouts]
+    torch.cuda.synchronize()
+    errs = []
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                for _ in range(nsteps):
+                    sims[r].step(states[r])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a rank's thread hangs"
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for l, st in zip(layouts, states):
+        check_owned(st, ref, l, f"native driver world={world} w={w}")
+
+
+@pytest.mark.gpu
+def test_native_driver_cfl_guard_and_errors():
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    dev = torch.device("cuda:0")
+    gs = global_state(24, 20, 70, seed=1)
+    gs["U"] = gs["U"] * 40.0                                   # CFL >> 1
+    l = SlabLayout(24, 1, 0, 6)
+    st = local_state(gs, l, dev)
+    sim = NativeSlabSimulator(l, CFG, sweeps_per_exchange=6, cfl_check_every=1)
+    with pytest.raises(RuntimeError, match="max .U. dt"):
+        sim.step(st)
+    with pytest.raises(RuntimeError, match="needs a communicator"):
+        ext.SlabDriver(1, 20, 70, 48, 0, 2, 6, 6)
+    with pytest.raises(RuntimeError, match="5 valid ghost planes"):
+        ext.SlabDriver(1, 20, 70, 48, 0, 2, 4, 4, comm=ext.slab_comm_loopback(ext.SlabLoopbackGroup(2), 0))
+
+
+@pytest.mark.gpu
+def test_native_driver_rccl_single_rank():
+    """RCCL called directly from C++ (librccl resolved at run time): unique id, communicator of one rank (the box has one
+    GPU), the all-reduce of the CFL guard through it, a step; same bits as the communicator-free driver."""
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout, rccl_comm
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    uid = ext.slab_rccl_unique_id()
+    assert isinstance(uid, bytes) and len(uid) == 128 and any(uid)
+    comm = rccl_comm(0, 1)
+    gs = global_state(24, 20, 70, seed=2)
+    l = SlabLayout(24, 1, 0, 6)
+    a, b = local_state(gs, l, dev), local_state(gs, l, dev)
+    NativeSlabSimulator(l, CFG, comm=comm, sweeps_per_exchange=6, cfl_check_every=1).step(a)
+    NativeSlabSimulator(l, CFG, comm=None, sweeps_per_exchange=6, cfl_check_every=0).step(b)
+    torch.cuda.synchronize()
+    for k in ("U", "density", "p"):
+        assert torch.equal(a[k], b[k]), k
