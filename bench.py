@@ -357,10 +357,22 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D):
 
     for _ in range(max(warmup, 3)):
         sim.step(bd)
+    step, launch = (lambda: sim.step(bd)), "eager (C++ driver)"
+    if world == 1:
+        # one rank: the step is a fixed launch sequence on fixed buffers -- capture it once, replay it per step
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sim.step(bd)
+            g.replay(); torch.cuda.synchronize()
+            step, launch = g.replay, "hip-graph replay of the C++ driver's step"
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"bench: native slab step not captured ({e}); running eagerly\n")
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        sim.step(bd)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -368,7 +380,7 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cells = res * res * layout.owned * world
-    return dict(ms_per_step=elapsed / steps * 1e3, value=cells * steps / elapsed / 1e6, unit="Mcells/s", steps=steps,
+    return dict(ms_per_step=elapsed / steps * 1e3, value=cells * steps / elapsed / 1e6, unit="Mcells/s", steps=steps, launch=launch,
                 transport="RCCL ncclSend/ncclRecv issued from C++ (librccl resolved at run time)" if world > 1 else None,
                 state_finite=bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all()))
 
