@@ -51,11 +51,11 @@ __device__ __forceinline__ float bfi_blend(int m, float a, float b) {   // m ? a
 template <int V, int R0, int N, bool MASKED>
 __device__ __forceinline__ void jacobi_rows(float (&p)[V], const float (&d)[V], float& carry, const unsigned (&mL)[2],
                                             const unsigned (&mR)[2], const unsigned (&mD)[2], const unsigned (&mU)[2],
-                                            const unsigned (&mC)[2], float (&delta)[N]) {
+                                            const unsigned (&mC)[2], float (&delta)[N], float top = 0.f) {
   float pc[N], pl[N], pr[N], sum[N], v[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) pc[n] = p[R0 + n];
-  const float up_last = (R0 + N < V) ? p[(R0 + N < V) ? R0 + N : 0] : 0.f;
+  const float up_last = (R0 + N < V) ? p[(R0 + N < V) ? R0 + N : 0] : top;
 #pragma unroll
   for (int n = 0; n < N; ++n) pl[n] = dpp_from_left(pc[n]);
 #pragma unroll
@@ -198,6 +198,121 @@ __global__ __launch_bounds__(256) void jacobi2d_reg_kernel(GridDims g, const flo
       const int y = y0 + r;
       if (y < g.H) (p_out + base + (size_t)y * g.W)[x] = p[r];
     }
+  }
+  if (sumsq) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) atomicAdd(&sumsq[b], local);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2D, workgroup tiles: the same register-resident sweeps, but NW waves stacked in y form ONE tile of 64 x (NW*RW) cells
+// and hand each other their edge rows through LDS once per sweep (one barrier per sweep, two LDS row images alternating),
+// so only the workgroup's outer ring is recomputed halo: the work per K sweeps drops from 64*(OY+2K)/((64-2K)*OY) times
+// the field (2.3x at K=4/OY=8, 2.7x at K=8/OY=16) to 64*NW*RW/((64-2K)*(NW*RW-2K)) (1.3x / 1.5x), and a wave's serial
+// chain per sweep is RW rows whatever K.  Same per-cell arithmetic (jacobi_rows): same bits.
+// ---------------------------------------------------------------------------------------------------
+template <int V, int R0, int N, bool MASKED>
+__device__ __forceinline__ void wg_sweep_rows(float (&p)[V], const float (&d)[V], float& carry, float top,
+                                              const unsigned (&mL)[2], const unsigned (&mR)[2], const unsigned (&mD)[2],
+                                              const unsigned (&mU)[2], const unsigned (&mC)[2], bool last, bool lane_ok,
+                                              int out_lo, int out_hi, float& local) {
+  if constexpr (R0 < V) {
+    constexpr int M = (V - R0 >= N) ? N : (V - R0);
+    float delta[M];
+    jacobi_rows<V, R0, M, MASKED>(p, d, carry, mL, mR, mD, mU, mC, delta, top);
+    if (last) {                                          // wave-uniform
+#pragma unroll
+      for (int n = 0; n < M; ++n)
+        if (R0 + n >= out_lo && R0 + n < out_hi && lane_ok) local += delta[n] * delta[n];
+    }
+    wg_sweep_rows<V, R0 + M, N, MASKED>(p, d, carry, top, mL, mR, mD, mU, mC, last, lane_ok, out_lo, out_hi, local);
+  }
+}
+
+template <int K, int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const float* __restrict__ flags,
+                                                             const float* __restrict__ div, const float* __restrict__ p_in,
+                                                             float* __restrict__ p_out, int from_zero,
+                                                             float* __restrict__ sumsq, int tiles_x) {
+  constexpr int V = RW, OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
+  constexpr int NI = 4;
+  static_assert(V <= 32 && OYW > 0, "tile shape");
+  __shared__ float edge[2][2][NW][64];                   // [sweep parity][0: first row, 1: last row][wave][lane]
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int b = blockIdx.y;
+  const int x = tx * OX - K + lane, y0 = ty * OYW - K + w * RW;      // this wave's first row
+  const bool xin = (x >= 0) & (x < g.W), xint = (x >= 1) & (x <= g.W - 2);
+  const size_t base = (size_t)b * g.DHW;
+  const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
+
+  float p[V], d[V];
+  unsigned ob = 0, cont = 0;
+  auto is_ob = [&](int y) {                              // obstacle (or outside the grid) at (x, y)
+    const bool yin = (y >= 0) & (y < g.H);
+    const int yc = y < 0 ? 0 : (y > g.H - 1 ? g.H - 1 : y);
+    const float f = (flags + base + (size_t)yc * g.W)[xc];
+    return !(xin & yin) | (f == FNX_OBST);
+  };
+#pragma unroll
+  for (int r = 0; r < V; ++r) {
+    const int y = y0 + r;
+    const bool yin = (y >= 0) & (y < g.H);
+    const int yc = y < 0 ? 0 : (y > g.H - 1 ? g.H - 1 : y);
+    const size_t row = base + (size_t)yc * g.W;
+    const float f = (flags + row)[xc];
+    const float dv = (div + row)[xc];
+    float pv = 0.f;
+    if (!from_zero) pv = (p_in + row)[xc];
+    const bool in = xin & yin;
+    d[r] = in ? dv : 0.f;
+    p[r] = in ? pv : 0.f;
+    const bool isob = !in | (f == FNX_OBST);
+    ob |= (unsigned)isob << r;
+    cont |= (unsigned)(xint & (y >= 1) & (y <= g.H - 2) & !isob) << r;
+  }
+  const unsigned ob_below = is_ob(y0 - 1), ob_above = is_ob(y0 + V);
+  const unsigned obL = dpp_from_left_u(ob), obR = dpp_from_right_u(ob);
+  const unsigned obD = (ob << 1) | ob_below, obU = (ob >> 1) | (ob_above << (V - 1));
+  // the workgroup's outermost ring is never evaluated (its neighbours are not in the tile)
+  if (w == 0) cont &= ~1u;
+  if (w == NW - 1) cont &= ~(1u << (V - 1));
+  if (lane == 0 || lane == 63) cont = 0;
+  unsigned mL[2] = {obL, 0}, mR[2] = {obR, 0}, mD[2] = {obD, 0}, mU[2] = {obU, 0}, mC[2] = {cont, 0};
+  // output rows of this wave: tile rows [K, NW*RW - K) that lie in the grid
+  int out_lo = K - w * RW, out_hi = NW * RW - K - w * RW;
+  if (out_lo < 0) out_lo = 0;
+  if (out_hi > V) out_hi = V;
+  if (out_hi > g.H - y0) out_hi = g.H - y0;
+  const bool lane_ok = (lane >= K) & (lane < 64 - K) & xin;
+  float local = 0.f;
+  constexpr unsigned ALL = V < 32 ? ((1u << V) - 1) : ~0u;
+  const unsigned ring = ALL & ~((w == 0 ? 1u : 0u) | (w == NW - 1 ? 1u << (V - 1) : 0u));
+  const bool edge_lane = (lane == 0) | (lane == 63);
+  const bool plain = edge_lane | ((cont == ring) & (((obL | obR | obD | obU) & ring) == 0));
+  const bool all_plain = __all(plain);
+#pragma unroll 1
+  for (int s = 0; s < K; ++s) {
+    float* e = &edge[s & 1][0][0][0];
+    e[w * 64 + lane] = p[0];
+    e[NW * 64 + w * 64 + lane] = p[V - 1];
+    __syncthreads();
+    float carry = w > 0 ? e[NW * 64 + (w - 1) * 64 + lane] : 0.f;           // last row of the wave below
+    const float top = w < NW - 1 ? e[(w + 1) * 64 + lane] : 0.f;            // first row of the wave above
+    const bool last = (s == K - 1) && (sumsq != nullptr);
+    if (all_plain) {
+      wg_sweep_rows<V, 0, NI, false>(p, d, carry, top, mL, mR, mD, mU, mC, last, lane_ok, out_lo, out_hi, local);
+    } else {
+      asm volatile("" : "+v"(mL[0]), "+v"(mR[0]), "+v"(mD[0]), "+v"(mU[0]), "+v"(mC[0]));
+      wg_sweep_rows<V, 0, NI, true>(p, d, carry, top, mL, mR, mD, mU, mC, last, lane_ok, out_lo, out_hi, local);
+    }
+  }
+  if (lane_ok) {
+#pragma unroll
+    for (int r = 0; r < V; ++r)
+      if (r >= out_lo && r < out_hi) (p_out + base + (size_t)(y0 + r) * g.W)[x] = p[r];
   }
   if (sumsq) {
 #pragma unroll
@@ -1242,10 +1357,32 @@ inline int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+template <int K, int RW, int NW>
+void launch_wg(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, bool from_zero,
+               float* sumsq, hipStream_t s) {
+  constexpr int OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
+  const int tiles_x = (g.W + OX - 1) / OX, tiles_y = (g.H + OYW - 1) / OYW;
+  jacobi2d_wg_kernel<K, RW, NW><<<dim3(tiles_x * tiles_y, g.B), 64 * NW, 0, s>>>(g, flags, div, p_in, p_out, from_zero ? 1 : 0, sumsq, tiles_x);
+}
+
 template <int K>
 void launch_reg(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out,
                 bool from_zero, float* sumsq, hipStream_t s) {
   constexpr int OX = 64 - 2 * K;
+  // workgroup tiles (jacobi2d_wg_kernel): FNX_JACOBI_WG = 0 off, else RW*100 + NW (e.g. 808: 8 rows x 8 waves)
+  static const int wg = env_int("FNX_JACOBI_WG", -1);
+  if (wg != 0) {
+    const long cells = (long)g.W * g.H * g.B;
+    // measured on MI355X (bench.py, Jacobi ms per step): 2048^2 x 100 sweeps K=8: 0.659 (wave tiles) -> 808: 0.450, 1604: 0.462,
+    // 804: 0.533, 1608: 0.539, 816: 0.597; 1024^2 x 28 K=7: 0.088 -> 808: 0.0615, 804: 0.0667; 128^2 x 28 K=8: 0.051 -> 804: 0.036
+    const int sel = wg > 0 ? wg : (cells <= (160l << 10) ? 804 : 808);
+    if constexpr (16 > 2 * K) if (sel == 404) { launch_wg<K, 4, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+    if constexpr (32 > 2 * K) if (sel == 804 || sel == 404) { launch_wg<K, 8, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+    if (sel == 808) { launch_wg<K, 8, 8>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+    if (sel == 1604) { launch_wg<K, 16, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+    if (sel == 1608) { launch_wg<K, 16, 8>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+    if (sel == 816) { launch_wg<K, 8, 16>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+  }
   static const int forced = env_int("FNX_JACOBI_OY", 0);
   int oy = forced;
   if (!oy) {
@@ -1270,8 +1407,12 @@ int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d) {
   if (is3d || g.D != 1) return 1;
   static const int forced = env_int("FNX_JACOBI_K", 0);
   if (forced >= 1 && forced <= KMAX_2D) return forced;
-  // small grids are bound by the serial chain of one wave (K*(OY+2K) row updates): fewer sweeps per launch win
-  return (long)g.W * g.H * g.B <= (2l << 20) ? 4 : KMAX_2D;
+  // workgroup tiles (jacobi2d_wg_kernel): a wave's chain per sweep is its 8 rows whatever K, so the halo (2K of the 64
+  // columns and rows of a tile) is what limits K: 7 where launches are still short (28 sweeps = 4 launches), else 8.
+  // (wave tiles, FNX_JACOBI_WG=0: the serial chain K*(OY+2K) of one wave favoured K = 4 on small grids)
+  static const int wg = env_int("FNX_JACOBI_WG", -1);
+  if (wg == 0) return (long)g.W * g.H * g.B <= (2l << 20) ? 4 : KMAX_2D;
+  return (long)g.W * g.H * g.B <= (2l << 20) ? 7 : KMAX_2D;
 }
 
 // nsweeps in [1, jacobi_max_sweeps_per_launch]; sumsq (B floats, pre-zeroed) receives ||p_n - p_{n-1}||^2 of the
