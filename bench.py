@@ -285,7 +285,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
         ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
         util = issued["conv_mfma"] / (tms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if tms > 0 else 0.0
-        kname = ("conv3_wino2_kernel (3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
+        kname = ("conv3_wino3_kernel (persistent software pipeline; 3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
@@ -302,7 +302,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
         byts = 16.0 * w["iters"] * cells * prof_steps
         ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
         kname = ("jacobi3d_march_kernel (z-marching, several sweeps per pass)" if is3d
-                 else "jacobi2d kernels (register/DPP temporal blocking)")
+                 else "jacobi2d_wg_kernel (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-8 sweeps per launch)")
         avg_ms = tms / max(nl, 1)
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                     traffic=traffic,
