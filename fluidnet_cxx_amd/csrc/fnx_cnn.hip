@@ -964,11 +964,13 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   // k-step is issued first; without it the accumulators start from zero).  The weight/transform stream (stage s+1) and the
   // halo stream (stage s+2) are always live: behind a workgroup's last tile they run on a stand-in tile whose results
   // nobody reads, which keeps every phase the same straight-line code.
-  auto phase = [&](auto m0, const float* wcur, float* wnext, const float* xcur, float* xnext, const float* rawnext,
-                   float* rawfree) __attribute__((always_inline)) {
+  auto phase_sched = [&](auto m0, auto late_, const float* wcur, float* wnext, const float* xcur, float* xnext,
+                         const float* rawnext, float* rawfree) __attribute__((always_inline)) {
     constexpr bool M0 = decltype(m0)::value;
+    constexpr bool LATE = decltype(late_)::value;         // the second wave of each SIMD runs its fillers half a phase later
     // (the fetches of the phase are issued BEHIND its first MFMAs, whose operands are already in registers: the matrix
     // pipe restarts right behind the barrier instead of idling through ~40 address/VMEM/LDS instructions per wave)
+    constexpr int S_XF = LATE ? 4 : 0, S_DMA = LATE ? 5 : 1, S_K0 = LATE ? 6 : 2, S_K1 = LATE ? 11 : 7, S_RAW = LATE ? 14 : 13;
 #pragma unroll
     for (int slot = 0; slot < 16; ++slot) {
       const int ks = slot < 8 ? 1 : 0, p = slot & 7;
@@ -981,16 +983,19 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (slot == 0) { prefetch(); xf_load(0, rawnext); }
-      if (slot == 1) stage_weights(wnext);
-      if (slot == 2) load_k(0, wcur, xcur);
-      // half patch i: loaded at slot 4i (i > 0), columns at 4i+3, rows + stores at 4i+4
-      const int ui = slot / 4, us = slot % 4;
-      if (us == 0 && ui > 0 && ui < UPT) xf_load(ui, rawnext);
-      if (us == 3 && ui < UPT) xf_cols(ui);
-      if (us == 0 && ui > 0 && ui - 1 < UPT) xf_rows_store(ui - 1, xnext);
-      if (slot == 7) load_k(1, wcur, xcur);                // the registers of k-step 1 are free: its MFMAs have all been issued
-      if (slot == 13) store_raw(rawfree);
+      if (slot == 0) prefetch();
+      if (slot == S_XF) xf_load(0, rawnext);
+      if (slot == S_DMA) stage_weights(wnext);
+      if (slot == S_K0) load_k(0, wcur, xcur);
+      // half patch i: loaded at slot S_XF + 4i, columns 3 slots later, rows + stores 4 slots later
+      const int rel = slot - S_XF, ui = rel / 4, us = rel % 4;
+      if (rel >= 0) {
+        if (us == 0 && ui > 0 && ui < UPT) xf_load(ui, rawnext);
+        if (us == 3 && ui < UPT) xf_cols(ui);
+        if (us == 0 && ui > 0 && ui - 1 < UPT) xf_rows_store(ui - 1, xnext);
+      }
+      if (slot == S_K1) load_k(1, wcur, xcur);             // the registers of k-step 1 are free: its MFMAs have all been issued
+      if (slot == S_RAW) store_raw(rawfree);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -998,109 +1003,122 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
 
-  int tM = blockIdx.x;
-  Tile TM = T0;
-  for (;;) {
-    const int niter = (dz_hi_of(TM) - dz_lo_of(TM)) * nchunk;   // even, >= 4 (the host checks Cin % (4 C))
-    const bool more = tM + tstep < ntiles;
-    const Tile TN = more ? next_tile(TM) : TM;          // the streams' next tile (stand-in behind the last one: this tile again)
-    phase(F_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);    // stage 0
-    for (int it = 1; it + 1 < niter; it += 2) {
-      phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);  // stage it (odd)
-      if (it + 3 == niter) enter_R(TN);         // stage niter-2 fetches the halo tile of the next tile's stage 0
-      phase(T_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);  // stage it+1 (even)
-    }
-    enter_W(TN);                                        // stage niter-1 fetches the weights of the next tile's stage 0
-    phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);
-    // the second k-step of the last stage
+  // The two waves of a SIMD (waves w and w + 4 of an 8-wave workgroup) would otherwise run the same instruction at the same
+  // time and wait at the same points, leaving the matrix pipe idle together: the second one runs the whole tile loop with
+  // the late filler schedule (ONE branch around two copies of the loop: a branch per phase made the register allocator
+  // spill 600 registers at the joins).
+  constexpr bool STAGGER = NWV == 8 && UPT == 1;
+  auto run = [&](auto late_) __attribute__((always_inline)) {
+    auto phase = [&](auto m0, const float* wcur, float* wnext, const float* xcur, float* xnext, const float* rawnext,
+                     float* rawfree) __attribute__((always_inline)) {
+      phase_sched(m0, late_, wcur, wnext, xcur, xnext, rawnext, rawfree);
+    };
+    int tM = blockIdx.x;
+    Tile TM = T0;
+    for (;;) {
+      const int niter = (dz_hi_of(TM) - dz_lo_of(TM)) * nchunk;   // even, >= 4 (the host checks Cin % (4 C))
+      const bool more = tM + tstep < ntiles;
+      const Tile TN = more ? next_tile(TM) : TM;          // the streams' next tile (stand-in behind the last one: this tile again)
+      phase(F_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);    // stage 0
+      for (int it = 1; it + 1 < niter; it += 2) {
+        phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);  // stage it (odd)
+        if (it + 3 == niter) enter_R(TN);         // stage niter-2 fetches the halo tile of the next tile's stage 0
+        phase(T_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);  // stage it+1 (even)
+      }
+      enter_W(TN);                                        // stage niter-1 fetches the weights of the next tile's stage 0
+      phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);
+      // the second k-step of the last stage
 #pragma unroll
-    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][p], bv[1][p], acc[p], 0, 0, 0);
+      for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][p], bv[1][p], acc[p], 0, 0, 0);
 
-    // Output transform A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]); this wave holds rows 2h, 2h+1 of M (acc[4*(row-2h) + s]):
-    //   h = 0:  t0 = M0 + M1, t1 = M1          h = 1:  t0 = M2, t1 = -M2 - M3
-    // Register r belongs to half (r >> 3): the partial outputs of the other half's registers go through LDS to the
-    // partner wave, the own ones are completed with the partner's, then bias, ReLU, store.  All of it on register PAIRS
-    // (r, r+1) as packed fp32 (v_pk_add_f32: the same IEEE additions, two per instruction); the barriers of the
-    // exchange wait for LDS only (a __syncthreads() would also wait for the stores of the round before to be acknowledged).
-    {
-      const int bx = l31 & 15, byl = l31 >> 4;
-      const int tx0 = TM.tx * 32, ty0 = TM.ty * (4 * NPG);
-      const int x = tx0 + 2 * bx, y = ty0 + 2 * (2 * pg + byl);
-      // channel of register r = 8 hh + 4 round + 2 j (+1):  cg*32 + 2 j + 8 (2 hh + round) + 4 half
-      const int co_own = TM.grp * RW + cg * 32 + 16 * h + 4 * half;
-      f32x2 bias2[2][2];
+      // Output transform A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]); this wave holds rows 2h, 2h+1 of M (acc[4*(row-2h) + s]):
+      //   h = 0:  t0 = M0 + M1, t1 = M1          h = 1:  t0 = M2, t1 = -M2 - M3
+      // Register r belongs to half (r >> 3): the partial outputs of the other half's registers go through LDS to the
+      // partner wave, the own ones are completed with the partner's, then bias, ReLU, store.  All of it on register PAIRS
+      // (r, r+1) as packed fp32 (v_pk_add_f32: the same IEEE additions, two per instruction); the barriers of the
+      // exchange wait for LDS only (a __syncthreads() would also wait for the stores of the round before to be acknowledged).
+      {
+        const int bx = l31 & 15, byl = l31 >> 4;
+        const int tx0 = TM.tx * 32, ty0 = TM.ty * (4 * NPG);
+        const int x = tx0 + 2 * bx, y = ty0 + 2 * (2 * pg + byl);
+        // channel of register r = 8 hh + 4 round + 2 j (+1):  cg*32 + 2 j + 8 (2 hh + round) + 4 half
+        const int co_own = TM.grp * RW + cg * 32 + 16 * h + 4 * half;
+        f32x2 bias2[2][2];
 #pragma unroll
-      for (int round = 0; round < 2; ++round)
+        for (int round = 0; round < 2; ++round)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bias2[round][j] = *(const f32x2*)&a.bias[co_own + 8 * round + 2 * j];
-      float* obase = a.y + ((size_t)TM.b * a.cout + co_own) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x;
-      const bool inx = x < a.W, iny = y < a.H, inx1 = x + 1 < a.W, iny1 = y + 1 < a.H;
-      const bool full = (tx0 + 32 <= a.W) & (ty0 + 4 * NPG <= a.H);       // (wave-uniform) no clipped pixel in the tile
-      f32x2* ex_out = (f32x2*)&exch[wave * 16 * 64] + lane;
-      const f32x2* ex_in = (const f32x2*)&exch[(wave ^ 1) * 16 * 64] + lane;
-      auto out_part = [&](auto hh_, int r, f32x2 (&pt)[4]) __attribute__((always_inline)) {
-        constexpr int HH = decltype(hh_)::value;           // this wave's position half
-        f32x2 t0[4], t1[4];
+          for (int j = 0; j < 2; ++j) bias2[round][j] = *(const f32x2*)&a.bias[co_own + 8 * round + 2 * j];
+        float* obase = a.y + ((size_t)TM.b * a.cout + co_own) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x;
+        const bool inx = x < a.W, iny = y < a.H, inx1 = x + 1 < a.W, iny1 = y + 1 < a.H;
+        const bool full = (tx0 + 32 <= a.W) & (ty0 + 4 * NPG <= a.H);       // (wave-uniform) no clipped pixel in the tile
+        f32x2* ex_out = (f32x2*)&exch[wave * 16 * 64] + lane;
+        const f32x2* ex_in = (const f32x2*)&exch[(wave ^ 1) * 16 * 64] + lane;
+        auto out_part = [&](auto hh_, int r, f32x2 (&pt)[4]) __attribute__((always_inline)) {
+          constexpr int HH = decltype(hh_)::value;           // this wave's position half
+          f32x2 t0[4], t1[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const f32x2 a0 = {acc[s][r], acc[s][r + 1]}, a1 = {acc[4 + s][r], acc[4 + s][r + 1]};
-          if (HH == 0) { t0[s] = a0 + a1; t1[s] = a1; }
-          else { t0[s] = a0; t1[s] = (-a0) - a1; }
-        }
-        pt[0] = (t0[0] + t0[1]) + t0[2]; pt[1] = (t0[1] - t0[2]) - t0[3];
-        pt[2] = (t1[0] + t1[1]) + t1[2]; pt[3] = (t1[1] - t1[2]) - t1[3];
-      };
-      auto send = [&](auto hh_, int round) __attribute__((always_inline)) {
-        constexpr int HH = decltype(hh_)::value;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x2 pt[4];
-          out_part(hh_, 8 * (1 - HH) + 4 * round + 2 * j, pt);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) ex_out[(j * 4 + q) * 64] = pt[q];
-        }
-      };
-      auto finish = [&](auto hh_, int round) __attribute__((always_inline)) {
-        constexpr int HH = decltype(hh_)::value;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x2 pt[4], v[4];
-          out_part(hh_, 8 * HH + 4 * round + 2 * j, pt);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v[q] = (pt[q] + ex_in[(j * 4 + q) * 64]) + bias2[round][j];
-            if (a.relu) v[q] = __builtin_elementwise_max(v[q], (f32x2){0.f, 0.f});
+          for (int s = 0; s < 4; ++s) {
+            const f32x2 a0 = {acc[s][r], acc[s][r + 1]}, a1 = {acc[4 + s][r], acc[4 + s][r + 1]};
+            if (HH == 0) { t0[s] = a0 + a1; t1[s] = a1; }
+            else { t0[s] = a0; t1[s] = (-a0) - a1; }
           }
-          float* o0 = obase + (size_t)(8 * round + 2 * j) * vol;
-          float* o1 = o0 + vol;
-          if (full) {
-            *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x);
-            *(float2*)o1 = make_float2(v[0].y, v[1].y); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y);
-          } else if (inx & iny) {
-            if (inx1) {
-              *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)o1 = make_float2(v[0].y, v[1].y);
-              if (iny1) { *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y); }
-            } else {
-              o0[0] = v[0].x; o1[0] = v[0].y;
-              if (iny1) { o0[a.W] = v[2].x; o1[a.W] = v[2].y; }
+          pt[0] = (t0[0] + t0[1]) + t0[2]; pt[1] = (t0[1] - t0[2]) - t0[3];
+          pt[2] = (t1[0] + t1[1]) + t1[2]; pt[3] = (t1[1] - t1[2]) - t1[3];
+        };
+        auto send = [&](auto hh_, int round) __attribute__((always_inline)) {
+          constexpr int HH = decltype(hh_)::value;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x2 pt[4];
+            out_part(hh_, 8 * (1 - HH) + 4 * round + 2 * j, pt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ex_out[(j * 4 + q) * 64] = pt[q];
+          }
+        };
+        auto finish = [&](auto hh_, int round) __attribute__((always_inline)) {
+          constexpr int HH = decltype(hh_)::value;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x2 pt[4], v[4];
+            out_part(hh_, 8 * HH + 4 * round + 2 * j, pt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q] = (pt[q] + ex_in[(j * 4 + q) * 64]) + bias2[round][j];
+              if (a.relu) v[q] = __builtin_elementwise_max(v[q], (f32x2){0.f, 0.f});
+            }
+            float* o0 = obase + (size_t)(8 * round + 2 * j) * vol;
+            float* o1 = o0 + vol;
+            if (full) {
+              *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x);
+              *(float2*)o1 = make_float2(v[0].y, v[1].y); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y);
+            } else if (inx & iny) {
+              if (inx1) {
+                *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)o1 = make_float2(v[0].y, v[1].y);
+                if (iny1) { *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y); }
+              } else {
+                o0[0] = v[0].x; o1[0] = v[0].y;
+                if (iny1) { o0[a.W] = v[2].x; o1[a.W] = v[2].y; }
+              }
             }
           }
-        }
-      };
-      using H0 = std::integral_constant<int, 0>;
-      using H1 = std::integral_constant<int, 1>;
+        };
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
 #pragma unroll
-      for (int round = 0; round < 2; ++round) {            // 4 of a half's 8 registers per round (16 values each way)
-        // (round 0: the previous tile's reads of the exchange buffer are many barriers back)
-        if (round) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); }       // lgkmcnt(0) only
-        if (h == 0) send(H0{}, round); else send(H1{}, round);
-        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
-        if (h == 0) finish(H0{}, round); else finish(H1{}, round);
+        for (int round = 0; round < 2; ++round) {            // 4 of a half's 8 registers per round (16 values each way)
+          // (round 0: the previous tile's reads of the exchange buffer are many barriers back)
+          if (round) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); }       // lgkmcnt(0) only
+          if (h == 0) send(H0{}, round); else send(H1{}, round);
+          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+          if (h == 0) finish(H0{}, round); else finish(H1{}, round);
+        }
       }
+      if (!more) break;
+      tM += tstep; TM = TN;
     }
-    if (!more) break;
-    tM += tstep; TM = TN;
-  }
+  };
+  if (STAGGER && wave >= NWV / 2) run(std::integral_constant<bool, STAGGER>{});
+  else run(std::integral_constant<bool, false>{});
 }
 
 // blob: (Cout,Cin,3x3) -> G g G^T as [16][Cin][Cout], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
