@@ -1007,7 +1007,8 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   // time and wait at the same points, leaving the matrix pipe idle together: the second one runs the whole tile loop with
   // the late filler schedule (ONE branch around two copies of the loop: a branch per phase made the register allocator
   // spill 600 registers at the joins).
-  constexpr bool STAGGER = NWV == 8 && UPT == 1;
+  // (2D only: with the 3D layers' 48 stages per tile the late schedule measured 5 % slower, 82 -> 86 ms at 256^3)
+  constexpr bool STAGGER = NWV == 8 && UPT == 1 && !IS3D;
   auto run = [&](auto late_) __attribute__((always_inline)) {
     auto phase = [&](auto m0, const float* wcur, float* wnext, const float* xcur, float* xnext, const float* rawnext,
                      float* rawfree) __attribute__((always_inline)) {
