@@ -263,6 +263,26 @@ void empty_domain_(Tensor flags, int boundary_width, const Geom* geom) {
   check_status(fnx_empty_domain(&g, flags.data_ptr<float>(), boundary_width, cur_stream(flags)));
 }
 
+// adjoints of the linear stencil operators (fnx_velocity_divergence_backward, fnx_velocity_update_backward)
+Tensor velocity_divergence_backward(Tensor grad_div, Tensor flags, bool is3D, const Geom* geom) {
+  FnxGrid g = grid_of(flags, is3D, geom);
+  check_scalar(grad_div, g, "grad_div");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor gU = at::empty({flags.size(0), is3D ? 3 : 2, flags.size(2), flags.size(3), flags.size(4)}, flags.options());
+  check_status(fnx_velocity_divergence_backward(&g, grad_div.data_ptr<float>(), flags.data_ptr<float>(), gU.data_ptr<float>(), cur_stream(flags)));
+  return gU;
+}
+std::vector<Tensor> velocity_update_backward(Tensor grad_U_out, Tensor flags, const Geom* geom) {
+  check_field(grad_U_out, "grad_U_out");
+  FnxGrid g = grid_of(flags, grad_U_out.size(1) == 3, geom);
+  check_vel(grad_U_out, g, "grad_U_out");
+  c10::hip::HIPGuard guard(flags.get_device());
+  Tensor gU = at::empty_like(grad_U_out), gp = at::empty_like(flags);
+  check_status(fnx_velocity_update_backward(&g, grad_U_out.data_ptr<float>(), flags.data_ptr<float>(), gU.data_ptr<float>(),
+                                            gp.data_ptr<float>(), cur_stream(flags)));
+  return {gU, gp};
+}
+
 // geometry written into flags (all z planes), lib/fluid/geometry_utils.py:4-63
 void create_cylinder_(Tensor flags, double center_x, double center_y, double radius) {
   FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
@@ -610,6 +630,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("flags_to_occupancy", &flags_to_occupancy, NoGil());
   m.def("max_abs", &max_abs, NoGil());
   m.def("empty_domain_", &empty_domain_, py::arg("flags"), py::arg("boundary_width"), GEOM, NoGil());
+  m.def("velocity_divergence_backward", &velocity_divergence_backward, py::arg("grad_div"), py::arg("flags"), py::arg("is3D"), GEOM, NoGil());
+  m.def("velocity_update_backward", &velocity_update_backward, py::arg("grad_U_out"), py::arg("flags"), GEOM, NoGil());
   m.def("create_cylinder_", &create_cylinder_, NoGil());
   m.def("create_box2d_", &create_box2d_, NoGil());
   m.def("get_centered", &get_centered, NoGil());

@@ -573,6 +573,24 @@ int fnx_get_centered(const FnxGrid* g, const float* U, float* centered, void* st
   return FNX_OK;
 }
 
+int fnx_velocity_divergence_backward(const FnxGrid* g, const float* grad_div, const float* flags, float* grad_U, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!grad_div || !flags || !grad_U) return fail(FNX_EINVAL, "velocity_divergence_backward: NULL tensor");
+  fnx::launch_divergence_bwd(make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global), g->is3D, grad_div, flags, grad_U, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
+int fnx_velocity_update_backward(const FnxGrid* g, const float* grad_U_out, const float* flags, float* grad_U, float* grad_p,
+                                 void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!grad_U_out || !flags || !grad_U || !grad_p) return fail(FNX_EINVAL, "velocity_update_backward: NULL tensor");
+  if (grad_U == grad_U_out) return fail(FNX_EINVAL, "velocity_update_backward: grad_U must not alias grad_U_out (a cell reads its +1 neighbours)");
+  fnx::launch_velocity_update_bwd(make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global), g->is3D, grad_U_out, flags, grad_U, grad_p, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
                        const float* rho_adv, float* div, void* stream) {
   if (int rc = check_grid(g)) return rc;

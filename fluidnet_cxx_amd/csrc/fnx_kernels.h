@@ -55,6 +55,9 @@ void launch_empty_domain(const GridDims& g, bool is3d, float* flags, int bnd, hi
 void launch_create_cylinder(const GridDims& g, float* flags, float cx, float cy, float r2, hipStream_t s);
 void launch_create_box2d(const GridDims& g, float* flags, float x0, float x1, float y0, float y1, hipStream_t s);
 void launch_get_centered(const GridDims& g, bool is3d, const float* U, float* out, hipStream_t s);
+void launch_divergence_bwd(const GridDims& g, bool is3d, const float* gdiv, const float* flags, float* gU, hipStream_t s);
+void launch_velocity_update_bwd(const GridDims& g, bool is3d, const float* gout, const float* flags, float* gU, float* gp,
+                                hipStream_t s);
 
 // fused step stages (fnx_step.hip)
 void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const float* U_adv, const float* rho_adv,

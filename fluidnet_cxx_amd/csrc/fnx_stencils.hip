@@ -307,6 +307,79 @@ __global__ __launch_bounds__(BX* BY) void get_centered_kernel(GridDims g, const 
   r[(size_t)2 * g.DHW] = z;
 }
 
+// ---- adjoints of the linear stencil operators (the training graph differentiates through velocityUpdate -> setWallBcs ->
+// velocityDivergence: lib/model.py:190-227, fluid_net_train.py:366; the reference gets them from autograd over its ATen
+// chains).  setWallBcs zeroes a flag-dependent set of entries, so its adjoint is itself.
+
+// d(c) = A(c) [ sum_a u_a(c) - u_a(c + e_a) ],  A(c) = interior and not an obstacle (velocity_divergence.py:46-74)
+//   => dL/du_a(q) = A(q) g(q) - A(q - e_a) g(q - e_a)
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void divergence_bwd_kernel(GridDims g, const float* __restrict__ gdiv,
+                                                                const float* __restrict__ flags, float* __restrict__ gU) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  const float* gd = gdiv + (size_t)c.b * g.DHW + o;
+  float* out = gU + (size_t)c.b * NC * g.DHW + o;
+  auto active = [&](int i, int j, int k, const float* f) { return !is_border<IS3D>(g, i, j, k) && *f != FNX_OBST; };
+  const float own = active(c.i, c.j, c.k, fl) ? gd[0] : 0.f;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+    const int coord = a == 0 ? c.i : (a == 1 ? c.j : c.k);
+    float prev = 0.f;
+    if (coord >= 1 && active(c.i - (a == 0), c.j - (a == 1), c.k - (a == 2), fl - off)) prev = *(gd - off);
+    out[(size_t)a * g.DHW] = own - prev;
+  }
+}
+
+// velocityUpdate (velocity_update.py:47-149): on interior cells u_a <- m_ff (u_a - (p - p_-)) + m_fe (u_a - p) + m_ef (u_a + p_-)
+// (3D: the m_ff term only), border cells untouched.  With g = dL/du_out:
+//   dL/du_a(c) = border ? g_a(c) : (m_ff + m_fe + m_ef)_a(c) g_a(c)
+//   dL/dp(c)   = sum_a [ -(m_ff + m_fe)_a(c) g_a(c) ]_{c interior} + sum_a [ (m_ff + m_ef)_a(c + e_a) g_a(c + e_a) ]_{c + e_a interior}
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void velocity_update_bwd_kernel(GridDims g, const float* __restrict__ gout,
+                                                                     const float* __restrict__ flags,
+                                                                     float* __restrict__ gU, float* __restrict__ gp) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  constexpr int NC = IS3D ? 3 : 2;
+  const size_t o = (size_t)c.k * g.HW + c.j * g.W + c.i;
+  const float* fl = flags + (size_t)c.b * g.DHW + o;
+  const float* go = gout + (size_t)c.b * NC * g.DHW + o;
+  float* gu = gU + (size_t)c.b * NC * g.DHW + o;
+  const bool inner = !is_border<IS3D>(g, c.i, c.j, c.k);
+  const float fc = fl[0];
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+    const float ga = go[(size_t)a * g.DHW];
+    float gua = ga;
+    if (inner) {
+      const float fm = *(fl - off);
+      const bool ff = fc == FNX_FLUID && fm == FNX_FLUID;
+      const bool fe = !IS3D && fc == FNX_FLUID && fm == FNX_EMPTY, ef = !IS3D && fc == FNX_EMPTY && fm == FNX_FLUID;
+      gua = (ff | fe | ef) ? ga : 0.f;
+      if (ff | fe) acc = acc - ga;
+    }
+    gu[(size_t)a * g.DHW] = gua;
+  }
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+    const int ni = c.i + (a == 0), nj = c.j + (a == 1), nk = c.k + (a == 2);
+    if (ni < g.W && nj < g.H && nk < g.D && !is_border<IS3D>(g, ni, nj, nk)) {
+      const float fn = *(fl + off);                      // the neighbour's cell type; its -1 neighbour along a is this cell
+      const bool ff = fn == FNX_FLUID && fc == FNX_FLUID, ef = !IS3D && fn == FNX_EMPTY && fc == FNX_FLUID;
+      if (ff | ef) acc = acc + *(go + (size_t)a * g.DHW + off);
+    }
+  }
+  gp[(size_t)c.b * g.DHW + o] = acc;
+}
+
 inline int stream_blocks(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b < 2048 ? (b ? b : 1) : 2048);
@@ -403,6 +476,17 @@ void launch_create_box2d(const GridDims& g, float* flags, float x0, float x1, fl
 void launch_get_centered(const GridDims& g, bool is3d, const float* U, float* out, hipStream_t s) {
   if (is3d) get_centered_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, out);
   else get_centered_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, out);
+}
+
+void launch_divergence_bwd(const GridDims& g, bool is3d, const float* gdiv, const float* flags, float* gU, hipStream_t s) {
+  if (is3d) divergence_bwd_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, gdiv, flags, gU);
+  else divergence_bwd_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, gdiv, flags, gU);
+}
+
+void launch_velocity_update_bwd(const GridDims& g, bool is3d, const float* gout, const float* flags, float* gU, float* gp,
+                                hipStream_t s) {
+  if (is3d) velocity_update_bwd_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, gout, flags, gU, gp);
+  else velocity_update_bwd_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, gout, flags, gU, gp);
 }
 
 }  // namespace fnx

@@ -80,18 +80,77 @@ def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, 
     return p, res
 
 
+# ---- autograd: the reference's operators are chains of differentiable ATen ops, and its training graph goes through
+# velocityUpdate -> setWallBcs -> velocityDivergence (model.py:190-227, fluid_net_train.py:366).  Here each operator is one
+# native launch, so its adjoint is one too (fnx_velocity_divergence_backward, fnx_velocity_update_backward; setWallBcs is
+# its own adjoint).  The in-place operators stay in place (`mark_dirty`), like the reference's slice assignments.
+class _DivergenceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, flags, geom):
+        ctx.save_for_backward(flags)
+        ctx.geom, ctx.is3d = geom, U.size(1) == 3
+        return ext.velocity_divergence(U, flags, geom)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flags,) = ctx.saved_tensors
+        return ext.velocity_divergence_backward(g.contiguous(), flags, ctx.is3d, ctx.geom), None, None
+
+
+class _VelocityUpdateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pressure, U, flags, geom):
+        ctx.save_for_backward(flags)
+        ctx.geom = geom
+        ext.velocity_update_(pressure, U, flags, geom)
+        ctx.mark_dirty(U)
+        return U
+
+    @staticmethod
+    def backward(ctx, g):
+        (flags,) = ctx.saved_tensors
+        gU, gp = ext.velocity_update_backward(g.contiguous(), flags, ctx.geom)
+        return gp, gU, None, None
+
+
+class _SetWallBcsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, flags, geom):
+        ctx.save_for_backward(flags)
+        ctx.geom = geom
+        ext.set_wall_bcs_(U, flags, geom)
+        ctx.mark_dirty(U)
+        return U
+
+    @staticmethod
+    def backward(ctx, g):
+        (flags,) = ctx.saved_tensors
+        g = g.contiguous().clone()
+        ext.set_wall_bcs_(g, flags, ctx.geom)              # zeroing a flag-dependent set of entries is its own adjoint
+        return g, None, None
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
+
 def velocityDivergence(U, flags, *, geom=None):
-    """lib/fluid/velocity_divergence.py:4-74"""
+    """lib/fluid/velocity_divergence.py:4-74 (differentiable w.r.t. U)"""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
+    if _needs_grad(U):
+        return _DivergenceFn.apply(U, flags, geom)
     return ext.velocity_divergence(U, flags, geom)
 
 
 def velocityUpdate(pressure, U, flags, *, geom=None):
-    """lib/fluid/velocity_update.py:6-162 -- in place on U, returns None."""
+    """lib/fluid/velocity_update.py:6-162 -- in place on U, returns None (differentiable w.r.t. pressure and U)."""
     _check5(pressure, U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
     assert pressure.shape == flags.shape, "size mismatch"
+    if _needs_grad(pressure, U):
+        _VelocityUpdateFn.apply(pressure, U, flags, geom)
+        return
     ext.velocity_update_(pressure, U, flags, geom)
 
 
@@ -124,9 +183,11 @@ def addViscosity(dt, U, flags, viscosity):
 
 
 def setWallBcs(U, flags, *, geom=None):
-    """lib/fluid/set_wall_bcs.py:4-86 -- in place on U, returns U."""
+    """lib/fluid/set_wall_bcs.py:4-86 -- in place on U, returns U (differentiable w.r.t. U)."""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not a scalar"
+    if _needs_grad(U):
+        return _SetWallBcsFn.apply(U, flags, geom)
     ext.set_wall_bcs_(U, flags, geom)
     return U
 

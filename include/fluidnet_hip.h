@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 8
+#define FNX_ABI_VERSION 9
 
 enum {
   FNX_OK = 0,
@@ -230,6 +230,16 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
 int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
                        const float* rho_adv, float* div, void* stream);
 int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream);
+
+/* Adjoints of the linear stencil operators the training graph differentiates through (lib/model.py:190-227 and
+ * fluid_net_train.py:366: velocityUpdate -> setWallBcs -> velocityDivergence; the reference gets them from autograd over
+ * its ATen chains).  grad_* are (B,C,D,H,W) like the quantities they belong to; outputs are overwritten.
+ *   velocityDivergence: grad_U = J^T grad_div
+ *   velocityUpdate:     grad_U, grad_p from grad_U_out (the gradient w.r.t. the updated velocity); grad_U must not alias it
+ *   setWallBcs:         zeroes a flag-dependent set of entries, so its adjoint is fnx_set_wall_bcs applied to the gradient */
+int fnx_velocity_divergence_backward(const FnxGrid* g, const float* grad_div, const float* flags, float* grad_U, void* stream);
+int fnx_velocity_update_backward(const FnxGrid* g, const float* grad_U_out, const float* flags, float* grad_U, float* grad_p,
+                                 void* stream);
 
 /* ---- z-slab decomposition of the 3D Jacobi step over the GPUs of one node (the reference is single
  * device, plume.py:131-135).  Rank r owns D_global / nranks planes and keeps `halo` ghost planes towards each

@@ -842,3 +842,58 @@ int ora_get_centered(const OraGrid* g, const float* U, float* out) {
         }
   return 0;
 }
+
+/* Adjoints of velocityDivergence and velocityUpdate (what autograd computes over the reference's ATen chains,
+ * velocity_divergence.py:46-74 and velocity_update.py:47-149), per cell. */
+static int ora_active(const OraGrid* g, const float* flags, int b, int k, int j, int i) {
+  return !is_border(g, i, j, k, 1) && flags[IDX(g, 1, b, 0, k, j, i)] != T_OBST;
+}
+int ora_velocity_divergence_backward(const OraGrid* g, const float* gdiv, const float* flags, float* gU) {
+  const int nc = g->is3D ? 3 : 2;
+  for (int b = 0; b < g->B; ++b)
+    for (int k = 0; k < g->D; ++k)
+      for (int j = 0; j < g->H; ++j)
+        for (int i = 0; i < g->W; ++i) {
+          const float own = ora_active(g, flags, b, k, j, i) ? gdiv[IDX(g, 1, b, 0, k, j, i)] : 0.f;
+          for (int a = 0; a < nc; ++a) {
+            const int pi = i - (a == 0), pj = j - (a == 1), pk = k - (a == 2);
+            float prev = 0.f;
+            if (pi >= 0 && pj >= 0 && pk >= 0 && ora_active(g, flags, b, pk, pj, pi)) prev = gdiv[IDX(g, 1, b, 0, pk, pj, pi)];
+            gU[IDX(g, nc, b, a, k, j, i)] = own - prev;
+          }
+        }
+  return 0;
+}
+int ora_velocity_update_backward(const OraGrid* g, const float* gout, const float* flags, float* gU, float* gp) {
+  const int nc = g->is3D ? 3 : 2;
+  for (int b = 0; b < g->B; ++b)
+    for (int k = 0; k < g->D; ++k)
+      for (int j = 0; j < g->H; ++j)
+        for (int i = 0; i < g->W; ++i) {
+          const int inner = !is_border(g, i, j, k, 1);
+          const float fc = flags[IDX(g, 1, b, 0, k, j, i)];
+          float acc = 0.f;
+          for (int a = 0; a < nc; ++a) {
+            const float ga = gout[IDX(g, nc, b, a, k, j, i)];
+            float gua = ga;
+            if (inner) {
+              const float fm = flags[IDX(g, 1, b, 0, k - (a == 2), j - (a == 1), i - (a == 0))];
+              const int ff = fc == T_FLUID && fm == T_FLUID;
+              const int fe = !g->is3D && fc == T_FLUID && fm == T_EMPTY, ef = !g->is3D && fc == T_EMPTY && fm == T_FLUID;
+              gua = (ff || fe || ef) ? ga : 0.f;
+              if (ff || fe) acc = acc - ga;
+            }
+            gU[IDX(g, nc, b, a, k, j, i)] = gua;
+          }
+          for (int a = 0; a < nc; ++a) {
+            const int ni = i + (a == 0), nj = j + (a == 1), nk = k + (a == 2);
+            if (ni < g->W && nj < g->H && nk < g->D && !is_border(g, ni, nj, nk, 1)) {
+              const float fn = flags[IDX(g, 1, b, 0, nk, nj, ni)];
+              const int ff = fn == T_FLUID && fc == T_FLUID, ef = !g->is3D && fn == T_EMPTY && fc == T_FLUID;
+              if (ff || ef) acc = acc + gout[IDX(g, nc, b, a, nk, nj, ni)];
+            }
+          }
+          gp[IDX(g, 1, b, 0, k, j, i)] = acc;
+        }
+  return 0;
+}

@@ -219,6 +219,23 @@ def get_centered(U):
     return out
 
 
+def velocity_divergence_backward(gdiv, flags, is3d=None):
+    gd, pg = _f(gdiv); f, pf = _f(flags)
+    g = _grid(f, is3d)
+    out = np.empty((f.shape[0], 3 if g.is3D else 2) + f.shape[2:], np.float32)
+    lib().ora_velocity_divergence_backward(ctypes.byref(g), pg, pf, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def velocity_update_backward(gout, flags):
+    go, pg = _f(gout); f, pf = _f(flags)
+    g = _grid(f, go.shape[1] == 3)
+    gU = np.empty_like(go); gp = np.empty_like(f)
+    lib().ora_velocity_update_backward(ctypes.byref(g), pg, pf, gU.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       gp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return gU, gp
+
+
 def pack_weights(wdict, ndim=2):
     """Flatten a torch-named weight dict into the canonical blob (see cnn_oracle.c header)."""
     from fluidnet_cxx_amd.weights import scalenet_layers

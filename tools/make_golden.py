@@ -11,7 +11,7 @@ Runs only in the build container (needs /root/reference, no GPU).  It
   3. runs every hot-path operator on seeded inputs and stores inputs + outputs as .npz.
 
 The fixtures are data only (inputs and expected outputs).  Usage:
-    python tools/make_golden.py [--only ops2d,ops3d,plume,sim,cnn,gen,stick,grid,dump]
+    python tools/make_golden.py [--only ops2d,ops3d,plume,sim,cnn,gen,stick,grid,dump,grad]
 """
 import argparse
 import importlib.util
@@ -352,6 +352,35 @@ def gen_dump(torch, lib, ext):
     print("  wrote dump.npz")
 
 
+def gen_grad(torch, lib, ext):
+    """Gradients of the stencil operators the training graph differentiates through (model.py:190-227 and
+    fluid_net_train.py:366: velocityUpdate -> setWallBcs -> velocityDivergence), from the reference's own autograd:
+    loss = sum(w_div * div) + sum(w_U * U), d loss / d p and d loss / d U_in, 2D with obstacles and Empty cells."""
+    fluid = lib.fluid
+    out = {}
+    rng = np.random.default_rng(31)
+    for tag, (B, H, W, empties) in (("a", (2, 20, 33, False)), ("b", (1, 24, 40, True))):
+        flags = make_flags(rng, B, 1, H, W, boxes=True, empties=empties)
+        U0 = rng.standard_normal((B, 2, 1, H, W)).astype(np.float32)
+        p0 = rng.standard_normal((B, 1, 1, H, W)).astype(np.float32)
+        wd = rng.standard_normal((B, 1, 1, H, W)).astype(np.float32)
+        wu = rng.standard_normal((B, 2, 1, H, W)).astype(np.float32)
+        tf = t(flags, torch)
+        tU0 = t(U0, torch).requires_grad_(True)
+        tp = t(p0, torch).requires_grad_(True)
+        U = tU0 * 1.0                                   # (the operators work in place: not on a leaf)
+        fluid.velocityUpdate(pressure=tp, U=U, flags=tf)
+        U = fluid.setWallBcs(U, tf)
+        div = fluid.velocityDivergence(U.contiguous(), tf)
+        loss = (div * t(wd, torch)).sum() + (U * t(wu, torch)).sum()
+        loss.backward()
+        out.update({f"{tag}_flags": flags, f"{tag}_U": U0, f"{tag}_p": p0, f"{tag}_wd": wd, f"{tag}_wu": wu,
+                    f"{tag}_U_out": U.detach().numpy().copy(), f"{tag}_div": div.detach().numpy().copy(),
+                    f"{tag}_grad_U": tU0.grad.numpy().copy(), f"{tag}_grad_p": tp.grad.numpy().copy()})
+    np.savez_compressed(os.path.join(OUT, "grad.npz"), **out)
+    print("  wrote grad.npz")
+
+
 def stick_flags(flags):
     """flags_stick as cylinder.py:76 builds it: a copy of flags with the no-slip cells set to TypeStick (128).  Marked
     here: the obstacle box (thick), the single obstacle cell, the 1-cell bar (fluid on both sides) and a stretch of the
@@ -408,7 +437,7 @@ def gen_stick(torch, lib, ext):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="ops2d,ops3d,plume,sim,cnn,gen,stick,grid,dump")
+    ap.add_argument("--only", default="ops2d,ops3d,plume,sim,cnn,gen,stick,grid,dump,grad")
     a = ap.parse_args()
     only = set(a.only.split(","))
     os.makedirs(OUT, exist_ok=True)
@@ -436,6 +465,8 @@ def main():
         gen_grid(torch, lib, ext)
     if "dump" in only:
         gen_dump(torch, lib, ext)
+    if "grad" in only:
+        gen_grad(torch, lib, ext)
 
 
 if __name__ == "__main__":
