@@ -775,6 +775,12 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArg
 //    4 ds_write2) so that all threads carry the same share, with no per-lane selects.
 //  * the transformed weights a workgroup DMAs per stage are one contiguous 16*4*RW-float block (repack_wino3_kernel).
 // ---------------------------------------------------------------------------------------------------
+// Output stores carry the non-temporal hint (the next layer reads them after this launch is through; measured 2.345 ->
+// 2.312 ms per 1024^2 forward).  The same hint on the halo fetch (aux = 2) measured 4 % SLOWER.  Neither changes the
+// L2 picture (PMC: 10.8 M hits / 7.9 M misses per launch): the streamed activations flush an XCD's 4 MB L2 about once per
+// tile period, so about half of the transformed-weight reads miss it and are served by the Infinity Cache -- that, not
+// HBM, is the "traffic beyond the activations" FETCH_SIZE shows for these launches (it counts Infinity-Cache hits).
+#define W3_ST(p, v) do { const float2 v_ = (v); __builtin_nontemporal_store((f32x2){v_.x, v_.y}, (f32x2*)(p)); } while (0)
 constexpr int W3C = 4;                                 // input channels per stage of conv3_wino3_kernel
 inline int wino3_rw(int cout) { return cout % 64 == 0 ? 64 : 32; }   // its output channels per workgroup
 template <int NCG, int NPG, bool IS3D = false>
@@ -1090,8 +1096,8 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
             float* o0 = obase + (size_t)(8 * round + 2 * j) * vol;
             float* o1 = o0 + vol;
             if (full) {
-              *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)(o0 + a.W) = make_float2(v[2].x, v[3].x);
-              *(float2*)o1 = make_float2(v[0].y, v[1].y); *(float2*)(o1 + a.W) = make_float2(v[2].y, v[3].y);
+              W3_ST((float2*)o0, make_float2(v[0].x, v[1].x)); W3_ST((float2*)(o0 + a.W), make_float2(v[2].x, v[3].x));
+              W3_ST((float2*)o1, make_float2(v[0].y, v[1].y)); W3_ST((float2*)(o1 + a.W), make_float2(v[2].y, v[3].y));
             } else if (inx & iny) {
               if (inx1) {
                 *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)o1 = make_float2(v[0].y, v[1].y);
