@@ -27,6 +27,12 @@ State.  Every workload is first advanced by >= 100 untimed steps (`config.develo
 the Jacobi projection (a physical plume) and then timed with the CNN.  W more untimed warm-up steps follow the HIP-graph
 capture, then EXACTLY K timed steps between barrier + synchronize pairs, max over ranks.
 
+The slab workload is timed through BOTH z-slab drivers, one after the other on the same state: the Python one
+(fluidnet_cxx_amd/slab.py over torch.distributed P2P) and the C++ one (fnx_slab_step: launches and RCCL ncclSend/ncclRecv
+issued from C++; `native_driver`, under a watchdog).  They issue the same kernels and exchanges and produce the same bits
+(tests/test_slab.py).  At N = 1 the Python-driver time is the headline; at N > 1 the faster of the two is (`config.driver`
+says which) and the other is kept beside it (`python_driver` / `native_driver`).
+
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
   roofline.frac          SURVEY 8d model: algorithmic bytes (16 B/cell/sweep) / launch time / 8 TB/s.  The solvers run
                          several sweeps per pass over HBM, so this can exceed 1; it is the contract's figure, not a
@@ -500,6 +506,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["native_driver"] = dict(error=f"{type(e).__name__}: {e}")
         dog.cancel()
+        nd = out["native_driver"]
+        out["config"]["driver"] = "python (fluidnet_cxx_amd/slab.py over torch.distributed P2P)"
+        if world > 1 and "error" not in nd and nd.get("state_finite") and nd["ms_per_step"] < out["ms_per_step"]:
+            # N > 1: both drivers issue the same kernels and exchanges (same bits, tests/test_slab.py); the one whose K timed
+            # steps ran faster is the headline, the other is kept beside it
+            out["python_driver"] = dict(ms_per_step=out["ms_per_step"], value=out["value"], unit="Mcells/s", steps=out["steps"])
+            out["value"], out["ms_per_step"] = nd["value"], nd["ms_per_step"]
+            out["steps_per_s"] = 1e3 / nd["ms_per_step"]
+            out["step_hbm_frac"] = out["step_hbm_frac"] * out["python_driver"]["ms_per_step"] / nd["ms_per_step"]
+            out["config"]["driver"] = "native (fnx_slab_step: C++ driver, RCCL ncclSend/ncclRecv issued from C++)"
+            out["config"]["launch"] = nd["launch"]
     emit()
     if world > 1:
         dist.barrier()
