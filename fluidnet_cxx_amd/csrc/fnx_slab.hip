@@ -14,6 +14,7 @@
 // Every owned cell goes through the arithmetic of the single-domain step: same bits (tests/test_slab.py).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <string.h>
 
 #include <condition_variable>
@@ -57,7 +58,7 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
-constexpr int kNcclInt8 = 0, kNcclFloat32 = 7, kNcclMax = 2;      // ncclDataType_t / ncclRedOp_t values of nccl.h
+constexpr int kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0, kNcclMax = 2;      // ncclDataType_t / ncclRedOp_t values of nccl.h
 
 int rccl_api(RcclApi** out) {
   static RcclApi api;
@@ -117,6 +118,11 @@ int rccl_allreduce_max(void* vctx, float* x, int n, void* stream) {
   NCCL_OK(c, c->api->AllReduce(x, x, (size_t)n, kNcclFloat32, kNcclMax, c->comm, (hipStream_t)stream));
   return FNX_OK;
 }
+int rccl_allreduce_sum(void* vctx, float* x, int n, void* stream) {
+  RcclCtx* c = (RcclCtx*)vctx;
+  NCCL_OK(c, c->api->AllReduce(x, x, (size_t)n, kNcclFloat32, kNcclSum, c->comm, (hipStream_t)stream));
+  return FNX_OK;
+}
 void rccl_destroy(void* vctx) {
   RcclCtx* c = (RcclCtx*)vctx;
   if (c->comm) c->api->CommDestroy(c->comm);
@@ -142,7 +148,7 @@ struct LoopGroup {
   int nranks;
   std::vector<LoopPair> pairs;   // pair i: ranks i, i+1
   std::mutex mu; std::condition_variable cv;
-  int red_count = 0, red_gen = 0; float red_val[64]; int red_n = 0;
+  int red_count = 0, red_gen = 0; float red_val[64], red_out[64]; int red_n = 0;   // (red_out: a finished round's result, safe from the next round's first arrival)
   explicit LoopGroup(int n) : nranks(n), pairs(n > 1 ? n - 1 : 0) {}
 };
 struct LoopCtx { LoopGroup* g; int rank; };
@@ -194,7 +200,7 @@ int loop_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
   if (c->rank < c->g->nranks - 1) SLAB_OK(loop_meet(c->g, c->rank, true, segs, nsegs, (hipStream_t)stream));
   return FNX_OK;
 }
-int loop_allreduce_max(void* vctx, float* x, int n, void* stream) {
+int loop_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
   LoopCtx* c = (LoopCtx*)vctx;
   LoopGroup* g = c->g;
   if (n > 64) return fnx::set_error(FNX_EINVAL, "loopback allreduce: n > 64");
@@ -205,15 +211,17 @@ int loop_allreduce_max(void* vctx, float* x, int n, void* stream) {
     std::unique_lock<std::mutex> lk(g->mu);
     const int gen = g->red_gen;
     if (g->red_count == 0) { g->red_n = n; for (int i = 0; i < n; ++i) g->red_val[i] = h[i]; }
-    else for (int i = 0; i < n; ++i) g->red_val[i] = h[i] > g->red_val[i] ? h[i] : g->red_val[i];
-    if (++g->red_count == g->nranks) { g->red_count = 0; ++g->red_gen; g->cv.notify_all(); }
+    else for (int i = 0; i < n; ++i) g->red_val[i] = sum ? g->red_val[i] + h[i] : (h[i] > g->red_val[i] ? h[i] : g->red_val[i]);
+    if (++g->red_count == g->nranks) { g->red_count = 0; for (int i = 0; i < n; ++i) g->red_out[i] = g->red_val[i]; ++g->red_gen; g->cv.notify_all(); }
     else g->cv.wait(lk, [&] { return g->red_gen != gen; });
-    for (int i = 0; i < n; ++i) h[i] = g->red_val[i];
+    for (int i = 0; i < n; ++i) h[i] = g->red_out[i];
   }
   SLAB_HIP(hipMemcpyAsync(x, h, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   SLAB_HIP(hipStreamSynchronize((hipStream_t)stream));
   return FNX_OK;
 }
+int loop_allreduce_max(void* vctx, float* x, int n, void* stream) { return loop_allreduce(vctx, x, n, stream, false); }
+int loop_allreduce_sum(void* vctx, float* x, int n, void* stream) { return loop_allreduce(vctx, x, n, stream, true); }
 void loop_destroy(void* vctx) { delete (LoopCtx*)vctx; }
 
 }  // namespace
@@ -345,7 +353,7 @@ int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* uniqu
   memcpy(&id, unique_id128, sizeof(id));
   const int r = api->CommInitRank(&c->comm, nranks, id, rank);
   if (r != 0) { delete c; return fnx::set_error(FNX_ECOMM, "ncclCommInitRank failed (%d: %s)", r, api->GetErrorString ? api->GetErrorString(r) : "?"); }
-  out->ctx = c; out->exchange = rccl_exchange; out->allreduce_max = rccl_allreduce_max; out->destroy = rccl_destroy;
+  out->ctx = c; out->exchange = rccl_exchange; out->allreduce_max = rccl_allreduce_max; out->allreduce_sum = rccl_allreduce_sum; out->destroy = rccl_destroy;
   return FNX_OK;
 }
 
@@ -357,7 +365,7 @@ int fnx_slab_loopback_group(void** group, int nranks) {
 int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank) {
   LoopGroup* g = (LoopGroup*)group;
   if (!out || !g || rank < 0 || rank >= g->nranks) return fnx::set_error(FNX_EINVAL, "loopback comm: bad arguments");
-  out->ctx = new LoopCtx{g, rank}; out->exchange = loop_exchange; out->allreduce_max = loop_allreduce_max; out->destroy = loop_destroy;
+  out->ctx = new LoopCtx{g, rank}; out->exchange = loop_exchange; out->allreduce_max = loop_allreduce_max; out->allreduce_sum = loop_allreduce_sum; out->destroy = loop_destroy;
   return FNX_OK;
 }
 void fnx_slab_loopback_group_free(void* group) {
@@ -368,7 +376,7 @@ void fnx_slab_loopback_group_free(void* group) {
 }
 void fnx_slab_comm_free(FnxSlabComm* comm) {
   if (comm && comm->destroy && comm->ctx) comm->destroy(comm->ctx);
-  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->destroy = nullptr; }
+  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->allreduce_sum = nullptr; comm->destroy = nullptr; }
 }
 
 int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset) {
@@ -399,7 +407,7 @@ int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* 
   s->w = cfg->sweeps_per_exchange < cfg->halo ? cfg->sweeps_per_exchange : cfg->halo;
   if (s->w < 1) s->w = 1;
   if (cfg->nranks > 1) {
-    if (!comm || !comm->exchange || !comm->allreduce_max) { delete s; return fnx::set_error(FNX_EINVAL, "slab_create: nranks > 1 needs a communicator"); }
+    if (!comm || !comm->exchange || !comm->allreduce_max || !comm->allreduce_sum) { delete s; return fnx::set_error(FNX_EINVAL, "slab_create: nranks > 1 needs a communicator"); }
     if (s->owned < 2 * s->w) { delete s; return fnx::set_error(FNX_EINVAL, "slab too thin for the sweep block"); }
     s->comm = *comm;
     if (hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -411,7 +419,7 @@ int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* 
   } else {
     s->comm = FnxSlabComm{};
   }
-  if (cfg->cfl_check_every > 0 && hipHostMalloc((void**)&s->h_cfl, sizeof(float)) != hipSuccess) {
+  if (hipHostMalloc((void**)&s->h_cfl, 64 * sizeof(float)) != hipSuccess) {     // CFL number / per-sample residuals
     fnx_slab_destroy(s);
     return fnx::set_error(FNX_EHIP, "slab_create: pinned host allocation failed");
   }
@@ -432,7 +440,7 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
   if (!s || !prm || !st) return fnx::set_error(FNX_EINVAL, "slab_step: NULL argument");
   if (!st->p || !st->U || !st->flags || !st->density) return fnx::set_error(FNX_EINVAL, "slab_step: the z-slab driver needs p, U, flags and a density field");
   if (prm->method != 0) return fnx::set_error(FNX_EINVAL, "slab_step: only the Jacobi projection shards (the CNN configurations are single-GPU)");
-  if (prm->p_tol > 0.f) return fnx::set_error(FNX_EINVAL, "slab_step: pTol > 0 needs the host-driven per-sweep test (fluidnet_cxx_amd/slab.py)");
+  if (prm->p_tol > 0.f && s->cfg.B > 63) return fnx::set_error(FNX_EINVAL, "slab_step: pTol > 0 supports up to 63 samples");
   if (prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
   Work W;
   if (!ws || carve(s, ws, &W) > ws_bytes) return fnx::set_error(FNX_EWORKSPACE, "slab_step: workspace too small (%zu < %zu)", ws_bytes, carve(s, nullptr, nullptr));
@@ -508,7 +516,31 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
   float *cur = st->p, *nxt = W.pbuf;
   int remaining = prm->jacobi_iter;
   bool zero_in = true;                       // the solve starts from p = 0 everywhere: the first pass reads nothing
-  if (world > 1 && s->owned >= 4 * w && remaining > w) {
+  if (prm->p_tol > 0.f) {
+    // the reference's convergence test (fluids_init.cpp:961-979; slab.py:_jacobi_ptol): one sweep per ghost exchange, the
+    // squared differences over the OWNED planes summed over the ranks, max over the samples of the root against pTol
+    const size_t plane = (size_t)s->cfg.H * s->cfg.W, vol = plane * DL;
+    SLAB_HIP(hipMemsetAsync(cur, 0, (size_t)s->cfg.B * vol * 4, stream));
+    const int a = has_lo ? lo : 0, b = has_hi ? top : DL;
+    for (int it = 0; it < prm->jacobi_iter; ++it) {
+      float* fc[1] = {cur};
+      if (it > 0) SLAB_OK(xchg(s, fc, c1, 1, 1, stream));
+      SLAB_OK(pass(cur, nxt, 1, a, b));
+      SLAB_HIP(hipMemsetAsync(W.cfl, 0, 64 * sizeof(float), stream));
+      for (int bb = 0; bb < s->cfg.B; ++bb) {
+        GridDims gd = make_dims(1, s->owned, s->cfg.H, s->cfg.W);
+        fnx::launch_residual(gd, nxt + (size_t)bb * vol + (size_t)lo * plane, cur + (size_t)bb * vol + (size_t)lo * plane, W.cfl + bb,
+                             W.cfl + 63, stream);                                   // (W.cfl[63]: this sample's root, unused)
+      }
+      if (world > 1) SLAB_OK(s->comm.allreduce_sum(s->comm.ctx, W.cfl, s->cfg.B, stream));
+      SLAB_HIP(hipMemcpyAsync(s->h_cfl, W.cfl, s->cfg.B * sizeof(float), hipMemcpyDeviceToHost, stream));
+      SLAB_HIP(hipStreamSynchronize(stream));
+      float worst = 0.f;
+      for (int bb = 0; bb < s->cfg.B; ++bb) { const float r = sqrtf(s->h_cfl[bb]); if (r > worst) worst = r; }
+      float* t = cur; cur = nxt; nxt = t;
+      if (worst < prm->p_tol) break;
+    }
+  } else if (world > 1 && s->owned >= 4 * w && remaining > w) {
     // "edge_first" (slab.py:_jacobi_edge_first)
     int npass = 0, passes[64];
     if (w % 2) passes[npass++] = 1;

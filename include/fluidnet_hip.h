@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 9
+#define FNX_ABI_VERSION 10
 
 enum {
   FNX_OK = 0,
@@ -257,8 +257,9 @@ typedef struct FnxSlabComm {
   void* ctx;
   /* Stream-ordered exchange of all segments with both neighbours (RCCL: one ncclGroupStart/Send/Recv/GroupEnd). */
   int (*exchange)(void* ctx, const FnxSlabSeg* segs, int nsegs, void* stream);
-  /* In-place max over all ranks of n DEVICE floats (CFL guard; control path only). */
+  /* In-place max / sum over all ranks of n DEVICE floats (CFL guard, pTol residual; control path only). */
   int (*allreduce_max)(void* ctx, float* x, int n, void* stream);
+  int (*allreduce_sum)(void* ctx, float* x, int n, void* stream);
   void (*destroy)(void* ctx);
 } FnxSlabComm;
 /* RCCL communicator (librccl is loaded on first use; no link-time dependency).  unique_id: the 128 bytes of
@@ -289,7 +290,8 @@ size_t fnx_slab_workspace_bytes(const FnxSlabConfig* cfg);
 int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* comm);
 void fnx_slab_destroy(FnxSlab* s);
 /* One time step.  st: the rank's local arrays (with ghost planes), st->density required, st->net unused; prm->method
- * must be 0 and prm->p_tol 0 (the per-sweep convergence test is host-driven: fluidnet_cxx_amd/slab.py has it);
+ * must be 0.  prm->p_tol > 0 runs the reference's convergence test (fluids_init.cpp:961-979): one sweep per ghost exchange,
+ * the squared differences over the owned planes all-reduced over the ranks, one host sync per sweep (as in fnx_jacobi);
  * prm->static_flags is ignored (FnxSlabConfig.static_flags).  ws: fnx_slab_workspace_bytes, kept between steps. */
 int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* stream);
 
