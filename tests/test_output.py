@@ -107,3 +107,31 @@ def test_vtk_cell_data_vs_reference(tmp_path, golden):
     for k in ("gradPx", "gradRhoy", "ux"):
         assert np.array_equal(np.nan_to_num(c3[k][:, :, 1]), np.nan_to_num(cells[k][:, :, 0])), k
     assert not np.nan_to_num(c3["gradPz"]).any()
+
+
+@pytest.mark.gpu
+def test_reference_shaped_driver_runs_and_restarts(tmp_path):
+    """examples/plume.py (the reference driver's loop on this backend): runs, writes the YAML echo, PNG, VTK and restart
+    files of every output event, and a run continued from its restart file ends in the bits of an uninterrupted one."""
+    import importlib.util
+    import os
+    import torch
+    import yaml
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("plume_example", os.path.join(repo, "examples", "plume.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    fa, fb = str(tmp_path / "a"), str(tmp_path / "b")
+    full, it = mod.main(["--res", "64", "--iters", "12", "--out-iter", "5", "--folder", fa])
+    assert it == 12
+    for name in ("plumeConfig.yaml", "output_00000.png", "output_00005.vtr", "output_00010.png", "output_00010.vtr", "restart.pth"):
+        assert os.path.isfile(os.path.join(fa, name)), name
+    assert yaml.safe_load(open(os.path.join(fa, "plumeConfig.yaml")))["jacobiIter"] == 28
+    # the restart file holds the state AFTER iteration 10; continue a copy of it to the end
+    os.makedirs(fb)
+    import shutil
+    shutil.copy(os.path.join(fa, "restart.pth"), os.path.join(fb, "restart.pth"))
+    # (the driver's loop re-runs the saved iteration number: plume.py increments `it` after saving, like the reference)
+    cont, it2 = mod.main(["--res", "64", "--iters", "11", "--out-iter", "50", "--folder", fb, "--restart"])
+    assert it2 == 11
+    for k in ("p", "U", "density"):
+        assert torch.equal(cont[k], full[k]), k
