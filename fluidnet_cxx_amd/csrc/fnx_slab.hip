@@ -445,6 +445,7 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
   Work W;
   if (!ws || carve(s, ws, &W) > ws_bytes) return fnx::set_error(FNX_EWORKSPACE, "slab_step: workspace too small (%zu < %zu)", ws_bytes, carve(s, nullptr, nullptr));
   hipStream_t stream = (hipStream_t)vstream;
+  s->pending = false;                        // (a step that failed half-way must not block the next one)
   const int world = s->cfg.nranks, rank = s->cfg.rank, w = s->w;
   const int lo = s->lo, top = s->lo + s->owned, DL = s->D_local;
   const bool has_lo = rank > 0, has_hi = rank < world - 1;
