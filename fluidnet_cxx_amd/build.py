@@ -95,9 +95,25 @@ def build_ext(force=False, verbose=False):
     return EXT
 
 
+def build_examples(force=False, verbose=False):
+    """examples/cabi_plume.bin: a C++ host on the C ABI alone (no torch); run by tests/test_abi.py on the GPU box."""
+    repo = os.path.dirname(HERE)
+    src = os.path.join(repo, "examples", "cabi_plume.cpp")
+    out = os.path.join(repo, "examples", "cabi_plume.bin")
+    if not os.path.exists(src) or not (force or _newer(out, [src, LIB, os.path.join(repo, "include", "fluidnet_hip.h")])):
+        return out
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-I", os.path.join(repo, "include"), src, "-L", HERE, "-lfluidnet_hip",
+           "-Wl,-rpath,$ORIGIN/../fluidnet_cxx_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
     build_lib(force, verbose)
     build_ext(force, verbose)
+    build_examples(force, verbose)
 
 
 if __name__ == "__main__":

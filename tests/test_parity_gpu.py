@@ -871,3 +871,32 @@ def test_profile_hooks(fl, ext, dev):
     ms, n = ext.profile_read(0)
     ext.profile_enable(False)
     assert n == 2 and 0 < ms < 50, (ms, n)        # 12 sweeps = launches of 7 + 5 on a small grid (workgroup tiles)
+
+
+def test_standalone_cpp_host_on_the_c_abi(dev):
+    """examples/cabi_plume.cpp: a C++ program with nothing but the HIP runtime and include/fluidnet_hip.h (no torch in its
+    process) runs 20 steps of the 128^2 plume through fnx_simulate_step; its field hashes equal the Python path's."""
+    import os
+    import subprocess
+    from fluidnet_cxx_amd import fluid, simulate
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "examples", "cabi_plume.bin")
+    assert os.path.isfile(exe), "examples/cabi_plume.bin is built by __graft_entry__.build()"
+    out = subprocess.run([exe, "20", "128"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = dict(l.split() for l in out.stdout.splitlines()[:3])
+
+    def fnv1a(a):
+        h = 1469598103934665603
+        for byte in a.tobytes():
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
+    res = 128
+    bd = dict(p=torch.zeros(1, 1, 1, res, res, device=dev), U=torch.zeros(1, 2, 1, res, res, device=dev),
+              flags=torch.zeros(1, 1, 1, res, res, device=dev), density=torch.zeros(1, 1, 1, res, res, device=dev))
+    fluid.emptyDomain(bd["flags"]); fluid.createPlumeBCs(bd, 0.1, 2, 0.145)
+    for _ in range(20):
+        simulate(PLUME_CFG, bd, None, "jacobi")
+    for k in ("U", "density", "p"):
+        assert got[k] == fnv1a(N(bd[k])), k
