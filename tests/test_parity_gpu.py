@@ -881,7 +881,10 @@ def test_standalone_cpp_host_on_the_c_abi(dev):
     from fluidnet_cxx_amd import fluid, simulate
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(repo, "examples", "cabi_plume.bin")
-    assert os.path.isfile(exe), "examples/cabi_plume.bin is built by __graft_entry__.build()"
+    if not os.path.isfile(exe):                     # normally built by __graft_entry__.build(); hipcc is on the GPU box too
+        from fluidnet_cxx_amd import build
+        build.build_examples()
+    assert os.path.isfile(exe), "examples/cabi_plume.bin missing and could not be built"
     out = subprocess.run([exe, "20", "128"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     got = dict(l.split() for l in out.stdout.splitlines()[:3])
