@@ -81,8 +81,8 @@ __device__ __forceinline__ void jacobi_rows(float (&p)[V], const float (&d)[V], 
   for (int n = 0; n < N; ++n) sum[n] = sum[n] + dn[n];
 #pragma unroll
   for (int n = 0; n < N; ++n) sum[n] = sum[n] + un[n];
-#pragma unroll
-  for (int n = 0; n < N; ++n) sum[n] = sum[n] + 0.f;
+  // the reference adds the two missing z neighbours as zeros: ((s + 0) + 0) == (s + 0) for every s (the first addition
+  // already turns a -0 into +0, NaN and inf pass through), so ONE addition reproduces the bits of both
 #pragma unroll
   for (int n = 0; n < N; ++n) sum[n] = sum[n] + 0.f;
 #pragma unroll
