@@ -61,6 +61,17 @@ __global__ __launch_bounds__(256) void rd(const float* __restrict__ p, float* __
       }
     } else if (MODE == 5) {      // dword gather: lane <-> x shifted by a per-lane 0/1 (interpolation-corner pattern)
       for (int q = 0; q < N_FLOATS / 64 - 2; ++q) { const int r = (q + wave * 97) % (N_FLOATS / 64 - 2); acc += p[r * 64 + lane + ((lane * 7 + r) & 1)]; }
+    } else if (MODE == 8) {      // dword per lane at a 16-B lane stride (one component of a float4 row: 256 B useful out of 1 KiB of lines)
+      for (int q2 = 0; q2 < N_FLOATS / 256 - 1; ++q2) { const int r = (q2 + wave * 97) % (N_FLOATS / 256 - 1); acc += p[(r * 64 + lane) * 4 + 3 + shift * 4]; }
+    } else if (MODE == 9) {      // dwordx2 per lane at a 16-B lane stride (half of a float4 row)
+      const float2* q = (const float2*)(p + shift * 4);
+      for (int q2 = 0; q2 < N_FLOATS / 256 - 1; ++q2) { const int r = (q2 + wave * 97) % (N_FLOATS / 256 - 1); float2 v = q[(r * 64 + lane) * 2 + 1]; acc += v.x + v.y; }
+    } else if (MODE == 10) {     // dword row stores
+      float* o2 = const_cast<float*>(p);
+      for (int q = 0; q < N_FLOATS / 64 - 1; ++q) { const int r = (q + wave * 97) % (N_FLOATS / 64 - 1); o2[r * 64 + lane + shift] = (float)q; }
+    } else if (MODE == 11) {     // dwordx4 stores
+      float4* o2 = (float4*)const_cast<float*>(p) + shift;
+      for (int q2 = 0; q2 < N_FLOATS / 256 - 1; ++q2) { const int r = (q2 + wave * 97) % (N_FLOATS / 256 - 1); o2[r * 64 + lane] = make_float4((float)q2, 1.f, 2.f, 3.f); }
     } else if (MODE == 6) {      // ubyte per lane (mask rows)
       const unsigned char* q = (const unsigned char*)p;
       for (int q2 = 0; q2 < N_FLOATS / 64 - 1; ++q2) { const int r = (q2 + wave * 97) % (N_FLOATS / 64 - 1); acc += (float)q[r * 64 + lane]; }
@@ -74,7 +85,7 @@ void run(const char* name, const float* d, float* o, int cus, double bytes_per_p
   const int iters = 4;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int shift = 0; shift < 2; ++shift) {
-    if (shift && MODE >= 5) break;
+    if (shift && MODE >= 5 && MODE < 8) break;
     rd<MODE><<<cus * 4, 256>>>(d, o, 2, shift);
     hipEventRecord(a);
     rd<MODE><<<cus * 4, 256>>>(d, o, iters, shift);
@@ -98,5 +109,9 @@ int main() {
   run<7>("global_load_lds_dwordx4 4 rows, 2 in flight", d, o, cus, full);
   run<5>("dword gather (+0/+1 per lane)", d, o, cus, full);
   run<6>("ubyte / lane (64 B per instr)", d, o, cus, full / 4);
+  run<8>("dword / lane, 16-B lane stride (useful bytes)", d, o, cus, full / 4);
+  run<9>("dwordx2 / lane, 16-B lane stride (useful bytes)", d, o, cus, full / 2);
+  run<10>("dword row stores", d, o, cus, full);
+  run<11>("dwordx4 stores", d, o, cus, full);
   return 0;
 }
