@@ -515,13 +515,17 @@ __device__ __forceinline__ float div6_tiny(float x) {
   return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r, zh, q1, vcc), 6.0f, x);
 }
 
-template <bool FREE>
+// SEL: 0 = no cell of the wave's rows has an obstacle neighbour, 1 = x neighbours only (every tile at an x wall of an
+// otherwise empty domain), 2 = any
+template <int SEL>
 __device__ __forceinline__ float relax3(unsigned m, float c, float xl, float xr, float yd, float yu, float zb,
                                         float zf, float dv, float& num) {
   const int mi = (int)m;
-  if (!FREE) {                                          // Neumann: an obstacle neighbour is replaced by the centre
+  if (SEL >= 1) {                                       // Neumann: an obstacle neighbour is replaced by the centre
     xl = bfi_blend(__builtin_amdgcn_sbfe(mi, 1, 1), c, xl);
     xr = bfi_blend(__builtin_amdgcn_sbfe(mi, 2, 1), c, xr);
+  }
+  if (SEL >= 2) {
     yd = bfi_blend(__builtin_amdgcn_sbfe(mi, 3, 1), c, yd);
     yu = bfi_blend(__builtin_amdgcn_sbfe(mi, 4, 1), c, yu);
     zb = bfi_blend(__builtin_amdgcn_sbfe(mi, 5, 1), c, zb);
@@ -647,26 +651,33 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   }
   float local = 0.f;
   const bool lane_out = (lane >= 2) & (lane <= 61) & xin;
-  bool prev_free = false;
+  int prev_sel = 2;
 
   // one sweep over N rows: centre rows C[0..N), y-neighbours from the same plane, z-neighbours B / F
-  auto sweep = [&](auto nn, bool free, const unsigned* M, const float* Cm1, const float* B, const float* F,
+  auto sweep = [&](auto nn, int sel, const unsigned* M, const float* Cm1, const float* B, const float* F,
                    const float* DV, float* out) __attribute__((always_inline)) {
     constexpr int N = decltype(nn)::value;
     float xs[N];
     bool bad = false;
-    if (free) {
+    if (sel == 0) {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<true>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<0>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        bad |= __builtin_amdgcn_classf(out[r], 0x90);
+      }
+    } else if (sel == 1) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float c = Cm1[r + 1];
+        out[r] = relax3<1>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<false>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<2>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     }
@@ -693,12 +704,13 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     unsigned ob = AM[SC][0];
 #pragma unroll
     for (int rr = 1; rr < R1; ++rr) ob |= AM[SC][rr];
-    const bool free1 = __builtin_amdgcn_ballot_w64((ob & 0x7eu) != 0) == 0;     // no cell of these rows has an obstacle neighbour
-    sweep(IC<R1>{}, free1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
+    // no cell of these rows has an obstacle neighbour (0) / only x neighbours (1) / any (2)
+    const int sel1 = __builtin_amdgcn_ballot_w64((ob & 0x78u) != 0) != 0 ? 2 : (__builtin_amdgcn_ballot_w64((ob & 0x06u) != 0) != 0 ? 1 : 0);
+    sweep(IC<R1>{}, sel1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
     // ---- sweep 2 on plane t-1, rows j0 .. j0+3 (p^1 of planes t-2, t-1, t = slots SN, SM, SC)
     if (t - 1 >= k_lo) {
       float v[Z2R];
-      sweep(IC<Z2R>{}, prev_free, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
+      sweep(IC<Z2R>{}, prev_sel, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
       const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
@@ -708,7 +720,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
         }
       }
     }
-    prev_free = free1;
+    prev_sel = sel1;
   };
 
   while (true) {
@@ -909,14 +921,14 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_dma_kernel(G
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<true>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<0>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<false>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<2>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     }
