@@ -298,11 +298,11 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
   else reuse_mask = false;
   const bool q = quirks(g);
   if (g->is3D && !reuse_mask) fnx::launch_jacobi3d_mask(d, q, flags, mask, s);
-  auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss) {
+  auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss, int lay = 0) {
     fnx::ProfScope ps(FNX_PROF_JACOBI, s);
     if (g->is3D) {
       if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, ss, s, 0, 0, from_zero);
-      else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, ss, s, 0, 0, from_zero);
+      else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, ss, s, 0, 0, from_zero, -1, lay);
       else fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
     } else {
       fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
@@ -323,11 +323,16 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
     if (residual) HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
     const float* in = nullptr;
     int done = 0;
+    // 3D: consecutive two-sweep passes hand each other p in the row-quad layout (fewer, wider vector-memory
+    // instructions: launch_jacobi3d_x2); the last launch of the solve writes rows
+    const bool quad = g->is3D && kmax == 2 && fnx::jacobi3d_quad_ok(d);
+    bool in_quad = false;
     for (int l = 0; l < nl; ++l) {
       float* out = ((nl - 1 - l) % 2 == 0) ? p : tmp;      // the last launch writes p
       const bool last = l == nl - 1;
-      sweep(in, out, plan[l], l == 0, (last && residual) ? sumsq : nullptr);
-      in = out;
+      const bool out_quad = quad && plan[l] == 2 && !last && plan[l + 1] == 2;
+      sweep(in, out, plan[l], l == 0, (last && residual) ? sumsq : nullptr, (in_quad ? 1 : 0) | (out_quad ? 2 : 0));
+      in = out; in_quad = out_quad;
       done += plan[l];
     }
     if (residual) fnx::launch_residual_finish(g->B, sumsq, residual, s);
@@ -380,14 +385,19 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
   const float* in = p;
   int done = 0;
+  const bool quad = g->is3D && kmax == 2 && fnx::jacobi3d_quad_ok(d);      // see jacobi_solve
+  bool in_quad = false;
   for (int l = 0; done < nsweeps; ++l) {
     int k = nsweeps - done < kmax ? nsweeps - done : kmax;
     if (g->is3D && kmax == 3 && nsweeps - done == 4) k = 2;
     float* out = (l % 2 == 0) ? tmp : p;
+    const bool out_quad = quad && k == 2 && nsweeps - done - k >= 2;        // the launch after this one is a two-sweep pass too
+    const int lay = (in_quad ? 1 : 0) | (out_quad ? 2 : 0);
+    in_quad = out_quad;
     { fnx::ProfScope ps(FNX_PROF_JACOBI, s);
       if (g->is3D) {
         if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, nullptr, s);
-        else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s);
+        else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s, 0, 0, false, -1, lay);
         else fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
       } else {
         fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s);

@@ -548,7 +548,13 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 }
 
 // ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
-template <bool RES, bool ZERO, bool SPLIT>
+// LAY: bit 0 = p_in, bit 1 = p_out is in the ROW-QUAD layout p[b][k][j/4][i][j%4] (H % 4 == 0) instead of p[b][k][j][i].
+// The pass is bound by the CU's vector-memory pipeline, whose cost is per instruction: in the quad layout a
+// wave's own four rows of a column are one 16-byte access and the two halo rows on either side one 8-byte access each, so a
+// step reads p^0 with 3 instructions instead of 8 and writes its four finished rows with 1 instead of 4.  A plane is the same
+// H*W floats in both layouts (ghost-plane exchanges do not care); the passes of a solve hand the quad layout to each other
+// and only the last one writes rows.
+template <bool RES, bool ZERO, bool SPLIT, int LAY>
 __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
@@ -626,6 +632,31 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
   };
   auto ldp = [&](unsigned cell) { return ZERO ? 0.f : ldf(r_p, cell); };
+  // quad layout: 16 B per column; the row groups below / of / above the tile (clamped into the grid: a clamped group stands
+  // for rows outside the grid, whose mask bytes -- read through rowb[] -- are those of a border row, i.e. 0)
+  static_assert(LAY == 0 || (Z2R == 4 && Z2NW == 1), "the quad layout holds the four rows of a tile");
+  const int Hq = g.H >> 2;
+  const unsigned xoff4 = (unsigned)xc * 16u;
+  const unsigned gq_c = (unsigned)(by * 4 * g.W), gq_m = (unsigned)((by > 0 ? by - 1 : 0) * 4 * g.W),
+                 gq_p = (unsigned)((by + 1 < Hq ? by + 1 : Hq - 1) * 4 * g.W);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // the 8 rows j0-2 .. j0+5 of plane offset `po` into dst[0..8)
+  auto load_p0 = [&](float* dst, unsigned po) __attribute__((always_inline)) {
+    if (ZERO) {
+#pragma unroll
+      for (int rr = 0; rr < R0; ++rr) dst[rr] = 0.f;
+    } else if (LAY & 1) {
+      const f32x2v lo = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r_p, xoff4 + 8u, (po + gq_m) * 4u, 0));
+      const f32x4 mid = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_p, xoff4, (po + gq_c) * 4u, 0));
+      const f32x2v hi = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r_p, xoff4, (po + gq_p) * 4u, 0));
+      dst[0] = lo.x; dst[1] = lo.y; dst[2] = mid.x; dst[3] = mid.y; dst[4] = mid.z; dst[5] = mid.w; dst[6] = hi.x; dst[7] = hi.y;
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < R0; ++rr) dst[rr] = ldp(po + rowb[rr]);
+    }
+  };
   auto ldm = [&](unsigned cell) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, (unsigned)xc, cell, 0); };
 
   float P0[4][R0];                                       // p^0 plane ring: slot (t+d)&3 for planes t-1..t+2
@@ -642,10 +673,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   // prologue: planes t-1, t, t+1 of p^0 (slots 3, 0, 1) and the aux data of plane t (slot 0), all rows from memory
   {
     const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
-#pragma unroll
-    for (int rr = 0; rr < R0; ++rr) {
-      P0[3][rr] = ldp(pm + rowb[rr]); P0[0][rr] = ldp(pc + rowb[rr]); P0[1][rr] = ldp(pp + rowb[rr]);
-    }
+    load_p0(P0[3], pm); load_p0(P0[0], pc); load_p0(P0[1], pp);
 #pragma unroll
     for (int rr = 0; rr < R1; ++rr) { AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]); AM[0][rr] = ldm(pc + rowb[rr + 1]); }
   }
@@ -696,8 +724,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     constexpr int SM = (PH + 3) & 3, SC = PH, SP = (PH + 1) & 3, SN = (PH + 2) & 3, BUF = PH & 1;
     // ---- issue the loads of p^0 plane t+2 and of the aux data of plane t+1 (used one step later)
     const unsigned p2 = planeoff(t + 2), p1 = planeoff(t + 1);
-#pragma unroll
-    for (int rr = 0; rr < R0; ++rr) P0[SN][rr] = ldp(p2 + rowb[rr]);
+    load_p0(P0[SN], p2);
 #pragma unroll
     for (int rr = 0; rr < R1; ++rr) { AD[SP][rr] = ldf(r_d, p1 + rowb[rr + 1]); AM[SP][rr] = ldm(p1 + rowb[rr + 1]); }
     // ---- sweep 1 on plane t, rows j0-1 .. j0+4
@@ -712,6 +739,13 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
       float v[Z2R];
       sweep(IC<Z2R>{}, prev_sel, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
       const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
+      if (LAY & 2) {                                       // j0 * W floats into the plane is the tile's row group in both layouts
+        static_assert(!(RES && (LAY & 2)), "the residual is taken by the last pass, which writes rows");
+        if (lane_out) {
+          const f32x4 o = {v[0], v[1], v[2], v[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_o, xoff4, ok, 0);
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
         if (lane_out && j0 + r < g.H) {
@@ -1460,8 +1494,17 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 }
 
 // two sweeps in one pass: p_in = p^n, p_out = p^{n+2}; sumsq receives ||p^{n+2} - p^{n+1}||^2
+static bool jacobi3d_dma() { static const bool on = [] { const char* e = getenv("FNX_JACOBI_DMA"); return e ? atoi(e) != 0 : false; }(); return on; }
+
+// can the two-sweep passes of this grid hand each other p in the row-quad layout (`lay` of launch_jacobi3d_x2)?
+bool jacobi3d_quad_ok(const GridDims& g) {
+  static const bool off = [] { const char* e = getenv("FNX_JACOBI_QUAD"); return e && atoi(e) == 0; }();   // A/B switch
+  return !off && !jacobi3d_dma() && g.H % 4 == 0 && Z2R == 4 && Z2NW == 1;
+}
+
+// lay: bit 0 = p_in, bit 1 = p_out in the row-quad layout (jacobi3d_quad_ok; sumsq only with a row-layout output)
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero, int kb2) {
+                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay) {
   if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
   static const int slots = [] {                          // resident waves: Z2WPS per SIMD (<= 128 VGPRs each)
     int dev = 0, cus = 256;
@@ -1488,8 +1531,8 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
   }
   if (kb2 >= 0 && (zchunk <= 0 || 2 * ntiles > slots)) {   // no room for both ranges at once: one after the other
-    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb, ke, from_zero, -1);
-    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb2, kb2 + np, from_zero, -1);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb, ke, from_zero, -1, lay);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb2, kb2 + np, from_zero, -1, lay);
     return;
   }
   long long G;
@@ -1503,12 +1546,20 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
-  static const bool dma = [] { const char* e = getenv("FNX_JACOBI_DMA"); return e ? atoi(e) != 0 : false; }();   // A/B switch (same bits, same speed: see the kernel comment)
+  static const bool dma = jacobi3d_dma();                  // A/B switch (same bits, same speed: see the kernel comment)
 #define J3D(R, Z, S) do { if (dma) jacobi3d_march2_dma_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); \
-                          else jacobi3d_march2_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
+                          else jacobi3d_march2_kernel<R, Z, S, 0><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
 #define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \
                        else { if (sumsq) J3D(true, false, S); else J3D(false, false, S); } } while (0)
-  if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true);
+#define J3Q(R, Z, S, L) jacobi3d_march2_kernel<R, Z, S, L><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2)
+#define J3Q_S(R, Z, L) do { if (zchunk > 0) J3Q(R, Z, false, L); else J3Q(R, Z, true, L); } while (0)
+  if (from_zero) lay &= 2;                                 // no input: its layout does not matter
+  if (lay == 0) { if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true); }
+  else if (lay == 2) { if (from_zero) J3Q_S(false, true, 2); else J3Q_S(false, false, 2); }      // (sumsq: not with a quad output)
+  else if (lay == 3) J3Q_S(false, false, 3);
+  else { if (sumsq) J3Q_S(true, false, 1); else J3Q_S(false, false, 1); }
+#undef J3Q_S
+#undef J3Q
 #undef J3D_RZ
 #undef J3D
 }

@@ -83,7 +83,8 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                      bool from_zero, float* sumsq, hipStream_t s, int kb = 0, int ke = 0);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1);
+                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0);
+bool jacobi3d_quad_ok(const GridDims& g);   // may two-sweep passes hand each other p in the row-quad layout (lay bits 0 / 1 = p_in / p_out)?
 bool jacobi3d_x3_available(const GridDims& g, int np, int nranges);
 bool launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                         float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1);
