@@ -471,7 +471,7 @@ struct PySlab {
 
 // `nsweeps` more sweeps on an existing pressure field (in place) -- used by the z-slab driver
 void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, c10::optional<Tensor> workspace,
-                    bool reuse_mask, const Geom* geom) {
+                    bool reuse_mask, const Geom* geom, bool from_zero) {
   FnxGrid g = grid_of(flags, is3D, geom);
   check_scalar(div, g, "div"); check_scalar(p, g, "p");
   c10::hip::HIPGuard guard(flags.get_device());
@@ -480,7 +480,8 @@ void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, 
   if (workspace.has_value() && workspace->defined() && (size_t)workspace->numel() * workspace->element_size() >= bytes) ws = *workspace;
   else { ws = at::empty({(int64_t)bytes}, flags.options().dtype(at::kByte)); reuse_mask = false; }
   check_status(fnx_jacobi_sweeps_ex(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(), nsweeps,
-                                    ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+                                    ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), (reuse_mask ? 1 : 0) | (from_zero ? 2 : 0),
+                                    cur_stream(flags)));
 }
 
 // one pass (1|2 sweeps) p_in -> p_out on the output planes [k_begin, k_end) -- z-slab driver (overlap with exchange)
@@ -645,7 +646,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0, GEOM, NoGil());
   m.def("step_workspace_bytes", &step_workspace_bytes);
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
-        py::arg("workspace") = py::none(), py::arg("reuse_mask") = false, GEOM, NoGil());
+        py::arg("workspace") = py::none(), py::arg("reuse_mask") = false, GEOM, py::arg("from_zero") = false, NoGil());
   m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
   m.def("jacobi_max_pass_sweeps", [](int B, int D, int H, int W, int nplanes, int nranges) {
     FnxGrid g{B, D, H, W, 1, 0, 0, 0};

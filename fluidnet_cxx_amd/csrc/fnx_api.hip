@@ -380,10 +380,11 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   c.take((size_t)g->B * 4); c.take(4);
   unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
-  if (g->is3D && !reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
+  const bool from_zero = (reuse_mask & 2) != 0;
+  if (g->is3D && !(reuse_mask & 1)) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   const int kmax = g->is3D ? (fnx::jacobi3d_x3_available(d, g->D, 1) ? 3 : 2) : fnx::jacobi_max_sweeps_per_launch(d, false);
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
-  const float* in = p;
+  const float* in = from_zero ? nullptr : p;
   int done = 0;
   const bool quad = g->is3D && kmax == 2 && fnx::jacobi3d_quad_ok(d);      // see jacobi_solve
   bool in_quad = false;
@@ -396,11 +397,12 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
     in_quad = out_quad;
     { fnx::ProfScope ps(FNX_PROF_JACOBI, s);
       if (g->is3D) {
-        if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, nullptr, s);
-        else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s, 0, 0, false, -1, lay);
-        else fnx::launch_jacobi3d(d, mask, div, in, out, false, nullptr, s);
+        const bool fz = from_zero && l == 0;
+        if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, nullptr, s, 0, 0, fz);
+        else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s, 0, 0, fz, -1, lay);
+        else fnx::launch_jacobi3d(d, mask, div, in, out, fz, nullptr, s);
       } else {
-        fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, false, nullptr, s);
+        fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, from_zero && l == 0, nullptr, s);
       } }
     in = out; done += k;
   }

@@ -541,6 +541,11 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
       float* t = cur; cur = nxt; nxt = t;
       if (worst < prm->p_tol) break;
     }
+  } else if (world == 1) {
+    // a single rank has nobody to exchange with: the whole solve in one call (its passes hand each other p in the
+    // solver's row-quad layout, which the plane-range passes below do not)
+    SLAB_OK(fnx_jacobi_sweeps_ex(&gj, st->flags, W.div, cur, prm->jacobi_iter, W.jac, W.jac_bytes, (s->mask_valid ? 1 : 0) | 2, stream));
+    s->mask_valid = true;
   } else if (world > 1 && s->owned >= 4 * w && remaining > w) {
     // "edge_first" (slab.py:_jacobi_edge_first)
     int npass = 0, passes[64];

@@ -157,13 +157,14 @@ class NativeOps:
                                         [float(gv["x"]), float(gv["y"]), float(gv["z"])],
                                         float(cfg.get("operatingDensity", 0.0)), True, self._bc_class(st), self._geom())
 
-    def jacobi_sweeps(self, flags, div, p, n):
+    def jacobi_sweeps(self, flags, div, p, n, from_zero=False):
+        """n sweeps in place; from_zero: the solve starts from p = 0 (p is not read)"""
         key = (tuple(flags.shape), flags.device)
         if self._ws is None or self._ws_key != key:
             B, _, D, H, W = flags.shape
             self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
             self._ws_key, self._mask_valid = key, False
-        self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid, self._geom(False))
+        self.ext.jacobi_sweeps_(flags, div, p, True, int(n), self._ws, self._mask_valid, self._geom(False), from_zero=bool(from_zero))
         self._mask_valid = True      # same flags for the rest of this step (begin_step resets)
 
     two_ranges = True            # jacobi_pass takes a second plane range of the same length (one launch for both faces)
@@ -413,6 +414,11 @@ class SlabSimulator:
             self._pbuf = torch.zeros_like(st["p"])
         cur, nxt = st["p"], self._pbuf
         fresh = getattr(ops, "zero_start", False)      # the operator set takes p_in=None for "p is 0 everywhere"
+        if l.world == 1 and fresh:
+            # nobody to exchange with: the whole solve in one call (its passes hand each other p in the solver's
+            # row-quad layout, which the plane-range passes below do not)
+            ops.jacobi_sweeps(st["flags"], div, cur, int(cfg["jacobiIter"]), from_zero=True)
+            return cur
         if not fresh:
             cur.zero_()
         lo, top = l.lo, l.lo + l.owned

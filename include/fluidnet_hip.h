@@ -108,8 +108,10 @@ int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p,
  * blocks of sweeps.  No residual. */
 int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
                       void* ws, size_t ws_bytes, void* stream);
-/* Same, for callers that keep `ws` alive between calls on the SAME flags: reuse_mask != 0 skips rebuilding the 3D
- * neighbour mask that an earlier call (with reuse_mask == 0) left in `ws`. */
+/* Same, for callers that keep `ws` alive between calls on the SAME flags: bit 0 of reuse_mask skips rebuilding the 3D
+ * neighbour mask that an earlier call (without it) left in `ws`.  Bit 1: the solve starts from p = 0 -- `p` is not read
+ * (it need not be zeroed), the first launch is the from-zero instantiation: a whole solve without the residual of
+ * fnx_jacobi, which is what the z-slab driver runs on a single rank. */
 int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
                          void* ws, size_t ws_bytes, int reuse_mask, void* stream);
 
