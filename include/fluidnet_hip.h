@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 10
+#define FNX_ABI_VERSION 11
 
 enum {
   FNX_OK = 0,
