@@ -283,6 +283,28 @@ def test_jacobi_pass_two_ranges(dev, ext, shape):
         ext.jacobi_pass_(flags, div, p, torch.empty_like(p), 2, 3, 17, ws, True, 10)
 
 
+@pytest.mark.parametrize("shape,n", [((2, 12, 24, 70), 10), ((1, 9, 21, 66), 7), ((1, 1, 40, 90), 20)])
+def test_jacobi_sweeps_from_zero_flag(dev, ext, fl, oracle, shape, n):
+    """fnx_jacobi_sweeps_ex with the from-zero bit (what the z-slab drivers run on a single rank): p is not read -- it is
+    handed over full of NaN -- and the result has the bits of the whole-solve entry point and of the oracle (3D with
+    H % 4 == 0: the passes hand each other p in the row-quad layout; H % 4 != 0: in rows; 2D)."""
+    B, D, H, W = shape
+    is3d = D > 1
+    s = random_state(B, D, H, W, 2.0, seed=n)
+    div = oracle.velocity_divergence(s["U"], s["flags"])
+    tf, td = T(s["flags"], dev), T(div, dev)
+    p = torch.full((B, 1, D, H, W), float("nan"), device=dev)
+    ws = torch.empty(ext.jacobi_workspace_bytes(B, D, H, W, is3d), dtype=torch.uint8, device=dev)
+    ext.jacobi_sweeps_(tf, td, p, is3d, n, ws, False, from_zero=True)
+    po, _, _ = oracle.jacobi(s["flags"], div, is3d, 0.0, n)
+    assert_bitexact(N(p), po, f"jacobi_sweeps from zero {shape} n={n}")
+    pj, _ = fl.solveLinearSystemJacobi(tf, td, is3d, 0.0, n)
+    assert torch.equal(p, pj)
+    ext.jacobi_sweeps_(tf, td, p, is3d, 4, ws, True)          # and 4 more sweeps from there (rows in, rows out)
+    po4 = oracle.jacobi_sweeps(s["flags"], div, po, is3d, 4)
+    assert_bitexact(N(p), po4, "4 more sweeps")
+
+
 def test_jacobi_pass_from_zero_respects_plane_range(dev, ext, oracle):
     """fnx_jacobi_pass with p_in = NULL ("p is 0 everywhere") and nsweeps 1 or 2 writes the planes [k_begin, k_end) only
     (the header's contract; the single-sweep from-zero kernel used to write every plane, which clobbered planes in
