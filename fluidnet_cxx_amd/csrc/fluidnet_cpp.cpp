@@ -486,15 +486,21 @@ void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, 
 
 // one pass (1|2 sweeps) p_in -> p_out on the output planes [k_begin, k_end) -- z-slab driver (overlap with exchange)
 void jacobi_pass_(Tensor flags, Tensor div, c10::optional<Tensor> p_in_opt, Tensor p_out, int nsweeps, int k_begin,
-                  int k_end, Tensor workspace, bool reuse_mask, int k_begin2, const Geom* geom) {
+                  int k_end, Tensor workspace, bool reuse_mask, int k_begin2, const Geom* geom, int layout) {
   FnxGrid g = grid_of(flags, true, geom);
   const bool zero = !(p_in_opt.has_value() && p_in_opt->defined());     // None: p = 0 (first pass of a solve)
   Tensor p_in = zero ? p_out : *p_in_opt;
   check_scalar(div, g, "div"); check_scalar(p_in, g, "p_in"); check_scalar(p_out, g, "p_out");
   c10::hip::HIPGuard guard(flags.get_device());
-  check_status(fnx_jacobi_pass2(&g, flags.data_ptr<float>(), div.data_ptr<float>(), zero ? nullptr : p_in.data_ptr<float>(),
-                                p_out.data_ptr<float>(), nsweeps, k_begin, k_end, k_begin2, workspace.data_ptr(),
-                                (size_t)workspace.numel() * workspace.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+  check_status(fnx_jacobi_pass_layout(&g, flags.data_ptr<float>(), div.data_ptr<float>(), zero ? nullptr : p_in.data_ptr<float>(),
+                                      p_out.data_ptr<float>(), nsweeps, k_begin, k_end, k_begin2, layout, workspace.data_ptr(),
+                                      (size_t)workspace.numel() * workspace.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+}
+
+// may two-sweep passes on this 3D grid hand each other the pressure in the row-quad layout (jacobi_pass_'s `layout`)?
+bool jacobi_quad_ok(int B, int D, int H, int W) {
+  FnxGrid g{B, D, H, W, 1, 0, 0, 0};
+  return fnx_jacobi_quad_ok(&g) != 0;
 }
 
 int64_t jacobi_workspace_bytes(int B, int D, int H, int W, bool is3D) {
@@ -654,7 +660,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   });
   m.def("jacobi_pass_", &jacobi_pass_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("nsweeps"),
         py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1, GEOM,
-        NoGil());
+        py::arg("layout") = 0, NoGil());
+  m.def("jacobi_quad_ok", &jacobi_quad_ok);
   m.def("pre_projection_", &pre_projection_, py::arg("U_adv"), py::arg("rho_adv"), py::arg("p"), py::arg("U"), py::arg("flags"),
         py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"),
         py::arg("dt"), py::arg("buoyancy_scale"), py::arg("gravity_vec"), py::arg("operating_density"),

@@ -414,7 +414,21 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
 int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                      int nsweeps, int k_begin, int k_end, int k_begin2, void* ws, size_t ws_bytes, int reuse_mask,
                      void* stream) {
+  return fnx_jacobi_pass_layout(g, flags, div, p_in, p_out, nsweeps, k_begin, k_end, k_begin2, 0, ws, ws_bytes, reuse_mask, stream);
+}
+
+int fnx_jacobi_quad_ok(const FnxGrid* g) {
+  if (check_grid(g) != FNX_OK || !g->is3D) return 0;
+  return fnx::jacobi3d_quad_ok(dims(g)) && !fnx::jacobi3d_x3_available(dims(g), g->D, 1) ? 1 : 0;
+}
+
+int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
+                           int nsweeps, int k_begin, int k_end, int k_begin2, int layout, void* ws, size_t ws_bytes,
+                           int reuse_mask, void* stream) {
   if (int rc = check_grid(g)) return rc;
+  if (layout < 0 || layout > 3) return fail(FNX_EINVAL, "jacobi_pass: layout must be 0..3");
+  if (layout != 0 && (nsweeps != 2 || !g->is3D || !fnx::jacobi3d_quad_ok(dims(g))))
+    return fail(FNX_EINVAL, "jacobi_pass: the row-quad layout needs a two-sweep pass on a grid fnx_jacobi_quad_ok accepts");
   if (!flags || !div || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
   if (!g->is3D) return fail(FNX_EINVAL, "jacobi_pass: 3D only (2D uses fnx_jacobi_sweeps)");
   const bool from_zero = p_in == nullptr;                 // the first pass of a solve: p = 0 everywhere, nothing to read
@@ -436,7 +450,7 @@ int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, con
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
   if (nsweeps == 3) fnx::launch_jacobi3d_x3(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
-  else if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
+  else if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2, layout);
   else {
     fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin, k_end);
     if (k_begin2 >= 0) fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin2, k_begin2 + (k_end - k_begin));

@@ -508,9 +508,10 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
 
   // ---- 3. Jacobi: blocks of w sweeps between ghost exchanges of p
   const FnxGrid gj = grid_of(s);
-  auto pass = [&](const float* pin, float* pout, int n, int kb, int ke, int kb2 = -1) {
-    const int rc = kb2 >= 0 ? fnx_jacobi_pass2(&gj, st->flags, W.div, pin, pout, n, kb, ke, kb2, W.jac, W.jac_bytes, s->mask_valid ? 1 : 0, stream)
-                            : fnx_jacobi_pass(&gj, st->flags, W.div, pin, pout, n, kb, ke, W.jac, W.jac_bytes, s->mask_valid ? 1 : 0, stream);
+  // lay: the row-quad layout of fnx_jacobi_pass_layout (bit 0: pin, bit 1: pout)
+  auto pass = [&](const float* pin, float* pout, int n, int kb, int ke, int kb2 = -1, int lay = 0) {
+    const int rc = fnx_jacobi_pass_layout(&gj, st->flags, W.div, pin, pout, n, kb, ke, kb2, pin ? lay : (lay & 2), W.jac, W.jac_bytes,
+                                          s->mask_valid ? 1 : 0, stream);
     s->mask_valid = true;
     return rc;
   };
@@ -551,6 +552,11 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
     int npass = 0, passes[64];
     if (w % 2) passes[npass++] = 1;
     for (int i = 0; i < w / 2; ++i) passes[npass++] = 2;
+    // every pass of the solve is a two-sweep pass: they hand each other the pressure in the solver's row-quad layout (both
+    // arrays, every plane range, the ghost planes the neighbours send -- they run the same schedule); the last pass of the
+    // solve writes rows
+    const bool quad = w % 2 == 0 && prm->jacobi_iter % 2 == 0 && fnx_jacobi_quad_ok(&gj) != 0;
+    const int Q = quad ? 3 : 0;
     int block = 0;
     while (remaining > w) {
       remaining -= w;
@@ -561,10 +567,10 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
         const int n = passes[pi];
         done += n;
         const float* pin = (zero_in && pi == 0) ? nullptr : src;
-        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + 2 * w - done, top - 2 * w + done));
+        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + 2 * w - done, top - 2 * w + done, Q));
         else {
-          if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + 2 * w - done));
-          if (has_hi) SLAB_OK(pass(pin, dst, n, top - 2 * w + done, top + w - done));
+          if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + 2 * w - done, -1, Q));
+          if (has_hi) SLAB_OK(pass(pin, dst, n, top - 2 * w + done, top + w - done, -1, Q));
         }
         float* t = src; src = dst; dst = t;
       }
@@ -575,7 +581,7 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
       for (int pi = 0; pi < npass; ++pi) {
         const int n = passes[pi];
         done += n;
-        SLAB_OK(pass((zero_in && pi == 0) ? nullptr : src, dst, n, has_lo ? lo + 2 * w - done : 0, has_hi ? top - 2 * w + done : DL));
+        SLAB_OK(pass((zero_in && pi == 0) ? nullptr : src, dst, n, has_lo ? lo + 2 * w - done : 0, has_hi ? top - 2 * w + done : DL, -1, Q));
         float* t = src; src = dst; dst = t;
       }
       if (fin != cur) { float* t = cur; cur = nxt; nxt = t; }
@@ -587,7 +593,7 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
       const int n = left >= 2 ? 2 : 1;
       left -= n; done += n;
       const int g = w - done > 0 ? w - done : 0;
-      SLAB_OK(pass(cur, nxt, n, has_lo ? lo - g : 0, has_hi ? top + g : DL));
+      SLAB_OK(pass(cur, nxt, n, has_lo ? lo - g : 0, has_hi ? top + g : DL, -1, left > 0 ? Q : (Q & 1)));
       float* t = cur; cur = nxt; nxt = t;
     }
   } else {

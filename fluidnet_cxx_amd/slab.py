@@ -169,14 +169,20 @@ class NativeOps:
 
     two_ranges = True            # jacobi_pass takes a second plane range of the same length (one launch for both faces)
 
-    def jacobi_pass(self, flags, div, p_in, p_out, n, k_begin, k_end, k_begin2=-1):
+    def quad_ok(self, flags):
+        """may two-sweep passes hand each other the pressure in the solver's row-quad layout (jacobi_pass's `lay`)?"""
+        B, _, D, H, W = flags.shape
+        return bool(self.ext.jacobi_quad_ok(B, D, H, W))
+
+    def jacobi_pass(self, flags, div, p_in, p_out, n, k_begin, k_end, k_begin2=-1, lay=0):
+        """lay: bit 0 = p_in, bit 1 = p_out in the row-quad layout (fnx_jacobi_pass_layout)"""
         key = (tuple(flags.shape), flags.device)
         if self._ws is None or self._ws_key != key:
             B, _, D, H, W = flags.shape
             self._ws = torch.empty(self.ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=flags.device)
             self._ws_key, self._mask_valid = key, False
         self.ext.jacobi_pass_(flags, div, p_in, p_out, int(n), int(k_begin), int(k_end), self._ws, self._mask_valid,
-                              int(k_begin2), self._geom(False))
+                              int(k_begin2), self._geom(False), layout=int(lay) & (3 if p_in is not None else 2))
         self._mask_valid = True
 
     def max_abs(self, x):
@@ -361,6 +367,11 @@ class SlabSimulator:
         flags = st["flags"]
         passes = [1] * (w % 2) + [2] * (w // 2)
         remaining = int(cfg["jacobiIter"])
+        # every pass of the solve is a two-sweep pass: they hand each other the pressure in the solver's row-quad layout
+        # (both arrays, every plane range, the ghost planes the neighbours send -- they run the same schedule); the last
+        # pass of the solve writes rows
+        quad = w % 2 == 0 and remaining % 2 == 0 and hasattr(ops, "quad_ok") and ops.quad_ok(flags)
+        Q = dict(lay=3) if quad else {}
         zero_in = fresh                      # the block starts from p = 0 everywhere: nothing to read
         block = 0
         while remaining > w:                 # a block that is followed by another one
@@ -374,12 +385,12 @@ class SlabSimulator:
                 done += n
                 pin = None if (zero_in and pi == 0) else src
                 if has_lo and has_hi and getattr(ops, "two_ranges", False):       # both faces in one launch
-                    ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done, top - 2 * w + done)
+                    ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done, top - 2 * w + done, **Q)
                 else:
                     if has_lo:
-                        ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done)
+                        ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + 2 * w - done, **Q)
                     if has_hi:
-                        ops.jacobi_pass(flags, div, pin, dst, n, top - 2 * w + done, top + w - done)
+                        ops.jacobi_pass(flags, div, pin, dst, n, top - 2 * w + done, top + w - done, **Q)
                 src, dst = dst, src
             fin = src
             yield "start", [fin], w
@@ -388,7 +399,7 @@ class SlabSimulator:
             for pi, n in enumerate(passes):
                 done += n
                 ops.jacobi_pass(flags, div, None if (zero_in and pi == 0) else src, dst, n,
-                                lo + 2 * w - done if has_lo else 0, top - 2 * w + done if has_hi else l.D_local)
+                                lo + 2 * w - done if has_lo else 0, top - 2 * w + done if has_hi else l.D_local, **Q)
                 src, dst = dst, src
             if fin is not cur:
                 cur, nxt = nxt, cur
@@ -398,10 +409,12 @@ class SlabSimulator:
         yield ("wait",)
         ops.set_slab(l.z_offset, l.D_global)
         done = 0
-        for n in [2] * (remaining // 2) + [1] * (remaining % 2):
+        tail = [2] * (remaining // 2) + [1] * (remaining % 2)
+        for ti, n in enumerate(tail):
             done += n
             g = max(w - done, 0)
-            ops.jacobi_pass(flags, div, cur, nxt, n, lo - g if has_lo else 0, top + g if has_hi else l.D_local)
+            kw = (Q if ti < len(tail) - 1 else dict(lay=1)) if quad else {}
+            ops.jacobi_pass(flags, div, cur, nxt, n, lo - g if has_lo else 0, top + g if has_hi else l.D_local, **kw)
             cur, nxt = nxt, cur
         return cur
 

@@ -130,6 +130,16 @@ int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, cons
 int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                      int nsweeps, int k_begin, int k_end, int k_begin2, void* ws, size_t ws_bytes, int reuse_mask,
                      void* stream);
+/* The same with the pressure arrays in the solver's ROW-QUAD layout p[b][k][j/4][i][j%4] (a plane is the same H*W floats as
+ * in the row layout p[b][k][j][i]: ghost-plane exchanges do not care): layout bit 0 = p_in, bit 1 = p_out is row-quad.
+ * Two-sweep passes only, on grids fnx_jacobi_quad_ok() accepts (3D, H % 4 == 0).  A chain of passes reads the pressure with
+ * 3 instead of 8 and writes it with 1 instead of 4 vector-memory instructions per step of the march when its passes hand each
+ * other this layout; the first pass of a solve has no input, the last one writes rows (layout 1).  fnx_jacobi and
+ * fnx_jacobi_sweeps do this internally. */
+int fnx_jacobi_quad_ok(const FnxGrid* g);
+int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
+                           int nsweeps, int k_begin, int k_end, int k_begin2, int layout, void* ws, size_t ws_bytes,
+                           int reuse_mask, void* stream);
 
 /* velocityUpdate (in place on U), lib/fluid/velocity_update.py:6-162 */
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream);

@@ -241,14 +241,18 @@ def test_layout_arithmetic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,halo,w,schedule", [(2, 6, 4, "last_pass"), (4, 6, 3, "last_pass"), (2, 6, 6, "last_pass"),
-                                                   (2, 6, 4, "edge_first"), (4, 6, 3, "edge_first"), (2, 6, 6, "edge_first"),
-                                                   (2, 5, 5, "edge_first"), (3, 6, 5, "edge_first")])
-def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule):
-    """Same decomposition check with the native HIP operators on one device (global-z geometry in the kernels)."""
+@pytest.mark.parametrize("world,halo,w,schedule,iters", [(2, 6, 4, "last_pass", 11), (4, 6, 3, "last_pass", 11), (2, 6, 6, "last_pass", 11),
+                                                         (2, 6, 4, "edge_first", 11), (4, 6, 3, "edge_first", 11), (2, 6, 6, "edge_first", 11),
+                                                         (2, 5, 5, "edge_first", 11), (3, 6, 5, "edge_first", 11),
+                                                         (3, 6, 4, "edge_first", 14), (2, 6, 6, "edge_first", 20), (4, 6, 2, "edge_first", 6)])
+def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule, iters):
+    """Same decomposition check with the native HIP operators on one device (global-z geometry in the kernels).  Even
+    sweep blocks with an even sweep count (H = 20): every pass is a two-sweep pass and they hand each other the pressure
+    in the solver's row-quad layout, ghost planes included."""
     from fluidnet_cxx_amd import simulate
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
     dev = torch.device("cuda:0")
+    CFG = dict(globals()["CFG"], jacobiIter=iters)
     D, H, W = (4 * w * world if schedule == "edge_first" else 32), 20, 70
     gs = global_state(D, H, W, seed=3)
     bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
@@ -264,15 +268,17 @@ def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule):
     for l, st in zip(layouts, states):
         check_owned(st, ref, l, f"gpu lockstep world={world}")
     # and against the CPU oracle (single domain)
-    oref = reference_steps(gs, 2)
-    for k in ("U", "density", "p"):
-        assert np.array_equal(ref[k], oref[k]), k
+    if iters == 11:
+        oref = reference_steps(gs, 2)
+        for k in ("U", "density", "p"):
+            assert np.array_equal(ref[k], oref[k]), k
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,halo,w,static", [(2, 6, 4, False), (4, 6, 3, False), (2, 6, 6, True), (3, 6, 5, True), (2, 5, 5, False),
-                                                 (2, 6, 4, "thin"), (1, 6, 6, True)])
-def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static):
+@pytest.mark.parametrize("world,halo,w,static,iters", [(2, 6, 4, False, 11), (4, 6, 3, False, 11), (2, 6, 6, True, 11), (3, 6, 5, True, 11),
+                                                       (2, 5, 5, False, 11), (2, 6, 4, "thin", 11), (1, 6, 6, True, 11),
+                                                       (3, 6, 4, True, 14), (2, 6, 6, False, 20), (1, 6, 6, True, 12)])
+def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static, iters):
     """The C++ z-slab driver (fnx_slab_step) on `world` slabs of one domain, each driven by its own host thread and HIP
     stream on one device, ghost planes through the in-process communicator (event-ordered device copies): every owned
     plane bit-identical to the single-domain step, 3 steps (the third reuses the solver mask and the BC class map under
@@ -283,6 +289,7 @@ def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static):
     from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
     dev = torch.device("cuda:0")
     thin = static == "thin"
+    CFG = dict(globals()["CFG"], jacobiIter=iters)       # (even counts with even sweep blocks: row-quad hand-over between the passes)
     D = (2 * w * world if thin else 4 * w * world) if world > 1 else 24
     H, W = 20, 70
     gs = global_state(D, H, W, seed=5)
