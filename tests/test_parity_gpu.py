@@ -305,6 +305,19 @@ def test_jacobi_sweeps_from_zero_flag(dev, ext, fl, oracle, shape, n):
     assert_bitexact(N(p), po4, "4 more sweeps")
 
 
+def test_jacobi_quad_handover_more_tiles_than_waves(dev, fl, oracle):
+    """3D solve on planes with more 60x4 tiles than resident waves (the launcher then splits the (tile, plane) space evenly
+    over the waves) and H % 4 == 0 (the passes hand each other p in the row-quad layout): bits of the oracle."""
+    B, D, H, W = 1, 7, 1040, 1030
+    rng = np.random.default_rng(11)
+    flags = make_flags(B, D, H, W, boxes=True)
+    div = rng.standard_normal((B, 1, D, H, W)).astype(np.float32)
+    for n in (6, 5):
+        pg, _ = fl.solveLinearSystemJacobi(T(flags, dev), T(div, dev), True, 0.0, n)
+        po, _, _ = oracle.jacobi(flags, div, True, 0.0, n)
+        assert_bitexact(N(pg), po, f"jacobi {n} sweeps on {D}x{H}x{W}")
+
+
 def test_jacobi_pass_from_zero_respects_plane_range(dev, ext, oracle):
     """fnx_jacobi_pass with p_in = NULL ("p is 0 everywhere") and nsweeps 1 or 2 writes the planes [k_begin, k_end) only
     (the header's contract; the single-sweep from-zero kernel used to write every plane, which clobbered planes in
