@@ -69,7 +69,8 @@ size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g
 size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
 // fix-up bitmaps of the 3D tile advection kernels (fnx_advect_march.h): 4 x one 64-bit word per 64-cell row segment
 size_t ws_advect_fix(const FnxGrid* g) { return g->is3D ? al(4 * 8 * (size_t)g->B * g->D * g->H * ((g->W + 63) / 64)) : 0; }
-size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + (g->is3D ? al(ncell(g)) : 0); }
+size_t ws_mask(const FnxGrid* g) { return g->is3D ? al(fnx::jacobi3d_mask_bytes(dims(g))) : 0; }   // 3D solver: neighbour-mask bytes, twice (rows / row groups)
+size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + ws_mask(g); }
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   // 2D: the fused advection launches keep both forward fields at once
@@ -79,7 +80,7 @@ size_t ws_step(const FnxGrid* g) {
   size_t tail = adv > solve ? adv : solve;
   if (cnn > tail) tail = cnn;
   return al(ncell(g) * 4) /*rho2*/ + al(ncell(g) * 4 * nc) /*U2*/ + al(ncell(g) * 4) /*div*/ +
-         (g->is3D ? al(ncell(g)) : 0) /*Jacobi obstacle mask, kept between steps*/ +
+         ws_mask(g) /*Jacobi obstacle mask, kept between steps*/ +
          al(ncell(g)) /*BC class map, kept between steps*/ + tail;
 }
 
@@ -292,7 +293,7 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
   float* tmp = (float*)c.take(ncell(g) * 4);
   float* sumsq = (float*)c.take((size_t)g->B * 4);
   float* res_ws = (float*)c.take(4);
-  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
+  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "solve_linear_system: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (g->is3D && kept_mask) mask = kept_mask;           // a slot nothing else in the step scribbles on
   else reuse_mask = false;
@@ -378,7 +379,7 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   Carver c(ws, ws_bytes);
   float* tmp = (float*)c.take(ncell(g) * 4);
   c.take((size_t)g->B * 4); c.take(4);
-  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ncell(g)) : nullptr;
+  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
   const bool from_zero = (reuse_mask & 2) != 0;
   if (g->is3D && !(reuse_mask & 1)) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
@@ -445,7 +446,7 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
   const GridDims d = dims(g);
   Carver c(ws, ws_bytes);
   c.take(ncell(g) * 4); c.take((size_t)g->B * 4); c.take(4);
-  unsigned char* mask = (unsigned char*)c.take(ncell(g));
+  unsigned char* mask = (unsigned char*)c.take(ws_mask(g));
   if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_pass: workspace too small (%zu < %zu)", ws_bytes, c.off);
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
@@ -683,7 +684,7 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   float* rho2 = (float*)c.take(n * 4);
   float* U2 = (float*)c.take(n * 4 * nc);
   float* div = (float*)c.take(n * 4);
-  unsigned char* kept_mask = g->is3D ? (unsigned char*)c.take(n) : nullptr;
+  unsigned char* kept_mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
   unsigned char* kept_cls = (unsigned char*)c.take(n);
   void* tail = c.take(0);
   const size_t tail_bytes = ws_bytes > c.off ? ws_bytes - c.off : 0;

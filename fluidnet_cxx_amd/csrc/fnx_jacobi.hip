@@ -355,6 +355,24 @@ __global__ __launch_bounds__(256) void jacobi3d_mask_kernel(GridDims g, const fl
   mask[o] = (unsigned char)m;
 }
 
+// The mask bytes in row groups of four for the two-sweep march: maskq[b][k][q][i] = bytes of rows 4q .. 4q+3 of column i
+// (0 = "not a fluid cell" for rows >= H).  1 B per cell like the byte mask, built from it once per mask.
+__global__ __launch_bounds__(256) void jacobi3d_maskq_kernel(GridDims g, const unsigned char* __restrict__ mask,
+                                                             unsigned* __restrict__ maskq) {
+  const int i = blockIdx.x * 64 + threadIdx.x, q = blockIdx.y * 4 + threadIdx.y;
+  const int Hq = (g.H + 3) >> 2;
+  if (i >= g.W || q >= Hq) return;
+  const size_t bk = blockIdx.z;                              // b * D + k
+  const unsigned char* m = mask + bk * g.HW + i;
+  unsigned w = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 4 * q + r;
+    if (j < g.H) w |= (unsigned)m[(size_t)j * g.W] << (8 * r);
+  }
+  maskq[(bk * Hq + q) * g.W + i] = w;
+}
+
 // first sweep from p = 0: ((((((0+0)+0)+0)+0)+0)+div)/6 == div/6 on 'cont' cells.  Writes the planes [kb, ke) of every
 // sample only (`first` = kb*HW, `count` = (ke-kb)*HW cells per sample; `per` = cells per sample).
 __global__ __launch_bounds__(256) void jacobi3d_first_kernel(int B, size_t per, size_t first, size_t count,
@@ -518,18 +536,18 @@ __device__ __forceinline__ float div6_tiny(float x) {
 // SEL: 0 = no cell of the wave's rows has an obstacle neighbour, 1 = x neighbours only (every tile at an x wall of an
 // otherwise empty domain), 2 = any
 template <int SEL>
-__device__ __forceinline__ float relax3(unsigned m, float c, float xl, float xr, float yd, float yu, float zb,
+__device__ __forceinline__ float relax3(unsigned m, int sh, float c, float xl, float xr, float yd, float yu, float zb,
                                         float zf, float dv, float& num) {
-  const int mi = (int)m;
+  const int mi = (int)m;                                // the cell's mask byte sits at bit `sh` of m
   if (SEL >= 1) {                                       // Neumann: an obstacle neighbour is replaced by the centre
-    xl = bfi_blend(__builtin_amdgcn_sbfe(mi, 1, 1), c, xl);
-    xr = bfi_blend(__builtin_amdgcn_sbfe(mi, 2, 1), c, xr);
+    xl = bfi_blend(__builtin_amdgcn_sbfe(mi, sh + 1, 1), c, xl);
+    xr = bfi_blend(__builtin_amdgcn_sbfe(mi, sh + 2, 1), c, xr);
   }
   if (SEL >= 2) {
-    yd = bfi_blend(__builtin_amdgcn_sbfe(mi, 3, 1), c, yd);
-    yu = bfi_blend(__builtin_amdgcn_sbfe(mi, 4, 1), c, yu);
-    zb = bfi_blend(__builtin_amdgcn_sbfe(mi, 5, 1), c, zb);
-    zf = bfi_blend(__builtin_amdgcn_sbfe(mi, 6, 1), c, zf);
+    yd = bfi_blend(__builtin_amdgcn_sbfe(mi, sh + 3, 1), c, yd);
+    yu = bfi_blend(__builtin_amdgcn_sbfe(mi, sh + 4, 1), c, yu);
+    zb = bfi_blend(__builtin_amdgcn_sbfe(mi, sh + 5, 1), c, zb);
+    zf = bfi_blend(__builtin_amdgcn_sbfe(mi, sh + 6, 1), c, zf);
   }
   float sum = xl + xr;
   sum = sum + yd;
@@ -555,7 +573,7 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 // H*W floats in both layouts (ghost-plane exchanges do not care); the passes of a solve hand the quad layout to each other
 // and only the last one writes rows.
 template <bool RES, bool ZERO, bool SPLIT, int LAY>
-__global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned char* __restrict__ mask,
+__global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned* __restrict__ maskq,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
                                                                       float* __restrict__ p_out,
@@ -627,7 +645,27 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   const size_t left = (size_t)(g.D - k0) * g.HW;                       // cells from plane k0 to the end of the sample
   const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
   const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
-  const BufRsrc r_m = make_rsrc(mask + seg0, ncell), r_o = make_rsrc(p_out + seg0, ncell * 4u);
+  const BufRsrc r_o = make_rsrc(p_out + seg0, ncell * 4u);
+  // Mask bytes in row groups of four, maskq[b][k][j/4][i] = the bytes of rows 4(j/4) .. +3 of column i (jacobi3d_maskq_kernel):
+  // the tile's own four rows are ONE dword load, the halo rows j0-1 / j0+4 byte 3 / byte 0 of the groups below / above (taking
+  // them from the byte mask's 64-B rows instead was measured: slower) -- 3 vector-memory instructions and registers per plane
+  // instead of 6, the same bytes of footprint as the byte mask
+  static_assert(Z2R == 4 && Z2NW == 1, "a mask word holds the rows of a 4-row tile");
+  const int HqM = (g.H + 3) >> 2, HqW = HqM * g.W;                      // row groups / words per plane
+  const size_t leftq = (size_t)(g.D - k0) * HqW;
+  const BufRsrc r_m = make_rsrc(maskq + ((size_t)b * g.D + k0) * HqW, (leftq > 0x3fffffffu ? 0x3fffffffu : (unsigned)leftq) * 4u);
+  const unsigned mq_c = (unsigned)(by * g.W) * 4u, mq_m = (unsigned)((by > 0 ? by - 1 : 0) * g.W) * 4u,
+                 mq_p = (unsigned)((by + 1 < HqM ? by + 1 : HqM - 1) * g.W) * 4u;
+  const bool has_m = by > 0, has_p = by + 1 < HqM;                       // a group outside the grid: mask 0
+  struct Mask3 { unsigned own, lo, hi; };
+  auto ldm = [&](int k) {
+    const unsigned po = (unsigned)((clampk(k) - k0) * HqW) * 4u;
+    Mask3 m;
+    m.own = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r_m, xoff, po + mq_c, 0);
+    m.lo = has_m ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, xoff + 3u, po + mq_m, 0) : 0u;
+    m.hi = has_p ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, xoff, po + mq_p, 0) : 0u;
+    return m;
+  };
   auto ldf = [&](const BufRsrc& r, unsigned cell) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
   };
@@ -657,15 +695,15 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
       for (int rr = 0; rr < R0; ++rr) dst[rr] = ldp(po + rowb[rr]);
     }
   };
-  auto ldm = [&](unsigned cell) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, (unsigned)xc, cell, 0); };
 
   float P0[4][R0];                                       // p^0 plane ring: slot (t+d)&3 for planes t-1..t+2
   float P1[4][R1];                                       // p^1 plane ring (3 live)
-  float AD[4][R1]; unsigned AM[4][R1];                   // div / mask ring, row slot rr <-> j = j0-1+rr
+  float AD[4][R1]; Mask3 AM[4];                          // div / mask ring, row slot rr <-> j = j0-1+rr (mask: lo, bytes 0..3 of own, hi)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { P1[q][rr] = 0.f; AD[q][rr] = 0.f; AM[q][rr] = 0u; }
+    for (int rr = 0; rr < R1; ++rr) { P1[q][rr] = 0.f; AD[q][rr] = 0.f; }
+    AM[q] = Mask3{0u, 0u, 0u};
 #pragma unroll
     for (int rr = 0; rr < R0; ++rr) P0[q][rr] = 0.f;
   }
@@ -675,37 +713,40 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
     load_p0(P0[3], pm); load_p0(P0[0], pc); load_p0(P0[1], pp);
 #pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]); AM[0][rr] = ldm(pc + rowb[rr + 1]); }
+    for (int rr = 0; rr < R1; ++rr) AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]);
+    AM[0] = ldm(t);
   }
   float local = 0.f;
   const bool lane_out = (lane >= 2) & (lane <= 61) & xin;
   int prev_sel = 2;
 
   // one sweep over N rows: centre rows C[0..N), y-neighbours from the same plane, z-neighbours B / F
-  auto sweep = [&](auto nn, int sel, const unsigned* M, const float* Cm1, const float* B, const float* F,
+  auto sweep = [&](auto nn, auto off, int sel, const Mask3 M, const float* Cm1, const float* B, const float* F,
                    const float* DV, float* out) __attribute__((always_inline)) {
-    constexpr int N = decltype(nn)::value;
+    constexpr int N = decltype(nn)::value, OFF = decltype(off)::value;      // row r is row slot OFF + r: slot 0 = lo, 1..4 = own bytes, 5 = hi
+    auto mword = [&](int r) { return (OFF + r) == 0 ? M.lo : ((OFF + r) == 5 ? M.hi : M.own); };
+    auto mshift = [&](int r) { return ((OFF + r) == 0 || (OFF + r) == 5) ? 0 : 8 * (OFF + r - 1); };
     float xs[N];
     bool bad = false;
     if (sel == 0) {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<0>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<0>(mword(r), mshift(r), c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     } else if (sel == 1) {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<1>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<1>(mword(r), mshift(r), c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<2>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<2>(mword(r), mshift(r), c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     }
@@ -716,7 +757,7 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     }
 #pragma unroll
     for (int r = 0; r < N; ++r)                            // cont ? v : 0
-      out[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[r]) & __builtin_amdgcn_sbfe((int)M[r], 0, 1));
+      out[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[r]) & __builtin_amdgcn_sbfe((int)mword(r), mshift(r), 1));
   };
 
   auto step = [&](auto ph, int t) __attribute__((always_inline)) {
@@ -726,18 +767,17 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     const unsigned p2 = planeoff(t + 2), p1 = planeoff(t + 1);
     load_p0(P0[SN], p2);
 #pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { AD[SP][rr] = ldf(r_d, p1 + rowb[rr + 1]); AM[SP][rr] = ldm(p1 + rowb[rr + 1]); }
+    for (int rr = 0; rr < R1; ++rr) AD[SP][rr] = ldf(r_d, p1 + rowb[rr + 1]);
+    AM[SP] = ldm(t + 1);
     // ---- sweep 1 on plane t, rows j0-1 .. j0+4
-    unsigned ob = AM[SC][0];
-#pragma unroll
-    for (int rr = 1; rr < R1; ++rr) ob |= AM[SC][rr];
+    const unsigned ob = AM[SC].own | ((AM[SC].lo | AM[SC].hi) & 0xffu);
     // no cell of these rows has an obstacle neighbour (0) / only x neighbours (1) / any (2)
-    const int sel1 = __builtin_amdgcn_ballot_w64((ob & 0x78u) != 0) != 0 ? 2 : (__builtin_amdgcn_ballot_w64((ob & 0x06u) != 0) != 0 ? 1 : 0);
-    sweep(IC<R1>{}, sel1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
+    const int sel1 = __builtin_amdgcn_ballot_w64((ob & 0x78787878u) != 0) != 0 ? 2 : (__builtin_amdgcn_ballot_w64((ob & 0x06060606u) != 0) != 0 ? 1 : 0);
+    sweep(IC<R1>{}, IC<0>{}, sel1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
     // ---- sweep 2 on plane t-1, rows j0 .. j0+3 (p^1 of planes t-2, t-1, t = slots SN, SM, SC)
     if (t - 1 >= k_lo) {
       float v[Z2R];
-      sweep(IC<Z2R>{}, prev_sel, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
+      sweep(IC<Z2R>{}, IC<1>{}, prev_sel, AM[SM], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
       const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
       if (LAY & 2) {                                       // j0 * W floats into the plane is the tile's row group in both layouts
         static_assert(!(RES && (LAY & 2)), "the residual is taken by the last pass, which writes rows");
@@ -955,14 +995,14 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_dma_kernel(G
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<0>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<0>(M[r], 0, c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < N; ++r) {
         const float c = Cm1[r + 1];
-        out[r] = relax3<2>(M[r], c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
+        out[r] = relax3<2>(M[r], 0, c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
         bad |= __builtin_amdgcn_classf(out[r], 0x90);
       }
     }
@@ -1487,10 +1527,16 @@ void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags
 }
 
 // 3D fast path (mask precomputed by launch_jacobi3d_mask)
+// the mask allocation: B*D*H*W neighbour-mask bytes, then (256-B aligned) the same bytes in row groups of four
+static size_t maskq_offset(const GridDims& g) { return (((size_t)g.B * g.DHW) + 255) & ~(size_t)255; }
+size_t jacobi3d_mask_bytes(const GridDims& g) { return maskq_offset(g) + (size_t)g.B * g.D * ((g.H + 3) / 4) * g.W * 4; }
+
 void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, unsigned char* mask, hipStream_t s) {
   const dim3 grid((g.W + 63) / 64, (g.H + 3) / 4, g.B * g.D), block(64, 4);
   if (quirks) jacobi3d_mask_kernel<true><<<grid, block, 0, s>>>(g, flags, mask);
   else jacobi3d_mask_kernel<false><<<grid, block, 0, s>>>(g, flags, mask);
+  const dim3 gridq((g.W + 63) / 64, ((g.H + 3) / 4 + 3) / 4, g.B * g.D);
+  jacobi3d_maskq_kernel<<<gridq, block, 0, s>>>(g, mask, (unsigned*)(mask + maskq_offset(g)));
 }
 
 // two sweeps in one pass: p_in = p^n, p_out = p^{n+2}; sumsq receives ||p^{n+2} - p^{n+1}||^2
@@ -1546,12 +1592,13 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
     if (G < 8) G = 8;
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
+  const unsigned* maskq = (const unsigned*)(mask + maskq_offset(g));
   static const bool dma = jacobi3d_dma();                  // A/B switch (same bits, same speed: see the kernel comment)
 #define J3D(R, Z, S) do { if (dma) jacobi3d_march2_dma_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); \
-                          else jacobi3d_march2_kernel<R, Z, S, 0><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
+                          else jacobi3d_march2_kernel<R, Z, S, 0><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
 #define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \
                        else { if (sumsq) J3D(true, false, S); else J3D(false, false, S); } } while (0)
-#define J3Q(R, Z, S, L) jacobi3d_march2_kernel<R, Z, S, L><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2)
+#define J3Q(R, Z, S, L) jacobi3d_march2_kernel<R, Z, S, L><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2)
 #define J3Q_S(R, Z, L) do { if (zchunk > 0) J3Q(R, Z, false, L); else J3Q(R, Z, true, L); } while (0)
   if (from_zero) lay &= 2;                                 // no input: its layout does not matter
   if (lay == 0) { if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true); }

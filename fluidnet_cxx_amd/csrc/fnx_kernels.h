@@ -78,6 +78,7 @@ void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags
                    float* p_out, int nsweeps, bool from_zero, float* sumsq, hipStream_t s);
 int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d);
 // 3D: flags -> 7-bit neighbour mask (once per solve), then one z-marching sweep per launch
+size_t jacobi3d_mask_bytes(const GridDims& g);   // bytes of the `mask` allocation of the 3D launches below (byte mask + the same bytes in row groups of four)
 void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, unsigned char* mask, hipStream_t s);
 // kb/ke: restrict the OUTPUT to planes [kb, ke) (0,0 = all planes); inputs are read from kb-1 (kb-2 for x2) on
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
