@@ -283,7 +283,7 @@ def test_jacobi_pass_two_ranges(dev, ext, shape):
         ext.jacobi_pass_(flags, div, p, torch.empty_like(p), 2, 3, 17, ws, True, 10)
 
 
-@pytest.mark.parametrize("shape,n", [((2, 12, 24, 70), 10), ((1, 9, 21, 66), 7), ((1, 1, 40, 90), 20)])
+@pytest.mark.parametrize("shape,n", [((2, 12, 24, 70), 10), ((1, 9, 21, 66), 7), ((1, 1, 40, 90), 20), ((1, 5, 4, 10), 6), ((2, 3, 8, 130), 8)])
 def test_jacobi_sweeps_from_zero_flag(dev, ext, fl, oracle, shape, n):
     """fnx_jacobi_sweeps_ex with the from-zero bit (what the z-slab drivers run on a single rank): p is not read -- it is
     handed over full of NaN -- and the result has the bits of the whole-solve entry point and of the oracle (3D with
