@@ -318,6 +318,33 @@ def test_jacobi_quad_handover_more_tiles_than_waves(dev, fl, oracle):
         assert_bitexact(N(pg), po, f"jacobi {n} sweeps on {D}x{H}x{W}")
 
 
+def test_jacobi_pass_layout_chain_and_errors(dev, ext, oracle):
+    """fnx_jacobi_pass_layout: a chain of two-sweep passes that hand each other p in the row-quad layout (first pass from
+    zero, last pass writes rows) has the bits of the oracle; the layout is refused for one-sweep passes and for grids
+    fnx_jacobi_quad_ok does not accept."""
+    B, D, H, W = 2, 10, 16, 70
+    rng = np.random.default_rng(21)
+    flags = make_flags(B, D, H, W, boxes=True)
+    div = rng.standard_normal((B, 1, D, H, W)).astype(np.float32)
+    tf, td = T(flags, dev), T(div, dev)
+    assert ext.jacobi_quad_ok(B, D, H, W) and not ext.jacobi_quad_ok(B, D, H + 1, W)
+    ws = torch.empty(ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=dev)
+    a = torch.full((B, 1, D, H, W), float("nan"), device=dev); b = torch.full_like(a, float("nan"))
+    ext.jacobi_pass_(tf, td, None, a, 2, 0, 0, ws, False, layout=2)      # from zero, quad out
+    ext.jacobi_pass_(tf, td, a, b, 2, 0, 0, ws, True, layout=3)          # quad in, quad out
+    ext.jacobi_pass_(tf, td, b, a, 2, 0, 0, ws, True, layout=3)
+    ext.jacobi_pass_(tf, td, a, b, 2, 0, 0, ws, True, layout=1)          # quad in, rows out
+    po, _, _ = oracle.jacobi(flags, div, True, 0.0, 8)
+    assert_bitexact(N(b), po, "four two-sweep passes through the row-quad layout")
+    with pytest.raises(RuntimeError, match="row-quad"):
+        ext.jacobi_pass_(tf, td, b, a, 1, 0, 0, ws, True, layout=1)
+    H2 = H + 2
+    f2 = T(make_flags(B, D, H2, W, boxes=False), dev); d2 = torch.zeros(B, 1, D, H2, W, device=dev)
+    ws2 = torch.empty(ext.jacobi_workspace_bytes(B, D, H2, W, True), dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="row-quad"):
+        ext.jacobi_pass_(f2, d2, None, torch.empty_like(d2), 2, 0, 0, ws2, False, layout=2)
+
+
 def test_jacobi_pass_from_zero_respects_plane_range(dev, ext, oracle):
     """fnx_jacobi_pass with p_in = NULL ("p is 0 everywhere") and nsweeps 1 or 2 writes the planes [k_begin, k_end) only
     (the header's contract; the single-sweep from-zero kernel used to write every plane, which clobbered planes in
