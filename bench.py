@@ -30,10 +30,17 @@ capture, then EXACTLY K timed steps between barrier + synchronize pairs, max ove
 The slab workload is timed through BOTH z-slab drivers, one after the other on the same state: the Python one
 (fluidnet_cxx_amd/slab.py over torch.distributed P2P) and the C++ one (fnx_slab_step: launches and RCCL ncclSend/ncclRecv
 issued from C++; `native_driver`, under a watchdog).  They issue the same kernels and exchanges and produce the same bits
-(tests/test_slab.py).  At N = 1 the Python-driver time is the headline; at N > 1 the faster of the two is (`config.driver`
-says which) and the other is kept beside it (`python_driver` / `native_driver`).
+(tests/test_slab.py).  At N = 1 the Python-driver time is the headline (one GPU: the step is GPU-bound either way); at N > 1 the
+C++ driver is (`config.driver` says so; if its leg fails the Python driver's number stands) and the other is kept beside it
+(`python_driver` / `native_driver`), together with `comm`: bytes posted per neighbour and step, the time the compute stream
+waited for exchanges, and a send/recv probe of the neighbour links.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+Prints ONE JSON line (rank 0) of < 4 kB: the contract fields, `summary` (per configuration: value, ms_per_step, steps_per_s,
+frac, frac_traffic or mfma_util -- so the metric's 256^3 Jacobi and 1024^2 CNN numbers sit at the front of the line),
+`roofline` and `cpu_baseline` (+ `cpu_baseline_cnn`).  Everything else (per-configuration config / roofline / kernel times,
+prose, PMC detail) goes to the side file named in `detail_file` (gpurun_out/bench_detail.json).
+  roofline.traffic       a RECORDED PMC figure (rocprofv3 --pmc passes of an earlier run of the same kernel; `traffic_source`
+                         names file and commit), not measured in this run: HIP events and PMC passes cannot share a run
   roofline.frac          SURVEY 8d model: algorithmic bytes (16 B/cell/sweep) / launch time / 8 TB/s.  The solvers run
                          several sweeps per pass over HBM, so this can exceed 1; it is the contract's figure, not a
                          utilisation.
@@ -180,7 +187,7 @@ def cpu_baseline(w, budget_s=12.0):
                 sample=f"{n} steps of the same {w['method']} step on a {D}x{res}x{res} grid, OpenMP {threads} threads; per-cell rate")
 
 
-def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edge_first"):
+def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="deep_first"):
     """Develop the state, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then profile
     the dominant kernel class with HIP events.  Returns the JSON-able result dict (without cpu_baseline)."""
     import torch
@@ -344,16 +351,20 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="edg
                 roofline=roof)
 
 
-def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D):
+def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="deep_first"):
     """The SAME per-GPU slab step through the C++ z-slab driver (fnx_slab_step: launches, RCCL ncclSend/ncclRecv and their
-    overlap issued from C++, csrc/fnx_slab.hip), continuing from the state the headline run developed.  Reported next to the
-    headline as `native_driver`; same bits as the Python driver (tests/test_slab.py)."""
+    overlap issued from C++, csrc/fnx_slab.hip), continuing from the state the Python-driver run developed; same bits as the
+    Python driver (tests/test_slab.py).  At N > 1 it also returns `comm`: a one-off probe of the communicator (ghost exchanges
+    of 6 MiB and of 4 KiB with each neighbour: bandwidth and latency of the link as this job sees it), and from a few extra
+    steps with the driver's statistics on, the bytes posted per neighbour and step, the number of exchanges, and the time the
+    compute stream stood waiting for posted exchanges (HIP events around each stream wait)."""
     import torch
     import torch.distributed as dist
+    from fluidnet_cxx_amd._ext import ext
     from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout, rccl_comm
     layout = SlabLayout(D * world, world, rank, halo=6)
     comm = rccl_comm(rank, world) if world > 1 else None
-    sim = NativeSlabSimulator(layout, m, comm=comm, sweeps_per_exchange=6, static_flags=True, cfl_check_every=0)
+    sim = NativeSlabSimulator(layout, m, comm=comm, sweeps_per_exchange=6, static_flags=True, cfl_check_every=0, schedule=schedule)
 
     def barrier():
         torch.cuda.synchronize()
@@ -361,6 +372,19 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D):
             dist.barrier()
         torch.cuda.synchronize()
 
+    comm_info = None
+    if world > 1:
+        big, small, reps = 6 << 20, 4096, 20
+        scratch = torch.zeros(4 * big, dtype=torch.uint8, device=dev)
+        ms_big = ext.slab_comm_probe(comm, big, reps, scratch)
+        ms_small = ext.slab_comm_probe(comm, small, reps, scratch)
+        t = torch.tensor([ms_big, ms_small], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_big, ms_small = (float(x) for x in t.tolist())
+        comm_info = dict(probe_6MiB_ms=ms_big, probe_6MiB_GBps_per_direction=(big / (ms_big * 1e-3) / 1e9) if ms_big > 0 else None,
+                         probe_4KiB_us=ms_small * 1e3,
+                         probe="max over ranks of the mean of 20 grouped ncclSend/ncclRecv exchanges with each z-neighbour, back to back")
+        del scratch
     for _ in range(max(warmup, 3)):
         sim.step(bd)
     step, launch = (lambda: sim.step(bd)), "eager (C++ driver)"
@@ -385,10 +409,86 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # a few more steps with the driver's statistics on (event pairs around each wait: outside the timed region)
+        n_stat = 5
+        sim._drv.stats_enable(True)
+        for _ in range(n_stat):
+            sim.step(bd)
+        torch.cuda.synchronize()
+        st = sim._drv.stats_read()
+        sim._drv.stats_enable(False)
+        t = torch.tensor([st["wait_ms"] / n_stat, st["bytes_per_neighbour"] / n_stat], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm_info.update(wait_ms_per_step=float(t[0]), bytes_per_neighbour_per_step=float(t[1]), exchanges_per_step=st["exchanges"] / n_stat,
+                         wait="max over ranks; time the compute stream stood in front of posted ghost exchanges, HIP events, 5 untimed steps")
     cells = res * res * layout.owned * world
-    return dict(ms_per_step=elapsed / steps * 1e3, value=cells * steps / elapsed / 1e6, unit="Mcells/s", steps=steps, launch=launch,
-                transport="RCCL ncclSend/ncclRecv issued from C++ (librccl resolved at run time)" if world > 1 else None,
-                state_finite=bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all()))
+    out = dict(ms_per_step=elapsed / steps * 1e3, value=cells * steps / elapsed / 1e6, unit="Mcells/s", steps=steps, launch=launch,
+               schedule=schedule,
+               transport="RCCL ncclSend/ncclRecv issued from C++ (librccl resolved at run time)" if world > 1 else None,
+               state_finite=bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all()))
+    return out, comm_info
+
+
+def _r(x, n=4):
+    """round to n significant digits (the line is for reading; the side file keeps full precision)"""
+    if isinstance(x, float) and x == x and x not in (float("inf"), float("-inf")) and x != 0.0:
+        return float(f"{x:.{n}g}")
+    return x
+
+
+def _short(res):
+    """one configuration's entry of `summary`"""
+    rf = res.get("roofline", {})
+    e = dict(value=_r(res["value"], 5), ms_per_step=_r(res["ms_per_step"], 5), steps_per_s=_r(res["steps_per_s"], 5),
+             frac=_r(rf.get("frac")), step_hbm_frac=_r(res.get("step_hbm_frac")))
+    if rf.get("bound") == "mfma":
+        e["mfma_util"] = _r(rf.get("mfma_util"))
+    e["frac_traffic"] = _r(rf.get("frac_traffic"))
+    return e
+
+
+def pmc_source():
+    """where roofline.traffic comes from: the committed PMC table and the commit that last changed it"""
+    src = "profiles/pmc_traffic.json"
+    try:
+        c = subprocess.run(["git", "log", "-1", "--format=%h", "--", src], cwd=REPO, capture_output=True, text=True, timeout=5).stdout.strip()
+        return f"recorded rocprofv3 PMC passes, {src}" + (f" @ {c}" if c else "")
+    except Exception:  # noqa: BLE001  (no git on the box)
+        return f"recorded rocprofv3 PMC passes, {src}"
+
+
+def compact(out):
+    """(the one printed line, the side file's content).  The line: contract fields, `summary` first, a short `config` and
+    `roofline`, the CPU baselines, and at N > 1 the drivers' numbers and `comm`."""
+    name = out["config"]["workload"]
+    line = {k: out[k] for k in ("metric",)}
+    line.update(value=_r(out["value"], 6), unit=out["unit"], n_gpus=out["n_gpus"], steps=out["steps"], warmup=out["warmup"],
+                ms_per_step=_r(out["ms_per_step"], 6), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                data="synthetic", steps_per_s=_r(out["steps_per_s"], 6))
+    summ = {name: _short(out)}
+    for k, v in out.get("also", {}).items():
+        summ[k] = _short(v) if "error" not in v else dict(error=v["error"][:120])
+    line["summary"] = summ
+    c = out["config"]
+    line["config"] = {k: c.get(k) for k in ("workload", "grid_per_gpu", "global_grid", "method", "jacobi_iters", "parallelism",
+                                            "launch", "driver", "developed_steps", "world_size", "backend") if c.get(k) is not None}
+    line["config"]["static_flags"] = "flags + BC arrays promised static (obstacle mask, BC class map reused)"
+    line["config"]["state_finite"] = c.get("state_finite_after_timing")
+    rf = out["roofline"]
+    line["roofline"] = dict(bound=rf["bound"], kernel=rf["kernel"].split(" (")[0], achieved=_r(rf["achieved"], 5), peak=rf["peak"],
+                            unit=rf["unit"], frac=_r(rf["frac"]), traffic=rf.get("traffic"), frac_traffic=_r(rf.get("frac_traffic")),
+                            traffic_source=pmc_source() if rf.get("traffic") else None,
+                            launches_per_step=_r(rf.get("launches_per_step")), avg_launch_ms=_r(rf.get("avg_launch_ms")),
+                            algorithmic=rf.get("algorithmic"))
+    line["kernel_ms_per_step"] = {k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()}
+    for k in ("cpu_baseline", "cpu_baseline_cnn"):
+        if k in out:
+            line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items()}
+    for k in ("native_driver", "python_driver", "comm"):
+        if k in out:
+            line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items()}
+    line["detail_file"] = "gpurun_out/bench_detail.json"
+    return line, out
 
 
 def self_spawn(a):
@@ -431,7 +531,7 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--schedule", default="edge_first", choices=["edge_first", "last_pass"],
+    ap.add_argument("--schedule", default="deep_first", choices=["deep_first", "edge_first", "last_pass"],
                     help="N > 1: how the slab driver orders a sweep block around its ghost exchange (slab.py)")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations reported under 'also' at N=1")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous, no GPU work")
@@ -481,36 +581,48 @@ def main():
             torch.cuda.empty_cache()
     if rank == 0 and not a.no_cpu_baseline and world == 1:       # the host baseline is reported with the single-GPU line only
         out["cpu_baseline"] = cpu_baseline(WORKLOADS[name])
+    if rank == 0 and not a.no_cpu_baseline and world == 1 and a.workload is None and not a.no_also:
+        out["cpu_baseline_cnn"] = cpu_baseline(WORKLOADS["plume2d_1024_cnn"], budget_s=6.0)
     done = []
 
     def emit():
         if rank == 0 and not done:
             done.append(1)
-            print(json.dumps(out), flush=True)
+            line, detail = compact(out)
+            try:
+                os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(REPO, "gpurun_out", "bench_detail.json"), "w") as f:
+                    json.dump(detail, f, indent=1)
+            except OSError as e:
+                line["detail_file"] = f"not written ({e})"
+            print(json.dumps(line, separators=(",", ":")), flush=True)
 
     if WORKLOADS[name].get("slab") and not a.no_native:
         # the same step through the C++ driver.  It has never met more than one GPU before the driver's multi-GPU run, so
-        # it runs under a watchdog: if it is not through in time the headline line is printed without it and the job ends
+        # it runs under a watchdog: if it is not through in time the Python-driver line is printed without it and the job ends
         import threading
 
         def bail():
             out["native_driver"] = dict(error="the native-driver leg did not finish within its time limit")
             emit()
             os._exit(0)
-        dog = threading.Timer(120.0, bail)
+        dog = threading.Timer(180.0, bail)
         dog.daemon = True
         dog.start()
         try:
             bd_s, m_s = run_workload.slab_state
-            out["native_driver"] = run_native_slab(a.steps, a.warmup, world, rank, dev, bd_s, m_s, WORKLOADS[name]["res"], WORKLOADS[name]["D"])
+            out["native_driver"], comm_info = run_native_slab(a.steps, a.warmup, world, rank, dev, bd_s, m_s, WORKLOADS[name]["res"],
+                                                              WORKLOADS[name]["D"], a.schedule)
+            if comm_info:
+                out["comm"] = comm_info
         except Exception as e:  # noqa: BLE001
             out["native_driver"] = dict(error=f"{type(e).__name__}: {e}")
         dog.cancel()
         nd = out["native_driver"]
         out["config"]["driver"] = "python (fluidnet_cxx_amd/slab.py over torch.distributed P2P)"
-        if world > 1 and "error" not in nd and nd.get("state_finite") and nd["ms_per_step"] < out["ms_per_step"]:
-            # N > 1: both drivers issue the same kernels and exchanges (same bits, tests/test_slab.py); the one whose K timed
-            # steps ran faster is the headline, the other is kept beside it
+        if world > 1 and "error" not in nd and nd.get("state_finite"):
+            # N > 1: the C++ driver is the product path (launches and RCCL calls issued from C++); both drivers issue the same
+            # kernels and exchanges (same bits, tests/test_slab.py), the Python driver's time is kept beside it
             out["python_driver"] = dict(ms_per_step=out["ms_per_step"], value=out["value"], unit="Mcells/s", steps=out["steps"])
             out["value"], out["ms_per_step"] = nd["value"], nd["ms_per_step"]
             out["steps_per_s"] = 1e3 / nd["ms_per_step"]

@@ -425,9 +425,11 @@ struct PySlab {
   FnxSlabConfig cfg{};
   std::shared_ptr<PySlabComm> comm;
   PySlab(int B, int H, int W, int D_global, int rank, int nranks, int halo, int sweeps_per_exchange, bool static_flags,
-         int cfl_check_every, std::shared_ptr<PySlabComm> comm_) : comm(comm_) {
+         int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule) : comm(comm_) {
     cfg.B = B; cfg.H = H; cfg.W = W; cfg.D_global = D_global; cfg.rank = rank; cfg.nranks = nranks; cfg.halo = halo;
     cfg.sweeps_per_exchange = sweeps_per_exchange; cfg.static_flags = static_flags ? 1 : 0; cfg.cfl_check_every = cfl_check_every;
+    TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass", "unknown z-slab schedule '", schedule, "'");
+    cfg.schedule = schedule == "deep_first" ? FNX_SLAB_DEEP_FIRST : (schedule == "edge_first" ? FNX_SLAB_EDGE_FIRST : FNX_SLAB_LAST_PASS);
     check_status(fnx_slab_create(&s, &cfg, comm ? &comm->c : nullptr));
   }
   ~PySlab() { fnx_slab_destroy(s); }
@@ -437,6 +439,14 @@ struct PySlab {
     return {o, l, h, z};
   }
   int64_t workspace_bytes() const { return (int64_t)fnx_slab_workspace_bytes(&cfg); }
+  void stats_enable(bool on) { check_status(fnx_slab_stats_enable(s, on ? 1 : 0)); }
+  py::dict stats_read() {
+    FnxSlabStats t{};
+    check_status(fnx_slab_stats_read(s, &t));
+    py::dict d;
+    d["bytes_per_neighbour"] = t.bytes_per_neighbour; d["wait_ms"] = t.wait_ms; d["exchanges"] = (int64_t)t.exchanges;
+    return d;
+  }
   void step(Tensor p, Tensor U, Tensor flags, Tensor density, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
             c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask, double dt, double maccormack_strength,
             bool sample_outside_fluid, double buoyancy_scale, std::vector<double> gravity_vec, double operating_density,
@@ -676,10 +686,22 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("slab_rccl_unique_id", &slab_rccl_unique_id);
   m.def("slab_comm_rccl", &slab_comm_rccl, py::arg("rank"), py::arg("nranks"), py::arg("unique_id"));
   m.def("slab_comm_loopback", &slab_comm_loopback, py::arg("group"), py::arg("rank"));
+  m.def("slab_comm_probe", [](std::shared_ptr<PySlabComm> comm, int64_t bytes, int reps, Tensor scratch) {
+    TORCH_CHECK(scratch.is_cuda() && scratch.is_contiguous() && (int64_t)scratch.numel() * scratch.element_size() >= 4 * bytes,
+                "slab_comm_probe: scratch must be a contiguous GPU tensor of at least 4 * bytes");
+    c10::hip::HIPGuard guard(scratch.get_device());
+    float ms = 0.f;
+    { py::gil_scoped_release nogil;
+      check_status(fnx_slab_comm_probe(&comm->c, scratch.data_ptr(), (size_t)bytes, reps, &ms, cur_stream(scratch))); }
+    return (double)ms;
+  }, py::arg("comm"), py::arg("bytes"), py::arg("reps"), py::arg("scratch"),
+        "average ms of one ghost exchange of `bytes` bytes with each neighbour (every rank must call it)");
   py::class_<PySlab>(m, "SlabDriver", "native z-slab driver of the 3D Jacobi step (fnx_slab_create / fnx_slab_step)")
-      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>>(), py::arg("B"), py::arg("H"),
+      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>, const std::string&>(), py::arg("B"), py::arg("H"),
            py::arg("W"), py::arg("D_global"), py::arg("rank"), py::arg("nranks"), py::arg("halo"), py::arg("sweeps_per_exchange"),
-           py::arg("static_flags") = false, py::arg("cfl_check_every") = 0, py::arg("comm") = nullptr)
+           py::arg("static_flags") = false, py::arg("cfl_check_every") = 0, py::arg("comm") = nullptr, py::arg("schedule") = "deep_first")
+      .def("stats_enable", &PySlab::stats_enable, py::arg("on"))
+      .def("stats_read", &PySlab::stats_read, "dict(bytes_per_neighbour, wait_ms, exchanges) since stats_enable(True); synchronises")
       .def("layout", &PySlab::layout, "(owned planes, ghost planes below, above, global plane of local plane 0)")
       .def("workspace_bytes", &PySlab::workspace_bytes)
       .def("step", &PySlab::step, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"),

@@ -4,12 +4,14 @@
 // (ncclSend/ncclRecv between z-neighbours, loaded with dlopen) and an in-process one (several slabs of a domain driven by
 // host threads of one process; the lock-step tests and single-process multi-device runs).
 //
-// The schedule is the one fluidnet_cxx_amd/slab.py documents ("edge_first"): per step
+// The schedules are the ones fluidnet_cxx_amd/slab.py documents ("deep_first", the default; "edge_first"; "last_pass"): per step
 //   1. ghost exchange of U, density (4 planes) posted; the planes whose advection reads no ghost plane are advected
 //      meanwhile, the two 4-plane edge windows after it has landed
-//   2. BC / buoyancy / wall stage + divergence on the owned planes; blocking exchange of div (w-1 planes)
-//   3. blocks of w Jacobi sweeps: the edge parts of all passes of a block first (a closed chain that ends in the w owned
-//      planes each neighbour needs), their exchange posted, the interior parts while it is in flight
+//   2. BC / buoyancy / wall stage + divergence on the owned planes; exchange of div (w-1 planes) posted
+//   3. blocks of w Jacobi sweeps.  deep_first: the deep parts of all passes of a block (they read no ghost plane) while the
+//      previous exchange is in flight, then the wait, then the edge parts (a chain of short launches that ends in the w owned
+//      planes each neighbour needs), their exchange posted.  edge_first: the edge parts first, the interior parts behind the
+//      posted exchange (div exchanged blocking)
 //   4. exchange of p (1 plane), velocity update + wall BCs + BCs on the owned planes
 // Every owned cell goes through the arithmetic of the single-domain step: same bits (tests/test_slab.py).
 #include <dlfcn.h>
@@ -17,6 +19,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -51,6 +55,7 @@ struct RcclApi {
   int (*GetUniqueId)(NcclUniqueId*) = nullptr;
   int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
   int (*CommDestroy)(NcclComm) = nullptr;
+  int (*CommAbort)(NcclComm) = nullptr;       // optional
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -75,6 +80,7 @@ int rccl_api(RcclApi** out) {
     api.GetUniqueId = (int (*)(NcclUniqueId*))sym("ncclGetUniqueId");
     api.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))sym("ncclCommInitRank");
     api.CommDestroy = (int (*)(NcclComm))sym("ncclCommDestroy");
+    api.CommAbort = (int (*)(NcclComm))sym("ncclCommAbort");
     api.GroupStart = (int (*)())sym("ncclGroupStart");
     api.GroupEnd = (int (*)())sym("ncclGroupEnd");
     api.Send = (int (*)(const void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclSend");
@@ -103,15 +109,25 @@ int rccl_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
   RcclCtx* c = (RcclCtx*)vctx;
   hipStream_t s = (hipStream_t)stream;
   NCCL_OK(c, c->api->GroupStart());
-  for (int i = 0; i < nsegs; ++i) {
+  // a failed Send / Recv must not leave the group open (it would poison every later call of this thread): the first
+  // error is kept, the group is closed, then the error is reported
+  int first = 0; const char* where = "";
+  auto rec = [&](int r, const char* w) { if (r != 0 && first == 0) { first = r; where = w; } };
+  for (int i = 0; i < nsegs && first == 0; ++i) {
     const FnxSlabSeg& g = segs[i];
-    if (c->rank > 0 && g.send_lo) NCCL_OK(c, c->api->Send(g.send_lo, g.bytes, kNcclInt8, c->rank - 1, c->comm, s));
-    if (c->rank > 0 && g.recv_lo) NCCL_OK(c, c->api->Recv(g.recv_lo, g.bytes, kNcclInt8, c->rank - 1, c->comm, s));
-    if (c->rank < c->nranks - 1 && g.send_hi) NCCL_OK(c, c->api->Send(g.send_hi, g.bytes, kNcclInt8, c->rank + 1, c->comm, s));
-    if (c->rank < c->nranks - 1 && g.recv_hi) NCCL_OK(c, c->api->Recv(g.recv_hi, g.bytes, kNcclInt8, c->rank + 1, c->comm, s));
+    if (c->rank > 0 && g.send_lo) rec(c->api->Send(g.send_lo, g.bytes, kNcclInt8, c->rank - 1, c->comm, s), "ncclSend");
+    if (c->rank > 0 && g.recv_lo) rec(c->api->Recv(g.recv_lo, g.bytes, kNcclInt8, c->rank - 1, c->comm, s), "ncclRecv");
+    if (c->rank < c->nranks - 1 && g.send_hi) rec(c->api->Send(g.send_hi, g.bytes, kNcclInt8, c->rank + 1, c->comm, s), "ncclSend");
+    if (c->rank < c->nranks - 1 && g.recv_hi) rec(c->api->Recv(g.recv_hi, g.bytes, kNcclInt8, c->rank + 1, c->comm, s), "ncclRecv");
   }
-  NCCL_OK(c, c->api->GroupEnd());
+  const int end = c->api->GroupEnd();
+  if (first != 0) return fnx::set_error(FNX_ECOMM, "RCCL error %d (%s) in %s", first, c->api->GetErrorString ? c->api->GetErrorString(first) : "?", where);
+  NCCL_OK(c, end);
   return FNX_OK;
+}
+void rccl_abort(void* vctx) {
+  RcclCtx* c = (RcclCtx*)vctx;
+  if (c->comm && c->api->CommAbort) { c->api->CommAbort(c->comm); c->comm = nullptr; }
 }
 int rccl_allreduce_max(void* vctx, float* x, int n, void* stream) {
   RcclCtx* c = (RcclCtx*)vctx;
@@ -141,7 +157,10 @@ struct LoopPair {
   int phase = 0;                 // 0: empty, 1: first party posted, 2: copies enqueued (first party may pick up)
   std::vector<FnxSlabSeg> segs;  // the first party's segments
   bool first_is_lower = false;
-  hipEvent_t ev_first = nullptr, ev_done = nullptr;
+  // one event per SIDE (0: the lower rank of the pair, 1: the upper one), created lazily by that side on ITS device and only
+  // ever recorded on its own streams; the other side only waits on it (an event and the stream it is recorded on must belong
+  // to the same device)
+  hipEvent_t ev[2] = {nullptr, nullptr};
   int rc = FNX_OK;
 };
 struct LoopGroup {
@@ -149,26 +168,44 @@ struct LoopGroup {
   std::vector<LoopPair> pairs;   // pair i: ranks i, i+1
   std::mutex mu; std::condition_variable cv;
   int red_count = 0, red_gen = 0; float red_val[64], red_out[64]; int red_n = 0;   // (red_out: a finished round's result, safe from the next round's first arrival)
+  std::atomic<bool> aborted{false};   // a rank failed: every party waiting for a peer gives up (FNX_ECOMM) instead of hanging
   explicit LoopGroup(int n) : nranks(n), pairs(n > 1 ? n - 1 : 0) {}
 };
 struct LoopCtx { LoopGroup* g; int rank; };
+constexpr int kLoopPeerTimeoutS = 120;   // a peer that never arrives (it failed before its exchange call) is an error, not a hang
+
+// waits on `cv` until pred() holds; false when the group was aborted or the peer did not show up in time
+template <class Pred>
+bool loop_wait(LoopGroup* g, std::condition_variable& cv, std::unique_lock<std::mutex>& lk, Pred pred) {
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(kLoopPeerTimeoutS);
+  while (!pred()) {
+    if (g->aborted.load()) return false;
+    if (cv.wait_for(lk, std::chrono::milliseconds(50)) == std::cv_status::timeout && std::chrono::steady_clock::now() > deadline) {
+      g->aborted.store(true);
+      return false;
+    }
+  }
+  return !g->aborted.load() || pred();
+}
+int loop_gone() { return fnx::set_error(FNX_ECOMM, "loopback exchange: a peer rank failed or did not arrive (group aborted)"); }
 
 // one side of pair `pi`; lower = this rank is the lower one of the pair (it sends its *_hi pointers)
 int loop_meet(LoopGroup* g, int pi, bool lower, const FnxSlabSeg* segs, int nsegs, hipStream_t s) {
   LoopPair& P = g->pairs[pi];
+  const int me = lower ? 0 : 1, other = 1 - me;
   std::unique_lock<std::mutex> lk(P.mu);
-  P.cv.wait(lk, [&] { return P.phase == 0 || (P.phase == 1 && P.first_is_lower != lower); });
+  if (!loop_wait(g, P.cv, lk, [&] { return P.phase == 0 || (P.phase == 1 && P.first_is_lower != lower); })) return loop_gone();
+  if (!P.ev[me]) SLAB_HIP(hipEventCreateWithFlags(&P.ev[me], hipEventDisableTiming));
   if (P.phase == 0) {                       // first to arrive
     P.segs.assign(segs, segs + nsegs);
     P.first_is_lower = lower;
     P.rc = FNX_OK;
-    if (!P.ev_first) { SLAB_HIP(hipEventCreateWithFlags(&P.ev_first, hipEventDisableTiming)); SLAB_HIP(hipEventCreateWithFlags(&P.ev_done, hipEventDisableTiming)); }
-    SLAB_HIP(hipEventRecord(P.ev_first, s));
+    SLAB_HIP(hipEventRecord(P.ev[me], s));
     P.phase = 1;
     P.cv.notify_all();
-    P.cv.wait(lk, [&] { return P.phase == 2; });
+    if (!loop_wait(g, P.cv, lk, [&] { return P.phase == 2; })) { P.phase = 0; P.cv.notify_all(); return loop_gone(); }
     const int rc = P.rc;
-    hipError_t e = hipStreamWaitEvent(s, P.ev_done, 0);
+    hipError_t e = rc == FNX_OK ? hipStreamWaitEvent(s, P.ev[other], 0) : hipSuccess;
     P.phase = 0;
     P.cv.notify_all();
     if (rc != FNX_OK) return rc;
@@ -178,7 +215,7 @@ int loop_meet(LoopGroup* g, int pi, bool lower, const FnxSlabSeg* segs, int nseg
   // second to arrive: both parties' buffers are known
   int rc = FNX_OK;
   if ((int)P.segs.size() != nsegs) rc = fnx::set_error(FNX_ECOMM, "loopback exchange: the two ranks of a pair posted %zu and %d segments", P.segs.size(), nsegs);
-  if (rc == FNX_OK && hipStreamWaitEvent(s, P.ev_first, 0) != hipSuccess) rc = fnx::set_error(FNX_EHIP, "hipStreamWaitEvent failed");
+  if (rc == FNX_OK && hipStreamWaitEvent(s, P.ev[other], 0) != hipSuccess) rc = fnx::set_error(FNX_EHIP, "hipStreamWaitEvent failed");
   for (int i = 0; i < nsegs && rc == FNX_OK; ++i) {
     const FnxSlabSeg& lo = lower ? segs[i] : P.segs[i];     // the lower rank's segment: its hi side faces the pair
     const FnxSlabSeg& hi = lower ? P.segs[i] : segs[i];
@@ -188,7 +225,7 @@ int loop_meet(LoopGroup* g, int pi, bool lower, const FnxSlabSeg* segs, int nseg
     if (lo.recv_hi && hi.send_lo && hipMemcpyAsync(lo.recv_hi, hi.send_lo, lo.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
       rc = fnx::set_error(FNX_EHIP, "hipMemcpyAsync failed");
   }
-  if (hipEventRecord(P.ev_done, s) != hipSuccess && rc == FNX_OK) rc = fnx::set_error(FNX_EHIP, "hipEventRecord failed");
+  if (rc == FNX_OK && hipEventRecord(P.ev[me], s) != hipSuccess) rc = fnx::set_error(FNX_EHIP, "hipEventRecord failed");
   P.rc = rc;
   P.phase = 2;
   P.cv.notify_all();
@@ -213,7 +250,7 @@ int loop_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
     if (g->red_count == 0) { g->red_n = n; for (int i = 0; i < n; ++i) g->red_val[i] = h[i]; }
     else for (int i = 0; i < n; ++i) g->red_val[i] = sum ? g->red_val[i] + h[i] : (h[i] > g->red_val[i] ? h[i] : g->red_val[i]);
     if (++g->red_count == g->nranks) { g->red_count = 0; for (int i = 0; i < n; ++i) g->red_out[i] = g->red_val[i]; ++g->red_gen; g->cv.notify_all(); }
-    else g->cv.wait(lk, [&] { return g->red_gen != gen; });
+    else if (!loop_wait(g, g->cv, lk, [&] { return g->red_gen != gen; })) return loop_gone();
     for (int i = 0; i < n; ++i) h[i] = g->red_out[i];
   }
   SLAB_HIP(hipMemcpyAsync(x, h, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -223,6 +260,12 @@ int loop_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
 int loop_allreduce_max(void* vctx, float* x, int n, void* stream) { return loop_allreduce(vctx, x, n, stream, false); }
 int loop_allreduce_sum(void* vctx, float* x, int n, void* stream) { return loop_allreduce(vctx, x, n, stream, true); }
 void loop_destroy(void* vctx) { delete (LoopCtx*)vctx; }
+void loop_abort(void* vctx) {
+  LoopGroup* g = ((LoopCtx*)vctx)->g;
+  g->aborted.store(true);
+  for (LoopPair& p : g->pairs) p.cv.notify_all();
+  g->cv.notify_all();
+}
 
 }  // namespace
 
@@ -237,6 +280,12 @@ struct FnxSlab {
   hipEvent_t ev_post = nullptr, ev_done = nullptr;
   bool pending = false;
   float* h_cfl = nullptr;    // pinned host float
+  // optional statistics (fnx_slab_stats_enable): bytes posted per neighbour and direction, exchanges, and how long the
+  // compute stream stood at each wait -- an event pair around the stream wait, read back in fnx_slab_stats_read
+  bool stats_on = false;
+  FnxSlabStats stats{};
+  std::vector<hipEvent_t> wait_ev;   // pairs: [2i] before, [2i+1] after the i-th wait since the last read
+  size_t wait_used = 0;
 };
 
 namespace {
@@ -248,6 +297,8 @@ int layout_of(const FnxSlabConfig* c, int* owned, int* lo, int* hi, int* zoff) {
   if (c->D_global % c->nranks) return fnx::set_error(FNX_EINVAL, "slab: D must divide evenly across ranks");
   const int ow = c->D_global / c->nranks;
   if (c->nranks > 1 && c->halo < 5) return fnx::set_error(FNX_EINVAL, "slab: advection + projection need 5 valid ghost planes (CFL <= 1)");
+  if (c->halo > FNX_SLAB_MAX_HALO) return fnx::set_error(FNX_EINVAL, "slab: halo %d > %d planes is not supported", c->halo, FNX_SLAB_MAX_HALO);
+  if (c->schedule < FNX_SLAB_DEEP_FIRST || c->schedule > FNX_SLAB_LAST_PASS) return fnx::set_error(FNX_EINVAL, "slab: unknown schedule %d", c->schedule);
   if (c->nranks > 1 && ow < c->halo) return fnx::set_error(FNX_EINVAL, "slab thinner than its halo");
   *owned = ow;
   *lo = c->rank > 0 ? c->halo : 0;
@@ -315,11 +366,29 @@ int post(FnxSlab* s, float* const* fields, float* const* sources, const int* cha
   SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), s->comm_stream));
   SLAB_HIP(hipEventRecord(s->ev_done, s->comm_stream));
   s->pending = true;
+  if (s->stats_on) {
+    size_t b = 0;
+    for (const FnxSlabSeg& g : segs) b += g.bytes;
+    s->stats.bytes_per_neighbour += (double)b;
+    s->stats.exchanges += 1;
+  }
   return FNX_OK;
 }
 int wait(FnxSlab* s, hipStream_t stream) {
   if (!s->pending) return FNX_OK;
+  hipEvent_t *e0 = nullptr, *e1 = nullptr;
+  if (s->stats_on) {
+    if (s->wait_used + 2 > s->wait_ev.size()) {
+      hipEvent_t a, b;
+      SLAB_HIP(hipEventCreate(&a)); SLAB_HIP(hipEventCreate(&b));
+      s->wait_ev.push_back(a); s->wait_ev.push_back(b);
+    }
+    e0 = &s->wait_ev[s->wait_used]; e1 = &s->wait_ev[s->wait_used + 1];
+    s->wait_used += 2;
+    SLAB_HIP(hipEventRecord(*e0, stream));
+  }
   SLAB_HIP(hipStreamWaitEvent(stream, s->ev_done, 0));
+  if (e1) SLAB_HIP(hipEventRecord(*e1, stream));
   s->pending = false;
   return FNX_OK;
 }
@@ -354,6 +423,7 @@ int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* uniqu
   const int r = api->CommInitRank(&c->comm, nranks, id, rank);
   if (r != 0) { delete c; return fnx::set_error(FNX_ECOMM, "ncclCommInitRank failed (%d: %s)", r, api->GetErrorString ? api->GetErrorString(r) : "?"); }
   out->ctx = c; out->exchange = rccl_exchange; out->allreduce_max = rccl_allreduce_max; out->allreduce_sum = rccl_allreduce_sum; out->destroy = rccl_destroy;
+  out->abort = rccl_abort;
   return FNX_OK;
 }
 
@@ -366,17 +436,18 @@ int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank) {
   LoopGroup* g = (LoopGroup*)group;
   if (!out || !g || rank < 0 || rank >= g->nranks) return fnx::set_error(FNX_EINVAL, "loopback comm: bad arguments");
   out->ctx = new LoopCtx{g, rank}; out->exchange = loop_exchange; out->allreduce_max = loop_allreduce_max; out->allreduce_sum = loop_allreduce_sum; out->destroy = loop_destroy;
+  out->abort = loop_abort;
   return FNX_OK;
 }
 void fnx_slab_loopback_group_free(void* group) {
   LoopGroup* g = (LoopGroup*)group;
   if (!g) return;
-  for (LoopPair& p : g->pairs) { if (p.ev_first) (void)hipEventDestroy(p.ev_first); if (p.ev_done) (void)hipEventDestroy(p.ev_done); }
+  for (LoopPair& p : g->pairs) for (hipEvent_t e : p.ev) if (e) (void)hipEventDestroy(e);
   delete g;
 }
 void fnx_slab_comm_free(FnxSlabComm* comm) {
   if (comm && comm->destroy && comm->ctx) comm->destroy(comm->ctx);
-  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->allreduce_sum = nullptr; comm->destroy = nullptr; }
+  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->allreduce_sum = nullptr; comm->destroy = nullptr; comm->abort = nullptr; }
 }
 
 int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset) {
@@ -433,10 +504,61 @@ void fnx_slab_destroy(FnxSlab* s) {
   if (s->ev_post) (void)hipEventDestroy(s->ev_post);
   if (s->ev_done) (void)hipEventDestroy(s->ev_done);
   if (s->h_cfl) (void)hipHostFree(s->h_cfl);
+  for (hipEvent_t e : s->wait_ev) (void)hipEventDestroy(e);
   delete s;
 }
 
+int fnx_slab_stats_enable(FnxSlab* s, int on) {
+  if (!s) return fnx::set_error(FNX_EINVAL, "slab_stats_enable: NULL slab");
+  s->stats_on = on != 0;
+  s->stats = FnxSlabStats{};
+  s->wait_used = 0;
+  return FNX_OK;
+}
+
+int fnx_slab_stats_read(FnxSlab* s, FnxSlabStats* out) {
+  if (!s || !out) return fnx::set_error(FNX_EINVAL, "slab_stats_read: NULL argument");
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < s->wait_used; i += 2) {
+    float t = 0.f;
+    SLAB_HIP(hipEventSynchronize(s->wait_ev[i + 1]));
+    if (hipEventElapsedTime(&t, s->wait_ev[i], s->wait_ev[i + 1]) == hipSuccess) ms += t;
+  }
+  s->stats.wait_ms += ms;
+  s->wait_used = 0;
+  *out = s->stats;
+  return FNX_OK;
+}
+
+int fnx_slab_comm_probe(const FnxSlabComm* comm, void* scratch, size_t bytes, int reps, float* ms_per_exchange, void* vstream) {
+  if (!comm || !comm->exchange || !scratch || bytes == 0 || reps < 1 || !ms_per_exchange) return fnx::set_error(FNX_EINVAL, "slab_comm_probe: bad arguments");
+  hipStream_t stream = (hipStream_t)vstream;
+  char* b = (char*)scratch;
+  FnxSlabSeg g{};
+  g.send_lo = b; g.recv_lo = b + bytes; g.send_hi = b + 2 * bytes; g.recv_hi = b + 3 * bytes; g.bytes = bytes;
+  hipEvent_t e0, e1;
+  SLAB_HIP(hipEventCreate(&e0)); SLAB_HIP(hipEventCreate(&e1));
+  int rc = comm->exchange(comm->ctx, &g, 1, stream);                      // warm-up (connection set-up)
+  if (rc == FNX_OK && hipEventRecord(e0, stream) != hipSuccess) rc = fnx::set_error(FNX_EHIP, "hipEventRecord failed");
+  for (int i = 0; i < reps && rc == FNX_OK; ++i) rc = comm->exchange(comm->ctx, &g, 1, stream);
+  if (rc == FNX_OK && (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fnx::set_error(FNX_EHIP, "probe: event failed");
+  float t = 0.f;
+  if (rc == FNX_OK && hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = fnx::set_error(FNX_EHIP, "probe: elapsed time failed");
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc == FNX_OK) *ms_per_exchange = t / reps;
+  return rc;
+}
+
+static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* vstream);
+
 int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* vstream) {
+  const int rc = slab_step_body(s, prm, st, ws, ws_bytes, vstream);
+  // a rank that fails must not leave its neighbours waiting in an exchange it will never join
+  if (rc != FNX_OK && rc != FNX_ECFL && s && s->cfg.nranks > 1 && s->comm.abort) s->comm.abort(s->comm.ctx);
+  return rc;
+}
+
+static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* vstream) {
   if (!s || !prm || !st) return fnx::set_error(FNX_EINVAL, "slab_step: NULL argument");
   if (!st->p || !st->U || !st->flags || !st->density) return fnx::set_error(FNX_EINVAL, "slab_step: the z-slab driver needs p, U, flags and a density field");
   if (prm->method != 0) return fnx::set_error(FNX_EINVAL, "slab_step: only the Jacobi projection shards (the CNN configurations are single-GPU)");
@@ -504,7 +626,12 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
   }
   float* fd[1] = {W.div};
   const int c1[1] = {1};
-  SLAB_OK(xchg(s, fd, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
+  // sweep blocks with an exchange between them (else: thin slabs, short solves, pTol: the "last_pass" code below)
+  const bool blocked = world > 1 && s->owned >= 4 * w && prm->jacobi_iter > w && !(prm->p_tol > 0.f);
+  const bool deep = blocked && s->cfg.schedule == FNX_SLAB_DEEP_FIRST;
+  // deep_first: the deep parts of the first sweep block read no ghost plane of div, its exchange is in flight behind them
+  if (deep) SLAB_OK(post(s, fd, nullptr, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
+  else SLAB_OK(xchg(s, fd, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
 
   // ---- 3. Jacobi: blocks of w sweeps between ghost exchanges of p
   const FnxGrid gj = grid_of(s);
@@ -512,12 +639,32 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
   auto pass = [&](const float* pin, float* pout, int n, int kb, int ke, int kb2 = -1, int lay = 0) {
     const int rc = fnx_jacobi_pass_layout(&gj, st->flags, W.div, pin, pout, n, kb, ke, kb2, pin ? lay : (lay & 2), W.jac, W.jac_bytes,
                                           s->mask_valid ? 1 : 0, stream);
-    s->mask_valid = true;
+    if (rc == FNX_OK) s->mask_valid = true;     // (a failed call may not have built the mask)
     return rc;
   };
   float *cur = st->p, *nxt = W.pbuf;
   int remaining = prm->jacobi_iter;
   bool zero_in = true;                       // the solve starts from p = 0 everywhere: the first pass reads nothing
+  // passes of a sweep block (an odd block runs its single sweep first), and whether they hand each other the pressure in the
+  // solver's row-quad layout (both arrays, every plane range, the ghost planes the neighbours send -- they run the same
+  // schedule); the last pass of the solve writes rows
+  int npass = 0, passes[FNX_SLAB_MAX_HALO];
+  if (w % 2) passes[npass++] = 1;
+  for (int i = 0; i < w / 2; ++i) passes[npass++] = 2;
+  const bool quad = w % 2 == 0 && prm->jacobi_iter % 2 == 0 && fnx_jacobi_quad_ok(&gj) != 0;
+  const int Q = quad ? 3 : 0;
+  // the last block of a blocked solve (<= w sweeps, no exchange after it): whole shrinking ranges
+  auto last_block = [&]() {
+    int done = 0;
+    for (int left = remaining; left > 0;) {
+      const int n = left >= 2 ? 2 : 1;
+      left -= n; done += n;
+      const int g = w - done > 0 ? w - done : 0;
+      SLAB_OK(pass(cur, nxt, n, has_lo ? lo - g : 0, has_hi ? top + g : DL, -1, left > 0 ? Q : (Q & 1)));
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    return (int)FNX_OK;
+  };
   if (prm->p_tol > 0.f) {
     // the reference's convergence test (fluids_init.cpp:961-979; slab.py:_jacobi_ptol): one sweep per ghost exchange, the
     // squared differences over the OWNED planes summed over the ranks, max over the samples of the root against pTol
@@ -547,16 +694,46 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
     // solver's row-quad layout, which the plane-range passes below do not)
     SLAB_OK(fnx_jacobi_sweeps_ex(&gj, st->flags, W.div, cur, prm->jacobi_iter, W.jac, W.jac_bytes, (s->mask_valid ? 1 : 0) | 2, stream));
     s->mask_valid = true;
-  } else if (world > 1 && s->owned >= 4 * w && remaining > w) {
+  } else if (deep) {
+    // "deep_first" (slab.py:_jacobi_deep_first): pass k of a block is cut split[k] planes inside each internal face; the deep
+    // parts of all passes run first (no ghost plane read: the previous exchange is still in flight), then the wait, then
+    // the edge parts (a chain of short launches), then the w owned planes next to each face go to the neighbours
+    int split[FNX_SLAB_MAX_HALO];
+    for (int k = 0, sp = 0; k < npass; ++k) {
+      sp = k == 0 ? passes[k] : (sp + passes[k] > w ? sp + passes[k] : w);
+      split[k] = sp;
+    }
+    if (s->owned < 2 * split[npass - 1] + 1) return fnx::set_error(FNX_EINVAL, "slab too thin for the deep_first sweep block");
+    while (remaining > w) {
+      remaining -= w;
+      float *src = cur, *dst = nxt;
+      for (int pi = 0; pi < npass; ++pi) {
+        SLAB_OK(pass((zero_in && pi == 0) ? nullptr : src, dst, passes[pi], has_lo ? lo + split[pi] : 0, has_hi ? top - split[pi] : DL, -1, Q));
+        float* t = src; src = dst; dst = t;
+      }
+      SLAB_OK(wait(s, stream));              // the ghost planes of `cur` (first block: of div)
+      src = cur; dst = nxt;
+      int done = 0;
+      for (int pi = 0; pi < npass; ++pi) {
+        const int n = passes[pi];
+        done += n;
+        const float* pin = (zero_in && pi == 0) ? nullptr : src;
+        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q));
+        else {
+          if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], -1, Q));
+          if (has_hi) SLAB_OK(pass(pin, dst, n, top - split[pi], top + w - done, -1, Q));
+        }
+        float* t = src; src = dst; dst = t;
+      }
+      if (src != cur) { float* t = cur; cur = nxt; nxt = t; }
+      float* ff[1] = {cur};
+      SLAB_OK(post(s, ff, nullptr, c1, 1, w, stream));
+      zero_in = false;
+    }
+    SLAB_OK(wait(s, stream));
+    SLAB_OK(last_block());
+  } else if (blocked && s->cfg.schedule == FNX_SLAB_EDGE_FIRST) {
     // "edge_first" (slab.py:_jacobi_edge_first)
-    int npass = 0, passes[64];
-    if (w % 2) passes[npass++] = 1;
-    for (int i = 0; i < w / 2; ++i) passes[npass++] = 2;
-    // every pass of the solve is a two-sweep pass: they hand each other the pressure in the solver's row-quad layout (both
-    // arrays, every plane range, the ghost planes the neighbours send -- they run the same schedule); the last pass of the
-    // solve writes rows
-    const bool quad = w % 2 == 0 && prm->jacobi_iter % 2 == 0 && fnx_jacobi_quad_ok(&gj) != 0;
-    const int Q = quad ? 3 : 0;
     int block = 0;
     while (remaining > w) {
       remaining -= w;
@@ -588,16 +765,9 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
       zero_in = false;
     }
     SLAB_OK(wait(s, stream));
-    int done = 0;
-    for (int left = remaining; left > 0;) {
-      const int n = left >= 2 ? 2 : 1;
-      left -= n; done += n;
-      const int g = w - done > 0 ? w - done : 0;
-      SLAB_OK(pass(cur, nxt, n, has_lo ? lo - g : 0, has_hi ? top + g : DL, -1, left > 0 ? Q : (Q & 1)));
-      float* t = cur; cur = nxt; nxt = t;
-    }
+    SLAB_OK(last_block());
   } else {
-    // "last_pass" (slab.py:_jacobi_last_pass): thin slabs, short solves, and the single-rank case
+    // "last_pass" (slab.py:_jacobi_last_pass): thin slabs, short solves
     bool pending = false, first = true;
     while (remaining > 0) {
       const int k = w < remaining ? w : remaining;

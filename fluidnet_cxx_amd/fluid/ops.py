@@ -130,15 +130,20 @@ class _SetWallBcsFn(torch.autograd.Function):
         return g, None, None
 
 
-def _needs_grad(*ts):
-    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+def _needs_grad(*ts, geom=None):
+    need = torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+    # the adjoint entry points cover whole fields; a windowed forward (planes outside [k_begin, k_end) left as they were)
+    # has no matching backward
+    assert not (need and geom is not None and (geom.k_begin != 0 or geom.k_end != 0)), \
+        "autograd through an operator with a compute window (Geom.k_begin / k_end) is not supported"
+    return need
 
 
 def velocityDivergence(U, flags, *, geom=None):
     """lib/fluid/velocity_divergence.py:4-74 (differentiable w.r.t. U)"""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
-    if _needs_grad(U):
+    if _needs_grad(U, geom=geom):
         return _DivergenceFn.apply(U, flags, geom)
     return ext.velocity_divergence(U, flags, geom)
 
@@ -148,7 +153,7 @@ def velocityUpdate(pressure, U, flags, *, geom=None):
     _check5(pressure, U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
     assert pressure.shape == flags.shape, "size mismatch"
-    if _needs_grad(pressure, U):
+    if _needs_grad(pressure, U, geom=geom):
         _VelocityUpdateFn.apply(pressure, U, flags, geom)
         return
     ext.velocity_update_(pressure, U, flags, geom)
@@ -186,7 +191,7 @@ def setWallBcs(U, flags, *, geom=None):
     """lib/fluid/set_wall_bcs.py:4-86 -- in place on U, returns U (differentiable w.r.t. U)."""
     _check5(U, flags)
     assert flags.size(1) == 1, "flags is not a scalar"
-    if _needs_grad(U):
+    if _needs_grad(U, geom=geom):
         return _SetWallBcsFn.apply(U, flags, geom)
     ext.set_wall_bcs_(U, flags, geom)
     return U

@@ -197,13 +197,13 @@ class NativeOps:
 class SlabSimulator:
     """`simulate(mconf, batch_dict, None, 'jacobi')` for one rank's slab of a 3D domain (in place on `state`)."""
 
-    def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4, schedule="edge_first",
+    def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4, schedule="deep_first",
                  static_flags=False, cfl_check_every=8):
         """cfl_check_every: every that many steps (0 = never) the step starts by reducing max |U| dt over all ranks and
         raises RuntimeError on EVERY rank when it exceeds 1 cell -- the bound the ghost widths, the advection windows and the
         overlapped U / density exchange rest on (a violation would otherwise read stale ghost planes silently).  Costs one
         pass over U and one 4-byte all-reduce(MAX) on the control path."""
-        assert schedule in ("last_pass", "edge_first")
+        assert schedule in ("last_pass", "edge_first", "deep_first")
         self.cfl_check_every = int(cfl_check_every)
         self.schedule = schedule
         self.static_flags = static_flags     # the caller promises that flags and BC arrays do not change between steps
@@ -290,12 +290,17 @@ class SlabSimulator:
         div = ops.pre_projection(U_adv, rho_adv, st, cfg)
         if window:
             window(0, 0)
-        yield "xchg", [div], max(w - 1, 1)
+        blocked = l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w and not float(cfg.get("pTol", 0.0)) > 0.0
+        deep = self.schedule == "deep_first" and blocked
+        # deep_first: the deep parts of the first sweep block read no ghost plane of div: its exchange is in flight behind them
+        yield ("start" if deep else "xchg"), [div], max(w - 1, 1)
 
         ops.set_slab(l.z_offset, l.D_global)
         if float(cfg.get("pTol", 0.0)) > 0.0:
             cur = yield from self._jacobi_ptol(st, div)
-        elif self.schedule == "edge_first" and l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w:
+        elif deep:
+            cur = yield from self._jacobi_deep_first(st, div)
+        elif self.schedule == "edge_first" and blocked:
             cur = yield from self._jacobi_edge_first(st, div)
         else:
             cur = yield from self._jacobi_last_pass(st, div)
@@ -418,6 +423,90 @@ class SlabSimulator:
             cur, nxt = nxt, cur
         return cur
 
+    @staticmethod
+    def deep_splits(passes, w):
+        """Plane offsets (from an internal face, into the owned block) at which pass k of a "deep_first" sweep block is cut
+        into its edge part [face - w + done_k, face + s_k) and its deep part [face + s_k, ...).  s_k >= s_(k-1) + n_k: the
+        deep part of pass k only reads what deeper-or-equal parts of pass k-1 wrote (block start: the owned planes).  From
+        the second pass on s_k >= w: the deep parts that write into the array the block started from stay clear of the w
+        owned planes next to the face, which the neighbour is still receiving from that array."""
+        s, out = 0, []
+        for k, n in enumerate(passes):
+            s = s + n if k == 0 else max(s + n, w)
+            out.append(s)
+        return out
+
+    def _jacobi_deep_first(self, st, div):
+        """Jacobi schedule "deep_first": the same blocks of w sweeps as "edge_first", cut the other way round.  Pass k of a
+        block (done_k sweeps into it) is split at s_k planes inside each internal face (deep_splits):
+
+            deep part of pass k   [lo + s_k, top - s_k)              reads no ghost plane and nothing an edge part wrote
+            edge part of pass k   [lo - w + done_k, lo + s_k)        (and its mirror image at the upper face)
+
+        The DEEP parts of all passes run first -- they need neither the ghost planes the previous block's exchange is still
+        delivering nor (in the first block) the ghost planes of div -- then the exchange is waited for, the edge parts
+        follow (a chain of short launches: 6 / 8 / 8 planes per face at w = 6 instead of edge_first's 14 / 10 / 6, whose
+        first launch alone marches 18 steps), and the w owned planes next to each face go to the neighbour while the next
+        block's deep parts run.  Both chains ping-pong between the same two arrays: the deep part of pass k+1 overwrites
+        the array pass k-1 wrote from plane lo + s_(k+1) upwards only, and the edge part of pass k reads it below plane
+        lo + s_k + n_k <= lo + s_(k+1) (sweep counts do not decrease within a block).  No plane is computed twice."""
+        l, cfg, ops, w = self.l, self.cfg, self.ops, self.w
+        if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
+            self._pbuf = torch.zeros_like(st["p"])
+        cur, nxt = st["p"], self._pbuf
+        fresh = getattr(ops, "zero_start", False)
+        if not fresh:
+            cur.zero_()
+        lo, top = l.lo, l.lo + l.owned
+        has_lo, has_hi = l.rank > 0, l.rank < l.world - 1
+        flags = st["flags"]
+        passes = [1] * (w % 2) + [2] * (w // 2)
+        splits = self.deep_splits(passes, w)
+        assert l.owned >= 2 * splits[-1] + 1, "slab too thin for the deep_first sweep block"
+        remaining = int(cfg["jacobiIter"])
+        quad = w % 2 == 0 and remaining % 2 == 0 and hasattr(ops, "quad_ok") and ops.quad_ok(flags)
+        Q = dict(lay=3) if quad else {}
+        zero_in = fresh                      # the solve starts from p = 0 everywhere: the first pass reads nothing
+        while remaining > w:                 # a block that is followed by another one
+            remaining -= w
+            src, dst = cur, nxt
+            for pi, n in enumerate(passes):
+                ops.jacobi_pass(flags, div, None if (zero_in and pi == 0) else src, dst, n,
+                                lo + splits[pi] if has_lo else 0, top - splits[pi] if has_hi else l.D_local, **Q)
+                src, dst = dst, src
+            yield ("wait",)                  # the ghost planes of `cur` (first block: of div)
+            ops.set_slab(l.z_offset, l.D_global)
+            src, dst, done = cur, nxt, 0
+            for pi, n in enumerate(passes):
+                done += n
+                pin = None if (zero_in and pi == 0) else src
+                if has_lo and has_hi and getattr(ops, "two_ranges", False):       # both faces in one launch
+                    ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + splits[pi], top - splits[pi], **Q)
+                else:
+                    if has_lo:
+                        ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + splits[pi], **Q)
+                    if has_hi:
+                        ops.jacobi_pass(flags, div, pin, dst, n, top - splits[pi], top + w - done, **Q)
+                src, dst = dst, src
+            if src is not cur:
+                cur, nxt = nxt, cur
+            yield "start", [cur], w
+            ops.set_slab(l.z_offset, l.D_global)
+            zero_in = False
+
+        # the last block (<= w sweeps, no exchange after it): whole shrinking ranges
+        yield ("wait",)
+        ops.set_slab(l.z_offset, l.D_global)
+        done = 0
+        tail = [2] * (remaining // 2) + [1] * (remaining % 2)
+        for ti, n in enumerate(tail):
+            done += n
+            g = max(w - done, 0)
+            kw = (Q if ti < len(tail) - 1 else dict(lay=1)) if quad else {}
+            ops.jacobi_pass(flags, div, cur, nxt, n, lo - g if has_lo else 0, top + g if has_hi else l.D_local, **kw)
+            cur, nxt = nxt, cur
+        return cur
+
     def _jacobi_last_pass(self, st, div):
         """Jacobi schedule "last_pass": blocks of w sweeps between ghost exchanges (temporal blocking in z); the last
         pass of a block first produces the w planes each neighbour needs, posts their exchange, and computes the interior
@@ -519,10 +608,10 @@ class NativeSlabSimulator:
     comm: an `ext.SlabComm` (`rccl_comm(...)` below, or `ext.slab_comm_loopback(group, rank)`); None for one rank."""
 
     def __init__(self, layout, mconf, comm=None, sweeps_per_exchange=4, static_flags=False, cfl_check_every=8, batch=1,
-                 H=None, W=None):
+                 H=None, W=None, schedule="deep_first"):
         from ._ext import ext
         self.ext, self.l, self.cfg, self.comm = ext, layout, mconf, comm
-        self._args = (int(sweeps_per_exchange), bool(static_flags), int(cfl_check_every))
+        self._args = (int(sweeps_per_exchange), bool(static_flags), int(cfl_check_every), str(schedule))
         self._drv = None
         self._ws = None
 
@@ -531,7 +620,7 @@ class NativeSlabSimulator:
             B, _, D, H, W = st["flags"].shape
             l = self.l
             self._drv = self.ext.SlabDriver(B, H, W, l.D_global, l.rank, l.world, l.halo, self._args[0], self._args[1],
-                                            self._args[2], self.comm)
+                                            self._args[2], self.comm, self._args[3])
             assert self._drv.layout() == [l.owned, l.lo, l.hi, l.z_offset] and D == l.D_local
             self._ws = torch.empty(self._drv.workspace_bytes(), dtype=torch.uint8, device=st["flags"].device)
         return self._drv

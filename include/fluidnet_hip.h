@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 11
+#define FNX_ABI_VERSION 12
 
 enum {
   FNX_OK = 0,
@@ -273,26 +273,46 @@ typedef struct FnxSlabComm {
   int (*allreduce_max)(void* ctx, float* x, int n, void* stream);
   int (*allreduce_sum)(void* ctx, float* x, int n, void* stream);
   void (*destroy)(void* ctx);
+  /* Optional (may be NULL): called by fnx_slab_step on the rank whose step FAILED, so that its neighbours -- which may already
+   * be waiting for it inside exchange() -- return FNX_ECOMM instead of hanging (RCCL: ncclCommAbort; loopback: a group flag). */
+  void (*abort)(void* ctx);
 } FnxSlabComm;
+/* Ordering contract of a communicator: fnx_slab_step issues exchange() on its internal communication stream and the
+ * control-path all-reduces (CFL guard, pTol residual) on the caller's stream; every rank issues the same calls in the same
+ * order (the step is deterministic).  An all-reduce is only issued when no exchange is pending (the caller's stream has
+ * been made to wait for the last one) and is followed by a host synchronisation before the next exchange is posted, so the
+ * two streams never have work of one communicator in flight at the same time. */
 /* RCCL communicator (librccl is loaded on first use; no link-time dependency).  unique_id: the 128 bytes of
  * fnx_slab_rccl_unique_id() from rank 0, distributed by the caller (MPI, torch.distributed, a file ...). */
 int fnx_slab_rccl_unique_id(void* out128);
 int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* unique_id128);
 /* In-process communicator for `nranks` slabs driven by `nranks` host threads of one process (one device, or several
- * with peer access): device-to-device copies ordered by events.  Create the group once, then one comm per rank. */
+ * with peer access: each side of a pair records only its own event on its own stream): device-to-device copies ordered by
+ * events.  A rank that waits for a peer longer than 120 s, or whose group was aborted (FnxSlabComm.abort), returns FNX_ECOMM.
+ * Create the group once, then one comm per rank. */
 int fnx_slab_loopback_group(void** group, int nranks);
 int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank);
 void fnx_slab_loopback_group_free(void* group);
 void fnx_slab_comm_free(FnxSlabComm* comm);
 
+#define FNX_SLAB_MAX_HALO 64
+/* How a block of sweeps_per_exchange Jacobi sweeps is ordered around its ghost exchange (all three give the same bits):
+ *   DEEP_FIRST  every pass is cut a few planes inside each internal face; the deep parts of all passes run first -- they read
+ *               no ghost plane, so the previous block's exchange (first block: the exchange of div) is still in flight --,
+ *               then the edge parts (short launches), whose last one produces the planes the neighbours need next
+ *   EDGE_FIRST  the edge parts of all passes first (shrinking plane ranges), their exchange posted, the interior parts behind it
+ *   LAST_PASS   whole passes; only the last pass of a block is split into edge and interior
+ * Slabs thinner than 4 sweep blocks, solves of at most one block and pTol > 0 always run LAST_PASS. */
+enum { FNX_SLAB_DEEP_FIRST = 0, FNX_SLAB_EDGE_FIRST = 1, FNX_SLAB_LAST_PASS = 2 };
 typedef struct FnxSlabConfig {
   int B, H, W, D_global;    /* the whole domain */
   int rank, nranks;         /* D_global % nranks == 0 */
-  int halo;                 /* ghost planes per internal face (>= 5; the pressure solve uses all of them) */
+  int halo;                 /* ghost planes per internal face (5 .. FNX_SLAB_MAX_HALO; the pressure solve uses all of them) */
   int sweeps_per_exchange;  /* Jacobi sweeps per ghost exchange of p (temporal blocking in z), clipped to halo */
   int static_flags;         /* 1: flags and BC arrays never change between steps (solver mask and BC class map are kept) */
   int cfl_check_every;      /* every that many steps the step begins with max |U| dt over all ranks (one host sync);
                                > 1 cell returns FNX_ECFL on every rank.  0 = never */
+  int schedule;             /* FNX_SLAB_DEEP_FIRST (0, the default) / FNX_SLAB_EDGE_FIRST / FNX_SLAB_LAST_PASS */
 } FnxSlabConfig;
 typedef struct FnxSlab FnxSlab;
 /* Local geometry of a rank (what to allocate): planes it owns, ghosts below / above, global plane of local plane 0. */
@@ -304,8 +324,26 @@ void fnx_slab_destroy(FnxSlab* s);
 /* One time step.  st: the rank's local arrays (with ghost planes), st->density required, st->net unused; prm->method
  * must be 0.  prm->p_tol > 0 runs the reference's convergence test (fluids_init.cpp:961-979): one sweep per ghost exchange,
  * the squared differences over the owned planes all-reduced over the ranks, one host sync per sweep (as in fnx_jacobi);
- * prm->static_flags is ignored (FnxSlabConfig.static_flags).  ws: fnx_slab_workspace_bytes, kept between steps. */
+ * up to 63 samples.  The bit-for-bit statement above holds for p_tol == 0; with p_tol > 0 every sweep still has the
+ * single-domain bits, but the residual is a sum in another order (per rank, then over the ranks), so a tolerance within
+ * rounding (~1e-7 relative) of a sweep's residual can stop one sweep earlier or later than fnx_jacobi does.
+ * prm->static_flags is ignored (FnxSlabConfig.static_flags).  ws: fnx_slab_workspace_bytes, kept between steps.
+ * On failure (other than FNX_ECFL, which every rank reports together) the communicator's abort() is called. */
 int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* stream);
+
+/* Communication statistics of a rank (off by default: the event pairs they need cannot be recorded inside a graph capture).
+ * enable(1) clears them; read() synchronises the recorded events, adds them up and clears the event list. */
+typedef struct FnxSlabStats {
+  double bytes_per_neighbour;  /* bytes posted towards EACH neighbour (and received from it) since enable() */
+  double wait_ms;              /* time the compute stream stood in front of posted exchanges (HIP events around each wait) */
+  long long exchanges;         /* ghost exchanges posted */
+} FnxSlabStats;
+int fnx_slab_stats_enable(FnxSlab* s, int on);
+int fnx_slab_stats_read(FnxSlab* s, FnxSlabStats* out);
+/* One-off probe of a communicator: `reps` exchanges of `bytes` bytes with each neighbour, back to back on `stream`, after
+ * one untimed exchange; *ms_per_exchange = average duration (HIP events; synchronises).  scratch: 4 * bytes of device
+ * memory.  Every rank of the communicator must call it with the same arguments. */
+int fnx_slab_comm_probe(const FnxSlabComm* comm, void* scratch, size_t bytes, int reps, float* ms_per_exchange, void* stream);
 
 /* MultiScaleNet / FluidNet.forward, lib/multi_scale_net.py:118-127 and lib/model.py:76-227 (ScaleNet variant).
  * weights_blob: 17 convs in the order convN_4[0..3], convN_2[0..5], convN_1[0..5], final; for each conv the

@@ -99,3 +99,79 @@ def test_adjoints_vs_oracle_and_dot_product(oracle, shape):
     lhs = float((Ux.double() * torch.from_numpy(gu).to(dev).double()).sum())
     rhs = float((x.double() * gU.double()).sum() + (pr.double() * gp.double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (lhs, rhs)
+
+
+def _aten_forward_3d(torch, p, U, flags):
+    """velocityUpdate -> velocityDivergence in 3D as plain (differentiable) tensor expressions: the default 3D semantics the
+    oracle and the kernels implement (fluid-fluid faces only, the reference's own 3D velocityUpdate raises:
+    solver_cpp/src/projection/update_vel.cpp:58-117 is the intent), written independently of both."""
+    f, P = flags[:, 0], p[:, 0]
+    D, H, W = f.shape[1:]
+    inner = (slice(None), slice(1, D - 1), slice(1, H - 1), slice(1, W - 1))
+    comps = []
+    for a, (dk, dj, di) in enumerate([(0, 0, 1), (0, 1, 0), (1, 0, 0)]):
+        lower = (slice(None), slice(1 - dk, D - 1 - dk), slice(1 - dj, H - 1 - dj), slice(1 - di, W - 1 - di))
+        m = ((f[inner] == 1) & (f[lower] == 1)).to(U.dtype)
+        comps.append(m * (U[:, a][inner] - (P[inner] - P[lower])))
+    V = U.clone()
+    V[:, :, 1:D - 1, 1:H - 1, 1:W - 1] = torch.stack(comps, 1)
+    div = torch.zeros_like(p)
+    d = (V[:, 0, 1:-1, 1:-1, 1:-1] - V[:, 0, 1:-1, 1:-1, 2:]) + (V[:, 1, 1:-1, 1:-1, 1:-1] - V[:, 1, 1:-1, 2:, 1:-1]) \
+        + (V[:, 2, 1:-1, 1:-1, 1:-1] - V[:, 2, 2:, 1:-1, 1:-1])
+    div[:, 0, 1:-1, 1:-1, 1:-1] = d * (f[inner] != 2).to(U.dtype)
+    return V, div
+
+
+def _case_3d():
+    rng = np.random.default_rng(21)
+    B, D, H, W = 2, 9, 12, 18
+    flags = make_flags(B, D, H, W, boxes=True)
+    return dict(flags=flags, p=rng.standard_normal((B, 1, D, H, W)).astype(np.float32),
+                U=rng.standard_normal((B, 3, D, H, W)).astype(np.float32),
+                wd=rng.standard_normal((B, 1, D, H, W)).astype(np.float32),
+                wu=rng.standard_normal((B, 3, D, H, W)).astype(np.float32))
+
+
+def test_oracle_adjoints_3d_vs_torch_autograd(oracle):
+    """3D: the reference has no working 3D velocityUpdate to differentiate, so the gradients are pinned to torch autograd over
+    an independent tensor formulation of the default 3D forward: forward values and both gradients."""
+    import torch
+    c = _case_3d()
+    p = torch.from_numpy(c["p"]).requires_grad_(True)
+    U = torch.from_numpy(c["U"]).requires_grad_(True)
+    V, div = _aten_forward_3d(torch, p, U, torch.from_numpy(c["flags"]))
+    assert_close_rel(oracle.velocity_update(c["p"], c["U"], c["flags"]), V.detach().numpy(), 1e-6, "3D velocityUpdate")
+    assert_close_rel(oracle.velocity_divergence(V.detach().numpy(), c["flags"]), div.detach().numpy(), 1e-6, "3D divergence")
+    ((div * torch.from_numpy(c["wd"])).sum() + (V * torch.from_numpy(c["wu"])).sum()).backward()
+    gV = c["wu"] + oracle.velocity_divergence_backward(c["wd"], c["flags"], True)
+    gU, gp = oracle.velocity_update_backward(gV, c["flags"])
+    assert_close_rel(gU, U.grad.numpy(), 1e-6, "3D grad U")
+    assert_close_rel(gp, p.grad.numpy(), 1e-6, "3D grad p")
+
+
+@pytest.mark.gpu
+def test_autograd_3d_vs_torch_autograd():
+    """The same through torch autograd over the NATIVE 3D operators (in place, mark_dirty) on the GPU."""
+    import torch
+    from fluidnet_cxx_amd import fluid
+    c = _case_3d()
+    dev = torch.device("cuda:0")
+    p0 = torch.from_numpy(c["p"]).requires_grad_(True)
+    U0 = torch.from_numpy(c["U"]).requires_grad_(True)
+    V0, div0 = _aten_forward_3d(torch, p0, U0, torch.from_numpy(c["flags"]))
+    ((div0 * torch.from_numpy(c["wd"])).sum() + (V0 * torch.from_numpy(c["wu"])).sum()).backward()
+    flags = torch.from_numpy(c["flags"]).to(dev)
+    p = torch.from_numpy(c["p"]).to(dev).requires_grad_(True)
+    U = torch.from_numpy(c["U"]).to(dev).requires_grad_(True)
+    V = U.clone()
+    fluid.velocityUpdate(p, V, flags)
+    div = fluid.velocityDivergence(V, flags)
+    assert_close_rel(V.detach().cpu().numpy(), V0.detach().numpy(), 1e-6, "3D velocityUpdate (native)")
+    assert_close_rel(div.detach().cpu().numpy(), div0.detach().numpy(), 1e-6, "3D divergence (native)")
+    ((div * torch.from_numpy(c["wd"]).to(dev)).sum() + (V * torch.from_numpy(c["wu"]).to(dev)).sum()).backward()
+    assert_close_rel(U.grad.cpu().numpy(), U0.grad.numpy(), 1e-6, "3D grad U (native)")
+    assert_close_rel(p.grad.cpu().numpy(), p0.grad.numpy(), 1e-6, "3D grad p (native)")
+    # the adjoints cover whole fields: a compute window (z-slab driver) has no differentiable form
+    from fluidnet_cxx_amd._ext import ext
+    with pytest.raises(AssertionError, match="compute window"):
+        fluid.velocityDivergence(U, flags, geom=ext.Geom(k_begin=2, k_end=5))

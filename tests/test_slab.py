@@ -122,11 +122,13 @@ def check_owned(st, ref, layout, what):
 
 @pytest.mark.parametrize("world,halo,w,schedule", [(3, 6, 4, "last_pass"), (2, 5, 2, "last_pass"), (2, 8, 5, "last_pass"),
                                                    (2, 6, 3, "last_pass"), (2, 6, 6, "last_pass"),
-                                                   (2, 6, 4, "edge_first"), (3, 6, 3, "edge_first"), (2, 5, 5, "edge_first")])
+                                                   (2, 6, 4, "edge_first"), (3, 6, 3, "edge_first"), (2, 5, 5, "edge_first"),
+                                                   (2, 6, 4, "deep_first"), (3, 6, 3, "deep_first"), (2, 5, 5, "deep_first"),
+                                                   (3, 6, 6, "deep_first"), (2, 6, 2, "deep_first")])
 def test_lockstep_slabs_match_single_domain_cpu(world, halo, w, schedule):
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
     D, H, W = 24 if (world == 3 or w == 6) else 20, 14, 18
-    if schedule == "edge_first":
+    if schedule != "last_pass":
         D = 4 * w * world                     # the schedule needs 4w owned planes per rank
     gs = global_state(D, H, W)
     ref = reference_steps(gs, 2)
@@ -135,7 +137,7 @@ def test_lockstep_slabs_match_single_domain_cpu(world, halo, w, schedule):
     sims = [SlabSimulator(l, CFG, ops=ops, sweeps_per_exchange=w, schedule=schedule) for l in layouts]
     states = [local_state(gs, l) for l in layouts]
     for n in range(2):
-        lockstep_step(sims, states, defer=(n == 1 and schedule == "edge_first"))
+        lockstep_step(sims, states, defer=(n == 1 and schedule != "last_pass"))
     for l, st in zip(layouts, states):
         check_owned(st, ref, l, f"lockstep world={world}")
 
@@ -206,13 +208,13 @@ def _dist_worker(rank, world, port, D, H, W, halo, w, schedule, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("schedule", ["last_pass", "edge_first", "ptol"])
+@pytest.mark.parametrize("schedule", ["last_pass", "edge_first", "deep_first", "ptol"])
 def test_gloo_two_ranks_match_single_domain(tmp_path, schedule):
     """world_size 2 over gloo: real send/recv between two processes ("ptol": the per-sweep residual all-reduce of the
     pTol > 0 solve; every variant also runs the CFL guard's all-reduce)."""
     import torch.multiprocessing as mp
     from fluidnet_cxx_amd.slab import SlabLayout
-    D, H, W, halo, w, world = (32 if schedule == "edge_first" else 24), 12, 16, 6, 4, 2
+    D, H, W, halo, w, world = (32 if schedule in ("edge_first", "deep_first") else 24), 12, 16, 6, 4, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     os.environ.setdefault("OMP_NUM_THREADS", "2")
@@ -244,7 +246,10 @@ def test_layout_arithmetic():
 @pytest.mark.parametrize("world,halo,w,schedule,iters", [(2, 6, 4, "last_pass", 11), (4, 6, 3, "last_pass", 11), (2, 6, 6, "last_pass", 11),
                                                          (2, 6, 4, "edge_first", 11), (4, 6, 3, "edge_first", 11), (2, 6, 6, "edge_first", 11),
                                                          (2, 5, 5, "edge_first", 11), (3, 6, 5, "edge_first", 11),
-                                                         (3, 6, 4, "edge_first", 14), (2, 6, 6, "edge_first", 20), (4, 6, 2, "edge_first", 6)])
+                                                         (3, 6, 4, "edge_first", 14), (2, 6, 6, "edge_first", 20), (4, 6, 2, "edge_first", 6),
+                                                         (2, 6, 4, "deep_first", 11), (4, 6, 3, "deep_first", 11), (2, 6, 6, "deep_first", 11),
+                                                         (2, 5, 5, "deep_first", 11), (3, 6, 5, "deep_first", 11), (3, 6, 4, "deep_first", 14),
+                                                         (3, 6, 6, "deep_first", 20), (4, 6, 2, "deep_first", 6)])
 def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule, iters):
     """Same decomposition check with the native HIP operators on one device (global-z geometry in the kernels).  Even
     sweep blocks with an even sweep count (H = 20): every pass is a two-sweep pass and they hand each other the pressure
@@ -253,7 +258,7 @@ def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule, iters)
     from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
     dev = torch.device("cuda:0")
     CFG = dict(globals()["CFG"], jacobiIter=iters)
-    D, H, W = (4 * w * world if schedule == "edge_first" else 32), 20, 70
+    D, H, W = (4 * w * world if schedule != "last_pass" else 32), 20, 70
     gs = global_state(D, H, W, seed=3)
     bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
     for _ in range(2):
@@ -278,7 +283,8 @@ def test_lockstep_slabs_match_single_domain_gpu(world, halo, w, schedule, iters)
 @pytest.mark.parametrize("world,halo,w,static,iters", [(2, 6, 4, False, 11), (4, 6, 3, False, 11), (2, 6, 6, True, 11), (3, 6, 5, True, 11),
                                                        (2, 5, 5, False, 11), (2, 6, 4, "thin", 11), (1, 6, 6, True, 11),
                                                        (3, 6, 4, True, 14), (2, 6, 6, False, 20), (1, 6, 6, True, 12)])
-def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static, iters):
+@pytest.mark.parametrize("schedule", ["deep_first", "edge_first"])
+def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static, iters, schedule):
     """The C++ z-slab driver (fnx_slab_step) on `world` slabs of one domain, each driven by its own host thread and HIP
     stream on one device, ghost planes through the in-process communicator (event-ordered device copies): every owned
     plane bit-identical to the single-domain step, 3 steps (the third reuses the solver mask and the BC class map under
@@ -302,7 +308,7 @@ def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static, i
     states = [local_state(gs, l, dev) for l in layouts]
     group = ext.SlabLoopbackGroup(world)
     sims = [NativeSlabSimulator(l, CFG, comm=ext.slab_comm_loopback(group, l.rank) if world > 1 else None, sweeps_per_exchange=w,
-                                static_flags=bool(static) and not thin, cfl_check_every=2) for l in layouts]
+                                static_flags=bool(static) and not thin, cfl_check_every=2, schedule=schedule) for l in layouts]
     torch.cuda.synchronize()
     errs = []
 
@@ -325,6 +331,42 @@ def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static, i
     torch.cuda.synchronize()
     for l, st in zip(layouts, states):
         check_owned(st, ref, l, f"native driver world={world} w={w}")
+
+
+@pytest.mark.gpu
+def test_native_driver_failing_rank_releases_its_neighbour():
+    """A rank whose step fails (here: its workspace is too small) never joins the exchange its neighbour is already waiting
+    in; the driver aborts the communicator, and the neighbour returns an error instead of hanging."""
+    import threading
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    dev = torch.device("cuda:0")
+    world, w, D = 2, 4, 32
+    gs = global_state(D, 20, 70, seed=2)
+    layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
+    states = [local_state(gs, l, dev) for l in layouts]
+    group = ext.SlabLoopbackGroup(world)
+    sims = [NativeSlabSimulator(l, CFG, comm=ext.slab_comm_loopback(group, l.rank), sweeps_per_exchange=w, cfl_check_every=0) for l in layouts]
+    sims[1]._driver(states[1])
+    sims[1]._ws = torch.empty(1024, dtype=torch.uint8, device=dev)          # far too small
+    errs = {}
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                sims[r].step(states[r])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs[r] = str(e)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ts), "the neighbour of the failed rank hangs"
+    assert "workspace too small" in errs.get(1, ""), errs
+    assert "peer rank failed" in errs.get(0, ""), errs
 
 
 @pytest.mark.gpu

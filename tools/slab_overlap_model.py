@@ -6,7 +6,7 @@ posted (as RCCL's does), spins for  latency + bytes / bandwidth  and then fills 
 edge planes: the physics is a periodic stack of this slab, the launch sequence and sizes are the real ones); the main
 stream waits for it where the driver waits.  This measures how much of a transfer each Jacobi schedule hides, for assumed
 link rates -- the multi-GPU box itself is only available to the round-end driver.
-usage: slab_overlap_model.py [schedule=last_pass|edge_first] [w=6]"""
+usage: slab_overlap_model.py [schedule=deep_first|edge_first|last_pass] [w=6]"""
 import os, sys, time, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -55,7 +55,7 @@ class ModelComm:
 
 
 def main():
-    schedule = sys.argv[1] if len(sys.argv) > 1 else "last_pass"
+    schedule = sys.argv[1] if len(sys.argv) > 1 else "deep_first"
     wsw = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     w = bench.WORKLOADS["plume3d_slab_jacobi"]; m = bench.mconf_for(w)
     layout = SlabLayout(64 * 3, 3, 1, 6)                                     # the middle one of three ranks

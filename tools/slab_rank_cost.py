@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 w = bench.WORKLOADS["plume3d_slab_jacobi"]; m = bench.mconf_for(w)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 wsw = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-schedule = sys.argv[3] if len(sys.argv) > 3 else "last_pass"
+schedule = sys.argv[3] if len(sys.argv) > 3 else "deep_first"
 D = 64 * world
 layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
 states = [bench.plume_state_torch(512, l.D_local, dev, l.z_offset, D) for l in layouts]
