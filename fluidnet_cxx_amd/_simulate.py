@@ -57,7 +57,8 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
                            float(maccormackStrength), bool(sampleOutsideFluid), float(buoyancyScale), gvec,
                            float(mconf.get("operatingDensity", 0.0)), float(mconf.get("pTol", 0.0)),
                            int(mconf.get("jacobiIter", 1)), sim_method,
-                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, int(static_flags), geom)
+                           float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, int(static_flags), geom,
+                           getattr(net, "precision_mode", "fp32") if sim_method == "convnet" else "fp32")
         if not has_density:
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return

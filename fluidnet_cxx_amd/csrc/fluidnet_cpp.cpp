@@ -145,11 +145,11 @@ std::vector<Tensor> solve_linear_system(Tensor flags, Tensor div, const bool is3
   Tensor residual = at::zeros({}, flags.options());
   Workspace ws(g, FNX_OP_JACOBI, flags);
   int iters = 0;
-  check_status(fnx_jacobi(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(),
-                          residual.data_ptr<float>(), p_tol, max_iter, &iters, ws.ptr, ws.bytes, cur_stream(flags)));
-  if (verbose) {
-    std::cout << "Jacobi: " << iters << " sweeps, residual " << residual.item<float>() << std::endl;
-  }
+  // verbose: the reference prints the residual after every sweep (fluids_init.cpp:968-971), which needs every iterate on the
+  // host -- one sweep per launch and a host sync per sweep, like pTol > 0
+  check_status((verbose ? fnx_jacobi_verbose : fnx_jacobi)(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(),
+                                                           residual.data_ptr<float>(), p_tol, max_iter, &iters, ws.ptr, ws.bytes,
+                                                           cur_stream(flags)));
   return {p, residual};
 }
 
@@ -319,7 +319,13 @@ Tensor scalenet_pack(Tensor blob, bool is3D) {
   return packed;
 }
 
-Tensor multiscale_forward(Tensor packed, Tensor x) {
+// precision_mode: "fp32" (default: Winograd where the launch fills the chip) or "fp32_direct" (FNX_PRECISION_*)
+static int precision_of(const std::string& m) {
+  TORCH_CHECK(m == "fp32" || m == "fp32_direct", "precision_mode must be 'fp32' or 'fp32_direct', got '", m, "'");
+  return m == "fp32_direct" ? FNX_PRECISION_FP32_DIRECT : FNX_PRECISION_FP32;
+}
+
+Tensor multiscale_forward(Tensor packed, Tensor x, const std::string& precision_mode) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "x must be a contiguous float32 GPU tensor");
   TORCH_CHECK((x.dim() == 4 || x.dim() == 5) && x.size(1) == 2, "x must be (B,2,H,W) or (B,2,D,H,W)");
   const bool is3D = x.dim() == 5 && x.size(2) > 1;
@@ -330,11 +336,12 @@ Tensor multiscale_forward(Tensor packed, Tensor x) {
   Tensor p = at::empty(osz, x.options());
   const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_FLUIDNET);
   Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
-  check_status(fnx_multiscale_forward(&g, packed.data_ptr(), x.data_ptr<float>(), p.data_ptr<float>(), ws.data_ptr(), bytes, cur_stream(x)));
+  check_status(fnx_multiscale_forward(&g, packed.data_ptr(), x.data_ptr<float>(), p.data_ptr<float>(), precision_of(precision_mode),
+                                      ws.data_ptr(), bytes, cur_stream(x)));
   return p;
 }
 
-std::vector<Tensor> fluidnet_forward(Tensor packed, Tensor input, double normalize_threshold) {
+std::vector<Tensor> fluidnet_forward(Tensor packed, Tensor input, double normalize_threshold, const std::string& precision_mode) {
   check_field(input, "input");
   const bool is3D = input.size(1) == 6;
   TORCH_CHECK(input.size(1) == 5 || input.size(1) == 6, "input must have 5 (2D) or 6 (3D) channels [p, U, flags, density]");
@@ -346,7 +353,8 @@ std::vector<Tensor> fluidnet_forward(Tensor packed, Tensor input, double normali
   const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_FLUIDNET);
   Tensor ws = at::empty({(int64_t)bytes}, input.options().dtype(at::kByte));
   check_status(fnx_fluidnet_forward(&g, packed.data_ptr(), input.data_ptr<float>(), (float)normalize_threshold,
-                                    p.data_ptr<float>(), U.data_ptr<float>(), ws.data_ptr(), bytes, cur_stream(input)));
+                                    p.data_ptr<float>(), U.data_ptr<float>(), precision_of(precision_mode), ws.data_ptr(), bytes,
+                                    cur_stream(input)));
   return {p, U};
 }
 
@@ -357,7 +365,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
                     double maccormack_strength, bool sample_outside_fluid, double buoyancy_scale,
                     std::vector<double> gravity_vec, double operating_density, double p_tol, int jacobi_iter,
                     const std::string method, double normalize_threshold, c10::optional<Tensor> workspace,
-                    int static_flags, const Geom* geom) {
+                    int static_flags, const Geom* geom, const std::string& precision_mode) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
@@ -369,6 +377,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   for (int a = 0; a < 3; ++a) prm.gravity_vec[a] = (float)gravity_vec[a];
   prm.operating_density = (float)operating_density; prm.p_tol = (float)p_tol; prm.jacobi_iter = jacobi_iter;
   prm.method = method == "convnet" ? 1 : 0; prm.normalize_threshold = (float)normalize_threshold;
+  prm.precision_mode = precision_of(precision_mode);
   auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> float* {
     if (!t.has_value() || !t->defined()) return nullptr;
     if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
@@ -653,21 +662,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("create_box2d_", &create_box2d_, NoGil());
   m.def("get_centered", &get_centered, NoGil());
   m.def("scalenet_pack", &scalenet_pack, NoGil());
-  m.def("multiscale_forward", &multiscale_forward, NoGil());
-  m.def("fluidnet_forward", &fluidnet_forward, NoGil());
+  m.def("multiscale_forward", &multiscale_forward, py::arg("packed"), py::arg("x"), py::arg("precision_mode") = "fp32", NoGil());
+  m.def("fluidnet_forward", &fluidnet_forward, py::arg("packed"), py::arg("input"), py::arg("normalize_threshold"),
+        py::arg("precision_mode") = "fp32", NoGil());
   m.def("simulate_step_", &simulate_step_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),
         py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("net"), py::arg("dt"),
         py::arg("maccormack_strength"), py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"),
         py::arg("operating_density"), py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("method"),
-        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0, GEOM, NoGil());
+        py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0, GEOM,
+        py::arg("precision_mode") = "fp32", NoGil());
   m.def("step_workspace_bytes", &step_workspace_bytes);
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
         py::arg("workspace") = py::none(), py::arg("reuse_mask") = false, GEOM, py::arg("from_zero") = false, NoGil());
   m.def("jacobi_workspace_bytes", &jacobi_workspace_bytes);
-  m.def("jacobi_max_pass_sweeps", [](int B, int D, int H, int W, int nplanes, int nranges) {
-    FnxGrid g{B, D, H, W, 1, 0, 0, 0};
-    return fnx_jacobi_max_pass_sweeps(&g, nplanes, nranges);
-  });
   m.def("jacobi_pass_", &jacobi_pass_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("nsweeps"),
         py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1, GEOM,
         py::arg("layout") = 0, NoGil());

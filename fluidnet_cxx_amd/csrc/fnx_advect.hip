@@ -689,13 +689,14 @@ void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, boo
   const size_t nwords = advect_fix_words(g);
   const dim3 block(BX, BY);
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
-  static const int march = [] { const char* e = getenv("FNX_ADVECT_MARCH"); return e ? atoi(e) : 3; }();   // A/B switch: bit 0 forward, bit 1 backward tile kernels
-  if (is3d && !quirks && (march & 1) && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu)
+  // 3D default semantics: the z-marching LDS tile kernels (fnx_advect_march.h); quirks mode and plane ranges beyond the
+  // tile kernels' 32-bit offsets: one thread per cell
+  if (is3d && !quirks && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu)
     launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix, fix + nwords, s);
   else
     DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
   if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
-  if (is3d && !quirks && (march & 2) && (size_t)(g.KN + 2) * g.HW < 0x3fffffffu) {
+  if (is3d && !quirks && (size_t)(g.KN + 2) * g.HW < 0x3fffffffu) {
     int ntx, nty, zchunk; unsigned G;
     tile_launch_geometry(g, ntx, nty, zchunk, G);
     unsigned long long* fb_s = fix + 2 * nwords;

@@ -70,7 +70,18 @@ size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 :
 // fix-up bitmaps of the 3D tile advection kernels (fnx_advect_march.h): 4 x one 64-bit word per 64-cell row segment
 size_t ws_advect_fix(const FnxGrid* g) { return g->is3D ? al(4 * 8 * (size_t)g->B * g->D * g->H * ((g->W + 63) / 64)) : 0; }
 size_t ws_mask(const FnxGrid* g) { return g->is3D ? al(fnx::jacobi3d_mask_bytes(dims(g))) : 0; }   // 3D solver: neighbour-mask bytes, twice (rows / row groups)
-size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al((size_t)g->B * 4) + al(4) + ws_mask(g); }
+// Jacobi workspace: ping-pong pressure, the residual's fixed-order partial sums, one result float, the 3D neighbour mask
+size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al(fnx::residual_scratch_bytes(g->B)) + al(4) + ws_mask(g); }
+struct JacobiWs { float* tmp; double* partials; float* res; unsigned char* mask; };
+bool carve_jacobi(const FnxGrid* g, void* ws, size_t ws_bytes, JacobiWs* out, size_t* need) {
+  Carver c(ws, ws_bytes);
+  out->tmp = (float*)c.take(ncell(g) * 4);
+  out->partials = (double*)c.take(fnx::residual_scratch_bytes(g->B));
+  out->res = (float*)c.take(4);
+  out->mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
+  *need = c.off;
+  return c.ok();
+}
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   // 2D: the fused advection launches keep both forward fields at once
@@ -274,70 +285,75 @@ int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags
 
 static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual, float p_tol,
                         int max_iter, int* iters_done, void* ws, size_t ws_bytes, unsigned char* kept_mask, bool reuse_mask,
-                        void* stream);
+                        void* stream, int verbose);
 
 int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual, float p_tol,
                int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream) {
-  return jacobi_solve(g, flags, div, p, residual, p_tol, max_iter, iters_done, ws, ws_bytes, nullptr, false, stream);
+  return jacobi_solve(g, flags, div, p, residual, p_tol, max_iter, iters_done, ws, ws_bytes, nullptr, false, stream, 0);
+}
+
+int fnx_jacobi_verbose(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual, float p_tol,
+                       int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream) {
+  return jacobi_solve(g, flags, div, p, residual, p_tol, max_iter, iters_done, ws, ws_bytes, nullptr, false, stream, 1);
 }
 
 static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual, float p_tol,
                         int max_iter, int* iters_done, void* ws, size_t ws_bytes, unsigned char* kept_mask, bool reuse_mask,
-                        void* stream) {
+                        void* stream, int verbose) {
   if (int rc = check_grid(g)) return rc;
   if (!flags || !div || !p) return fail(FNX_EINVAL, "solve_linear_system: NULL tensor");
   if (max_iter < 1) return fail(FNX_EINVAL, "At least 1 iteration is needed (maxIter < 1)");
   hipStream_t s = (hipStream_t)stream;
   const GridDims d = dims(g);
-  Carver c(ws, ws_bytes);
-  float* tmp = (float*)c.take(ncell(g) * 4);
-  float* sumsq = (float*)c.take((size_t)g->B * 4);
-  float* res_ws = (float*)c.take(4);
-  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
-  if (!c.ok()) return fail(FNX_EWORKSPACE, "solve_linear_system: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  JacobiWs W; size_t need;
+  if (!carve_jacobi(g, ws, ws_bytes, &W, &need)) return fail(FNX_EWORKSPACE, "solve_linear_system: workspace too small (%zu < %zu)", ws_bytes, need);
+  float* tmp = W.tmp;
+  unsigned char* mask = W.mask;
   if (g->is3D && kept_mask) mask = kept_mask;           // a slot nothing else in the step scribbles on
   else reuse_mask = false;
   const bool q = quirks(g);
   if (g->is3D && !reuse_mask) fnx::launch_jacobi3d_mask(d, q, flags, mask, s);
-  auto sweep = [&](const float* in, float* out, int k, bool from_zero, float* ss, int lay = 0) {
+  auto sweep = [&](const float* in, float* out, int k, bool from_zero, int lay = 0) {
     fnx::ProfScope ps(FNX_PROF_JACOBI, s);
     if (g->is3D) {
-      if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, ss, s, 0, 0, from_zero);
-      else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, ss, s, 0, 0, from_zero, -1, lay);
-      else fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, ss, s);
+      if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, s, 0, 0, from_zero, -1, lay);
+      else fnx::launch_jacobi3d(d, mask, div, in, out, from_zero, s);
     } else {
-      fnx::launch_jacobi(d, false, q, flags, div, in, out, k, from_zero, ss, s);
+      fnx::launch_jacobi(d, flags, div, in, out, k, from_zero, s);
     }
   };
-  if (!(p_tol > 0.f)) {
-    // sweeps per launch: 2D up to kmax (register temporal blocking); 3D pairs (the first one knows p = 0)
-    int plan[1024]; int nl = 0, left = max_iter;
-    // sweeps per launch: 2D up to kmax (register temporal blocking); 3D three per pass where the grid allows it (a
-    // remainder of 1 is split 2 + 2 rather than 3 + 1: the single-sweep kernel is the slowest per sweep)
-    const int kmax = g->is3D ? (fnx::jacobi3d_x3_available(d, g->D, 1) ? 3 : 2) : fnx::jacobi_max_sweeps_per_launch(d, false);
-    while (left > 0 && nl < 1023) {
-      int k = left < kmax ? left : kmax;
-      if (g->is3D && kmax == 3 && left == 4) k = 2;
+  // ||a - b||_2 per sample, max over the batch, reproducible (fixed-order fp64 partial sums, no atomics)
+  const size_t per = (size_t)g->D * g->H * g->W;
+  auto residual_of = [&](const float* a, const float* b, float* out) { fnx::launch_residual(g->B, per, 0, per, a, b, W.partials, nullptr, out, s); };
+  const bool per_sweep = p_tol > 0.f || verbose;        // the reference's per-sweep host test / per-sweep print
+  if (!per_sweep) {
+    // Sweeps per launch: 2D up to kmax (register temporal blocking); 3D pairs (the first one knows p = 0).  When the caller
+    // wants the residual ||p_n - p_(n-1)||, the last sweep runs on its own so that both iterates are in memory.
+    const int fused = residual ? max_iter - 1 : max_iter;
+    int plan[1024]; int nl = 0, left = fused;
+    const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
+    while (left > 0 && nl < 1022) {
+      const int k = left < kmax ? left : kmax;
       plan[nl++] = k; left -= k;
     }
     if (left > 0) return fail(FNX_EINVAL, "solve_linear_system: max_iter too large for one call (%d)", max_iter);
-    if (residual) HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
+    const int ntot = nl + (residual ? 1 : 0);
     const float* in = nullptr;
-    int done = 0;
     // 3D: consecutive two-sweep passes hand each other p in the row-quad layout (fewer, wider vector-memory
-    // instructions: launch_jacobi3d_x2); the last launch of the solve writes rows
-    const bool quad = g->is3D && kmax == 2 && fnx::jacobi3d_quad_ok(d);
+    // instructions: launch_jacobi3d_x2); the last of them writes rows
+    const bool quad = g->is3D && fnx::jacobi3d_quad_ok(d);
     bool in_quad = false;
     for (int l = 0; l < nl; ++l) {
-      float* out = ((nl - 1 - l) % 2 == 0) ? p : tmp;      // the last launch writes p
-      const bool last = l == nl - 1;
-      const bool out_quad = quad && plan[l] == 2 && !last && plan[l + 1] == 2;
-      sweep(in, out, plan[l], l == 0, (last && residual) ? sumsq : nullptr, (in_quad ? 1 : 0) | (out_quad ? 2 : 0));
+      float* out = ((ntot - 1 - l) % 2 == 0) ? p : tmp;    // the last launch writes p
+      const bool out_quad = quad && plan[l] == 2 && l + 1 < nl && plan[l + 1] == 2;
+      sweep(in, out, plan[l], l == 0, (in_quad ? 1 : 0) | (out_quad ? 2 : 0));
       in = out; in_quad = out_quad;
-      done += plan[l];
     }
-    if (residual) fnx::launch_residual_finish(g->B, sumsq, residual, s);
-    if (iters_done) *iters_done = done;
+    if (residual) {
+      sweep(in, p, 1, nl == 0);
+      residual_of(p, in, residual);
+    }
+    if (iters_done) *iters_done = max_iter;
   } else {
     // the reference's own per-sweep convergence test (fluids_init.cpp:961-979): one host read per sweep
     const float* in = nullptr;
@@ -346,18 +362,25 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
     float r = 0.f;
     for (;;) {
       float* out = bufs[sweeps & 1];
-      HIP_OK(hipMemsetAsync(sumsq, 0, (size_t)g->B * 4, s));
-      sweep(in, out, 1, sweeps == 0, sumsq);
-      fnx::launch_residual_finish(g->B, sumsq, res_ws, s);
-      HIP_OK(hipMemcpyAsync(&r, res_ws, 4, hipMemcpyDeviceToHost, s));
+      sweep(in, out, 1, sweeps == 0);
+      residual_of(out, in, W.res);
+      HIP_OK(hipMemcpyAsync(&r, W.res, 4, hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
       in = out;
       ++sweeps;
-      if (r < p_tol) break;
-      if (sweeps >= max_iter) break;
+      if (verbose) printf("Jacobi iteration %d: residual %g\n", sweeps, (double)r);      // fluids_init.cpp:968-971
+      if (r < p_tol) {
+        if (verbose) printf("Jacobi max residual fell below p_tol (%g) (terminating)\n", (double)p_tol);          // :973-978
+        break;
+      }
+      if (sweeps >= max_iter) {
+        if (verbose) printf("Jacobi max iteration count (%d) reached (terminating)\n", max_iter);                 // :982-987
+        break;
+      }
     }
+    if (verbose) fflush(stdout);
     if (in != p) HIP_OK(hipMemcpyAsync(p, in, ncell(g) * 4, hipMemcpyDeviceToDevice, s));
-    if (residual) HIP_OK(hipMemcpyAsync(residual, res_ws, 4, hipMemcpyDeviceToDevice, s));
+    if (residual) HIP_OK(hipMemcpyAsync(residual, W.res, 4, hipMemcpyDeviceToDevice, s));
     if (iters_done) *iters_done = sweeps;
   }
   HIP_OK(hipGetLastError());
@@ -376,34 +399,31 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   if (nsweeps < 1) return fail(FNX_EINVAL, "At least 1 iteration is needed (maxIter < 1)");
   hipStream_t s = (hipStream_t)stream;
   const GridDims d = dims(g);
-  Carver c(ws, ws_bytes);
-  float* tmp = (float*)c.take(ncell(g) * 4);
-  c.take((size_t)g->B * 4); c.take(4);
-  unsigned char* mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
-  if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  JacobiWs W; size_t need;
+  if (!carve_jacobi(g, ws, ws_bytes, &W, &need)) return fail(FNX_EWORKSPACE, "jacobi_sweeps: workspace too small (%zu < %zu)", ws_bytes, need);
+  float* tmp = W.tmp;
+  unsigned char* mask = W.mask;
   const bool from_zero = (reuse_mask & 2) != 0;
   if (g->is3D && !(reuse_mask & 1)) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
-  const int kmax = g->is3D ? (fnx::jacobi3d_x3_available(d, g->D, 1) ? 3 : 2) : fnx::jacobi_max_sweeps_per_launch(d, false);
+  const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
   const float* in = from_zero ? nullptr : p;
   int done = 0;
-  const bool quad = g->is3D && kmax == 2 && fnx::jacobi3d_quad_ok(d);      // see jacobi_solve
+  const bool quad = g->is3D && fnx::jacobi3d_quad_ok(d);      // see jacobi_solve
   bool in_quad = false;
   for (int l = 0; done < nsweeps; ++l) {
-    int k = nsweeps - done < kmax ? nsweeps - done : kmax;
-    if (g->is3D && kmax == 3 && nsweeps - done == 4) k = 2;
+    const int k = nsweeps - done < kmax ? nsweeps - done : kmax;
     float* out = (l % 2 == 0) ? tmp : p;
     const bool out_quad = quad && k == 2 && nsweeps - done - k >= 2;        // the launch after this one is a two-sweep pass too
     const int lay = (in_quad ? 1 : 0) | (out_quad ? 2 : 0);
     in_quad = out_quad;
     { fnx::ProfScope ps(FNX_PROF_JACOBI, s);
+      const bool fz = from_zero && l == 0;
       if (g->is3D) {
-        const bool fz = from_zero && l == 0;
-        if (k == 3) fnx::launch_jacobi3d_x3(d, mask, div, in, out, nullptr, s, 0, 0, fz);
-        else if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, nullptr, s, 0, 0, fz, -1, lay);
-        else fnx::launch_jacobi3d(d, mask, div, in, out, fz, nullptr, s);
+        if (k == 2) fnx::launch_jacobi3d_x2(d, mask, div, in, out, s, 0, 0, fz, -1, lay);
+        else fnx::launch_jacobi3d(d, mask, div, in, out, fz, s);
       } else {
-        fnx::launch_jacobi(d, false, quirks(g), flags, div, in, out, k, from_zero && l == 0, nullptr, s);
+        fnx::launch_jacobi(d, flags, div, in, out, k, fz, s);
       } }
     in = out; done += k;
   }
@@ -420,7 +440,7 @@ int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, con
 
 int fnx_jacobi_quad_ok(const FnxGrid* g) {
   if (check_grid(g) != FNX_OK || !g->is3D) return 0;
-  return fnx::jacobi3d_quad_ok(dims(g)) && !fnx::jacobi3d_x3_available(dims(g), g->D, 1) ? 1 : 0;
+  return fnx::jacobi3d_quad_ok(dims(g)) ? 1 : 0;
 }
 
 int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
@@ -433,9 +453,7 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
   if (!flags || !div || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
   if (!g->is3D) return fail(FNX_EINVAL, "jacobi_pass: 3D only (2D uses fnx_jacobi_sweeps)");
   const bool from_zero = p_in == nullptr;                 // the first pass of a solve: p = 0 everywhere, nothing to read
-  if (nsweeps < 1 || nsweeps > 3) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1, 2 or 3");
-  if (nsweeps == 3 && !fnx::jacobi3d_x3_available(dims(g), k_end > k_begin ? k_end - k_begin : g->D, k_begin2 >= 0 ? 2 : 1))
-    return fail(FNX_EINVAL, "jacobi_pass: a 3-sweep pass is not available for this grid (fnx_jacobi_max_pass_sweeps)");
+  if (nsweeps < 1 || nsweeps > 2) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1 or 2");
   if (k_begin < 0 || k_end > g->D || (k_end != 0 && k_end <= k_begin)) return fail(FNX_EINVAL, "jacobi_pass: bad plane range");
   if (k_begin2 >= 0) {
     const int n = k_end - k_begin;
@@ -444,30 +462,34 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
   }
   hipStream_t s = (hipStream_t)stream;
   const GridDims d = dims(g);
-  Carver c(ws, ws_bytes);
-  c.take(ncell(g) * 4); c.take((size_t)g->B * 4); c.take(4);
-  unsigned char* mask = (unsigned char*)c.take(ws_mask(g));
-  if (!c.ok()) return fail(FNX_EWORKSPACE, "jacobi_pass: workspace too small (%zu < %zu)", ws_bytes, c.off);
+  JacobiWs W; size_t need;
+  if (!carve_jacobi(g, ws, ws_bytes, &W, &need)) return fail(FNX_EWORKSPACE, "jacobi_pass: workspace too small (%zu < %zu)", ws_bytes, need);
+  unsigned char* mask = W.mask;
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-  if (nsweeps == 3) fnx::launch_jacobi3d_x3(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2);
-  else if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, nullptr, s, k_begin, k_end, from_zero, k_begin2, layout);
+  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, s, k_begin, k_end, from_zero, k_begin2, layout);
   else {
-    fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin, k_end);
-    if (k_begin2 >= 0) fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, nullptr, s, k_begin2, k_begin2 + (k_end - k_begin));
+    fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, s, k_begin, k_end);
+    if (k_begin2 >= 0) fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, s, k_begin2, k_begin2 + (k_end - k_begin));
   }
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }
 
-int fnx_jacobi_max_pass_sweeps(const FnxGrid* g, int nplanes, int nranges) {
-  if (check_grid(g) != FNX_OK || !g->is3D) return 0;
-  return fnx::jacobi3d_x3_available(dims(g), nplanes, nranges < 1 ? 1 : nranges) ? 3 : 2;
-}
-
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                     int nsweeps, int k_begin, int k_end, void* ws, size_t ws_bytes, int reuse_mask, void* stream) {
   return fnx_jacobi_pass2(g, flags, div, p_in, p_out, nsweeps, k_begin, k_end, -1, ws, ws_bytes, reuse_mask, stream);
+}
+
+int fnx_residual(const FnxGrid* g, const float* a, const float* b, float* sumsq, float* residual, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!a || (!sumsq && !residual)) return fail(FNX_EINVAL, "residual: NULL tensor");
+  if (!ws || ws_bytes < fnx::residual_scratch_bytes(g->B)) return fail(FNX_EWORKSPACE, "residual: workspace too small (%zu < %zu)", ws_bytes, fnx::residual_scratch_bytes(g->B));
+  const GridDims d = dims(g);
+  const size_t per = (size_t)g->D * g->H * g->W;
+  fnx::launch_residual(g->B, per, (size_t)d.K0 * d.HW, (size_t)d.KN * d.HW, a, b, (double*)ws, sumsq, residual, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
 }
 
 int fnx_velocity_update(const FnxGrid* g, const float* p, float* U, const float* flags, void* stream) {
@@ -691,16 +713,11 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   if (!c.ok() || ws_bytes < ws_step(g)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small (%zu < %zu)", ws_bytes, ws_step(g));
   const bool has_rho = st->density != nullptr;
   // simulate.py:75-93: advect density then velocity (both by the OLD U)
-  static const bool no_fuse = getenv("FNX_ADVECT_NOFUSE") != nullptr;       // A/B switch
-  if (has_rho && !no_fuse) {
+  if (has_rho) {
     // forward passes of both advections in one launch, backward/clamp passes in another (same cell functions)
     if (int rc = fnx_advect_step(g, prm->dt, st->density, st->U, st->flags, rho2, U2, prm->sample_outside_fluid,
                                  prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
-  } else {
-    if (has_rho) {
-      if (int rc = fnx_advect_scalar(g, prm->dt, st->density, st->U, st->flags, rho2, FNX_ADVECT_MACCORMACK, 1,
-                                     prm->sample_outside_fluid, prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
-    }
+  } else {                                     // simulate.py:71-83: no 'density' key in the batch
     if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
                                 prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   }
@@ -718,13 +735,15 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   float* rho = has_rho ? st->density : nullptr;
   if (prm->method == 0) {
     // simulate.py:144-168
-    if (int rc = jacobi_solve(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, kept_mask, (prm->static_flags & 1) != 0, stream)) return rc;
+    if (int rc = jacobi_solve(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, kept_mask, (prm->static_flags & 1) != 0, stream, 0)) return rc;
     return fnx_post_projection(g, st, stream);
   } else {
     // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),
     // so the concatenation is not materialised: U is projected in place.
     if (tail_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the CNN");
-    if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, st->p, st->U, tail, stream)) return rc;
+    if (prm->precision_mode != FNX_PRECISION_FP32 && prm->precision_mode != FNX_PRECISION_FP32_DIRECT)
+      return fail(FNX_EINVAL, "simulate_step: unknown precision_mode %d", prm->precision_mode);
+    if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, prm->precision_mode, st->p, st->U, tail, stream)) return rc;
   }
   fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
   HIP_OK(hipGetLastError());

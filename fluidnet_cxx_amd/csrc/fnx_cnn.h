@@ -30,7 +30,7 @@ size_t multiscale_ws_bytes(const GridDims& g, bool is3d);
 size_t fluidnet_ws_bytes(const GridDims& g, bool is3d);
 
 // x (B,2,D,H,W) -> p (B,1,D,H,W)
-void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, void* ws,
+void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                         hipStream_t s);
 
 // pieces of FluidNet.forward (lib/model.py:76-227)
@@ -45,6 +45,6 @@ void launch_gather_input(const GridDims& g, int nc, const float* input, float* U
 
 struct FnxGrid;
 namespace fnx {
-int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, float* p_out, float* U, void* ws,
-                  void* stream);
+int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, int precision_mode, float* p_out, float* U,
+                  void* ws, void* stream);
 }

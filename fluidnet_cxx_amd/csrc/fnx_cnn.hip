@@ -22,19 +22,13 @@ struct PackedLayer { size_t w_off, b_off; };   // float offsets into the packed 
 
 // 5x5(x5) layers (Cin 3 or 32, Cout 32 or 8) run on v_mfma_f32_16x16x4_f32: Cin is padded to a multiple of 4 (one
 // k-step) and Cout to a multiple of 16 (one M block) with zero weights.
-inline bool mfma16_layer(const ConvLayer& L) {
-  static const bool thin_direct = getenv("FNX_CONV_THIN_DIRECT") != nullptr;   // A/B switch: keep them on the direct kernel
-  return !thin_direct && L.k == 5 && (L.cin % 8 == 0 || L.cin <= 4) && L.cout <= 32;
-}
+inline bool mfma16_layer(const ConvLayer& L) { return L.k == 5 && (L.cin % 8 == 0 || L.cin <= 4) && L.cout <= 32; }
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // Cout <= 8 (and a Cin the 8-channel stage fits): two x-adjacent pixels share one 16-row M block (conv5_mfma16_kernel PAIR)
-inline bool pair_layer(int cin, int cout) {
-  static const bool off = getenv("FNX_CONV_NOPAIR") != nullptr;       // A/B switch
-  return !off && cout <= 8 && cin % 8 == 0;
-}
+inline bool pair_layer(int cin, int cout) { return cout <= 8 && cin % 8 == 0; }
 inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 && L.cout % 32 == 0; }
-// 2D 3x3 MFMA layers also run in the Winograd domain (conv3_wino_kernel): their transformed weights G g G^T
-// ([16][Cin][Cout]) follow the [tap][Cin][Cout] image in the packed buffer
+// the 3x3(x3) MFMA layers also run in the Winograd domain (conv3_wino3_kernel): their transformed weights G g G^T
+// ([dz][16][Cin][Cout], then the same values in the kernel's stage-contiguous order) follow the [tap][Cin][Cout] image
 inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_layer(L); }
 inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
   if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + 2 * (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
@@ -370,395 +364,29 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 2D 3x3 convolution in the Winograd domain, F(2x2, 3x3), fp32 on v_mfma_f32_32x32x2_f32:
+// 3x3(x3) convolution in the Winograd domain, F(2x2, 3x3), fp32 on v_mfma_f32_32x32x2_f32:
 //   Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A      (Lavin & Gray; d = 4x4 input patch of a 2x2 output block)
 // 16 multiplies per 4 outputs instead of 36: the contraction over input channels becomes 16 independent GEMMs (one per
 // position p of the 4x4 transform domain)
 //   D_p[cout 32][block 32] += Wt_p[cout][k] * Xt_p[k][block],   k = two consecutive input channels
-// A wave owns 32 output channels x 32 blocks (16 x 2 blocks = 32 x 4 pixels) and ALL 16 positions: 16 accumulators of
-// 16 registers (the AGPR half of a 512-register budget, one wave per SIMD).  Workgroup = 4 waves = NCG output-channel
-// groups x NPG pixel groups (stacked in y).  A stage is WCH input channels:
-//   raw halo tile  global -> registers (prefetched during the previous stage's MFMAs) -> LDS
-//   B^T d B        per (channel, block) patch by the 256 threads, LDS -> LDS [p][c][block]
-//   G g G^T        precomputed at pack time, [p][cin][cout]; the stage's slice goes global -> LDS by global_load_lds (DMA,
-//                  double-buffered, one stage ahead)
-//   16 * WCH/2 MFMAs per wave with the operand reads of k-step i+1 issued under the MFMAs of k-step i
+//   raw halo tile  global -> registers (prefetched two stages ahead) -> LDS
+//   B^T d B        per (channel, block) half patch by all threads, LDS -> LDS [position pair][c][block][2]
+//   G g G^T        precomputed at pack time; the stage's slice goes global -> LDS by global_load_lds (DMA, one stage ahead)
 // and the epilogue applies A^T . A per output channel register, adds the bias, clamps (ReLU) and stores pixel pairs.
+// The 16 positions of a (32 output channels x 32 blocks) tile are split over TWO waves (8 positions = 128 accumulator
+// registers each), so that a wave fits a 256-register budget and two waves share a SIMD: while one is between its barriers
+// the other one's MFMAs keep the matrix cores busy (all 16 positions in one 512-register wave, one wave per SIMD, exposes
+// every such gap: measured 2.78 vs 2.42 ms per 1024^2 forward).  Workgroup = 2 position halves x NCG output-channel groups
+// x NPG pixel groups stacked in y (4 or 8 waves); stage = 4 input channels.  Each wave ends with partial outputs (A^T . A
+// is linear in the positions); the two halves swap half of their 16 output-channel registers through LDS and each finishes
+// (bias, ReLU, store) its own 8.
 // Numerics: not the summation order of a direct convolution; the transforms are exact in binary up to the roundings of
 // their additions (measured against the CPU oracle: max |d| 7.1e-8 at |ref| <= 7.7e-2, the direct kernel 7.5e-8;
-// tools/cnn_error_probe.py, tests/test_parity_gpu.py::test_cnn_winograd_layers_vs_oracle).
-// ---------------------------------------------------------------------------------------------------
-constexpr int WCH = 8;            // input channels per stage
-constexpr int WCOLS = 34;         // 32 pixels + halo
-
-template <int NCG>
-__global__ __launch_bounds__(256, 1) void conv3_wino_kernel(ConvArgs a, const float* __restrict__ wt) {
-  constexpr int NPG = 4 / NCG;
-  constexpr int ROWS = 4 * NPG + 2;              // raw tile rows: y0-1 .. y0+4*NPG
-  constexpr int NB = 32 * NPG;                   // blocks per workgroup
-  constexpr int RW = 32 * NCG;                   // output channels per workgroup = floats per weight row
-  constexpr int WROWS = 16 * WCH;                // (position, cin) rows per stage
-  constexpr int LPR = RW / 4, RPI = 64 / LPR, NWI = WROWS / RPI;
-  constexpr int NEL = WCH * ROWS * WCOLS, NLD = (NEL + 255) / 256;
-  constexpr int NPATCH = WCH * NB, PPT = NPATCH / 256;         // patches per thread (1, 2 or 4)
-  __shared__ __attribute__((aligned(16))) float raw[NEL];
-  __shared__ __attribute__((aligned(16))) float xt[16 * WCH * NB];
-  // two separate arrays (not wbuf[2][..]): the compiler then knows that the DMA into one cannot alias the reads of the
-  // other and does not drain vmcnt (the next stage's loads, just issued) in front of the MFMA phase
-  __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];
-  __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int cg = wave % NCG, pg = wave / NCG;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * NPG);
-  const int ngrp = a.cout / RW;
-  const int grp = blockIdx.z % ngrp, b = blockIdx.z / ngrp;
-  const int cout0 = grp * RW;
-  const size_t plane = (size_t)a.H * a.W;
-
-  f32x16 acc[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-
-  const float* xb = a.x + (size_t)b * a.cin * plane;
-  // Staging slots: element idx = threadIdx.x + 256*t of the [WCH][ROWS][34] halo tile.  Loads go through a buffer
-  // resource that spans the stage's WCH channel planes: an out-of-image element gets an out-of-range offset and the
-  // hardware returns 0 for it -- no select between the load and the LDS store (the compiler hoists such a select to
-  // the load and drains vmcnt there, in front of the MFMA phase the load is supposed to hide under).
-  unsigned uoff[NLD];
-#pragma unroll
-  for (int t = 0; t < NLD; ++t) {
-    const int idx = threadIdx.x + 256 * t;
-    const int cc = idx / (ROWS * WCOLS);
-    const int rem = idx - cc * ROWS * WCOLS;
-    const int row = rem / WCOLS, col = rem - row * WCOLS;
-    const int gx = x0 - 1 + col, gy = y0 - 1 + row;
-    const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    uoff[t] = ok ? (unsigned)(((size_t)cc * plane + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
-  }
-  const unsigned stage_bytes = (unsigned)((size_t)WCH * plane * 4);        // < 2^32: checked by the host (launch_conv)
-  float stage[NLD];
-  auto prefetch = [&](int c0) {
-    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * plane, stage_bytes);
-#pragma unroll
-    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
-  };
-  auto stage_weights = [&](int c0, float* wdst) {
-#pragma unroll
-    for (int q = 0; q < NWI / 4; ++q) {
-      const int wi = wave + 4 * q;                      // wave-uniform
-      const int row = wi * RPI + lane / LPR;            // (p, ci)
-      const int pp = row / WCH, ci = row - pp * WCH;
-      const float* src = wt + ((size_t)pp * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
-    }
-  };
-  const int niter = a.cin / WCH;                        // even (checked by the host)
-  prefetch(0); stage_weights(0, wbuf0);
-  auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
-    // raw tile of this stage -> LDS (the previous stage's transform reads finished before its second barrier)
-#pragma unroll
-    for (int t = 0; t < NLD; ++t)
-      if (threadIdx.x + 256 * t < NEL) raw[threadIdx.x + 256 * t] = stage[t];
-    __syncthreads();                                   // raw visible; every wave is done with xt of the previous stage
-    // input transform B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int q = threadIdx.x + 256 * i;
-      const int n = q % NB, c = q / NB;
-      const int bx = n & 15, by = n >> 4;
-      const float* d = &raw[c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx];
-      float t[4][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float d0 = d[s], d1 = d[WCOLS + s], d2 = d[2 * WCOLS + s], d3 = d[3 * WCOLS + s];
-        t[0][s] = d0 - d2; t[1][s] = d1 + d2; t[2][s] = d2 - d1; t[3][s] = d1 - d3;
-      }
-      float* o = &xt[c * NB + n];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o[(4 * r + 0) * WCH * NB] = t[r][0] - t[r][2];
-        o[(4 * r + 1) * WCH * NB] = t[r][1] + t[r][2];
-        o[(4 * r + 2) * WCH * NB] = t[r][2] - t[r][1];
-        o[(4 * r + 3) * WCH * NB] = t[r][1] - t[r][3];
-      }
-    }
-    __syncthreads();                                   // xt + this stage's weight DMA (issued one stage ago) visible
-    // next stage's raw tile (-> registers) and weights (-> LDS) are in flight during the MFMAs; issued after the barrier so
-    // that its vmcnt(0) only covers transfers that had a whole MFMA phase to land
-    if (it + 1 < niter) { prefetch((it + 1) * WCH); stage_weights((it + 1) * WCH, wnext); }
-    {
-      const float* wl = &wcur[half * RW + cg * 32 + l31];
-      const float* tl = &xt[half * NB + pg * 32 + l31];
-      float av[2][16], bv[2][16];
-      auto load_k = [&](int ks, float (&A)[16], float (&B)[16]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-          A[p] = wl[(p * WCH + 2 * ks) * RW];
-          B[p] = tl[(p * WCH + 2 * ks) * NB];
-        }
-      };
-      load_k(0, av[0], bv[0]);
-#pragma unroll
-      for (int ks = 0; ks < WCH / 2; ++ks) {
-        if (ks + 1 < WCH / 2) load_k(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][p], bv[ks & 1][p], acc[p], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  for (int it = 0; it < niter; it += 2) {
-    stage_body(it, wbuf0, wbuf1);
-    stage_body(it + 1, wbuf1, wbuf0);
-  }
-  // output transform A^T M A, A^T = [1 1 1 0; 0 1 -1 -1], per output-channel register
-  const int bx = l31 & 15, byl = l31 >> 4;
-  const int x = x0 + 2 * bx, y = y0 + 2 * (2 * pg + byl);
-  if (x < a.W && y < a.H) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cout0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float bias = a.bias[co];
-      float t0[4], t1[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        t0[s] = (acc[s][r] + acc[4 + s][r]) + acc[8 + s][r];
-        t1[s] = (acc[4 + s][r] - acc[8 + s][r]) - acc[12 + s][r];
-      }
-      float y00 = ((t0[0] + t0[1]) + t0[2]) + bias, y01 = ((t0[1] - t0[2]) - t0[3]) + bias;
-      float y10 = ((t1[0] + t1[1]) + t1[2]) + bias, y11 = ((t1[1] - t1[2]) - t1[3]) + bias;
-      if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-      float* o = a.y + ((size_t)b * a.cout + co) * plane + (size_t)y * a.W + x;
-      if (x + 1 < a.W) {
-        *(float2*)o = make_float2(y00, y01);
-        if (y + 1 < a.H) *(float2*)(o + a.W) = make_float2(y10, y11);
-      } else {
-        o[0] = y00;
-        if (y + 1 < a.H) o[a.W] = y10;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Second Winograd kernel: the same F(2x2,3x3) GEMMs with the 16 positions of a (32 output channels x 32 blocks) tile
-// split over TWO waves (8 positions = 128 accumulator registers each), so that a wave fits a 256-register budget and
-// TWO workgroups share a CU: while one is between its barriers (halo tile -> LDS, input transform, operand latency)
-// the other one's MFMAs keep the matrix cores busy -- with one 512-register wave per SIMD (conv3_wino_kernel) every
-// such gap is exposed (measured: MFMA phase 407 us of a 1073 us layer).  Workgroup = 4 waves = 2 position halves x
-// NCG output-channel groups x (2/NCG) pixel groups; stage = 4 input channels (43 KB of LDS per workgroup).  Each wave
-// ends with partial outputs (A^T . A is linear in the positions); the two halves swap half of their 16 output-channel
-// registers through LDS and each finishes (bias, ReLU, store) its own 8.
-// ---------------------------------------------------------------------------------------------------
-// IS3D: a 3x3x3 convolution is the sum over its three z taps of 3x3 convolutions of the planes z-1, z, z+1 -- the same
-// 16 GEMMs with three times the contraction length (transformed weights [dz][16][Cin][Cout]); Winograd in x and y only.
-// Workgroup = 2 position halves x NCG output-channel groups x NPG pixel groups (4 or 8 waves).  The weights of a stage are
-// streamed from L2 once per workgroup: with 32 blocks (128 pixels) per workgroup that stream, 4.3 GB for a 64->128 layer
-// at 1024^2, is what bounds the kernel (measured: 430 us of load/DMA time against 437 us of MFMA time); NPG = 2 halves it.
-template <int NCG, int NPG, int W2CH, bool IS3D = false>      // W2CH = input channels per stage
-__global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArgs a, const float* __restrict__ wt) {
-  constexpr int NWV = 2 * NCG * NPG, NT = 64 * NWV;          // waves, threads
-  constexpr int ROWS = 4 * NPG + 2;
-  constexpr int NB = 32 * NPG;
-  constexpr int RW = 32 * NCG;
-  constexpr int WROWS = 16 * W2CH;
-  constexpr int LPR = RW / 4, RPI = 64 / LPR, NWI = WROWS / RPI;
-  constexpr int NEL = W2CH * ROWS * WCOLS, NLD = (NEL + NT - 1) / NT;
-  constexpr int NPATCH = W2CH * NB, PPT = (NPATCH + NT - 1) / NT;     // (channel, block) patches per stage / per thread
-  __shared__ __attribute__((aligned(16))) float raw[NEL];
-  __shared__ __attribute__((aligned(16))) float xt[16 * W2CH * NB];
-  __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];     // (separate arrays: see conv3_mfma_kernel)
-  __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int h = wave & 1, g = wave >> 1;                // position half; output-channel or pixel group
-  const int cg = g % NCG, pg = g / NCG;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * (4 * NPG);
-  const int ngrp = a.cout / RW;
-  int zb = blockIdx.z;
-  const int grp = zb % ngrp; zb /= ngrp;
-  const int z = zb % a.D, b = zb / a.D;
-  const int cout0 = grp * RW;
-  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
-
-  f32x16 acc[8];
-#pragma unroll
-  for (int p = 0; p < 8; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-
-  const float* xb = a.x + (size_t)b * a.cin * vol;
-  unsigned uoff[NLD];                                   // (out-of-image slots: out-of-range offset, the load returns 0)
-#pragma unroll
-  for (int t = 0; t < NLD; ++t) {
-    const int idx = threadIdx.x + NT * t;
-    const int cc = idx / (ROWS * WCOLS);
-    const int rem = idx - cc * ROWS * WCOLS;
-    const int row = rem / WCOLS, col = rem - row * WCOLS;
-    const int gx = x0 - 1 + col, gy = y0 - 1 + row;
-    const bool ok = (idx < NEL) & (gx >= 0) & (gx < a.W) & (gy >= 0) & (gy < a.H);
-    uoff[t] = ok ? (unsigned)(((size_t)cc * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
-  }
-  const unsigned stage_bytes = (unsigned)((size_t)W2CH * vol * 4 - 1) + 1u;
-  float stage[NLD];
-  auto prefetch = [&](int dz, int c0) {
-    const int zz = IS3D ? z + dz - 1 : 0;
-    const BufRsrcC r = make_rsrc_c(xb + (size_t)c0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
-#pragma unroll
-    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
-  };
-  auto stage_weights = [&](int dz, int c0, float* wdst) {
-#pragma unroll
-    for (int q = 0; q < NWI / NWV; ++q) {
-      const int wi = wave + NWV * q;
-      const int row = wi * RPI + lane / LPR;            // (p, ci)
-      const int pp = row / W2CH, ci = row - pp * W2CH;
-      const float* src = wt + ((size_t)(dz * 16 + pp) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
-    }
-  };
-  // iteration space: (dz, c0) pairs with an in-range z plane; Cin / W2CH is even (checked by the host), so is niter
-  const int nchunk = a.cin / W2CH;
-  int dz_lo = 0, dz_hi = IS3D ? 3 : 1;
-  if (IS3D) { if (z == 0) dz_lo = 1; if (z == a.D - 1) dz_hi = 2; }
-  const int niter = (dz_hi - dz_lo) * nchunk;
-  if (niter > 0) { prefetch(dz_lo, 0); stage_weights(dz_lo, 0, wbuf0); }
-  // (A prefetch distance of two stages -- three weight buffers, two register sets -- was tried twice: with __syncthreads()
-  // it changes nothing, because the workgroup-scope fence of every barrier waits for ALL outstanding LDS DMA; with
-  // fence-free barriers (s_waitcnt lgkmcnt(0); s_barrier) and explicit vmcnt(K) waits it is correct and 4 % SLOWER,
-  // 947 vs 908 us for 64->128 at 1024^2: the transfers' latency is not what the stage waits for.)
-  auto stage_body = [&](int it, float* wcur, float* wnext) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < NLD; ++t)
-      if (threadIdx.x + NT * t < NEL) raw[threadIdx.x + NT * t] = stage[t];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PPT; ++i)
-    if (NPATCH % NT == 0 || threadIdx.x + NT * i < NPATCH) {        // B^T d B
-      const int q = threadIdx.x + NT * i;
-      const int n = q % NB, c = q / NB;
-      const int bx = n & 15, by = n >> 4;
-      const float* d = &raw[c * ROWS * WCOLS + (2 * by) * WCOLS + 2 * bx];
-      float t[4][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float d0 = d[s], d1 = d[WCOLS + s], d2 = d[2 * WCOLS + s], d3 = d[3 * WCOLS + s];
-        t[0][s] = d0 - d2; t[1][s] = d1 + d2; t[2][s] = d2 - d1; t[3][s] = d1 - d3;
-      }
-      float* o = &xt[c * NB + n];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o[(4 * r + 0) * W2CH * NB] = t[r][0] - t[r][2];
-        o[(4 * r + 1) * W2CH * NB] = t[r][1] + t[r][2];
-        o[(4 * r + 2) * W2CH * NB] = t[r][2] - t[r][1];
-        o[(4 * r + 3) * W2CH * NB] = t[r][1] - t[r][3];
-      }
-    }
-    __syncthreads();
-    if (it + 1 < niter) {
-      const int dzn = dz_lo + (it + 1) / nchunk, cn = ((it + 1) % nchunk) * W2CH;
-      prefetch(dzn, cn); stage_weights(dzn, cn, wnext);
-    }
-    {
-      const float* wl = &wcur[(8 * h * W2CH + half) * RW + cg * 32 + l31];
-      const float* tl = &xt[(8 * h * W2CH + half) * NB + pg * 32 + l31];
-      float av[2][8], bv[2][8];
-      auto load_k = [&](int ks, float (&A)[8], float (&B)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          A[p] = wl[(p * W2CH + 2 * ks) * RW];
-          B[p] = tl[(p * W2CH + 2 * ks) * NB];
-        }
-      };
-      load_k(0, av[0], bv[0]);
-#pragma unroll
-      for (int ks = 0; ks < W2CH / 2; ++ks) {
-        if (ks + 1 < W2CH / 2) load_k(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][p], bv[ks & 1][p], acc[p], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  for (int it = 0; it < niter; it += 2) {
-    stage_body(it, wbuf0, wbuf1);
-    stage_body(it + 1, wbuf1, wbuf0);
-  }
-  // Output transform A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]); this wave holds rows 2h, 2h+1 of M (acc[4*(row-2h) + s]):
-  //   h = 0:  t0 = M0 + M1, t1 = M1          h = 1:  t0 = M2, t1 = -M2 - M3
-  // Register r belongs to half (r >> 3): the partial outputs of the other half's registers go to LDS, the own ones are
-  // completed with the partner's.
-  float part[16][4];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float t0[4], t1[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (h == 0) { t0[s] = acc[s][r] + acc[4 + s][r]; t1[s] = acc[4 + s][r]; }
-      else { t0[s] = acc[s][r]; t1[s] = (-acc[s][r]) - acc[4 + s][r]; }
-    }
-    part[r][0] = (t0[0] + t0[1]) + t0[2]; part[r][1] = (t0[1] - t0[2]) - t0[3];
-    part[r][2] = (t1[0] + t1[1]) + t1[2]; part[r][3] = (t1[1] - t1[2]) - t1[3];
-  }
-  const int bx = l31 & 15, byl = l31 >> 4;
-  const int x = x0 + 2 * bx, y = y0 + 2 * (2 * pg + byl);
-  // exchange buffer (per wave and round: 4 registers x 4 outputs x 64 lanes): xt itself when it is large enough
-  constexpr bool XT_BIG = 16 * W2CH * NB >= NWV * 16 * 64;
-  __shared__ __attribute__((aligned(16))) float exch_sep[XT_BIG ? 1 : NWV * 16 * 64];
-  float* exch = XT_BIG ? xt : exch_sep;
-  float* ex_out = &exch[wave * 16 * 64 + lane];          // what this wave sends: registers of the other half
-  const float* ex_in = &exch[(wave ^ 1) * 16 * 64 + lane];
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {              // 4 of the 8 registers per round (16 KB of LDS)
-    __syncthreads();                                     // (round 0: every wave is done with the stage buffers' neighbours; round 1: round 0 was read)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((r >> 3) != h && ((r >> 2) & 1) == round) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ex_out[((r & 3) * 4 + q) * 64] = part[r][q];
-      }
-    __syncthreads();
-    if (x < a.W && y < a.H) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((r >> 3) == h && ((r >> 2) & 1) == round) {
-          const int co = cout0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float bias = a.bias[co];
-          float v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v[q] = (part[r][q] + ex_in[((r & 3) * 4 + q) * 64]) + bias;
-            if (a.relu) v[q] = fmaxf(v[q], 0.f);
-          }
-          float* o = a.y + ((size_t)b * a.cout + co) * vol + (size_t)z * plane + (size_t)y * a.W + x;
-          if (x + 1 < a.W) {
-            *(float2*)o = make_float2(v[0], v[1]);
-            if (y + 1 < a.H) *(float2*)(o + a.W) = make_float2(v[2], v[3]);
-          } else {
-            o[0] = v[0];
-            if (y + 1 < a.H) o[a.W] = v[2];
-          }
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Third Winograd kernel: conv3_wino2_kernel's decomposition (two position halves x NCG output-channel groups x NPG pixel
-// groups; the same transforms, the same MFMA order per accumulator, the same epilogue arithmetic: SAME BITS) as a
-// PERSISTENT software pipeline.  wino2 serialises every stage -- halo tile -> LDS, barrier, transform, barrier, operand
-// reads, MFMAs -- and pays a full prologue (two dependent global round trips) and epilogue per 256-pixel tile with nothing
-// to overlap them: one 8-wave workgroup fills a CU's registers.  Measured on it at 1024^2: time = rounds x (5.5 us + stages
-// x 1.31 us) against 0.91 us of MFMA work per stage, 47 % of the MFMA peak.  Here:
+// tools/cnn_error_probe.py, tests/test_parity_gpu.py::test_cnn_winograd_layers_vs_oracle).  FNX_PRECISION_FP32_DIRECT
+// (fnx_multiscale_forward's precision_mode) keeps every layer on the direct kernels instead.
+// The kernel is a PERSISTENT software pipeline (the round-1 kernel serialised every stage -- halo tile -> LDS, barrier,
+// transform, barrier, operand reads, MFMAs -- and paid a full prologue and epilogue per 256-pixel tile: time = rounds x
+// (5.5 us + stages x 1.31 us) against 0.91 us of MFMA work per stage, 47 % of the MFMA peak at 1024^2):
 //  * every LDS image has two copies and a phase has ONE barrier.  Between two barriers a wave issues
 //      global -> registers   halo tile of stage s+2          (first; lands during the MFMAs)
 //      global -> LDS (DMA)   transformed weights of stage s+1
@@ -781,6 +409,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino2_kernel(ConvArg
 // tile period, so about half of the transformed-weight reads miss it and are served by the Infinity Cache -- that, not
 // HBM, is the "traffic beyond the activations" FETCH_SIZE shows for these launches (it counts Infinity-Cache hits).
 #define W3_ST(p, v) do { const float2 v_ = (v); __builtin_nontemporal_store((f32x2){v_.x, v_.y}, (f32x2*)(p)); } while (0)
+constexpr int WCOLS = 34;                              // halo tile row: 32 pixels + halo
 constexpr int W3C = 4;                                 // input channels per stage of conv3_wino3_kernel
 inline int wino3_rw(int cout) { return cout % 64 == 0 ? 64 : 32; }   // its output channels per workgroup
 template <int NCG, int NPG, bool IS3D = false>
@@ -1353,79 +982,50 @@ void launch_conv_mfma_t(const ConvArgs& a, bool is3d, hipStream_t s) {
 }
 
 void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
-  static const bool wide = getenv("FNX_CONV_WIDE") != nullptr;     // experiment switch: 128 output channels per wave
   // small images (the quarter-resolution tower): shorter tiles (16 -> 8 -> 4 rows per block) until the launch has a
-  // block for every CU slot
+  // block for every CU slot.  (Measured and not kept: 128 output channels per wave; 8-row tiles with 4-channel stages at
+  // 3 waves/SIMD, 2.5 % slower.)
   const int ngrp = a.cout / (a.cout % 64 == 0 ? 64 : 32);
   auto blocks = [&](int rows) { return (long)((a.W + 31) / 32) * ((a.H + rows - 1) / rows) * a.B * a.D * ngrp; };
-  static const int pr_env = [] { const char* e = getenv("FNX_CONV_PR"); return e ? atoi(e) : 0; }();   // experiment switch
-  const int pr = pr_env ? pr_env : (blocks(16) >= 512 ? 4 : (blocks(8) >= 512 ? 2 : 1));
-  static const bool occ3 = getenv("FNX_CONV_OCC3") != nullptr;     // experiment: 8-row tiles, 4-channel stages, 3 waves/SIMD
-  if (occ3 && a.cout % 64 == 0 && a.cin % 4 == 0) { launch_conv_mfma_t<2, 2, 4, 3>(a, is3d, s); return; }
-  if (a.cout % 128 == 0 && wide) launch_conv_mfma_t<4, 2>(a, is3d, s);
-  else if (a.cout % 64 == 0) {
+  const int pr = blocks(16) >= 512 ? 4 : (blocks(8) >= 512 ? 2 : 1);
+  if (a.cout % 64 == 0) {
     if (pr == 4) launch_conv_mfma_t<2, 4>(a, is3d, s); else if (pr == 2) launch_conv_mfma_t<2, 2>(a, is3d, s); else launch_conv_mfma_t<2, 1>(a, is3d, s);
   } else {
     if (pr == 4) launch_conv_mfma_t<1, 4>(a, is3d, s); else if (pr == 2) launch_conv_mfma_t<1, 2>(a, is3d, s); else launch_conv_mfma_t<1, 1>(a, is3d, s);
   }
 }
 
-// Winograd F(2x2,3x3) for the 2D 3x3 MFMA layers, when the launch fills the chip (one workgroup per CU at a time)
+// Winograd F(2x2,3x3) for the 3x3(x3) MFMA layers, when the launch fills the chip (one persistent workgroup per CU slot);
+// false: nothing launched (small grid), the caller uses the direct kernel
 bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t s) {
-  // FNX_CONV_WINO: 0 = off (direct implicit GEMM), 1 = conv3_wino_kernel, 2 (default) = conv3_wino2_kernel
-  static const int mode = [] { const char* e = getenv("FNX_CONV_WINO"); return e ? atoi(e) : 3; }();
-  if (mode == 0 || a.cin % (2 * WCH) != 0 || a.cout % 32 != 0) return false;
-  if (a.D != 1 && (mode < 2 || !is3d)) return false;
-  if (mode == 2 || mode == 3) {
-    // 64 output channels per workgroup with 4-channel stages; the 32-channel layers: two pixel groups, 8-channel stages
-    // (measured at 1024^2: 64->32 297 -> 274 us; 8-channel stages with 32 output channels per workgroup on the wider
-    // layers: 918 -> 1065 us, the input tile is read and transformed once per 32 instead of 64 output channels)
-    static const int v8 = [] { const char* e = getenv("FNX_WINO2_WAVES8"); return e ? atoi(e) : 1; }();   // A/B switch
-    const int ncg = a.cout % 64 == 0 ? 2 : 1;
-    int npg = 2 / ncg;
-    if (ncg == 2 && v8 && (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B * a.D * (a.cout / 64) >= 512) npg = 2;   // 8 waves
-    const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * a.D * (a.cout / (32 * ncg)));
-    if ((long)grid.x * grid.y * grid.z < (npg * ncg == 4 ? 512 : 1024)) return false;
-    if (mode == 3 && a.cin % (4 * W3C) == 0) {
-      // persistent: one workgroup per CU slot (8-wave workgroups fill a CU's registers; two 4-wave ones fit), walking
-      // over the tiles x fastest
-      assert(wino3_rw(a.cout) == 32 * ncg);
-      if (ncg == 1) npg = 2;
-      const float* w3 = wt + (size_t)16 * (is3d ? 3 : 1) * a.cin * a.cout;   // the stage-contiguous image follows [16][Cin][Cout]
-      const int ntx = (a.W + 31) / 32, nty = (a.H + 4 * npg - 1) / (4 * npg);
-      const long nt = (long)ntx * nty * a.B * a.D * (a.cout / (32 * ncg));
-      static const int ncu = [] { int d = 0; hipDeviceProp_t pr; hipGetDevice(&d); hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
-      const int slots = ncu * (ncg * npg == 4 ? 1 : 2);
-      if (nt < (npg * ncg == 4 ? 512 : 1024) || nt > 0x7fffffffl) return false;
-      const int nwg = (int)(nt < slots ? nt : slots);
-      if (is3d) {
-        if (ncg == 2 && npg == 2) conv3_wino3_kernel<2, 2, true><<<nwg, 512, 0, s>>>(a, w3, ntx, nty, (int)nt);
-        else if (ncg == 2) conv3_wino3_kernel<2, 1, true><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
-        else conv3_wino3_kernel<1, 2, true><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
-      } else if (ncg == 2 && npg == 2) conv3_wino3_kernel<2, 2><<<nwg, 512, 0, s>>>(a, w3, ntx, nty, (int)nt);
-      else if (ncg == 2) conv3_wino3_kernel<2, 1><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
-      else conv3_wino3_kernel<1, 2><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
-      return true;
-    }
-    if (is3d) {
-      if (ncg == 2 && npg == 2) conv3_wino2_kernel<2, 2, 4, true><<<grid, 512, 0, s>>>(a, wt);
-      else if (ncg == 2) conv3_wino2_kernel<2, 1, 4, true><<<grid, 256, 0, s>>>(a, wt);
-      else conv3_wino2_kernel<1, 2, 8, true><<<grid, 256, 0, s>>>(a, wt);
-    } else if (ncg == 2 && npg == 2) conv3_wino2_kernel<2, 2, 4><<<grid, 512, 0, s>>>(a, wt);
-    else if (ncg == 2) conv3_wino2_kernel<2, 1, 4><<<grid, 256, 0, s>>>(a, wt);
-    else conv3_wino2_kernel<1, 2, 8><<<grid, 256, 0, s>>>(a, wt);
-    return true;
-  }
-  const int ncg = a.cout % 128 == 0 ? 4 : (a.cout % 64 == 0 ? 2 : 1), npg = 4 / ncg;
-  const dim3 grid((a.W + 31) / 32, (a.H + 4 * npg - 1) / (4 * npg), a.B * (a.cout / (32 * ncg)));
-  if ((long)grid.x * grid.y * grid.z < 512) return false;
-  if (ncg == 4) conv3_wino_kernel<4><<<grid, 256, 0, s>>>(a, wt);
-  else if (ncg == 2) conv3_wino_kernel<2><<<grid, 256, 0, s>>>(a, wt);
-  else conv3_wino_kernel<1><<<grid, 256, 0, s>>>(a, wt);
+  if (a.cin % (4 * W3C) != 0 || a.cout % 32 != 0) return false;
+  if (a.D != 1 && !is3d) return false;
+  // 64 output channels per workgroup where Cout allows it; 8-wave workgroups (two pixel groups share a stage's weights)
+  // when the launch is large enough (measured at 1024^2: 64->32 297 -> 274 us against 4-wave workgroups)
+  const int ncg = a.cout % 64 == 0 ? 2 : 1;
+  int npg = 2 / ncg;
+  if (ncg == 2 && (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B * a.D * (a.cout / 64) >= 512) npg = 2;   // 8 waves
+  if (ncg == 1) npg = 2;
+  assert(wino3_rw(a.cout) == 32 * ncg);
+  const float* w3 = wt + (size_t)16 * (is3d ? 3 : 1) * a.cin * a.cout;   // the stage-contiguous image follows [dz][16][Cin][Cout]
+  const int ntx = (a.W + 31) / 32, nty = (a.H + 4 * npg - 1) / (4 * npg);
+  const long nt = (long)ntx * nty * a.B * a.D * (a.cout / (32 * ncg));
+  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; hipGetDevice(&d); hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
+  const int slots = ncu * (ncg * npg == 4 ? 1 : 2);      // 8-wave workgroups fill a CU's registers; two 4-wave ones fit
+  if (nt < (npg * ncg == 4 ? 512 : 1024) || nt > 0x7fffffffl) return false;
+  const int nwg = (int)(nt < slots ? nt : slots);
+  if (is3d) {
+    if (ncg == 2 && npg == 2) conv3_wino3_kernel<2, 2, true><<<nwg, 512, 0, s>>>(a, w3, ntx, nty, (int)nt);
+    else if (ncg == 2) conv3_wino3_kernel<2, 1, true><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+    else conv3_wino3_kernel<1, 2, true><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+  } else if (ncg == 2 && npg == 2) conv3_wino3_kernel<2, 2><<<nwg, 512, 0, s>>>(a, w3, ntx, nty, (int)nt);
+  else if (ncg == 2) conv3_wino3_kernel<2, 1><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
+  else conv3_wino3_kernel<1, 2><<<nwg, 256, 0, s>>>(a, w3, ntx, nty, (int)nt);
   return true;
 }
 
-void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const PackedLayer& pl, const float* x, float* y,
+// direct: FNX_PRECISION_FP32_DIRECT -- no Winograd, every layer a direct sum over its taps
+void launch_conv(const ConvLayer& L, bool is3d, bool direct, const float* packed, const PackedLayer& pl, const float* x, float* y,
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
   // (the MFMA kernels address a stage of 8 channel volumes through one 32-bit buffer range: 2^27 cells per sample at
@@ -1433,7 +1033,7 @@ void launch_conv(const ConvLayer& L, bool is3d, const float* packed, const Packe
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
-    if (wino_layer(L, is3d) && launch_conv_wino(a, is3d, packed + pl.w_off + layer_weight_floats(L, is3d), s)) {
+    if (!direct && wino_layer(L, is3d) && launch_conv_wino(a, is3d, packed + pl.w_off + layer_weight_floats(L, is3d), s)) {
       prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 4.0 * (is3d ? 3 : 1));   // 16 multiplies per 2x2 outputs (per z tap)
       return;
     }
@@ -1539,7 +1139,7 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
                                                 layer_taps(L, is3d));
       if (wino_layer(L, is3d)) {
         const int kd = is3d ? 3 : 1;
-        float* w2 = pk + pl.w_off + nw;                         // [dz][16][Cin][Cout]  (conv3_wino_kernel, conv3_wino2_kernel)
+        float* w2 = pk + pl.w_off + nw;                         // [dz][16][Cin][Cout]
         float* w3 = w2 + (size_t)16 * kd * L.cin * L.cout;      // stage-contiguous     (conv3_wino3_kernel)
         pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, w2, L.cin, L.cout, kd);
         repack_wino3_kernel<<<64, 256, 0, s>>>(w2, w3, L.cin, L.cout, kd, wino3_rw(L.cout));
@@ -1566,8 +1166,9 @@ size_t multiscale_ws_bytes(const GridDims& g, bool is3d) {
          al256(half * 4) + al256(quart * 4);
 }
 
-void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, void* ws,
+void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                         hipStream_t s) {
+  const bool direct = precision_mode == FNX_PRECISION_FP32_DIRECT;
   const Sizes z = sizes(g, is3d);
   const size_t full = (size_t)g.B * g.DHW, half = (size_t)g.B * z.Dh * z.Hh * z.Wh, quart = (size_t)g.B * z.Dq * z.Hq * z.Wq;
   char* w = (char*)ws;
@@ -1583,7 +1184,7 @@ void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const 
     const float* cur = in;
     for (int l = 0; l < n; ++l) {
       float* dst = (l == n - 1) ? out : ((l & 1) ? bufB : bufA);
-      launch_conv(LAYERS[l0 + l], is3d, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s);
+      launch_conv(LAYERS[l0 + l], is3d, direct, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s);
       cur = dst;
     }
   };
@@ -1722,8 +1323,8 @@ size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
 // FluidNet.forward after the channel split (model.py:120-227), U in place: U holds UDiv on entry and the
 // projected velocity on exit.  ws needs fluidnet_ws_bytes() minus the flags copy.
 namespace fnx {
-int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, float* p_out, float* U, void* ws,
-                  void* stream) {
+int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, int precision_mode, float* p_out, float* U,
+                  void* ws, void* stream) {
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   hipStream_t s = (hipStream_t)stream;
   const int nc = g->is3D ? 3 : 2;
@@ -1738,7 +1339,7 @@ int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, floa
   if (int rc = fnx_velocity_divergence(g, U, flags, div, stream)) return rc;     // model.py:125-126
   launch_scale_std(d, nc, U, thr, partial, scale, s);                            // model.py:129-144
   launch_pack_input(d, nc, div, flags, scale, U, x, s);                          // model.py:146-168
-  multiscale_forward(d, g->is3D, packed, x, p_out, msws, s);                     // model.py:174-175
+  multiscale_forward(d, g->is3D, packed, x, p_out, precision_mode, msws, s);     // model.py:174-175
   if (int rc = fnx_velocity_update(g, p_out, U, flags, stream)) return rc;       // model.py:213-218
   launch_unscale(d, nc, scale, p_out, U, s);                                     // model.py:221-223
   if (int rc = fnx_set_wall_bcs(g, U, flags, stream)) return rc;                 // model.py:226
@@ -1761,18 +1362,22 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
 }
 
-int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, void* ws, size_t ws_bytes,
-                           void* stream) {
+static bool bad_precision(int m) { return m != FNX_PRECISION_FP32 && m != FNX_PRECISION_FP32_DIRECT; }
+
+int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode, void* ws,
+                           size_t ws_bytes, void* stream) {
   if (!g || !packed || !x || !p || !ws) return FNX_EINVAL;
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32 or FNX_PRECISION_FP32_DIRECT)", precision_mode);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
-  fnx::multiscale_forward(d, g->is3D, packed, x, p, ws, (hipStream_t)stream);
+  fnx::multiscale_forward(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
 }
 
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float thr, float* p_out,
-                         float* U_out, void* ws, size_t ws_bytes, void* stream) {
+                         float* U_out, int precision_mode, void* ws, size_t ws_bytes, void* stream) {
   if (!g || !packed || !input || !p_out || !U_out || !ws) return FNX_EINVAL;
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32 or FNX_PRECISION_FP32_DIRECT)", precision_mode);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -1782,7 +1387,7 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
   void* rest = (char*)ws + ((full * 4 + 255) & ~(size_t)255);
   // model.py:104-119: split the channels
   fnx::launch_gather_input(d, nc, input, U_out, flags, s);
-  return fnx::fluidnet_core(g, packed, flags, thr, p_out, U_out, rest, stream);
+  return fnx::fluidnet_core(g, packed, flags, thr, precision_mode, p_out, U_out, rest, stream);
 }
 
 }  // extern "C"

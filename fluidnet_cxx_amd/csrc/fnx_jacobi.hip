@@ -2,11 +2,11 @@
 // which issues ~120 ATen ops plus a host sync per sweep.
 //
 // 2D: temporal blocking in REGISTERS.  A 1024^2 field is 4 MiB, so one sweep per launch would be launch-latency
-// bound (2 us of HBM time per sweep vs ~2 us per kernel boundary).  Each wavefront instead loads a
-// 64 x (32+2K) halo tile of p and div into VGPRs once, runs K sweeps with DPP lane shifts for the x
-// neighbours (no LDS, no barrier) and writes back its (64-2K) x 32 centre: HBM traffic per K sweeps is
-// ~1 read + 1 write of the field instead of K, and a 28-sweep solve is 4 launches.
-// 3D: one sweep per launch, z-marching with coalesced 256-B rows (HBM-bound at 16 B/cell/sweep).
+// bound (2 us of HBM time per sweep vs ~2 us per kernel boundary).  A workgroup of 8 (4) waves instead holds one
+// 64 x 64 (64 x 32) tile of p and div in VGPRs, runs K = 7-8 sweeps with DPP lane shifts for the x neighbours and one
+// LDS row hand-over between the waves per sweep, and writes back the tile's centre: HBM traffic per K sweeps is ~1 read
+// + 1 write of the field instead of K, and a 28-sweep solve is 4 launches.
+// 3D: two sweeps per pass, z-marching with coalesced 256-B rows (16-byte row quads between the passes of a solve).
 //
 // Arithmetic per cell is exactly the reference's: ((((((n1+n2)+n3)+n4)+n5)+n6)+div)/denom, with
 // obstacle neighbours replaced by the centre value (Neumann) and border cells held at 0 (Dirichlet).
@@ -17,12 +17,11 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
-// 2D: register-resident temporal blocking, one independent tile per wavefront.
+// 2D: register-resident temporal blocking.
 //   lane  <-> one grid column (64 columns per wave, OX = 64-2K of them are output)
-//   regs  <-> V = OY+2K rows of p and div per lane (OY = 32 output rows)
+//   regs  <-> RW rows of p and div per lane
 //   x neighbours: DPP wave_shr:1 / wave_shl:1 (one VALU op, no LDS); y neighbours: the adjacent registers.
-// K sweeps run with no LDS, no barrier and no memory traffic; ring s of the tile goes stale at sweep s and the
-// 2K-wide halo is simply recomputed by the neighbouring waves (redundancy 64*V/(OX*OY): 1.43x at K=4, 2.0x at K=8).
+// Ring s of a tile goes stale at sweep s and the 2K-wide halo is recomputed by the neighbouring tiles.
 // ---------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ float dpp_from_left(float v) {    // value held by lane-1 (0 into lane 0)
@@ -99,143 +98,29 @@ __device__ __forceinline__ void jacobi_rows(float (&p)[V], const float (&d)[V], 
   for (int n = 0; n < N; ++n) { delta[n] = v[n] - pc[n]; p[R0 + n] = v[n]; }
 }
 
-template <int V, int R0, int N, bool MASKED, int K>
-__device__ __forceinline__ void jacobi_sweep_rows(float (&p)[V], const float (&d)[V], float& carry,
-                                                  const unsigned (&mL)[2], const unsigned (&mR)[2],
-                                                  const unsigned (&mD)[2], const unsigned (&mU)[2],
-                                                  const unsigned (&mC)[2], bool last, bool lane_ok, int rows_in_grid,
-                                                  float& local) {
-  if constexpr (R0 < V) {
-    constexpr int M = (V - R0 >= N) ? N : (V - R0);
-    float delta[M];
-    jacobi_rows<V, R0, M, MASKED>(p, d, carry, mL, mR, mD, mU, mC, delta);
-    if (last) {                                          // wave-uniform
-#pragma unroll
-      for (int n = 0; n < M; ++n)
-        if (R0 + n >= K && R0 + n < V - K && lane_ok && R0 + n < rows_in_grid) local += delta[n] * delta[n];
-    }
-    jacobi_sweep_rows<V, R0 + M, N, MASKED, K>(p, d, carry, mL, mR, mD, mU, mC, last, lane_ok, rows_in_grid, local);
-  }
-}
-
-template <int K, int OY>
-__global__ __launch_bounds__(256) void jacobi2d_reg_kernel(GridDims g, const float* __restrict__ flags,
-                                                           const float* __restrict__ div,
-                                                           const float* __restrict__ p_in, float* __restrict__ p_out,
-                                                           int from_zero, float* __restrict__ sumsq, int tiles_x,
-                                                           int tiles_y) {
-  constexpr int V = OY + 2 * K, OX = 64 - 2 * K;
-  constexpr int NI = 4;                                  // rows advanced in lockstep
-  const int lane = threadIdx.x & 63;
-  // the tile index is wave-uniform: say so, and all row addressing below becomes scalar work
-  const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  const int b = blockIdx.y;
-  if (tile >= tiles_x * tiles_y) return;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int x = tx * OX - K + lane, y0 = ty * OY - K;
-  const bool xin = (x >= 0) & (x < g.W), xint = (x >= 1) & (x <= g.W - 2);
-  const size_t base = (size_t)b * g.DHW;
-  const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);      // clamped column: loads are unconditional, then masked
-
-  float p[V], d[V];
-  unsigned long long ob = 0, cont = 0;
-#pragma unroll
-  for (int r = 0; r < V; ++r) {
-    const int y = y0 + r;                                        // scalar
-    const bool yin = (y >= 0) & (y < g.H);
-    const int yc = y < 0 ? 0 : (y > g.H - 1 ? g.H - 1 : y);
-    const size_t row = base + (size_t)yc * g.W;                  // scalar
-    const float f = (flags + row)[xc];
-    const float dv = (div + row)[xc];
-    float pv = 0.f;
-    if (!from_zero) pv = (p_in + row)[xc];
-    const bool in = xin & yin;
-    d[r] = in ? dv : 0.f;
-    p[r] = in ? pv : 0.f;
-    const bool isob = !in | (f == FNX_OBST);
-    ob |= (unsigned long long)isob << r;
-    cont |= (unsigned long long)(xint & (y >= 1) & (y <= g.H - 2) & !isob) << r;
-  }
-  // obstacle masks of the four neighbours; the outermost ring of the tile is never evaluated
-  const unsigned long long obL = ((unsigned long long)dpp_from_left_u((unsigned)(ob >> 32)) << 32) | dpp_from_left_u((unsigned)ob);
-  const unsigned long long obR = ((unsigned long long)dpp_from_right_u((unsigned)(ob >> 32)) << 32) | dpp_from_right_u((unsigned)ob);
-  const unsigned long long obD = ob << 1, obU = ob >> 1;
-  cont &= ~(1ull | (1ull << (V - 1)));
-  if (lane == 0 || lane == 63) cont = 0;
-
-  unsigned mL[2] = {(unsigned)obL, (unsigned)(obL >> 32)}, mR[2] = {(unsigned)obR, (unsigned)(obR >> 32)};
-  unsigned mD[2] = {(unsigned)obD, (unsigned)(obD >> 32)}, mU[2] = {(unsigned)obU, (unsigned)(obU >> 32)};
-  unsigned mC[2] = {(unsigned)cont, (unsigned)(cont >> 32)};
-  const bool lane_ok = (lane >= K) & (lane < 64 - K) & xin;
-  const int rows_in_grid = g.H - y0;                     // rows r < rows_in_grid lie inside the grid
-  float local = 0.f;
-  // Fast path (wave-uniform): every evaluated cell of this tile is a plain fluid cell with no obstacle neighbour
-  // (all tiles away from walls and obstacles) -> the selects disappear: 2 DPP moves + 7 VALU ops per cell.
-  constexpr unsigned long long RING = ~(1ull | (1ull << (V - 1))) & ((V < 64) ? ((1ull << V) - 1) : ~0ull);
-  const bool edge_lane = (lane == 0) | (lane == 63);
-  const bool plain = edge_lane | ((cont == RING) & (((obL | obR | obD | obU) & RING) == 0));
-  if (__all(plain)) {
-#pragma unroll 1
-    for (int s = 0; s < K; ++s) {
-      const bool last = (s == K - 1) && (sumsq != nullptr);
-      float carry = 0.f;
-      jacobi_sweep_rows<V, 0, NI, false, K>(p, d, carry, mL, mR, mD, mU, mC, last, lane_ok, rows_in_grid, local);
-    }
-  } else {
-#pragma unroll 1
-    for (int s = 0; s < K; ++s) {
-      // keeps the compiler from hoisting 5*V bit tests out of the sweep loop into (spilled) SGPR pairs
-      asm volatile("" : "+v"(mL[0]), "+v"(mL[1]), "+v"(mR[0]), "+v"(mR[1]), "+v"(mD[0]), "+v"(mD[1]), "+v"(mU[0]),
-                   "+v"(mU[1]), "+v"(mC[0]), "+v"(mC[1]));
-      const bool last = (s == K - 1) && (sumsq != nullptr);
-      float carry = 0.f;
-      jacobi_sweep_rows<V, 0, NI, true, K>(p, d, carry, mL, mR, mD, mU, mC, last, lane_ok, rows_in_grid, local);
-    }
-  }
-  if (lane_ok) {
-#pragma unroll
-    for (int r = K; r < V - K; ++r) {
-      const int y = y0 + r;
-      if (y < g.H) (p_out + base + (size_t)y * g.W)[x] = p[r];
-    }
-  }
-  if (sumsq) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) atomicAdd(&sumsq[b], local);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// 2D, workgroup tiles: the same register-resident sweeps, but NW waves stacked in y form ONE tile of 64 x (NW*RW) cells
-// and hand each other their edge rows through LDS once per sweep (one barrier per sweep, two LDS row images alternating),
-// so only the workgroup's outer ring is recomputed halo: the work per K sweeps drops from 64*(OY+2K)/((64-2K)*OY) times
-// the field (2.3x at K=4/OY=8, 2.7x at K=8/OY=16) to 64*NW*RW/((64-2K)*(NW*RW-2K)) (1.3x / 1.5x), and a wave's serial
-// chain per sweep is RW rows whatever K.  Same per-cell arithmetic (jacobi_rows): same bits.
+// 2D, workgroup tiles: NW waves stacked in y form ONE tile of 64 x (NW*RW) cells and hand each other their edge rows
+// through LDS once per sweep (one barrier per sweep, two LDS row images alternating), so only the workgroup's outer ring
+// is recomputed halo: the work per K sweeps is 64*NW*RW/((64-2K)*(NW*RW-2K)) times the field (1.8x at K = 8 with 8 waves
+// of 8 rows; one independent 64 x (16+2K) tile per wave, the round-1 kernel, did 2.7x), and a wave's serial chain per
+// sweep is RW rows whatever K.
 // ---------------------------------------------------------------------------------------------------
 template <int V, int R0, int N, bool MASKED>
 __device__ __forceinline__ void wg_sweep_rows(float (&p)[V], const float (&d)[V], float& carry, float top,
                                               const unsigned (&mL)[2], const unsigned (&mR)[2], const unsigned (&mD)[2],
-                                              const unsigned (&mU)[2], const unsigned (&mC)[2], bool last, bool lane_ok,
-                                              int out_lo, int out_hi, float& local) {
+                                              const unsigned (&mU)[2], const unsigned (&mC)[2]) {
   if constexpr (R0 < V) {
     constexpr int M = (V - R0 >= N) ? N : (V - R0);
     float delta[M];
     jacobi_rows<V, R0, M, MASKED>(p, d, carry, mL, mR, mD, mU, mC, delta, top);
-    if (last) {                                          // wave-uniform
-#pragma unroll
-      for (int n = 0; n < M; ++n)
-        if (R0 + n >= out_lo && R0 + n < out_hi && lane_ok) local += delta[n] * delta[n];
-    }
-    wg_sweep_rows<V, R0 + M, N, MASKED>(p, d, carry, top, mL, mR, mD, mU, mC, last, lane_ok, out_lo, out_hi, local);
+    wg_sweep_rows<V, R0 + M, N, MASKED>(p, d, carry, top, mL, mR, mD, mU, mC);
   }
 }
 
 template <int K, int RW, int NW>
 __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const float* __restrict__ flags,
                                                              const float* __restrict__ div, const float* __restrict__ p_in,
-                                                             float* __restrict__ p_out, int from_zero,
-                                                             float* __restrict__ sumsq, int tiles_x) {
+                                                             float* __restrict__ p_out, int from_zero, int tiles_x) {
   constexpr int V = RW, OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
   constexpr int NI = 4;
   static_assert(V <= 32 && OYW > 0, "tile shape");
@@ -287,7 +172,6 @@ __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const 
   if (out_hi > V) out_hi = V;
   if (out_hi > g.H - y0) out_hi = g.H - y0;
   const bool lane_ok = (lane >= K) & (lane < 64 - K) & xin;
-  float local = 0.f;
   constexpr unsigned ALL = V < 32 ? ((1u << V) - 1) : ~0u;
   const unsigned ring = ALL & ~((w == 0 ? 1u : 0u) | (w == NW - 1 ? 1u << (V - 1) : 0u));
   const bool edge_lane = (lane == 0) | (lane == 63);
@@ -301,23 +185,17 @@ __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const 
     __syncthreads();
     float carry = w > 0 ? e[NW * 64 + (w - 1) * 64 + lane] : 0.f;           // last row of the wave below
     const float top = w < NW - 1 ? e[(w + 1) * 64 + lane] : 0.f;            // first row of the wave above
-    const bool last = (s == K - 1) && (sumsq != nullptr);
     if (all_plain) {
-      wg_sweep_rows<V, 0, NI, false>(p, d, carry, top, mL, mR, mD, mU, mC, last, lane_ok, out_lo, out_hi, local);
+      wg_sweep_rows<V, 0, NI, false>(p, d, carry, top, mL, mR, mD, mU, mC);
     } else {
       asm volatile("" : "+v"(mL[0]), "+v"(mR[0]), "+v"(mD[0]), "+v"(mU[0]), "+v"(mC[0]));
-      wg_sweep_rows<V, 0, NI, true>(p, d, carry, top, mL, mR, mD, mU, mC, last, lane_ok, out_lo, out_hi, local);
+      wg_sweep_rows<V, 0, NI, true>(p, d, carry, top, mL, mR, mD, mU, mC);
     }
   }
   if (lane_ok) {
 #pragma unroll
     for (int r = 0; r < V; ++r)
       if (r >= out_lo && r < out_hi) (p_out + base + (size_t)(y0 + r) * g.W)[x] = p[r];
-  }
-  if (sumsq) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) atomicAdd(&sumsq[b], local);
   }
 }
 
@@ -378,20 +256,13 @@ __global__ __launch_bounds__(256) void jacobi3d_maskq_kernel(GridDims g, const u
 __global__ __launch_bounds__(256) void jacobi3d_first_kernel(int B, size_t per, size_t first, size_t count,
                                                              const float* __restrict__ div,
                                                              const unsigned char* __restrict__ mask,
-                                                             float* __restrict__ p_out, float* __restrict__ sumsq) {
+                                                             float* __restrict__ p_out) {
   for (int b = 0; b < B; ++b) {
-    float local = 0.f;
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) {
       const size_t o = (size_t)b * per + first + q;
       float sum = 0.f + 0.f; sum = sum + 0.f; sum = sum + 0.f; sum = sum + 0.f; sum = sum + 0.f;
       const float v = (mask[o] & MZ_CONT) ? (sum + div[o]) / 6.f : 0.f;
       p_out[o] = v;
-      local += v * v;
-    }
-    if (sumsq) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], local);
     }
   }
 }
@@ -399,7 +270,7 @@ __global__ __launch_bounds__(256) void jacobi3d_first_kernel(int B, size_t per, 
 __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const unsigned char* __restrict__ mask,
                                                              const float* __restrict__ div,
                                                              const float* __restrict__ p_in, float* __restrict__ p_out,
-                                                             float* __restrict__ sumsq, int nzc, int kb, int ke) {
+                                                             int nzc, int kb, int ke) {
   const int lane = threadIdx.x;                          // blockDim = (64, 4): one wave per threadIdx.y
   const int i = blockIdx.x * 64 + lane;
   const int j0 = (blockIdx.y * 4 + threadIdx.y) * ZR;
@@ -436,7 +307,6 @@ __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const u
   for (int r = 0; r < ZR; ++r) { pb[r] = ld(clampk(k_lo - 1), jr[r], ic); pc[r] = ld(k_lo, jr[r], ic); pf[r] = ld(clampk(k_lo + 1), jr[r], ic); }
   Aux cur, nxt;
   load_aux(k_lo, cur);
-  float local = 0.f;
   for (int k = k_lo; k < k_hi; ++k) {
     // issue the loads of plane k+1 (aux) and k+2 (own rows) before touching plane k
     float pn[ZR];
@@ -467,20 +337,11 @@ __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const u
       sum = sum + n6;
       float v = (sum + cur.dv[r]) / 6.f;
       v = (m & MZ_CONT) ? v : 0.f;
-      if (xin && jin[r]) {
-        p_out[ok + (size_t)jr[r] * g.W + i] = v;
-        const float d = v - c;
-        local += d * d;
-      }
+      if (xin && jin[r]) p_out[ok + (size_t)jr[r] * g.W + i] = v;
     }
 #pragma unroll
     for (int r = 0; r < ZR; ++r) { pb[r] = pc[r]; pc[r] = pf[r]; pf[r] = pn[r]; }
     cur = nxt;
-  }
-  if (sumsq) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) atomicAdd(&sumsq[b], local);
   }
 }
 
@@ -572,12 +433,11 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 // step reads p^0 with 3 instructions instead of 8 and writes its four finished rows with 1 instead of 4.  A plane is the same
 // H*W floats in both layouts (ghost-plane exchanges do not care); the passes of a solve hand the quad layout to each other
 // and only the last one writes rows.
-template <bool RES, bool ZERO, bool SPLIT, int LAY>
+template <bool ZERO, bool SPLIT, int LAY>
 __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned* __restrict__ maskq,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
-                                                                      float* __restrict__ p_out,
-                                                                      float* __restrict__ sumsq, int nxt, int nyt,
+                                                                      float* __restrict__ p_out, int nxt, int nyt,
                                                                       int zchunk, int kb, int ke, int kb2) {
   constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
   const int lane = threadIdx.x;
@@ -716,7 +576,6 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     for (int rr = 0; rr < R1; ++rr) AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]);
     AM[0] = ldm(t);
   }
-  float local = 0.f;
   const bool lane_out = (lane >= 2) & (lane <= 61) & xin;
   int prev_sel = 2;
 
@@ -780,7 +639,6 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
       sweep(IC<Z2R>{}, IC<1>{}, prev_sel, AM[SM], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
       const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
       if (LAY & 2) {                                       // j0 * W floats into the plane is the tile's row group in both layouts
-        static_assert(!(RES && (LAY & 2)), "the residual is taken by the last pass, which writes rows");
         if (lane_out) {
           const f32x4 o = {v[0], v[1], v[2], v[3]};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_o, xoff4, ok, 0);
@@ -788,10 +646,8 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
       } else
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
-        if (lane_out && j0 + r < g.H) {
+        if (lane_out && j0 + r < g.H)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
-          if (RES) { const float d = v[r] - P1[SM][r + 1]; local += d * d; }
-        }
       }
     }
     prev_sel = sel1;
@@ -803,576 +659,27 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
     step(IC<2>{}, t); if (++t > k_hi) break;
     step(IC<3>{}, t); if (++t > k_hi) break;
   }
-  if (RES) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) atomicAdd(&sumsq[b], local);
-  }
   }  // segments
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The same march with its row loads going through the LDS-DMA path.
-//
-// What bounds the kernel above is not HBM and not the VALU but the texture addresser: a wave-level VMEM instruction
-// costs the CU's TA ~14 cycles whether it moves 64 B (a mask row), 256 B (a dword row) or more (measured,
-// tools/ubench/ta_bench.hip: dword rows 18.6 B/clk/CU, dwordx4 53 B/clk/CU), and a step issues 20 row loads + 4 row
-// stores = ~340 TA cycles for 4 x 60 cells, which IS the measured 51 us per pass at 16.8 M cells.  Here the rows of a
-// step arrive as buffer_load_dwordx4 ... lds: one instruction fetches FOUR 256-B rows (lane l: row l/16, columns
-// 4(l%16)..+3; ~31 TA cycles, i.e. 7.8 per row instead of 13.5) and drops them into the wave's private LDS stage as
-// [row][64 columns]; a ds_read_b32 per row then brings them into the lane <-> column register layout the sweeps use
-// (the transposition is free: it is the LDS address).  The six 64-B mask rows come in ONE instruction (lane l: row l/4).
-// No VGPRs are tied up by loads in flight, the stage is double buffered, and nothing synchronises between waves.
-// Per step: 5 DMA instructions instead of 20 loads.
-// ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
-template <bool RES, bool ZERO, bool SPLIT>
-__global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_dma_kernel(GridDims g, const unsigned char* __restrict__ mask,
-                                                                      const float* __restrict__ div,
-                                                                      const float* __restrict__ p_in,
-                                                                      float* __restrict__ p_out,
-                                                                      float* __restrict__ sumsq, int nxt, int nyt,
-                                                                      int zchunk, int kb, int ke, int kb2) {
-  constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
-  const int lane = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  // One resident set of waves.  !SPLIT: every tile is cut into the same plane chunks and a wave takes one
-  // (tile, chunk); all waves of a chunk start together and march the same planes at the same pace, so the halo
-  // columns/rows two neighbouring tiles both touch are fetched from HBM once and hit in L2 the second time.  Workgroup
-  // ids go round-robin over the 8 XCDs; renumbering gives XCD q the tiles [q*G/8, (q+1)*G/8), i.e. whole bands of
-  // neighbouring tiles.  SPLIT (more tiles than resident waves): the (tile, plane) space is cut into gridDim.x equal
-  // contiguous ranges instead.
-  const int G = gridDim.x, np = ke - kb;
-  const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int ntiles = nxt * nyt * g.B;
-  int L0, L1;
-  int kbase = kb;                                        // kb2 >= 0: a second plane range [kb2, kb2 + np) in the same launch
-  if (!SPLIT) {
-    int zc = gid / ntiles;
-    const int tl = gid - zc * ntiles;
-    if (kb2 >= 0) {                                      // chunks [0, nzc1) belong to the first range, [nzc1, 2 nzc1) to the second
-      const int nzc1 = (np + zchunk - 1) / zchunk;
-      if (zc >= nzc1) { zc -= nzc1; kbase = kb2; }
-    }
-    L0 = tl * np + zc * zchunk;
-    L1 = min(L0 + zchunk, (tl + 1) * np);
-    if (zc * zchunk >= np) L1 = L0;                      // padding block
-  } else {
-    const long long T = (long long)ntiles * np;
-    auto cut = [&](int q) {                              // range boundary, snapped away from 1-2 plane slivers at tile ends
-      int L = (int)(T * q / G);
-      const int pk = L % np;
-      if (pk < 3) L -= pk; else if (pk > np - 3) L += np - pk;
-      return L;
-    };
-    L0 = cut(gid); L1 = cut(gid + 1);
-  }
-  for (; L0 < L1;) {                                     // one pass unless SPLIT
-  const int tile = L0 / np, pk = L0 - tile * np;
-  const int seg = min(np - pk, L1 - L0);
-  L0 = SPLIT ? L0 + seg : L1;
-  const int bx = tile % nxt, l1 = tile / nxt;
-  const int by = l1 % nyt, b = l1 / nyt;
-  const int x = bx * 60 - 2 + lane;
-  const int j0 = (by * Z2NW + w) * Z2R;
-  const int k_lo = kbase + pk, k_hi = k_lo + seg;           // output planes [k_lo, k_hi) of this segment
-  const bool xin = (x >= 0) & (x < g.W);
-  const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
-  const size_t base = (size_t)b * g.DHW;
-
-  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
-  // Rows / planes / columns outside the grid are clamped onto the border, whose mask byte is 0 (border cells are
-  // never 'cont'), so no validity selects are needed: a clamped cell relaxes to 0 like the border cell it aliases.
-  unsigned rowb[R0];                                     // wave-uniform cell offset of row slot rr (j = j0-2+rr) in a plane
-#pragma unroll
-  for (int rr = 0; rr < R0; ++rr) {
-    const int j = j0 - 2 + rr;
-    rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
-  }
-  // buffer offsets are 32-bit: they are taken relative to the first plane this segment touches, so only the segment
-  // (<= a few dozen planes), not the whole field, has to stay below 4 GB
-  const int k0 = clampk(k_lo - 2);
-  auto planeoff = [&](int k) { return (unsigned)((clampk(k) - k0) * g.HW); };
-  // buffer addressing: per-lane voffset (the column) + wave-uniform soffset (plane/row), no 64-bit VALU address math
-  const unsigned xoff = (unsigned)xc * 4u;
-  const size_t seg0 = base + (size_t)k0 * g.HW;
-  const size_t left = (size_t)(g.D - k0) * g.HW;                       // cells from plane k0 to the end of the sample
-  const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
-  const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
-  const BufRsrc r_m = make_rsrc(mask + seg0, ncell), r_o = make_rsrc(p_out + seg0, ncell * 4u);
-  // ---- DMA addressing.  Columns are NOT clamped per lane (a 16-byte chunk is 4 columns): a chunk left of column 0 or
-  // right of column W-1 reads the neighbouring row's cells -- or, outside the sample, nothing (the buffer range check
-  // returns 0) -- and whatever arrives there only ever feeds border cells, whose mask byte is 0.  Rows and planes are
-  // clamped as before (wave-uniform).
-  const int x0 = bx * 60 - 2;
-  const int rs = lane >> 4, cq = lane & 15;              // row within a 4-row group, 16-byte chunk within the row
-  unsigned vrow_p[R0 / 4], vrow_a[2];                    // per-lane byte offset of "my" row of group q (+ my chunk)
-#pragma unroll
-  for (int q = 0; q < R0 / 4; ++q) {
-    unsigned ro = rowb[4 * q];
-    if (rs == 1) ro = rowb[4 * q + 1]; else if (rs == 2) ro = rowb[4 * q + 2]; else if (rs == 3) ro = rowb[4 * q + 3];
-    vrow_p[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {                          // div rows: slots 1..6 of the p^0 numbering (j0-1 .. j0+4)
-    unsigned ro = rowb[R0 - 1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int slot = 1 + 4 * q + u; if (rs == u && slot < R0) ro = rowb[slot < R0 ? slot : R0 - 1]; }
-    vrow_a[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
-  }
-  // mask rows: one byte per cell.  A dwordx4 transfer needs a dword-aligned address, x0 = 60 bx - 2 is not one in bytes:
-  // the chunks start at column x0 - 2 (a multiple of 4) and a row is 5 chunks = 80 bytes, of which [2, 66) are the
-  // wave's columns.  Lane l fetches chunk l%5 of row slot 1 + l/5 (lanes 0 .. 5 R1 - 1): all six rows in ONE instruction.
-  constexpr int MROW = 80;
-  unsigned vrow_m;
-  {
-    const int mr = lane / 5, mc = lane - mr * 5;
-    unsigned ro = rowb[R0 - 1];
-#pragma unroll
-    for (int u = 0; u < R1; ++u) if (mr == u) ro = rowb[1 + u];
-    vrow_m = ro + (unsigned)(x0 - 2 + 16 * mc);
-  }
-  const bool m_lane = lane < 5 * R1;
-  // LDS stage: p^0 rows [R0][64] floats, aux rows [8][64] floats, mask rows [R1][64] bytes (padded to 1 KiB); two stages
-  constexpr int STAGE_F = R0 * 64 + 8 * 64 + 256;
-  __shared__ __attribute__((aligned(16))) float stage[2][STAGE_F];
-  typedef __attribute__((address_space(3))) void* LdsPtr;
-  auto dma_p = [&](int st, unsigned plane_cells) {         // p^0 rows of one plane -> stage st
-    if (ZERO) return;
-#pragma unroll
-    for (int q = 0; q < R0 / 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_p, (LdsPtr)&stage[st][q * 256], 16, vrow_p[q], plane_cells * 4u, 0, 0);
-  };
-  auto dma_a = [&](int st, unsigned plane_cells) {         // div + mask rows of one plane -> stage st
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_d, (LdsPtr)&stage[st][R0 * 64 + q * 256], 16, vrow_a[q], plane_cells * 4u, 0, 0);
-    if (m_lane)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_m, (LdsPtr)&stage[st][R0 * 64 + 8 * 64], 16, vrow_m, plane_cells, 0, 0);
-  };
-  auto lds_p = [&](int st, int rr) { return ZERO ? 0.f : stage[st][rr * 64 + lane]; };
-  auto lds_d = [&](int st, int rr) { return stage[st][R0 * 64 + rr * 64 + lane]; };          // rr: aux row slot (j = j0-1+rr)
-  auto lds_m = [&](int st, int rr) { return (unsigned)((const unsigned char*)&stage[st][R0 * 64 + 8 * 64])[rr * MROW + 2 + lane]; };
-  auto ldf = [&](const BufRsrc& r, unsigned cell) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
-  };
-  auto ldp = [&](unsigned cell) { return ZERO ? 0.f : ldf(r_p, cell); };
-  auto ldm = [&](unsigned cell) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, (unsigned)xc, cell, 0); };
-
-  float P0[4][R0];                                       // p^0 plane ring: slot (t+d)&3 for planes t-1..t+2
-  float P1[4][R1];                                       // p^1 plane ring (3 live)
-  float AD[4][R1]; unsigned AM[4][R1];                   // div / mask ring, row slot rr <-> j = j0-1+rr
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { P1[q][rr] = 0.f; AD[q][rr] = 0.f; AM[q][rr] = 0u; }
-#pragma unroll
-    for (int rr = 0; rr < R0; ++rr) P0[q][rr] = 0.f;
-  }
-  int t = k_lo - 1;
-  // prologue: planes t-1, t, t+1 of p^0 (slots 3, 0, 1) and the aux data of plane t (slot 0), all rows from memory
-  {
-    const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
-#pragma unroll
-    for (int rr = 0; rr < R0; ++rr) {
-      P0[3][rr] = ldp(pm + rowb[rr]); P0[0][rr] = ldp(pc + rowb[rr]); P0[1][rr] = ldp(pp + rowb[rr]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]); AM[0][rr] = ldm(pc + rowb[rr + 1]); }
-    // the first step's "next" rows (p^0 plane t+2, aux plane t+1) already travel through the DMA path
-    dma_p(0, planeoff(t + 2)); dma_a(0, planeoff(t + 1));
-  }
-  float local = 0.f;
-  const bool lane_out = (lane >= 2) & (lane <= 61) & xin;
-  bool prev_free = false;
-
-  // one sweep over N rows: centre rows C[0..N), y-neighbours from the same plane, z-neighbours B / F
-  auto sweep = [&](auto nn, bool free, const unsigned* M, const float* Cm1, const float* B, const float* F,
-                   const float* DV, float* out) __attribute__((always_inline)) {
-    constexpr int N = decltype(nn)::value;
-    float xs[N];
-    bool bad = false;
-    if (free) {
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const float c = Cm1[r + 1];
-        out[r] = relax3<0>(M[r], 0, c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
-        bad |= __builtin_amdgcn_classf(out[r], 0x90);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const float c = Cm1[r + 1];
-        out[r] = relax3<2>(M[r], 0, c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
-        bad |= __builtin_amdgcn_classf(out[r], 0x90);
-      }
-    }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: scaled division
-#pragma unroll
-      for (int r = 0; r < N; ++r)
-        if (__builtin_amdgcn_classf(out[r], 0x90)) out[r] = div6_tiny(xs[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < N; ++r)                            // cont ? v : 0
-      out[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[r]) & __builtin_amdgcn_sbfe((int)M[r], 0, 1));
-  };
-
-  auto step = [&](auto ph, int t) __attribute__((always_inline)) {
-    constexpr int PH = decltype(ph)::value;
-    constexpr int SM = (PH + 3) & 3, SC = PH, SP = (PH + 1) & 3, SN = (PH + 2) & 3, BUF = PH & 1;
-    // ---- p^0 plane t+2 and the aux data of plane t+1 (used one step later): they were sent to LDS stage `par` one step
-    // ago; pick them up, then start the DMA of the following planes into the other stage.  (The compiler does not track
-    // LDS-DMA: the waits are explicit.  vmcnt(0) also covers the row stores of the previous step.)
-    // lgkmcnt(0) too: the previous step's reads of the OTHER stage (long complete) must have left it before it is refilled
-    __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
-#pragma unroll
-    for (int rr = 0; rr < R0; ++rr) P0[SN][rr] = lds_p(BUF, rr);        // (steps alternate stages: BUF = PH & 1, the prologue filled 0)
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { AD[SP][rr] = lds_d(BUF, rr); AM[SP][rr] = lds_m(BUF, rr); }
-    if (t < k_hi) {                                      // (the last step of a segment has no successor to feed)
-      dma_p(BUF ^ 1, planeoff(t + 3)); dma_a(BUF ^ 1, planeoff(t + 2));
-    }
-    // ---- sweep 1 on plane t, rows j0-1 .. j0+4
-    unsigned ob = AM[SC][0];
-#pragma unroll
-    for (int rr = 1; rr < R1; ++rr) ob |= AM[SC][rr];
-    const bool free1 = __builtin_amdgcn_ballot_w64((ob & 0x7eu) != 0) == 0;     // no cell of these rows has an obstacle neighbour
-    sweep(IC<R1>{}, free1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
-    // ---- sweep 2 on plane t-1, rows j0 .. j0+3 (p^1 of planes t-2, t-1, t = slots SN, SM, SC)
-    if (t - 1 >= k_lo) {
-      float v[Z2R];
-      sweep(IC<Z2R>{}, prev_free, &AM[SM][1], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
-      const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
-#pragma unroll
-      for (int r = 0; r < Z2R; ++r) {
-        if (lane_out && j0 + r < g.H) {
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
-          if (RES) { const float d = v[r] - P1[SM][r + 1]; local += d * d; }
-        }
-      }
-    }
-    prev_free = free1;
-  };
-
-  while (true) {
-    step(IC<0>{}, t); if (++t > k_hi) break;
-    step(IC<1>{}, t); if (++t > k_hi) break;
-    step(IC<2>{}, t); if (++t > k_hi) break;
-    step(IC<3>{}, t); if (++t > k_hi) break;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): no LDS-DMA may outlive the segment (or the wave)
-  if (RES) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) atomicAdd(&sumsq[b], local);
-  }
-  }  // segments
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 3D, THREE sweeps per pass.
-//
-// At 16.8 M cells a 2-sweep pass moves 250 MB in 49 us = 5.1 TB/s, which is what this memory system gives a mixed
-// read/write stream whose footprint sits at the edge of the 256 MiB Infinity Cache (tools/ubench/bw_bench.hip: copy 7.4
-// TB/s at 192 MiB, 5.0 TB/s from 512 MiB on); the LDS-DMA loader above changed nothing, so the texture addresser is not
-// the limit either.  What is left is moving fewer bytes per sweep: the same march with a third register level.  A wave owns
-// 58 columns x 4 rows; per step t it builds p^1(plane t) on 8 rows, p^2(plane t-1) on 6 and the finished p^3(plane t-2)
-// on its 4, each from the three planes of the level below held in a 3-slot register ring (10 / 8 / 6 rows).  The row
-// loads go through the LDS-DMA path (which costs no VGPRs for loads in flight -- what makes the third level fit): at the
-// END of a step the rows of p^0(plane t+2) and the div / mask rows of plane t+1 are picked up from the LDS stage into the
-// ring slots the step has just freed, and the DMA of the following plane is issued into the other stage.  The mask bytes
-// of a plane's 8 rows are packed four to a register.  Redundancy: 18 row updates per 12 finished, 58 of 64 lanes, and 4
-// lead-in steps per z chunk instead of 2 -- 1.25x the VALU work per sweep of the 2-sweep kernel for 2/3 of its traffic.
-// ---------------------------------------------------------------------------------------------------
-constexpr int Z3K = 3, Z3R = 4, Z3RW = Z3R + 2 * Z3K, Z3C = 64 - 2 * Z3K;     // sweeps, output rows, row slots, output columns
-constexpr int Z3WPS = 3;                                                     // waves per SIMD the register budget is sized for
-
-template <bool FREE, int SH>
-__device__ __forceinline__ float relax3p(int mp, float c, float xl, float xr, float yd, float yu, float zb, float zf, float dv,
-                                         float& num) {
-  if (!FREE) {                                          // Neumann: an obstacle neighbour is replaced by the centre
-    xl = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 1, 1), c, xl);
-    xr = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 2, 1), c, xr);
-    yd = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 3, 1), c, yd);
-    yu = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 4, 1), c, yu);
-    zb = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 5, 1), c, zb);
-    zf = bfi_blend(__builtin_amdgcn_sbfe(mp, SH + 6, 1), c, zf);
-  }
-  float sum = xl + xr;
-  sum = sum + yd;
-  sum = sum + yu;
-  sum = sum + zb;
-  sum = sum + zf;
-  num = sum + dv;
-  return div6_fast(num);
-}
-
-template <bool RES, bool ZERO>
-__global__ __launch_bounds__(64, Z3WPS) void jacobi3d_march3_kernel(GridDims g, const unsigned char* __restrict__ mask,
-                                                                   const float* __restrict__ div,
-                                                                   const float* __restrict__ p_in, float* __restrict__ p_out,
-                                                                   float* __restrict__ sumsq, int nxt, int nyt, int zchunk,
-                                                                   int kb, int ke, int kb2) {
-  constexpr int K = Z3K, R = Z3R, RW = Z3RW, NA = RW - 2;             // NA: aux (div / mask) rows = row slots 1 .. RW-2
-  constexpr int NPQ = (RW + 3) / 4, NAQ = (NA + 3) / 4;               // DMA instructions per plane: p^0 rows, div rows
-  constexpr int MROW = 80;                                            // bytes per mask row in LDS (5 chunks)
-  constexpr int STAGE_F = NPQ * 256 + NAQ * 256 + (NA * MROW + 3) / 4;
-  __shared__ __attribute__((aligned(16))) float stage0[STAGE_F];
-  __shared__ __attribute__((aligned(16))) float stage1[STAGE_F];
-  const int lane = threadIdx.x;
-  const int G = gridDim.x, np = ke - kb;
-  const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int ntiles = nxt * nyt * g.B;
-  int zc = gid / ntiles;
-  const int tile = gid - zc * ntiles;
-  int kbase = kb;
-  if (kb2 >= 0) {                                        // chunks [0, nzc1) belong to the first range, the rest to the second
-    const int nzc1 = (np + zchunk - 1) / zchunk;
-    if (zc >= nzc1) { zc -= nzc1; kbase = kb2; }
-  }
-  if (zc * zchunk >= np) return;                         // padding block
-  const int bx = tile % nxt, l1 = tile / nxt;
-  const int by = l1 % nyt, b = l1 / nyt;
-  const int k_lo = kbase + zc * zchunk, k_hi = kbase + min((zc + 1) * zchunk, np);     // output planes [k_lo, k_hi)
-  // Columns.  Tile bx finishes columns [bx*58, bx*58 + 58); its lanes start K columns to the left -- except the first tile,
-  // which starts AT column 0: a DMA chunk must not start before the row (the buffer range check then drops all 16 bytes,
-  // real columns included), and column 0, a border column, needs no left neighbour.
-  const int lane_lo = bx == 0 ? 0 : K;
-  const int x0 = bx * Z3C - lane_lo;
-  const int x = x0 + lane;
-  const int j0 = by * R;
-  const bool xin = x < g.W;
-  const size_t base = (size_t)b * g.DHW;
-  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
-  unsigned rowb[RW];                                     // wave-uniform cell offset of row slot rr (j = j0-K+rr) in a plane
-#pragma unroll
-  for (int rr = 0; rr < RW; ++rr) {
-    const int j = j0 - K + rr;
-    rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
-  }
-  const int k0 = clampk(k_lo - K);
-  auto planeoff = [&](int k) { return (unsigned)((clampk(k) - k0) * g.HW); };
-  // buffer resources: from plane k0 to the END OF THE TENSOR (a chunk hanging over the sample's end reads the next
-  // sample, or 0 past the last one); the plane offset travels in the VGPR offset (the range check ignores an SGPR offset)
-  const size_t seg0 = base + (size_t)k0 * g.HW;
-  const size_t left = (size_t)(g.D - k0) * g.HW + (size_t)(g.B - 1 - b) * g.DHW;
-  const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
-  const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
-  const BufRsrc r_m = make_rsrc(mask + seg0, ncell), r_o = make_rsrc(p_out + seg0, ncell * 4u);
-  // DMA: one instruction = 4 rows of 256 B (lane l: row l/16, chunk l%16); mask: one instruction = NA rows of 5 chunks
-  const int rs = lane >> 4, cq = lane & 15;
-  unsigned vrow_p[NPQ], vrow_a[NAQ];
-#pragma unroll
-  for (int q = 0; q < NPQ; ++q) {
-    unsigned ro = rowb[RW - 1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int slot = 4 * q + u; if (rs == u && slot < RW) ro = rowb[slot < RW ? slot : RW - 1]; }
-    vrow_p[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
-  }
-#pragma unroll
-  for (int q = 0; q < NAQ; ++q) {
-    unsigned ro = rowb[RW - 1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int slot = 1 + 4 * q + u; if (rs == u && slot < RW - 1) ro = rowb[slot < RW ? slot : RW - 1]; }
-    vrow_a[q] = (ro + (unsigned)(x0 + 4 * cq)) * 4u;
-  }
-  // mask bytes: chunks start at the multiple of 4 at or below x0 (a dwordx4 needs a dword-aligned address); my byte sits
-  // `moff` bytes into the row's 80
-  const int xm0 = x0 & ~3, moff = x0 - xm0;
-  unsigned vrow_m;
-  {
-    const int mr = lane / 5, mc = lane - mr * 5;
-    unsigned ro = rowb[RW - 1];
-#pragma unroll
-    for (int u = 0; u < NA; ++u) if (mr == u) ro = rowb[1 + u];
-    vrow_m = ro + (unsigned)(xm0 + 16 * mc);
-  }
-  const bool m_lane = lane < 5 * NA;
-  typedef __attribute__((address_space(3))) void* LdsPtr;
-  auto dma = [&](float* st, int kp, int ka) {            // p^0 rows of plane kp, div + mask rows of plane ka -> stage st
-    const unsigned pp = planeoff(kp) * 4u, pa = planeoff(ka);
-    if (!ZERO) {
-#pragma unroll
-      for (int q = 0; q < NPQ; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_p, (LdsPtr)(st + q * 256), 16, vrow_p[q] + pp, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < NAQ; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_d, (LdsPtr)(st + NPQ * 256 + q * 256), 16, vrow_a[q] + pa * 4u, 0, 0, 0);
-    if (m_lane) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_m, (LdsPtr)(st + (NPQ + NAQ) * 256), 16, vrow_m + pa, 0, 0, 0);
-  };
-  // rings: level-s planes in slot (plane - k_lo + 3K) mod 3
-  float P0[3][RW], P1[3][RW], P2[3][RW], AD[3][NA];
-  int AM[3][(NA + 3) / 4];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) { P0[q][rr] = 0.f; P1[q][rr] = 0.f; P2[q][rr] = 0.f; }
-#pragma unroll
-    for (int rr = 0; rr < NA; ++rr) AD[q][rr] = 0.f;
-#pragma unroll
-    for (int rr = 0; rr < (NA + 3) / 4; ++rr) AM[q][rr] = 0;
-  }
-  auto pick_p = [&](auto sl, const float* st) {          // LDS stage -> P0 slot
-    constexpr int S = decltype(sl)::value;
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) P0[S][rr] = ZERO ? 0.f : st[rr * 64 + lane];
-  };
-  auto pick_a = [&](auto sl, const float* st) {          // LDS stage -> AD / AM slot (mask bytes packed 4 rows to a register)
-    constexpr int S = decltype(sl)::value;
-#pragma unroll
-    for (int rr = 0; rr < NA; ++rr) AD[S][rr] = st[NPQ * 256 + rr * 64 + lane];
-    const unsigned char* mb = (const unsigned char*)(st + (NPQ + NAQ) * 256) + moff + lane;
-#pragma unroll
-    for (int q4 = 0; q4 < (NA + 3) / 4; ++q4) {
-      unsigned v = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (4 * q4 + u < NA) v |= (unsigned)mb[(4 * q4 + u) * MROW] << (8 * u);
-      AM[S][q4] = (int)v;
-    }
-  };
-  float local = 0.f;
-  const bool lane_out = (lane >= lane_lo) & (lane < lane_lo + Z3C) & xin;
-
-  // one sweep: level L-1 planes (slots SB, SCc, SF = back, centre, front) -> rows [L, RW-L) of `out`
-  auto sweep = [&](auto lvl, bool free, const int (&M)[(NA + 3) / 4], const float (&C)[RW], const float (&Bk)[RW], const float (&Fr)[RW],
-                   const float (&DV)[NA], float (&out)[RW]) __attribute__((always_inline)) {
-    constexpr int L = decltype(lvl)::value;
-    float xs[RW];
-    bool bad = false;
-#pragma unroll
-    for (int rr = L; rr < RW - L; ++rr) {
-      const float c = C[rr];
-      const int mp = M[(rr - 1) >> 2];
-      // (the shift of row rr's byte is a compile-time constant per unrolled iteration)
-      float v;
-      switch ((rr - 1) & 3) {
-        case 0: v = free ? relax3p<true, 0>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
-                         : relax3p<false, 0>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
-        case 1: v = free ? relax3p<true, 8>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
-                         : relax3p<false, 8>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
-        case 2: v = free ? relax3p<true, 16>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
-                         : relax3p<false, 16>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
-        default: v = free ? relax3p<true, 24>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr])
-                          : relax3p<false, 24>(mp, c, dpp_from_left(c), dpp_from_right(c), C[rr - 1], C[rr + 1], Bk[rr], Fr[rr], DV[rr - 1], xs[rr]); break;
-      }
-      out[rr] = v;
-      bad |= __builtin_amdgcn_classf(v, 0x90);
-    }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {     // a denormal quotient somewhere: scaled division
-#pragma unroll
-      for (int rr = L; rr < RW - L; ++rr)
-        if (__builtin_amdgcn_classf(out[rr], 0x90)) out[rr] = div6_tiny(xs[rr]);
-    }
-#pragma unroll
-    for (int rr = L; rr < RW - L; ++rr)                    // cont ? v : 0
-      out[rr] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[rr]) & __builtin_amdgcn_sbfe(M[(rr - 1) >> 2], 8 * ((rr - 1) & 3), 1));
-  };
-
-  bool fr_c = false, fr_m = false;                       // "no obstacle neighbour on any row" of planes t-1, t-2 (wave-uniform)
-  // one step.  PH = ring slot of plane t; planes t-1 / t-2 / t+1 sit in (PH+2)%3 / (PH+1)%3 / (PH+1)%3 (t+1 replaces t-2).
-  auto step = [&](auto ph, int t, const float* st_cur, float* st_nxt) __attribute__((always_inline)) {
-    constexpr int S0 = decltype(ph)::value, S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;     // slots of planes t, t-1, t-2
-    constexpr int SN = S2;                                                            // plane t+1 (p^0) shares the slot of t-2
-    // ---- sweep 1: p^1(plane t) from p^0 planes t-1, t, t+1
-    int ob = AM[S0][0];
-#pragma unroll
-    for (int q4 = 1; q4 < (NA + 3) / 4; ++q4) ob |= AM[S0][q4];
-    const bool fr_t = __builtin_amdgcn_ballot_w64((ob & 0x7e7e7e7e) != 0) == 0;
-    sweep(IC<1>{}, fr_t, AM[S0], P0[S0], P0[S1], P0[SN], AD[S0], P1[S0]);
-    // ---- sweep 2: p^2(plane t-1) from p^1 planes t-2, t-1, t
-    if (t - 1 >= k_lo - 1) sweep(IC<2>{}, fr_c, AM[S1], P1[S1], P1[S2], P1[S0], AD[S1], P2[S1]);
-    // ---- sweep 3: finished p^3(plane t-2) from p^2 planes t-3, t-2, t-1 (p^2(t-3) sits in slot S0: not yet overwritten)
-    float v[RW];
-    const bool fin = t - 2 >= k_lo;
-    if (fin) sweep(IC<3>{}, fr_m, AM[S2], P2[S2], P2[S0], P2[S1], AD[S2], v);
-    // ---- next planes: p^0(t+2) replaces p^0(t-1) (slot S1), the aux rows of plane t+1 replace those of plane t-2 (slot S2).
-    // That pair was requested two steps ago; the pair requested one step ago (the youngest NDMA VMEM instructions: this
-    // step's stores are issued BEFORE its DMA, so nothing younger follows them) may stay in flight -- a plain vmcnt(0)
-    // would wait for it too and halve the prefetch distance.  vmcnt(NDMA) also covers the previous step's stores.
-    constexpr int NDMA = (ZERO ? 0 : NPQ) + NAQ + 1;
-    if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    pick_p(IC<S1>{}, st_cur);
-    pick_a(IC<S2>{}, st_cur);
-    if (fin) {
-      const unsigned ok = (unsigned)((t - 2 - k0) * g.HW + j0 * g.W) * 4u + (unsigned)x0 * 4u + (unsigned)lane * 4u;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (lane_out && j0 + r < g.H) {
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[K + r]), r_o, ok + (unsigned)(r * g.W) * 4u, 0, 0);
-          if (RES) { const float d = v[K + r] - P2[S2][K + r]; local += d * d; }
-        }
-      }
-    }
-    // the following pair goes into the stage just read; a pair nobody will pick is still requested (the instruction count
-    // per step must not vary for the counted wait) -- it reads clamped planes
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the reads above have left the stage
-    dma(st_nxt, t + 4, t + 3);
-    fr_m = fr_c; fr_c = fr_t;
-  };
-
-  // ---- prologue: p^0 planes t-1, t, t+1 and the aux rows of plane t straight from memory (t = k_lo - 2); then the
-  // stages take over: p^0(t+2) + aux(t+1) -> stage0 (picked at the end of the first step), p^0(t+3) + aux(t+2) -> stage1
-  int t = k_lo - (K - 1);
-  {
-    const unsigned xoff = (unsigned)(x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x)) * 4u;
-    auto ldf = [&](const BufRsrc& r, unsigned cell) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0)); };
-    const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
-      if (!ZERO) { P0[2][rr] = ldf(r_p, pm + rowb[rr]); P0[0][rr] = ldf(r_p, pc + rowb[rr]); P0[1][rr] = ldf(r_p, pp + rowb[rr]); }
-    }
-    unsigned mb[NA];
-#pragma unroll
-    for (int rr = 0; rr < NA; ++rr) {
-      AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]);
-      mb[rr] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_m, xoff >> 2, pc + rowb[rr + 1], 0);
-    }
-#pragma unroll
-    for (int q4 = 0; q4 < (NA + 3) / 4; ++q4) {
-      unsigned vv = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (4 * q4 + u < NA) vv |= mb[4 * q4 + u] << (8 * u);
-      AM[0][q4] = (int)vv;
-    }
-    dma(stage0, t + 2, t + 1);
-    dma(stage1, t + 3, t + 2);
-  }
-  // The first step's plane t sits in slot 0 and reads stage0; slots advance by one and stages alternate per step.
-  while (true) {
-    step(IC<0>{}, t, stage0, stage0); if (++t > k_hi + 1) break;
-    step(IC<1>{}, t, stage1, stage1); if (++t > k_hi + 1) break;
-    step(IC<2>{}, t, stage0, stage0); if (++t > k_hi + 1) break;
-    step(IC<0>{}, t, stage1, stage1); if (++t > k_hi + 1) break;
-    step(IC<1>{}, t, stage0, stage0); if (++t > k_hi + 1) break;
-    step(IC<2>{}, t, stage1, stage1); if (++t > k_hi + 1) break;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the wave
-  if (RES) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) atomicAdd(&sumsq[b], local);
-  }
-}
-
-// Generic single sweep (3D, and any 2D shape): one thread per cell.
 constexpr int BX = 64, BY = 4;
 
-template <bool IS3D, bool QUIRKS>
+// 2D, one sweep per launch, one thread per cell: the pTol > 0 solve (the reference's per-sweep convergence test needs every
+// iterate in memory) and the last sweep of a solve whose caller wants the residual
 __global__ __launch_bounds__(BX* BY) void jacobi_sweep_kernel(GridDims g, const float* __restrict__ flags,
                                                               const float* __restrict__ div,
                                                               const float* __restrict__ p_in,
-                                                              float* __restrict__ p_out, bool from_zero,
-                                                              float* __restrict__ sumsq) {
+                                                              float* __restrict__ p_out, bool from_zero) {
   const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
-  const int bk = blockIdx.z;
-  const int b = IS3D ? bk / g.D : bk, k = IS3D ? bk - b * g.D : 0;
-  float d2 = 0.f;
+  const int b = blockIdx.z;
   if (i < g.W && j < g.H) {
-    const size_t o = (size_t)b * g.DHW + (size_t)k * g.HW + j * g.W + i;
+    const size_t o = (size_t)b * g.DHW + j * g.W + i;
     float v = 0.f;
     const float pc = from_zero ? 0.f : p_in[o];
-    if (!is_border<IS3D>(g, i, j, k) && flags[o] != FNX_OBST) {
+    if (!is_border<false>(g, i, j, 0) && flags[o] != FNX_OBST) {
       if (from_zero) {
         float sum = 0.f + 0.f; sum = sum + 0.f; sum = sum + 0.f; sum = sum + 0.f; sum = sum + 0.f;
-        v = (sum + div[o]) / (IS3D ? 6.f : 4.f);
+        v = (sum + div[o]) / 4.f;
       } else {
         const float n1 = flags[o - 1] == FNX_OBST ? pc : p_in[o - 1];
         const float n2 = flags[o + 1] == FNX_OBST ? pc : p_in[o + 1];
@@ -1381,31 +688,55 @@ __global__ __launch_bounds__(BX* BY) void jacobi_sweep_kernel(GridDims g, const 
         float sum = n1 + n2;
         sum = sum + n3;
         sum = sum + n4;
-        if (IS3D) {
-          // reference applies no Neumann substitution in z (fluids_init.cpp:935-943) -> QUIRKS
-          const float n5 = (!QUIRKS && flags[o - g.HW] == FNX_OBST) ? pc : p_in[o - g.HW];
-          const float n6 = (!QUIRKS && flags[o + g.HW] == FNX_OBST) ? pc : p_in[o + g.HW];
-          sum = sum + n5;
-          sum = sum + n6;
-        } else {
-          sum = sum + 0.f;
-          sum = sum + 0.f;
-        }
-        v = (sum + div[o]) / (IS3D ? 6.f : 4.f);
+        sum = sum + 0.f;
+        sum = sum + 0.f;
+        v = (sum + div[o]) / 4.f;
       }
     }
     p_out[o] = v;
-    const float d = v - pc;
-    d2 = d * d;
-  }
-  if (sumsq) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) d2 += __shfl_down(d2, off, 64);
-    if (threadIdx.x == 0) atomicAdd(&sumsq[b], d2);      // blockDim.x == 64: one wave per row of the block
   }
 }
 
-__global__ void residual_finish_kernel(int B, const float* __restrict__ sumsq, float* __restrict__ res) {
+// ---- residual ||a - b||_2 per sample (cpp/fluids_init.cpp:961-971), reproducible: a FIXED grid of RES_BLOCKS blocks per
+// sample, every block sums the squared differences of its grid-stride cells in a fixed order (fp64), the finishing kernel adds
+// the RES_BLOCKS partials in index order.  No atomics: the same bits run to run, so a pTol exit does not depend on the
+// order the waves retire in.  b == nullptr: b is all zeros (the first sweep of a solve).
+constexpr int RES_BLOCKS = 512;
+__global__ __launch_bounds__(256) void residual_partial_kernel(size_t per_sample, size_t count, size_t a_first, const float* __restrict__ a,
+                                                               const float* __restrict__ bq, double* __restrict__ partials) {
+  const int b = blockIdx.y;
+  const float* pa = a + (size_t)b * per_sample + a_first;
+  const float* pb = bq ? bq + (size_t)b * per_sample + a_first : nullptr;
+  double acc = 0.0;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)RES_BLOCKS * 256) {
+    const float d = pa[q] - (pb ? pb[q] : 0.f);            // the reference's p - p_prev, in fp32
+    acc += (double)d * (double)d;
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {               // fixed tree: thread t adds thread t + off
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[(size_t)b * RES_BLOCKS + blockIdx.x] = sh[0];
+}
+
+// sumsq[b] = sum of the sample's partials in index order (fp64 -> fp32); res (may be null) = max_b sqrt(sumsq[b])
+__global__ void residual_finish_kernel(int B, const double* __restrict__ partials, float* __restrict__ sumsq, float* __restrict__ res) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float m = 0.f;
+    for (int b = 0; b < B; ++b) {
+      double t = 0.0;
+      for (int q = 0; q < RES_BLOCKS; ++q) t += partials[(size_t)b * RES_BLOCKS + q];
+      if (sumsq) sumsq[b] = (float)t;
+      m = fmaxf(m, (float)sqrt(t));
+    }
+    if (res) *res = m;
+  }
+}
+
+__global__ void residual_root_kernel(int B, const float* __restrict__ sumsq, float* __restrict__ res) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float m = 0.f;
     for (int b = 0; b < B; ++b) m = fmaxf(m, sqrtf(sumsq[b]));
@@ -1413,74 +744,26 @@ __global__ void residual_finish_kernel(int B, const float* __restrict__ sumsq, f
   }
 }
 
-__global__ __launch_bounds__(256) void residual_kernel(GridDims g, const float* __restrict__ a,
-                                                       const float* __restrict__ bq, float* __restrict__ sumsq) {
-  const int b = blockIdx.y;
-  float acc = 0.f;
-  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)g.DHW; q += (size_t)gridDim.x * 256) {
-    const float d = a[(size_t)b * g.DHW + q] - bq[(size_t)b * g.DHW + q];
-    acc += d * d;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], acc);
-}
-
-template <int K, int OY>
-void launch_reg_oy(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out,
-                   bool from_zero, float* sumsq, hipStream_t s) {
-  constexpr int OX = 64 - 2 * K;
-  const int tiles_x = (g.W + OX - 1) / OX, tiles_y = (g.H + OY - 1) / OY;
-  const dim3 grid((tiles_x * tiles_y + 3) / 4, g.B);
-  jacobi2d_reg_kernel<K, OY><<<grid, 256, 0, s>>>(g, flags, div, p_in, p_out, from_zero ? 1 : 0, sumsq, tiles_x, tiles_y);
-}
-
-// Tile height selection.  Small grids are latency-bound by the serial instruction chain of ONE wave
-// (~K*V*20 VALU ops, no other wave on the SIMD to hide behind), large grids by total VALU work, which grows with
-// the halo redundancy 64*V/(OX*OY).  So: short tiles when there are few waves, tall tiles when there are many.
-inline int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 template <int K, int RW, int NW>
 void launch_wg(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, bool from_zero,
-               float* sumsq, hipStream_t s) {
+               hipStream_t s) {
   constexpr int OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
   const int tiles_x = (g.W + OX - 1) / OX, tiles_y = (g.H + OYW - 1) / OYW;
-  jacobi2d_wg_kernel<K, RW, NW><<<dim3(tiles_x * tiles_y, g.B), 64 * NW, 0, s>>>(g, flags, div, p_in, p_out, from_zero ? 1 : 0, sumsq, tiles_x);
+  jacobi2d_wg_kernel<K, RW, NW><<<dim3(tiles_x * tiles_y, g.B), 64 * NW, 0, s>>>(g, flags, div, p_in, p_out, from_zero ? 1 : 0, tiles_x);
 }
 
+// Tile shape.  Measured on MI355X (bench.py, Jacobi ms per step; rows per wave x waves): 2048^2 x 100 sweeps K = 8: 8 x 8 0.450,
+// 16 x 4 0.462, 8 x 4 0.533, 16 x 8 0.539, 8 x 16 0.597; 1024^2 x 28 K = 7: 8 x 8 0.0615, 8 x 4 0.0667; 128^2 x 28 K = 8:
+// 8 x 4 0.036 (one 64 x 64 tile per CU leaves most of a small grid's CUs idle) -> 8 rows x 4 waves up to 160 Kcells, else
+// 8 rows x 8 waves.
 template <int K>
-void launch_reg(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out,
-                bool from_zero, float* sumsq, hipStream_t s) {
-  constexpr int OX = 64 - 2 * K;
-  // workgroup tiles (jacobi2d_wg_kernel): FNX_JACOBI_WG = 0 off, else RW*100 + NW (e.g. 808: 8 rows x 8 waves)
-  static const int wg = env_int("FNX_JACOBI_WG", -1);
-  if (wg != 0) {
-    const long cells = (long)g.W * g.H * g.B;
-    // measured on MI355X (bench.py, Jacobi ms per step): 2048^2 x 100 sweeps K=8: 0.659 (wave tiles) -> 808: 0.450, 1604: 0.462,
-    // 804: 0.533, 1608: 0.539, 816: 0.597; 1024^2 x 28 K=7: 0.088 -> 808: 0.0615, 804: 0.0667; 128^2 x 28 K=8: 0.051 -> 804: 0.036
-    const int sel = wg > 0 ? wg : (cells <= (160l << 10) ? 804 : 808);
-    if constexpr (16 > 2 * K) if (sel == 404) { launch_wg<K, 4, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
-    if constexpr (32 > 2 * K) if (sel == 804 || sel == 404) { launch_wg<K, 8, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
-    if (sel == 808) { launch_wg<K, 8, 8>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
-    if (sel == 1604) { launch_wg<K, 16, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
-    if (sel == 1608) { launch_wg<K, 16, 8>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
-    if (sel == 816) { launch_wg<K, 8, 16>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return; }
+void launch_tiles(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, bool from_zero,
+                  hipStream_t s) {
+  const long cells = (long)g.W * g.H * g.B;
+  if constexpr (32 > 2 * K) {
+    if (cells <= (160l << 10)) { launch_wg<K, 8, 4>(g, flags, div, p_in, p_out, from_zero, s); return; }
   }
-  static const int forced = env_int("FNX_JACOBI_OY", 0);
-  int oy = forced;
-  if (!oy) {
-    // measured on MI355X (tools/ubench/jacobi_bench.cpp, tools/jacobi2d_small_probe.py): <= 160 Kcells: 4-row tiles
-    // (28 sweeps at 128^2: 46 -> 39 us, at 384^2: 50 -> 48 us, at 512^2: 55 -> 63 us); <= 2 Mcells: 8; <= 8 Mcells: 16; else 32
-    const long cells = (long)g.W * g.H * g.B;
-    oy = cells <= (160l << 10) ? 4 : (cells <= (2l << 20) ? 8 : (cells <= (8l << 20) ? 16 : 32));
-  }
-  if (oy == 32) launch_reg_oy<K, 32>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
-  else if (oy == 16) launch_reg_oy<K, 16>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
-  else if (oy == 4) launch_reg_oy<K, 4>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
-  else launch_reg_oy<K, 8>(g, flags, div, p_in, p_out, from_zero, sumsq, s);
+  launch_wg<K, 8, 8>(g, flags, div, p_in, p_out, from_zero, s);
 }
 
 }  // namespace
@@ -1491,39 +774,25 @@ constexpr int KMAX_2D = 8;
 
 int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d) {
   if (is3d || g.D != 1) return 1;
-  static const int forced = env_int("FNX_JACOBI_K", 0);
-  if (forced >= 1 && forced <= KMAX_2D) return forced;
-  // workgroup tiles (jacobi2d_wg_kernel): a wave's chain per sweep is its 8 rows whatever K, so the halo (2K of the 64
-  // columns and rows of a tile) is what limits K: 7 where launches are still short (28 sweeps = 4 launches), else 8.
-  // (wave tiles, FNX_JACOBI_WG=0: the serial chain K*(OY+2K) of one wave favoured K = 4 on small grids)
-  static const int wg = env_int("FNX_JACOBI_WG", -1);
-  if (wg == 0) return (long)g.W * g.H * g.B <= (2l << 20) ? 4 : KMAX_2D;
+  // a wave's chain per sweep is its 8 rows whatever K, so the halo (2K of the 64 columns and rows of a tile) is what limits K:
+  // 7 where launches are still short (28 sweeps = 4 launches), else 8
   return (long)g.W * g.H * g.B <= (2l << 20) ? 7 : KMAX_2D;
 }
 
-// nsweeps in [1, jacobi_max_sweeps_per_launch]; sumsq (B floats, pre-zeroed) receives ||p_n - p_{n-1}||^2 of the
-// LAST sweep of this launch when non-null.
-void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags, const float* div, const float* p_in,
-                   float* p_out, int nsweeps, bool from_zero, float* sumsq, hipStream_t s) {
-  if (!is3d && g.D == 1 && nsweeps > 1 && nsweeps <= KMAX_2D) {
-    switch (nsweeps) {
-      case 2: launch_reg<2>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-      case 3: launch_reg<3>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-      case 4: launch_reg<4>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-      case 5: launch_reg<5>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-      case 6: launch_reg<6>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-      case 7: launch_reg<7>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-      case 8: launch_reg<8>(g, flags, div, p_in, p_out, from_zero, sumsq, s); return;
-    }
+// 2D: nsweeps in [1, jacobi_max_sweeps_per_launch] sweeps from p_in into p_out
+void launch_jacobi(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, int nsweeps,
+                   bool from_zero, hipStream_t s) {
+  switch (nsweeps) {
+    case 2: launch_tiles<2>(g, flags, div, p_in, p_out, from_zero, s); return;
+    case 3: launch_tiles<3>(g, flags, div, p_in, p_out, from_zero, s); return;
+    case 4: launch_tiles<4>(g, flags, div, p_in, p_out, from_zero, s); return;
+    case 5: launch_tiles<5>(g, flags, div, p_in, p_out, from_zero, s); return;
+    case 6: launch_tiles<6>(g, flags, div, p_in, p_out, from_zero, s); return;
+    case 7: launch_tiles<7>(g, flags, div, p_in, p_out, from_zero, s); return;
+    case 8: launch_tiles<8>(g, flags, div, p_in, p_out, from_zero, s); return;
   }
-  // generic path: exactly one sweep
-  const dim3 grid((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.D), block(BX, BY);
-  if (is3d) {
-    if (quirks) jacobi_sweep_kernel<true, true><<<grid, block, 0, s>>>(g, flags, div, p_in, p_out, from_zero, sumsq);
-    else jacobi_sweep_kernel<true, false><<<grid, block, 0, s>>>(g, flags, div, p_in, p_out, from_zero, sumsq);
-  } else {
-    jacobi_sweep_kernel<false, false><<<grid, block, 0, s>>>(g, flags, div, p_in, p_out, from_zero, sumsq);
-  }
+  const dim3 grid((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B), block(BX, BY);           // exactly one sweep
+  jacobi_sweep_kernel<<<grid, block, 0, s>>>(g, flags, div, p_in, p_out, from_zero);
 }
 
 // 3D fast path (mask precomputed by launch_jacobi3d_mask)
@@ -1539,46 +808,35 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
   jacobi3d_maskq_kernel<<<gridq, block, 0, s>>>(g, mask, (unsigned*)(mask + maskq_offset(g)));
 }
 
-// two sweeps in one pass: p_in = p^n, p_out = p^{n+2}; sumsq receives ||p^{n+2} - p^{n+1}||^2
-static bool jacobi3d_dma() { static const bool on = [] { const char* e = getenv("FNX_JACOBI_DMA"); return e ? atoi(e) != 0 : false; }(); return on; }
-
 // can the two-sweep passes of this grid hand each other p in the row-quad layout (`lay` of launch_jacobi3d_x2)?
-bool jacobi3d_quad_ok(const GridDims& g) {
-  static const bool off = [] { const char* e = getenv("FNX_JACOBI_QUAD"); return e && atoi(e) == 0; }();   // A/B switch
-  return !off && !jacobi3d_dma() && g.H % 4 == 0 && Z2R == 4 && Z2NW == 1;
-}
+bool jacobi3d_quad_ok(const GridDims& g) { return g.H % 4 == 0 && Z2R == 4 && Z2NW == 1; }
 
-// lay: bit 0 = p_in, bit 1 = p_out in the row-quad layout (jacobi3d_quad_ok; sumsq only with a row-layout output)
+// two sweeps in one pass: p_in = p^n, p_out = p^{n+2}.  lay: bit 0 = p_in, bit 1 = p_out in the row-quad layout
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay) {
+                        hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay) {
   if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
   static const int slots = [] {                          // resident waves: Z2WPS per SIMD (<= 128 VGPRs each)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* e = getenv("FNX_JACOBI_BLOCKS");
-    return e ? atoi(e) : (Z2WPS * 4 / Z2NW) * cus;
+    return (Z2WPS * 4 / Z2NW) * cus;
   }();
-  static const int zenv = [] { const char* e = getenv("FNX_JACOBI_ZCHUNK"); return e ? atoi(e) : -1; }();
-  // Smallest plane chunk.  Every (tile, chunk) wave is resident at once, so a launch lasts (chunk + 4 lead-in planes) x
-  // the per-plane latency of ONE wave, whatever the occupancy: small plane ranges (the slab driver's edge parts, small
+  // Smallest plane chunk.  Every (tile, chunk) wave is resident at once, so a launch lasts (chunk + 2 lead-in steps) x
+  // the per-step time of one wave, whatever the occupancy: small plane ranges (the slab driver's edge parts, small
   // grids) are cut as finely as the wave slots allow (measured 20 -> 14 us for 14 planes of 512^2).
-  static const int zmin = [] { const char* e = getenv("FNX_JACOBI_ZMIN"); return e ? atoi(e) : 2; }();
+  constexpr int zmin = 2;
   const int nxt = (g.W + 59) / 60, nyt = (g.H + Z2NW * Z2R - 1) / (Z2NW * Z2R);
   const int np = ke - kb, ntiles = nxt * nyt * g.B;
-  int zchunk = zenv;
-  if (zchunk < 0) {
-    // as many equal plane chunks per tile as fit one resident set
-    int nzc = slots / ntiles;
-    if (kb2 >= 0) nzc /= 2;                              // two plane ranges share the resident set
-    if (nzc < 1) nzc = 1;
-    zchunk = (np + nzc - 1) / nzc;
-    if (zchunk < zmin) zchunk = zmin;
-    if (ntiles > slots) zchunk = 0;                      // more tiles than slots: even split of the (tile, plane) space
-    if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
-  }
+  // as many equal plane chunks per tile as fit one resident set
+  int nzc = slots / ntiles;
+  if (kb2 >= 0) nzc /= 2;                                // two plane ranges share the resident set
+  if (nzc < 1) nzc = 1;
+  int zchunk = (np + nzc - 1) / nzc;
+  if (zchunk < zmin) zchunk = zmin;
+  if (ntiles > slots) zchunk = 0;                        // more tiles than slots: even split of the (tile, plane) space
+  if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
   if (kb2 >= 0 && (zchunk <= 0 || 2 * ntiles > slots)) {   // no room for both ranges at once: one after the other
-    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb, ke, from_zero, -1, lay);
-    launch_jacobi3d_x2(g, mask, div, p_in, p_out, sumsq, s, kb2, kb2 + np, from_zero, -1, lay);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, s, kb, ke, from_zero, -1, lay);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, s, kb2, kb2 + np, from_zero, -1, lay);
     return;
   }
   long long G;
@@ -1593,99 +851,42 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
   const unsigned* maskq = (const unsigned*)(mask + maskq_offset(g));
-  static const bool dma = jacobi3d_dma();                  // A/B switch (same bits, same speed: see the kernel comment)
-#define J3D(R, Z, S) do { if (dma) jacobi3d_march2_dma_kernel<R, Z, S><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); \
-                          else jacobi3d_march2_kernel<R, Z, S, 0><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2); } while (0)
-#define J3D_RZ(S) do { if (from_zero) { if (sumsq) J3D(true, true, S); else J3D(false, true, S); } \
-                       else { if (sumsq) J3D(true, false, S); else J3D(false, false, S); } } while (0)
-#define J3Q(R, Z, S, L) jacobi3d_march2_kernel<R, Z, S, L><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2)
-#define J3Q_S(R, Z, L) do { if (zchunk > 0) J3Q(R, Z, false, L); else J3Q(R, Z, true, L); } while (0)
+#define J3Q(Z, S, L) jacobi3d_march2_kernel<Z, S, L><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2)
+#define J3Q_S(Z, L) do { if (zchunk > 0) J3Q(Z, false, L); else J3Q(Z, true, L); } while (0)
   if (from_zero) lay &= 2;                                 // no input: its layout does not matter
-  if (lay == 0) { if (zchunk > 0) J3D_RZ(false); else J3D_RZ(true); }
-  else if (lay == 2) { if (from_zero) J3Q_S(false, true, 2); else J3Q_S(false, false, 2); }      // (sumsq: not with a quad output)
-  else if (lay == 3) J3Q_S(false, false, 3);
-  else { if (sumsq) J3Q_S(true, false, 1); else J3Q_S(false, false, 1); }
+  if (lay == 0) { if (from_zero) J3Q_S(true, 0); else J3Q_S(false, 0); }
+  else if (lay == 2) { if (from_zero) J3Q_S(true, 2); else J3Q_S(false, 2); }
+  else if (lay == 3) J3Q_S(false, 3);
+  else J3Q_S(false, 1);
 #undef J3Q_S
 #undef J3Q
-#undef J3D_RZ
-#undef J3D
-}
-
-// three sweeps in one pass: p_in = p^n, p_out = p^{n+3}; returns false (nothing launched) when the grid has more tiles than
-// resident waves -- the caller then uses the 2-sweep / 1-sweep launches
-static int jacobi3d_x3_slots() {
-  static const int slots = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return Z3WPS * 4 * cus;
-  }();
-  return slots;
-}
-
-// can a pass over `np` planes (x `nranges` plane ranges) of this grid run as a 3-sweep launch?
-bool jacobi3d_x3_available(const GridDims& g, int np, int nranges) {
-  // Opt-in (FNX_JACOBI_X3=1).  Measured at 16.8 M cells: 103 us per 3-sweep pass = 68 us per two sweeps against 49 us for
-  // the 2-sweep kernel; at 67 M cells 279 against 256.  Same bits (the whole Jacobi test set passes with it on).  The
-  // counters say why: 53 % of the wave time sits in s_waitcnt -- at 147-168 VGPRs only 2.25 waves per SIMD are resident and
-  // each runs one DMA pair ahead, too little in flight to cover the memory latency -- and its L2-side traffic per pass is
-  // 295 MB against 250 MB (10-row reads, 4 lead-in planes per chunk), so the byte saving per sweep is 21 %, not 33 %.
-  static const bool on = [] { const char* e = getenv("FNX_JACOBI_X3"); return e && atoi(e) != 0; }();
-  if (!on) return false;
-  if (np <= 0) np = g.D;
-  const int ntiles = ((g.W + Z3C - 1) / Z3C) * ((g.H + Z3R - 1) / Z3R) * g.B;
-  return (long)ntiles * nranges <= jacobi3d_x3_slots() && (size_t)(np + 2 * Z3K + 2) * g.HW < 0x3fffffffu;
-}
-
-bool launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb, int ke, bool from_zero, int kb2) {
-  if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
-  const int slots = jacobi3d_x3_slots();
-  const int nxt = (g.W + Z3C - 1) / Z3C, nyt = (g.H + Z3R - 1) / Z3R;
-  const int np = ke - kb, ntiles = nxt * nyt * g.B;
-  const int nr = kb2 >= 0 ? 2 : 1;
-  if (!jacobi3d_x3_available(g, np, nr)) return false;
-  int nzc = slots / (ntiles * nr);
-  if (nzc < 1) nzc = 1;
-  int zchunk = (np + nzc - 1) / nzc;
-  if (zchunk < 4) zchunk = np < 4 ? np : 4;
-  long long G = (long long)ntiles * ((np + zchunk - 1) / zchunk) * nr;
-  G = ((G + 7) / 8) * 8;
-  const dim3 grid((unsigned)G), block(64);
-  if (from_zero) {
-    if (sumsq) jacobi3d_march3_kernel<true, true><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
-    else jacobi3d_march3_kernel<false, true><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
-  } else {
-    if (sumsq) jacobi3d_march3_kernel<true, false><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
-    else jacobi3d_march3_kernel<false, false><<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nxt, nyt, zchunk, kb, ke, kb2);
-  }
-  return true;
 }
 
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                     bool from_zero, float* sumsq, hipStream_t s, int kb, int ke) {
+                     bool from_zero, hipStream_t s, int kb, int ke) {
   if (ke <= kb) { kb = 0; ke = g.D; }
   if (from_zero) {
     const size_t count = (size_t)(ke - kb) * g.HW;
     size_t nb = (count + 256 * 4 - 1) / (256 * 4);
     if (nb > 4096) nb = 4096;
-    jacobi3d_first_kernel<<<(unsigned)nb, 256, 0, s>>>(g.B, (size_t)g.DHW, (size_t)kb * g.HW, count, div, mask, p_out, sumsq);
+    jacobi3d_first_kernel<<<(unsigned)nb, 256, 0, s>>>(g.B, (size_t)g.DHW, (size_t)kb * g.HW, count, div, mask, p_out);
     return;
   }
   const int nzc = (ke - kb + ZCHUNK - 1) / ZCHUNK;
   const dim3 grid((g.W + 63) / 64, (g.H + 4 * ZR - 1) / (4 * ZR), g.B * nzc), block(64, 4);
-  jacobi3d_march_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, sumsq, nzc, kb, ke);
+  jacobi3d_march_kernel<<<grid, block, 0, s>>>(g, mask, div, p_in, p_out, nzc, kb, ke);
 }
 
-void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s) {
-  residual_finish_kernel<<<1, 64, 0, s>>>(B, sumsq, res);
+size_t residual_scratch_bytes(int B) { return (size_t)B * RES_BLOCKS * sizeof(double); }
+
+void launch_residual(int B, size_t per_sample, size_t first, size_t count, const float* a, const float* b, double* partials,
+                     float* sumsq, float* res, hipStream_t s) {
+  residual_partial_kernel<<<dim3(RES_BLOCKS, B), 256, 0, s>>>(per_sample, count, first, a, b, partials);
+  residual_finish_kernel<<<1, 64, 0, s>>>(B, partials, sumsq, res);
 }
 
-void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s) {
-  int blocks = (g.DHW + 256 * 8 - 1) / (256 * 8);
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
-  residual_kernel<<<dim3(blocks, g.B), 256, 0, s>>>(g, a, b, sumsq);
-  residual_finish_kernel<<<1, 64, 0, s>>>(g.B, sumsq, res);
+void launch_residual_root(int B, const float* sumsq, float* res, hipStream_t s) {
+  residual_root_kernel<<<1, 64, 0, s>>>(B, sumsq, res);
 }
 
 }  // namespace fnx

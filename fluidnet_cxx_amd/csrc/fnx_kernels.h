@@ -72,24 +72,25 @@ void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const fl
                         const float* rhoBCInvMask, unsigned char* cls, hipStream_t s);
 
 // Jacobi (fnx_jacobi.hip)
-// `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is
-// not read.  sumsq (B floats, pre-zeroed) receives sum (p_n - p_{n-1})^2 of the last sweep when non-null.
-void launch_jacobi(const GridDims& g, bool is3d, bool quirks, const float* flags, const float* div, const float* p_in,
-                   float* p_out, int nsweeps, bool from_zero, float* sumsq, hipStream_t s);
+// 2D: `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is not read
+void launch_jacobi(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, int nsweeps,
+                   bool from_zero, hipStream_t s);
 int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d);
-// 3D: flags -> 7-bit neighbour mask (once per solve), then one z-marching sweep per launch
+// 3D: flags -> 7-bit neighbour mask (once per solve), then z-marching passes of two sweeps (one for an odd remainder)
 size_t jacobi3d_mask_bytes(const GridDims& g);   // bytes of the `mask` allocation of the 3D launches below (byte mask + the same bytes in row groups of four)
 void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, unsigned char* mask, hipStream_t s);
 // kb/ke: restrict the OUTPUT to planes [kb, ke) (0,0 = all planes); inputs are read from kb-1 (kb-2 for x2) on
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                     bool from_zero, float* sumsq, hipStream_t s, int kb = 0, int ke = 0);
+                     bool from_zero, hipStream_t s, int kb = 0, int ke = 0);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0);
+                        hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0);
 bool jacobi3d_quad_ok(const GridDims& g);   // may two-sweep passes hand each other p in the row-quad layout (lay bits 0 / 1 = p_in / p_out)?
-bool jacobi3d_x3_available(const GridDims& g, int np, int nranges);
-bool launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        float* sumsq, hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1);
-void launch_residual_finish(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
-void launch_residual(const GridDims& g, const float* a, const float* b, float* sumsq, float* res, hipStream_t s);
+// Reproducible residual (no atomics): per sample b the squared differences of a[b*per_sample + first + q] - b[...] (b == null:
+// zeros), q < count, summed in a fixed order in fp64 through `partials` (residual_scratch_bytes(B)); sumsq (B floats, may be
+// null) receives the sums, res (1 float, may be null) max_b sqrt(sum)
+size_t residual_scratch_bytes(int B);
+void launch_residual(int B, size_t per_sample, size_t first, size_t count, const float* a, const float* b, double* partials,
+                     float* sumsq, float* res, hipStream_t s);
+void launch_residual_root(int B, const float* sumsq, float* res, hipStream_t s);   // res = max_b sqrt(sumsq[b])
 
 }  // namespace fnx

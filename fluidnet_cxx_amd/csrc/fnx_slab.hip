@@ -167,7 +167,7 @@ struct LoopGroup {
   int nranks;
   std::vector<LoopPair> pairs;   // pair i: ranks i, i+1
   std::mutex mu; std::condition_variable cv;
-  int red_count = 0, red_gen = 0; float red_val[64], red_out[64]; int red_n = 0;   // (red_out: a finished round's result, safe from the next round's first arrival)
+  int red_count = 0, red_gen = 0; std::vector<float> red_val, red_out;   // (red_out: a finished round's result, safe from the next round's first arrival)
   std::atomic<bool> aborted{false};   // a rank failed: every party waiting for a peer gives up (FNX_ECOMM) instead of hanging
   explicit LoopGroup(int n) : nranks(n), pairs(n > 1 ? n - 1 : 0) {}
 };
@@ -240,16 +240,17 @@ int loop_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
 int loop_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
   LoopCtx* c = (LoopCtx*)vctx;
   LoopGroup* g = c->g;
-  if (n > 64) return fnx::set_error(FNX_EINVAL, "loopback allreduce: n > 64");
-  float h[64];
+  if (n < 1) return fnx::set_error(FNX_EINVAL, "loopback allreduce: n < 1");
+  std::vector<float> hv((size_t)n);
+  float* h = hv.data();
   SLAB_HIP(hipMemcpyAsync(h, x, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   SLAB_HIP(hipStreamSynchronize((hipStream_t)stream));
   {
     std::unique_lock<std::mutex> lk(g->mu);
     const int gen = g->red_gen;
-    if (g->red_count == 0) { g->red_n = n; for (int i = 0; i < n; ++i) g->red_val[i] = h[i]; }
+    if (g->red_count == 0) g->red_val.assign(h, h + n);
     else for (int i = 0; i < n; ++i) g->red_val[i] = sum ? g->red_val[i] + h[i] : (h[i] > g->red_val[i] ? h[i] : g->red_val[i]);
-    if (++g->red_count == g->nranks) { g->red_count = 0; for (int i = 0; i < n; ++i) g->red_out[i] = g->red_val[i]; ++g->red_gen; g->cv.notify_all(); }
+    if (++g->red_count == g->nranks) { g->red_count = 0; g->red_out = g->red_val; ++g->red_gen; g->cv.notify_all(); }
     else if (!loop_wait(g, g->cv, lk, [&] { return g->red_gen != gen; })) return loop_gone();
     for (int i = 0; i < n; ++i) h[i] = g->red_out[i];
   }
@@ -315,7 +316,8 @@ FnxGrid grid_of(const FnxSlab* s, int kb = 0, int ke = 0) {
 }
 
 struct Work {                      // the step's scratch, carved from the caller's workspace
-  float *rho_adv, *U_adv, *div, *pbuf, *cfl;
+  float *rho_adv, *U_adv, *div, *pbuf, *cfl;   // cfl: max(64, B) floats (CFL number / per-sample sums of squares)
+  double* part;                                // the residual's fixed-order partial sums (pTol > 0)
   unsigned char* cls;
   void *jac, *adv;
   size_t jac_bytes, adv_bytes;
@@ -328,7 +330,7 @@ size_t carve(const FnxSlab* s, void* ws, Work* w) {
   auto take = [&](size_t bytes) { void* r = base ? base + off : nullptr; off += al(bytes); return r; };
   Work t;
   t.rho_adv = (float*)take(n1 * 4); t.U_adv = (float*)take(n1 * 12); t.div = (float*)take(n1 * 4); t.pbuf = (float*)take(n1 * 4);
-  t.cfl = (float*)take(256); t.cls = (unsigned char*)take(n1);
+  t.cfl = (float*)take((size_t)(g.B > 64 ? g.B : 64) * 4); t.part = (double*)take(fnx::residual_scratch_bytes(g.B)); t.cls = (unsigned char*)take(n1);
   t.jac_bytes = fnx_workspace_bytes(&g, FNX_OP_JACOBI); t.jac = take(t.jac_bytes);
   t.adv_bytes = fnx_workspace_bytes(&g, FNX_OP_ADVECT_STEP); t.adv = take(t.adv_bytes);
   if (w) *w = t;
@@ -490,7 +492,7 @@ int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* 
   } else {
     s->comm = FnxSlabComm{};
   }
-  if (hipHostMalloc((void**)&s->h_cfl, 64 * sizeof(float)) != hipSuccess) {     // CFL number / per-sample residuals
+  if (hipHostMalloc((void**)&s->h_cfl, (size_t)(cfg->B > 64 ? cfg->B : 64) * sizeof(float)) != hipSuccess) {     // CFL number / per-sample residuals
     fnx_slab_destroy(s);
     return fnx::set_error(FNX_EHIP, "slab_create: pinned host allocation failed");
   }
@@ -562,7 +564,6 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   if (!s || !prm || !st) return fnx::set_error(FNX_EINVAL, "slab_step: NULL argument");
   if (!st->p || !st->U || !st->flags || !st->density) return fnx::set_error(FNX_EINVAL, "slab_step: the z-slab driver needs p, U, flags and a density field");
   if (prm->method != 0) return fnx::set_error(FNX_EINVAL, "slab_step: only the Jacobi projection shards (the CNN configurations are single-GPU)");
-  if (prm->p_tol > 0.f && s->cfg.B > 63) return fnx::set_error(FNX_EINVAL, "slab_step: pTol > 0 supports up to 63 samples");
   if (prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
   Work W;
   if (!ws || carve(s, ws, &W) > ws_bytes) return fnx::set_error(FNX_EWORKSPACE, "slab_step: workspace too small (%zu < %zu)", ws_bytes, carve(s, nullptr, nullptr));
@@ -675,12 +676,8 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       float* fc[1] = {cur};
       if (it > 0) SLAB_OK(xchg(s, fc, c1, 1, 1, stream));
       SLAB_OK(pass(cur, nxt, 1, a, b));
-      SLAB_HIP(hipMemsetAsync(W.cfl, 0, 64 * sizeof(float), stream));
-      for (int bb = 0; bb < s->cfg.B; ++bb) {
-        GridDims gd = make_dims(1, s->owned, s->cfg.H, s->cfg.W);
-        fnx::launch_residual(gd, nxt + (size_t)bb * vol + (size_t)lo * plane, cur + (size_t)bb * vol + (size_t)lo * plane, W.cfl + bb,
-                             W.cfl + 63, stream);                                   // (W.cfl[63]: this sample's root, unused)
-      }
+      // per-sample sums of squares over the owned planes, in a fixed order (reproducible: fnx_residual)
+      fnx::launch_residual(s->cfg.B, vol, (size_t)lo * plane, (size_t)s->owned * plane, nxt, cur, W.part, W.cfl, nullptr, stream);
       if (world > 1) SLAB_OK(s->comm.allreduce_sum(s->comm.ctx, W.cfl, s->cfg.B, stream));
       SLAB_HIP(hipMemcpyAsync(s->h_cfl, W.cfl, s->cfg.B * sizeof(float), hipMemcpyDeviceToHost, stream));
       SLAB_HIP(hipStreamSynchronize(stream));

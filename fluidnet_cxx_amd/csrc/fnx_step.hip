@@ -2,11 +2,17 @@
 //
 // The reference runs setConstVals -> addBuoyancy -> setWallBcs -> setConstVals -> velocityDivergence as ~250
 // ATen ops; as separate HIP kernels they are 9 launches that each stream the same 4-24 MiB fields.  Here:
-//   pre_projection_kernel : U_adv, rho_adv (advection outputs) -> U, rho (BCs, buoyancy, wall BCs applied) and div
+//   stage2d_div_kernel    : U_adv, rho_adv (advection outputs) -> U, rho (BCs, buoyancy, wall BCs applied) and div; each
+//                           thread produces its own cell and re-derives the +1 neighbours' velocity components the
+//                           divergence needs (radius-1 recompute instead of a second pass over HBM)
+//   stage3d_kernel        : the same stages in 3D without the divergence (the recompute would cost ~54 loads per cell; a
+//                           plain divergence pass follows: 0.67 -> 0.59 ms at 256^3)
 //   post_projection_kernel: U -= grad p, wall BCs, BCs                      (simulate.py:154-168)
-// Each thread produces its own cell and re-derives the +1 neighbours' velocity components it needs for the
-// divergence (radius-1 recompute instead of a second pass over HBM).  Per-cell arithmetic is exactly the
-// sequence of the separate operators (fnx_stencils.hip), so results are bit-identical to the unfused path.
+// Per-cell arithmetic is exactly the sequence of the separate operators (fnx_stencils.hip), so results are bit-identical
+// to the unfused path.  The stages of one velocity component `a` of a cell, in order (what the comments below call "the
+// stage sequence"): setConstVals (simulate.py:96), addBuoyancy on interior fluid cells whose -1 neighbour is fluid
+// (source_terms.py:47-116), setWallBcs (set_wall_bcs.py:45-84; skipped before the convnet, simulate.py:120), setConstVals
+// (simulate.py:133).
 #include "fnx_device.h"
 #include "fnx_kernels.h"
 
@@ -23,117 +29,11 @@ struct StepPtrs {
   const unsigned char* cls;                          // optional BC class map (bit 0: velocity BCs are x*1+0, bit 1: density)
 };
 
-// velocity component `a` of cell (k,j,i) after setConstVals, addBuoyancy, setWallBcs, setConstVals
-// IDENT: every BC this evaluation touches is the identity x*1 + 0 (wave-uniform fast path: no BC or class loads at all)
-template <bool IS3D, bool QUIRKS, bool WALL, bool IDENT = false>
-__device__ __forceinline__ float staged_u(const GridDims& g, const StepPtrs& P, int b, int a, int k, int j, int i,
-                                          bool buoy, float s_a, float rho_star) {
-  constexpr int NC = IS3D ? 3 : 2;
-  const size_t o = (size_t)k * g.HW + j * g.W + i;
-  const size_t ou = ((size_t)b * NC + a) * g.DHW + o, os = (size_t)b * g.DHW + o;
-  const bool ubc = P.UBC != nullptr;
-  float u = P.U_adv[ou];
-  float m = 1.f, c = 0.f;
-  if (ubc) {                                                                                  // simulate.py:96
-    if (!IDENT && !(P.cls && (P.cls[os] & 1))) { m = P.UBCInvMask[ou]; c = P.UBC[ou]; }      // (identity cells: no loads)
-    const float t = u * m; u = t + c;
-  }
-  const float fc = P.flags[os];
-  const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
-  const int idx = a == 0 ? i : (a == 1 ? j : k);          // local index: guards the read
-  const float fm = idx > 0 ? P.flags[os - off] : fc;
-  if (buoy && P.rho_adv && !is_border<IS3D>(g, i, j, k) && fc == FNX_FLUID && fm == FNX_FLUID) {   // source_terms.py
-    const bool rbc = P.rhoBC != nullptr;
-    float r0 = P.rho_adv[os], r1 = P.rho_adv[os - off];
-    if (rbc) {
-      float m0 = 1.f, c0 = 0.f, m1 = 1.f, c1 = 0.f;
-      if (!IDENT && !(P.cls && (P.cls[os] & 2))) { m0 = P.rhoBCInvMask[os]; c0 = P.rhoBC[os]; }
-      if (!IDENT && !(P.cls && (P.cls[os - off] & 2))) { m1 = P.rhoBCInvMask[os - off]; c1 = P.rhoBC[os - off]; }
-      float t = r0 * m0; r0 = t + c0;
-      t = r1 * m1; r1 = t + c1;
-    }
-    if (a == 2 && QUIRKS) u = u + s_a * (0.5f * (r0 + (k + g.zoff <= 1 ? 0.f : r1)));
-    else u = u + s_a * ((0.5f * (r0 + r1)) - rho_star);
-  }
-  // set_wall_bcs.py:45-84 (z: only k > 0); skipped before the convnet (simulate.py:120)
-  if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {
-    if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
-      if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
-    }
-  }
-  if (ubc) { const float t = u * m; u = t + c; }                                             // simulate.py:133
-  return u;
-}
-
-template <bool IS3D, bool QUIRKS, bool WALL>
-__global__ __launch_bounds__(BX* BY) void pre_projection_kernel(GridDims g, StepPtrs P, int buoy, float sx, float sy,
-                                                                float sz, float rho_star) {
-  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
-  const int bk = blockIdx.z;
-  const int b = IS3D ? bk / g.KN : bk, k = IS3D ? g.K0 + (bk - b * g.KN) : 0;
-  if (i >= g.W || j >= g.H) return;
-  constexpr int NC = IS3D ? 3 : 2;
-  const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
-  const bool by = buoy != 0;
-  // staging pass without the fused divergence (3D): when every lane of the wave only touches identity cells -- its own
-  // and the -1 neighbours whose density the buoyancy term averages -- no BC array and no further class byte is read
-  bool ident = false;
-  if (P.cls && !P.div) {
-    bool mine = P.cls[os] == 3;
-    if (i > 0) mine = mine & ((P.cls[os - 1] & 2) != 0);
-    if (j > 0) mine = mine & ((P.cls[os - g.W] & 2) != 0);
-    if (IS3D && k > 0) mine = mine & ((P.cls[os - g.HW] & 2) != 0);
-    ident = __builtin_amdgcn_ballot_w64(!mine) == 0;
-  }
-  float u0, u1, u2 = 0.f;
-  if (ident) {
-    u0 = staged_u<IS3D, QUIRKS, WALL, true>(g, P, b, 0, k, j, i, by, sx, rho_star);
-    u1 = staged_u<IS3D, QUIRKS, WALL, true>(g, P, b, 1, k, j, i, by, sy, rho_star);
-    if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL, true>(g, P, b, 2, k, j, i, by, sz, rho_star);
-  } else {
-    u0 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i, by, sx, rho_star);
-    u1 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j, i, by, sy, rho_star);
-    if (IS3D) u2 = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k, j, i, by, sz, rho_star);
-  }
-  float rnew = 0.f;
-  if (P.rho_adv) {
-    float r = P.rho_adv[os];
-    if (P.rhoBC) {
-      float m = 1.f, c = 0.f;
-      if (!ident && !(P.cls && (P.cls[os] & 2))) { m = P.rhoBCInvMask[os]; c = P.rhoBC[os]; }
-      float t = r * m; r = t + c;       // simulate.py:96
-      t = r * m; r = t + c;             // simulate.py:133
-    }
-    rnew = r;
-  }
-  float d = 0.f;
-  if (P.div) {
-    if (!is_border<IS3D>(g, i, j, k)) {
-      const float u0p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 0, k, j, i + 1, by, sx, rho_star);
-      const float u1p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 1, k, j + 1, i, by, sy, rho_star);
-      d = ((u0 - u0p) + u1) - u1p;
-      if (IS3D) {
-        const float u2p = staged_u<IS3D, QUIRKS, WALL>(g, P, b, 2, k + 1, j, i, by, sz, rho_star);
-        d = d + (u2 - u2p);
-      }
-    }
-    if (P.flags[os] == FNX_OBST) d = 0.f;
-  }
-  // all loads above, all stores below: identical loads of the six staged_u evaluations (flags, rho, masks of the
-  // shared cells) are then merged by the compiler instead of being re-issued after a possibly aliasing store
-  P.U[((size_t)b * NC + 0) * g.DHW + o] = u0;
-  P.U[((size_t)b * NC + 1) * g.DHW + o] = u1;
-  if (IS3D) P.U[((size_t)b * NC + 2) * g.DHW + o] = u2;
-  if (P.rho_adv) P.rho[os] = rnew;
-  if (P.div) P.div[os] = d;
-}
-
-// The 3D staging pass (pre_projection without the fused divergence) as straight-line code: every load of a cell -- its
-// three advected velocity components, the density and the flags of the cell and of its three -1 neighbours, and, unless
-// the whole wave is in identity BC cells, the BC arrays of those cells -- is issued unconditionally up front (a -1
-// neighbour that does not exist reads the cell itself) and the stage conditions become selects.  staged_u nests its
-// loads inside those conditions, which turned the kernel into a chain of load -> wait -> branch round trips (58 waits:
-// 257 us at 512x512x64 whether or not the BC loads were skipped).  Same operations in the same order: same bits.
+// The 3D staging pass as straight-line code: every load of a cell -- its three advected velocity components, the density
+// and the flags of the cell and of its three -1 neighbours, and, unless the whole wave is in identity BC cells, the BC
+// arrays of those cells -- is issued unconditionally up front (a -1 neighbour that does not exist reads the cell itself)
+// and the stage conditions become selects.  (With the loads nested inside the conditions the kernel was a chain of load ->
+// wait -> branch round trips: 58 waits, 257 us at 512x512x64 whether or not the BC loads were skipped; now 120 us.)
 template <bool QUIRKS, bool WALL>
 __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P, int buoy, float sx, float sy, float sz,
                                                          float rho_star) {
@@ -142,7 +42,7 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
   const int b = bk / g.KN, k = g.K0 + (bk - b * g.KN);
   if (i >= g.W || j >= g.H) return;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
-  const int off[3] = { i > 0 ? 1 : 0, j > 0 ? g.W : 0, k > 0 ? g.HW : 0 };     // 0: "the cell itself" (staged_u: fm = fc)
+  const int off[3] = { i > 0 ? 1 : 0, j > 0 ? g.W : 0, k > 0 ? g.HW : 0 };     // 0: "the cell itself" (a missing neighbour counts as the cell's own type)
   const bool has_rho = P.rho_adv != nullptr, ubc = P.UBC != nullptr, rbc = P.rhoBC != nullptr;
   bool ident = false;
   if (P.cls) {
@@ -173,7 +73,7 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
       for (int a = 0; a < 3; ++a) { rm1[a] = P.rhoBCInvMask[os - off[a]]; rc1[a] = P.rhoBC[os - off[a]]; }
     }
   }
-  // ---- the stages of staged_u, per component
+  // ---- the stage sequence, per component
   const bool border = is_border<true>(g, i, j, k);
   const float sa[3] = { sx, sy, sz };
   float un[3];
@@ -209,7 +109,7 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
 // velocity of itself, of u_x at (i+1, j) and of u_y at (i, j+1); all the loads those four evaluations make -- flags and
 // density at the cell and its four neighbours, four advected velocity values and, unless the whole wave is in identity
 // BC cells, their BC entries -- are issued up front (clamped indices where a neighbour does not exist; such values are
-// never used) and staged_u's conditions become selects.  Same operations in the same order: same bits.
+// never used) and the stage conditions become selects.
 template <bool WALL>
 __device__ __forceinline__ float stage_eval2d(int a, float u, bool ubc, float um, float uc, float fc, float fm, bool border,
                                               bool buoy, float r0, float r1, bool rbc, float rm0, float rc0, float rm1,
@@ -236,8 +136,8 @@ __global__ __launch_bounds__(BX* BY) void stage2d_div_kernel(GridDims g, StepPtr
   const size_t o = (size_t)j * g.W + i, os = (size_t)b * g.DHW + o;
   const bool has_rho = P.rho_adv != nullptr, ubc = P.UBC != nullptr, rbc = P.rhoBC != nullptr && has_rho;
   const bool buoy = buoy_ != 0 && has_rho;
-  // neighbour offsets; 0 where the neighbour does not exist (staged_u: fm = fc at index 0; the +1 values of a border
-  // cell are never used)
+  // neighbour offsets; 0 where the neighbour does not exist (a missing -1 neighbour counts as the cell's own type; the
+  // +1 values of a border cell are never used)
   const int xm = i > 0 ? 1 : 0, ym = j > 0 ? g.W : 0, xp = i < g.W - 1 ? 1 : 0, yp = j < g.H - 1 ? g.W : 0;
   bool ident = false;
   if (P.cls) {
@@ -378,27 +278,16 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
                            float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s, const unsigned char* cls) {
   StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div, cls};
   const dim3 grid = cell_grid(g), block(BX, BY);
-#define PRE(A, Q, WL) pre_projection_kernel<A, Q, WL><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star)
-  static const bool flat = [] { const char* e = getenv("FNX_STAGE3D_FLAT"); return !e || atoi(e) != 0; }();   // A/B switch
-  if (!is3d && flat) {
+  if (!is3d) {
     if (wall_bcs) stage2d_div_kernel<true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, rho_star);
     else stage2d_div_kernel<false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, rho_star);
     return;
   }
-  if (is3d && !div && flat) {
-    if (quirks) { if (wall_bcs) stage3d_kernel<true, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
-                  else stage3d_kernel<true, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
-    else        { if (wall_bcs) stage3d_kernel<false, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
-                  else stage3d_kernel<false, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
-    return;
-  }
-  if (is3d) {
-    if (quirks) { if (wall_bcs) PRE(true, true, true); else PRE(true, true, false); }
-    else        { if (wall_bcs) PRE(true, false, true); else PRE(true, false, false); }
-  } else {
-    if (wall_bcs) PRE(false, false, true); else PRE(false, false, false);
-  }
-#undef PRE
+  // 3D: staging only (div must be null: fnx_pre_projection follows it with a divergence pass)
+  if (quirks) { if (wall_bcs) stage3d_kernel<true, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
+                else stage3d_kernel<true, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
+  else        { if (wall_bcs) stage3d_kernel<false, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
+                else stage3d_kernel<false, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
 }
 
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,

@@ -42,13 +42,16 @@ def blob_from_state_dict(sd, ndim=2):
 class MultiScaleNet:
     """x (B,2,H,W) or (B,2,D,H,W) -> (B,1,...)   (multi_scale_net.py:118-127)"""
 
-    def __init__(self, state_dict, device="cuda", is3D=False):
+    def __init__(self, state_dict, device="cuda", is3D=False, precision_mode="fp32"):
         self.is3D = bool(is3D)
+        # "fp32": exact-fp32 MFMA arithmetic, 3x3 layers in the Winograd domain where the launch fills the chip;
+        # "fp32_direct": every convolution a direct sum over its taps (include/fluidnet_hip.h: FNX_PRECISION_*)
+        self.precision_mode = precision_mode
         blob = torch.from_numpy(blob_from_state_dict(state_dict, 3 if is3D else 2)).to(device)
         self.packed = ext.scalenet_pack(blob, self.is3D)
 
     def __call__(self, x):
-        return ext.multiscale_forward(self.packed, x.contiguous())
+        return ext.multiscale_forward(self.packed, x.contiguous(), self.precision_mode)
 
 
 class FluidNet:
@@ -71,6 +74,8 @@ class FluidNet:
         self.inDims = mconf.get("inputDim", 2)
         self.is3D = bool(mconf.get("is3D", False))
         self.threshold = float(mconf.get("normalizeInputThreshold", 1e-5))
+        # not a reference key: "fp32" (default) or "fp32_direct" (no Winograd), see MultiScaleNet
+        self.precision_mode = str(mconf.get("precisionMode", "fp32"))
         self.training = False
         self._ndim = 3 if self.is3D else 2
         self._params = OrderedDict((k, torch.from_numpy(v)) for k, v in make_scalenet_weights(0, ndim=self._ndim).items())
@@ -147,7 +152,7 @@ class FluidNet:
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if self._ms is None or self._ms_device != device:
-            self._ms = MultiScaleNet(self._params, device, self.is3D)
+            self._ms = MultiScaleNet(self._params, device, self.is3D, self.precision_mode)
             self._ms_device = device
         return self._ms
 
@@ -165,7 +170,7 @@ class FluidNet:
 
     def __call__(self, input_):
         ms = self._ensure_packed(input_.device)
-        p, U = ext.fluidnet_forward(ms.packed, input_.contiguous(), self.threshold)
+        p, U = ext.fluidnet_forward(ms.packed, input_.contiguous(), self.threshold, self.precision_mode)
         return p, U
 
     forward = __call__

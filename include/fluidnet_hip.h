@@ -99,9 +99,20 @@ int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags
 
 /* solveLinearSystemJacobi: pybind `solve_linear_system`, cpp/fluids_init.cpp:809-1004.
  * p: output (B,1,D,H,W).  residual: DEVICE pointer to 1 float (max over batch of ||p - p_prev||_2 of the
- * last sweep) or NULL.  iters_done: HOST pointer or NULL.  p_tol <= 0 never synchronises. */
+ * last sweep) or NULL.  iters_done: HOST pointer or NULL.  p_tol <= 0 never synchronises.
+ * The residual is reproducible: squared differences summed in a fixed order in fp64 (no atomics), so the sweep at which a
+ * p_tol > 0 solve stops is the same run to run.  With residual != NULL the last sweep runs as its own launch (both
+ * iterates must be in memory); fnx_simulate_step passes NULL. */
 int fnx_jacobi(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual,
                float p_tol, int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream);
+/* The same with `verbose` of the reference (cpp/fluids_init.cpp:968-987): "Jacobi iteration N: residual R" on stdout after
+ * EVERY sweep and the two termination messages -- one sweep per launch and one host synchronisation per sweep. */
+int fnx_jacobi_verbose(const FnxGrid* g, const float* flags, const float* div, float* p, float* residual,
+                       float p_tol, int max_iter, int* iters_done, void* ws, size_t ws_bytes, void* stream);
+/* ||a - b||_2 per sample over the compute window of g (b == NULL: zeros), reproducible as above: sumsq (B DEVICE floats, may be
+ * NULL) receives the sums of squares, residual (1 DEVICE float, may be NULL) max_b sqrt(sum).  ws: B * 4096 bytes.  What the
+ * z-slab driver all-reduces over the ranks for p_tol > 0. */
+int fnx_residual(const FnxGrid* g, const float* a, const float* b, float* sumsq, float* residual, void* ws, size_t ws_bytes, void* stream);
 
 /* `nsweeps` more Jacobi sweeps starting from the pressure already in `p` (in place).  Same per-sweep arithmetic as
  * fnx_jacobi (cpp/fluids_init.cpp:858-994); used by the z-slab driver, which exchanges ghost planes of p between
@@ -115,11 +126,7 @@ int fnx_jacobi_sweeps(const FnxGrid* g, const float* flags, const float* div, fl
 int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div, float* p, int nsweeps,
                          void* ws, size_t ws_bytes, int reuse_mask, void* stream);
 
-/* How many sweeps one fnx_jacobi_pass launch can run for passes over `nplanes` planes (0 = all) in `nranges` (1 or 2)
- * plane ranges of this 3D grid: 3 where the 3-sweep kernel applies, else 2. */
-int fnx_jacobi_max_pass_sweeps(const FnxGrid* g, int nplanes, int nranges);
-
-/* One pass of 1, 2 or 3 sweeps (3D) from p_in into p_out restricted to the output planes [k_begin, k_end)
+/* One pass of 1 or 2 sweeps (3D) from p_in into p_out restricted to the output planes [k_begin, k_end)
  * (0,0 = all); explicit buffers, no ping-pong.  p_in == NULL: the pressure is 0 everywhere (first pass of a solve).  Lets the z-slab driver compute the planes its neighbours need
  * first, start the ghost exchange, and compute the interior while the exchange is in flight.  `ws` as for
  * fnx_jacobi_sweeps_ex (holds the neighbour mask). */
@@ -207,6 +214,7 @@ typedef struct FnxStepParams {
   int   jacobi_iter;          /* mconf['jacobiIter'] */
   int   method;               /* 0 = 'jacobi', 1 = 'convnet' */
   float normalize_threshold;  /* mconf['normalizeInputThreshold'] (convnet) */
+  int   precision_mode;       /* convnet: FNX_PRECISION_FP32 (0, the default) or FNX_PRECISION_FP32_DIRECT, see fnx_multiscale_forward */
   int   static_flags;         /* promises about the previous fnx_simulate_step on this workspace (no reference key; every
                                  reference simulation keeps its flags and BC arrays fixed):
                                  bit 0: `flags` is unchanged -> the 3D Jacobi solver reuses the obstacle mask it left there;
@@ -324,9 +332,9 @@ void fnx_slab_destroy(FnxSlab* s);
 /* One time step.  st: the rank's local arrays (with ghost planes), st->density required, st->net unused; prm->method
  * must be 0.  prm->p_tol > 0 runs the reference's convergence test (fluids_init.cpp:961-979): one sweep per ghost exchange,
  * the squared differences over the owned planes all-reduced over the ranks, one host sync per sweep (as in fnx_jacobi);
- * up to 63 samples.  The bit-for-bit statement above holds for p_tol == 0; with p_tol > 0 every sweep still has the
- * single-domain bits, but the residual is a sum in another order (per rank, then over the ranks), so a tolerance within
- * rounding (~1e-7 relative) of a sweep's residual can stop one sweep earlier or later than fnx_jacobi does.
+ * every rank's part reproducible (fnx_residual).  The bit-for-bit statement above holds for p_tol == 0; with p_tol > 0 every
+ * sweep still has the single-domain bits, but the residual is summed per rank and then over the ranks (fp32 all-reduce), so a
+ * tolerance within rounding (~1e-7 relative) of a sweep's residual can stop one sweep earlier or later than fnx_jacobi does.
  * prm->static_flags is ignored (FnxSlabConfig.static_flags).  ws: fnx_slab_workspace_bytes, kept between steps.
  * On failure (other than FNX_ECFL, which every rank reports together) the communicator's abort() is called. */
 int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* stream);
@@ -352,12 +360,20 @@ int fnx_slab_comm_probe(const FnxSlabComm* comm, void* scratch, size_t bytes, in
 size_t fnx_scalenet_weight_floats(int is3D);
 size_t fnx_scalenet_packed_bytes(int is3D);
 int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* stream);
+/* precision_mode of the CNN entry points (and FnxStepParams.precision_mode).  Both are exact-fp32 arithmetic on
+ * v_mfma_f32_*_f32 (no reduced-precision path exists; an opt-in split-bf16 mode would get its own value here and its own label in
+ * every report):
+ *   FNX_PRECISION_FP32         the default: 3x3(x3) layers of launches that fill the chip run in the Winograd F(2x2,3x3) domain
+ *                              (2.25x fewer multiplies, not the summation order of a direct convolution; within 1e-5 |ref|max of
+ *                              the torch reference, tests/test_parity_gpu.py)
+ *   FNX_PRECISION_FP32_DIRECT  every convolution as a direct sum over its taps (implicit GEMM), no Winograd */
+enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1 };
 /* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
-int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p,
+int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                            void* ws, size_t ws_bytes, void* stream);
 /* input: (B,5|6,D,H,W) = [p, U, flags, density] -> p_out (B,1,..), U_out (B,2|3,..) */
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float normalize_threshold,
-                         float* p_out, float* U_out, void* ws, size_t ws_bytes, void* stream);
+                         float* p_out, float* U_out, int precision_mode, void* ws, size_t ws_bytes, void* stream);
 
 /* Optional timing of the dominant kernels with HIP events on the launch stream (used by bench.py for the roofline
  * figures).  While enabled, every launch of the tagged kernel class is bracketed by an event pair (up to 16384 pairs,

@@ -1,6 +1,6 @@
-"""Helper process of test_parity_gpu.py::test_cnn_benchmark_size: one MultiScaleNet forward on a seeded input, saved as
-.npy.  Run in its own process because the conv kernel selection (FNX_CONV_WINO=0: direct implicit-GEMM kernels instead of
-the Winograd ones) is read once per process.   python tests/cnn_forward_helper.py D H W seed out.npy"""
+"""Helper of test_parity_gpu.py::test_cnn_benchmark_size: one MultiScaleNet forward on a seeded input, with the default
+kernel selection ("fp32": Winograd where the launch fills the chip) or precision_mode "fp32_direct" (direct implicit-GEMM
+kernels only).   python tests/cnn_forward_helper.py D H W seed out.npy [precision_mode]"""
 import os
 import sys
 
@@ -21,13 +21,13 @@ def make_input(D, H, W, seed):
     return x
 
 
-def forward(x, dev="cuda:0"):
+def forward(x, dev="cuda:0", precision_mode="fp32"):
     import torch
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     is3d = x.shape[2] > 1
     mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
-                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d)
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d, precisionMode=precision_mode)
     net = FluidNet.from_weights(mconf, make_scalenet_weights(0, ndim=3 if is3d else 2), dev)
     t = torch.from_numpy(x).to(dev)
     if not is3d:
@@ -39,4 +39,4 @@ def forward(x, dev="cuda:0"):
 
 if __name__ == "__main__":
     D, H, W, seed = (int(v) for v in sys.argv[1:5])
-    np.save(sys.argv[5], forward(make_input(D, H, W, seed)))
+    np.save(sys.argv[5], forward(make_input(D, H, W, seed), precision_mode=sys.argv[6] if len(sys.argv) > 6 else "fp32"))

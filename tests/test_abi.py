@@ -43,6 +43,18 @@ def test_no_oracle_in_product(built):
                 assert "import oracle" not in txt and "from oracle" not in txt and "ora_" not in txt, f
 
 
+def test_no_environment_switches_in_product(built):
+    """Kernel selection is a function of the arguments alone: the library reads no environment variable (round 2 had ~18
+    getenv switches selecting variants once per process -- hidden process-global state in a library whose contract says
+    'no globals'), and its dynamic symbol table does not import getenv."""
+    import subprocess
+    for root, _, files in os.walk(os.path.join(REPO, "fluidnet_cxx_amd", "csrc")):
+        for f in files:
+            assert "getenv" not in open(os.path.join(root, f)).read(), f
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", built.LIB]).decode()
+    assert "getenv" not in syms
+
+
 def test_extension_entry_points(built):
     from fluidnet_cxx_amd._ext import ext
     # the reference's pybind names (pytorch/lib/fluid/cpp/fluids_init.cpp:1009-1014)

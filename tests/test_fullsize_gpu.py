@@ -1,0 +1,130 @@
+"""Benchmark-size launch plans against the CPU oracle (not against themselves).
+
+Every configuration `bench.py` times is advanced to a developed state on the GPU (>= 30 steps: a plume exists, the pressure
+front crosses the denormal range, traces leave their cells), then ONE more step is taken by the HIP path -- with exactly the
+launch plan bench.py uses at that size (workspace, static_flags promises, XCD-renumbered plane chunks, row-quad hand-over,
+row-group mask, LDS-tile advection with its fix-up launches, the fused BC stages with their class map) -- and by
+`oracle.simulate_step` from the same state on the host.  U, density and p must agree bit for bit.  One oracle step of a
+16.8 M-cell Jacobi-100 configuration is a few seconds on the GPU box's host cores.
+
+3D numbers are the DEFAULT 3D semantics (FnxGrid.ref_quirks = 0): the reference's own 3D path raises (velocityUpdate,
+setWallBcs) or carries defects Q10-Q15, so for 3D the oracle -- pinned to the reference in 2D and in quirks mode -- is the
+definition; the obstacle-adjacent 3D behaviour has no reference-side check beyond tests/test_parity_gpu.py's axis symmetry."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import PLUME_CFG, assert_bitexact, make_flags, random_state
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+DEVELOP = 30
+
+
+def _np_state(bd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in bd.items()}
+
+
+@pytest.mark.parametrize("name", ["plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_jacobi", "plume3d_slab_jacobi"])
+def test_benchmark_size_step_vs_oracle(oracle, name):
+    import bench
+    from fluidnet_cxx_amd import simulate
+    from fluidnet_cxx_amd._ext import ext
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS[name]
+    m = bench.mconf_for(w)
+    is3d = w["D"] > 1
+    if w.get("slab"):
+        # one z-slab of configs[4] the way bench.py runs it at N = 1: the C++ driver (fnx_slab_step), static flags
+        from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+        layout = SlabLayout(w["D"], 1, 0, halo=6)
+        bd = bench.plume_state_torch(w["res"], layout.D_local, dev, layout.z_offset, layout.D_global)
+        sim = NativeSlabSimulator(layout, m, comm=None, sweeps_per_exchange=6, static_flags=True, cfl_check_every=8)
+
+        def step():
+            sim.step(bd)
+    else:
+        bd = bench.build_state(w, dev)
+        ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
+        seen = []
+
+        def step():
+            simulate(m, bd, None, "jacobi", workspace=ws, static_flags=(0, 3, 7)[min(len(seen), 2)])
+            seen.append(1)
+    for _ in range(DEVELOP):
+        step()
+    torch.cuda.synchronize()
+    st = _np_state(bd)
+    umax = float(np.abs(st["U"]).max()) * float(m["dt"])
+    assert umax > 0.05, f"the state did not develop (max |U| dt = {umax})"
+    step()
+    torch.cuda.synchronize()
+    ref = oracle.simulate_step(st, m, "jacobi")
+    for k in ("U", "density", "p"):
+        assert_bitexact(bd[k].cpu().numpy(), ref[k], f"{name}: {k} after step {DEVELOP + 1} (max |U| dt = {umax:.3f})")
+
+
+@pytest.mark.parametrize("cfl", [0.5, 3.0])
+def test_tile_advection_vs_oracle_large(oracle, cfl):
+    """The 3D LDS-tile advection kernels (fnx_advect_step: z-marching tiles + fix-up launches) DIRECTLY against the oracle on a
+    64 x 128 x 200 domain with obstacles and Empty cells: CFL 0.5 (almost every cell on the in-tile path) and 3 (most cells
+    leave the tile and go through the fix-up launches)."""
+    from fluidnet_cxx_amd._ext import ext
+    dev = torch.device("cuda:0")
+    B, D, H, W = 1, 64, 128, 200
+    dt = 0.13
+    s = random_state(B, D, H, W, cfl / (dt * 4.0), seed=33, empties=True)      # ~4 sigma of the velocity is `cfl` cells
+    # a few more obstacles than make_flags' one box: bars and plates across tile and plane-chunk boundaries
+    f = s["flags"]
+    f[:, :, 20:23, 60:70, 55:130] = 2
+    f[:, :, 5:60, 30, 100:104] = 2
+    f[:, :, 40, 90:120, 10:190] = 2
+    tf, tU, trho = (torch.from_numpy(s[k]).to(dev) for k in ("flags", "U", "rho"))
+    for so in (False, True):
+        r, u = ext.advect_step(dt, trho, tU, tf, so, 0.7)
+        want_r = oracle.advect_scalar(dt, s["rho"], s["U"], f, "maccormackFluidNet", 1, so, 0.7)
+        want_u = oracle.advect_vel(dt, s["U"], s["U"], f, "maccormackFluidNet", 1, 0.7)
+        assert_bitexact(r.cpu().numpy(), want_r, f"density, CFL {cfl}, sample_outside={so}")
+        assert_bitexact(u.cpu().numpy(), want_u, f"U, CFL {cfl}, sample_outside={so}")
+
+
+def _long_state(D, H, W, seed):
+    rng = np.random.default_rng(seed)
+    nc = 3 if D > 1 else 2
+    flags = make_flags(1, D, H, W, boxes=True)
+    st = dict(flags=flags, p=np.zeros((1, 1, D, H, W), np.float32), U=np.zeros((1, nc, D, H, W), np.float32),
+              density=np.zeros((1, 1, D, H, W), np.float32))
+    UBC = np.zeros_like(st["U"]); M = np.ones_like(st["U"])
+    UBC[0, 1, :, 0:4, W // 3:2 * W // 3] = 2.0; M[:, :, :, 0:4] = 0
+    dBC = np.zeros_like(st["density"]); dM = np.ones_like(st["density"])
+    dBC[0, 0, :, 0:4, W // 3:2 * W // 3] = 0.1; dM[0, 0, :, 0:4, W // 3:2 * W // 3] = 0
+    st["U"] += (rng.standard_normal(st["U"].shape) * 0.05).astype(np.float32)
+    st.update(UBC=UBC, UBCInvMask=M, densityBC=dBC, densityBCInvMask=dM)
+    return st
+
+
+@pytest.mark.parametrize("case", [("2D 160x200", (1, 160, 200), 120, 28, 40), ("3D 40x48x56", (40, 48, 56), 60, 40, 20)])
+def test_long_simulation_stays_bit_identical(oracle, case):
+    """A shortened tools/long_parity.py: the HIP path and the oracle side by side through 120 (2D) / 60 (3D) steps of a domain
+    with obstacles and an inflow, compared bit for bit every 40 / 20 steps -- differences that only show once the flow has
+    developed (long traces, the clamp, the pressure front) have nowhere to hide."""
+    from fluidnet_cxx_amd import simulate
+    name, (D, H, W), steps, iters, every = case
+    dev = torch.device("cuda:0")
+    cfg = dict(PLUME_CFG, jacobiIter=iters, gravityVec=dict(x=0.0, y=-1.0, z=0.2 if D > 1 else 0.0))
+    st = _long_state(D, H, W, 5)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in st.items()}
+    for it in range(1, steps + 1):
+        simulate(cfg, bd, None, "jacobi")
+        st = oracle.simulate_step(st, cfg, "jacobi")
+        if it % every == 0:
+            for k in ("U", "density", "p"):
+                assert_bitexact(bd[k].cpu().numpy(), st[k], f"{name}: {k} after {it} steps")
+    assert float(np.abs(st["U"]).max()) > 0.5, "the flow did not develop"

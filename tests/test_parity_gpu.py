@@ -151,26 +151,41 @@ def test_jacobi_denormal_front(fl, dev, oracle, shape):
     assert_bitexact(N(pg), po, "jacobi through the denormal range")
 
 
-def test_jacobi_three_sweep_kernel_opt_in(oracle, tmp_path):
-    """The 3-sweep-per-pass 3D kernel (FNX_JACOBI_X3=1, off by default: it is slower, see fnx_jacobi.hip) gives the same bits
-    as the oracle; the switch is read once per process, hence the subprocess."""
-    import os as _os, subprocess, sys as _sys
-    code = (
-        "import sys, numpy as np, torch\n"
-        "sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
-        "from util import random_state\n"
-        "from fluidnet_cxx_amd import fluid as fl\n"
-        "from oracle import oracle as O\n"
-        "for (B, D, H, W, n) in ((1, 20, 21, 130, 7), (2, 9, 12, 33, 3), (1, 40, 64, 200, 10)):\n"
-        "    s = random_state(B, D, H, W, 2.0, seed=D)\n"
-        "    div = O.velocity_divergence(s['U'], s['flags'])\n"
-        "    p, _ = fl.solveLinearSystemJacobi(torch.from_numpy(s['flags']).cuda(), torch.from_numpy(div).cuda(), True, 0.0, n)\n"
-        "    po, _, _ = O.jacobi(s['flags'], div, True, 0.0, n)\n"
-        "    assert np.array_equal(p.cpu().numpy().view(np.int32), po.view(np.int32)), (B, D, H, W, n)\n"
-        "print('x3 ok')\n")
-    r = subprocess.run([_sys.executable, "-c", code], env=dict(_os.environ, FNX_JACOBI_X3="1"), capture_output=True, text=True,
-                       timeout=600, cwd=_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
-    assert r.returncode == 0 and "x3 ok" in r.stdout, r.stderr[-2000:]
+@pytest.mark.parametrize("shape,n", [((2, 1, 70, 130), 9), ((1, 12, 24, 66), 7), ((1, 1, 40, 90), 1), ((2, 6, 12, 70), 1)])
+def test_jacobi_residual_value_and_reproducibility(fl, dev, oracle, shape, n):
+    """solve_linear_system's second return value, max_b ||p_n - p_(n-1)||_2 (fluids_init.cpp:961-966): equal to the oracle's
+    within fp32 rounding of a long sum, and -- summed in a fixed order, no atomics -- the same bits on every run; asking for
+    it does not change the pressure (the last sweep runs as its own launch)."""
+    B, D, H, W = shape
+    is3d = D > 1
+    s = random_state(B, D, H, W, 2.0, seed=17)
+    div = oracle.velocity_divergence(s["U"], s["flags"])
+    po, ro, _ = oracle.jacobi(s["flags"], div, is3d, 0.0, n)
+    tf, td = T(s["flags"], dev), T(div, dev)
+    runs = [fl.solveLinearSystemJacobi(tf, td, is3d, 0.0, n) for _ in range(4)]
+    for p, r in runs:
+        assert_bitexact(N(p), po, "pressure")
+        assert float(r) == float(runs[0][1]), "the residual differs between two runs of the same solve"
+    assert abs(float(runs[0][1]) - ro) <= 2e-6 * max(ro, 1e-30), (float(runs[0][1]), ro)
+
+
+def test_jacobi_verbose_prints_every_sweep(fl, dev, oracle, capfd):
+    """verbose=True (fluids_init.cpp:968-987): one "Jacobi iteration N: residual R" line per sweep and the termination line;
+    the pressure is the non-verbose one."""
+    s = random_state(1, 1, 24, 40, 2.0, seed=4)
+    div = oracle.velocity_divergence(s["U"], s["flags"])
+    tf, td = T(s["flags"], dev), T(div, dev)
+    p0, r0 = fl.solveLinearSystemJacobi(tf, td, False, 0.0, 5)
+    capfd.readouterr()
+    p1, r1 = fl.solveLinearSystemJacobi(tf, td, False, 0.0, 5, verbose=True)
+    out = capfd.readouterr().out
+    lines = [l for l in out.splitlines() if l.startswith("Jacobi iteration")]
+    assert [int(l.split()[2].rstrip(":")) for l in lines] == [1, 2, 3, 4, 5], out
+    assert "Jacobi max iteration count (5) reached (terminating)" in out
+    assert abs(float(lines[-1].split()[-1]) - float(r1)) <= 1e-5 * float(r1)
+    assert_bitexact(N(p1), N(p0), "verbose pressure"); assert float(r0) == float(r1)
+    _, ro, _ = oracle.jacobi(s["flags"], div, False, 0.0, 5)
+    assert abs(float(r1) - ro) <= 2e-6 * ro
 
 
 def test_jacobi_tolerance_exit(fl, dev, oracle):
@@ -588,26 +603,20 @@ def test_raw_c_abi_jacobi_through_ctypes(dev, oracle):
 def test_cnn_benchmark_size(dev, oracle, tmp_path, shape):
     """The CNN at the sizes bench.py times (configs[1] 1024^2, configs[3] 256^3): the launch geometries there (tile
     counts, 8-wave Winograd workgroups, multi-GiB ping-pong buffers) are otherwise only timed.
-      (1) the whole field of the Winograd path against the direct implicit-GEMM MFMA kernels (FNX_CONV_WINO=0, a separate
-          process: the switch is read once) -- two independent kernel families, 1e-5 of |ref|max;
+      (1) the whole field of the Winograd path against the direct implicit-GEMM MFMA kernels (precision_mode "fp32_direct")
+          -- two independent kernel families, 1e-5 of |ref|max;
       (2) the oracle on crops: MultiScaleNet is local (receptive field < 48 cells at full resolution) and its resampling
           grids align for offsets that are multiples of 4, so the oracle on a crop must agree with the full-field result
           away from the crop's artificial edges -- domain corners / edges (true zero padding) and the interior."""
-    import subprocess
-    import sys as _sys
-    import os as _os
     from cnn_forward_helper import forward, make_input
     D, H, W = shape
     is3d = D > 1
     x = make_input(D, H, W, seed=5)
     got = forward(x)
     assert np.isfinite(got).all()
-    out = tmp_path / "direct.npy"
-    env = dict(_os.environ, FNX_CONV_WINO="0")
-    subprocess.run([_sys.executable, _os.path.join(_os.path.dirname(__file__), "cnn_forward_helper.py"), str(D), str(H), str(W), "5",
-                    str(out)], check=True, env=env, timeout=900)
-    direct = np.load(out)
-    assert not np.array_equal(got, direct), "FNX_CONV_WINO=0 did not select another kernel"
+    direct = forward(x, precision_mode="fp32_direct")
+    torch.cuda.empty_cache()
+    assert not np.array_equal(got, direct), "precision_mode='fp32_direct' did not select another kernel"
     assert_close_rel(got, direct, 1e-5, f"Winograd vs direct MFMA conv at {shape}")
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     blob = oracle.pack_weights(make_scalenet_weights(0, ndim=3 if is3d else 2), 3 if is3d else 2)
@@ -932,7 +941,8 @@ def test_profile_hooks(fl, ext, dev):
     torch.cuda.synchronize()
     ms, n = ext.profile_read(0)
     ext.profile_enable(False)
-    assert n == 2 and 0 < ms < 50, (ms, n)        # 12 sweeps = launches of 7 + 5 on a small grid (workgroup tiles)
+    # 12 sweeps with the residual wanted = launches of 7 + 4 on a small grid (workgroup tiles) + the last sweep on its own
+    assert n == 3 and 0 < ms < 50, (ms, n)
 
 
 def test_standalone_cpp_host_on_the_c_abi(dev):

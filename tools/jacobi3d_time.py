@@ -1,4 +1,4 @@
-"""GPU experiment: time of one 3D Jacobi solve (us per 2-sweep pass) for a grid, under the current FNX_JACOBI_* switches.
+"""GPU experiment: time of one 3D Jacobi solve (us per 2-sweep pass) for a grid.
    python tools/jacobi3d_time.py D H W [iters]"""
 import sys
 import torch
