@@ -42,14 +42,20 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
     p, U, flags = batch_dict["p"], batch_dict["U"], batch_dict["flags"]
     has_density = "density" in batch_dict
 
-    simple = (viscosity == 0 and gravityScale == 0 and not mconf.get("correctScalar", False)
-              and "flags_stick" not in batch_dict and not output_div
-              and not ("periodic-x" in mconf and "periodic-y" in mconf)
-              # no 'density' key but a density BC: the reference applies setConstVals to its zeros (simulate.py:82-97)
+    is3D = U.size(1) == 3
+    # the optional stages (viscosity, gravityScale, correctScalar, the periodic patches, flags_stick) are branches of the
+    # native step (FnxStepParams / FnxState); what stays on the operator path: output_div (a training-time early return),
+    # the stages the reference only has in 2D asked for in 3D (they raise there, as the operators do), and
+    # no 'density' key but a density BC: the reference applies setConstVals to its zeros (simulate.py:82-97)
+    simple = (not output_div and not (is3D and (viscosity > 0 or "flags_stick" in batch_dict))
               and (has_density or not ("densityBC" in batch_dict and "densityBCInvMask" in batch_dict)))
     if fused and simple:
+        periodic = 0
+        if "periodic-x" in mconf and "periodic-y" in mconf:                     # simulate.py:121, :157
+            periodic = 1 | (2 if mconf["periodic-x"] else 0) | (4 if mconf["periodic-y"] else 0)
+        want_gvec = has_density and (buoyancyScale > 0 or gravityScale > 0)
         # gravityVec is only read when buoyancy is applied (simulate.py:99-105)
-        gvec = _gravity(mconf, 1.0)[0] if (has_density and buoyancyScale > 0) else [0.0, 0.0, 0.0]
+        gvec = _gravity(mconf, 1.0)[0] if want_gvec else [0.0, 0.0, 0.0]
         density = batch_dict["density"] if has_density else None
         packed = net.packed_for(U.device) if (sim_method == "convnet") else None
         ext.simulate_step_(p, U, flags, density, batch_dict.get("UBC"), batch_dict.get("UBCInvMask"),
@@ -58,7 +64,10 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
                            float(mconf.get("operatingDensity", 0.0)), float(mconf.get("pTol", 0.0)),
                            int(mconf.get("jacobiIter", 1)), sim_method,
                            float(mconf.get("normalizeInputThreshold", 1e-5)), workspace, int(static_flags), geom,
-                           getattr(net, "precision_mode", "fp32") if sim_method == "convnet" else "fp32")
+                           getattr(net, "precision_mode", "fp32") if sim_method == "convnet" else "fp32",
+                           float(viscosity), float(gravityScale) if gravityScale > 0 else 0.0,
+                           bool(mconf.get("correctScalar", False)) and has_density, periodic,
+                           batch_dict.get("flags_stick") if sim_method == "convnet" else None)
         if not has_density:
             batch_dict["density"] = torch.zeros_like(flags)     # simulate.py:82-83
         return

@@ -194,6 +194,15 @@ void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt
   check_status(fnx_add_gravity(&g, U.data_ptr<float>(), flags.data_ptr<float>(), gv, (float)dt, cur_stream(U)));
 }
 
+// correctScalar (cpp/advection.py:9-12), in place on src
+void correct_scalar_(double dt, Tensor src, Tensor div, Tensor flags) {
+  check_field(src, "src");
+  FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
+  check_scalar(src, g, "src"); check_scalar(div, g, "div");
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_correct_scalar(&g, (float)dt, src.data_ptr<float>(), div.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(src)));
+}
+
 void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, nullptr);
@@ -365,10 +374,12 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
                     double maccormack_strength, bool sample_outside_fluid, double buoyancy_scale,
                     std::vector<double> gravity_vec, double operating_density, double p_tol, int jacobi_iter,
                     const std::string method, double normalize_threshold, c10::optional<Tensor> workspace,
-                    int static_flags, const Geom* geom, const std::string& precision_mode) {
+                    int static_flags, const Geom* geom, const std::string& precision_mode, double viscosity,
+                    double gravity_scale, bool correct_scalar, int periodic, c10::optional<Tensor> flags_stick) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
+  TORCH_CHECK(viscosity >= 0, "Viscosity must be positive");
   TORCH_CHECK(method == "jacobi" || method == "convnet", "Simulation method not supported. Choose either convnet or jacobi.");
   TORCH_CHECK(gravity_vec.size() == 3, "gravityVec needs x, y, z");
   FnxStepParams prm{};
@@ -378,6 +389,8 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   prm.operating_density = (float)operating_density; prm.p_tol = (float)p_tol; prm.jacobi_iter = jacobi_iter;
   prm.method = method == "convnet" ? 1 : 0; prm.normalize_threshold = (float)normalize_threshold;
   prm.precision_mode = precision_of(precision_mode);
+  prm.viscosity = (float)viscosity; prm.gravity_scale = (float)gravity_scale; prm.correct_scalar = correct_scalar ? 1 : 0;
+  prm.periodic = periodic;
   auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> float* {
     if (!t.has_value() || !t->defined()) return nullptr;
     if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
@@ -389,6 +402,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
   st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
   st.net = (net.has_value() && net->defined()) ? net->data_ptr() : nullptr;
+  st.flags_stick = opt(flags_stick, false, "flags_stick");
   c10::hip::HIPGuard guard(flags.get_device());
   const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_STEP);
   Tensor ws;
@@ -648,6 +662,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("velocity_update_", &velocity_update_, py::arg("pressure"), py::arg("U"), py::arg("flags"), GEOM, NoGil());
   m.def("add_buoyancy_", &add_buoyancy_, py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("gravity"),
         py::arg("rho_star"), py::arg("dt"), GEOM, NoGil());
+  m.def("correct_scalar_", &correct_scalar_, py::arg("dt"), py::arg("src"), py::arg("div"), py::arg("flags"), NoGil());
   m.def("add_gravity_", &add_gravity_, py::arg("U"), py::arg("flags"), py::arg("gravity"), py::arg("dt"), GEOM, NoGil());
   m.def("add_viscosity_", &add_viscosity_, NoGil());
   m.def("set_wall_bcs_", &set_wall_bcs_, py::arg("U"), py::arg("flags"), GEOM, NoGil());
@@ -670,7 +685,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("maccormack_strength"), py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"),
         py::arg("operating_density"), py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("method"),
         py::arg("normalize_threshold"), py::arg("workspace") = py::none(), py::arg("static_flags") = 0, GEOM,
-        py::arg("precision_mode") = "fp32", NoGil());
+        py::arg("precision_mode") = "fp32", py::arg("viscosity") = 0.0, py::arg("gravity_scale") = 0.0,
+        py::arg("correct_scalar") = false, py::arg("periodic") = 0, py::arg("flags_stick") = py::none(), NoGil());
   m.def("step_workspace_bytes", &step_workspace_bytes);
   m.def("jacobi_sweeps_", &jacobi_sweeps_, py::arg("flags"), py::arg("div"), py::arg("p"), py::arg("is3D"), py::arg("nsweeps"),
         py::arg("workspace") = py::none(), py::arg("reuse_mask") = false, GEOM, py::arg("from_zero") = false, NoGil());
@@ -718,6 +734,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
   m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });
+  m.def("roctx_enable", [](bool on) { check_status(fnx_roctx_enable(on ? 1 : 0)); });
   m.def("profile_read_work", [](int tag) { double w = 0; fnx_profile_read_work(tag, &w); return w; });
   m.def("profile_read", [](int tag) { double ms = 0; int n = 0; fnx_profile_read(tag, &ms, &n); return std::make_pair(ms, n); });
 }

@@ -7,6 +7,7 @@
 #include "../../include/fluidnet_hip.h"
 #include "fnx_cnn.h"
 #include "fnx_kernels.h"
+#include <dlfcn.h>
 
 namespace {
 
@@ -92,7 +93,8 @@ size_t ws_step(const FnxGrid* g) {
   if (cnn > tail) tail = cnn;
   return al(ncell(g) * 4) /*rho2*/ + al(ncell(g) * 4 * nc) /*U2*/ + al(ncell(g) * 4) /*div*/ +
          ws_mask(g) /*Jacobi obstacle mask, kept between steps*/ +
-         al(ncell(g)) /*BC class map, kept between steps*/ + tail;
+         al(ncell(g)) /*BC class map, kept between steps*/ +
+         (g->is3D ? 0 : al(ncell(g) * 4 * nc)) /*2D: the viscous velocity that is advected (FnxStepParams.viscosity)*/ + tail;
 }
 
 }  // namespace
@@ -122,7 +124,15 @@ struct Prof {
 } g_prof;
 }  // namespace
 
+// roctx ranges around the same phases (the reference has no tracing hooks; rocprofv3 --marker-trace shows
+// them).  The marker library is resolved on request (fnx_roctx_enable), never linked: without it the ranges are no-ops.
+namespace {
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool on = false; } g_roctx;
+const char* const kProfNames[FNX_PROF_NTAGS] = {"fnx:jacobi", "fnx:conv_mfma", "fnx:advect", "fnx:stage", "fnx:conv_direct", "fnx:conv_mfma16"};
+}  // namespace
+
 void prof_begin(int tag, hipStream_t s) {
+  if (g_roctx.on) g_roctx.push(kProfNames[tag]);
   if (!g_prof.on || g_prof.n >= PROF_MAX) { if (g_prof.on) g_prof.open_idx[tag] = -1; return; }
   const int i = g_prof.n++;
   if (i >= g_prof.created) {
@@ -139,6 +149,7 @@ void prof_add_work(int tag, double amount) {
 }
 
 void prof_end(int tag, hipStream_t s) {
+  if (g_roctx.on) g_roctx.pop();
   if (!g_prof.on) return;
   const int i = g_prof.open_idx[tag];
   if (i >= 0) hipEventRecord(g_prof.ev[i][1], s);
@@ -150,6 +161,23 @@ extern "C" {
 int fnx_profile_enable(int on) {
   fnx::g_prof.on = on != 0;
   if (on) { fnx::g_prof.n = 0; for (int t = 0; t < FNX_PROF_NTAGS; ++t) { fnx::g_prof.open_idx[t] = -1; fnx::g_prof.work[t] = 0.0; } }
+  return FNX_OK;
+}
+
+int fnx_roctx_enable(int on) {
+  if (!on) { fnx::g_roctx.on = false; return FNX_OK; }
+  if (!fnx::g_roctx.push) {
+    void* h = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) return fail(FNX_EINVAL, "roctx_enable: no roctx library found (librocprofiler-sdk-roctx.so / libroctx64.so)");
+    fnx::g_roctx.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    fnx::g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!fnx::g_roctx.push || !fnx::g_roctx.pop) { fnx::g_roctx.push = nullptr; return fail(FNX_EINVAL, "roctx_enable: roctxRangePushA / roctxRangePop not found"); }
+  }
+  fnx::g_roctx.on = true;
   return FNX_OK;
 }
 
@@ -509,6 +537,14 @@ int fnx_add_gravity(const FnxGrid* g, float* U, const float* flags, const float 
   return FNX_OK;
 }
 
+int fnx_correct_scalar(const FnxGrid* g, float dt, float* src, const float* div, const float* flags, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!src || !div || !flags) return fail(FNX_EINVAL, "correct_scalar: NULL tensor");
+  fnx::launch_correct_scalar(dims(g), g->is3D, dt * 0.5f, src, div, flags, (hipStream_t)stream);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_add_viscosity(const FnxGrid* g, float dt, const float* U_in, float* U_out, const float* flags, float viscosity,
                       void* stream) {
   if (int rc = check_grid(g)) return rc;
@@ -656,17 +692,33 @@ int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxStat
     sx = gx * prm->dt; sy = gy * prm->dt; sz = gz * prm->dt;     // strength = gravity * dt, source_terms.py:45
   }
   const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  // simulate.py:107-114: addGravity(gravityVec * -gravityScale) after the buoyancy, inside the density branch
+  const bool grav = has_rho && prm->gravity_scale > 0.f;
+  float gv[3] = {0.f, 0.f, 0.f};
+  if (grav) {
+    const float ns = -prm->gravity_scale;
+    for (int a = 0; a < 3; ++a) gv[a] = (prm->gravity_vec[a] * ns) * prm->dt;       // force = gravity * dt, source_terms.py
+  }
+  // simulate.py:119-130: setWallBcs and the periodic patches in the Jacobi branch only; with 'flags_stick' the convnet branch
+  // runs setWallBcsStick between the stages and the second setConstVals, which are then the caller's (fnx_simulate_step)
+  const bool wall = prm->method == 0;
+  const bool periodic = wall && (prm->periodic & 1);
+  const bool second_bcs = !(prm->method == 1 && st->flags_stick);
   fnx::ProfScope ps(FNX_PROF_STAGE, (hipStream_t)stream);
   // 3D: the fused kernel re-derives three neighbour velocities per cell (~54 loads); staging then a plain divergence
-  // pass is faster there (measured 0.67 -> 0.59 ms at 256^3).  2D keeps the single fused pass.
-  const bool split = g->is3D != 0;
+  // pass is faster there (measured 0.67 -> 0.59 ms at 256^3).  2D keeps the single fused pass, unless the periodic patches
+  // have to go between the stages and the divergence.
+  const bool split = g->is3D != 0 || periodic;
   // split: the divergence pass reads the staged U of the +1 neighbours, so the staging pass covers one more plane
   GridDims ds = dims(g);
   if (split && div && ds.K0 + ds.KN < ds.D) ds.KN += 1;
   fnx::launch_pre_projection(ds, g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                              rbc ? st->densityBCInvMask : nullptr, st->U, st->density, (split && div) ? nullptr : div, buoy, sx, sy, sz,
-                             prm->operating_density, prm->method == 0, (hipStream_t)stream, st->bc_class);
+                             prm->operating_density, wall, (hipStream_t)stream, st->bc_class, grav ? gv : nullptr, second_bcs);
+  if (periodic)
+    fnx::launch_periodic_pre(ds, g->is3D, U_adv, ubc ? st->UBC : nullptr, ubc ? st->UBCInvMask : nullptr, st->U,
+                             (prm->periodic & 2) != 0, (prm->periodic & 4) != 0, (hipStream_t)stream);
   if (split && div) fnx::launch_divergence(dims(g), g->is3D, st->U, st->flags, div, (hipStream_t)stream);
   HIP_OK(hipGetLastError());
   return FNX_OK;
@@ -708,18 +760,37 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   float* div = (float*)c.take(n * 4);
   unsigned char* kept_mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
   unsigned char* kept_cls = (unsigned char*)c.take(n);
+  float* orig = g->is3D ? nullptr : (float*)c.take(n * 4 * nc);        // 2D: the viscous velocity (prm->viscosity > 0)
   void* tail = c.take(0);
   const size_t tail_bytes = ws_bytes > c.off ? ws_bytes - c.off : 0;
   if (!c.ok() || ws_bytes < ws_step(g)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small (%zu < %zu)", ws_bytes, ws_step(g));
   const bool has_rho = st->density != nullptr;
-  // simulate.py:75-93: advect density then velocity (both by the OLD U)
-  if (has_rho) {
+  const bool viscous = prm->viscosity > 0.f;
+  if (prm->viscosity < 0.f) return fail(FNX_EINVAL, "Viscosity must be positive");
+  if (viscous && g->is3D) return fail(FNX_EINVAL, "simulate_step: viscosity is 2D only (reference viscosity.py:5)");
+  const bool stick = prm->method == 1 && st->flags_stick != nullptr;           // simulate.py:129-130, :165-166
+  if (stick && g->is3D) return fail(FNX_EINVAL, "simulate_step: flags_stick is 2D only (set_wall_bcs_stick.py:85-86)");
+  const bool periodic = prm->method == 0 && (prm->periodic & 1);
+  // simulate.py:66-93: advect density then velocity (both by the OLD U; the velocity advected is the viscous one)
+  if (viscous) {
+    if (int rc = fnx_add_viscosity(g, prm->dt, st->U, orig, st->flags, prm->viscosity, stream)) return rc;
+    if (has_rho) {
+      if (int rc = fnx_advect_scalar(g, prm->dt, st->density, st->U, st->flags, rho2, FNX_ADVECT_MACCORMACK, 1,
+                                     prm->sample_outside_fluid, prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
+    }
+    if (int rc = fnx_advect_vel(g, prm->dt, orig, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1, prm->maccormack_strength,
+                                tail, tail_bytes, stream)) return rc;
+  } else if (has_rho) {
     // forward passes of both advections in one launch, backward/clamp passes in another (same cell functions)
     if (int rc = fnx_advect_step(g, prm->dt, st->density, st->U, st->flags, rho2, U2, prm->sample_outside_fluid,
                                  prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
   } else {                                     // simulate.py:71-83: no 'density' key in the batch
     if (int rc = fnx_advect_vel(g, prm->dt, st->U, st->U, st->flags, U2, FNX_ADVECT_MACCORMACK, 1,
                                 prm->maccormack_strength, tail, tail_bytes, stream)) return rc;
+  }
+  if (has_rho && prm->correct_scalar) {        // simulate.py:79-81: by the divergence of the OLD U (st->U is still untouched)
+    fnx::launch_divergence(dims(g), g->is3D, st->U, st->flags, div, s);
+    if (int rc = fnx_correct_scalar(g, prm->dt, rho2, div, st->flags, stream)) return rc;
   }
   // static BC arrays (static_flags bit 1): the BC stages go by the class map kept in the workspace (built once, bit 2)
   FnxState stc = *st;
@@ -729,21 +800,42 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
     stc.bc_class = kept_cls;
   }
   st = &stc;
-  // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, wall BCs, BCs, -div
+  // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, gravity, wall BCs (+ periodic patches), BCs, -div
   if (int rc = fnx_pre_projection(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream)) return rc;
   const GridDims d = dims(g);
   float* rho = has_rho ? st->density : nullptr;
+  // setWallBcsStick is out of place: st->U -> U2 (free since the staging pass) and back
+  auto stick_pass = [&]() -> int {
+    if (int rc = fnx_set_wall_bcs_stick(g, st->U, U2, st->flags, st->flags_stick, stream)) return rc;
+    HIP_OK(hipMemcpyAsync(st->U, U2, n * 4 * nc, hipMemcpyDeviceToDevice, s));
+    return FNX_OK;
+  };
   if (prm->method == 0) {
     // simulate.py:144-168
     if (int rc = jacobi_solve(g, st->flags, div, st->p, nullptr, prm->p_tol, prm->jacobi_iter, nullptr, tail, tail_bytes, kept_mask, (prm->static_flags & 1) != 0, stream, 0)) return rc;
-    return fnx_post_projection(g, st, stream);
+    if (!periodic) return fnx_post_projection(g, st, stream);
+    // simulate.py:157-164: the patches read the field as it was before setWallBcs; their source row / column (border cells,
+    // which velocityUpdate leaves alone) is saved ahead of the in-place pass.  The solve is through with the tail.
+    if (tail_bytes < fnx::periodic_save_bytes(d)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the periodic patches");
+    const bool ubc = st->UBC && st->UBCInvMask;
+    const bool px = (prm->periodic & 2) != 0, py = (prm->periodic & 4) != 0;
+    fnx::launch_periodic_post(d, g->is3D, st->U, (float*)tail, nullptr, nullptr, px, py, 0, s);
+    if (int rc = fnx_post_projection(g, st, stream)) return rc;
+    fnx::launch_periodic_post(d, g->is3D, st->U, (float*)tail, ubc ? st->UBC : nullptr, ubc ? st->UBCInvMask : nullptr, px, py, 1, s);
+    HIP_OK(hipGetLastError());
+    return FNX_OK;
   } else {
+    if (stick) {                                // simulate.py:129-133: setWallBcsStick, then the second setConstVals
+      if (int rc = stick_pass()) return rc;
+      if (int rc = fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream)) return rc;
+    }
     // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),
     // so the concatenation is not materialised: U is projected in place.
     if (tail_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the CNN");
     if (prm->precision_mode != FNX_PRECISION_FP32 && prm->precision_mode != FNX_PRECISION_FP32_DIRECT)
       return fail(FNX_EINVAL, "simulate_step: unknown precision_mode %d", prm->precision_mode);
     if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, prm->precision_mode, st->p, st->U, tail, stream)) return rc;
+    if (stick) { if (int rc = stick_pass()) return rc; }                        // simulate.py:165-166
   }
   fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
   HIP_OK(hipGetLastError());

@@ -167,7 +167,15 @@ __device__ __forceinline__ float interpol_with_fluid(const GridDims& g, const Fi
 
 // ---------------------------------------------------------------------------------------------------
 // Line trace, cpp/calc_line_trace.cpp:259-424 -- one ray per thread, bounded loops.
+// The reference's AT_ASSERTM sanity checks of the march (:185-190, :346, :365, :391) are device asserts in a debug build
+// (FNX_EXTRA_HIPCC_FLAGS=-DFNX_DEBUG_ASSERTS python -m fluidnet_cxx_amd.build --force); the release build has none.
 // ---------------------------------------------------------------------------------------------------
+#ifdef FNX_DEBUG_ASSERTS
+#include <cassert>
+#define FNX_DASSERT(cond, msg) assert((cond) && msg)
+#else
+#define FNX_DASSERT(cond, msg) ((void)0)
+#endif
 __device__ __forceinline__ bool out_of_domain(const GridDims& g, const float p[3]) {   // :16-27
   return (p[0] <= 0.f) | (p[0] >= (float)g.W) | (p[1] <= 0.f) | (p[1] >= (float)g.H) | (p[2] <= 0.f) | (p[2] >= (float)g.Dglob);
 }
@@ -228,6 +236,7 @@ __device__ inline void line_trace(const GridDims& g, const Field& flags, const f
     for (int c = 0; c < 3; ++c) next[c] = out[c] + dir[c] * step;
     if (out_of_domain(g, next)) {
       // Case 1: calcRayBorderIntersection from the ORIGINAL pos (:327, :175-257)
+      FNX_DASSERT(!out_of_domain(g, pos), "Error: source location is already outside the domain!");             // :185-186
       float min_step = INFINITY, ipos[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -251,11 +260,13 @@ __device__ inline void line_trace(const GridDims& g, const Field& flags, const f
 #pragma unroll
         for (int c = 0; c < 3; ++c) ipos[c] = fminf(fmaxf(next[c], FNX_HIT_MARGIN), size[c] - FNX_HIT_MARGIN);
       }
+      FNX_DASSERT(!out_of_domain(g, ipos), "Error: case 1 exited bounds!");                                      // :346
       if (!blocked_cell(g, flags, ipos)) { out[0] = ipos[0]; out[1] = ipos[1]; out[2] = ipos[2]; return; }
       next[0] = ipos[0]; next[1] = ipos[1]; next[2] = ipos[2];
     }
     if (blocked_cell(g, flags, next)) {
       // Case 2 (:362-411): back off to the blocker's face, at most 4 times
+      FNX_DASSERT(!blocked_cell(g, flags, out), "Error: Ray source is already in a blocked cell!");              // :365
       bool cont = true;
       for (int count = 0; count <= 4; ++count) {
         if (!blocked_cell(g, flags, next)) break;
@@ -263,6 +274,7 @@ __device__ inline void line_trace(const GridDims& g, const Field& flags, const f
         float ctr[3], ipos[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) ctr[c] = (float)(int)next[c] + 0.5f;
+        FNX_DASSERT(!out_of_domain(g, ctr), "Error: Center of blocker cell is out of the domain!");              // :391
         if (!ray_box(out, dir, ctr, ipos)) { cont = false; break; }
         next[0] = ipos[0]; next[1] = ipos[1]; next[2] = ipos[2];
       }

@@ -41,6 +41,8 @@ void launch_divergence(const GridDims& g, bool is3d, const float* U, const float
 void launch_velocity_update(const GridDims& g, bool is3d, const float* p, float* U, const float* flags, hipStream_t s);
 void launch_add_gravity(const GridDims& g, bool is3d, float* U, const float* flags, float fx, float fy, float fz,
                         hipStream_t s);
+void launch_correct_scalar(const GridDims& g, bool is3d, float half_dt, float* src, const float* div, const float* flags,
+                           hipStream_t s);
 void launch_add_viscosity(const GridDims& g, const float* Uin, float* Uout, const float* flags, float coef,
                           hipStream_t s);
 void launch_add_buoyancy(const GridDims& g, bool is3d, bool quirks, float* U, const float* flags, const float* rho,
@@ -64,7 +66,15 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
                            float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s,
-                           const unsigned char* cls = nullptr);
+                           const unsigned char* cls = nullptr, const float* gravity = nullptr, bool second_bcs = true);
+// gravity: 3 host floats (gravity * dt) or null; second_bcs = false leaves out the setConstVals of simulate.py:133
+// periodic patches of the Jacobi branch (simulate.py:121-128, :157-164); `save`: periodic_save_bytes(g), mode 0 = save the
+// source row / column before the post-projection pass, 1 = write the destinations after it
+void launch_periodic_pre(const GridDims& g, bool is3d, const float* U_adv, const float* UBC, const float* UBCInvMask, float* U,
+                         bool px, bool py, hipStream_t s);
+size_t periodic_save_bytes(const GridDims& g);
+void launch_periodic_post(const GridDims& g, bool is3d, float* U, float* save, const float* UBC, const float* UBCInvMask,
+                          bool px, bool py, int mode, hipStream_t s);
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
                             const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
                             hipStream_t s, const unsigned char* cls = nullptr);

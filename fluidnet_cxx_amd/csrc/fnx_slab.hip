@@ -565,6 +565,8 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   if (!st->p || !st->U || !st->flags || !st->density) return fnx::set_error(FNX_EINVAL, "slab_step: the z-slab driver needs p, U, flags and a density field");
   if (prm->method != 0) return fnx::set_error(FNX_EINVAL, "slab_step: only the Jacobi projection shards (the CNN configurations are single-GPU)");
   if (prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
+  if (prm->viscosity != 0.f || prm->gravity_scale != 0.f || prm->correct_scalar || prm->periodic)
+    return fnx::set_error(FNX_EINVAL, "slab_step: the optional stages (viscosity, gravityScale, correctScalar, periodic) are single-domain only");
   Work W;
   if (!ws || carve(s, ws, &W) > ws_bytes) return fnx::set_error(FNX_EWORKSPACE, "slab_step: workspace too small (%zu < %zu)", ws_bytes, carve(s, nullptr, nullptr));
   hipStream_t stream = (hipStream_t)vstream;

@@ -128,6 +128,22 @@ __global__ __launch_bounds__(BX* BY) void add_gravity_kernel(GridDims g, float* 
   }
 }
 
+// correctScalar, lib/fluid/cpp/advection.py:9-12: src += (dt*0.5) * src * div on fluid cells (left to right: the scalar
+// times src, times div, added to src)
+template <bool IS3D>
+__global__ __launch_bounds__(BX* BY) void correct_scalar_kernel(GridDims g, float half_dt, float* __restrict__ src,
+                                                                const float* __restrict__ div,
+                                                                const float* __restrict__ flags) {
+  const CellId c = cell_id<IS3D>(g);
+  if (!c.valid) return;
+  const size_t o = (size_t)c.b * g.DHW + (size_t)c.k * g.HW + c.j * g.W + c.i;
+  if (flags[o] != FNX_FLUID) return;
+  const float x = src[o];
+  const float t = half_dt * x;
+  const float u = t * div[o];
+  src[o] = x + u;
+}
+
 // addViscosity (2D), lib/fluid/viscosity.py:57-70: out = m * (u + coef * (u[i+1] + u[j+1] + u[i-1] + u[i-1,j-1] - 4u)),
 // border cells copied; the fourth neighbour is the reference's (i-1, j-1).
 __global__ __launch_bounds__(BX* BY) void add_viscosity_kernel(GridDims g, const float* __restrict__ Uin,
@@ -413,6 +429,12 @@ void launch_add_gravity(const GridDims& g, bool is3d, float* U, const float* fla
                         hipStream_t s) {
   if (is3d) add_gravity_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, fx, fy, fz);
   else add_gravity_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, U, flags, fx, fy, fz);
+}
+
+void launch_correct_scalar(const GridDims& g, bool is3d, float half_dt, float* src, const float* div, const float* flags,
+                           hipStream_t s) {
+  if (is3d) correct_scalar_kernel<true><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, half_dt, src, div, flags);
+  else correct_scalar_kernel<false><<<cell_grid(g), dim3(BX, BY), 0, s>>>(g, half_dt, src, div, flags);
 }
 
 void launch_add_viscosity(const GridDims& g, const float* Uin, float* Uout, const float* flags, float coef,

@@ -27,7 +27,15 @@ struct StepPtrs {
   const float* rhoBC; const float* rhoBCInvMask;     // may be null
   float* U; float* rho; float* div;
   const unsigned char* cls;                          // optional BC class map (bit 0: velocity BCs are x*1+0, bit 1: density)
+  int grav; float gx, gy, gz;                        // addGravity after the buoyancy (simulate.py:107-114); strengths = gravity * dt
+  int bc2;                                           // 0: leave out the second setConstVals (simulate.py:133) -- the caller runs
+                                                     // setWallBcsStick between the two (simulate.py:129-133)
 };
+
+// addGravity's condition for one component of a non-border cell (source_terms.py:122-219; add_gravity_kernel)
+__device__ __forceinline__ bool gravity_applies(float fc, float fm) {
+  return (fc == FNX_FLUID || fc == FNX_EMPTY) && (fm == FNX_FLUID || (fm == FNX_EMPTY && fc == FNX_FLUID));
+}
 
 // The 3D staging pass as straight-line code: every load of a cell -- its three advected velocity components, the density
 // and the flags of the cell and of its three -1 neighbours, and, unless the whole wave is in identity BC cells, the BC
@@ -76,6 +84,7 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
   // ---- the stage sequence, per component
   const bool border = is_border<true>(g, i, j, k);
   const float sa[3] = { sx, sy, sz };
+  const float ga[3] = { P.gx, P.gy, P.gz };
   float un[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -87,18 +96,19 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
       if (a == 2 && QUIRKS) v = v + sa[a] * (0.5f * (q0 + (k + g.zoff <= 1 ? 0.f : q1)));
       else v = v + sa[a] * ((0.5f * (q0 + q1)) - rho_star);
     }
+    if (P.grav && has_rho && !border && gravity_applies(fc, fm[a])) v = v + ga[a];          // source_terms.py:122-219
     if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {                                        // set_wall_bcs.py:45-84
       if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
         if (fm[a] == FNX_OBST || (fc == FNX_OBST && fm[a] == FNX_FLUID)) v = 0.f;
       }
     }
-    if (ubc) { const float t = v * um[a]; v = t + uc[a]; }                                   // simulate.py:133
+    if (ubc && P.bc2) { const float t = v * um[a]; v = t + uc[a]; }                          // simulate.py:133
     un[a] = v;
   }
   float rnew = r0;
   if (has_rho && rbc) {
     float t = rnew * rm0; rnew = t + rc0;       // simulate.py:96
-    t = rnew * rm0; rnew = t + rc0;             // simulate.py:133
+    if (P.bc2) { t = rnew * rm0; rnew = t + rc0; }   // simulate.py:133
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) P.U[((size_t)b * 3 + a) * g.DHW + o] = un[a];
@@ -113,16 +123,17 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
 template <bool WALL>
 __device__ __forceinline__ float stage_eval2d(int a, float u, bool ubc, float um, float uc, float fc, float fm, bool border,
                                               bool buoy, float r0, float r1, bool rbc, float rm0, float rc0, float rm1,
-                                              float rc1, float s_a, float rho_star) {
+                                              float rc1, float s_a, float rho_star, bool grav, float g_a, bool bc2) {
   if (ubc) { const float t = u * um; u = t + uc; }                                           // simulate.py:96
   if (buoy && !border && fc == FNX_FLUID && fm == FNX_FLUID) {                               // source_terms.py
     if (rbc) { float t = r0 * rm0; r0 = t + rc0; t = r1 * rm1; r1 = t + rc1; }
     u = u + s_a * ((0.5f * (r0 + r1)) - rho_star);
   }
+  if (grav && !border && gravity_applies(fc, fm)) u = u + g_a;                               // source_terms.py:122-219
   if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {                                         // set_wall_bcs.py:45-84
     if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
   }
-  if (ubc) { const float t = u * um; u = t + uc; }                                           // simulate.py:133
+  if (ubc && bc2) { const float t = u * um; u = t + uc; }                                    // simulate.py:133
   (void)a;
   return u;
 }
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(BX* BY) void stage2d_div_kernel(GridDims g, StepPtr
   const size_t o = (size_t)j * g.W + i, os = (size_t)b * g.DHW + o;
   const bool has_rho = P.rho_adv != nullptr, ubc = P.UBC != nullptr, rbc = P.rhoBC != nullptr && has_rho;
   const bool buoy = buoy_ != 0 && has_rho;
+  const bool grav = P.grav != 0 && has_rho, bc2 = P.bc2 != 0;
   // neighbour offsets; 0 where the neighbour does not exist (a missing -1 neighbour counts as the cell's own type; the
   // +1 values of a border cell are never used)
   const int xm = i > 0 ? 1 : 0, ym = j > 0 ? g.W : 0, xp = i < g.W - 1 ? 1 : 0, yp = j < g.H - 1 ? g.W : 0;
@@ -166,17 +178,17 @@ __global__ __launch_bounds__(BX* BY) void stage2d_div_kernel(GridDims g, StepPtr
   }
   // ---- the four staged values
   const bool border = is_border<false>(g, i, j, 0);
-  const float v0 = stage_eval2d<WALL>(0, u0, ubc, m0, c0, F00, Fm0, border, buoy, R00, Rm0, rbc, rm00, rc00, rmm0, rcm0, sx, rho_star);
-  const float v1 = stage_eval2d<WALL>(1, u1, ubc, m1, c1, F00, F0m, border, buoy, R00, R0m, rbc, rm00, rc00, rm0m, rc0m, sy, rho_star);
+  const float v0 = stage_eval2d<WALL>(0, u0, ubc, m0, c0, F00, Fm0, border, buoy, R00, Rm0, rbc, rm00, rc00, rmm0, rcm0, sx, rho_star, grav, P.gx, bc2);
+  const float v1 = stage_eval2d<WALL>(1, u1, ubc, m1, c1, F00, F0m, border, buoy, R00, R0m, rbc, rm00, rc00, rm0m, rc0m, sy, rho_star, grav, P.gy, bc2);
   float rnew = R00;
-  if (rbc) { float t = rnew * rm00; rnew = t + rc00; t = rnew * rm00; rnew = t + rc00; }    // simulate.py:96, :133
+  if (rbc) { float t = rnew * rm00; rnew = t + rc00; if (bc2) { t = rnew * rm00; rnew = t + rc00; } }    // simulate.py:96, :133
   float d = 0.f;
   if (P.div) {
     if (!border) {
       const float v0p = stage_eval2d<WALL>(0, u0p, ubc, m0p, c0p, Fp0, F00, is_border<false>(g, i + 1, j, 0), buoy, Rp0, R00, rbc,
-                                           rmp0, rcp0, rm00, rc00, sx, rho_star);
+                                           rmp0, rcp0, rm00, rc00, sx, rho_star, grav, P.gx, bc2);
       const float v1p = stage_eval2d<WALL>(1, u1p, ubc, m1p, c1p, F0p, F00, is_border<false>(g, i, j + 1, 0), buoy, R0p, R00, rbc,
-                                           rm0p, rc0p, rm00, rc00, sy, rho_star);
+                                           rm0p, rc0p, rm00, rc00, sy, rho_star, grav, P.gy, bc2);
       d = ((v0 - v0p) + v1) - v1p;
     }
     if (F00 == FNX_OBST) d = 0.f;
@@ -266,6 +278,53 @@ __global__ __launch_bounds__(256) void bc_classify_kernel(size_t n, size_t dhw, 
   }
 }
 
+// The periodic patches of the Jacobi branch (simulate.py:121-128 before the projection, :157-164 after it):
+//   U_temp = U.clone(); U = setWallBcs(U); U[:,1,:,:,1] = U_temp[:,1,:,:,W-1] (periodic-x); U[:,0,:,1] = U_temp[:,0,:,H-1]
+//   (periodic-y); then setConstVals.
+// Both sources are border cells (column W-1, row H-1).  Thread t of a (b, plane) pair handles row j = t of the x patch
+// (t < H) or column i = t - H of the y patch.
+//
+// Before the projection the value of a border cell ahead of setWallBcs is setConstVals of the advected velocity (buoyancy
+// and gravity leave border cells alone), so the patch is re-derived from the stage's inputs: src = U_adv*m + c at the source
+// cell, then the second setConstVals at the destination.
+__global__ __launch_bounds__(256) void periodic_pre_kernel(GridDims g, int nc, const float* __restrict__ U_adv,
+                                                           const float* __restrict__ UBC, const float* __restrict__ UBCInvMask,
+                                                           float* __restrict__ U, int px, int py) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int bk = blockIdx.y, b = bk / g.KN, k = g.K0 + (bk - b * g.KN);
+  if (t >= g.H + g.W) return;
+  const bool xp = t < g.H;
+  if (xp ? !px : !py) return;
+  const int a = xp ? 1 : 0;
+  const size_t base = ((size_t)b * nc + a) * g.DHW + (size_t)k * g.HW;
+  const size_t src = base + (xp ? (size_t)t * g.W + (g.W - 1) : (size_t)(g.H - 1) * g.W + (t - g.H));
+  const size_t dst = base + (xp ? (size_t)t * g.W + 1 : (size_t)g.W + (t - g.H));
+  float v = U_adv[src];
+  if (UBC) { float q = v * UBCInvMask[src]; v = q + UBC[src]; q = v * UBCInvMask[dst]; v = q + UBC[dst]; }
+  U[dst] = v;
+}
+
+// After the projection velocityUpdate leaves border cells alone, so U_temp's source row / column is what the state held
+// before the in-place post-projection pass: saved by mode 0, written (with the destination's setConstVals) by mode 1.
+__global__ __launch_bounds__(256) void periodic_post_kernel(GridDims g, int nc, float* __restrict__ U, float* __restrict__ save,
+                                                            const float* __restrict__ UBC, const float* __restrict__ UBCInvMask,
+                                                            int px, int py, int mode) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int bk = blockIdx.y, b = bk / g.KN, k = g.K0 + (bk - b * g.KN);
+  if (t >= g.H + g.W) return;
+  const bool xp = t < g.H;
+  if (xp ? !px : !py) return;
+  const int a = xp ? 1 : 0;
+  const size_t base = ((size_t)b * nc + a) * g.DHW + (size_t)k * g.HW;
+  const size_t src = base + (xp ? (size_t)t * g.W + (g.W - 1) : (size_t)(g.H - 1) * g.W + (t - g.H));
+  const size_t dst = base + (xp ? (size_t)t * g.W + 1 : (size_t)g.W + (t - g.H));
+  float* sv = save + (size_t)bk * (g.H + g.W) + t;
+  if (mode == 0) { *sv = U[src]; return; }
+  float v = *sv;
+  if (UBC) { const float q = v * UBCInvMask[dst]; v = q + UBC[dst]; }
+  U[dst] = v;
+}
+
 inline dim3 cell_grid(const GridDims& g) { return dim3((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B * g.KN); }
 
 }  // namespace
@@ -275,8 +334,10 @@ namespace fnx {
 void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const float* U_adv, const float* rho_adv,
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
-                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s, const unsigned char* cls) {
-  StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div, cls};
+                           float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s, const unsigned char* cls,
+                           const float* gravity, bool second_bcs) {
+  StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div, cls,
+             gravity ? 1 : 0, gravity ? gravity[0] : 0.f, gravity ? gravity[1] : 0.f, gravity ? gravity[2] : 0.f, second_bcs ? 1 : 0};
   const dim3 grid = cell_grid(g), block(BX, BY);
   if (!is3d) {
     if (wall_bcs) stage2d_div_kernel<true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, rho_star);
@@ -296,6 +357,20 @@ void launch_post_projection(const GridDims& g, bool is3d, const float* p, float*
   const dim3 grid = cell_grid(g), block(BX, BY);
   if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
   else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
+}
+
+void launch_periodic_pre(const GridDims& g, bool is3d, const float* U_adv, const float* UBC, const float* UBCInvMask, float* U,
+                         bool px, bool py, hipStream_t s) {
+  const dim3 grid((g.H + g.W + 255) / 256, g.B * g.KN);
+  periodic_pre_kernel<<<grid, 256, 0, s>>>(g, is3d ? 3 : 2, U_adv, UBC, UBCInvMask, U, px, py);
+}
+
+size_t periodic_save_bytes(const GridDims& g) { return (size_t)g.B * g.KN * (g.H + g.W) * sizeof(float); }
+
+void launch_periodic_post(const GridDims& g, bool is3d, float* U, float* save, const float* UBC, const float* UBCInvMask,
+                          bool px, bool py, int mode, hipStream_t s) {
+  const dim3 grid((g.H + g.W + 255) / 256, g.B * g.KN);
+  periodic_post_kernel<<<grid, 256, 0, s>>>(g, is3d ? 3 : 2, U, save, UBC, UBCInvMask, px, py, mode);
 }
 
 void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const float* UBCInvMask, const float* rhoBC,

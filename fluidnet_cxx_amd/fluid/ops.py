@@ -66,8 +66,9 @@ def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_wid
 
 def correctScalar(dt, src, div, flags):
     """cpp/advection.py:9-12 (off in all shipped configs): src += dt*0.5*src*div on fluid cells, in place."""
-    maskFluid = flags.eq(1)
-    src.copy_(torch.where(maskFluid, src + dt * 0.5 * src * div, src))
+    _check5(src, flags)
+    assert div.shape == src.shape == flags.shape, "Size mismatch"
+    ext.correct_scalar_(float(dt), src, div, flags)
 
 
 def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, verbose=False, *, geom=None):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 12
+#define FNX_ABI_VERSION 13
 
 enum {
   FNX_OK = 0,
@@ -158,6 +158,9 @@ int fnx_add_buoyancy(const FnxGrid* g, float* U, const float* flags, const float
 /* addGravity (in place on U), lib/fluid/source_terms.py:122-219.  gravity: 3 HOST floats. */
 int fnx_add_gravity(const FnxGrid* g, float* U, const float* flags, const float gravity[3], float dt, void* stream);
 
+/* correctScalar (in place on src), lib/fluid/cpp/advection.py:9-12: src += (dt * 0.5) * src * div on fluid cells. */
+int fnx_correct_scalar(const FnxGrid* g, float dt, float* src, const float* div, const float* flags, void* stream);
+
 /* addViscosity, lib/fluid/viscosity.py:7-70 (2D only, like the reference).  The reference updates U in place from
  * a fully evaluated right-hand side; here U_in is the old field and U_out (a distinct buffer) receives the result. */
 int fnx_add_viscosity(const FnxGrid* g, float dt, const float* U_in, float* U_out, const float* flags,
@@ -221,6 +224,16 @@ typedef struct FnxStepParams {
                                  bit 1: UBC / UBCInvMask / densityBC / densityBCInvMask are unchanged -> the BC stages use a
                                         1-byte-per-cell class map kept in the workspace (see FnxState.bc_class);
                                  bit 2: that class map was already built by an earlier call with bit 1 set */
+  /* Optional stages of lib/simulate.py (all off when zero; fnx_slab_step refuses them): */
+  float viscosity;            /* mconf['viscosity'] > 0 (2D only, like addViscosity): the velocity advected is
+                                 addViscosity(U.clone()), advected by U (simulate.py:66-69, :85-93) */
+  float gravity_scale;        /* mconf['gravityScale'] > 0: addGravity(gravityVec * -gravityScale) after the buoyancy, only with
+                                 a density (simulate.py:107-114) */
+  int   correct_scalar;       /* mconf['correctScalar']: density += dt/2 * density * div(U) on fluid cells after its
+                                 advection (simulate.py:79-81, cpp/advection.py:9-12) */
+  int   periodic;             /* bit 0: mconf has BOTH 'periodic-x' and 'periodic-y'; bit 1 / bit 2: their values.  Method 0
+                                 only (simulate.py:121-128, :157-164): U[:,1,:,:,1] = U_temp[:,1,:,:,W-1],
+                                 U[:,0,:,1] = U_temp[:,0,:,H-1] after each setWallBcs, U_temp the field before it */
 } FnxStepParams;
 
 typedef struct FnxState {
@@ -235,6 +248,10 @@ typedef struct FnxState {
    * of the cell, bit 1 = the same for the density.  The BC stages then skip the 8 BC loads of such a cell (32 of its 64-68
    * bytes) and apply t = x*1, t + 0 directly: same bits.  Only valid while the four BC arrays do not change. */
   const unsigned char* bc_class;
+  /* Optional (B,1,1,H,W) copy of flags with the no-slip cells set to 128 ('flags_stick' in batch_dict, cylinder.py:76), or
+   * NULL.  Method 1 (convnet), 2D only: setWallBcsStick before the second setConstVals and after the net
+   * (simulate.py:129-130, :165-166).  Method 0 ignores it, as the reference does. */
+  const float* flags_stick;
 } FnxState;
 
 /* Classifies every cell for FnxState.bc_class (reads the four BC arrays once; st->bc_class itself is ignored). */
@@ -245,8 +262,11 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
 
 /* The two fused stages of fnx_simulate_step, exposed for drivers that interleave their own work (halo exchange):
  *   pre : simulate.py:96-133 + :144  U_adv, rho_adv (advection outputs) -> st->U, st->density, div
- *         (setConstVals, addBuoyancy, setWallBcs [method 0 only], setConstVals, velocityDivergence [div != NULL])
- *   post: simulate.py:154-168        velocityUpdate(st->p), setWallBcs, setConstVals, in place on st->U / st->density */
+ *         (setConstVals, addBuoyancy, addGravity [prm->gravity_scale > 0], setWallBcs + periodic patches [method 0 only],
+ *         setConstVals [not with st->flags_stick in method 1: the caller runs setWallBcsStick first], velocityDivergence
+ *         [div != NULL])
+ *   post: simulate.py:154-168        velocityUpdate(st->p), setWallBcs, setConstVals, in place on st->U / st->density (no
+ *         periodic patches: fnx_simulate_step wraps it with them) */
 int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
                        const float* rho_adv, float* div, void* stream);
 int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream);
@@ -382,6 +402,10 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
 enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PROF_STAGE = 3, FNX_PROF_CONV_DIRECT = 4,
        FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_NTAGS = 6 };
 int fnx_profile_enable(int on);
+/* roctx ranges ("fnx:jacobi", "fnx:advect", "fnx:stage", "fnx:conv_*") around the enqueue of the same kernel classes, for
+ * `rocprofv3 --marker-trace`.  The marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is loaded by this call,
+ * not linked; off by default.  The reference has no tracing hooks. */
+int fnx_roctx_enable(int on);
 int fnx_profile_read(int tag, double* total_ms, int* launches);
 /* What the recorded launches of a class ISSUED: for the conv classes the multiply-add FLOPs actually sent to the matrix
  * cores (a Winograd F(2x2,3x3) launch issues 16/36 of the direct convolution's), so that issued / time / peak is the

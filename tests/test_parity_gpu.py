@@ -785,18 +785,73 @@ def test_rollout_batch_of_two(dev, oracle):
             assert_bitexact(N(bd[k])[b:b + 1], st[k], f"sample {b}: {k}")
 
 
-def test_sim64_optional_stages_vs_reference(dev, golden):
-    """viscosity + correctScalar + gravity + periodic patches through simulate(): bit-exact against the reference."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_sim64_optional_stages_vs_reference(dev, golden, fused):
+    """viscosity + correctScalar + gravity + periodic patches through simulate(): bit-exact against the reference, as
+    branches of the native step (fused, the default) and operator by operator."""
     from fluidnet_cxx_amd import simulate
     from util import F2_CFG
     s = golden("sim64")
     mconf = dict(PLUME_CFG, **F2_CFG)
     bd = to_dev(plume_state(64), dev)
     for it in range(1, 7):
-        simulate(mconf, bd, None, "jacobi")
+        simulate(mconf, bd, None, "jacobi", fused=fused)
         if it in (1, 3, 6):
             for k in ("U", "density", "p"):
                 assert_bitexact(N(bd[k]), s[f"f2_{k}_{it}"], f"{k} after {it} steps")
+
+
+OPTIONAL_STAGES = [("viscosity", dict(viscosity=0.02)), ("gravity", dict(gravityScale=0.5)), ("correct", dict(correctScalar=True)),
+                   ("periodic_y", {"periodic-x": False, "periodic-y": True}),          # rayleighTaylor.py:158-159
+                   ("periodic_x", {"periodic-x": True, "periodic-y": False}),
+                   ("periodic_keys_false", {"periodic-x": False, "periodic-y": False}),
+                   ("all", dict(viscosity=0.02, gravityScale=0.5, correctScalar=True, **{"periodic-x": True, "periodic-y": True}))]
+
+
+@pytest.mark.parametrize("name,extra", OPTIONAL_STAGES, ids=[c[0] for c in OPTIONAL_STAGES])
+@pytest.mark.parametrize("D", [1, 12])
+def test_fused_optional_stages_vs_oracle(dev, oracle, name, extra, D):
+    """Every optional stage of lib/simulate.py as a branch of fnx_simulate_step (FnxStepParams.viscosity / gravity_scale /
+    correct_scalar / periodic), alone and together, in 2D and 3D, with obstacles, an inflow BC and a developed flow: bit for
+    bit the oracle's step and the operator-by-operator path's."""
+    from fluidnet_cxx_amd import simulate
+    extra = dict(extra)
+    if D > 1:
+        extra.pop("viscosity", None)                        # 2D only in the reference (viscosity.py:5)
+        if not extra:
+            pytest.skip("viscosity is 2D only")
+    H, W = (40, 72) if D > 1 else (72, 136)
+    st = plume_state(W, D)
+    st = {k: np.ascontiguousarray(v[:, :, :, :H]) for k, v in st.items()}
+    st["flags"] = make_flags(1, D, H, W, boxes=True)
+    rng = np.random.default_rng(3)
+    st["U"] = (st["U"] + rng.standard_normal(st["U"].shape).astype(np.float32) * np.float32(1.5)).astype(np.float32)
+    st["density"] = rng.random(st["density"].shape).astype(np.float32)
+    mconf = dict(PLUME_CFG, jacobiIter=9, **extra)
+    bd_f, bd_u = to_dev(st, dev), to_dev(st, dev)
+    ws = torch.empty(ext_step_bytes(bd_f), dtype=torch.uint8, device=dev)
+    for it in range(3):
+        simulate(mconf, bd_f, None, "jacobi", workspace=ws, static_flags=(0 if it == 0 else (3 if it == 1 else 7)))
+        simulate(mconf, bd_u, None, "jacobi", fused=False)
+        st = oracle.simulate_step(st, mconf, "jacobi")
+        for k in ("U", "density", "p"):
+            assert_bitexact(N(bd_f[k]), st[k], f"{name} D={D}: fused {k} after step {it + 1} vs oracle")
+            assert_bitexact(N(bd_u[k]), st[k], f"{name} D={D}: operator path {k} after step {it + 1} vs oracle")
+
+
+def ext_step_bytes(bd):
+    from fluidnet_cxx_amd._ext import ext
+    f = bd["flags"]
+    return ext.step_workspace_bytes(f.size(0), f.size(2), f.size(3), f.size(4), bd["U"].size(1) == 3)
+
+
+def test_fused_optional_stages_refusals(dev):
+    from fluidnet_cxx_amd import simulate
+    bd = to_dev(plume_state(24, 8), dev)
+    with pytest.raises((RuntimeError, AssertionError), match="2D|2d"):
+        simulate(dict(PLUME_CFG, viscosity=0.1), bd, None, "jacobi")
+    with pytest.raises(AssertionError, match="Viscosity must be positive"):
+        simulate(dict(PLUME_CFG, viscosity=-0.1), to_dev(plume_state(24), dev), None, "jacobi")
 
 
 def test_set_wall_bcs_stick_vs_reference(dev, fl, ext, golden, oracle):
@@ -822,7 +877,10 @@ def test_set_wall_bcs_stick_vs_reference(dev, fl, ext, golden, oracle):
         ext.set_wall_bcs_stick_(torch.zeros(1, 3, 4, 8, 8, device=dev), f3, f3.clone())
 
 
-def test_sim64_stick_convnet_vs_reference(dev, golden):
+@pytest.mark.parametrize("fused", [True, False])
+def test_sim64_stick_convnet_vs_reference(dev, golden, fused):
+    """'flags_stick' in the batch (convnet method): setWallBcsStick before the second setConstVals and after the net, as a
+    branch of the native step (FnxState.flags_stick) and operator by operator, against the reference."""
     from fluidnet_cxx_amd import FluidNet, simulate
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     z = golden("stick")
@@ -833,7 +891,7 @@ def test_sim64_stick_convnet_vs_reference(dev, golden):
     st["flags"] = z["sim_flags"]; st["flags_stick"] = z["sim_flags_stick"]
     bd = to_dev(st, dev)
     for it in range(1, 4):
-        simulate(mconf, bd, net, "convnet")
+        simulate(mconf, bd, net, "convnet", fused=fused)
         for k in ("U", "density", "p"):
             assert_close_rel(N(bd[k]), z[f"sim_{k}_{it}"], 1e-5, f"stick convnet {k} after {it}")
 
@@ -975,3 +1033,18 @@ def test_standalone_cpp_host_on_the_c_abi(dev):
         simulate(PLUME_CFG, bd, None, "jacobi")
     for k in ("U", "density", "p"):
         assert got[k] == fnv1a(N(bd[k])), k
+
+
+def test_roctx_ranges_do_not_change_results(dev, ext, oracle):
+    """fnx_roctx_enable: ranges around the kernel classes (for rocprofv3 --marker-trace); a step with them on is the same step."""
+    from fluidnet_cxx_amd import simulate
+    st = plume_state(48)
+    bd = to_dev(st, dev)
+    ext.roctx_enable(True)
+    try:
+        simulate(PLUME_CFG, bd, None, "jacobi")
+    finally:
+        ext.roctx_enable(False)
+    st = oracle.simulate_step(st, PLUME_CFG, "jacobi")
+    for k in ("U", "density", "p"):
+        assert_bitexact(N(bd[k]), st[k], k)
