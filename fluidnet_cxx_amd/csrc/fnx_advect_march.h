@@ -43,6 +43,7 @@ constexpr int ATNW = ATR / ATRPW;    // waves per workgroup
 constexpr int ATRR = ATR + 2;        // rows held: j0-1 .. j0+8
 constexpr int ATP = 68;              // row pitch in floats: columns x0-1 .. x0+66 = 17 chunks of 16 bytes
 constexpr int ATNQ = (ATRR + 2) / 3; // DMA instructions per field-plane (3 rows each): 4
+constexpr int AFSZ_ = ATRR * ATP;    // floats per field-plane
 
 typedef __amdgpu_buffer_rsrc_t ABuf;
 typedef __attribute__((address_space(3))) void* ALds;
@@ -107,8 +108,8 @@ __device__ __forceinline__ float atrilin_fluid(const float (&c)[8], unsigned fb,
 struct ATile {
   int lane, w, x, j0, b, k_lo, k_hi, k0;
   int xs;                        // LDS column of my cell = lane + xs (the tile's first LDS column is x0 - xs)
-  unsigned voff[ATNQ];           // per-lane byte offset of "my" row + chunk inside a plane, per DMA instruction
-  bool dma_lane[ATNQ];
+  unsigned voff;                 // per-lane byte offset of "my" row + chunk inside a plane for this wave's DMA instruction
+  bool dma_lane;
   unsigned hw;
   int bx, ntx;
   // fix-up bitmap word of my 64-cell row segment in plane k, row j
@@ -138,22 +139,23 @@ __device__ __forceinline__ bool atile_setup(ATile& m, const GridDims& g, int ntx
   m.k_hi = min(m.k_lo + zchunk, g.K0 + g.KN);
   m.hw = (unsigned)g.HW;
   m.k0 = m.k_lo - 1 < 0 ? 0 : m.k_lo - 1;
-  // DMA instruction q moves held rows 3q .. 3q+2: lane l fetches the 16-byte chunk l%17 of row 3q + l/17 (51 lanes).
+  // DMA instruction q of a field-plane moves held rows 3q .. 3q+2: lane l fetches the 16-byte chunk l%17 of row 3q + l/17
+  // (51 lanes).  Wave w issues instruction q = w of EVERY field-plane (ATNQ == ATNW): one per-lane offset, one lane mask and a
+  // scalar LDS row offset per wave, no per-instruction dispatch (dealing the instructions round-robin made every wave walk
+  // all 20 slots of a plane behind per-lane compares: ~180 instructions of a ~1100-instruction step).
   // Rows are clamped into the grid; columns are not (a chunk is 4 columns): right of column W-1 it reads the next row's
   // cells (or 0 past the end of the tensor: the buffer range check) -- only border cells ever see those.  On the LEFT no
   // chunk may start before column 0: a negative offset fails the range check for the whole 16 bytes, columns 0..2
   // included, so the tiles of the first tile column hold columns 0 .. 67 (no left halo: column 0 is a border column and
   // never looks left) and every other tile holds x0-1 .. x0+66.
   m.xs = bx == 0 ? 0 : 1;
+  static_assert(ATNQ == ATNW, "one DMA instruction of a field-plane per wave");
   const int rsub = m.lane / 17, cq = m.lane - rsub * 17;
-#pragma unroll
-  for (int q = 0; q < ATNQ; ++q) {
-    const int hr = 3 * q + rsub;
-    int jr = m.j0 - 1 + hr;
-    jr = jr < 0 ? 0 : (jr > g.H - 1 ? g.H - 1 : jr);
-    m.voff[q] = (unsigned)(jr * g.W + (bx * 64 - m.xs) + 4 * cq) * 4u;
-    m.dma_lane[q] = (m.lane < 51) & (hr < ATRR);
-  }
+  const int hr = 3 * m.w + rsub;
+  int jr = m.j0 - 1 + hr;
+  jr = jr < 0 ? 0 : (jr > g.H - 1 ? g.H - 1 : jr);
+  m.voff = (unsigned)(jr * g.W + (bx * 64 - m.xs) + 4 * cq) * 4u;
+  m.dma_lane = (m.lane < 51) & (hr < ATRR);
   return true;
 }
 
@@ -166,16 +168,12 @@ __device__ __forceinline__ ABuf atile_rsrc(const ATile& m, const GridDims& g, co
   return amake_rsrc(chan + (size_t)m.k0 * g.HW, ncell * 4u);
 }
 
-// field-plane number `first` of a plane (ATRR rows) -> LDS at `dst` ([ATRR][ATP] floats); a plane's instructions are dealt
-// round-robin to the workgroup's waves
-__device__ __forceinline__ void atile_dma(const ATile& m, const ABuf& rs, float* dst, unsigned plane_bytes, int first) {
-#pragma unroll
-  for (int q = 0; q < ATNQ; ++q) {
-    if (((first * ATNQ + q) % ATNW) == m.w) {             // wave-uniform: instruction n of the plane goes to wave n mod ATNW
-      if (m.dma_lane[q])
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ALds)(dst + 3 * q * ATP), 16, m.voff[q] + plane_bytes, 0, 0, 0);
-    }
-  }
+// this wave's three rows of a field-plane (ATRR rows) -> LDS at `dst` ([ATRR][ATP] floats); call under `if (m.dma_lane)`.
+// The array's address is taken in the LDS address space before the (scalar) row offset is added: a cast of the sum would
+// carry a null-pointer test per instruction.
+typedef __attribute__((address_space(3))) float* ALdsF;
+__device__ __forceinline__ void atile_dma(const ATile& m, const ABuf& rs, float (&dst)[AFSZ_], unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ALds)((ALdsF)&dst[0] + 3 * ATP * m.w), 16, off, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -192,7 +190,7 @@ __device__ __forceinline__ void atile_dma(const ATile& m, const ABuf& rs, float*
 // stores of a step are thus never waited for before the NEXT step's wait, one step's compute later (a plain
 // __syncthreads() would fence them right away: vmcnt counts stores too).
 // ---------------------------------------------------------------------------------------------------
-constexpr int AFSZ = ATRR * ATP;                         // floats per field-plane
+constexpr int AFSZ = AFSZ_;                              // floats per field-plane
 
 #define ATILE_LDS(NF)                                                          \
   __shared__ __attribute__((aligned(16))) float ring0[NF][AFSZ];               \
@@ -224,10 +222,12 @@ __device__ __forceinline__ void atile_march(const GridDims& g, const ATile& m, c
                                             float (&ring3)[NF][AFSZ], float (&fst0)[AFSZ], float (&fst1)[AFSZ], Body body) {
   const int hr0 = ATRPW * m.w + 1, col = m.lane + m.xs;
   auto dma_plane = [&](float (&ring)[NF][AFSZ], float (&fst)[AFSZ], int k) {
-    const unsigned pb = m.planeoff(g, k);
+    const unsigned off = m.voff + m.planeoff(g, k);
+    if (m.dma_lane) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) atile_dma(m, rs[f], ring[f], pb, f);
-    atile_dma(m, rs_f, fst, pb, NF);
+      for (int f = 0; f < NF; ++f) atile_dma(m, rs[f], ring[f], off);
+      atile_dma(m, rs_f, fst, off);
+    }
   };
   unsigned FB0, FB1;
   int k = m.k_lo;
