@@ -666,16 +666,16 @@ static void tile_launch_geometry(const GridDims& g, int& ntx, int& nty, int& zch
 }
 
 static void launch_fwd_tile(const GridDims& g, bool sample_outside, float dt, const float* rho, const float* U,
-                            const float* flags, float* rho_fwd, int* cell, float* U_fwd, unsigned long long* fix_s,
+                            const float* flags, float* rho_fwd, int* cell, float* U_fwd, float* box, unsigned long long* fix_s,
                             unsigned long long* fix_v, hipStream_t s) {
   int ntx, nty, zchunk; unsigned G;
   tile_launch_geometry(g, ntx, nty, zchunk, G);
   const unsigned nfix = (unsigned)(((size_t)g.B * g.KN * g.H * ntx + 255) / 256);
   if (sample_outside) {
-    advect3d_fwd_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx, nty, zchunk);
+    advect3d_fwd_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, (float2*)box, fix_s, fix_v, ntx, nty, zchunk);
     advect3d_fwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
   } else {
-    advect3d_fwd_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx, nty, zchunk);
+    advect3d_fwd_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, (float2*)box, fix_s, fix_v, ntx, nty, zchunk);
     advect3d_fwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
   }
 }
@@ -691,11 +691,13 @@ void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, boo
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
   // 3D default semantics: the z-marching LDS tile kernels (fnx_advect_march.h); quirks mode and plane ranges beyond the
   // tile kernels' 32-bit offsets: one thread per cell
-  if (is3d && !quirks && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu)
-    launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix, fix + nwords, s);
-  else
+  // (the tile kernel also reduces the clamp bounds of the density step from the rho planes it streams)
+  if (is3d && !quirks && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu) {
+    launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, box, fix, fix + nwords, s);
+  } else {
     DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
-  if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
+    if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
+  }
   if (is3d && !quirks && (size_t)(g.KN + 2) * g.HW < 0x3fffffffu) {
     int ntx, nty, zchunk; unsigned G;
     tile_launch_geometry(g, ntx, nty, zchunk, G);

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_k
                                                                    const float* __restrict__ flags,
                                                                    float* __restrict__ rho_fwd, int* __restrict__ cell_out,
                                                                    float* __restrict__ U_fwd,
+                                                                   float2* __restrict__ box,
                                                                    unsigned long long* __restrict__ fix_s,
                                                                    unsigned long long* __restrict__ fix_v, int ntx, int nty,
                                                                    int zchunk) {
@@ -323,10 +324,59 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_k
   const int lane = m.lane, w = m.w, i = m.x, hr0 = ATRPW * w + 1, col = lane + m.xs;
   const bool xin = i < g.W;
   const float ndt = -dt;
+  // Clamp bounds of the density's MacCormack step (box_minmax_kernel's field, fnx_advect.hip) from the rho planes this
+  // kernel streams anyway: per plane the 3x3 reduction of my rows (cells that are fluid -- unless SAMPLE_OUTSIDE -- and inside
+  // the grid; a clamped halo row / plane is a duplicate of a box member, which min and max do not see), kept for the planes
+  // k-1 and k, combined with plane k+1's.  min / max are exact and order-free: the bits of the separate pass.
+  const unsigned xmask = ((i >= 1 ? 1u : 0u) | (xin ? 2u : 0u) | (i + 1 < g.W ? 4u : 0u)) * 0x249u;      // 4 rows x (dx = -1, 0, +1)
+  // A cell that is not a member enters as a NaN (all ones), which v_min / v_max skip; whether a box has a member at all is
+  // kept as bits (a member whose value is itself a NaN must still count: the end of the body restores the separate pass's
+  // +inf / -inf for a box whose members are all NaN).
+  float bxmn[2][ATRPW], bxmx[2][ATRPW]; unsigned bxan[2];
+  auto box_plane = [&](const float (&rX)[NF][AFSZ], unsigned fb, float (&omn)[ATRPW], float (&omx)[ATRPW], unsigned& oan) __attribute__((always_inline)) {
+    const unsigned fbx = (SAMPLE_OUTSIDE ? 0xfffu : fb) & xmask;
+    const int nfb = (int)~fbx;
+    float rmn[ATRPW + 2], rmx[ATRPW + 2];
+    const float* q = &rX[0][(hr0 - 1) * ATP + col - 1];
+#pragma unroll
+    for (int rr = 0; rr < ATRPW + 2; ++rr) {
+      float v[3];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        v[dx] = __int_as_float(__float_as_int(q[rr * ATP + dx]) | __builtin_amdgcn_sbfe(nfb, 3 * rr + dx, 1));   // member ? value : NaN
+      rmn[rr] = fminf(fminf(v[0], v[1]), v[2]);
+      rmx[rr] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+    }
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      omn[r] = fminf(fminf(rmn[r], rmn[r + 1]), rmn[r + 2]);
+      omx[r] = fmaxf(fmaxf(rmx[r], rmx[r + 1]), rmx[r + 2]);
+    }
+    oan = fbx | (fbx >> 1) | (fbx >> 2);                                                   // bit 3 rr: a member in row rr
+  };
 
   auto body = [&](int k, unsigned fbm, unsigned fbc, unsigned fbp, const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ],
                   const float (&rP)[NF][AFSZ], auto pre_store) __attribute__((always_inline)) {
     const int kg = k + g.zoff;
+    if (k == m.k_lo) {                                     // first step of the chunk: planes k-1 and k
+      box_plane(rM, fbm, bxmn[0], bxmx[0], bxan[0]);
+      box_plane(rC, fbc, bxmn[1], bxmx[1], bxan[1]);
+    }
+    float bpmn[ATRPW], bpmx[ATRPW]; unsigned bpan;
+    box_plane(rP, fbp, bpmn, bpmx, bpan);
+    const unsigned anyrows = bxan[0] | bxan[1] | bpan;
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      float lo = fminf(fminf(bxmn[0][r], bxmn[1][r]), bpmn[r]), hi = fmaxf(fmaxf(bxmx[0][r], bxmx[1][r]), bpmx[r]);
+      const bool any = ((anyrows >> (3 * r)) & 0x49u) != 0;
+      lo = lo != lo ? INFINITY : lo; hi = hi != hi ? -INFINITY : hi;                      // members, but every one a NaN
+      // stored right away (nothing here waits for a store before the next step's wait for its plane)
+      const int j = m.j0 + ATRPW * w + r;
+      if (xin && j < g.H) box[sb1 + (size_t)k * g.HW + (size_t)j * g.W + i] = make_float2(any ? lo : __builtin_nanf(""), hi);
+      bxmn[0][r] = bxmn[1][r]; bxmx[0][r] = bxmx[1][r];
+      bxmn[1][r] = bpmn[r]; bxmx[1][r] = bpmx[r];
+    }
+    bxan[0] = bxan[1]; bxan[1] = bpan;
     const float ctrz = (float)kg + 0.5f;
     const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
     float o_rho[ATRPW], o_u[ATRPW][3]; int o_cell[ATRPW];
