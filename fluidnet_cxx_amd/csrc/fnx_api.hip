@@ -359,7 +359,7 @@ static int jacobi_solve(const FnxGrid* g, const float* flags, const float* div, 
     // wants the residual ||p_n - p_(n-1)||, the last sweep runs on its own so that both iterates are in memory.
     const int fused = residual ? max_iter - 1 : max_iter;
     int plan[1024]; int nl = 0, left = fused;
-    const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
+    const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false, fused);
     while (left > 0 && nl < 1022) {
       const int k = left < kmax ? left : kmax;
       plan[nl++] = k; left -= k;
@@ -433,7 +433,7 @@ int fnx_jacobi_sweeps_ex(const FnxGrid* g, const float* flags, const float* div,
   unsigned char* mask = W.mask;
   const bool from_zero = (reuse_mask & 2) != 0;
   if (g->is3D && !(reuse_mask & 1)) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
-  const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false);
+  const int kmax = g->is3D ? 2 : fnx::jacobi_max_sweeps_per_launch(d, false, nsweeps);
   // ping-pong p -> tmp -> p ...; an odd number of launches ends in tmp and is copied back
   const float* in = from_zero ? nullptr : p;
   int done = 0;

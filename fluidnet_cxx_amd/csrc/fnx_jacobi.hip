@@ -117,13 +117,18 @@ __device__ __forceinline__ void wg_sweep_rows(float (&p)[V], const float (&d)[V]
   }
 }
 
-template <int K, int RW, int NW>
+// K (sweeps of the launch = halo width) is a launch argument: it only enters the tile origin, the output window and the trip
+// count.  Small grids run DEEP launches (K up to 28: a 128^2 solve of 28 sweeps is ONE launch of 256 tiles with an 8 x 8
+// output window each, one per CU, instead of four launches of 7 sweeps: the grid is launch-latency bound, the recomputed halo
+// costs idle CUs nothing).
+template <int RW, int NW>
 __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const float* __restrict__ flags,
                                                              const float* __restrict__ div, const float* __restrict__ p_in,
-                                                             float* __restrict__ p_out, int from_zero, int tiles_x) {
-  constexpr int V = RW, OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
+                                                             float* __restrict__ p_out, int from_zero, int tiles_x, int K) {
+  constexpr int V = RW;
+  const int OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
   constexpr int NI = 4;
-  static_assert(V <= 32 && OYW > 0, "tile shape");
+  static_assert(V <= 32, "tile shape");
   __shared__ float edge[2][2][NW][64];                   // [sweep parity][0: first row, 1: last row][wave][lane]
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -744,36 +749,54 @@ __global__ void residual_root_kernel(int B, const float* __restrict__ sumsq, flo
   }
 }
 
-template <int K, int RW, int NW>
+template <int RW, int NW>
 void launch_wg(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, bool from_zero,
-               hipStream_t s) {
-  constexpr int OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
+               int K, hipStream_t s) {
+  const int OX = 64 - 2 * K, OYW = NW * RW - 2 * K;
   const int tiles_x = (g.W + OX - 1) / OX, tiles_y = (g.H + OYW - 1) / OYW;
-  jacobi2d_wg_kernel<K, RW, NW><<<dim3(tiles_x * tiles_y, g.B), 64 * NW, 0, s>>>(g, flags, div, p_in, p_out, from_zero ? 1 : 0, tiles_x);
+  jacobi2d_wg_kernel<RW, NW><<<dim3(tiles_x * tiles_y, g.B), 64 * NW, 0, s>>>(g, flags, div, p_in, p_out, from_zero ? 1 : 0, tiles_x, K);
 }
 
 // Tile shape.  Measured on MI355X (bench.py, Jacobi ms per step; rows per wave x waves): 2048^2 x 100 sweeps K = 8: 8 x 8 0.450,
 // 16 x 4 0.462, 8 x 4 0.533, 16 x 8 0.539, 8 x 16 0.597; 1024^2 x 28 K = 7: 8 x 8 0.0615, 8 x 4 0.0667; 128^2 x 28 K = 8:
 // 8 x 4 0.036 (one 64 x 64 tile per CU leaves most of a small grid's CUs idle) -> 8 rows x 4 waves up to 160 Kcells, else
 // 8 rows x 8 waves.
-template <int K>
 void launch_tiles(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, bool from_zero,
-                  hipStream_t s) {
+                  int K, hipStream_t s) {
   const long cells = (long)g.W * g.H * g.B;
-  if constexpr (32 > 2 * K) {
-    if (cells <= (160l << 10)) { launch_wg<K, 8, 4>(g, flags, div, p_in, p_out, from_zero, s); return; }
-  }
-  launch_wg<K, 8, 8>(g, flags, div, p_in, p_out, from_zero, s);
+  if (K <= 8 && cells <= (160l << 10)) { launch_wg<8, 4>(g, flags, div, p_in, p_out, from_zero, K, s); return; }
+  launch_wg<8, 8>(g, flags, div, p_in, p_out, from_zero, K, s);
 }
 
 }  // namespace
 
 namespace fnx {
 
-constexpr int KMAX_2D = 8;
+constexpr int KMAX_2D = 8, KDEEP_2D = 28;
 
-int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d) {
+// 64 x 64 tiles with an output window of (64 - 2K)^2: how many a launch of K sweeps needs
+static long tiles_2d(const GridDims& g, int K) {
+  const int o = 64 - 2 * K;
+  return (long)((g.W + o - 1) / o) * ((g.H + o - 1) / o) * g.B;
+}
+
+int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d, int total) {
   if (is3d || g.D != 1) return 1;
+  // Small grids are launch-latency bound (a launch costs ~5 us + ~0.35 us per sweep whatever the halo does to the work, as
+  // long as every tile has a CU to itself): the fewest launches whose tiles all run at once, the sweeps dealt evenly.
+  if (total > KMAX_2D) {
+    static const long cus = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return (long)n;
+    }();
+    int kcap = 0;
+    for (int K = KDEEP_2D; K > KMAX_2D; --K) if (tiles_2d(g, K) <= cus) { kcap = K; break; }
+    if (kcap) {
+      const int nl = (total + kcap - 1) / kcap;
+      return (total + nl - 1) / nl;
+    }
+  }
   // a wave's chain per sweep is its 8 rows whatever K, so the halo (2K of the 64 columns and rows of a tile) is what limits K:
   // 7 where launches are still short (28 sweeps = 4 launches), else 8
   return (long)g.W * g.H * g.B <= (2l << 20) ? 7 : KMAX_2D;
@@ -782,15 +805,7 @@ int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d) {
 // 2D: nsweeps in [1, jacobi_max_sweeps_per_launch] sweeps from p_in into p_out
 void launch_jacobi(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, int nsweeps,
                    bool from_zero, hipStream_t s) {
-  switch (nsweeps) {
-    case 2: launch_tiles<2>(g, flags, div, p_in, p_out, from_zero, s); return;
-    case 3: launch_tiles<3>(g, flags, div, p_in, p_out, from_zero, s); return;
-    case 4: launch_tiles<4>(g, flags, div, p_in, p_out, from_zero, s); return;
-    case 5: launch_tiles<5>(g, flags, div, p_in, p_out, from_zero, s); return;
-    case 6: launch_tiles<6>(g, flags, div, p_in, p_out, from_zero, s); return;
-    case 7: launch_tiles<7>(g, flags, div, p_in, p_out, from_zero, s); return;
-    case 8: launch_tiles<8>(g, flags, div, p_in, p_out, from_zero, s); return;
-  }
+  if (nsweeps >= 2 && nsweeps <= KDEEP_2D) { launch_tiles(g, flags, div, p_in, p_out, from_zero, nsweeps, s); return; }
   const dim3 grid((g.W + BX - 1) / BX, (g.H + BY - 1) / BY, g.B), block(BX, BY);           // exactly one sweep
   jacobi_sweep_kernel<<<grid, block, 0, s>>>(g, flags, div, p_in, p_out, from_zero);
 }

@@ -85,7 +85,7 @@ void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const fl
 // 2D: `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is not read
 void launch_jacobi(const GridDims& g, const float* flags, const float* div, const float* p_in, float* p_out, int nsweeps,
                    bool from_zero, hipStream_t s);
-int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d);
+int  jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d, int total_sweeps);   // total_sweeps: what the solve still has to run
 // 3D: flags -> 7-bit neighbour mask (once per solve), then z-marching passes of two sweeps (one for an odd remainder)
 size_t jacobi3d_mask_bytes(const GridDims& g);   // bytes of the `mask` allocation of the 3D launches below (byte mask + the same bytes in row groups of four)
 void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, unsigned char* mask, hipStream_t s);
