@@ -108,6 +108,7 @@ __device__ __forceinline__ float atrilin_fluid(const float (&c)[8], unsigned fb,
 struct ATile {
   int lane, w, x, j0, b, k_lo, k_hi, k0;
   int xs;                        // LDS column of my cell = lane + xs (the tile's first LDS column is x0 - xs)
+  int q, fsel;                   // this wave's DMA instruction of a field-plane, and which field-planes it serves
   unsigned voff;                 // per-lane byte offset of "my" row + chunk inside a plane for this wave's DMA instruction
   bool dma_lane;
   unsigned hw;
@@ -149,9 +150,10 @@ __device__ __forceinline__ bool atile_setup(ATile& m, const GridDims& g, int ntx
   // included, so the tiles of the first tile column hold columns 0 .. 67 (no left halo: column 0 is a border column and
   // never looks left) and every other tile holds x0-1 .. x0+66.
   m.xs = bx == 0 ? 0 : 1;
-  static_assert(ATNQ == ATNW, "one DMA instruction of a field-plane per wave");
+  static_assert(ATNW % ATNQ == 0, "whole sets of DMA instructions per workgroup");
+  m.q = m.w % ATNQ; m.fsel = m.w / ATNQ;                 // (8 waves: waves 0-3 move the even field-planes, 4-7 the odd ones)
   const int rsub = m.lane / 17, cq = m.lane - rsub * 17;
-  const int hr = 3 * m.w + rsub;
+  const int hr = 3 * m.q + rsub;
   int jr = m.j0 - 1 + hr;
   jr = jr < 0 ? 0 : (jr > g.H - 1 ? g.H - 1 : jr);
   m.voff = (unsigned)(jr * g.W + (bx * 64 - m.xs) + 4 * cq) * 4u;
@@ -173,7 +175,7 @@ __device__ __forceinline__ ABuf atile_rsrc(const ATile& m, const GridDims& g, co
 // carry a null-pointer test per instruction.
 typedef __attribute__((address_space(3))) float* ALdsF;
 __device__ __forceinline__ void atile_dma(const ATile& m, const ABuf& rs, float (&dst)[AFSZ_], unsigned off) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ALds)((ALdsF)&dst[0] + 3 * ATP * m.w), 16, off, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ALds)((ALdsF)&dst[0] + 3 * ATP * m.q), 16, off, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -223,10 +225,12 @@ __device__ __forceinline__ void atile_march(const GridDims& g, const ATile& m, c
   const int hr0 = ATRPW * m.w + 1, col = m.lane + m.xs;
   auto dma_plane = [&](float (&ring)[NF][AFSZ], float (&fst)[AFSZ], int k) {
     const unsigned off = m.voff + m.planeoff(g, k);
+    constexpr int NSET = ATNW / ATNQ;
     if (m.dma_lane) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) atile_dma(m, rs[f], ring[f], off);
-      atile_dma(m, rs_f, fst, off);
+      for (int f = 0; f < NF; ++f)
+        if (NSET == 1 || f % NSET == m.fsel) atile_dma(m, rs[f], ring[f], off);
+      if (NSET == 1 || NF % NSET == m.fsel) atile_dma(m, rs_f, fst, off);
     }
   };
   unsigned FB0, FB1;

@@ -15,7 +15,8 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 wsw = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 schedule = sys.argv[3] if len(sys.argv) > 3 else "deep_first"
 D = 64 * world
-layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
+halo = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
 states = [bench.plume_state_torch(512, l.D_local, dev, l.z_offset, D) for l in layouts]
 sims = [SlabSimulator(l, m, sweeps_per_exchange=wsw, schedule=schedule, static_flags=True) for l in layouts]
 for _ in range(3): lockstep_step(sims, states)
