@@ -611,12 +611,14 @@ Tensor pre_projection_(Tensor U_adv, c10::optional<Tensor> rho_adv, Tensor p, Te
 
 void post_projection_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> density, c10::optional<Tensor> UBC,
                       c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> densityBC,
-                      c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> bc_class, const Geom* geom) {
+                      c10::optional<Tensor> densityBCInvMask, c10::optional<Tensor> bc_class, const Geom* geom,
+                      bool density_bc_applied) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(p, g, "p");
   FnxState st = make_state(g, p, U, flags, density, UBC, UBCInvMask, densityBC, densityBCInvMask);
   st.bc_class = bc_class_ptr(bc_class, flags);
+  st.density_bc_applied = density_bc_applied ? 1 : 0;
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_post_projection(&g, &st, cur_stream(U)));
 }
@@ -701,7 +703,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("jacobi_method"), py::arg("bc_class") = py::none(), GEOM, NoGil());
   m.def("post_projection_", &post_projection_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),
         py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("bc_class") = py::none(), GEOM,
-        NoGil());
+        py::arg("density_bc_applied") = false, NoGil());
   m.def("bc_classify", &bc_classify, "uint8 class map of static BC arrays (FnxState.bc_class)", NoGil());
   py::class_<PyLoopbackGroup, std::shared_ptr<PyLoopbackGroup>>(m, "SlabLoopbackGroup", "in-process communicator group: n slabs driven by n host threads")
       .def(py::init<int>(), py::arg("nranks"));

@@ -731,7 +731,7 @@ int fnx_post_projection(const FnxGrid* g, const FnxState* st, void* stream) {
   fnx::ProfScope ps(FNX_PROF_STAGE, (hipStream_t)stream);
   fnx::launch_post_projection(dims(g), g->is3D, st->p, st->U, st->density, st->flags, ubc ? st->UBC : nullptr,
                               ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
-                              rbc ? st->densityBCInvMask : nullptr, (hipStream_t)stream, st->bc_class);
+                              rbc ? st->densityBCInvMask : nullptr, (hipStream_t)stream, st->bc_class, st->density_bc_applied != 0);
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }
@@ -799,6 +799,7 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
     if (!(prm->static_flags & 4)) { if (int rc = fnx_bc_classify(g, st, kept_cls, stream)) return rc; }
     stc.bc_class = kept_cls;
   }
+  stc.density_bc_applied = 1;                  // by the pre-projection stage below, with these BC arrays
   st = &stc;
   // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, gravity, wall BCs (+ periodic patches), BCs, -div
   if (int rc = fnx_pre_projection(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream)) return rc;

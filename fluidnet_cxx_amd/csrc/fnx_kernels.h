@@ -77,7 +77,7 @@ void launch_periodic_post(const GridDims& g, bool is3d, float* U, float* save, c
                           bool px, bool py, int mode, hipStream_t s);
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
                             const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
-                            hipStream_t s, const unsigned char* cls = nullptr);
+                            hipStream_t s, const unsigned char* cls = nullptr, bool rho_bc_applied = false);
 void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                         const float* rhoBCInvMask, unsigned char* cls, hipStream_t s);
 

@@ -807,6 +807,7 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   SLAB_OK(xchg(s, fp, c1, 1, 1, stream));
   {
     const FnxGrid g = world > 1 ? grid_of(s, lo, top) : grid_of(s);
+    state.density_bc_applied = 1;            // the staging pass of this step, on the same planes, with the same BC arrays
     SLAB_OK(fnx_post_projection(&g, &state, stream));
   }
   return FNX_OK;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
                                                                  const float* __restrict__ UBCInvMask,
                                                                  const float* __restrict__ rhoBC,
                                                                  const float* __restrict__ rhoBCInvMask,
-                                                                 const unsigned char* __restrict__ cls) {
+                                                                 const unsigned char* __restrict__ cls, int rho_done) {
   const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
   const int b = IS3D ? bk / g.KN : bk, k = IS3D ? g.K0 + (bk - b * g.KN) : 0;
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
     }
     U[ou] = u;
   }
-  if (rho && rhoBC) {
+  // (rho_done: the density has been through this setConstVals before and an identity cell would get its own bits back)
+  if (rho && rhoBC && !(rho_done && (cl & 2))) {
     float m = 1.f, c = 0.f;
     if (!(cl & 2)) { m = rhoBCInvMask[os]; c = rhoBC[os]; }
     const float t = rho[os] * m; rho[os] = t + c;
@@ -353,10 +354,11 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
 
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
                             const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
-                            hipStream_t s, const unsigned char* cls) {
+                            hipStream_t s, const unsigned char* cls, bool rho_bc_applied) {
   const dim3 grid = cell_grid(g), block(BX, BY);
-  if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
-  else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls);
+  const int rd = (cls && rho_bc_applied) ? 1 : 0;
+  if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd);
+  else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd);
 }
 
 void launch_periodic_pre(const GridDims& g, bool is3d, const float* U_adv, const float* UBC, const float* UBCInvMask, float* U,

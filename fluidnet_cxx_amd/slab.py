@@ -190,8 +190,9 @@ class NativeOps:
         return self.ext.max_abs(x)
 
     def post_projection(self, st):
+        # (the staging pass of this step has applied the density BCs on the same planes: FnxState.density_bc_applied)
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
-                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st), self._geom())
+                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st), self._geom(), True)
 
 
 class SlabSimulator:

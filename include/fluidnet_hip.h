@@ -252,6 +252,11 @@ typedef struct FnxState {
    * NULL.  Method 1 (convnet), 2D only: setWallBcsStick before the second setConstVals and after the net
    * (simulate.py:129-130, :165-166).  Method 0 ignores it, as the reference does. */
   const float* flags_stick;
+  /* Optional promise to fnx_post_projection (0 = none): `density` already went through setConstVals with these BC arrays
+   * since it was last written -- fnx_pre_projection leaves it that way.  On a cell of bc_class whose density BC is the
+   * identity (x*1 + 0) a further setConstVals then changes no bit (the first one has already turned a -0 into +0), and the
+   * pass neither reads nor writes the density there (8 of the ~41 bytes a cell of that pass moves).  Ignored without bc_class. */
+  int density_bc_applied;
 } FnxState;
 
 /* Classifies every cell for FnxState.bc_class (reads the four BC arrays once; st->bc_class itself is ignored). */
