@@ -34,7 +34,8 @@ void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const 
                         hipStream_t s);
 
 // pieces of FluidNet.forward (lib/model.py:76-227)
-void launch_scale_std(const GridDims& g, int nc, const float* U, float thr, double* partial /*2*B doubles*/,
+size_t scale_std_scratch_bytes(int B);      // `partial` of launch_scale_std (fixed-order fp64 partial sums, no atomics)
+void launch_scale_std(const GridDims& g, int nc, const float* U, float thr, double* partial,
                       float* scale /*B*/, hipStream_t s);
 void launch_pack_input(const GridDims& g, int nc, const float* div, const float* flags, const float* scale, float* U,
                        float* x, hipStream_t s);

@@ -1205,7 +1205,20 @@ void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const 
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// _ScaleNet (model.py:8-23): unbiased std over C*D*H*W per sample, clamp(thr, inf)
+// _ScaleNet (model.py:8-23): unbiased std over C*D*H*W per sample, clamp(thr, inf).  Reproducible: every workgroup writes
+// its own pair of fp64 partial sums (fixed element -> thread -> wave -> workgroup order, no atomics) and one workgroup per
+// sample adds them up in index order.
+constexpr int STD_MAXB = 1024;                              // partial pairs per sample
+__device__ __forceinline__ void std_block_sum(double& s, double& ss, double (&red)[8]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[2 * wave] = s; red[2 * wave + 1] = ss; }
+  __syncthreads();
+  s = (red[0] + red[2]) + (red[4] + red[6]);
+  ss = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
 __global__ __launch_bounds__(256) void std_partial_kernel(size_t n, const float* __restrict__ U, double* __restrict__ partial) {
   const int b = blockIdx.y;
   const float* u = U + (size_t)b * n;
@@ -1214,22 +1227,23 @@ __global__ __launch_bounds__(256) void std_partial_kernel(size_t n, const float*
     const double v = u[q];
     s += v; ss += v * v;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
   __shared__ double red[8];
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[2 * wave] = s; red[2 * wave + 1] = ss; }
-  __syncthreads();
-  if (threadIdx.x == 0) {     // one atomic pair per workgroup
-    atomicAdd(&partial[2 * b], (red[0] + red[2]) + (red[4] + red[6]));
-    atomicAdd(&partial[2 * b + 1], (red[1] + red[3]) + (red[5] + red[7]));
+  std_block_sum(s, ss, red);
+  if (threadIdx.x == 0) {
+    double* o = partial + 2 * ((size_t)b * STD_MAXB + blockIdx.x);
+    o[0] = s; o[1] = ss;
   }
 }
 
-__global__ void std_finish_kernel(int B, size_t n, const double* __restrict__ partial, float thr, float* __restrict__ scale) {
-  const int b = threadIdx.x;
-  if (b < B) {
-    const double s = partial[2 * b], ss = partial[2 * b + 1];
+__global__ __launch_bounds__(256) void std_finish_kernel(int nb, size_t n, const double* __restrict__ partial, float thr,
+                                                         float* __restrict__ scale) {
+  const int b = blockIdx.x;
+  const double* pb = partial + 2 * (size_t)b * STD_MAXB;
+  double s = 0.0, ss = 0.0;
+  for (int q = threadIdx.x; q < nb; q += 256) { s += pb[2 * q]; ss += pb[2 * q + 1]; }
+  __shared__ double red[8];
+  std_block_sum(s, ss, red);
+  if (threadIdx.x == 0) {
     double var = (ss - s * s / (double)n) / (double)(n - 1);
     if (var < 0.0) var = 0.0;
     const float sd = (float)sqrt(var);
@@ -1287,14 +1301,15 @@ inline dim3 bgrid(size_t n1, int B) {
 
 }  // namespace
 
+size_t scale_std_scratch_bytes(int B) { return sizeof(double) * 2 * STD_MAXB * (size_t)B; }
+
 void launch_scale_std(const GridDims& g, int nc, const float* U, float thr, double* partial, float* scale, hipStream_t s) {
   const size_t n = (size_t)nc * g.DHW;
-  hipMemsetAsync(partial, 0, sizeof(double) * 2 * g.B, s);
-  size_t nb = (n + 256 * 16 - 1) / (256 * 16);
-  if (nb > 256) nb = 256;
+  size_t nb = (n + 256 * 8 - 1) / (256 * 8);
+  if (nb > STD_MAXB) nb = STD_MAXB;
   if (nb < 1) nb = 1;
   std_partial_kernel<<<dim3((unsigned)nb, g.B), 256, 0, s>>>(n, U, partial);
-  std_finish_kernel<<<1, 64 * ((g.B + 63) / 64), 0, s>>>(g.B, n, partial, thr, scale);
+  std_finish_kernel<<<g.B, 256, 0, s>>>((int)nb, n, partial, thr, scale);
 }
 
 void launch_pack_input(const GridDims& g, int nc, const float* div, const float* flags, const float* scale, float* U,
@@ -1313,7 +1328,7 @@ void launch_gather_input(const GridDims& g, int nc, const float* input, float* U
 size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
   const size_t full = (size_t)g.B * g.DHW;
   return multiscale_ws_bytes(g, is3d) + al256(full * 4) /*flags*/ + al256(full * 4) /*div*/ + al256(full * 2 * 4) /*x*/ +
-         al256(sizeof(double) * 2 * g.B) + al256(sizeof(float) * g.B);
+         al256(scale_std_scratch_bytes(g.B)) + al256(sizeof(float) * g.B);
 }
 
 }  // namespace fnx
@@ -1333,7 +1348,7 @@ int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, floa
   auto take = [&](size_t bytes) { void* r = w; w += (bytes + 255) & ~(size_t)255; return r; };
   float* div = (float*)take(full * 4);
   float* x = (float*)take(full * 2 * 4);
-  double* partial = (double*)take(sizeof(double) * 2 * g->B);
+  double* partial = (double*)take(scale_std_scratch_bytes(g->B));
   float* scale = (float*)take(sizeof(float) * g->B);
   void* msws = w;
   if (int rc = fnx_velocity_divergence(g, U, flags, div, stream)) return rc;     // model.py:125-126
