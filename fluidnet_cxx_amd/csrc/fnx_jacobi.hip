@@ -121,6 +121,24 @@ __device__ __forceinline__ void wg_sweep_rows(float (&p)[V], const float (&d)[V]
 // count.  Small grids run DEEP launches (K up to 28: a 128^2 solve of 28 sweeps is ONE launch of 256 tiles with an 8 x 8
 // output window each, one per CU, instead of four launches of 7 sweeps: the grid is launch-latency bound, the recomputed halo
 // costs idle CUs nothing).
+// the same, skipping row groups that lie wholly in the tile's stale rings (rows < s + 1 or > rows_total - 2 - s at sweep s)
+template <int V, int R0, int N, bool MASKED>
+__device__ __forceinline__ void wg_sweep_live(float (&p)[V], const float (&d)[V], float& carry, float top,
+                                              const unsigned (&mL)[2], const unsigned (&mR)[2], const unsigned (&mD)[2],
+                                              const unsigned (&mU)[2], const unsigned (&mC)[2], int tr0, int s, int rows_total) {
+  if constexpr (R0 < V) {
+    constexpr int M = (V - R0 >= N) ? N : (V - R0);
+    const bool stale = (tr0 + R0 + M - 1 < s + 1) | (tr0 + R0 > rows_total - 2 - s);
+    if (stale) {
+      carry = p[R0 + M - 1];                               // what the next group sees below it: this group's last row, unchanged
+    } else {
+      float delta[M];
+      jacobi_rows<V, R0, M, MASKED>(p, d, carry, mL, mR, mD, mU, mC, delta, top);
+    }
+    wg_sweep_live<V, R0 + M, N, MASKED>(p, d, carry, top, mL, mR, mD, mU, mC, tr0, s, rows_total);
+  }
+}
+
 template <int RW, int NW>
 __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const float* __restrict__ flags,
                                                              const float* __restrict__ div, const float* __restrict__ p_in,
@@ -190,11 +208,14 @@ __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const 
     __syncthreads();
     float carry = w > 0 ? e[NW * 64 + (w - 1) * 64 + lane] : 0.f;           // last row of the wave below
     const float top = w < NW - 1 ? e[(w + 1) * 64 + lane] : 0.f;            // first row of the wave above
-    if (all_plain) {
-      wg_sweep_rows<V, 0, NI, false>(p, d, carry, top, mL, mR, mD, mU, mC);
-    } else {
+    // Sweep s + 1 makes the tile's ring s stale (its neighbours are not in the tile); nothing inside the output window ever
+    // reads a stale cell, so a group of rows that lies wholly in rings 0..s is not evaluated (wave-uniform): a deep launch
+    // (K = 28) skips 40 % of its row updates, a K = 8 launch the outer groups of its first and last wave.
+    const int tr0 = w * RW;                                // first tile row of this wave
+    if (all_plain) wg_sweep_live<V, 0, NI, false>(p, d, carry, top, mL, mR, mD, mU, mC, tr0, s, NW * RW);
+    else {
       asm volatile("" : "+v"(mL[0]), "+v"(mR[0]), "+v"(mD[0]), "+v"(mU[0]), "+v"(mC[0]));
-      wg_sweep_rows<V, 0, NI, true>(p, d, carry, top, mL, mR, mD, mU, mC);
+      wg_sweep_live<V, 0, NI, true>(p, d, carry, top, mL, mR, mD, mU, mC, tr0, s, NW * RW);
     }
   }
   if (lane_ok) {
