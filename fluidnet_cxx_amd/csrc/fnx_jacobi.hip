@@ -793,7 +793,7 @@ void launch_tiles(const GridDims& g, const float* flags, const float* div, const
 
 namespace fnx {
 
-constexpr int KMAX_2D = 8, KDEEP_2D = 28;
+constexpr int KMAX_2D = 8, KLARGE_2D = 10, KDEEP_2D = 28;
 
 // 64 x 64 tiles with an output window of (64 - 2K)^2: how many a launch of K sweeps needs
 static long tiles_2d(const GridDims& g, int K) {
@@ -803,6 +803,7 @@ static long tiles_2d(const GridDims& g, int K) {
 
 int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d, int total) {
   if (is3d || g.D != 1) return 1;
+
   // Small grids are launch-latency bound (a launch costs ~5 us + ~0.35 us per sweep whatever the halo does to the work, as
   // long as every tile has a CU to itself): the fewest launches whose tiles all run at once, the sweeps dealt evenly.
   if (total > KMAX_2D) {
@@ -819,8 +820,13 @@ int jacobi_max_sweeps_per_launch(const GridDims& g, bool is3d, int total) {
     }
   }
   // a wave's chain per sweep is its 8 rows whatever K, so the halo (2K of the 64 columns and rows of a tile) is what limits K:
-  // 7 where launches are still short (28 sweeps = 4 launches), else 8
-  return (long)g.W * g.H * g.B <= (2l << 20) ? 7 : KMAX_2D;
+  // 7 where launches are still short (28 sweeps = 4 launches); on large grids at most 10, the sweeps dealt evenly over the
+  // launches (measured at 2048^2 x 100 sweeps, ms per step: 13 launches of <= 8 0.584, 12 of <= 9 0.607, 10 of 10 0.574, 9 of <= 12
+  // 0.615, 8 of <= 14 0.630)
+  if ((long)g.W * g.H * g.B <= (2l << 20)) return 7;
+  const int nl = (total + KLARGE_2D - 1) / KLARGE_2D;
+  const int k = (total + nl - 1) / nl;
+  return k < 1 ? 1 : k;
 }
 
 // 2D: nsweeps in [1, jacobi_max_sweeps_per_launch] sweeps from p_in into p_out
