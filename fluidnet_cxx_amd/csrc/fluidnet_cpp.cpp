@@ -119,18 +119,20 @@ Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::stri
 // the two advections of one step fused (fnx_advect_step): returns {density_adv, U_adv}
 std::vector<Tensor> advect_step(float dt, Tensor density, Tensor U, Tensor flags, const bool sample_outside_fluid,
                                 const float maccormack_strength, c10::optional<Tensor> out_density,
-                                c10::optional<Tensor> out_U, const Geom* geom) {
+                                c10::optional<Tensor> out_U, const Geom* geom, const std::string& plan) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(density, g, "density");
+  TORCH_CHECK(plan == "auto" || plan == "tiles" || plan == "cells", "plan must be 'auto', 'tiles' or 'cells'");
+  const int pl = plan == "tiles" ? FNX_ADVECT_PLAN_TILES : (plan == "cells" ? FNX_ADVECT_PLAN_CELLS : FNX_ADVECT_PLAN_AUTO);
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor rd = (out_density.has_value() && out_density->defined()) ? *out_density : at::empty_like(density);
   Tensor ud = (out_U.has_value() && out_U->defined()) ? *out_U : at::empty_like(U);
   check_scalar(rd, g, "out_density"); check_vel(ud, g, "out_U");
   Workspace ws(g, FNX_OP_ADVECT_STEP, U);
-  check_status(fnx_advect_step(&g, dt, density.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
-                               rd.data_ptr<float>(), ud.data_ptr<float>(), sample_outside_fluid, maccormack_strength, ws.ptr,
-                               ws.bytes, cur_stream(U)));
+  check_status(fnx_advect_step_plan(&g, dt, density.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                                    rd.data_ptr<float>(), ud.data_ptr<float>(), sample_outside_fluid, maccormack_strength, pl,
+                                    ws.ptr, ws.bytes, cur_stream(U)));
   return {rd, ud};
 }
 
@@ -654,7 +656,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("out") = py::none(), GEOM, NoGil());
   m.def("advect_step", &advect_step, py::arg("dt"), py::arg("density"), py::arg("U"), py::arg("flags"),
         py::arg("sample_outside_fluid"), py::arg("maccormack_strength"), py::arg("out_density") = py::none(),
-        py::arg("out_U") = py::none(), GEOM, NoGil());
+        py::arg("out_U") = py::none(), GEOM, py::arg("plan") = "auto", NoGil());
   m.def("advect_vel", &advect_vel, "Advect Velocity", py::arg("dt"), py::arg("orig"), py::arg("U"), py::arg("flags"),
         py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none(), GEOM, NoGil());
   m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method", py::arg("flags"),

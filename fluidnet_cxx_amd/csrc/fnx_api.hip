@@ -68,8 +68,8 @@ struct Carver {
 
 size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4) + (g->is3D ? al(ncell(g) * 8) : 0); }   // fwd, traced cell, 3D clamp bounds
 size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
-// fix-up bitmaps of the 3D tile advection kernels (fnx_advect_march.h): 4 x one 64-bit word per 64-cell row segment
-size_t ws_advect_fix(const FnxGrid* g) { return g->is3D ? al(4 * 8 * (size_t)g->B * g->D * g->H * ((g->W + 63) / 64)) : 0; }
+// fix-up bitmaps of the tile advection kernels (fnx_advect_march.h, fnx_advect_tile2d.h): 4 x one 64-bit word per 64-cell row segment
+size_t ws_advect_fix(const FnxGrid* g) { return al(4 * 8 * (size_t)g->B * g->D * g->H * ((g->W + 63) / 64)); }
 size_t ws_mask(const FnxGrid* g) { return g->is3D ? al(fnx::jacobi3d_mask_bytes(dims(g))) : 0; }   // 3D solver: neighbour-mask bytes, twice (rows / row groups)
 // Jacobi workspace: ping-pong pressure, the residual's fixed-order partial sums, one result float, the 3D neighbour mask
 size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al(fnx::residual_scratch_bytes(g->B)) + al(4) + ws_mask(g); }
@@ -283,7 +283,14 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
 int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
                     float* density_dst, float* U_dst, int sample_outside, float strength, void* ws, size_t ws_bytes,
                     void* stream) {
+  return fnx_advect_step_plan(g, dt, density, U, flags, density_dst, U_dst, sample_outside, strength, FNX_ADVECT_PLAN_AUTO, ws, ws_bytes, stream);
+}
+
+int fnx_advect_step_plan(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
+                         float* density_dst, float* U_dst, int sample_outside, float strength, int plan, void* ws,
+                         size_t ws_bytes, void* stream) {
   if (int rc = check_grid(g)) return rc;
+  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_CELLS) return fail(FNX_EINVAL, "advect_step: unknown plan %d", plan);
   if (!density || !U || !flags || !density_dst || !U_dst) return fail(FNX_EINVAL, "advect_step: NULL tensor");
   if (density_dst == density || U_dst == U) return fail(FNX_EINVAL, "advect_step: dst must not alias the inputs");
   hipStream_t s = (hipStream_t)stream;
@@ -293,12 +300,12 @@ int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const floa
   int* cell = (int*)c.take(n * 4);
   float* box = g->is3D ? (float*)c.take(n * 8) : nullptr;
   float* U_fwd = (float*)c.take(n * 4 * nc);
-  unsigned long long* fix = g->is3D ? (unsigned long long*)c.take(ws_advect_fix(g)) : nullptr;
+  unsigned long long* fix = (unsigned long long*)c.take(ws_advect_fix(g));
   if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_step: workspace too small (%zu < %zu)", ws_bytes, c.off);
   const GridDims d = dims(g);
   fnx::ProfScope ps(FNX_PROF_ADVECT, s);
   fnx::launch_advect_fused(d, widened(d, 2), g->is3D, quirks(g), sample_outside != 0, dt, strength * 0.5f, density, U, flags,
-                           rho_fwd, cell, U_fwd, box, density_dst, U_dst, fix, s);
+                           rho_fwd, cell, U_fwd, box, density_dst, U_dst, fix, s, plan);
   HIP_OK(hipGetLastError());
   return FNX_OK;
 }

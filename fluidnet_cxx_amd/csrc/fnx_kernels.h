@@ -28,7 +28,8 @@ void launch_sl_scalar_bwd_clamp(const GridDims& g, bool is3d, bool quirks, bool 
 size_t advect_fix_words(const GridDims& g);
 void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, bool sample_outside, float dt,
                          float half_s, const float* rho, const float* U, const float* flags, float* rho_fwd, int* cell,
-                         float* U_fwd, float* box, float* rho_dst, float* U_dst, unsigned long long* fix, hipStream_t s);
+                         float* U_fwd, float* box, float* rho_dst, float* U_dst, unsigned long long* fix, hipStream_t s,
+                         int plan = 0);   // plan: FNX_ADVECT_PLAN_*
 void launch_box_minmax(const GridDims& g, bool sample_outside, const float* src, const float* flags, float* box,
                        hipStream_t s);
 void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const float* src, const float* U,

@@ -93,6 +93,13 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
 int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
                     float* density_dst, float* U_dst, int sample_outside, float strength, void* ws, size_t ws_bytes,
                     void* stream);
+/* The same with the kernel family chosen by the caller instead of by grid size (same bits either way): */
+enum { FNX_ADVECT_PLAN_AUTO = 0,      /* what fnx_advect_step does: LDS tile kernels in 3D and on 2D grids of >= 1.5 M cells */
+       FNX_ADVECT_PLAN_TILES = 1,     /* LDS tile kernels + fix-up launches (CFL < 1 is their fast path, any CFL is correct) */
+       FNX_ADVECT_PLAN_CELLS = 2 };   /* one thread per cell, gathers from global memory */
+int fnx_advect_step_plan(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
+                         float* density_dst, float* U_dst, int sample_outside, float strength, int plan, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* velocityDivergence, lib/fluid/velocity_divergence.py:4-74 */
 int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags, float* div, void* stream);

@@ -769,6 +769,35 @@ def test_advect_step_equals_the_two_advections(fl, ext, dev, shape):
             assert_bitexact(N(u), N(fl.advectVelocity(0.13, tUn, tUn, tf, "maccormackFluidNet", 1, 0.7)), f"U, U sign {sign}")
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 70, 3.0), (1, 96, 200, 0.4), (1, 33, 130, 0.8), (1, 17, 64, 0.0), (2, 64, 129, 6.0), (1, 150, 67, 1.5),
+                                   (1, 16, 192, 0.6), (3, 35, 258, 1.0)])
+def test_advect2d_tile_kernels_equal_the_cell_kernels(fl, ext, dev, oracle, shape):
+    """The 2D LDS tile kernels (fnx_advect_step's plan on grids of >= 1.5 M cells, here forced: plan='tiles') == one thread
+    per cell (plan='cells') == advectScalar + advectVelocity == the oracle, bit for bit: CFL from 0 over the all-fast-path
+    range to mostly-fallback lanes, obstacles and Empty cells, one to five x tiles, partial tiles in x and y, batch 1-3, both
+    sample_outside_fluid settings, and every trace towards one corner (the chunks that hang over the tensors' ends)."""
+    B, H, W, sigma = shape
+    s = random_state(B, 1, H, W, sigma, seed=23, empties=True)
+    tf, tU, trho = T(s["flags"], dev), T(s["U"], dev), T(s["rho"], dev)
+    for so in (False, True):
+        rt, ut = ext.advect_step(0.13, trho, tU, tf, so, 0.7, plan="tiles")
+        rc, uc = ext.advect_step(0.13, trho, tU, tf, so, 0.7, plan="cells")
+        assert_bitexact(N(rt), N(rc), f"density so={so}: tiles vs cells")
+        assert_bitexact(N(ut), N(uc), f"U so={so}: tiles vs cells")
+        assert_bitexact(N(rt), N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7)), f"density so={so}")
+        assert_bitexact(N(ut), N(fl.advectVelocity(0.13, tU, tU, tf, "maccormackFluidNet", 1, 0.7)), f"U so={so}")
+        if sigma > 0:        # (sigma 0 is a field of +0 / -0: the clamp's min / max of equal zeros of either sign is the C library's choice on the CPU)
+            assert_bitexact(N(rt), oracle.advect_scalar(0.13, s["rho"], s["U"], s["flags"], "maccormackFluidNet", 1, so, 0.7), f"density so={so} vs oracle")
+    if sigma > 0:
+        assert_bitexact(N(ut), oracle.advect_vel(0.13, s["U"], s["U"], s["flags"], "maccormackFluidNet", 1, 0.7), "U vs oracle")
+    for sign in (-1.0, 1.0):
+        tUn = (tU.abs() * sign).contiguous()
+        rt, ut = ext.advect_step(0.13, trho, tUn, tf, False, 0.7, plan="tiles")
+        rc, uc = ext.advect_step(0.13, trho, tUn, tf, False, 0.7, plan="cells")
+        assert_bitexact(N(rt), N(rc), f"density, U sign {sign}")
+        assert_bitexact(N(ut), N(uc), f"U, U sign {sign}")
+
+
 def test_rollout_batch_of_two(dev, oracle):
     """Long-term loop with batch > 1 (fluid_net_train.py:349-373): every sample evolves exactly as it does alone."""
     from fluidnet_cxx_amd import rollout
