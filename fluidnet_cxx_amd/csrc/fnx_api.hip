@@ -842,8 +842,11 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
     if (tail_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the CNN");
     if (prm->precision_mode != FNX_PRECISION_FP32 && prm->precision_mode != FNX_PRECISION_FP32_DIRECT)
       return fail(FNX_EINVAL, "simulate_step: unknown precision_mode %d", prm->precision_mode);
-    if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, prm->precision_mode, st->p, st->U, tail, stream)) return rc;
-    if (stick) { if (int rc = stick_pass()) return rc; }                        // simulate.py:165-166
+    // without flags_stick the tail of the net's forward and the step's last setConstVals are one pass (fluidnet_core)
+    if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, prm->precision_mode, st->p, st->U, tail, stream,
+                                    stick ? nullptr : st)) return rc;
+    if (!stick) { HIP_OK(hipGetLastError()); return FNX_OK; }
+    if (int rc = stick_pass()) return rc;                                       // simulate.py:165-166
   }
   fnx_set_const_vals(g, st->U, st->UBC, st->UBCInvMask, rho, st->densityBC, st->densityBCInvMask, stream);
   HIP_OK(hipGetLastError());

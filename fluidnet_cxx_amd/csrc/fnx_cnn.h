@@ -45,7 +45,10 @@ void launch_gather_input(const GridDims& g, int nc, const float* input, float* U
 }  // namespace fnx
 
 struct FnxGrid;
+struct FnxState;
 namespace fnx {
+// bcs != nullptr: the fused step's form -- the last setConstVals of the step (simulate.py:168) is part of the pass behind the
+// net (bcs supplies density, the BC arrays, bc_class and density_bc_applied; p_out must not be the workspace)
 int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, int precision_mode, float* p_out, float* U,
-                  void* ws, void* stream);
+                  void* ws, void* stream, const FnxState* bcs = nullptr);
 }

@@ -1269,6 +1269,31 @@ __global__ __launch_bounds__(256) void pack_input_kernel(size_t n1, int nc, cons
   }
 }
 
+// the fused step's variant: x[b,0] = velocityDivergence(U, flags) / s (velocity_divergence.py:46-74, the divergence_kernel's
+// expression) ; x[b,1] = occupancy(flags); U is left as it is -- the pass behind the net divides and multiplies
+// (launch_post_projection with `scale`).  x fastest: i = q % W.
+template <bool IS3D>
+__global__ __launch_bounds__(256) void pack_div_kernel(GridDims g, const float* __restrict__ U, const float* __restrict__ flags,
+                                                       const float* __restrict__ scale, float* __restrict__ x) {
+  const int b = blockIdx.y;
+  const size_t n1 = (size_t)g.DHW;
+  constexpr int NC = IS3D ? 3 : 2;
+  const float s = scale[b];
+  const float* u = U + (size_t)b * NC * n1;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n1; q += (size_t)gridDim.x * 256) {
+    const int i = (int)(q % g.W), j = (int)((q / g.W) % g.H), k = (int)(q / g.HW);
+    const float f = flags[(size_t)b * n1 + q];
+    float d = 0.f;
+    if (!is_border<IS3D>(g, i, j, k)) {
+      d = ((u[q] - u[q + 1]) + u[n1 + q]) - u[n1 + q + g.W];
+      if (IS3D) d = d + (u[2 * n1 + q] - u[2 * n1 + q + g.HW]);
+    }
+    if (f == FNX_OBST) d = 0.f;
+    x[((size_t)b * 2) * n1 + q] = d / s;
+    x[((size_t)b * 2 + 1) * n1 + q] = f == FNX_FLUID ? 0.f : (f == FNX_OBST ? 1.f : f);
+  }
+}
+
 __global__ __launch_bounds__(256) void unscale_kernel(size_t n1, int nc, const float* __restrict__ scale,
                                                       float* __restrict__ p, float* __restrict__ U) {
   const int b = blockIdx.y;
@@ -1327,7 +1352,7 @@ void launch_gather_input(const GridDims& g, int nc, const float* input, float* U
 
 size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
   const size_t full = (size_t)g.B * g.DHW;
-  return multiscale_ws_bytes(g, is3d) + al256(full * 4) /*flags*/ + al256(full * 4) /*div*/ + al256(full * 2 * 4) /*x*/ +
+  return multiscale_ws_bytes(g, is3d) + al256(full * 4) /*flags*/ + al256(full * 4) /*div, or the net's p before the fused tail*/ + al256(full * 2 * 4) /*x*/ +
          al256(scale_std_scratch_bytes(g.B)) + al256(sizeof(float) * g.B);
 }
 
@@ -1339,7 +1364,7 @@ size_t fluidnet_ws_bytes(const GridDims& g, bool is3d) {
 // projected velocity on exit.  ws needs fluidnet_ws_bytes() minus the flags copy.
 namespace fnx {
 int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, float thr, int precision_mode, float* p_out, float* U,
-                  void* ws, void* stream) {
+                  void* ws, void* stream, const FnxState* bcs) {
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   hipStream_t s = (hipStream_t)stream;
   const int nc = g->is3D ? 3 : 2;
@@ -1351,6 +1376,27 @@ int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, floa
   double* partial = (double*)take(scale_std_scratch_bytes(g->B));
   float* scale = (float*)take(sizeof(float) * g->B);
   void* msws = w;
+  if (bcs) {
+    // The fused step (fnx_simulate_step, convnet, no flags_stick): three launches around the net instead of eight, the same
+    // arithmetic per value.  The divergence goes straight into the net's input, U is not rewritten before the net, and
+    // velocityUpdate, the un-normalisation, setWallBcs and the step's last setConstVals (simulate.py:168) are one pass.
+    launch_scale_std(d, nc, U, thr, partial, scale, s);                          // model.py:129-144
+    {
+      size_t blocks = ((size_t)d.DHW + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      const dim3 grid((unsigned)blocks, g->B);
+      if (g->is3D) pack_div_kernel<true><<<grid, 256, 0, s>>>(d, U, flags, scale, x);       // model.py:125-126, :146-168
+      else pack_div_kernel<false><<<grid, 256, 0, s>>>(d, U, flags, scale, x);
+    }
+    float* pnet = div;                                                           // (the divergence buffer is free here)
+    multiscale_forward(d, g->is3D, packed, x, pnet, precision_mode, msws, s);    // model.py:174-175
+    const bool ubc = bcs->UBC && bcs->UBCInvMask, rbc = bcs->densityBC && bcs->densityBCInvMask;
+    ProfScope ps(FNX_PROF_STAGE, s);
+    launch_post_projection(d, g->is3D, pnet, U, bcs->density, flags, ubc ? bcs->UBC : nullptr, ubc ? bcs->UBCInvMask : nullptr,
+                           rbc ? bcs->densityBC : nullptr, rbc ? bcs->densityBCInvMask : nullptr, s, bcs->bc_class,
+                           bcs->density_bc_applied != 0, scale, p_out);          // model.py:213-226, simulate.py:168
+    return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+  }
   if (int rc = fnx_velocity_divergence(g, U, flags, div, stream)) return rc;     // model.py:125-126
   launch_scale_std(d, nc, U, thr, partial, scale, s);                            // model.py:129-144
   launch_pack_input(d, nc, div, flags, scale, U, x, s);                          // model.py:146-168

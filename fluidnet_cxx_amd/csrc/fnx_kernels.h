@@ -78,7 +78,10 @@ void launch_periodic_post(const GridDims& g, bool is3d, float* U, float* save, c
                           bool px, bool py, int mode, hipStream_t s);
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
                             const float* UBC, const float* UBCInvMask, const float* rhoBC, const float* rhoBCInvMask,
-                            hipStream_t s, const unsigned char* cls = nullptr, bool rho_bc_applied = false);
+                            hipStream_t s, const unsigned char* cls = nullptr, bool rho_bc_applied = false,
+                            const float* scale = nullptr, float* p_scaled = nullptr);
+// scale (B device floats) / p_scaled: the tail of FluidNet.forward in the same pass (u = U / s into the update, u * s and
+// p_scaled = p * s out of it); p_scaled must not alias p (a cell reads p of its -1 neighbours)
 void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                         const float* rhoBCInvMask, unsigned char* cls, hipStream_t s);
 
