@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BX* BY) void stage2d_div_kernel(GridDims g, StepPtr
 // With `scale` (the convnet branch: model.py:213-226 then simulate.py:168) the same pass is the tail of FluidNet.forward: U holds
 // the unnormalised velocity and p the net's output for U / s, so u = U / s goes into the update, the updated u and the pressure are
 // multiplied by s again (p_scaled receives p * s), then wall BCs and BCs -- the operators' own arithmetic in their own order.
-template <bool IS3D>
+template <bool IS3D, bool SCALE>
 __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, const float* __restrict__ p,
                                                                  float* __restrict__ U, float* __restrict__ rho,
                                                                  const float* __restrict__ flags,
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
   const float fc = flags[os], P = p[os];
   const unsigned cl = cls ? cls[os] : 0u;
   const bool border = is_border<IS3D>(g, i, j, k);
-  const float sc = scale ? scale[b] : 1.f;
-  if (p_scaled) p_scaled[os] = P * sc;
+  const float sc = SCALE ? scale[b] : 1.f;
+  if (SCALE) p_scaled[os] = P * sc;
 #pragma unroll
   for (int a = 0; a < NC; ++a) {
     const size_t ou = ((size_t)b * NC + a) * g.DHW + o;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
     const int idx = a == 0 ? i : (a == 1 ? j : k);
     const float fm = idx > 0 ? flags[os - off] : fc;
     float u = U[ou];
-    if (scale) u = u / sc;                                 // model.py:129-168: the net saw U / s
+    if (SCALE) u = u / sc;                                 // model.py:129-168: the net saw U / s
     if (!border) {     // velocity_update.py:47-149
       const float Pm = p[os - off];
       const float m_ff = (fc == FNX_FLUID && fm == FNX_FLUID) ? 1.f : 0.f;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
         u = m_ff * (u - (P - Pm));
       }
     }
-    if (scale) u = u * sc;                                 // model.py:221-223
+    if (SCALE) u = u * sc;                                 // model.py:221-223
     if (fc == FNX_FLUID || fc == FNX_OBST) {
       if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
         if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
@@ -365,8 +365,14 @@ void launch_post_projection(const GridDims& g, bool is3d, const float* p, float*
                             hipStream_t s, const unsigned char* cls, bool rho_bc_applied, const float* scale, float* p_scaled) {
   const dim3 grid = cell_grid(g), block(BX, BY);
   const int rd = (cls && rho_bc_applied) ? 1 : 0;
-  if (is3d) post_projection_kernel<true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd, scale, p_scaled);
-  else post_projection_kernel<false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd, scale, p_scaled);
+  // (the scaled form is its own instantiation: as a run-time branch it cost the Jacobi step's pass 124 -> 163 us at 512x512x64)
+  if (scale && p_scaled) {
+    if (is3d) post_projection_kernel<true, true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd, scale, p_scaled);
+    else post_projection_kernel<false, true><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd, scale, p_scaled);
+  } else {
+    if (is3d) post_projection_kernel<true, false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd, nullptr, nullptr);
+    else post_projection_kernel<false, false><<<grid, block, 0, s>>>(g, p, U, rho, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, cls, rd, nullptr, nullptr);
+  }
 }
 
 void launch_periodic_pre(const GridDims& g, bool is3d, const float* U_adv, const float* UBC, const float* UBCInvMask, float* U,
