@@ -770,7 +770,7 @@ def test_advect_step_equals_the_two_advections(fl, ext, dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 70, 3.0), (1, 96, 200, 0.4), (1, 33, 130, 0.8), (1, 17, 64, 0.0), (2, 64, 129, 6.0), (1, 150, 67, 1.5),
-                                   (1, 16, 192, 0.6), (3, 35, 258, 1.0)])
+                                   (1, 16, 192, 0.6), (3, 35, 258, 1.0), (1, 1101, 1500, 0.9)])
 def test_advect2d_tile_kernels_equal_the_cell_kernels(fl, ext, dev, oracle, shape):
     """The 2D LDS tile kernels (fnx_advect_step's plan on grids of >= 1.5 M cells, here forced: plan='tiles') == one thread
     per cell (plan='cells') == advectScalar + advectVelocity == the oracle, bit for bit: CFL from 0 over the all-fast-path
@@ -782,6 +782,8 @@ def test_advect2d_tile_kernels_equal_the_cell_kernels(fl, ext, dev, oracle, shap
     for so in (False, True):
         rt, ut = ext.advect_step(0.13, trho, tU, tf, so, 0.7, plan="tiles")
         rc, uc = ext.advect_step(0.13, trho, tU, tf, so, 0.7, plan="cells")
+        ra, ua = ext.advect_step(0.13, trho, tU, tf, so, 0.7)                  # the plan fnx_advect_step picks by grid size
+        assert_bitexact(N(ra), N(rc), f"density so={so}: auto vs cells"); assert_bitexact(N(ua), N(uc), f"U so={so}: auto vs cells")
         assert_bitexact(N(rt), N(rc), f"density so={so}: tiles vs cells")
         assert_bitexact(N(ut), N(uc), f"U so={so}: tiles vs cells")
         assert_bitexact(N(rt), N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7)), f"density so={so}")
