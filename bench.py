@@ -20,6 +20,10 @@ At N = 1 the same JSON line carries, under "also", the other configurations the 
   plume3d_256_cnn      configs[3]: 3D plume 256^3, CNN pressure (Conv3d analogue of ScaleNet on the MFMA)
   plume3d_hbm_jacobi   3D plume 512 x 512 x 256, Jacobi-100: the solver's working set (1.3 GiB) exceeds the 256 MiB
                        Infinity Cache, so its roofline numbers are against HBM proper
+  plume2d_128_b32_cnn  the training-shaped call: 32 samples of 128^2 through one `simulate(..., 'convnet')` (the long-term rollout
+                       of fluid_net_train.py:349-373 issues such calls under no_grad); also reports samples/s
+`metric_configs` in the printed line repeats, for the two configurations the metric is quoted on (256^3 Jacobi, 1024^2 CNN), the
+workload name, the numbers and that configuration's own roofline block.
 Other names for --workload: plume2d_128_jacobi (configs[0]), plume3d_128_cnn.
 
 State.  Every workload is first advanced by >= 100 untimed steps (`config.developed_steps`) so that a plume exists
@@ -87,9 +91,13 @@ WORKLOADS = {
     "plume3d_256_cnn": dict(res=256, D=256, method="convnet", iters=0, kind="plume"),      # configs[3]
     "plume3d_128_cnn": dict(res=128, D=128, method="convnet", iters=0, kind="plume"),
     "plume3d_slab_jacobi": dict(res=512, D=64, method="jacobi", iters=100, kind="plume", slab=True),
+    # the training-shaped call (fluid_net_train.py:349-373, trainConfig.yaml batchSize 32/64 at 128^2): the long-term rollout runs
+    # `simulate(..., 'convnet')` on the whole batch under no_grad; a step here is one such call on 32 samples
+    "plume2d_128_b32_cnn": dict(res=128, D=1, method="convnet", iters=0, kind="plume", batch=32),
 }
 ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_cnn",
-        "plume3d_hbm_jacobi"]
+        "plume3d_hbm_jacobi", "plume2d_128_b32_cnn"]
+METRIC_CONFIGS = ["plume3d_256_jacobi", "plume2d_1024_cnn"]      # the two configurations BASELINE.json's metric is quoted on
 
 
 def mfma_flops_per_cell(is3d):
@@ -136,7 +144,10 @@ def build_state(w, dev):
     import torch
     res, D = w["res"], w["D"]
     if w["kind"] == "plume":
-        return plume_state_torch(res, D, dev)
+        st = plume_state_torch(res, D, dev)
+        if w.get("batch", 1) > 1:
+            st = {k: v.repeat(w["batch"], 1, 1, 1, 1).contiguous() for k, v in st.items()}
+        return st
     # Rayleigh-Taylor (reference init_conditions.py:121-125, rayleighTaylorConfig.yaml)
     from fluidnet_cxx_amd import fluid
     bd = dict(p=torch.zeros(1, 1, 1, res, res, device=dev), U=torch.zeros(1, 2, 1, res, res, device=dev),
@@ -218,7 +229,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     else:
         bd = build_state(w, dev)
         net = FluidNet.from_weights(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev) if w["method"] == "convnet" else None
-        ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
+        ws = torch.empty(ext.step_workspace_bytes(w.get("batch", 1), w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
         seen = []
 
         def eager_step(method=None):
@@ -227,7 +238,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
             meth = method or w["method"]
             simulate(m, bd, net if meth == "convnet" else None, meth, workspace=ws, static_flags=(0, 3, 7)[min(len(seen), 2)])
             seen.append(1)
-        cells = w["res"] * w["res"] * w["D"]
+        cells = w["res"] * w["res"] * w["D"] * w.get("batch", 1)
         static_desc = "static_flags 0, 3, then 7: flags + BC arrays promised static (solver obstacle mask and BC class map reused)"
     step = eager_step
 
@@ -293,19 +304,20 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     if os.path.exists(tfile):
         traffic_detail = json.load(open(tfile)).get(name)
         traffic = traffic_detail.get("bytes_per_launch") if traffic_detail else None
+    traffic_src = (traffic_detail or {}).get("source")
     if w["method"] == "convnet":
         tms, nl = times["conv_mfma"]
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
         ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
         util = issued["conv_mfma"] / (tms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if tms > 0 else 0.0
-        kname = ("conv3_wino3_kernel (persistent software pipeline; 3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
+        kname = ("conv3_wino3_kernel<2,2," + ("true" if is3d else "false") + "> (+ <1,2,.> for the 32-channel outputs; persistent software pipeline; 3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
         avg_ms = tms / max(nl, 1)
         roof = dict(bound="mfma", kernel=kname, achieved=ach,
                     peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, mfma_util=util,
-                    issued_tflop_per_step=issued["conv_mfma"] / prof_steps / 1e12, traffic=traffic,
+                    issued_tflop_per_step=issued["conv_mfma"] / prof_steps / 1e12, traffic=traffic, traffic_source=traffic_src,
                     frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                     traffic_detail=traffic_detail,
                     launches_per_step=nl / prof_steps, avg_launch_ms=avg_ms,
@@ -314,11 +326,12 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
         tms, nl = times["jacobi"]
         byts = 16.0 * w["iters"] * cells * prof_steps
         ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-        kname = ("jacobi3d_march_kernel (z-marching, several sweeps per pass)" if is3d
-                 else "jacobi2d_wg_kernel (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-8 sweeps per launch)")
+        kname = ("jacobi3d_march2_kernel<false,false,3> (the steady-state instantiation: z-marching, TWO sweeps per pass, p handed from "
+                 "pass to pass in the row-quad layout; the first pass of a solve is <true,..>, the last one writes rows)" if is3d
+                 else "jacobi2d_wg_kernel<8,8> (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-10 sweeps per launch)")
         avg_ms = tms / max(nl, 1)
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=traffic,
+                    traffic=traffic, traffic_source=traffic_src,
                     frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                     traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
                     avg_launch_ms=avg_ms,
@@ -333,7 +346,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                 unit="Mcells/s", steps_per_s=steps / elapsed, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=ms,
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
-                            global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]],
+                            global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]], batch=w.get("batch", 1),
                             cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
                             parallelism=("1 GPU" if world == 1 else
                                          f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 6 sweeps per exchange, "
@@ -346,6 +359,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                             static_flags=static_desc,
                             state_finite_after_timing=finite,
                             weights="hash-seeded random init (pretrained blob absent from the reference)" if net else None),
+                samples_per_s=(w["batch"] * steps / elapsed) if w.get("batch", 1) > 1 else None,
                 step_hbm_frac=step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 kernel_ms_per_step={k: v[0] / prof_steps for k, v in times.items() if v[1] > 0},
                 roofline=roof)
@@ -444,12 +458,17 @@ def _short(res):
     if rf.get("bound") == "mfma":
         e["mfma_util"] = _r(rf.get("mfma_util"))
     e["frac_traffic"] = _r(rf.get("frac_traffic"))
+    if res.get("samples_per_s"):
+        e["samples_per_s"] = _r(res["samples_per_s"], 5)
     return e
 
 
-def pmc_source():
-    """where roofline.traffic comes from: the committed PMC table and the commit that last changed it"""
+def pmc_source(summary_file=None):
+    """where roofline.traffic comes from: the rocprofv3 PMC summary it was taken from (recorded in the committed PMC table) and the
+    commit that last changed the table"""
     src = "profiles/pmc_traffic.json"
+    if summary_file:
+        return f"recorded rocprofv3 PMC passes, {summary_file} (via {src})"
     try:
         c = subprocess.run(["git", "log", "-1", "--format=%h", "--", src], cwd=REPO, capture_output=True, text=True, timeout=5).stdout.strip()
         return f"recorded rocprofv3 PMC passes, {src}" + (f" @ {c}" if c else "")
@@ -477,9 +496,23 @@ def compact(out):
     rf = out["roofline"]
     line["roofline"] = dict(bound=rf["bound"], kernel=rf["kernel"].split(" (")[0], achieved=_r(rf["achieved"], 5), peak=rf["peak"],
                             unit=rf["unit"], frac=_r(rf["frac"]), traffic=rf.get("traffic"), frac_traffic=_r(rf.get("frac_traffic")),
-                            traffic_source=pmc_source() if rf.get("traffic") else None,
+                            traffic_source=pmc_source(rf.get("traffic_source")) if rf.get("traffic") else None,
                             launches_per_step=_r(rf.get("launches_per_step")), avg_launch_ms=_r(rf.get("avg_launch_ms")),
                             algorithmic=rf.get("algorithmic"))
+    # the two configurations the metric is quoted on, with their own workload name and roofline in the printed line
+    mc = {}
+    for k in METRIC_CONFIGS:
+        v = out if k == name else out.get("also", {}).get(k)
+        if v and "error" not in v:
+            r2 = v["roofline"]
+            e = dict(workload=k, value=_r(v["value"], 5), unit="Mcells/s", ms_per_step=_r(v["ms_per_step"], 5), steps_per_s=_r(v["steps_per_s"], 5),
+                     roofline=dict(bound=r2["bound"], kernel=r2["kernel"].split(" (")[0], achieved=_r(r2["achieved"], 5), peak=r2["peak"],
+                                   unit=r2["unit"], frac=_r(r2["frac"]), traffic=r2.get("traffic"), frac_traffic=_r(r2.get("frac_traffic"))))
+            if r2["bound"] == "mfma":
+                e["roofline"]["mfma_util"] = _r(r2.get("mfma_util"))
+            mc[k] = e
+    if mc:
+        line["metric_configs"] = mc
     line["kernel_ms_per_step"] = {k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()}
     for k in ("cpu_baseline", "cpu_baseline_cnn"):
         if k in out:
@@ -574,7 +607,7 @@ def main():
             big = other in ("plume3d_256_cnn", "plume3d_hbm_jacobi")
             try:
                 r = run_workload(other, min(a.steps, 5 if big else 20), min(a.warmup, 2 if big else 5), not a.no_graph, 1, 0, dev)
-                out["also"][other] = {k: r[k] for k in ("value", "unit", "steps_per_s", "ms_per_step", "step_hbm_frac", "steps",
+                out["also"][other] = {k: r[k] for k in ("value", "unit", "steps_per_s", "samples_per_s", "ms_per_step", "step_hbm_frac", "steps",
                                                         "config", "roofline", "kernel_ms_per_step")}
             except Exception as e:  # noqa: BLE001  (an "also" line must not take the headline down)
                 out["also"][other] = dict(error=f"{type(e).__name__}: {e}")

@@ -198,9 +198,9 @@ void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt
 
 // correctScalar (cpp/advection.py:9-12), in place on src
 void correct_scalar_(double dt, Tensor src, Tensor div, Tensor flags) {
-  check_field(src, "src");
+  check_field(src, "src"); check_field(flags, "flags");
   FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
-  check_scalar(src, g, "src"); check_scalar(div, g, "div");
+  check_scalar(src, g, "src"); check_scalar(div, g, "div"); check_scalar(flags, g, "flags");
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_correct_scalar(&g, (float)dt, src.data_ptr<float>(), div.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(src)));
 }
@@ -708,7 +708,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("density_bc_applied") = false, NoGil());
   m.def("bc_classify", &bc_classify, "uint8 class map of static BC arrays (FnxState.bc_class)", NoGil());
   py::class_<PyLoopbackGroup, std::shared_ptr<PyLoopbackGroup>>(m, "SlabLoopbackGroup", "in-process communicator group: n slabs driven by n host threads")
-      .def(py::init<int>(), py::arg("nranks"));
+      .def(py::init<int>(), py::arg("nranks"))
+      .def("set_timeout", [](PyLoopbackGroup& g, double seconds) { check_status(fnx_slab_loopback_group_set_timeout(g.g, seconds)); }, py::arg("seconds"),
+           "how long a rank waits for a peer before its call fails (the group stays usable); default 120 s")
+      .def("reset", [](PyLoopbackGroup& g) { check_status(fnx_slab_loopback_group_reset(g.g)); },
+           "clear an abort (no rank may be inside a call of the group)");
   py::class_<PySlabComm, std::shared_ptr<PySlabComm>>(m, "SlabComm", "ghost-plane communicator of the native z-slab driver (FnxSlabComm)");
   m.def("slab_rccl_unique_id", &slab_rccl_unique_id);
   m.def("slab_comm_rccl", &slab_comm_rccl, py::arg("rank"), py::arg("nranks"), py::arg("unique_id"));

@@ -7,6 +7,7 @@
 #include "../../include/fluidnet_hip.h"
 #include "fnx_cnn.h"
 #include "fnx_kernels.h"
+#include <atomic>
 #include <dlfcn.h>
 
 namespace {
@@ -127,13 +128,16 @@ struct Prof {
 // roctx ranges around the same phases (the reference has no tracing hooks; rocprofv3 --marker-trace shows
 // them).  The marker library is resolved on request (fnx_roctx_enable), never linked: without it the ranges are no-ops.
 namespace {
-struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool on = false; } g_roctx;
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; std::atomic<bool> on{false}; } g_roctx;
 const char* const kProfNames[FNX_PROF_NTAGS] = {"fnx:jacobi", "fnx:conv_mfma", "fnx:advect", "fnx:stage", "fnx:conv_direct", "fnx:conv_mfma16"};
 }  // namespace
 
-void prof_begin(int tag, hipStream_t s) {
-  if (g_roctx.on) g_roctx.push(kProfNames[tag]);
-  if (!g_prof.on || g_prof.n >= PROF_MAX) { if (g_prof.on) g_prof.open_idx[tag] = -1; return; }
+// A scope pops the range it pushed and no other: fnx_roctx_enable may be toggled (from another thread, or inside an open scope
+// such as the pTol loop of a solve) between a scope's begin and end.
+bool prof_begin(int tag, hipStream_t s) {
+  const bool pushed = g_roctx.on.load(std::memory_order_acquire);
+  if (pushed) g_roctx.push(kProfNames[tag]);
+  if (!g_prof.on || g_prof.n >= PROF_MAX) { if (g_prof.on) g_prof.open_idx[tag] = -1; return pushed; }
   const int i = g_prof.n++;
   if (i >= g_prof.created) {
     hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]);
@@ -142,14 +146,15 @@ void prof_begin(int tag, hipStream_t s) {
   g_prof.tag[i] = tag;
   g_prof.open_idx[tag] = i;
   hipEventRecord(g_prof.ev[i][0], s);
+  return pushed;
 }
 
 void prof_add_work(int tag, double amount) {
   if (g_prof.on && g_prof.open_idx[tag] >= 0) g_prof.work[tag] += amount;
 }
 
-void prof_end(int tag, hipStream_t s) {
-  if (g_roctx.on) g_roctx.pop();
+void prof_end(int tag, hipStream_t s, bool pushed) {
+  if (pushed) g_roctx.pop();
   if (!g_prof.on) return;
   const int i = g_prof.open_idx[tag];
   if (i >= 0) hipEventRecord(g_prof.ev[i][1], s);
@@ -165,7 +170,7 @@ int fnx_profile_enable(int on) {
 }
 
 int fnx_roctx_enable(int on) {
-  if (!on) { fnx::g_roctx.on = false; return FNX_OK; }
+  if (!on) { fnx::g_roctx.on.store(false, std::memory_order_release); return FNX_OK; }
   if (!fnx::g_roctx.push) {
     void* h = nullptr;
     for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
@@ -177,7 +182,7 @@ int fnx_roctx_enable(int on) {
     fnx::g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
     if (!fnx::g_roctx.push || !fnx::g_roctx.pop) { fnx::g_roctx.push = nullptr; return fail(FNX_EINVAL, "roctx_enable: roctxRangePushA / roctxRangePop not found"); }
   }
-  fnx::g_roctx.on = true;
+  fnx::g_roctx.on.store(true, std::memory_order_release);
   return FNX_OK;
 }
 

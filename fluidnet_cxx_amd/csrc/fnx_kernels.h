@@ -9,13 +9,13 @@ namespace fnx {
 int set_error(int code, const char* fmt, ...);
 
 // event-pair timing of kernel classes (fnx_api.hip); no-ops unless fnx_profile_enable(1)
-void prof_begin(int tag, hipStream_t s);
-void prof_end(int tag, hipStream_t s);
+bool prof_begin(int tag, hipStream_t s);      // true: a roctx range was pushed (prof_end pops only then)
+void prof_end(int tag, hipStream_t s, bool pushed);
 void prof_add_work(int tag, double amount);   // adds to the class's work counter while a recorded launch of it is open
 struct ProfScope {
-  int tag; hipStream_t s;
-  ProfScope(int t, hipStream_t st) : tag(t), s(st) { prof_begin(tag, s); }
-  ~ProfScope() { prof_end(tag, s); }
+  int tag; hipStream_t s; bool pushed;
+  ProfScope(int t, hipStream_t st) : tag(t), s(st), pushed(prof_begin(t, st)) {}
+  ~ProfScope() { prof_end(tag, s, pushed); }
 };
 
 // advection (fnx_advect.hip)

@@ -169,32 +169,39 @@ struct LoopGroup {
   std::mutex mu; std::condition_variable cv;
   int red_count = 0, red_gen = 0; std::vector<float> red_val, red_out;   // (red_out: a finished round's result, safe from the next round's first arrival)
   std::atomic<bool> aborted{false};   // a rank failed: every party waiting for a peer gives up (FNX_ECOMM) instead of hanging
+  // a peer that never arrives (it failed before its exchange call) is an error, not a hang; fnx_slab_loopback_group_set_timeout
+  std::atomic<int> timeout_ms{120 * 1000};
   explicit LoopGroup(int n) : nranks(n), pairs(n > 1 ? n - 1 : 0) {}
 };
 struct LoopCtx { LoopGroup* g; int rank; };
-constexpr int kLoopPeerTimeoutS = 120;   // a peer that never arrives (it failed before its exchange call) is an error, not a hang
 
-// waits on `cv` until pred() holds; false when the group was aborted or the peer did not show up in time
+// waits on `cv` until pred() holds.  WAIT_ABORTED: the group was aborted (a rank failed; sticky until
+// fnx_slab_loopback_group_reset).  WAIT_TIMEOUT: the peer did not show up in time -- this call fails, the group is NOT poisoned:
+// a slow but healthy peer (first-call kernel load, a debugger) costs the caller one error it can retry after, not the group.
+enum LoopWait { WAIT_OK = 0, WAIT_ABORTED, WAIT_TIMEOUT };
 template <class Pred>
-bool loop_wait(LoopGroup* g, std::condition_variable& cv, std::unique_lock<std::mutex>& lk, Pred pred) {
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(kLoopPeerTimeoutS);
+LoopWait loop_wait(LoopGroup* g, std::condition_variable& cv, std::unique_lock<std::mutex>& lk, Pred pred) {
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(g->timeout_ms.load());
   while (!pred()) {
-    if (g->aborted.load()) return false;
-    if (cv.wait_for(lk, std::chrono::milliseconds(50)) == std::cv_status::timeout && std::chrono::steady_clock::now() > deadline) {
-      g->aborted.store(true);
-      return false;
-    }
+    if (g->aborted.load()) return WAIT_ABORTED;
+    if (cv.wait_for(lk, std::chrono::milliseconds(50)) == std::cv_status::timeout && std::chrono::steady_clock::now() > deadline)
+      return pred() ? WAIT_OK : WAIT_TIMEOUT;
   }
-  return !g->aborted.load() || pred();
+  return WAIT_OK;
 }
-int loop_gone() { return fnx::set_error(FNX_ECOMM, "loopback exchange: a peer rank failed or did not arrive (group aborted)"); }
+int loop_gone(LoopGroup* g, LoopWait why) {
+  if (why == WAIT_TIMEOUT)
+    return fnx::set_error(FNX_ECOMM, "loopback exchange: timed out after %d ms waiting for a peer rank (the group stays usable; "
+                                     "fnx_slab_loopback_group_set_timeout changes the limit)", g->timeout_ms.load());
+  return fnx::set_error(FNX_ECOMM, "loopback exchange: a peer rank failed (group aborted; fnx_slab_loopback_group_reset clears it)");
+}
 
 // one side of pair `pi`; lower = this rank is the lower one of the pair (it sends its *_hi pointers)
 int loop_meet(LoopGroup* g, int pi, bool lower, const FnxSlabSeg* segs, int nsegs, hipStream_t s) {
   LoopPair& P = g->pairs[pi];
   const int me = lower ? 0 : 1, other = 1 - me;
   std::unique_lock<std::mutex> lk(P.mu);
-  if (!loop_wait(g, P.cv, lk, [&] { return P.phase == 0 || (P.phase == 1 && P.first_is_lower != lower); })) return loop_gone();
+  if (LoopWait w = loop_wait(g, P.cv, lk, [&] { return P.phase == 0 || (P.phase == 1 && P.first_is_lower != lower); })) return loop_gone(g, w);
   if (!P.ev[me]) SLAB_HIP(hipEventCreateWithFlags(&P.ev[me], hipEventDisableTiming));
   if (P.phase == 0) {                       // first to arrive
     P.segs.assign(segs, segs + nsegs);
@@ -203,7 +210,7 @@ int loop_meet(LoopGroup* g, int pi, bool lower, const FnxSlabSeg* segs, int nseg
     SLAB_HIP(hipEventRecord(P.ev[me], s));
     P.phase = 1;
     P.cv.notify_all();
-    if (!loop_wait(g, P.cv, lk, [&] { return P.phase == 2; })) { P.phase = 0; P.cv.notify_all(); return loop_gone(); }
+    if (LoopWait w = loop_wait(g, P.cv, lk, [&] { return P.phase == 2; })) { P.phase = 0; P.cv.notify_all(); return loop_gone(g, w); }
     const int rc = P.rc;
     hipError_t e = rc == FNX_OK ? hipStreamWaitEvent(s, P.ev[other], 0) : hipSuccess;
     P.phase = 0;
@@ -251,7 +258,10 @@ int loop_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
     if (g->red_count == 0) g->red_val.assign(h, h + n);
     else for (int i = 0; i < n; ++i) g->red_val[i] = sum ? g->red_val[i] + h[i] : (h[i] > g->red_val[i] ? h[i] : g->red_val[i]);
     if (++g->red_count == g->nranks) { g->red_count = 0; g->red_out = g->red_val; ++g->red_gen; g->cv.notify_all(); }
-    else if (!loop_wait(g, g->cv, lk, [&] { return g->red_gen != gen; })) return loop_gone();
+    else if (LoopWait w = loop_wait(g, g->cv, lk, [&] { return g->red_gen != gen; })) {
+      if (g->red_gen == gen && g->red_count > 0) --g->red_count;       // this rank leaves the unfinished round
+      return loop_gone(g, w);
+    }
     for (int i = 0; i < n; ++i) h[i] = g->red_out[i];
   }
   SLAB_HIP(hipMemcpyAsync(x, h, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -439,6 +449,21 @@ int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank) {
   if (!out || !g || rank < 0 || rank >= g->nranks) return fnx::set_error(FNX_EINVAL, "loopback comm: bad arguments");
   out->ctx = new LoopCtx{g, rank}; out->exchange = loop_exchange; out->allreduce_max = loop_allreduce_max; out->allreduce_sum = loop_allreduce_sum; out->destroy = loop_destroy;
   out->abort = loop_abort;
+  return FNX_OK;
+}
+int fnx_slab_loopback_group_set_timeout(void* group, double seconds) {
+  LoopGroup* g = (LoopGroup*)group;
+  if (!g || !(seconds > 0.0) || seconds > 86400.0) return fnx::set_error(FNX_EINVAL, "loopback group: timeout must be in (0, 86400] s");
+  g->timeout_ms.store((int)(seconds * 1000.0 + 0.5) < 1 ? 1 : (int)(seconds * 1000.0 + 0.5));
+  return FNX_OK;
+}
+int fnx_slab_loopback_group_reset(void* group) {
+  LoopGroup* g = (LoopGroup*)group;
+  if (!g) return fnx::set_error(FNX_EINVAL, "loopback group is NULL");
+  // (the caller's promise: no rank is inside an exchange or all-reduce of this group)
+  for (LoopPair& p : g->pairs) { std::lock_guard<std::mutex> lk(p.mu); p.phase = 0; p.rc = FNX_OK; p.segs.clear(); }
+  { std::lock_guard<std::mutex> lk(g->mu); g->red_count = 0; }
+  g->aborted.store(false);
   return FNX_OK;
 }
 void fnx_slab_loopback_group_free(void* group) {

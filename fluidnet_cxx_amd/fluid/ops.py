@@ -66,9 +66,16 @@ def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_wid
 
 def correctScalar(dt, src, div, flags):
     """cpp/advection.py:9-12 (off in all shipped configs): src += dt*0.5*src*div on fluid cells, in place."""
-    _check5(src, flags)
-    assert div.shape == src.shape == flags.shape, "Size mismatch"
-    ext.correct_scalar_(float(dt), src, div, flags)
+    native = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 5 for t in (src, div, flags)) \
+        and div.shape == src.shape == flags.shape
+    if native:
+        ext.correct_scalar_(float(dt), src, div, flags)
+        return
+    # the reference's statement (cpp/advection.py:9-12) as written, for what it accepts and the native operator does not:
+    # broadcastable shapes, strided views, other dtypes.  Still on the tensors' own device: CPU tensors raise like every operator.
+    assert src.is_cuda and div.is_cuda and flags.is_cuda, "fluidnet_cxx_amd has no CPU path: tensors must be on the GPU"
+    mask = flags.eq(1)
+    src.copy_(torch.where(mask, src + (dt * 0.5 * src) * div, src))
 
 
 def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, verbose=False, *, geom=None):

@@ -189,10 +189,13 @@ class NativeOps:
         """max |x| as a 0-dim tensor on x's device (no host sync)"""
         return self.ext.max_abs(x)
 
-    def post_projection(self, st):
-        # (the staging pass of this step has applied the density BCs on the same planes: FnxState.density_bc_applied)
+    def post_projection(self, st, density_bc_applied=False):
+        # density_bc_applied (FnxState.density_bc_applied): the caller's promise that pre_projection of THIS step has applied
+        # the density BCs on the same planes with the same BC arrays -- the pass then leaves the density of identity-class cells
+        # alone (same bits).  SlabSimulator._step makes it; any other caller gets the full setConstVals.
         self.ext.post_projection_(st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"), st.get("UBCInvMask"),
-                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st), self._geom(), True)
+                                  st.get("densityBC"), st.get("densityBCInvMask"), self._bc_class(st), self._geom(),
+                                  bool(density_bc_applied))
 
 
 class SlabSimulator:
@@ -311,7 +314,7 @@ class SlabSimulator:
         ops.set_slab(l.z_offset, l.D_global)
         if window and l.world > 1:
             window(lo_, top_)
-        ops.post_projection(st)
+        ops.post_projection(st, density_bc_applied=True)     # ops.pre_projection above ran on the same planes and BC arrays
         if window:
             window(0, 0)
         ops.set_slab(0, 0)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 13
+#define FNX_ABI_VERSION 14
 
 enum {
   FNX_OK = 0,
@@ -328,9 +328,13 @@ int fnx_slab_rccl_unique_id(void* out128);
 int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* unique_id128);
 /* In-process communicator for `nranks` slabs driven by `nranks` host threads of one process (one device, or several
  * with peer access: each side of a pair records only its own event on its own stream): device-to-device copies ordered by
- * events.  A rank that waits for a peer longer than 120 s, or whose group was aborted (FnxSlabComm.abort), returns FNX_ECOMM.
- * Create the group once, then one comm per rank. */
+ * events.  A rank whose peer does not arrive within the group's timeout (120 s unless set) returns FNX_ECOMM from that call
+ * and the group stays usable (a slow peer is not a dead one); a rank whose group was aborted (FnxSlabComm.abort: some rank's
+ * step failed) returns FNX_ECOMM until fnx_slab_loopback_group_reset, which the caller may issue once no rank is inside a call
+ * of the group.  Create the group once, then one comm per rank. */
 int fnx_slab_loopback_group(void** group, int nranks);
+int fnx_slab_loopback_group_set_timeout(void* group, double seconds);
+int fnx_slab_loopback_group_reset(void* group);
 int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank);
 void fnx_slab_loopback_group_free(void* group);
 void fnx_slab_comm_free(FnxSlabComm* comm);

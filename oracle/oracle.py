@@ -270,9 +270,27 @@ def scale_std(U, thr=1e-5):
     return s
 
 
-def fluidnet_forward(blob, inp, thr=1e-5):
+def fluidnet_forward(blob, inp, thr=1e-5, net=None):
+    """FluidNet.forward (lib/model.py:118-227; ora_fluidnet_forward).  `net`: a callable x (B,2,D,H,W) -> p (B,1,D,H,W) that
+    stands in for the MultiScaleNet (lib/multi_scale_net.py:118-127) -- the stages around the net are then the oracle's own
+    operators applied in ora_fluidnet_forward's order with its arithmetic (fp32 divisions and products per element), so a test
+    can pin everything a step does around a net whose output it takes from elsewhere."""
     B, cin, D, H, W = inp.shape
     nc = cin - 3
+    if net is not None:
+        inp = np.ascontiguousarray(inp, np.float32)
+        U = inp[:, 1:1 + nc].copy()
+        flags = inp[:, 1 + nc:2 + nc].copy()
+        div = velocity_divergence(U, flags)
+        s = scale_std(U, thr).reshape(B, 1, 1, 1, 1)
+        U = (U / s).astype(np.float32)
+        occ = np.where(flags == 1, np.float32(0), np.where(flags == 2, np.float32(1), flags)).astype(np.float32)
+        x = np.concatenate([(div / s).astype(np.float32), occ], 1)
+        p = np.ascontiguousarray(net(x), np.float32)
+        U = velocity_update(p, U, flags)
+        p = (p * s).astype(np.float32)
+        U = (U * s).astype(np.float32)
+        return p, set_wall_bcs(U, flags)
     g = OraGrid(B, D, H, W, int(nc == 3), 0, 0)
     inp, pi = _f(inp); blob, pb = _f(blob)
     p = np.empty((B, 1, D, H, W), np.float32); U = np.empty((B, nc, D, H, W), np.float32)
@@ -282,7 +300,7 @@ def fluidnet_forward(blob, inp, thr=1e-5):
     return p, U
 
 
-def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False):
+def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False, net=None):
     """One time step in the order of the reference's lib/simulate.py:28-171.
 
     state: dict with p, U, flags, density (+ optional UBC, UBCInvMask, densityBC, densityBCInvMask);
@@ -343,7 +361,7 @@ def simulate_step(state, cfg, method="jacobi", blob=None, quirks=False):
         U = wall_bcs(U)
     else:
         inp = np.concatenate([state["p"], U, flags, rho], 1)
-        p, U = fluidnet_forward(blob, inp, cfg.get("normalizeInputThreshold", 1e-5))
+        p, U = fluidnet_forward(blob, inp, cfg.get("normalizeInputThreshold", 1e-5), net)
         if stick is not None:                                    # simulate.py:165-166
             U = set_wall_bcs_stick(U, flags, stick)
     U, rho = const_vals(U, rho)

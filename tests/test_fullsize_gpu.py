@@ -128,3 +128,109 @@ def test_long_simulation_stays_bit_identical(oracle, case):
             for k in ("U", "density", "p"):
                 assert_bitexact(bd[k].cpu().numpy(), st[k], f"{name}: {k} after {it} steps")
     assert float(np.abs(st["U"]).max()) > 0.5, "the flow did not develop"
+
+
+# ---- the convnet step (lib/simulate.py:131-143 + lib/model.py:118-227) against the oracle --------------------------------------
+# The fused convnet step is three launches around the net (fnx_cnn.hip: pack_div_kernel -- the divergence of U / s straight into
+# the net's input --, the net, post_projection_kernel<IS3D, SCALE=true> -- velocityUpdate, un-normalisation, setWallBcs, the step's
+# last setConstVals) behind the advection and staging launches.  Tolerances: the net's arithmetic is a tolerance statement
+# (1e-5 * |ref|max on p and U, like every CNN test); everything that does not pass through the net is bit for bit.
+
+def _cnn_cfg(is3d):
+    return dict(PLUME_CFG, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                normalizeInputChan="UDiv", is3D=is3d, gravityVec=dict(x=0.0, y=-1.0, z=0.2 if is3d else 0.0))
+
+
+def _cnn_state(B, D, H, W, seed):
+    """B samples with obstacles, an inflow (velocity + density BCs), different random velocities and densities per sample"""
+    rng = np.random.default_rng(seed)
+    nc = 3 if D > 1 else 2
+    flags = make_flags(B, D, H, W, boxes=True)
+    if D > 1:
+        flags[:, :, 2:D - 2, H // 2, W // 2:W // 2 + 9] = 2          # a bar through most planes
+    st = dict(flags=flags, p=rng.standard_normal((B, 1, D, H, W)).astype(np.float32),
+              U=(rng.standard_normal((B, nc, D, H, W)) * 0.6).astype(np.float32),
+              density=rng.random((B, 1, D, H, W)).astype(np.float32))
+    UBC = np.zeros_like(st["U"]); M = np.ones_like(st["U"])
+    UBC[:, 1, :, 0:4, W // 3:2 * W // 3] = 2.0; M[:, :, :, 0:4] = 0
+    dBC = np.zeros_like(st["density"]); dM = np.ones_like(st["density"])
+    dBC[:, 0, :, 0:4, W // 3:2 * W // 3] = 0.1; dM[:, 0, :, 0:4, W // 3:2 * W // 3] = 0
+    st.update(UBC=UBC, UBCInvMask=M, densityBC=dBC, densityBCInvMask=dM)
+    return st
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 40, 72), (2, 1, 48, 80), (1, 16, 36, 132)])
+def test_convnet_step_vs_oracle(oracle, shape):
+    """Three consecutive fused convnet steps (workspace; static_flags 0, 3, 7: the BC class map is built, then reused) in 3D and
+    2D with obstacles, inflow BCs and a batch of two: each step against oracle.simulate_step(state before it, "convnet")."""
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    from util import assert_close_rel
+    B, D, H, W = shape
+    is3d = D > 1
+    dev = torch.device("cuda:0")
+    cfg = _cnn_cfg(is3d)
+    wts = make_scalenet_weights(0, ndim=3 if is3d else 2)
+    blob = oracle.pack_weights(wts, 3 if is3d else 2)
+    net = FluidNet.from_weights(cfg, wts, dev)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in _cnn_state(B, D, H, W, 21).items()}
+    ws = torch.empty(ext.step_workspace_bytes(B, D, H, W, is3d), dtype=torch.uint8, device=dev)
+    for it in range(3):
+        st = _np_state(bd)
+        simulate(cfg, bd, net, "convnet", workspace=ws, static_flags=(0, 3, 7)[it])
+        torch.cuda.synchronize()
+        ref = oracle.simulate_step(st, cfg, "convnet", blob)
+        assert_bitexact(bd["density"].cpu().numpy(), ref["density"], f"density, step {it + 1}")
+        for k in ("p", "U"):
+            for b in range(B):          # per sample: each has its own scale
+                assert_close_rel(bd[k][b].cpu().numpy(), ref[k][b], 1e-5, f"{k}, sample {b}, step {it + 1}")
+        # the cells setWallBcs / setConstVals pin do not pass through the net: the inflow rows carry the BC values exactly
+        got = bd["U"].cpu().numpy()
+        assert_bitexact(got[:, :, :, 0:4], ref["U"][:, :, :, 0:4], f"U on the inflow rows, step {it + 1}")
+
+
+@pytest.mark.parametrize("name", ["plume2d_1024_cnn", "plume3d_256_cnn"])
+def test_benchmark_size_convnet_step_vs_oracle(oracle, name):
+    """The convnet step bench.py times at 1024^2 (the metric's configs[1]) and 256^3 (configs[3]), from a developed plume, with
+    its launch plan (workspace, static_flags, Winograd MFMA layers): every stage AROUND the net bit for bit against the oracle.
+    The oracle runs the step with the HIP net standing in for its MultiScaleNet (`net=`: ext.multiscale_forward on the input the
+    ORACLE's stages produced -- the divergence of the staged, normalised velocity), so U, density and p of the HIP step must
+    equal the oracle's bit for bit: the advection, the staging pass, pack_div_kernel (else the net sees another input), the
+    scale, post_projection_kernel<.,SCALE> and the last setConstVals.  The net itself at this size: test_cnn_benchmark_size."""
+    import bench
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS[name]
+    m = bench.mconf_for(w)
+    is3d = w["D"] > 1
+    net = FluidNet.from_weights(m, make_scalenet_weights(0, ndim=3 if is3d else 2), dev)
+    bd = bench.build_state(w, dev)
+    ws = torch.empty(ext.step_workspace_bytes(1, w["D"], w["res"], w["res"], is3d), dtype=torch.uint8, device=dev)
+    seen = []
+
+    def step(method):
+        simulate(m, bd, net if method == "convnet" else None, method, workspace=ws, static_flags=(0, 3, 7)[min(len(seen), 2)])
+        seen.append(1)
+    m["jacobiIter"] = 28 if not is3d else 40          # developed with the Jacobi projection, as bench.py does
+    for _ in range(DEVELOP):
+        step("jacobi")
+    step("convnet")                                    # (and one CNN step, so that p is a net output like in the timed loop)
+    torch.cuda.synchronize()
+    st = _np_state(bd)
+    umax = float(np.abs(st["U"]).max()) * float(m["dt"])
+    assert umax > 0.05, f"the state did not develop (max |U| dt = {umax})"
+    step("convnet")
+    torch.cuda.synchronize()
+    packed = net.packed_for(dev)
+    calls = []
+
+    def hip_net(x):
+        calls.append(1)
+        return ext.multiscale_forward(packed, torch.from_numpy(x).to(dev), "fp32").cpu().numpy()
+    ref = oracle.simulate_step(st, m, "convnet", None, net=hip_net)
+    assert calls == [1]
+    for k in ("density", "U", "p"):
+        assert_bitexact(bd[k].cpu().numpy(), ref[k], f"{name}: {k} after the convnet step (max |U| dt = {umax:.3f})")

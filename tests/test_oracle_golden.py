@@ -168,3 +168,21 @@ def test_known_answers(oracle):
     U1 = np.zeros_like(U0); U1[:, 0] = 1.0
     sh = oracle.advect_scalar(1.0, rho, U1, flags, "eulerFluidNet", 1, True)
     np.testing.assert_array_equal(sh[..., 2:-2, 3:-2], rho[..., 2:-2, 2:-3])
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 24, 40), (1, 8, 16, 24)])
+def test_fluidnet_forward_net_hook_same_bits(oracle, shape):
+    """oracle.fluidnet_forward(..., net=f) -- the stages around the MultiScaleNet written with the oracle's operators so that a
+    test can take the net's output from elsewhere (tests/test_fullsize_gpu.py does, at 1024^2 and 256^3) -- is bit for bit
+    ora_fluidnet_forward when f is the oracle's own net."""
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    from util import random_state
+    B, D, H, W = shape
+    is3d = D > 1
+    s = random_state(B, D, H, W, 0.7, seed=12)
+    blob = oracle.pack_weights(make_scalenet_weights(0, ndim=3 if is3d else 2), 3 if is3d else 2)
+    inp = np.concatenate([s["p"], s["U"], s["flags"], s["rho"]], 1)
+    p0, U0 = oracle.fluidnet_forward(blob, inp, 1e-5)
+    p1, U1 = oracle.fluidnet_forward(blob, inp, 1e-5, net=lambda x: oracle.multiscale_forward(blob, x, is3d))
+    assert_bitexact(p1, p0, "p")
+    assert_bitexact(U1, U0, "U")

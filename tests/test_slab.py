@@ -91,7 +91,7 @@ class OracleOps:
     def max_abs(self, x):
         return x.abs().max()
 
-    def post_projection(self, st):
+    def post_projection(self, st, density_bc_applied=False):
         O = self.O
         n = {k: v.numpy() for k, v in st.items()}
         U = O.velocity_update(n["p"], n["U"], n["flags"])
