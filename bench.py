@@ -564,7 +564,7 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--schedule", default="deep_first", choices=["deep_first", "edge_first", "last_pass"],
+    ap.add_argument("--schedule", default="deep_first", choices=["deep_first", "deep_beside", "edge_first", "last_pass"],
                     help="N > 1: how the slab driver orders a sweep block around its ghost exchange (slab.py)")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations reported under 'also' at N=1")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous, no GPU work")

@@ -453,8 +453,10 @@ struct PySlab {
          int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule) : comm(comm_) {
     cfg.B = B; cfg.H = H; cfg.W = W; cfg.D_global = D_global; cfg.rank = rank; cfg.nranks = nranks; cfg.halo = halo;
     cfg.sweeps_per_exchange = sweeps_per_exchange; cfg.static_flags = static_flags ? 1 : 0; cfg.cfl_check_every = cfl_check_every;
-    TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass", "unknown z-slab schedule '", schedule, "'");
-    cfg.schedule = schedule == "deep_first" ? FNX_SLAB_DEEP_FIRST : (schedule == "edge_first" ? FNX_SLAB_EDGE_FIRST : FNX_SLAB_LAST_PASS);
+    TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass" || schedule == "deep_beside",
+                "unknown z-slab schedule '", schedule, "'");
+    cfg.schedule = schedule == "deep_first" ? FNX_SLAB_DEEP_FIRST : (schedule == "edge_first" ? FNX_SLAB_EDGE_FIRST :
+                   (schedule == "deep_beside" ? FNX_SLAB_DEEP_BESIDE : FNX_SLAB_LAST_PASS));
     check_status(fnx_slab_create(&s, &cfg, comm ? &comm->c : nullptr));
   }
   ~PySlab() { fnx_slab_destroy(s); }
@@ -717,6 +719,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("slab_rccl_unique_id", &slab_rccl_unique_id);
   m.def("slab_comm_rccl", &slab_comm_rccl, py::arg("rank"), py::arg("nranks"), py::arg("unique_id"));
   m.def("slab_comm_loopback", &slab_comm_loopback, py::arg("group"), py::arg("rank"));
+  m.def("slab_comm_link_model", [](double latency_us, double gbps) {
+    auto c = std::make_shared<PySlabComm>();
+    check_status(fnx_slab_comm_link_model(&c->c, latency_us, gbps));
+    return c;
+  }, py::arg("latency_us"), py::arg("gbytes_per_s"), "rehearsal communicator: one process runs a middle rank's step against an assumed link");
   m.def("slab_comm_probe", [](std::shared_ptr<PySlabComm> comm, int64_t bytes, int reps, Tensor scratch) {
     TORCH_CHECK(scratch.is_cuda() && scratch.is_contiguous() && (int64_t)scratch.numel() * scratch.element_size() >= 4 * bytes,
                 "slab_comm_probe: scratch must be a contiguous GPU tensor of at least 4 * bytes");

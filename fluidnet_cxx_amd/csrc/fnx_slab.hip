@@ -278,6 +278,35 @@ void loop_abort(void* vctx) {
   g->cv.notify_all();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Link-model communicator: ONE rank rehearses a middle slab on one GPU.  An exchange occupies its stream for
+// latency + bytes-per-direction / bandwidth (a one-wave kernel that sleeps on the device's constant-rate clock) and then
+// fills the ghost planes from the slab's own edge planes (the lower neighbour's top planes are taken to be this slab's top
+// planes: a periodic stack of this slab -- the launch sequence, sizes and stream ordering are the real ones, the physics is
+// not).  What it measures is how much of a transfer of an assumed link a schedule hides.
+// ---------------------------------------------------------------------------------------------------------------
+struct ModelCtx { double latency_us, gbps; };
+__global__ void link_model_wait_kernel(unsigned long long ticks) {       // wall_clock64: 100 MHz on gfx950
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int model_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
+  ModelCtx* c = (ModelCtx*)vctx;
+  hipStream_t s = (hipStream_t)stream;
+  size_t bytes = 0;
+  for (int i = 0; i < nsegs; ++i) bytes += segs[i].bytes;
+  const double us = c->gbps > 0.0 ? c->latency_us + (double)bytes / (c->gbps * 1e3) : 0.0;
+  if (us > 0.0) link_model_wait_kernel<<<1, 64, 0, s>>>((unsigned long long)(us * 100.0));
+  for (int i = 0; i < nsegs; ++i) {
+    const FnxSlabSeg& g = segs[i];
+    if (g.recv_lo && g.send_hi) SLAB_HIP(hipMemcpyAsync(g.recv_lo, g.send_hi, g.bytes, hipMemcpyDeviceToDevice, s));
+    if (g.recv_hi && g.send_lo) SLAB_HIP(hipMemcpyAsync(g.recv_hi, g.send_lo, g.bytes, hipMemcpyDeviceToDevice, s));
+  }
+  return FNX_OK;
+}
+int model_allreduce(void*, float*, int, void*) { return FNX_OK; }        // one rank: its own value
+void model_destroy(void* vctx) { delete (ModelCtx*)vctx; }
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -289,6 +318,9 @@ struct FnxSlab {
   bool mask_valid = false, cls_valid = false;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_post = nullptr, ev_done = nullptr;
+  // deep_beside: the edge chain's stream, its fork / join events and one event per deep pass of a block
+  hipStream_t edge_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_deep[FNX_SLAB_MAX_HALO] = {};
   bool pending = false;
   float* h_cfl = nullptr;    // pinned host float
   // optional statistics (fnx_slab_stats_enable): bytes posted per neighbour and direction, exchanges, and how long the
@@ -309,7 +341,7 @@ int layout_of(const FnxSlabConfig* c, int* owned, int* lo, int* hi, int* zoff) {
   const int ow = c->D_global / c->nranks;
   if (c->nranks > 1 && c->halo < 5) return fnx::set_error(FNX_EINVAL, "slab: advection + projection need 5 valid ghost planes (CFL <= 1)");
   if (c->halo > FNX_SLAB_MAX_HALO) return fnx::set_error(FNX_EINVAL, "slab: halo %d > %d planes is not supported", c->halo, FNX_SLAB_MAX_HALO);
-  if (c->schedule < FNX_SLAB_DEEP_FIRST || c->schedule > FNX_SLAB_LAST_PASS) return fnx::set_error(FNX_EINVAL, "slab: unknown schedule %d", c->schedule);
+  if (c->schedule < FNX_SLAB_DEEP_FIRST || c->schedule > FNX_SLAB_DEEP_BESIDE) return fnx::set_error(FNX_EINVAL, "slab: unknown schedule %d", c->schedule);
   if (c->nranks > 1 && ow < c->halo) return fnx::set_error(FNX_EINVAL, "slab thinner than its halo");
   *owned = ow;
   *lo = c->rank > 0 ? c->halo : 0;
@@ -439,6 +471,14 @@ int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* uniqu
   return FNX_OK;
 }
 
+int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_per_s) {
+  if (!out || latency_us < 0.0 || gbytes_per_s < 0.0) return fnx::set_error(FNX_EINVAL, "slab_comm_link_model: bad arguments");
+  out->ctx = new ModelCtx{latency_us, gbytes_per_s};
+  out->exchange = model_exchange; out->allreduce_max = model_allreduce; out->allreduce_sum = model_allreduce;
+  out->destroy = model_destroy; out->abort = nullptr;
+  return FNX_OK;
+}
+
 int fnx_slab_loopback_group(void** group, int nranks) {
   if (!group || nranks < 1) return fnx::set_error(FNX_EINVAL, "loopback group: bad arguments");
   *group = new (std::nothrow) LoopGroup(nranks);
@@ -514,6 +554,13 @@ int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* 
       fnx_slab_destroy(s);
       return fnx::set_error(FNX_EHIP, "slab_create: stream / event creation failed");
     }
+    if (cfg->schedule == FNX_SLAB_DEEP_BESIDE) {
+      bool ok = hipStreamCreateWithFlags(&s->edge_stream, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; ok && i < (s->w + 1) / 2; ++i) ok = hipEventCreateWithFlags(&s->ev_deep[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { fnx_slab_destroy(s); return fnx::set_error(FNX_EHIP, "slab_create: stream / event creation failed"); }
+    }
   } else {
     s->comm = FnxSlabComm{};
   }
@@ -530,6 +577,10 @@ void fnx_slab_destroy(FnxSlab* s) {
   if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
   if (s->ev_post) (void)hipEventDestroy(s->ev_post);
   if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+  if (s->edge_stream) (void)hipStreamDestroy(s->edge_stream);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  for (hipEvent_t e : s->ev_deep) if (e) (void)hipEventDestroy(e);
   if (s->h_cfl) (void)hipHostFree(s->h_cfl);
   for (hipEvent_t e : s->wait_ev) (void)hipEventDestroy(e);
   delete s;
@@ -656,7 +707,8 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   const int c1[1] = {1};
   // sweep blocks with an exchange between them (else: thin slabs, short solves, pTol: the "last_pass" code below)
   const bool blocked = world > 1 && s->owned >= 4 * w && prm->jacobi_iter > w && !(prm->p_tol > 0.f);
-  const bool deep = blocked && s->cfg.schedule == FNX_SLAB_DEEP_FIRST;
+  const bool beside = blocked && s->cfg.schedule == FNX_SLAB_DEEP_BESIDE;
+  const bool deep = blocked && (s->cfg.schedule == FNX_SLAB_DEEP_FIRST || beside);
   // deep_first: the deep parts of the first sweep block read no ghost plane of div, its exchange is in flight behind them
   if (deep) SLAB_OK(post(s, fd, nullptr, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
   else SLAB_OK(xchg(s, fd, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
@@ -664,9 +716,9 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   // ---- 3. Jacobi: blocks of w sweeps between ghost exchanges of p
   const FnxGrid gj = grid_of(s);
   // lay: the row-quad layout of fnx_jacobi_pass_layout (bit 0: pin, bit 1: pout)
-  auto pass = [&](const float* pin, float* pout, int n, int kb, int ke, int kb2 = -1, int lay = 0) {
+  auto pass = [&](const float* pin, float* pout, int n, int kb, int ke, int kb2 = -1, int lay = 0, hipStream_t on = nullptr) {
     const int rc = fnx_jacobi_pass_layout(&gj, st->flags, W.div, pin, pout, n, kb, ke, kb2, pin ? lay : (lay & 2), W.jac, W.jac_bytes,
-                                          s->mask_valid ? 1 : 0, stream);
+                                          s->mask_valid ? 1 : 0, on ? on : stream);
     if (rc == FNX_OK) s->mask_valid = true;     // (a failed call may not have built the mask)
     return rc;
   };
@@ -718,6 +770,51 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
     // solver's row-quad layout, which the plane-range passes below do not)
     SLAB_OK(fnx_jacobi_sweeps_ex(&gj, st->flags, W.div, cur, prm->jacobi_iter, W.jac, W.jac_bytes, (s->mask_valid ? 1 : 0) | 2, stream));
     s->mask_valid = true;
+  } else if (beside) {
+    // "deep_beside" (slab.py:_jacobi_deep_beside): the plane ranges of "deep_first", the edge chain of a block issued on its
+    // own stream beside the deep chain: E_k waits for D_(k-1) only (what it reads just inside its split, and the array it
+    // overwrites below it); the edge stream also waits for the previous exchange and posts the next one; the next block's
+    // D_0 waits for the edge chain (join).  A block takes max(deep chain, exchange + edge chain) instead of their sum.
+    int split[FNX_SLAB_MAX_HALO];
+    for (int k = 0, sp = 0; k < npass; ++k) {
+      sp = k == 0 ? passes[k] : (sp + passes[k] > w ? sp + passes[k] : w);
+      split[k] = sp;
+    }
+    if (s->owned < 2 * split[npass - 1] + 1) return fnx::set_error(FNX_EINVAL, "slab too thin for the deep_first sweep block");
+    hipStream_t es = s->edge_stream;
+    bool first_launch = true;
+    while (remaining > w) {
+      remaining -= w;
+      SLAB_HIP(hipEventRecord(s->ev_fork, stream));        // fork: behind the previous block's join (first block: the staging pass)
+      SLAB_HIP(hipStreamWaitEvent(es, s->ev_fork, 0));
+      SLAB_OK(wait(s, es));                                // the ghost planes of `cur` (first block: of div): the EDGE stream waits
+      float *src = cur, *dst = nxt;
+      int done = 0;
+      for (int pi = 0; pi < npass; ++pi) {
+        const int n = passes[pi];
+        done += n;
+        const float* pin = (zero_in && pi == 0) ? nullptr : src;
+        SLAB_OK(pass(pin, dst, n, has_lo ? lo + split[pi] : 0, has_hi ? top - split[pi] : DL, -1, Q));
+        SLAB_HIP(hipEventRecord(s->ev_deep[pi], stream));
+        // E_pi behind D_(pi-1); the very first launch of a step may have built the solver's obstacle mask: E_0 behind it
+        if (pi > 0 || first_launch) SLAB_HIP(hipStreamWaitEvent(es, s->ev_deep[pi > 0 ? pi - 1 : 0], 0));
+        first_launch = false;
+        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q, es));
+        else {
+          if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], -1, Q, es));
+          if (has_hi) SLAB_OK(pass(pin, dst, n, top - split[pi], top + w - done, -1, Q, es));
+        }
+        float* t = src; src = dst; dst = t;
+      }
+      if (src != cur) { float* t = cur; cur = nxt; nxt = t; }
+      float* ff[1] = {cur};
+      SLAB_OK(post(s, ff, nullptr, c1, 1, w, es));         // posted behind the edge chain, from its stream
+      SLAB_HIP(hipEventRecord(s->ev_join, es));            // join: the next block's D_0 reads what the last edge part wrote
+      SLAB_HIP(hipStreamWaitEvent(stream, s->ev_join, 0));
+      zero_in = false;
+    }
+    SLAB_OK(wait(s, stream));
+    SLAB_OK(last_block());
   } else if (deep) {
     // "deep_first" (slab.py:_jacobi_deep_first): pass k of a block is cut split[k] planes inside each internal face; the deep
     // parts of all passes run first (no ghost plane read: the previous exchange is still in flight), then the wait, then

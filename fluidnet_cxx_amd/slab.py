@@ -207,7 +207,7 @@ class SlabSimulator:
         raises RuntimeError on EVERY rank when it exceeds 1 cell -- the bound the ghost widths, the advection windows and the
         overlapped U / density exchange rest on (a violation would otherwise read stale ghost planes silently).  Costs one
         pass over U and one 4-byte all-reduce(MAX) on the control path."""
-        assert schedule in ("last_pass", "edge_first", "deep_first")
+        assert schedule in ("last_pass", "edge_first", "deep_first", "deep_beside")
         self.cfl_check_every = int(cfl_check_every)
         self.schedule = schedule
         self.static_flags = static_flags     # the caller promises that flags and BC arrays do not change between steps
@@ -295,13 +295,15 @@ class SlabSimulator:
         if window:
             window(0, 0)
         blocked = l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w and not float(cfg.get("pTol", 0.0)) > 0.0
-        deep = self.schedule == "deep_first" and blocked
+        deep = self.schedule in ("deep_first", "deep_beside") and blocked
         # deep_first: the deep parts of the first sweep block read no ghost plane of div: its exchange is in flight behind them
         yield ("start" if deep else "xchg"), [div], max(w - 1, 1)
 
         ops.set_slab(l.z_offset, l.D_global)
         if float(cfg.get("pTol", 0.0)) > 0.0:
             cur = yield from self._jacobi_ptol(st, div)
+        elif deep and self.schedule == "deep_beside":
+            cur = yield from self._jacobi_deep_beside(st, div)
         elif deep:
             cur = yield from self._jacobi_deep_first(st, div)
         elif self.schedule == "edge_first" and blocked:
@@ -511,6 +513,94 @@ class SlabSimulator:
             cur, nxt = nxt, cur
         return cur
 
+    def _jacobi_deep_beside(self, st, div):
+        """Jacobi schedule "deep_beside": the plane ranges, arrays and arithmetic of "deep_first" (see there), with the edge chain of
+        a block issued BESIDE its deep chain instead of behind it -- on a second stream that also waits for the previous
+        exchange and posts the next one:
+
+            main stream   D0 ----------> D1 ----------> D2 ----------> [join] D0' ...
+            edge stream   [wait xchg] E0 --(D0)--> E1 --(D1)--> E2, post xchg [join]
+
+        (Dk / Ek: deep / edge part of pass k.)  What orders them is what they read and write: Ek reads the planes Dk-1 wrote
+        just inside its split and writes below the split, where Dk-1 was still reading the array Ek overwrites -- so Ek waits
+        for Dk-1, nothing else; the next block's D0 reads what E2 wrote and waits for the whole edge chain (the join).  A deep
+        launch of the solver occupies three quarters of the wave slots (one resident set of (tile, plane chunk) waves) and
+        runs at the pace of VALU issue; the short edge launches (latency-bound marches of 6-8 planes behind 4 lead-in planes)
+        fill the rest instead of running alone, and the two stream hand-overs around the exchange leave the main stream.
+        A block then takes max(deep chain, exchange + edge chain) instead of their sum.  Without a second stream (CPU
+        operator sets of the tests) the launches are issued in the same interleaved order on one queue: same bits."""
+        l, cfg, ops, w = self.l, self.cfg, self.ops, self.w
+        if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
+            self._pbuf = torch.zeros_like(st["p"])
+        cur, nxt = st["p"], self._pbuf
+        fresh = getattr(ops, "zero_start", False)
+        if not fresh:
+            cur.zero_()
+        lo, top = l.lo, l.lo + l.owned
+        has_lo, has_hi = l.rank > 0, l.rank < l.world - 1
+        flags = st["flags"]
+        passes = [1] * (w % 2) + [2] * (w // 2)
+        splits = self.deep_splits(passes, w)
+        assert l.owned >= 2 * splits[-1] + 1, "slab too thin for the deep_first sweep block"
+        remaining = int(cfg["jacobiIter"])
+        quad = w % 2 == 0 and remaining % 2 == 0 and hasattr(ops, "quad_ok") and ops.quad_ok(flags)
+        Q = dict(lay=3) if quad else {}
+        zero_in = fresh
+        side = self._side_stream(cur)
+        main = torch.cuda.current_stream(cur.device) if side is not None else None
+        ev_deep = [torch.cuda.Event() for _ in passes] if side is not None else None
+        import contextlib
+        on_edge = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        first_launch = True
+        # (the communication requests name the stream they are to be served on -- a generator must not yield inside a stream
+        # context: lockstep_step interleaves several ranks' generators on one thread)
+        while remaining > w:                 # a block that is followed by another one
+            remaining -= w
+            if side is not None:
+                side.wait_stream(main)       # fork: behind the previous block's join (first block: behind the staging pass)
+            yield ("wait", side)             # the ghost planes of `cur` (first block: of div) -- the EDGE stream waits
+            ops.set_slab(l.z_offset, l.D_global)
+            src, dst, done = cur, nxt, 0
+            for pi, n in enumerate(passes):
+                done += n
+                pin = None if (zero_in and pi == 0) else src
+                ops.jacobi_pass(flags, div, pin, dst, n, lo + splits[pi] if has_lo else 0, top - splits[pi] if has_hi else l.D_local, **Q)
+                if side is not None:
+                    ev_deep[pi].record(main)
+                with on_edge():
+                    if side is not None and (pi > 0 or first_launch):
+                        # E_pi behind D_(pi-1); the very first launch of a step may build the solver's obstacle mask: E0 behind it
+                        side.wait_event(ev_deep[pi - 1 if pi > 0 else 0])
+                    if has_lo and has_hi and getattr(ops, "two_ranges", False):       # both faces in one launch
+                        ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + splits[pi], top - splits[pi], **Q)
+                    else:
+                        if has_lo:
+                            ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done, lo + splits[pi], **Q)
+                        if has_hi:
+                            ops.jacobi_pass(flags, div, pin, dst, n, top - splits[pi], top + w - done, **Q)
+                first_launch = False
+                src, dst = dst, src
+            if src is not cur:
+                cur, nxt = nxt, cur
+            yield "start", [cur], w, None, side      # posted behind the edge chain, on its stream
+            ops.set_slab(l.z_offset, l.D_global)
+            if side is not None:
+                main.wait_stream(side)       # join: the next block's D0 reads what E_last wrote
+            zero_in = False
+
+        # the last block (<= w sweeps, no exchange after it): whole shrinking ranges
+        yield ("wait",)
+        ops.set_slab(l.z_offset, l.D_global)
+        done = 0
+        tail = [2] * (remaining // 2) + [1] * (remaining % 2)
+        for ti, n in enumerate(tail):
+            done += n
+            g = max(w - done, 0)
+            kw = (Q if ti < len(tail) - 1 else dict(lay=1)) if quad else {}
+            ops.jacobi_pass(flags, div, cur, nxt, n, lo - g if has_lo else 0, top + g if has_hi else l.D_local, **kw)
+            cur, nxt = nxt, cur
+        return cur
+
     def _jacobi_last_pass(self, st, div):
         """Jacobi schedule "last_pass": blocks of w sweeps between ghost exchanges (temporal blocking in z); the last
         pass of a block first produces the w planes each neighbour needs, posts their exchange, and computes the interior
@@ -584,7 +674,11 @@ class SlabSimulator:
         return cur
 
     def step(self, st):
+        import contextlib
         handle = None
+
+        def on(stream):      # a request may name the stream it is served on (deep_beside: the edge stream posts and waits)
+            return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         try:
             for req in self.phases(st):
                 if req[0] == "xchg":
@@ -593,9 +687,11 @@ class SlabSimulator:
                     if self.l.world > 1:
                         dist.all_reduce(req[1], op=dist.ReduceOp.MAX if req[0] == "allmax" else dist.ReduceOp.SUM, group=self.comm.group)
                 elif req[0] == "start":
-                    handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None)
+                    with on(req[4] if len(req) > 4 else None):
+                        handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None)
                 else:
-                    self.comm.finish(handle)
+                    with on(req[1] if len(req) > 1 else None):
+                        self.comm.finish(handle)
                     handle = None
         finally:
             self.ops.set_slab(0, 0)
@@ -661,13 +757,18 @@ def lockstep_step(sims, states, defer=False):
 
     def serve(reqs):
         width = reqs[0][2]
+        multi = any(len(q) > 4 and q[4] is not None for q in reqs)     # posted from side streams: order the copies by full syncs
+        if multi:
+            torch.cuda.synchronize()
         for r in range(len(sims) - 1):           # pair (r, r+1)
             lo, hi = sims[r].l, sims[r + 1].l
-            srcs = [q[3] if len(q) > 3 else q[1] for q in (reqs[r], reqs[r + 1])]     # arrays the edge planes are sent from
+            srcs = [q[3] if len(q) > 3 and q[3] is not None else q[1] for q in (reqs[r], reqs[r + 1])]     # arrays the edge planes are sent from
             for f_lo, f_hi, s_lo, s_hi in zip(reqs[r][1], reqs[r + 1][1], *srcs):
                 top = lo.lo + lo.owned
                 f_lo[:, :, top:top + width].copy_(s_hi[:, :, hi.lo:hi.lo + width])
                 f_hi[:, :, hi.lo - width:hi.lo].copy_(s_lo[:, :, top - width:top])
+        if multi:
+            torch.cuda.synchronize()
 
     while True:
         reqs = []

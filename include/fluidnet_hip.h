@@ -337,6 +337,12 @@ int fnx_slab_loopback_group_set_timeout(void* group, double seconds);
 int fnx_slab_loopback_group_reset(void* group);
 int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank);
 void fnx_slab_loopback_group_free(void* group);
+/* Link-model communicator (a rehearsal aid, not a transport): lets ONE process run the step of a middle rank (rank r of n with
+ * 0 < r < n - 1) on one GPU.  An exchange occupies its stream for latency_us + bytes per direction / gbytes_per_s (0 GB/s: no
+ * transfer time) and fills the ghost planes from the slab's own edge planes, so launch sequence, message sizes and stream
+ * ordering are those of a real run and the time a schedule leaves exposed for an assumed link can be measured; the field
+ * values are those of a periodic stack of this slab.  All-reduces return the rank's own value. */
+int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_per_s);
 void fnx_slab_comm_free(FnxSlabComm* comm);
 
 #define FNX_SLAB_MAX_HALO 64
@@ -346,8 +352,11 @@ void fnx_slab_comm_free(FnxSlabComm* comm);
  *               then the edge parts (short launches), whose last one produces the planes the neighbours need next
  *   EDGE_FIRST  the edge parts of all passes first (shrinking plane ranges), their exchange posted, the interior parts behind it
  *   LAST_PASS   whole passes; only the last pass of a block is split into edge and interior
+ *   DEEP_BESIDE the parts of DEEP_FIRST, the edge chain of a block on a second stream BESIDE its deep chain (edge part k waits
+ *               for deep part k-1 only; that stream also waits for the previous exchange and posts the next one): a block
+ *               takes max(deep chain, exchange + edge chain) instead of their sum
  * Slabs thinner than 4 sweep blocks, solves of at most one block and pTol > 0 always run LAST_PASS. */
-enum { FNX_SLAB_DEEP_FIRST = 0, FNX_SLAB_EDGE_FIRST = 1, FNX_SLAB_LAST_PASS = 2 };
+enum { FNX_SLAB_DEEP_FIRST = 0, FNX_SLAB_EDGE_FIRST = 1, FNX_SLAB_LAST_PASS = 2, FNX_SLAB_DEEP_BESIDE = 3 };
 typedef struct FnxSlabConfig {
   int B, H, W, D_global;    /* the whole domain */
   int rank, nranks;         /* D_global % nranks == 0 */
@@ -356,7 +365,7 @@ typedef struct FnxSlabConfig {
   int static_flags;         /* 1: flags and BC arrays never change between steps (solver mask and BC class map are kept) */
   int cfl_check_every;      /* every that many steps the step begins with max |U| dt over all ranks (one host sync);
                                > 1 cell returns FNX_ECFL on every rank.  0 = never */
-  int schedule;             /* FNX_SLAB_DEEP_FIRST (0, the default) / FNX_SLAB_EDGE_FIRST / FNX_SLAB_LAST_PASS */
+  int schedule;             /* FNX_SLAB_DEEP_FIRST (0, the default) / FNX_SLAB_EDGE_FIRST / FNX_SLAB_LAST_PASS / FNX_SLAB_DEEP_BESIDE */
 } FnxSlabConfig;
 typedef struct FnxSlab FnxSlab;
 /* Local geometry of a rank (what to allocate): planes it owns, ghosts below / above, global plane of local plane 0. */
