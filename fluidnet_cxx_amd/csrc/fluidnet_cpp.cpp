@@ -330,9 +330,10 @@ Tensor scalenet_pack(Tensor blob, bool is3D) {
   return packed;
 }
 
-// precision_mode: "fp32" (default: Winograd where the launch fills the chip) or "fp32_direct" (FNX_PRECISION_*)
+// precision_mode: "fp32" (default: Winograd where the launch fills the chip), "fp32_direct" or "bf16x6" (FNX_PRECISION_*)
 static int precision_of(const std::string& m) {
-  TORCH_CHECK(m == "fp32" || m == "fp32_direct", "precision_mode must be 'fp32' or 'fp32_direct', got '", m, "'");
+  TORCH_CHECK(m == "fp32" || m == "fp32_direct" || m == "bf16x6", "precision_mode must be 'fp32', 'fp32_direct' or 'bf16x6', got '", m, "'");
+  if (m == "bf16x6") return FNX_PRECISION_BF16X6;
   return m == "fp32_direct" ? FNX_PRECISION_FP32_DIRECT : FNX_PRECISION_FP32;
 }
 

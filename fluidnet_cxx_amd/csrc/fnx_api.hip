@@ -129,7 +129,7 @@ struct Prof {
 // them).  The marker library is resolved on request (fnx_roctx_enable), never linked: without it the ranges are no-ops.
 namespace {
 struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; std::atomic<bool> on{false}; } g_roctx;
-const char* const kProfNames[FNX_PROF_NTAGS] = {"fnx:jacobi", "fnx:conv_mfma", "fnx:advect", "fnx:stage", "fnx:conv_direct", "fnx:conv_mfma16"};
+const char* const kProfNames[FNX_PROF_NTAGS] = {"fnx:jacobi", "fnx:conv_mfma", "fnx:advect", "fnx:stage", "fnx:conv_direct", "fnx:conv_mfma16", "fnx:conv_bf16"};
 }  // namespace
 
 // A scope pops the range it pushed and no other: fnx_roctx_enable may be toggled (from another thread, or inside an open scope
@@ -845,7 +845,7 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
     // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),
     // so the concatenation is not materialised: U is projected in place.
     if (tail_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the CNN");
-    if (prm->precision_mode != FNX_PRECISION_FP32 && prm->precision_mode != FNX_PRECISION_FP32_DIRECT)
+    if (prm->precision_mode < FNX_PRECISION_FP32 || prm->precision_mode > FNX_PRECISION_BF16X6)
       return fail(FNX_EINVAL, "simulate_step: unknown precision_mode %d", prm->precision_mode);
     // without flags_stick the tail of the net's forward and the step's last setConstVals are one pass (fluidnet_core)
     if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, prm->precision_mode, st->p, st->U, tail, stream,

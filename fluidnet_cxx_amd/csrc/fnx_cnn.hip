@@ -30,8 +30,13 @@ inline bool mfma_layer(const ConvLayer& L) { return L.k == 3 && L.cin % 16 == 0 
 // the 3x3(x3) MFMA layers also run in the Winograd domain (conv3_wino3_kernel): their transformed weights G g G^T
 // ([dz][16][Cin][Cout], then the same values in the kernel's stage-contiguous order) follow the [tap][Cin][Cout] image
 inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_layer(L); }
+// FNX_PRECISION_BF16X6 (conv3_wbf_kernel): the wino layers with 64 output channels per workgroup; their transformed weights
+// cut into three bf16 pieces, in the kernel's MFMA operand layout (1.5x the fp32 image), follow the two fp32 images
+inline bool wbf_layer(const ConvLayer& L, bool is3d) { return wino_layer(L, is3d) && L.cin % 16 == 0 && L.cout % 64 == 0; }
 inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
-  if (wino_layer(L, is3d)) return layer_weight_floats(L, is3d) + 2 * (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
+  if (wino_layer(L, is3d))
+    return layer_weight_floats(L, is3d) + 2 * (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout +
+           (wbf_layer(L, is3d) ? (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout * 3 / 2 : 0);
   if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
@@ -797,6 +802,8 @@ __global__ void repack_wino3_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+#include "fnx_cnn_bf16x6.h"
+
 // ---------------------------------------------------------------------------------------------------
 // Implicit-GEMM 5x5(x5) convolution for the thin layers (3->32 and 32->8) on v_mfma_f32_16x16x4_f32 (exact fp32):
 //   D[cout 16][pixel 16] += A[cout][k] * B[k][pixel],  k = four consecutive input channels of one tap
@@ -1024,12 +1031,22 @@ bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t
   return true;
 }
 
-// direct: FNX_PRECISION_FP32_DIRECT -- no Winograd, every layer a direct sum over its taps
-void launch_conv(const ConvLayer& L, bool is3d, bool direct, const float* packed, const PackedLayer& pl, const float* x, float* y,
+// mode: FNX_PRECISION_* (FP32_DIRECT: no Winograd, every layer a direct sum over its taps; BF16X6: conv3_wbf_kernel where it applies)
+void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, const PackedLayer& pl, const float* x, float* y,
                  int B, int D, int H, int W, hipStream_t s) {
   ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
   // (the MFMA kernels address a stage of 8 channel volumes through one 32-bit buffer range: 2^27 cells per sample at
   // most; beyond that -- 137 GB per 128-channel activation -- the direct kernel below still works)
+  const bool direct = mode == FNX_PRECISION_FP32_DIRECT;
+  if (mode == FNX_PRECISION_BF16X6 && wbf_layer(L, is3d)) {
+    ProfScope ps(FNX_PROF_CONV_BF16, s);
+    const size_t nwino = (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
+    if (launch_conv_wbf(a, is3d, (const unsigned*)(packed + pl.w_off + layer_weight_floats(L, is3d) + 2 * nwino), s)) {
+      // six bf16 MFMA products per Winograd-domain multiply (16 per 2x2 outputs and z tap)
+      prof_add_work(FNX_PROF_CONV_BF16, (double)B * D * H * W * 2.0 * L.cin * L.cout * 4.0 * (is3d ? 3 : 1) * 6.0);
+      return;
+    }
+  }
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
@@ -1143,6 +1160,8 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
         float* w3 = w2 + (size_t)16 * kd * L.cin * L.cout;      // stage-contiguous     (conv3_wino3_kernel)
         pack_layer_wino_kernel<<<64, 256, 0, s>>>(blob + off, w2, L.cin, L.cout, kd);
         repack_wino3_kernel<<<64, 256, 0, s>>>(w2, w3, L.cin, L.cout, kd, wino3_rw(L.cout));
+        if (wbf_layer(L, is3d))                                 // FNX_PRECISION_BF16X6: three bf16 pieces, MFMA operand layout
+          pack_wbf_kernel<<<256, 256, 0, s>>>(w2, (unsigned*)(w3 + (size_t)16 * kd * L.cin * L.cout), L.cin, L.cout, kd);
       }
     }
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
@@ -1168,7 +1187,7 @@ size_t multiscale_ws_bytes(const GridDims& g, bool is3d) {
 
 void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                         hipStream_t s) {
-  const bool direct = precision_mode == FNX_PRECISION_FP32_DIRECT;
+  const int mode = precision_mode;
   const Sizes z = sizes(g, is3d);
   const size_t full = (size_t)g.B * g.DHW, half = (size_t)g.B * z.Dh * z.Hh * z.Wh, quart = (size_t)g.B * z.Dq * z.Hq * z.Wq;
   char* w = (char*)ws;
@@ -1184,7 +1203,7 @@ void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const 
     const float* cur = in;
     for (int l = 0; l < n; ++l) {
       float* dst = (l == n - 1) ? out : ((l & 1) ? bufB : bufA);
-      launch_conv(LAYERS[l0 + l], is3d, direct, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s);
+      launch_conv(LAYERS[l0 + l], is3d, mode, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s);
       cur = dst;
     }
   };
@@ -1423,12 +1442,12 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
 }
 
-static bool bad_precision(int m) { return m != FNX_PRECISION_FP32 && m != FNX_PRECISION_FP32_DIRECT; }
+static bool bad_precision(int m) { return m < FNX_PRECISION_FP32 || m > FNX_PRECISION_BF16X6; }
 
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                            size_t ws_bytes, void* stream) {
   if (!g || !packed || !x || !p || !ws) return FNX_EINVAL;
-  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32 or FNX_PRECISION_FP32_DIRECT)", precision_mode);
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6)", precision_mode);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   fnx::multiscale_forward(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream);
@@ -1438,7 +1457,7 @@ int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x,
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float thr, float* p_out,
                          float* U_out, int precision_mode, void* ws, size_t ws_bytes, void* stream) {
   if (!g || !packed || !input || !p_out || !U_out || !ws) return FNX_EINVAL;
-  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32 or FNX_PRECISION_FP32_DIRECT)", precision_mode);
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6)", precision_mode);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;

@@ -224,7 +224,7 @@ typedef struct FnxStepParams {
   int   jacobi_iter;          /* mconf['jacobiIter'] */
   int   method;               /* 0 = 'jacobi', 1 = 'convnet' */
   float normalize_threshold;  /* mconf['normalizeInputThreshold'] (convnet) */
-  int   precision_mode;       /* convnet: FNX_PRECISION_FP32 (0, the default) or FNX_PRECISION_FP32_DIRECT, see fnx_multiscale_forward */
+  int   precision_mode;       /* convnet: FNX_PRECISION_FP32 (0, the default), FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6, see fnx_multiscale_forward */
   int   static_flags;         /* promises about the previous fnx_simulate_step on this workspace (no reference key; every
                                  reference simulation keeps its flags and BC arrays fixed):
                                  bit 0: `flags` is unchanged -> the 3D Jacobi solver reuses the obstacle mask it left there;
@@ -405,14 +405,19 @@ int fnx_slab_comm_probe(const FnxSlabComm* comm, void* scratch, size_t bytes, in
 size_t fnx_scalenet_weight_floats(int is3D);
 size_t fnx_scalenet_packed_bytes(int is3D);
 int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* stream);
-/* precision_mode of the CNN entry points (and FnxStepParams.precision_mode).  Both are exact-fp32 arithmetic on
- * v_mfma_f32_*_f32 (no reduced-precision path exists; an opt-in split-bf16 mode would get its own value here and its own label in
- * every report):
+/* precision_mode of the CNN entry points (and FnxStepParams.precision_mode).  The first two are exact-fp32 arithmetic on
+ * v_mfma_f32_*_f32; the third is opt-in and carries its own label in every report (bench.py never puts it in the headline):
  *   FNX_PRECISION_FP32         the default: 3x3(x3) layers of launches that fill the chip run in the Winograd F(2x2,3x3) domain
  *                              (2.25x fewer multiplies, not the summation order of a direct convolution; within 1e-5 |ref|max of
  *                              the torch reference, tests/test_parity_gpu.py)
- *   FNX_PRECISION_FP32_DIRECT  every convolution as a direct sum over its taps (implicit GEMM), no Winograd */
-enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1 };
+ *   FNX_PRECISION_FP32_DIRECT  every convolution as a direct sum over its taps (implicit GEMM), no Winograd
+ *   FNX_PRECISION_BF16X6       FNX_PRECISION_FP32 with the Winograd-domain GEMMs of the 64- and 128-output-channel 3x3(x3) layers on
+ *                              the bf16 matrix cores: every fp32 operand cut EXACTLY into three bf16 pieces (8 + 8 + 8 significand
+ *                              bits), a product evaluated as six bf16 x bf16 MFMAs with fp32 accumulation (the three dropped
+ *                              cross terms are below 2^-23 of the product: the size of one fp32 rounding).  Same tolerance as the
+ *                              other modes in the tests (1e-5 |ref|max against oracle and goldens); every other layer as in
+ *                              FNX_PRECISION_FP32 */
+enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2 };
 /* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                            void* ws, size_t ws_bytes, void* stream);
@@ -425,7 +430,7 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
  * later launches are not recorded).  fnx_profile_read synchronises the recorded events and returns the summed
  * kernel time and the number of launches of that class; fnx_profile_enable(1) also clears earlier records. */
 enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PROF_STAGE = 3, FNX_PROF_CONV_DIRECT = 4,
-       FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_NTAGS = 6 };
+       FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_CONV_BF16 = 6 /* FNX_PRECISION_BF16X6 launches; work = bf16 MFMA FLOPs issued */, FNX_PROF_NTAGS = 7 };
 int fnx_profile_enable(int on);
 /* roctx ranges ("fnx:jacobi", "fnx:advect", "fnx:stage", "fnx:conv_*") around the enqueue of the same kernel classes, for
  * `rocprofv3 --marker-trace`.  The marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is loaded by this call,

@@ -531,6 +531,39 @@ def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
         assert_close_rel(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 1e-5, "MultiScaleNet")
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 16, 126, 130), (1, 6, 72, 300)])
+def test_cnn_bf16x6_vs_oracle(dev, oracle, shape):
+    """precisionMode 'bf16x6' (FNX_PRECISION_BF16X6: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
+    product, conv3_wbf_kernel) at the SAME tolerance as the exact-fp32 modes -- 1e-5 of |ref|max against the oracle -- on grids
+    with partial tiles, odd sizes, batch 2, 3D (z borders: two- and three-plane stage lists); and it is another kernel than the
+    default's (different bits), no further from the oracle than a few times the default is."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    B, D, H, W = shape
+    is3d = D > 1
+    nd = 3 if is3d else 2
+    w = make_scalenet_weights(0, ndim=nd)
+    s = random_state(B, D, H, W, 0.5, seed=12)
+    inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
+    po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, nd), inp)
+    outs = {}
+    for mode in ("bf16x6", "fp32"):
+        mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                     normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d, precisionMode=mode)
+        net = FluidNet.from_weights(mconf, w, dev)
+        p, U = net(T(inp, dev))
+        outs[mode] = N(p)
+        assert_close_rel(N(p), po, 1e-5, f"FluidNet p ({mode})"); assert_close_rel(N(U), Uo, 1e-5, f"FluidNet U ({mode})")
+    assert not np.array_equal(outs["bf16x6"], outs["fp32"]), "precisionMode='bf16x6' did not select another kernel"
+    e6 = np.abs(outs["bf16x6"].astype(np.float64) - po).max(); e32 = np.abs(outs["fp32"].astype(np.float64) - po).max()
+    assert e6 <= 4.0 * e32 + 1e-7 * np.abs(po).max(), f"bf16x6 is {e6 / max(e32, 1e-300):.1f}x further from the oracle than fp32 ({e6:.3e} vs {e32:.3e})"
+    # the MultiScaleNet alone, on inputs of O(1) magnitude
+    x = np.random.default_rng(3).standard_normal((B, 2, D, H, W)).astype(np.float32)
+    xt = T(x, dev) if is3d else T(x[:, :, 0], dev)
+    want = oracle.multiscale_forward(oracle.pack_weights(w, nd), x)
+    assert_close_rel(N(net.multiScale(xt)).reshape(want.shape), want, 1e-5, "MultiScaleNet")
+
+
 def test_fluidnet_built_like_the_reference_driver(dev, golden):
     """plume.py:119-123 verbatim: FluidNet(mconf, dropout=False) -> .cuda() -> .load_state_dict(state['state_dict']) ->
     forward; and a net moved / reloaded after its first forward repacks its weights."""
@@ -618,6 +651,12 @@ def test_cnn_benchmark_size(dev, oracle, tmp_path, shape):
     torch.cuda.empty_cache()
     assert not np.array_equal(got, direct), "precision_mode='fp32_direct' did not select another kernel"
     assert_close_rel(got, direct, 1e-5, f"Winograd vs direct MFMA conv at {shape}")
+    # (3) the opt-in bf16x6 mode (six bf16 MFMA products per fp32 product) over the whole field, same tolerance
+    b6 = forward(x, precision_mode="bf16x6")
+    torch.cuda.empty_cache()
+    assert not np.array_equal(got, b6), "precision_mode='bf16x6' did not select another kernel"
+    assert_close_rel(b6, direct, 1e-5, f"bf16x6 Winograd vs direct MFMA conv at {shape}")
+    del b6
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     blob = oracle.pack_weights(make_scalenet_weights(0, ndim=3 if is3d else 2), 3 if is3d else 2)
     M = 48                                                           # margin kept from a crop's artificial edges

@@ -1,13 +1,28 @@
-import sys, os; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+"""GPU-box probe: error of each precision mode of the MultiScaleNet forward against the CPU oracle (fp32, direct sums) and against
+an fp64 evaluation of the same net on the host (torch, CPU), on a 515 x 509 random input (2D) and a 16 x 126 x 130 one (3D).
+usage: python tools/cnn_error_probe.py [2d|3d]"""
+import os, sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 from oracle import oracle as O
 from fluidnet_cxx_amd import FluidNet
 from fluidnet_cxx_amd.weights import make_scalenet_weights
-dev=torch.device('cuda:0')
-w=make_scalenet_weights(0)
-mconf=dict(model="ScaleNet", inputChannels=dict(div=True,pDiv=False,UDiv=False), normalizeInput=True, normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=False)
-net=FluidNet.from_weights(mconf,w,dev)
-x=np.random.default_rng(3).standard_normal((1,2,1,515,509)).astype(np.float32)
-out=net.multiScale(torch.from_numpy(x).to(dev)).cpu().numpy()
-ref=O.multiscale_forward(O.pack_weights(w,2),x)
-print("FNX_CONV_WINO=%s: max|d| %.3e, max|ref| %.3e, rel %.3e" % (os.environ.get("FNX_CONV_WINO","2"), np.abs(out-ref).max(), np.abs(ref).max(), np.abs(out-ref).max()/max(1,np.abs(ref).max())))
+dev = torch.device('cuda:0')
+for case in (sys.argv[1:] or ["2d", "3d"]):
+    is3d = case == "3d"
+    nd = 3 if is3d else 2
+    w = make_scalenet_weights(0, ndim=nd)
+    shape = (1, 2, 16, 126, 130) if is3d else (1, 2, 1, 515, 509)
+    x = np.random.default_rng(3).standard_normal(shape).astype(np.float32)
+    ref = O.multiscale_forward(O.pack_weights(w, nd), x)
+    outs = {}
+    for mode in ("fp32", "fp32_direct", "bf16x6"):
+        mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                     normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d, precisionMode=mode)
+        net = FluidNet.from_weights(mconf, w, dev)
+        t = torch.from_numpy(x).to(dev)
+        out = net.multiScale(t if is3d else t[:, :, 0].contiguous()).cpu().numpy().reshape(ref.shape)
+        outs[mode] = out
+        d = np.abs(out.astype(np.float64) - ref).max()
+        print(f"{case} {mode:12s}: max|d| vs oracle {d:.3e}, |ref|max {np.abs(ref).max():.3e}, relative {d / np.abs(ref).max():.3e}", flush=True)
+    print(f"{case} bf16x6 vs fp32: max|d| {np.abs(outs['bf16x6'].astype(np.float64) - outs['fp32']).max():.3e}; identical: {np.array_equal(outs['bf16x6'], outs['fp32'])}")
