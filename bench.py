@@ -74,7 +74,8 @@ DEVELOP_STEPS = 100          # "warm-up 100 steps so a plume exists"
 
 # algorithmic bytes per cell, 2D / 3D
 STEP_BYTES = {False: lambda n: 340 + 16 * n, True: lambda n: 452 + 16 * n}
-PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4, conv_mfma16=5)
+PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4, conv_mfma16=5, conv_bf16=6)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 # plumeConfig.yaml:29-76 with BASELINE.json's overrides (jacobiIter per workload, pTol 0)
 PLUME_CFG = dict(dt=0.1, maccormackStrength=0.6, sampleOutsideFluid=False, buoyancyScale=0.25, gravityScale=0,
@@ -94,9 +95,13 @@ WORKLOADS = {
     # the training-shaped call (fluid_net_train.py:349-373, trainConfig.yaml batchSize 32/64 at 128^2): the long-term rollout runs
     # `simulate(..., 'convnet')` on the whole batch under no_grad; a step here is one such call on 32 samples
     "plume2d_128_b32_cnn": dict(res=128, D=1, method="convnet", iters=0, kind="plume", batch=32),
+    # OPT-IN precision mode, never the headline: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
+    # product (FNX_PRECISION_BF16X6; same 1e-5 |ref|max tolerance against the oracle as the exact-fp32 modes, tests/)
+    "plume2d_1024_cnn_bf16x6": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x6"),
+    "plume3d_256_cnn_bf16x6": dict(res=256, D=256, method="convnet", iters=0, kind="plume", precision="bf16x6"),
 }
 ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_cnn",
-        "plume3d_hbm_jacobi", "plume2d_128_b32_cnn"]
+        "plume3d_hbm_jacobi", "plume2d_128_b32_cnn", "plume2d_1024_cnn_bf16x6", "plume3d_256_cnn_bf16x6"]
 METRIC_CONFIGS = ["plume3d_256_jacobi", "plume2d_1024_cnn"]      # the two configurations BASELINE.json's metric is quoted on
 
 
@@ -164,6 +169,8 @@ def mconf_for(w):
     m["jacobiIter"] = max(w["iters"], 1)
     m.update(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
              normalizeInputChan="UDiv", is3D=w["D"] > 1)
+    if w.get("precision"):
+        m["precisionMode"] = w["precision"]
     return m
 
 
@@ -307,16 +314,30 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     traffic_src = (traffic_detail or {}).get("source")
     if w["method"] == "convnet":
         tms, nl = times["conv_mfma"]
+        if w.get("precision") == "bf16x6":      # achieved/frac: all the 3x3(x3) MFMA layers, whichever kernel ran them
+            tms, nl = tms + times["conv_bf16"][0], nl + times["conv_bf16"][1]
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
         ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
         util = issued["conv_mfma"] / (tms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if tms > 0 else 0.0
+        if w.get("precision") == "bf16x6":
+            util = None                          # (two instruction kinds in one figure would mean nothing: see roofline.bf16x6)
         kname = ("conv3_wino3_kernel<2,2," + ("true" if is3d else "false") + "> (+ <1,2,.> for the 32-channel outputs; persistent software pipeline; 3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
         avg_ms = tms / max(nl, 1)
+        if w.get("precision") == "bf16x6":
+            # the opt-in mode: its own kernel, priced against the bf16 MFMA peak on the bf16 FLOPs it issues (six per fp32 product)
+            tb, nb = times["conv_bf16"]
+            ub = issued["conv_bf16"] / (tb * 1e-3) / 1e12 if tb > 0 else 0.0
+            roof_bf16 = dict(kernel="conv3_wbf_kernel<" + ("true" if is3d else "false") + "> (FNX_PRECISION_BF16X6: Winograd-domain GEMMs as six "
+                             "v_mfma_f32_32x32x16_bf16 per fp32 product; the 32-output-channel layers stay on conv3_wino3_kernel)",
+                             achieved=ub, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s (bf16 issued)", frac=ub / MFMA_BF16_PEAK_TF,
+                             launches_per_step=nb / prof_steps, ms_per_step=tb / prof_steps)
+        else:
+            roof_bf16 = None
         roof = dict(bound="mfma", kernel=kname, achieved=ach,
-                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, mfma_util=util,
+                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, mfma_util=util, bf16x6=roof_bf16,
                     issued_tflop_per_step=issued["conv_mfma"] / prof_steps / 1e12, traffic=traffic, traffic_source=traffic_src,
                     frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                     traffic_detail=traffic_detail,
@@ -347,7 +368,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
                             global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]], batch=w.get("batch", 1),
-                            cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"],
+                            cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"], precision=w.get("precision", "fp32"),
                             parallelism=("1 GPU" if world == 1 else
                                          f"{world} z-slabs, neighbour P2P ghost exchange (RCCL send/recv), halo 6, 6 sweeps per exchange, "
                                          f"schedule {schedule}"),
@@ -457,6 +478,9 @@ def _short(res):
              frac=_r(rf.get("frac")), step_hbm_frac=_r(res.get("step_hbm_frac")))
     if rf.get("bound") == "mfma":
         e["mfma_util"] = _r(rf.get("mfma_util"))
+        if rf.get("bf16x6"):
+            e["precision"] = "bf16x6 (opt-in)"
+            e["bf16_mfma_util"] = _r(rf["bf16x6"]["frac"])
     e["frac_traffic"] = _r(rf.get("frac_traffic"))
     if res.get("samples_per_s"):
         e["samples_per_s"] = _r(res["samples_per_s"], 5)
@@ -604,7 +628,7 @@ def main():
         # the other configurations the metric / north star name (single-GPU by definition), measured in the same run
         out["also"] = {}
         for other in ALSO:
-            big = other in ("plume3d_256_cnn", "plume3d_hbm_jacobi")
+            big = other in ("plume3d_256_cnn", "plume3d_hbm_jacobi", "plume3d_256_cnn_bf16x6")
             try:
                 r = run_workload(other, min(a.steps, 5 if big else 20), min(a.warmup, 2 if big else 5), not a.no_graph, 1, 0, dev)
                 out["also"][other] = {k: r[k] for k in ("value", "unit", "steps_per_s", "samples_per_s", "ms_per_step", "step_hbm_frac", "steps",

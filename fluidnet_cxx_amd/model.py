@@ -46,6 +46,7 @@ class MultiScaleNet:
         self.is3D = bool(is3D)
         # "fp32": exact-fp32 MFMA arithmetic, 3x3 layers in the Winograd domain where the launch fills the chip;
         # "fp32_direct": every convolution a direct sum over its taps (include/fluidnet_hip.h: FNX_PRECISION_*)
+        # "bf16x6" (opt-in): the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32 product
         self.precision_mode = precision_mode
         blob = torch.from_numpy(blob_from_state_dict(state_dict, 3 if is3D else 2)).to(device)
         self.packed = ext.scalenet_pack(blob, self.is3D)
@@ -74,7 +75,7 @@ class FluidNet:
         self.inDims = mconf.get("inputDim", 2)
         self.is3D = bool(mconf.get("is3D", False))
         self.threshold = float(mconf.get("normalizeInputThreshold", 1e-5))
-        # not a reference key: "fp32" (default) or "fp32_direct" (no Winograd), see MultiScaleNet
+        # not a reference key: "fp32" (default), "fp32_direct" (no Winograd) or "bf16x6" (opt-in), see MultiScaleNet
         self.precision_mode = str(mconf.get("precisionMode", "fp32"))
         self.training = False
         self._ndim = 3 if self.is3D else 2

@@ -189,6 +189,37 @@ class NativeOps:
         """max |x| as a 0-dim tensor on x's device (no host sync)"""
         return self.ext.max_abs(x)
 
+    # ---- the CNN projection's pieces (SlabSimulator._convnet_projection) ----
+    def convnet_stage(self, U_adv, rho_adv, st, cfg):
+        """setConstVals, addBuoyancy, setConstVals on the window (simulate.py:96-133 of the convnet method: no wall BCs)"""
+        gv = cfg["gravityVec"]
+        self.ext.pre_projection_(U_adv, rho_adv, st["p"], st["U"], st["flags"], st.get("density"), st.get("UBC"),
+                                 st.get("UBCInvMask"), st.get("densityBC"), st.get("densityBCInvMask"), float(cfg["dt"]),
+                                 float(cfg["buoyancyScale"]), [float(gv["x"]), float(gv["y"]), float(gv["z"])],
+                                 float(cfg.get("operatingDensity", 0.0)), False, self._bc_class(st), self._geom())
+
+    def divergence(self, U, flags):
+        return self.ext.velocity_divergence(U, flags, self._geom(False))
+
+    def occupancy(self, flags):
+        return self.ext.flags_to_occupancy(flags)
+
+    def multiscale(self, net, x):
+        return net.multiScale(x)
+
+    def convnet_post(self, pn, Un, s, st):
+        """model.py:190-227 + simulate.py:154-168 on the window: U = (Un - grad pn) * s, p = pn * s, setWallBcs, setConstVals"""
+        g = self._geom()
+        self.ext.velocity_update_(pn, Un, st["flags"], g)
+        k0, k1 = self._win if self._win[1] > self._win[0] else (0, Un.shape[2])
+        st["U"][:, :, k0:k1] = Un[:, :, k0:k1] * s
+        st["p"][:, :, k0:k1] = pn[:, :, k0:k1] * s
+        self.ext.set_wall_bcs_(st["U"], st["flags"], g)
+        if st.get("UBC") is not None or st.get("densityBC") is not None:
+            # (pointwise: the ghost planes it also touches are refreshed by the next step's exchange)
+            self.ext.set_const_vals_(st["U"], st.get("UBC"), st.get("UBCInvMask"), st.get("density"), st.get("densityBC"),
+                                     st.get("densityBCInvMask"))
+
     def post_projection(self, st, density_bc_applied=False):
         # density_bc_applied (FnxState.density_bc_applied): the caller's promise that pre_projection of THIS step has applied
         # the density BCs on the same planes with the same BC arrays -- the pass then leaves the density of identity-class cells
@@ -201,13 +232,24 @@ class NativeOps:
 class SlabSimulator:
     """`simulate(mconf, batch_dict, None, 'jacobi')` for one rank's slab of a 3D domain (in place on `state`)."""
 
+    # ghost planes of the normalised velocity the CNN projection needs: the MultiScaleNet's receptive field (< 48 cells at full
+    # resolution: test_cnn_benchmark_size's crop margin) + 1 for the divergence; a multiple of 4 so that the quarter- and
+    # half-resolution grids of a rank's crop coincide with the global ones
+    NET_MARGIN = 48
+
     def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4, schedule="deep_first",
-                 static_flags=False, cfl_check_every=8):
+                 static_flags=False, cfl_check_every=8, method="jacobi", net=None):
         """cfl_check_every: every that many steps (0 = never) the step starts by reducing max |U| dt over all ranks and
         raises RuntimeError on EVERY rank when it exceeds 1 cell -- the bound the ghost widths, the advection windows and the
         overlapped U / density exchange rest on (a violation would otherwise read stale ghost planes silently).  Costs one
         pass over U and one 4-byte all-reduce(MAX) on the control path."""
         assert schedule in ("last_pass", "edge_first", "deep_first", "deep_beside")
+        assert method in ("jacobi", "convnet")
+        self.method, self.net = method, net
+        if method == "convnet" and layout.world > 1:
+            assert net is not None, "method 'convnet' needs the net (a FluidNet, or any x -> p callable for the CPU operator sets)"
+            assert layout.halo >= self.NET_MARGIN + 1 and layout.owned % 4 == 0 and layout.halo % 4 == 0, \
+                "the CNN projection needs halo >= 49 ghost planes (a multiple of 4) and owned planes a multiple of 4"
         self.cfl_check_every = int(cfl_check_every)
         self.schedule = schedule
         self.static_flags = static_flags     # the caller promises that flags and BC arrays do not change between steps
@@ -291,6 +333,9 @@ class SlabSimulator:
                 U_adv = ops.advect_vel(dt, st["U"], st["flags"], strength)
         if window and l.world > 1:
             window(lo_, top_)
+        if self.method == "convnet":
+            yield from self._convnet_projection(st, U_adv, rho_adv, window, lo_, top_)
+            return
         div = ops.pre_projection(U_adv, rho_adv, st, cfg)
         if window:
             window(0, 0)
@@ -317,6 +362,55 @@ class SlabSimulator:
         if window and l.world > 1:
             window(lo_, top_)
         ops.post_projection(st, density_bc_applied=True)     # ops.pre_projection above ran on the same planes and BC arrays
+        if window:
+            window(0, 0)
+        ops.set_slab(0, 0)
+
+    def _convnet_projection(self, st, U_adv, rho_adv, window, lo_, top_):
+        """The CNN pressure projection on a z-slab (lib/simulate.py:96-168 with sim_method 'convnet', lib/model.py:118-227).
+
+        The staging pass (setConstVals, addBuoyancy, setConstVals -- no wall BCs in this method) runs on the owned planes.
+        _ScaleNet (model.py:8-23: the unbiased std of U over the WHOLE domain) becomes a control-path reduction: every rank sums
+        u and u^2 over its owned planes in fp64, the (sum, sumsq) pairs are all-gathered and added up in RANK ORDER on every rank --
+        the same bits everywhere, whatever the transport's reduction order would have been (not the single-domain kernel's
+        summation order: a tolerance statement, like every CNN comparison).  The normalised velocity's ghost planes (NET_MARGIN + 1)
+        are exchanged ONCE; each rank then evaluates the net on its owned planes +- NET_MARGIN -- a crop whose offset and depth are
+        multiples of 4, so its resampling grids coincide with the global ones and everything further than the receptive field
+        from the crop's artificial faces equals the single-domain result -- and finishes (velocityUpdate, un-normalise,
+        setWallBcs, setConstVals) on the owned planes.  Costs 2 x 48 redundant planes of net per interior rank: the simple, exact
+        variant (a per-layer halo exchange would remove the redundancy)."""
+        l, cfg, ops = self.l, self.cfg, self.ops
+        G = self.NET_MARGIN
+        ops.convnet_stage(U_adv, rho_adv, st, cfg)                   # -> st["U"], st["density"] on the owned planes
+        if window:
+            window(0, 0)
+        U, flags = st["U"], st["flags"]
+        B, nc = U.shape[0], U.shape[1]
+        own = U[:, :, lo_:top_].double()
+        part = torch.stack([own.sum(dim=(1, 2, 3, 4)), (own * own).sum(dim=(1, 2, 3, 4))], 1)      # (B, 2) fp64
+        gathered = [part]
+        yield "allgather", part, gathered                              # -> gathered: the ranks' pairs in rank order
+        tot = torch.zeros_like(part)
+        for g_ in gathered:                                            # fixed order: the same bits on every rank
+            tot = tot + g_.to(part.device)
+        n = float(nc) * l.D_global * U.shape[3] * U.shape[4]
+        var = ((tot[:, 1] - tot[:, 0] * tot[:, 0] / n) / (n - 1.0)).clamp_min(0.0)
+        thr = float(cfg.get("normalizeInputThreshold", 1e-5))
+        s = var.sqrt().float().clamp_min(thr).view(B, 1, 1, 1, 1)      # model.py:14-21
+        Un = torch.zeros_like(U)
+        Un[:, :, lo_:top_] = U[:, :, lo_:top_] / s
+        if l.world > 1:
+            yield "xchg", [Un], G + 1
+        ops.set_slab(l.z_offset, l.D_global)
+        e0 = max(lo_ - G, 0) if l.rank > 0 else 0
+        e1 = min(top_ + G, l.D_local) if l.rank < l.world - 1 else l.D_local
+        div = ops.divergence(Un, flags)                                 # (valid on e0 .. e1: U_z of plane e1 is a ghost plane)
+        x = torch.cat([div[:, :, e0:e1], ops.occupancy(flags)[:, :, e0:e1]], 1).contiguous()
+        pn = torch.zeros_like(st["p"])
+        pn[:, :, e0:e1] = ops.multiscale(self.net, x)
+        if window and l.world > 1:
+            window(lo_, top_)
+        ops.convnet_post(pn, Un, s, st)                                 # velocityUpdate, * s, setWallBcs, setConstVals (owned planes)
         if window:
             window(0, 0)
         ops.set_slab(0, 0)
@@ -686,6 +780,11 @@ class SlabSimulator:
                 elif req[0] in ("allmax", "allsum"):
                     if self.l.world > 1:
                         dist.all_reduce(req[1], op=dist.ReduceOp.MAX if req[0] == "allmax" else dist.ReduceOp.SUM, group=self.comm.group)
+                elif req[0] == "allgather":
+                    if self.l.world > 1:
+                        out = [torch.empty_like(req[1]) for _ in range(self.l.world)]
+                        dist.all_gather(out, req[1].contiguous(), group=self.comm.group)
+                        req[2][:] = out
                 elif req[0] == "start":
                     with on(req[4] if len(req) > 4 else None):
                         handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None)
@@ -780,6 +879,11 @@ def lockstep_step(sims, states, defer=False):
         if all(r is None for r in reqs):
             break
         assert all(r is not None for r in reqs) and len({r[0] for r in reqs}) == 1, "ranks fell out of step"
+        if reqs[0][0] == "allgather":
+            parts = [r[1].clone() for r in reqs]
+            for r in reqs:
+                r[2][:] = [p_.to(r[1].device) for p_ in parts]
+            continue
         if reqs[0][0] in ("allmax", "allsum"):
             ts = [r[1] for r in reqs]
             red = torch.stack([t.to(ts[0].device) for t in ts])

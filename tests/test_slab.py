@@ -91,6 +91,37 @@ class OracleOps:
     def max_abs(self, x):
         return x.abs().max()
 
+    # ---- the CNN projection's pieces (SlabSimulator._convnet_projection) ----
+    def convnet_stage(self, U_adv, rho_adv, st, cfg):
+        O = self.O
+        n = {k: v.numpy() for k, v in st.items()}
+        U, rho = O.set_const_vals(U_adv.numpy(), n["UBC"], n["UBCInvMask"], rho_adv.numpy(), n["densityBC"], n["densityBCInvMask"])
+        gv = cfg["gravityVec"]
+        g = (np.array([gv["x"], gv["y"], gv["z"]], np.float32) * np.float32(-cfg["buoyancyScale"])).astype(np.float32)
+        U = O.add_buoyancy(U, n["flags"], rho, g, cfg["operatingDensity"], cfg["dt"])
+        U, rho = O.set_const_vals(U, n["UBC"], n["UBCInvMask"], rho, n["densityBC"], n["densityBCInvMask"])
+        st["U"].copy_(torch.from_numpy(U)); st["density"].copy_(torch.from_numpy(rho))
+
+    def divergence(self, U, flags):
+        return torch.from_numpy(self.O.velocity_divergence(U.numpy(), flags.numpy()))
+
+    def occupancy(self, flags):
+        return torch.from_numpy(self.O.flags_to_occupancy(flags.numpy()))
+
+    def multiscale(self, net, x):
+        return torch.from_numpy(net(x.numpy()))
+
+    def convnet_post(self, pn, Un, s, st):
+        O = self.O
+        n = {k: v.numpy() for k, v in st.items()}
+        U = O.velocity_update(pn.numpy(), Un.numpy(), n["flags"])
+        sn = s.numpy()
+        U = (U * sn).astype(np.float32)
+        U = O.set_wall_bcs(U, n["flags"])
+        U, rho = O.set_const_vals(U, n["UBC"], n["UBCInvMask"], n["density"], n["densityBC"], n["densityBCInvMask"])
+        st["U"].copy_(torch.from_numpy(U)); st["density"].copy_(torch.from_numpy(rho))
+        st["p"].copy_(torch.from_numpy((pn.numpy() * sn).astype(np.float32)))
+
     def post_projection(self, st, density_bc_applied=False):
         O = self.O
         n = {k: v.numpy() for k, v in st.items()}
@@ -233,6 +264,116 @@ def test_gloo_two_ranks_match_single_domain(tmp_path, schedule):
         z = np.load(tmp_path / f"rank{r}.npz")
         for k in ("U", "density", "p"):
             assert np.array_equal(z[k], ref[k][:, :, l.z_begin:l.z_begin + l.owned]), (k, r)
+
+
+CNN_CFG = dict(CFG, model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+               normalizeInputChan="UDiv", is3D=True, normalizeInputThreshold=1e-5)
+
+
+def _cnn_reference(gs, nsteps):
+    from oracle import oracle as O
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    blob = O.pack_weights(make_scalenet_weights(0, ndim=3), 3)
+    st = dict(gs)
+    for _ in range(nsteps):
+        st = O.simulate_step(st, CNN_CFG, "convnet", blob)
+    return st, (lambda x: O.multiscale_forward(blob, x, True))
+
+
+def _check_cnn_owned(st, ref, layout, what, density_exact=True):
+    """density bit for bit in a step from a common state (it does not pass through the net); p and U within 1e-5 of |ref|max (the
+    std's summation order and the launch geometry of a crop differ from the single domain's)"""
+    own = slice(layout.z_begin, layout.z_begin + layout.owned)
+    a = st["density"][:, :, layout.owned_slice].cpu().numpy(); b = ref["density"][:, :, own]
+    if density_exact:
+        assert np.array_equal(a.view(np.int32), b.view(np.int32)), f"{what}: density differs on rank {layout.rank}"
+    for k in ("p", "U") + (() if density_exact else ("density",)):
+        a = st[k][:, :, layout.owned_slice].cpu().numpy().astype(np.float64); b = ref[k][:, :, own]
+        scale = float(np.abs(ref[k]).max())
+        d = float(np.abs(a - b).max())
+        assert d <= 1e-5 * scale, f"{what}: {k} on rank {layout.rank}: max |d| = {d:.3e} > 1e-5 * {scale:.3e}"
+
+
+def test_lockstep_convnet_slabs_match_single_domain_cpu():
+    """The CNN projection on z-slabs (SlabSimulator(method='convnet')): two slabs of a 128-plane domain in lock-step with the
+    oracle as operator set and as net, two steps, against oracle.simulate_step(..., 'convnet') on the whole domain."""
+    from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
+    D, H, W, world, halo = 128, 12, 16, 2, 52
+    gs = global_state(D, H, W, seed=4)
+    gs["U"] = (gs["U"] * 0.4).astype(np.float32)                      # CFL < 1
+    ref1, net = _cnn_reference(gs, 1)
+    ref2, _ = _cnn_reference(ref1, 1)
+    layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
+    sims = [SlabSimulator(l, CNN_CFG, ops=OracleOps(), method="convnet", net=net) for l in layouts]
+    states = [local_state(gs, l) for l in layouts]
+    for n, ref in enumerate((ref1, ref2)):
+        lockstep_step(sims, states)
+        for l, st in zip(layouts, states):
+            # (the second step starts from velocities that agree to rounding only: its density too is a tolerance statement)
+            _check_cnn_owned(st, ref, l, f"cpu lockstep convnet, step {n + 1}", density_exact=(n == 0))
+
+
+def _dist_cnn_worker(rank, world, port, D, H, W, halo, out_dir):
+    import torch.distributed as dist
+    from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gs = global_state(D, H, W, seed=4)
+        gs["U"] = (gs["U"] * 0.4).astype(np.float32)
+        _, net = _cnn_reference(gs, 0)
+        layout = SlabLayout(D, world, rank, halo)
+        st = local_state(gs, layout)
+        sim = SlabSimulator(layout, CNN_CFG, ops=OracleOps(), method="convnet", net=net)
+        sim.step(st)
+        np.savez(os.path.join(out_dir, f"cnn_rank{rank}.npz"), **{k: st[k][:, :, layout.owned_slice].numpy() for k in ("U", "density", "p")})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_two_ranks_convnet_match_single_domain(tmp_path):
+    """world_size 2 over gloo: the (sum, sumsq) all-gather of the _ScaleNet std in rank order and the 49-plane exchange of the
+    normalised velocity between two processes; one step against the single-domain oracle."""
+    import torch.multiprocessing as mp
+    from fluidnet_cxx_amd.slab import SlabLayout
+    D, H, W, halo, world = 128, 12, 16, 52, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
+    mp.spawn(_dist_cnn_worker, args=(world, port, D, H, W, halo, str(tmp_path)), nprocs=world, join=True)
+    gs = global_state(D, H, W, seed=4)
+    gs["U"] = (gs["U"] * 0.4).astype(np.float32)
+    ref, _ = _cnn_reference(gs, 1)
+    for r in range(world):
+        l = SlabLayout(D, world, r, halo)
+        z = np.load(tmp_path / f"cnn_rank{r}.npz")
+        _check_cnn_owned({k: torch.from_numpy(np.pad(z[k], [(0, 0), (0, 0), (l.lo, l.hi), (0, 0), (0, 0)])) for k in ("U", "density", "p")}, ref, l,
+                         "gloo convnet")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_lockstep_convnet_slabs_match_single_domain_gpu(world):
+    """The CNN projection on z-slabs with the native operators: `world` slabs of 64 planes in lock-step on one device against the
+    single-domain `simulate(..., 'convnet')`, two steps (p, U within 1e-5 of |ref|max; the first step's density bit for bit)."""
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd.slab import SlabLayout, SlabSimulator, lockstep_step
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    dev = torch.device("cuda:0")
+    D, H, W, halo = 64 * world, 40, 72, 52
+    gs = global_state(D, H, W, seed=6)
+    gs["U"] = (gs["U"] * 0.4).astype(np.float32)
+    net = FluidNet.from_weights(CNN_CFG, make_scalenet_weights(0, ndim=3), dev)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
+    sims = [SlabSimulator(l, CNN_CFG, method="convnet", net=net, static_flags=True) for l in layouts]
+    states = [local_state(gs, l, dev) for l in layouts]
+    for n in range(2):
+        simulate(CNN_CFG, bd, net, "convnet")
+        ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
+        lockstep_step(sims, states)
+        for l, st in zip(layouts, states):
+            _check_cnn_owned(st, ref, l, f"gpu lockstep convnet world={world}, step {n + 1}", density_exact=(n == 0))
 
 
 def test_layout_arithmetic():
