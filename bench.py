@@ -484,7 +484,7 @@ def _short(res):
     e["frac_traffic"] = _r(rf.get("frac_traffic"))
     if res.get("samples_per_s"):
         e["samples_per_s"] = _r(res["samples_per_s"], 5)
-    return e
+    return {k: v for k, v in e.items() if v is not None}       # (the line has a 4 kB budget)
 
 
 def pmc_source(summary_file=None):

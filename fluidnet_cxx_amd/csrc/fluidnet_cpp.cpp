@@ -451,13 +451,15 @@ struct PySlab {
   FnxSlabConfig cfg{};
   std::shared_ptr<PySlabComm> comm;
   PySlab(int B, int H, int W, int D_global, int rank, int nranks, int halo, int sweeps_per_exchange, bool static_flags,
-         int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule) : comm(comm_) {
+         int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule, const std::string& method) : comm(comm_) {
     cfg.B = B; cfg.H = H; cfg.W = W; cfg.D_global = D_global; cfg.rank = rank; cfg.nranks = nranks; cfg.halo = halo;
     cfg.sweeps_per_exchange = sweeps_per_exchange; cfg.static_flags = static_flags ? 1 : 0; cfg.cfl_check_every = cfl_check_every;
     TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass" || schedule == "deep_beside",
                 "unknown z-slab schedule '", schedule, "'");
     cfg.schedule = schedule == "deep_first" ? FNX_SLAB_DEEP_FIRST : (schedule == "edge_first" ? FNX_SLAB_EDGE_FIRST :
                    (schedule == "deep_beside" ? FNX_SLAB_DEEP_BESIDE : FNX_SLAB_LAST_PASS));
+    TORCH_CHECK(method == "jacobi" || method == "convnet", "unknown z-slab method '", method, "'");
+    cfg.method = method == "convnet" ? 1 : 0;
     check_status(fnx_slab_create(&s, &cfg, comm ? &comm->c : nullptr));
   }
   ~PySlab() { fnx_slab_destroy(s); }
@@ -478,7 +480,8 @@ struct PySlab {
   void step(Tensor p, Tensor U, Tensor flags, Tensor density, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask,
             c10::optional<Tensor> densityBC, c10::optional<Tensor> densityBCInvMask, double dt, double maccormack_strength,
             bool sample_outside_fluid, double buoyancy_scale, std::vector<double> gravity_vec, double operating_density,
-            double p_tol, int jacobi_iter, Tensor workspace) {
+            double p_tol, int jacobi_iter, Tensor workspace, c10::optional<Tensor> net, const std::string& precision_mode,
+            double normalize_threshold) {
     check_field(U, "U");
     Geom none;
     FnxGrid g = grid_of(flags, true, &none);
@@ -493,6 +496,11 @@ struct PySlab {
     prm.buoyancy_scale = (float)buoyancy_scale;
     for (int a = 0; a < 3; ++a) prm.gravity_vec[a] = (float)gravity_vec[a];
     prm.operating_density = (float)operating_density; prm.p_tol = (float)p_tol; prm.jacobi_iter = jacobi_iter; prm.method = 0;
+    const bool cnn = net.has_value() && net->defined();
+    if (cnn) {                                       // the CNN projection (a driver created with method = "convnet")
+      TORCH_CHECK(net->is_cuda() && net->is_contiguous(), "net: the packed weights (scalenet_pack) on the GPU");
+      prm.method = 1; prm.precision_mode = precision_of(precision_mode); prm.normalize_threshold = (float)normalize_threshold;
+    }
     auto opt = [&](c10::optional<Tensor>& t, bool vel, const char* name) -> float* {
       if (!t.has_value() || !t->defined()) return nullptr;
       if (vel) check_vel(*t, g, name); else check_scalar(*t, g, name);
@@ -502,6 +510,7 @@ struct PySlab {
     st.p = p.data_ptr<float>(); st.U = U.data_ptr<float>(); st.flags = flags.data_ptr<float>(); st.density = density.data_ptr<float>();
     st.UBC = opt(UBC, true, "UBC"); st.UBCInvMask = opt(UBCInvMask, true, "UBCInvMask");
     st.densityBC = opt(densityBC, false, "densityBC"); st.densityBCInvMask = opt(densityBCInvMask, false, "densityBCInvMask");
+    if (cnn) st.net = net->data_ptr();
     c10::hip::HIPGuard guard(flags.get_device());
     check_status(fnx_slab_step(s, &prm, &st, workspace.data_ptr(), (size_t)workspace.numel() * workspace.element_size(), cur_stream(U)));
   }
@@ -736,9 +745,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   }, py::arg("comm"), py::arg("bytes"), py::arg("reps"), py::arg("scratch"),
         "average ms of one ghost exchange of `bytes` bytes with each neighbour (every rank must call it)");
   py::class_<PySlab>(m, "SlabDriver", "native z-slab driver of the 3D Jacobi step (fnx_slab_create / fnx_slab_step)")
-      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>, const std::string&>(), py::arg("B"), py::arg("H"),
+      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>, const std::string&, const std::string&>(), py::arg("B"), py::arg("H"),
            py::arg("W"), py::arg("D_global"), py::arg("rank"), py::arg("nranks"), py::arg("halo"), py::arg("sweeps_per_exchange"),
-           py::arg("static_flags") = false, py::arg("cfl_check_every") = 0, py::arg("comm") = nullptr, py::arg("schedule") = "deep_first")
+           py::arg("static_flags") = false, py::arg("cfl_check_every") = 0, py::arg("comm") = nullptr, py::arg("schedule") = "deep_first",
+           py::arg("method") = "jacobi")
       .def("stats_enable", &PySlab::stats_enable, py::arg("on"))
       .def("stats_read", &PySlab::stats_read, "dict(bytes_per_neighbour, wait_ms, exchanges) since stats_enable(True); synchronises")
       .def("layout", &PySlab::layout, "(owned planes, ghost planes below, above, global plane of local plane 0)")
@@ -746,7 +756,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("step", &PySlab::step, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"),
            py::arg("densityBC"), py::arg("densityBCInvMask"), py::arg("dt"), py::arg("maccormack_strength"),
            py::arg("sample_outside_fluid"), py::arg("buoyancy_scale"), py::arg("gravity_vec"), py::arg("operating_density"),
-           py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("workspace"), NoGil());
+           py::arg("p_tol"), py::arg("jacobi_iter"), py::arg("workspace"), py::arg("net") = py::none(), py::arg("precision_mode") = "fp32",
+           py::arg("normalize_threshold") = 1e-5, NoGil());
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
   m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });

@@ -42,6 +42,17 @@ void launch_pack_input(const GridDims& g, int nc, const float* div, const float*
 void launch_unscale(const GridDims& g, int nc, const float* scale, float* p, float* U, hipStream_t s);
 void launch_gather_input(const GridDims& g, int nc, const float* input, float* U, float* flags, hipStream_t s);
 
+// pieces of the CNN projection on a z-slab (fnx_slab_step with method 1; fnx_slab.hip)
+size_t window_sums_scratch_bytes(int B);                       // `partial` of launch_window_sums_encode
+// this rank's fp64 (sum, sumsq) of U over the planes [k0, k1) of every channel, as 3 floats per double in ITS slots of
+// red[nranks][B][2][3] (all other slots zero): a float all-reduce(sum) over the ranks then is an exact all-gather
+void launch_window_sums_encode(const GridDims& g, int nc, int k0, int k1, const float* U, int rank, int nranks, double* partial,
+                               float* red, hipStream_t s);
+// scale[b] = clamp(unbiased std over n elements, thr) from the gathered sums, added in rank order
+void launch_scale_from_sums(int nranks, int B, double n, float thr, const float* red, float* scale, hipStream_t s);
+// x[b,0] = div(U / scale[b]), x[b,1] = occupancy(flags) on the planes of g's compute window (U is not modified)
+void launch_pack_div(const GridDims& g, bool is3d, const float* U, const float* flags, const float* scale, float* x, hipStream_t s);
+
 }  // namespace fnx
 
 struct FnxGrid;

@@ -1299,7 +1299,9 @@ __global__ __launch_bounds__(256) void pack_div_kernel(GridDims g, const float* 
   constexpr int NC = IS3D ? 3 : 2;
   const float s = scale[b];
   const float* u = U + (size_t)b * NC * n1;
-  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n1; q += (size_t)gridDim.x * 256) {
+  // (planes of the compute window only: a z-slab's last ghost plane has no +1 neighbour in the array)
+  const size_t q0 = (size_t)g.K0 * g.HW, q1 = (size_t)(g.K0 + g.KN) * g.HW;
+  for (size_t q = q0 + (size_t)blockIdx.x * 256 + threadIdx.x; q < q1; q += (size_t)gridDim.x * 256) {
     const int i = (int)(q % g.W), j = (int)((q / g.W) % g.H), k = (int)(q / g.HW);
     const float f = flags[(size_t)b * n1 + q];
     float d = 0.f;
@@ -1343,7 +1345,80 @@ inline dim3 bgrid(size_t n1, int B) {
   return dim3((unsigned)blocks, B);
 }
 
+// ---- _ScaleNet on a z-slab (fnx_slab_step, method 1): the std over the WHOLE domain from per-rank sums ----
+constexpr int WIN_BLOCKS = 256;
+// block q of sample b: sum and sum of squares (fp64) of its share of the planes [k0, k1) of every channel, in a fixed order
+__global__ __launch_bounds__(256) void window_sums_partial_kernel(GridDims g, int nc, int k0, int k1, const float* __restrict__ U,
+                                                                  double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const size_t per = (size_t)(k1 - k0) * g.HW, n = per * nc;
+  const float* u = U + (size_t)b * nc * g.DHW;
+  double s = 0.0, ss = 0.0;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const size_t c = q / per, r = q - c * per;
+    const double v = (double)u[c * g.DHW + (size_t)k0 * g.HW + r];
+    s += v; ss += v * v;
+  }
+  __shared__ double red[8];
+  std_block_sum(s, ss, red);
+  if (threadIdx.x == 0) { partial[2 * ((size_t)b * WIN_BLOCKS + blockIdx.x)] = s; partial[2 * ((size_t)b * WIN_BLOCKS + blockIdx.x) + 1] = ss; }
+}
+// One block per sample: the partials in index order -> this rank's (sum, sumsq), written as three floats per double (exact:
+// 24 + 24 + 5 bits) into ITS slots of `red` ([rank][sample][2][3]); every other slot is zeroed.  A float all-reduce(sum) over the
+// ranks then IS an all-gather (x + 0 + ... + 0 is exact in any order), with the communicator's existing entry point.
+__global__ __launch_bounds__(256) void window_sums_encode_kernel(int rank, int nranks, int B, const double* __restrict__ partial,
+                                                                 float* __restrict__ red) {
+  const int b = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int q = threadIdx.x; q < WIN_BLOCKS; q += 256) { s += partial[2 * ((size_t)b * WIN_BLOCKS + q)]; ss += partial[2 * ((size_t)b * WIN_BLOCKS + q) + 1]; }
+  __shared__ double sh[8];
+  std_block_sum(s, ss, sh);
+  for (int q = threadIdx.x; q < nranks * 6; q += 256) red[((size_t)(q / 6) * B + b) * 6 + q % 6] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = red + ((size_t)rank * B + b) * 6;
+    const double v[2] = {s, ss};
+    for (int k = 0; k < 2; ++k) {
+      const float f1 = (float)v[k]; const double r1 = v[k] - (double)f1;
+      const float f2 = (float)r1; const float f3 = (float)(r1 - (double)f2);
+      o[3 * k] = f1; o[3 * k + 1] = f2; o[3 * k + 2] = f3;
+    }
+  }
+}
+// the ranks' sums added in RANK ORDER (the same bits on every rank), unbiased std over n elements, clamp(thr, inf)   (model.py:14-21)
+__global__ void scale_from_sums_kernel(int nranks, int B, double n, float thr, const float* __restrict__ red, float* __restrict__ scale) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0, ss = 0.0;
+  for (int r = 0; r < nranks; ++r) {
+    const float* o = red + ((size_t)r * B + b) * 6;
+    s += ((double)o[0] + (double)o[1]) + (double)o[2];
+    ss += ((double)o[3] + (double)o[4]) + (double)o[5];
+  }
+  double var = (ss - s * s / n) / (n - 1.0);
+  if (var < 0.0) var = 0.0;
+  const float sd = (float)sqrt(var);
+  scale[b] = sd < thr ? thr : sd;
+}
+
 }  // namespace
+
+size_t window_sums_scratch_bytes(int B) { return sizeof(double) * 2 * WIN_BLOCKS * (size_t)B; }
+void launch_window_sums_encode(const GridDims& g, int nc, int k0, int k1, const float* U, int rank, int nranks, double* partial,
+                               float* red, hipStream_t s) {
+  window_sums_partial_kernel<<<dim3(WIN_BLOCKS, g.B), 256, 0, s>>>(g, nc, k0, k1, U, partial);
+  window_sums_encode_kernel<<<g.B, 256, 0, s>>>(rank, nranks, g.B, partial, red);
+}
+void launch_scale_from_sums(int nranks, int B, double n, float thr, const float* red, float* scale, hipStream_t s) {
+  scale_from_sums_kernel<<<(B + 63) / 64, 64, 0, s>>>(nranks, B, n, thr, red, scale);
+}
+void launch_pack_div(const GridDims& g, bool is3d, const float* U, const float* flags, const float* scale, float* x, hipStream_t s) {
+  size_t blocks = ((size_t)g.KN * g.HW + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks, g.B);
+  if (is3d) pack_div_kernel<true><<<grid, 256, 0, s>>>(g, U, flags, scale, x);
+  else pack_div_kernel<false><<<grid, 256, 0, s>>>(g, U, flags, scale, x);
+}
 
 size_t scale_std_scratch_bytes(int B) { return sizeof(double) * 2 * STD_MAXB * (size_t)B; }
 

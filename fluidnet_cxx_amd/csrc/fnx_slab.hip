@@ -28,6 +28,7 @@
 
 #include "../../include/fluidnet_hip.h"
 #include "fnx_kernels.h"
+#include "fnx_cnn.h"
 
 namespace {
 
@@ -343,6 +344,10 @@ int layout_of(const FnxSlabConfig* c, int* owned, int* lo, int* hi, int* zoff) {
   if (c->halo > FNX_SLAB_MAX_HALO) return fnx::set_error(FNX_EINVAL, "slab: halo %d > %d planes is not supported", c->halo, FNX_SLAB_MAX_HALO);
   if (c->schedule < FNX_SLAB_DEEP_FIRST || c->schedule > FNX_SLAB_DEEP_BESIDE) return fnx::set_error(FNX_EINVAL, "slab: unknown schedule %d", c->schedule);
   if (c->nranks > 1 && ow < c->halo) return fnx::set_error(FNX_EINVAL, "slab thinner than its halo");
+  if (c->method != 0 && c->method != 1) return fnx::set_error(FNX_EINVAL, "slab: method %d (0: Jacobi, 1: CNN projection)", c->method);
+  if (c->method == 1 && c->nranks > 1 && (c->halo < FNX_SLAB_NET_MARGIN + 1 || c->halo % 4 != 0 || ow % 4 != 0))
+    return fnx::set_error(FNX_EINVAL, "slab: the CNN projection needs halo >= %d ghost planes, a multiple of 4, and owned planes a multiple of 4",
+                          FNX_SLAB_NET_MARGIN + 1);
   *owned = ow;
   *lo = c->rank > 0 ? c->halo : 0;
   *hi = c->rank < c->nranks - 1 ? c->halo : 0;
@@ -357,8 +362,19 @@ FnxGrid grid_of(const FnxSlab* s, int kb = 0, int ke = 0) {
   return g;
 }
 
+// the planes [e0, e1) of the local array the CNN projection evaluates the net on: owned +- FNX_SLAB_NET_MARGIN, clipped at the domain ends
+void net_range(const FnxSlab* s, int* e0, int* e1) {
+  const int lo = s->lo, top = s->lo + s->owned;
+  *e0 = s->cfg.rank > 0 ? lo - FNX_SLAB_NET_MARGIN : 0;
+  *e1 = s->cfg.rank < s->cfg.nranks - 1 ? top + FNX_SLAB_NET_MARGIN : s->D_local;
+}
+
 struct Work {                      // the step's scratch, carved from the caller's workspace
   float *rho_adv, *U_adv, *div, *pbuf, *cfl;   // cfl: max(64, B) floats (CFL number / per-sample sums of squares)
+  // CNN projection (cfg.method 1): net input on the local array / on the crop, the net's output on the crop, the gathered sums, scale
+  float *x_local, *x_crop, *p_crop, *red, *scale;
+  double* wpart;
+  void* msws;
   double* part;                                // the residual's fixed-order partial sums (pTol > 0)
   unsigned char* cls;
   void *jac, *adv;
@@ -375,6 +391,16 @@ size_t carve(const FnxSlab* s, void* ws, Work* w) {
   t.cfl = (float*)take((size_t)(g.B > 64 ? g.B : 64) * 4); t.part = (double*)take(fnx::residual_scratch_bytes(g.B)); t.cls = (unsigned char*)take(n1);
   t.jac_bytes = fnx_workspace_bytes(&g, FNX_OP_JACOBI); t.jac = take(t.jac_bytes);
   t.adv_bytes = fnx_workspace_bytes(&g, FNX_OP_ADVECT_STEP); t.adv = take(t.adv_bytes);
+  t.x_local = t.x_crop = t.p_crop = t.red = t.scale = nullptr; t.wpart = nullptr; t.msws = nullptr;
+  if (s->cfg.method == 1) {
+    int e0, e1;
+    net_range(s, &e0, &e1);
+    const size_t nc1 = (size_t)g.B * (e1 - e0) * g.H * g.W;
+    t.x_local = (float*)take(n1 * 8); t.x_crop = (float*)take(nc1 * 8); t.p_crop = (float*)take(nc1 * 4);
+    t.red = (float*)take((size_t)s->cfg.nranks * g.B * 6 * 4); t.scale = (float*)take((size_t)g.B * 4);
+    t.wpart = (double*)take(fnx::window_sums_scratch_bytes(g.B));
+    t.msws = take(fnx::multiscale_ws_bytes(make_dims(g.B, e1 - e0, g.H, g.W), true));
+  }
   if (w) *w = t;
   return off;
 }
@@ -639,8 +665,12 @@ int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void
 static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* vstream) {
   if (!s || !prm || !st) return fnx::set_error(FNX_EINVAL, "slab_step: NULL argument");
   if (!st->p || !st->U || !st->flags || !st->density) return fnx::set_error(FNX_EINVAL, "slab_step: the z-slab driver needs p, U, flags and a density field");
-  if (prm->method != 0) return fnx::set_error(FNX_EINVAL, "slab_step: only the Jacobi projection shards (the CNN configurations are single-GPU)");
-  if (prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
+  if (prm->method != 0 && prm->method != 1) return fnx::set_error(FNX_EINVAL, "slab_step: unknown method %d", prm->method);
+  if (prm->method == 1 && (s->cfg.method != 1 || !st->net))
+    return fnx::set_error(FNX_EINVAL, "slab_step: the CNN projection needs a driver created with cfg.method = 1 and st->net (the packed weights)");
+  if (prm->method == 1 && (prm->precision_mode < FNX_PRECISION_FP32 || prm->precision_mode > FNX_PRECISION_BF16X6))
+    return fnx::set_error(FNX_EINVAL, "slab_step: unknown precision_mode %d", prm->precision_mode);
+  if (prm->method == 0 && prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
   if (prm->viscosity != 0.f || prm->gravity_scale != 0.f || prm->correct_scalar || prm->periodic)
     return fnx::set_error(FNX_EINVAL, "slab_step: the optional stages (viscosity, gravityScale, correctScalar, periodic) are single-domain only");
   Work W;
@@ -697,6 +727,46 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   } else {
     SLAB_OK(xchg(s, f2, c2, 2, gw, stream));
     if (world > 1) SLAB_OK(advect(a_, b_)); else SLAB_OK(advect(0, 0));
+  }
+  if (prm->method == 1) {
+    // ---- the CNN projection (slab.py:_convnet_projection; lib/model.py:118-227, simulate.py:96-168 with 'convnet')
+    const FnxGrid gw = world > 1 ? grid_of(s, lo, top) : grid_of(s);
+    SLAB_OK(fnx_pre_projection(&gw, prm, &state, W.U_adv, W.rho_adv, nullptr, stream));     // setConstVals, addBuoyancy, setConstVals (owned planes)
+    const GridDims dl = make_dims(s->cfg.B, DL, s->cfg.H, s->cfg.W, s->z_offset, s->cfg.D_global);
+    // _ScaleNet: (sum, sumsq) of U over the owned planes -> every rank's pair on every rank -> std in rank order
+    fnx::launch_window_sums_encode(dl, 3, lo, top, st->U, rank, world, W.wpart, W.red, stream);
+    if (world > 1) {
+      SLAB_OK(s->comm.allreduce_sum(s->comm.ctx, W.red, world * s->cfg.B * 6, stream));
+      SLAB_HIP(hipStreamSynchronize(stream));                  // (the communicator's ordering contract: no exchange behind an all-reduce in flight)
+    }
+    fnx::launch_scale_from_sums(world, s->cfg.B, 3.0 * (double)s->cfg.D_global * s->cfg.H * s->cfg.W, prm->normalize_threshold, W.red, W.scale, stream);
+    // the un-normalised velocity's ghost planes, once (the net's input is div(U / s) on owned +- 48 planes)
+    float* fu[1] = {st->U};
+    const int c3[1] = {3};
+    SLAB_OK(xchg(s, fu, c3, 1, FNX_SLAB_NET_MARGIN + 1, stream));
+    int e0, e1;
+    net_range(s, &e0, &e1);
+    const int De = e1 - e0;
+    GridDims de = dl; de.K0 = e0; de.KN = De;
+    fnx::launch_pack_div(de, true, st->U, st->flags, W.scale, W.x_local, stream);
+    const size_t plane = (size_t)s->cfg.H * s->cfg.W, vol = plane * DL, volc = plane * De;
+    for (int b = 0; b < s->cfg.B; ++b)
+      for (int c = 0; c < 2; ++c)
+        SLAB_HIP(hipMemcpyAsync(W.x_crop + ((size_t)b * 2 + c) * volc, W.x_local + ((size_t)b * 2 + c) * vol + (size_t)e0 * plane, volc * 4,
+                                hipMemcpyDeviceToDevice, stream));
+    fnx::multiscale_forward(make_dims(s->cfg.B, De, s->cfg.H, s->cfg.W), true, st->net, W.x_crop, W.p_crop, prm->precision_mode, W.msws, stream);
+    // the net's output back at its place in a local array (only the planes e0 .. e1 of it are ever read: owned and owned - 1)
+    float* pn = W.div;
+    for (int b = 0; b < s->cfg.B; ++b)
+      SLAB_HIP(hipMemcpyAsync(pn + (size_t)b * vol + (size_t)e0 * plane, W.p_crop + (size_t)b * volc, volc * 4, hipMemcpyDeviceToDevice, stream));
+    // velocityUpdate on U / s, un-normalise, setWallBcs, the step's last setConstVals: one pass over the owned planes
+    GridDims dw = dl;
+    if (world > 1) { dw.K0 = lo; dw.KN = s->owned; }
+    const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+    fnx::launch_post_projection(dw, true, pn, st->U, st->density, st->flags, ubc ? st->UBC : nullptr, ubc ? st->UBCInvMask : nullptr,
+                                rbc ? st->densityBC : nullptr, rbc ? st->densityBCInvMask : nullptr, stream, state.bc_class, true, W.scale, st->p);
+    SLAB_HIP(hipGetLastError());
+    return FNX_OK;
   }
   // ---- 2. BC / buoyancy / wall stage + divergence on the owned planes
   {

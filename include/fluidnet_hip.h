@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 14
+#define FNX_ABI_VERSION 15
 
 enum {
   FNX_OK = 0,
@@ -366,7 +366,13 @@ typedef struct FnxSlabConfig {
   int cfl_check_every;      /* every that many steps the step begins with max |U| dt over all ranks (one host sync);
                                > 1 cell returns FNX_ECFL on every rank.  0 = never */
   int schedule;             /* FNX_SLAB_DEEP_FIRST (0, the default) / FNX_SLAB_EDGE_FIRST / FNX_SLAB_LAST_PASS / FNX_SLAB_DEEP_BESIDE */
+  int method;               /* 0: Jacobi projection; 1: the driver is also sized for the CNN projection (prm->method 1 in
+                               fnx_slab_step): needs halo >= FNX_SLAB_NET_MARGIN + 1, halo % 4 == 0, D_global / nranks % 4 == 0
+                               when nranks > 1, and a workspace that holds the net's activations for owned + 2 x 48 planes */
 } FnxSlabConfig;
+/* ghost planes of the MultiScaleNet's input a rank evaluates beyond its owned planes: the net's receptive field (< 48 cells at
+ * full resolution), a multiple of 4 so that the rank's quarter- and half-resolution grids coincide with the global ones */
+#define FNX_SLAB_NET_MARGIN 48
 typedef struct FnxSlab FnxSlab;
 /* Local geometry of a rank (what to allocate): planes it owns, ghosts below / above, global plane of local plane 0. */
 int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset);
@@ -374,8 +380,13 @@ size_t fnx_slab_workspace_bytes(const FnxSlabConfig* cfg);
 /* comm is borrowed (must outlive the slab).  nranks == 1 needs no communicator (comm may be NULL). */
 int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* comm);
 void fnx_slab_destroy(FnxSlab* s);
-/* One time step.  st: the rank's local arrays (with ghost planes), st->density required, st->net unused; prm->method
- * must be 0.  prm->p_tol > 0 runs the reference's convergence test (fluids_init.cpp:961-979): one sweep per ghost exchange,
+/* One time step.  st: the rank's local arrays (with ghost planes), st->density required.  prm->method 0: the Jacobi projection
+ * (st->net unused).  prm->method 1 (cfg.method 1, st->net = the packed weights): the CNN projection, lib/model.py:118-227 on
+ * z-slabs -- _ScaleNet's std over the whole domain from per-rank fp64 (sum, sumsq) gathered and added in RANK ORDER (the same
+ * bits on every rank; one host synchronisation), FNX_SLAB_NET_MARGIN + 1 ghost planes of U exchanged once, the net evaluated on
+ * owned +- FNX_SLAB_NET_MARGIN planes, velocityUpdate / un-normalise / setWallBcs / setConstVals on the owned planes: p and U
+ * within the CNN tolerance (1e-5 |ref|max) of the single-domain step, density bit for bit.
+ * Jacobi:  prm->p_tol > 0 runs the reference's convergence test (fluids_init.cpp:961-979): one sweep per ghost exchange,
  * the squared differences over the owned planes all-reduced over the ranks, one host sync per sweep (as in fnx_jacobi);
  * every rank's part reproducible (fnx_residual).  The bit-for-bit statement above holds for p_tol == 0; with p_tol > 0 every
  * sweep still has the single-domain bits, but the residual is summed per rank and then over the ranks (fp32 all-reduce), so a

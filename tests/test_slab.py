@@ -480,6 +480,55 @@ def test_native_driver_threads_match_single_domain_gpu(world, halo, w, static, i
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_driver_convnet_threads_match_single_domain_gpu(world):
+    """The C++ driver's CNN projection (fnx_slab_step, prm.method 1): `world` slabs of 64 planes, one host thread and stream
+    each, the in-process communicator (the std's all-gather as an exact float all-reduce, the 49-plane exchange of U): two steps
+    against the single-domain `simulate(..., 'convnet')` -- p, U within 1e-5 of |ref|max, the first step's density bit for bit."""
+    import threading
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    dev = torch.device("cuda:0")
+    D, H, W, halo = 64 * world, 40, 72, 52
+    gs = global_state(D, H, W, seed=6)
+    gs["U"] = (gs["U"] * 0.4).astype(np.float32)
+    net = FluidNet.from_weights(CNN_CFG, make_scalenet_weights(0, ndim=3), dev)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    refs = []
+    for _ in range(2):
+        simulate(CNN_CFG, bd, net, "convnet")
+        refs.append({k: bd[k].cpu().numpy() for k in ("U", "density", "p")})
+    layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
+    states = [local_state(gs, l, dev) for l in layouts]
+    group = ext.SlabLoopbackGroup(world)
+    sims = [NativeSlabSimulator(l, CNN_CFG, comm=ext.slab_comm_loopback(group, l.rank) if world > 1 else None, static_flags=True,
+                                cfl_check_every=2, method="convnet", net=net) for l in layouts]
+    torch.cuda.synchronize()
+    for n in range(2):
+        errs = []
+
+        def run(r):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    sims[r].step(states[r])
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:  # noqa: BLE001
+                errs.append((r, e))
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ts), "a rank's thread hangs"
+        assert not errs, errs
+        torch.cuda.synchronize()
+        for l, st in zip(layouts, states):
+            _check_cnn_owned(st, refs[n], l, f"native convnet driver world={world}, step {n + 1}", density_exact=(n == 0))
+
+
+@pytest.mark.gpu
 def test_native_driver_failing_rank_releases_its_neighbour():
     """A rank whose step fails (here: its workspace is too small) never joins the exchange its neighbour is already waiting
     in; the driver aborts the communicator, and the neighbour returns an error instead of hanging."""
