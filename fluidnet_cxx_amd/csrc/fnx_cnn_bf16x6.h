@@ -91,7 +91,13 @@ typedef __attribute__((address_space(3))) float* WbLdsF;
 // the transform from the OTHER copy; the compiler cannot prove that (also not with __restrict__ on the phase's parameters) and
 // puts an s_waitcnt vmcnt in front of the first ds_read after every DMA issue -- a global round trip per stage.  As inline asm the
 // reads carry no memory operand; the phase waits for them itself (lgkmcnt(0): LDS returns in order, and the compiler's own
-// counts stay on the safe side with more operations in flight).
+// counts stay on the safe side with more operations in flight).  The result registers are NOT valid before that wait: this holds
+// only while the compiler has no reason to touch them in between -- a variant of this kernel that spilled (256 VGPRs + scratch)
+// copied them early and computed garbage; the kernel as built uses 234 VGPRs and no scratch, and the parity tests would show it.
+// Measured and not kept (profiles/r04/e_wbf_ablation_3d_register_staged_fetch.txt): the halo through registers in 16-byte quads
+// instead of the DMA (needs W % 4 == 0, 248 VGPRs): same bits, 61.5 vs 58.6 ms per 256^3 forward -- the kernel is bound by the
+// LDS data path (per phase ~1 800 cycles of ds_read_b128 / ds_read_b64 / ds_write_b32 traffic against 1 536 of MFMA) and by how
+// little of it two waves per SIMD overlap with their MFMAs, not by how the halo arrives.
 template <int OFF>
 __device__ __forceinline__ f32x2 wb_lds_read64(unsigned addr) {
   f32x2 v;
