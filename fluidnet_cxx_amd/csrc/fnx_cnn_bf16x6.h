@@ -120,12 +120,25 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
   const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
   const unsigned stage_bytes = (unsigned)((size_t)WB_C * vol * 4 - 1) + 1u;
 
-  // tile: x fastest, then y, output-channel group, z, sample
+  // Tile numbering.  3D: x fastest, then y, output-channel group, z, sample -- workgroups go to the 8 XCDs round-robin
+  // (blockIdx % 8), so with 8 tiles across 256 cells an XCD keeps one x column and walks it in y, then z.  2D: XCD x takes the
+  // x-th eighth of the sequence and the sequence runs channel group fastest, so the workgroups an XCD runs side by side include
+  // both channel groups of a tile: the second read of its input hits that XCD's L2 (1024^2 forward: conv3_wbf 1.68 -> 1.60 ms).
+  // (3D measured with the same renumbering, alone and with 4 / 8 / 16 planes of one (x, y) tile side by side: 60.3-61.7 ms per
+  // 256^3 forward against 58.6 in the plain order -- the planes are 256 KB apart and crowd the same L2 sets.)
   int t = blockIdx.x;
-  const int tx = t % ntx; t /= ntx;
-  const int ty = t % nty; t /= nty;
-  const int grp = t % ngrp; t /= ngrp;
-  const int tz = t % a.D, tb = t / a.D;
+  int tx, ty, grp, tz, tb;
+  if (!IS3D && (gridDim.x & 7) == 0) {
+    t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
+    grp = t % ngrp; t /= ngrp;
+    tx = t % ntx; t /= ntx;
+    ty = t % nty; tb = t / nty; tz = 0;
+  } else {
+    tx = t % ntx; t /= ntx;
+    ty = t % nty; t /= nty;
+    grp = t % ngrp; t /= ngrp;
+    tz = t % a.D; tb = t / a.D;
+  }
   const int tx0 = tx * 32, ty0 = ty * 8;
   const int dz_lo = IS3D && tz == 0 ? 1 : 0, dz_hi = IS3D ? (tz == a.D - 1 ? 2 : 3) : 1;
   const int nstage = (dz_hi - dz_lo) * nchunk;              // >= 2 (the host checks Cin >= 32)
