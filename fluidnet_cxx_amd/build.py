@@ -24,7 +24,8 @@ HIP_UNITS = {
     "fnx_jacobi.hip": ["-ffp-contract=off"],
     "fnx_step.hip": ["-ffp-contract=off"],
     "fnx_api.hip": ["-ffp-contract=off"],
-    "fnx_cnn.hip": [],
+    # (resource-usage remarks: build_lib checks that conv3_wbf_kernel has no scratch -- its asynchronous LDS reads rely on it)
+    "fnx_cnn.hip": ["-Rpass-analysis=kernel-resource-usage"],
     "fnx_slab.hip": [],
 }
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 adds into v_pk_add_f32 + v_pk_mov shuffles, measured
@@ -38,6 +39,17 @@ def _newer(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _scratch_users(remarks, kernel):
+    """[(function, scratch bytes per lane, VGPR spills)] of the instantiations of `kernel` that use scratch, from hipcc's
+    -Rpass-analysis=kernel-resource-usage remarks"""
+    import re
+    bad = []
+    for m in re.finditer(r"Function Name: (\S*" + re.escape(kernel) + r"\S*).*?ScratchSize \[bytes/lane\]: (\d+).*?VGPRs Spill: (\d+)", remarks, re.S):
+        if int(m.group(2)) or int(m.group(3)):
+            bad.append((m.group(1), int(m.group(2)), int(m.group(3))))
+    return bad
 
 
 def build_lib(force=False, verbose=False):
@@ -63,6 +75,13 @@ def build_lib(force=False, verbose=False):
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"--- {unit} ---\n{out.decode()}\n")
+        elif unit == "fnx_cnn.hip":
+            bad = _scratch_users(out.decode(), "conv3_wbf_kernel")
+            if bad:
+                failed = True
+                os.remove(os.path.join(HERE, "build", "fnx_cnn.o"))
+                sys.stderr.write("fnx_cnn.hip: conv3_wbf_kernel must not spill (fnx_cnn_bf16x6.h: the results of its inline-asm LDS reads are "
+                                 f"only valid behind an explicit wait; a spill copies them before it): {bad}\n")
         elif verbose and out:
             print(out.decode())
     if failed:
