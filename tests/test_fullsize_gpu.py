@@ -190,14 +190,15 @@ def test_convnet_step_vs_oracle(oracle, shape):
         assert_bitexact(got[:, :, :, 0:4], ref["U"][:, :, :, 0:4], f"U on the inflow rows, step {it + 1}")
 
 
-@pytest.mark.parametrize("name", ["plume2d_1024_cnn", "plume3d_256_cnn"])
+@pytest.mark.parametrize("name", ["plume2d_1024_cnn", "plume3d_256_cnn", "plume2d_1024_cnn_bf16x6"])
 def test_benchmark_size_convnet_step_vs_oracle(oracle, name):
     """The convnet step bench.py times at 1024^2 (the metric's configs[1]) and 256^3 (configs[3]), from a developed plume, with
     its launch plan (workspace, static_flags, Winograd MFMA layers): every stage AROUND the net bit for bit against the oracle.
     The oracle runs the step with the HIP net standing in for its MultiScaleNet (`net=`: ext.multiscale_forward on the input the
     ORACLE's stages produced -- the divergence of the staged, normalised velocity), so U, density and p of the HIP step must
     equal the oracle's bit for bit: the advection, the staging pass, pack_div_kernel (else the net sees another input), the
-    scale, post_projection_kernel<.,SCALE> and the last setConstVals.  The net itself at this size: test_cnn_benchmark_size."""
+    scale, post_projection_kernel<.,SCALE> and the last setConstVals.  The net itself at this size: test_cnn_benchmark_size.
+    (`_bf16x6`: the same step with the opt-in precision mode travelling through mconf -> FluidNet -> fnx_simulate_step.)"""
     import bench
     from fluidnet_cxx_amd import FluidNet, simulate
     from fluidnet_cxx_amd._ext import ext
@@ -229,7 +230,7 @@ def test_benchmark_size_convnet_step_vs_oracle(oracle, name):
 
     def hip_net(x):
         calls.append(1)
-        return ext.multiscale_forward(packed, torch.from_numpy(x).to(dev), "fp32").cpu().numpy()
+        return ext.multiscale_forward(packed, torch.from_numpy(x).to(dev), w.get("precision", "fp32")).cpu().numpy()
     ref = oracle.simulate_step(st, m, "convnet", None, net=hip_net)
     assert calls == [1]
     for k in ("density", "U", "p"):
