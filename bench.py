@@ -74,7 +74,7 @@ DEVELOP_STEPS = 100          # "warm-up 100 steps so a plume exists"
 
 # algorithmic bytes per cell, 2D / 3D
 STEP_BYTES = {False: lambda n: 340 + 16 * n, True: lambda n: 452 + 16 * n}
-PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4, conv_mfma16=5, conv_bf16=6, step2d=7)
+PROF = dict(jacobi=0, conv_mfma=1, advect=2, stage=3, conv_direct=4, conv_mfma16=5, conv_bf16=6)
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 # plumeConfig.yaml:29-76 with BASELINE.json's overrides (jacobiIter per workload, pTol 0)
@@ -350,13 +350,6 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
         kname = ("jacobi3d_march2_kernel<false,false,3> (the steady-state instantiation: z-marching, TWO sweeps per pass, p handed from "
                  "pass to pass in the row-quad layout; the first pass of a solve is <true,..>, the last one writes rows)" if is3d
                  else "jacobi2d_wg_kernel<8,8> (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-10 sweeps per launch)")
-        if nl == 0 and times["step2d"][1] > 0:
-            # small 2D grids: the whole step is ONE launch (csrc/fnx_small.hip); the solve's bytes over the launch's time
-            tms, nl = times["step2d"]
-            ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-            kname = ("small_step2d_kernel (the WHOLE step as one launch of 1024-thread workgroups, one per 32x32 block: advection, "
-                     "stages, Jacobi rounds of <= 16 sweeps on 64x64 register tiles and the post-projection pass separated by grid "
-                     "barriers; achieved = the solve's algorithmic bytes over the whole launch: latency-bound, not HBM-bound)")
         avg_ms = tms / max(nl, 1)
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                     traffic=traffic, traffic_source=traffic_src,

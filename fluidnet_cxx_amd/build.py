@@ -23,7 +23,6 @@ HIP_UNITS = {
     "fnx_advect.hip": ["-ffp-contract=off"],
     "fnx_jacobi.hip": ["-ffp-contract=off"],
     "fnx_step.hip": ["-ffp-contract=off"],
-    "fnx_small.hip": ["-ffp-contract=off"],
     "fnx_api.hip": ["-ffp-contract=off"],
     # (resource-usage remarks: build_lib checks that conv3_wbf_kernel has no scratch -- its asynchronous LDS reads rely on it)
     "fnx_cnn.hip": ["-Rpass-analysis=kernel-resource-usage"],

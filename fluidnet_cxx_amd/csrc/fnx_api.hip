@@ -95,8 +95,7 @@ size_t ws_step(const FnxGrid* g) {
   return al(ncell(g) * 4) /*rho2*/ + al(ncell(g) * 4 * nc) /*U2*/ + al(ncell(g) * 4) /*div*/ +
          ws_mask(g) /*Jacobi obstacle mask, kept between steps*/ +
          al(ncell(g)) /*BC class map, kept between steps*/ +
-         (g->is3D ? 0 : al(ncell(g) * 4 * nc)) /*2D: the viscous velocity that is advected (FnxStepParams.viscosity)*/ +
-         (g->is3D ? 0 : al(8)) /*2D: the single-launch step's arrival counter, kept between steps*/ + tail;
+         (g->is3D ? 0 : al(ncell(g) * 4 * nc)) /*2D: the viscous velocity that is advected (FnxStepParams.viscosity)*/ + tail;
 }
 
 }  // namespace
@@ -130,7 +129,7 @@ struct Prof {
 // them).  The marker library is resolved on request (fnx_roctx_enable), never linked: without it the ranges are no-ops.
 namespace {
 struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; std::atomic<bool> on{false}; } g_roctx;
-const char* const kProfNames[FNX_PROF_NTAGS] = {"fnx:jacobi", "fnx:conv_mfma", "fnx:advect", "fnx:stage", "fnx:conv_direct", "fnx:conv_mfma16", "fnx:conv_bf16", "fnx:step2d"};
+const char* const kProfNames[FNX_PROF_NTAGS] = {"fnx:jacobi", "fnx:conv_mfma", "fnx:advect", "fnx:stage", "fnx:conv_direct", "fnx:conv_mfma16", "fnx:conv_bf16"};
 }  // namespace
 
 // A scope pops the range it pushed and no other: fnx_roctx_enable may be toggled (from another thread, or inside an open scope
@@ -689,47 +688,29 @@ int fnx_velocity_update_backward(const FnxGrid* g, const float* grad_U_out, cons
   return FNX_OK;
 }
 
-// strengths of the staging pass: buoyancy (gravity.mul_(-buoyancyScale), simulate.py:101-105; strength = gravity * dt,
-// source_terms.py:45) and addGravity(gravityVec * -gravityScale) after it, inside the density branch (simulate.py:107-114)
-struct StageScalars { bool buoy, grav; float sx, sy, sz, gv[3]; };
-static StageScalars stage_scalars(const FnxStepParams* prm, bool has_rho) {
-  StageScalars q{};
-  q.buoy = has_rho && prm->buoyancy_scale > 0.f;
-  if (q.buoy) {
-    const float ns = -prm->buoyancy_scale;
-    const float gx = prm->gravity_vec[0] * ns, gy = prm->gravity_vec[1] * ns, gz = prm->gravity_vec[2] * ns;
-    q.sx = gx * prm->dt; q.sy = gy * prm->dt; q.sz = gz * prm->dt;
-  }
-  q.grav = has_rho && prm->gravity_scale > 0.f;
-  if (q.grav) {
-    const float ns = -prm->gravity_scale;
-    for (int a = 0; a < 3; ++a) q.gv[a] = (prm->gravity_vec[a] * ns) * prm->dt;       // force = gravity * dt, source_terms.py
-  }
-  return q;
-}
-
-static int pre_projection_impl(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
-                               const float* rho_adv, float* div, void* stream, unsigned long long* bar_reset);
-
 int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
                        const float* rho_adv, float* div, void* stream) {
-  return pre_projection_impl(g, prm, st, U_adv, rho_adv, div, stream, nullptr);
-}
-
-// bar_reset (2D): see launch_pre_projection
-static int pre_projection_impl(const FnxGrid* g, const FnxStepParams* prm, const FnxState* st, const float* U_adv,
-                               const float* rho_adv, float* div, void* stream, unsigned long long* bar_reset) {
   if (int rc = check_grid(g)) return rc;
   if (!prm || !st || !st->U || !st->flags || !U_adv) return fail(FNX_EINVAL, "pre_projection: NULL state");
   if (rho_adv && !st->density) return fail(FNX_EINVAL, "pre_projection: rho_adv given but state has no density");
   // a cell reads the advected fields of its +1 / -1 neighbours while other threads write theirs: no in-place use
   if (U_adv == st->U || (rho_adv && rho_adv == st->density)) return fail(FNX_EINVAL, "pre_projection: the advected fields must not alias the state");
   const bool has_rho = rho_adv != nullptr;
-  const StageScalars q = stage_scalars(prm, has_rho);
-  const bool buoy = q.buoy, grav = q.grav;
-  const float sx = q.sx, sy = q.sy, sz = q.sz;
-  const float* gv = q.gv;
+  const bool buoy = has_rho && prm->buoyancy_scale > 0.f;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (buoy) {
+    const float ns = -prm->buoyancy_scale;                       // gravity.mul_(-buoyancyScale), simulate.py:101-105
+    const float gx = prm->gravity_vec[0] * ns, gy = prm->gravity_vec[1] * ns, gz = prm->gravity_vec[2] * ns;
+    sx = gx * prm->dt; sy = gy * prm->dt; sz = gz * prm->dt;     // strength = gravity * dt, source_terms.py:45
+  }
   const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
+  // simulate.py:107-114: addGravity(gravityVec * -gravityScale) after the buoyancy, inside the density branch
+  const bool grav = has_rho && prm->gravity_scale > 0.f;
+  float gv[3] = {0.f, 0.f, 0.f};
+  if (grav) {
+    const float ns = -prm->gravity_scale;
+    for (int a = 0; a < 3; ++a) gv[a] = (prm->gravity_vec[a] * ns) * prm->dt;       // force = gravity * dt, source_terms.py
+  }
   // simulate.py:119-130: setWallBcs and the periodic patches in the Jacobi branch only; with 'flags_stick' the convnet branch
   // runs setWallBcsStick between the stages and the second setConstVals, which are then the caller's (fnx_simulate_step)
   const bool wall = prm->method == 0;
@@ -746,7 +727,7 @@ static int pre_projection_impl(const FnxGrid* g, const FnxStepParams* prm, const
   fnx::launch_pre_projection(ds, g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                              rbc ? st->densityBCInvMask : nullptr, st->U, st->density, (split && div) ? nullptr : div, buoy, sx, sy, sz,
-                             prm->operating_density, wall, (hipStream_t)stream, st->bc_class, grav ? gv : nullptr, second_bcs, bar_reset);
+                             prm->operating_density, wall, (hipStream_t)stream, st->bc_class, grav ? gv : nullptr, second_bcs);
   if (periodic)
     fnx::launch_periodic_pre(ds, g->is3D, U_adv, ubc ? st->UBC : nullptr, ubc ? st->UBCInvMask : nullptr, st->U,
                              (prm->periodic & 2) != 0, (prm->periodic & 4) != 0, (hipStream_t)stream);
@@ -792,7 +773,6 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   unsigned char* kept_mask = g->is3D ? (unsigned char*)c.take(ws_mask(g)) : nullptr;
   unsigned char* kept_cls = (unsigned char*)c.take(n);
   float* orig = g->is3D ? nullptr : (float*)c.take(n * 4 * nc);        // 2D: the viscous velocity (prm->viscosity > 0)
-  unsigned long long* kept_bar = g->is3D ? nullptr : (unsigned long long*)c.take(8);   // 2D: arrival counter of the single-launch step
   void* tail = c.take(0);
   const size_t tail_bytes = ws_bytes > c.off ? ws_bytes - c.off : 0;
   if (!c.ok() || ws_bytes < ws_step(g)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small (%zu < %zu)", ws_bytes, ws_step(g));
@@ -803,39 +783,6 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   const bool stick = prm->method == 1 && st->flags_stick != nullptr;           // simulate.py:129-130, :165-166
   if (stick && g->is3D) return fail(FNX_EINVAL, "simulate_step: flags_stick is 2D only (set_wall_bcs_stick.py:85-86)");
   const bool periodic = prm->method == 0 && (prm->periodic & 1);
-  // Small 2D grids, the plain Jacobi-method step: ONE launch (fnx_small.hip: the phases below separated by grid barriers, same
-  // cell functions, same bits).  Its arrival counter lives in the workspace: a step that takes the launches below leaves it zeroed
-  // (the staging pass does it), so the single launch needs the promise that the previous step ran on this workspace (bit 0).
-  const GridDims d2 = dims(g);
-  const bool small_ok = !g->is3D && prm->method == 0 && has_rho && !viscous && !prm->correct_scalar && !periodic &&
-                        !(prm->p_tol > 0.f) && prm->jacobi_iter >= 1 && fnx::small_step2d_fits(d2);
-  if (small_ok && (prm->static_flags & 1) && !(prm->static_flags & 8)) {
-    const unsigned char* cls = nullptr;
-    if ((prm->static_flags & 2) && (st->UBC || st->densityBC)) {
-      if (!(prm->static_flags & 4)) { if (int rc = fnx_bc_classify(g, st, kept_cls, stream)) return rc; }
-      cls = kept_cls;
-    }
-    Carver t(tail, tail_bytes);
-    fnx::SmallStep2D a{};
-    a.rho_fwd = (float*)t.take(n * 4); a.cell = (int*)t.take(n * 4); a.U_fwd = (float*)t.take(n * 4 * nc);
-    if (!t.ok()) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small");
-    const bool ubc = st->UBC && st->UBCInvMask, rbc = st->densityBC && st->densityBCInvMask;
-    const StageScalars q = stage_scalars(prm, true);
-    a.dt = prm->dt; a.half_s = prm->maccormack_strength * 0.5f; a.sample_outside = prm->sample_outside_fluid != 0;
-    a.rho = st->density; a.U = st->U; a.flags = st->flags; a.p = st->p;
-    a.UBC = ubc ? st->UBC : nullptr; a.UBCInvMask = ubc ? st->UBCInvMask : nullptr;
-    a.rhoBC = rbc ? st->densityBC : nullptr; a.rhoBCInvMask = rbc ? st->densityBCInvMask : nullptr;
-    a.cls = cls;
-    a.rho2 = rho2; a.U2 = U2; a.div = div; a.p_tmp = orig;              // (the viscous velocity's slot is free: !viscous)
-    a.buoyancy = q.buoy ? 1 : 0; a.sx = q.sx; a.sy = q.sy; a.rho_star = prm->operating_density;
-    a.grav = q.grav ? 1 : 0; a.gx = q.gv[0]; a.gy = q.gv[1];
-    a.jacobi_iter = prm->jacobi_iter;
-    a.barrier = kept_bar;
-    fnx::ProfScope ps(FNX_PROF_STEP2D, s);
-    fnx::launch_small_step2d(d2, a, s);
-    HIP_OK(hipGetLastError());
-    return FNX_OK;
-  }
   // simulate.py:66-93: advect density then velocity (both by the OLD U; the velocity advected is the viscous one)
   if (viscous) {
     if (int rc = fnx_add_viscosity(g, prm->dt, st->U, orig, st->flags, prm->viscosity, stream)) return rc;
@@ -867,8 +814,7 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
   stc.density_bc_applied = 1;                  // by the pre-projection stage below, with these BC arrays
   st = &stc;
   // simulate.py:96-133 (+ :144 divergence) in one pass: BCs, buoyancy, gravity, wall BCs (+ periodic patches), BCs, -div
-  if (int rc = pre_projection_impl(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream,
-                                   small_ok ? kept_bar : nullptr)) return rc;
+  if (int rc = fnx_pre_projection(g, prm, st, U2, has_rho ? rho2 : nullptr, prm->method == 0 ? div : nullptr, stream)) return rc;
   const GridDims d = dims(g);
   float* rho = has_rho ? st->density : nullptr;
   // setWallBcsStick is out of place: st->U -> U2 (free since the staging pass) and back

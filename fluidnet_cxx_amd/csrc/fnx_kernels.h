@@ -67,10 +67,8 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
                            float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s,
-                           const unsigned char* cls = nullptr, const float* gravity = nullptr, bool second_bcs = true,
-                           unsigned long long* bar_reset = nullptr);
-// gravity: 3 host floats (gravity * dt) or null; second_bcs = false leaves out the setConstVals of simulate.py:133;
-// bar_reset (2D): a 64-bit word the pass zeroes -- the single-launch step's arrival counter (SmallStep2D.barrier)
+                           const unsigned char* cls = nullptr, const float* gravity = nullptr, bool second_bcs = true);
+// gravity: 3 host floats (gravity * dt) or null; second_bcs = false leaves out the setConstVals of simulate.py:133
 // periodic patches of the Jacobi branch (simulate.py:121-128, :157-164); `save`: periodic_save_bytes(g), mode 0 = save the
 // source row / column before the post-projection pass, 1 = write the destinations after it
 void launch_periodic_pre(const GridDims& g, bool is3d, const float* U_adv, const float* UBC, const float* UBCInvMask, float* U,
@@ -86,24 +84,6 @@ void launch_post_projection(const GridDims& g, bool is3d, const float* p, float*
 // p_scaled = p * s out of it); p_scaled must not alias p (a cell reads p of its -1 neighbours)
 void launch_bc_classify(const GridDims& g, bool is3d, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                         const float* rhoBCInvMask, unsigned char* cls, hipStream_t s);
-
-// The whole Jacobi-method step of a small 2D grid in ONE launch (fnx_small.hip): both advections, the stages, the solve
-// (jacobi_iter sweeps from p = 0) and the post-projection pass, separated by grid barriers -- the per-cell / per-tile functions of the
-// launches above on the same arrays, same bits.  density / U / p are updated in place; the rest is workspace (n = B*H*W cells).
-struct SmallStep2D {
-  float dt, half_s; int sample_outside;
-  float* rho; float* U; const float* flags; float* p;
-  const float* UBC; const float* UBCInvMask; const float* rhoBC; const float* rhoBCInvMask;     // may be null (in pairs)
-  const unsigned char* cls;                                                                     // BC class map or null
-  float* rho_fwd; int* cell; float* U_fwd;           // n, n, 2n: the forward passes' outputs
-  float* rho2; float* U2; float* div; float* p_tmp;  // n, 2n, n, n
-  int buoyancy; float sx, sy, rho_star;              // as launch_pre_projection
-  int grav; float gx, gy;
-  int jacobi_iter;
-  unsigned long long* barrier;                       // arrival counter: a multiple of the workgroup count at launch (0 at first use)
-};
-bool small_step2d_fits(const GridDims& g);           // few enough 32 x 32 blocks that a grid barrier is cheaper than a kernel boundary
-void launch_small_step2d(const GridDims& g, const SmallStep2D& a, hipStream_t s);
 
 // Jacobi (fnx_jacobi.hip)
 // 2D: `nsweeps` sweeps (1..jacobi_max_sweeps_per_launch) from p_in into p_out; from_zero: p_in is all zeros and is not read

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 16
+#define FNX_ABI_VERSION 15
 
 enum {
   FNX_OK = 0,
@@ -230,12 +230,7 @@ typedef struct FnxStepParams {
                                  bit 0: `flags` is unchanged -> the 3D Jacobi solver reuses the obstacle mask it left there;
                                  bit 1: UBC / UBCInvMask / densityBC / densityBCInvMask are unchanged -> the BC stages use a
                                         1-byte-per-cell class map kept in the workspace (see FnxState.bc_class);
-                                 bit 2: that class map was already built by an earlier call with bit 1 set;
-                                 bit 3: do NOT run the step as one launch.  (Small 2D grids -- at most 32 blocks of 32 x 32
-                                        cells, e.g. the reference's 128 x 128 default -- with method 0, a density, pTol <= 0 and
-                                        none of the optional stages below run the whole step as ONE launch with grid barriers
-                                        between its phases when bit 0 is set: its arrival counter is a word of the workspace
-                                        that the multi-launch step leaves zeroed.  Same bits either way.) */
+                                 bit 2: that class map was already built by an earlier call with bit 1 set */
   /* Optional stages of lib/simulate.py (all off when zero; fnx_slab_step refuses them): */
   float viscosity;            /* mconf['viscosity'] > 0 (2D only, like addViscosity): the velocity advected is
                                  addViscosity(U.clone()), advected by U (simulate.py:66-69, :85-93) */
@@ -446,8 +441,7 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
  * later launches are not recorded).  fnx_profile_read synchronises the recorded events and returns the summed
  * kernel time and the number of launches of that class; fnx_profile_enable(1) also clears earlier records. */
 enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PROF_STAGE = 3, FNX_PROF_CONV_DIRECT = 4,
-       FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_CONV_BF16 = 6 /* FNX_PRECISION_BF16X6 launches; work = bf16 MFMA FLOPs issued */,
-       FNX_PROF_STEP2D = 7 /* the single-launch step of small 2D grids (FnxStepParams.static_flags) */, FNX_PROF_NTAGS = 8 };
+       FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_CONV_BF16 = 6 /* FNX_PRECISION_BF16X6 launches; work = bf16 MFMA FLOPs issued */, FNX_PROF_NTAGS = 7 };
 int fnx_profile_enable(int on);
 /* roctx ranges ("fnx:jacobi", "fnx:advect", "fnx:stage", "fnx:conv_*") around the enqueue of the same kernel classes, for
  * `rocprofv3 --marker-trace`.  The marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is loaded by this call,
