@@ -337,19 +337,25 @@ static int precision_of(const std::string& m) {
   return m == "fp32_direct" ? FNX_PRECISION_FP32_DIRECT : FNX_PRECISION_FP32;
 }
 
-Tensor multiscale_forward(Tensor packed, Tensor x, const std::string& precision_mode) {
+Tensor multiscale_forward(Tensor packed, Tensor x, const std::string& precision_mode, std::vector<int64_t> trim) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "x must be a contiguous float32 GPU tensor");
   TORCH_CHECK((x.dim() == 4 || x.dim() == 5) && x.size(1) == 2, "x must be (B,2,H,W) or (B,2,D,H,W)");
+  TORCH_CHECK(trim.empty() || trim.size() == 4, "trim: {full-tower low, high, half-tower low, high} full-resolution planes");
   const bool is3D = x.dim() == 5 && x.size(2) > 1;
   FnxGrid g{}; g.B = (int)x.size(0); g.is3D = is3D; g.ref_quirks = 0; g.z_offset = 0; g.D_global = 0;
   g.D = x.dim() == 5 ? (int)x.size(2) : 1; g.H = (int)x.size(x.dim() - 2); g.W = (int)x.size(x.dim() - 1);
   c10::hip::HIPGuard guard(x.get_device());
+  int tr[4] = {0, 0, 0, 0};
+  for (size_t a = 0; a < trim.size(); ++a) tr[a] = (int)trim[a];
   std::vector<int64_t> osz = x.sizes().vec(); osz[1] = 1;
+  if (x.dim() == 5) osz[2] -= tr[0] + tr[1];
+  TORCH_CHECK(x.dim() == 5 || !(tr[0] | tr[1] | tr[2] | tr[3]), "trim needs a (B,2,D,H,W) input");
+  TORCH_CHECK(x.dim() != 5 || osz[2] > 0, "trim leaves no planes");
   Tensor p = at::empty(osz, x.options());
   const size_t bytes = fnx_workspace_bytes(&g, FNX_OP_FLUIDNET);
   Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
-  check_status(fnx_multiscale_forward(&g, packed.data_ptr(), x.data_ptr<float>(), p.data_ptr<float>(), precision_of(precision_mode),
-                                      ws.data_ptr(), bytes, cur_stream(x)));
+  check_status(fnx_multiscale_forward_crop(&g, packed.data_ptr(), x.data_ptr<float>(), p.data_ptr<float>(), precision_of(precision_mode),
+                                           tr, ws.data_ptr(), bytes, cur_stream(x)));
   return p;
 }
 
@@ -693,7 +699,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("create_box2d_", &create_box2d_, NoGil());
   m.def("get_centered", &get_centered, NoGil());
   m.def("scalenet_pack", &scalenet_pack, NoGil());
-  m.def("multiscale_forward", &multiscale_forward, py::arg("packed"), py::arg("x"), py::arg("precision_mode") = "fp32", NoGil());
+  m.def("multiscale_forward", &multiscale_forward, py::arg("packed"), py::arg("x"), py::arg("precision_mode") = "fp32",
+        py::arg("trim") = std::vector<int64_t>(), NoGil());
   m.def("fluidnet_forward", &fluidnet_forward, py::arg("packed"), py::arg("input"), py::arg("normalize_threshold"),
         py::arg("precision_mode") = "fp32", NoGil());
   m.def("simulate_step_", &simulate_step_, py::arg("p"), py::arg("U"), py::arg("flags"), py::arg("density"), py::arg("UBC"),

@@ -32,6 +32,10 @@ size_t fluidnet_ws_bytes(const GridDims& g, bool is3d);
 // x (B,2,D,H,W) -> p (B,1,D,H,W)
 void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                         hipStream_t s);
+// the same on nested z-crops (fnx_cnn.hip): trim = {full-tower low, high, half-tower low, high} in full-resolution planes,
+// multiples of 4; p receives g.D - trim[0] - trim[1] planes.  Workspace: multiscale_ws_bytes(g)
+void multiscale_forward_crop(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode,
+                             void* ws, hipStream_t s, const int trim[4]);
 
 // pieces of FluidNet.forward (lib/model.py:76-227)
 size_t scale_std_scratch_bytes(int B);      // `partial` of launch_scale_std (fixed-order fp64 partial sums, no atomics)

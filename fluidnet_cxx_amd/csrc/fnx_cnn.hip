@@ -1088,9 +1088,14 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int
 }
 
 // x (B,C,Di,Hi,Wi) -> channels [c_off, c_off+C) of y (B,Ctot,Do,Ho,Wo)
+// ZWin: either tensor may hold a window of planes of a deeper notional tensor (the nested crops of multiscale_forward_crop):
+// the interpolation runs in the notional depths (full_in -> full_out), x holds notional planes [in_off, in_off + Di) and y the
+// notional planes [out_off, out_off + Do); a source plane outside x's window is clamped into it (only planes nobody uses read
+// such values).  {Di, 0, Do, 0} = whole tensors.
+struct ZWin { int full_in, in_off, full_out, out_off; };
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
                                                      int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Ctot,
-                                                     int c_off) {
+                                                     int c_off, ZWin zw) {
   const size_t n = (size_t)B * C * Do * Ho * Wo;
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
     size_t r = q;
@@ -1101,12 +1106,15 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x
     int x0, x1, y0, y1, z0, z1; float s0, s1, t0, t1, f0, f1;
     src_index(i, Wi, Wo, x0, x1, s0, s1);
     src_index(j, Hi, Ho, y0, y1, t0, t1);
-    src_index(k, Di, Do, z0, z1, f0, f1);
+    src_index(k + zw.out_off, zw.full_in, zw.full_out, z0, z1, f0, f1);
+    z0 -= zw.in_off; z1 -= zw.in_off;
+    z0 = z0 < 0 ? 0 : (z0 > Di - 1 ? Di - 1 : z0);
+    z1 = z1 < 0 ? 0 : (z1 > Di - 1 ? Di - 1 : z1);
     const float* xi = x + ((size_t)b * C + c) * Di * Hi * Wi;
 #define XI(zz, yy, xx) xi[((size_t)(zz) * Hi + (yy)) * Wi + (xx)]
     const float lo = t0 * (s0 * XI(z0, y0, x0) + s1 * XI(z0, y0, x1)) + t1 * (s0 * XI(z0, y1, x0) + s1 * XI(z0, y1, x1));
     float v = lo;
-    if (Di > 1 || Do > 1) {
+    if (zw.full_in > 1 || zw.full_out > 1) {
       const float hi = t0 * (s0 * XI(z1, y0, x0) + s1 * XI(z1, y0, x1)) + t1 * (s0 * XI(z1, y1, x0) + s1 * XI(z1, y1, x1));
       v = f0 * lo + f1 * hi;
     }
@@ -1116,11 +1124,12 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x
 }
 
 void launch_resize(const float* x, float* y, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Ctot,
-                   int c_off, hipStream_t s) {
+                   int c_off, hipStream_t s, const ZWin* zw = nullptr) {
   const size_t n = (size_t)B * C * Do * Ho * Wo;
   size_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  resize_kernel<<<(int)blocks, 256, 0, s>>>(x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, Ctot, c_off);
+  const ZWin whole{Di, 0, Do, 0};
+  resize_kernel<<<(int)blocks, 256, 0, s>>>(x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, Ctot, c_off, zw ? *zw : whole);
 }
 
 struct Sizes { int Dq, Hq, Wq, Dh, Hh, Wh; };
@@ -1187,6 +1196,19 @@ size_t multiscale_ws_bytes(const GridDims& g, bool is3d) {
 
 void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                         hipStream_t s) {
+  const int none[4] = {0, 0, 0, 0};
+  multiscale_forward_crop(g, is3d, packed, x, p, precision_mode, ws, s, none);
+}
+
+// The forward pass on NESTED z-crops (the z-slab driver's CNN projection, fnx_slab.hip): x covers g.D planes; the quarter-resolution
+// tower runs on all of them, the half-resolution tower on planes [trim[2], g.D - trim[3]) and the full-resolution tower on
+// [trim[0], g.D - trim[1]) (full-resolution plane counts, multiples of 4 so that every window starts on a plane of each coarser
+// grid; trim[2] <= trim[0], trim[3] <= trim[1]); p receives g.D - trim[0] - trim[1] planes.  A tower whose window ends at an
+// artificial face computes garbage within its receptive radius of that face (8 / 14 / 16 full-resolution planes for the full / half /
+// quarter tower) -- the caller sizes the windows so that this never reaches what it uses (SlabSimulator.NET_TRIMS).  Everything
+// else is the arithmetic of the untrimmed pass: the resampling runs in the untrimmed grids' coordinates.
+void multiscale_forward_crop(const GridDims& g, bool is3d, const void* packed, const float* x, float* p, int precision_mode,
+                             void* ws, hipStream_t s, const int trim[4]) {
   const int mode = precision_mode;
   const Sizes z = sizes(g, is3d);
   const size_t full = (size_t)g.B * g.DHW, half = (size_t)g.B * z.Dh * z.Hh * z.Wh, quart = (size_t)g.B * z.Dq * z.Hq * z.Wq;
@@ -1207,16 +1229,21 @@ void multiscale_forward(const GridDims& g, bool is3d, const void* packed, const 
       cur = dst;
     }
   };
+  // windows (planes of each tower's own grid)
+  const int f_lo = trim[0], f_n = g.D - trim[0] - trim[1];              // full-resolution tower
+  const int h_lo = trim[2] / 2, h_n = z.Dh - trim[2] / 2 - trim[3] / 2;  // half-resolution tower
   // multi_scale_net.py:119-126
   launch_resize(x, xq, g.B, 2, g.D, g.H, g.W, z.Dq, z.Hq, z.Wq, 2, 0, s);
   tower(0, 4, xq, c4, z.Dq, z.Hq, z.Wq);
-  launch_resize(x, in2, g.B, 2, g.D, g.H, g.W, z.Dh, z.Hh, z.Wh, 3, 0, s);
-  launch_resize(c4, in2, g.B, 1, z.Dq, z.Hq, z.Wq, z.Dh, z.Hh, z.Wh, 3, 2, s);
-  tower(4, 6, in2, c2, z.Dh, z.Hh, z.Wh);
-  launch_resize(x, in1, g.B, 2, g.D, g.H, g.W, g.D, g.H, g.W, 3, 0, s);
-  launch_resize(c2, in1, g.B, 1, z.Dh, z.Hh, z.Wh, g.D, g.H, g.W, 3, 2, s);
+  const ZWin x_to_h{g.D, 0, z.Dh, h_lo}, q_to_h{z.Dq, 0, z.Dh, h_lo};
+  launch_resize(x, in2, g.B, 2, g.D, g.H, g.W, h_n, z.Hh, z.Wh, 3, 0, s, &x_to_h);
+  launch_resize(c4, in2, g.B, 1, z.Dq, z.Hq, z.Wq, h_n, z.Hh, z.Wh, 3, 2, s, &q_to_h);
+  tower(4, 6, in2, c2, h_n, z.Hh, z.Wh);
+  const ZWin x_to_f{g.D, 0, g.D, f_lo}, h_to_f{z.Dh, h_lo, g.D, f_lo};
+  launch_resize(x, in1, g.B, 2, g.D, g.H, g.W, f_n, g.H, g.W, 3, 0, s, &x_to_f);
+  launch_resize(c2, in1, g.B, 1, h_n, z.Hh, z.Wh, f_n, g.H, g.W, 3, 2, s, &h_to_f);
   // convN_1 (6 layers) then final 1x1: 7 convs, the last one writes p
-  tower(10, 7, in1, p, g.D, g.H, g.W);
+  tower(10, 7, in1, p, f_n, g.H, g.W);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1526,6 +1553,22 @@ int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x,
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   fnx::multiscale_forward(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+}
+
+int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
+                                const int trim[4], void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !packed || !x || !p || !ws || !trim) return FNX_EINVAL;
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6)", precision_mode);
+  if (!g->is3D && (trim[0] | trim[1] | trim[2] | trim[3])) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: z windows need a 3D grid");
+  for (int a = 0; a < 4; ++a)
+    if (trim[a] < 0 || trim[a] % 4) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: trim[%d] = %d must be a non-negative multiple of 4", a, trim[a]);
+  if (trim[2] > trim[0] || trim[3] > trim[1]) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: the half-resolution window must contain the full-resolution one");
+  if ((trim[0] | trim[1] | trim[2] | trim[3]) && (g->D % 4 || g->D - trim[0] - trim[1] < 4))
+    return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: D = %d must be a multiple of 4 and leave at least 4 planes (trims %d + %d)", g->D, trim[0], trim[1]);
+  const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
+  if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
+  fnx::multiscale_forward_crop(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream, trim);
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
 }
 

@@ -754,11 +754,24 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       for (int c = 0; c < 2; ++c)
         SLAB_HIP(hipMemcpyAsync(W.x_crop + ((size_t)b * 2 + c) * volc, W.x_local + ((size_t)b * 2 + c) * vol + (size_t)e0 * plane, volc * 4,
                                 hipMemcpyDeviceToDevice, stream));
-    fnx::multiscale_forward(make_dims(s->cfg.B, De, s->cfg.H, s->cfg.W), true, st->net, W.x_crop, W.p_crop, prm->precision_mode, W.msws, stream);
-    // the net's output back at its place in a local array (only the planes e0 .. e1 of it are ever read: owned and owned - 1)
+    // nested crops (slab.py: NET_MARGIN_FULL / _HALF): where the window ends at an artificial face the full- / half-resolution
+    // towers stop 8 / 24 planes outside the owned ones; at a domain face nothing is trimmed
+    const bool cut_lo = rank > 0 && lo - e0 == FNX_SLAB_NET_MARGIN, cut_hi = rank < world - 1 && e1 - top == FNX_SLAB_NET_MARGIN;
+    const int trim[4] = { cut_lo ? FNX_SLAB_NET_MARGIN - FNX_SLAB_NET_MARGIN_FULL : 0, cut_hi ? FNX_SLAB_NET_MARGIN - FNX_SLAB_NET_MARGIN_FULL : 0,
+                          cut_lo ? FNX_SLAB_NET_MARGIN - FNX_SLAB_NET_MARGIN_HALF : 0, cut_hi ? FNX_SLAB_NET_MARGIN - FNX_SLAB_NET_MARGIN_HALF : 0 };
+    fnx::multiscale_forward_crop(make_dims(s->cfg.B, De, s->cfg.H, s->cfg.W), true, st->net, W.x_crop, W.p_crop, prm->precision_mode, W.msws,
+                                 stream, trim);
+    // the net's output back at its place in a local array
     float* pn = W.div;
+    const int p0 = e0 + trim[0], pd = De - trim[0] - trim[1];
     for (int b = 0; b < s->cfg.B; ++b)
-      SLAB_HIP(hipMemcpyAsync(pn + (size_t)b * vol + (size_t)e0 * plane, W.p_crop + (size_t)b * volc, volc * 4, hipMemcpyDeviceToDevice, stream));
+      SLAB_HIP(hipMemcpyAsync(pn + (size_t)b * vol + (size_t)p0 * plane, W.p_crop + (size_t)b * plane * pd, plane * pd * 4, hipMemcpyDeviceToDevice, stream));
+    // ... exact on the owned planes; velocityUpdate also reads the plane below them: the lower neighbour's top plane
+    if (world > 1) {
+      float* fp[1] = {pn};
+      const int c1p[1] = {1};
+      SLAB_OK(xchg(s, fp, c1p, 1, 1, stream));
+    }
     // velocityUpdate on U / s, un-normalise, setWallBcs, the step's last setConstVals: one pass over the owned planes
     GridDims dw = dl;
     if (world > 1) { dw.K0 = lo; dw.KN = s->owned; }

@@ -51,8 +51,10 @@ class MultiScaleNet:
         blob = torch.from_numpy(blob_from_state_dict(state_dict, 3 if is3D else 2)).to(device)
         self.packed = ext.scalenet_pack(blob, self.is3D)
 
-    def __call__(self, x):
-        return ext.multiscale_forward(self.packed, x.contiguous(), self.precision_mode)
+    def __call__(self, x, trim=None):
+        """trim (3D, the z-slab driver): nested z-crops -- [full-tower low, high, half-tower low, high] full-resolution planes
+        (include/fluidnet_hip.h: fnx_multiscale_forward_crop); the result then holds planes [trim[0], D - trim[1])"""
+        return ext.multiscale_forward(self.packed, x.contiguous(), self.precision_mode, list(trim) if trim is not None else [])
 
 
 class FluidNet:

@@ -204,8 +204,8 @@ class NativeOps:
     def occupancy(self, flags):
         return self.ext.flags_to_occupancy(flags)
 
-    def multiscale(self, net, x):
-        return net.multiScale(x)
+    def multiscale(self, net, x, trim=None):
+        return net.multiScale(x, trim if trim is not None and any(trim) else None)
 
     def convnet_post(self, pn, Un, s, st):
         """model.py:190-227 + simulate.py:154-168 on the window: U = (Un - grad pn) * s, p = pn * s, setWallBcs, setConstVals"""
@@ -236,6 +236,12 @@ class SlabSimulator:
     # resolution: test_cnn_benchmark_size's crop margin) + 1 for the divergence; a multiple of 4 so that the quarter- and
     # half-resolution grids of a rank's crop coincide with the global ones
     NET_MARGIN = 48
+    # ... of which the towers need less: the full-resolution tower's receptive radius is 8 planes (5^3, four 3^3, 5^3), the half-
+    # resolution tower's 2 x (2 + 5) = 14 (+ 2 for the resampling above it, + the 8 = 24), the quarter-resolution tower's 4 x 4 = 16
+    # (+ 4, + the 24 = 44 <= NET_MARGIN).  A rank evaluates each tower only on owned +- its own margin (nested crops,
+    # fnx_multiscale_forward_crop) -- 1.3 x the FLOPs of its owned planes at 64 planes per rank instead of 2.5 x.  The pressure
+    # is then exact on the owned planes; the plane below them that velocityUpdate reads comes from the neighbour.
+    NET_MARGIN_FULL, NET_MARGIN_HALF = 8, 24
 
     def __init__(self, layout, mconf, ops=None, group=None, sweeps_per_exchange=4, schedule="deep_first",
                  static_flags=False, cfl_check_every=8, method="jacobi", net=None):
@@ -377,8 +383,10 @@ class SlabSimulator:
         are exchanged ONCE; each rank then evaluates the net on its owned planes +- NET_MARGIN -- a crop whose offset and depth are
         multiples of 4, so its resampling grids coincide with the global ones and everything further than the receptive field
         from the crop's artificial faces equals the single-domain result -- and finishes (velocityUpdate, un-normalise,
-        setWallBcs, setConstVals) on the owned planes.  Costs 2 x 48 redundant planes of net per interior rank: the simple, exact
-        variant (a per-layer halo exchange would remove the redundancy)."""
+        setWallBcs, setConstVals) on the owned planes.  The three towers run on NESTED crops of that window (owned +- 8 / 24 / 48
+        planes for the full- / half- / quarter-resolution tower: NET_MARGIN_FULL / _HALF), so an interior rank of 64 planes spends 1.3 x
+        the FLOPs of its owned planes (2.5 x with every tower on the whole window; a per-layer halo exchange of up to 128-channel
+        planes would remove the rest); the pressure of the one plane below the owned ones comes from the neighbour."""
         l, cfg, ops = self.l, self.cfg, self.ops
         G = self.NET_MARGIN
         ops.convnet_stage(U_adv, rho_adv, st, cfg)                   # -> st["U"], st["density"] on the owned planes
@@ -406,8 +414,15 @@ class SlabSimulator:
         e1 = min(top_ + G, l.D_local) if l.rank < l.world - 1 else l.D_local
         div = ops.divergence(Un, flags)                                 # (valid on e0 .. e1: U_z of plane e1 is a ghost plane)
         x = torch.cat([div[:, :, e0:e1], ops.occupancy(flags)[:, :, e0:e1]], 1).contiguous()
+        # nested crops: where the window ends at an artificial face (a neighbour's planes go on beyond it) the full- / half-
+        # resolution towers stop NET_MARGIN_FULL / _HALF planes outside the owned ones; at a domain face nothing is trimmed
+        cut_lo, cut_hi = l.rank > 0 and lo_ - e0 == G, l.rank < l.world - 1 and e1 - top_ == G
+        trim = [G - self.NET_MARGIN_FULL if cut_lo else 0, G - self.NET_MARGIN_FULL if cut_hi else 0,
+                G - self.NET_MARGIN_HALF if cut_lo else 0, G - self.NET_MARGIN_HALF if cut_hi else 0]
         pn = torch.zeros_like(st["p"])
-        pn[:, :, e0:e1] = ops.multiscale(self.net, x)
+        pn[:, :, e0 + trim[0]:e1 - trim[1]] = ops.multiscale(self.net, x, trim)
+        if l.world > 1:
+            yield "xchg", [pn], 1           # exact on the owned planes; velocityUpdate also reads the neighbour's plane below them
         if window and l.world > 1:
             window(lo_, top_)
         ops.convnet_post(pn, Un, s, st)                                 # velocityUpdate, * s, setWallBcs, setConstVals (owned planes)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 15
+#define FNX_ABI_VERSION 16
 
 enum {
   FNX_OK = 0,
@@ -368,11 +368,19 @@ typedef struct FnxSlabConfig {
   int schedule;             /* FNX_SLAB_DEEP_FIRST (0, the default) / FNX_SLAB_EDGE_FIRST / FNX_SLAB_LAST_PASS / FNX_SLAB_DEEP_BESIDE */
   int method;               /* 0: Jacobi projection; 1: the driver is also sized for the CNN projection (prm->method 1 in
                                fnx_slab_step): needs halo >= FNX_SLAB_NET_MARGIN + 1, halo % 4 == 0, D_global / nranks % 4 == 0
-                               when nranks > 1, and a workspace that holds the net's activations for owned + 2 x 48 planes */
+                               when nranks > 1, and a workspace that holds the net's activations for owned + 2 x 48 planes (sized for the
+                               untrimmed window; the towers run on nested crops of it, see FNX_SLAB_NET_MARGIN_FULL) */
 } FnxSlabConfig;
 /* ghost planes of the MultiScaleNet's input a rank evaluates beyond its owned planes: the net's receptive field (< 48 cells at
  * full resolution), a multiple of 4 so that the rank's quarter- and half-resolution grids coincide with the global ones */
 #define FNX_SLAB_NET_MARGIN 48
+/* ... of which the towers need less: the full-resolution tower's receptive radius is 8 planes (5^3, four 3^3, 5^3), the
+ * half-resolution tower's 14 (+ 2 for the resampling above it, + the 8), the quarter-resolution tower's 16 (+ 4, + the 24 = 44).  A
+ * rank therefore runs each tower only on owned +- its own margin (nested crops, fnx_multiscale_forward_crop): 1.3 x the FLOPs of
+ * its owned planes at 64 planes per rank instead of 2.5 x.  The pressure is then exact on the owned planes; the one plane below them
+ * that velocityUpdate reads comes from the neighbour (a one-plane exchange of p). */
+#define FNX_SLAB_NET_MARGIN_FULL 8
+#define FNX_SLAB_NET_MARGIN_HALF 24
 typedef struct FnxSlab FnxSlab;
 /* Local geometry of a rank (what to allocate): planes it owns, ghosts below / above, global plane of local plane 0. */
 int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset);
@@ -432,6 +440,15 @@ enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16
 /* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                            void* ws, size_t ws_bytes, void* stream);
+/* The same pass on NESTED z-crops (what the z-slab driver's CNN projection runs on a rank's window, fnx_slab_step): x covers D
+ * planes; the quarter-resolution tower runs on all of them, the half-resolution tower on planes [trim[2], D - trim[3]) and the
+ * full-resolution tower on [trim[0], D - trim[1]) -- full-resolution plane counts, multiples of 4 (D too), trim[2] <= trim[0],
+ * trim[3] <= trim[1].  p: (B,1,D - trim[0] - trim[1],H,W), the planes [trim[0], D - trim[1]).  Where a window ends at an artificial
+ * face the tower's output is only meaningful beyond its receptive radius from that face (8 / 14 / 16 full-resolution planes for the
+ * full / half / quarter tower, + 2 / 4 for the resampling between them): the caller sizes the windows (FNX_SLAB_NET_MARGIN and
+ * FNX_SLAB_NET_TRIM_* below).  trim = {0,0,0,0} is fnx_multiscale_forward.  Workspace: as fnx_multiscale_forward for D planes. */
+int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
+                                const int trim[4], void* ws, size_t ws_bytes, void* stream);
 /* input: (B,5|6,D,H,W) = [p, U, flags, density] -> p_out (B,1,..), U_out (B,2|3,..) */
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float normalize_threshold,
                          float* p_out, float* U_out, int precision_mode, void* ws, size_t ws_bytes, void* stream);

@@ -81,16 +81,23 @@ static inline void src_index(int dst, int in, int out, int* i0, int* i1, float* 
   *l0 = 1.f - *l1;
 }
 
-/* x (B*C, Di,Hi,Wi) -> y (B*C, Do,Ho,Wo) written at channel offset c_off of a (B, Ctot, ...) tensor */
-static void resize_linear(const float* x, float* y, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                          int Ctot, int c_off) {
+/* x (B*C, Di,Hi,Wi) -> y (B*C, Do,Ho,Wo) written at channel offset c_off of a (B, Ctot, ...) tensor.
+ * zw (ora_multiscale_forward_crop; NULL = whole tensors): either tensor may hold a WINDOW of planes of a deeper notional tensor --
+ * the interpolation runs in the notional depths zw[0] -> zw[2]; x holds the notional planes [zw[1], zw[1] + Di), y the notional
+ * planes [zw[3], zw[3] + Do); a source plane outside x's window is clamped into it. */
+static void resize_linear_win(const float* x, float* y, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                              int Ctot, int c_off, const int* zw) {
+  const int full_in = zw ? zw[0] : Di, in_off = zw ? zw[1] : 0, full_out = zw ? zw[2] : Do, out_off = zw ? zw[3] : 0;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b)
     for (int c = 0; c < C; ++c) {
       const float* xi = x + ((size_t)b * C + c) * Di * Hi * Wi;
       float* yo = y + ((size_t)b * Ctot + c_off + c) * Do * Ho * Wo;
       for (int z = 0; z < Do; ++z) {
-        int z0, z1; float f0, f1; src_index(z, Di, Do, &z0, &z1, &f0, &f1);
+        int z0, z1; float f0, f1; src_index(z + out_off, full_in, full_out, &z0, &z1, &f0, &f1);
+        z0 -= in_off; z1 -= in_off;
+        z0 = z0 < 0 ? 0 : (z0 > Di - 1 ? Di - 1 : z0);
+        z1 = z1 < 0 ? 0 : (z1 > Di - 1 ? Di - 1 : z1);
         for (int j = 0; j < Ho; ++j) {
           int y0, y1; float t0, t1; src_index(j, Hi, Ho, &y0, &y1, &t0, &t1);
           for (int i = 0; i < Wo; ++i) {
@@ -98,7 +105,7 @@ static void resize_linear(const float* x, float* y, int B, int C, int Di, int Hi
 #define XI(zz, yy, xx) xi[((size_t)(zz) * Hi + (yy)) * Wi + (xx)]
             float lo = t0 * (s0 * XI(z0, y0, x0) + s1 * XI(z0, y0, x1)) + t1 * (s0 * XI(z0, y1, x0) + s1 * XI(z0, y1, x1));
             float v = lo;
-            if (Di > 1 || Do > 1) {
+            if (full_in > 1 || full_out > 1) {
               float hi = t0 * (s0 * XI(z1, y0, x0) + s1 * XI(z1, y0, x1)) + t1 * (s0 * XI(z1, y1, x0) + s1 * XI(z1, y1, x1));
               v = f0 * lo + f1 * hi;
             }
@@ -108,6 +115,10 @@ static void resize_linear(const float* x, float* y, int B, int C, int Di, int Hi
         }
       }
     }
+}
+static void resize_linear(const float* x, float* y, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                          int Ctot, int c_off) {
+  resize_linear_win(x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, Ctot, c_off, NULL);
 }
 
 static size_t layer_floats(const Layer* L, int is3D) {
@@ -159,6 +170,36 @@ int ora_multiscale_forward(const OraGrid* g, const float* wts, const float* x, f
   float* c1; wts = run_tower(T1, 6, wts, NULL, B, D, H, W, is3D, in1, &c1);
   float* fin; wts = run_tower(TF, 1, wts, NULL, B, D, H, W, is3D, c1, &fin);
   memcpy(p, fin, (size_t)B * D * H * W * sizeof(float));
+  free(xq); free(c4); free(in2); free(c2); free(in1); free(c1); free(fin);
+  return 0;
+}
+
+/* The forward pass on NESTED z-crops: not a reference function -- the checker of fnx_multiscale_forward_crop (include/fluidnet_hip.h),
+ * which the z-slab driver's CNN projection runs on a rank's window.  The same towers and resampling as ora_multiscale_forward
+ * (multi_scale_net.py:118-127), the quarter-resolution tower on all D planes of x, the half-resolution tower on the planes
+ * [trim[2], D - trim[3]), the full-resolution tower on [trim[0], D - trim[1]) (full-resolution plane counts, multiples of 4 like D);
+ * the resampling runs in the untrimmed grids' coordinates.  p: (B,1,D - trim[0] - trim[1],H,W). */
+int ora_multiscale_forward_crop(const OraGrid* g, const float* wts, const float* x, const int* trim, float* p) {
+  const int B = g->B, D = g->D, H = g->H, W = g->W;
+  if (!g->is3D || D % 4 || trim[0] % 4 || trim[1] % 4 || trim[2] % 4 || trim[3] % 4 || trim[2] > trim[0] || trim[3] > trim[1]) return 1;
+  const int Dq = (int)(D * 0.25), Hq = (int)(H * 0.25), Wq = (int)(W * 0.25);
+  const int Dh = (int)(D * 0.5), Hh = (int)(H * 0.5), Wh = (int)(W * 0.5);
+  const int f_lo = trim[0], f_n = D - trim[0] - trim[1], h_lo = trim[2] / 2, h_n = Dh - trim[2] / 2 - trim[3] / 2;
+  float* xq = (float*)malloc((size_t)B * 2 * Dq * Hq * Wq * sizeof(float));
+  resize_linear(x, xq, B, 2, D, H, W, Dq, Hq, Wq, 2, 0);
+  float* c4; wts = run_tower(T4, 4, wts, NULL, B, Dq, Hq, Wq, 1, xq, &c4);
+  float* in2 = (float*)malloc((size_t)B * 3 * h_n * Hh * Wh * sizeof(float));
+  const int x_to_h[4] = { D, 0, Dh, h_lo }, q_to_h[4] = { Dq, 0, Dh, h_lo };
+  resize_linear_win(x, in2, B, 2, D, H, W, h_n, Hh, Wh, 3, 0, x_to_h);
+  resize_linear_win(c4, in2, B, 1, Dq, Hq, Wq, h_n, Hh, Wh, 3, 2, q_to_h);
+  float* c2; wts = run_tower(T2, 6, wts, NULL, B, h_n, Hh, Wh, 1, in2, &c2);
+  float* in1 = (float*)malloc((size_t)B * 3 * f_n * H * W * sizeof(float));
+  const int x_to_f[4] = { D, 0, D, f_lo }, h_to_f[4] = { Dh, h_lo, D, f_lo };
+  resize_linear_win(x, in1, B, 2, D, H, W, f_n, H, W, 3, 0, x_to_f);
+  resize_linear_win(c2, in1, B, 1, h_n, Hh, Wh, f_n, H, W, 3, 2, h_to_f);
+  float* c1; wts = run_tower(T1, 6, wts, NULL, B, f_n, H, W, 1, in1, &c1);
+  float* fin; wts = run_tower(TF, 1, wts, NULL, B, f_n, H, W, 1, c1, &fin);
+  memcpy(p, fin, (size_t)B * f_n * H * W * sizeof(float));
   free(xq); free(c4); free(in2); free(c2); free(in1); free(c1); free(fin);
   return 0;
 }

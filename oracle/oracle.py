@@ -261,6 +261,19 @@ def multiscale_forward(blob, x, is3d=None):
     return p if x.ndim == 5 else p[:, :, 0]
 
 
+def multiscale_forward_crop(blob, x, trim):
+    """The forward pass on nested z-crops (the checker of fnx_multiscale_forward_crop; ora_multiscale_forward_crop):
+    x (B,2,D,H,W), trim = [full-tower low, high, half-tower low, high] -> p (B,1,D - trim[0] - trim[1],H,W)"""
+    B, _, D, H, W = x.shape
+    g = OraGrid(B, D, H, W, 1, 0, 0)
+    x, px = _f(x); blob, pb = _f(blob)
+    tr = (ctypes.c_int * 4)(*[int(t) for t in trim])
+    p = np.empty((B, 1, D - int(trim[0]) - int(trim[1]), H, W), np.float32)
+    rc = lib().ora_multiscale_forward_crop(ctypes.byref(g), pb, px, tr, p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    assert rc == 0, "multiscale_forward_crop: 3D only, D and the trims multiples of 4, half window containing the full one"
+    return p
+
+
 def scale_std(U, thr=1e-5):
     B, nc, D, H, W = U.shape
     g = OraGrid(B, D, H, W, int(nc == 3), 0, 0)

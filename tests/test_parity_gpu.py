@@ -564,6 +564,45 @@ def test_cnn_bf16x6_vs_oracle(dev, oracle, shape):
     assert_close_rel(N(net.multiScale(xt)).reshape(want.shape), want, 1e-5, "MultiScaleNet")
 
 
+@pytest.mark.parametrize("case", ["middle", "bottom", "top", "batch2_bf16x6"])
+def test_multiscale_forward_nested_crops_vs_oracle(dev, oracle, ext, case):
+    """fnx_multiscale_forward_crop (a z-slab rank's window: quarter-resolution tower on owned +- 48 planes, half- / full-resolution
+    towers on owned +- 24 / 8) against the oracle's towers on the same nested windows -- every plane of the result, 1e-5 of
+    |ref|max -- and, on the owned planes, against the UNTRIMMED pass over the whole domain (what the margins are for); a window
+    that ends at a domain face is not trimmed there.  Refusals: trims that are not multiples of 4 or not nested."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.slab import SlabSimulator as S
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    G, MF, MH = S.NET_MARGIN, S.NET_MARGIN_FULL, S.NET_MARGIN_HALF
+    B = 2 if case.startswith("batch2") else 1
+    Dg, H, W, owned = 160, 16, 24, 16
+    own = dict(middle=(72, 88), bottom=(0, 16), top=(144, 160), batch2_bf16x6=(72, 88))[case]
+    e0, e1 = max(own[0] - G, 0), min(own[1] + G, Dg)
+    cut_lo, cut_hi = own[0] - e0 == G, e1 - own[1] == G
+    trim = [G - MF if cut_lo else 0, G - MF if cut_hi else 0, G - MH if cut_lo else 0, G - MH if cut_hi else 0]
+    w = make_scalenet_weights(0, ndim=3)
+    blob = oracle.pack_weights(w, 3)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((B, 2, Dg, H, W)).astype(np.float32)
+    x[:, 1] = rng.random((B, Dg, H, W)) < 0.1
+    xw = np.ascontiguousarray(x[:, :, e0:e1])
+    mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True, normalizeInputChan="UDiv",
+                 normalizeInputThreshold=1e-5, is3D=True, precisionMode="bf16x6" if case.endswith("bf16x6") else "fp32")
+    net = FluidNet.from_weights(mconf, w, dev)
+    got = N(net.multiScale(T(xw, dev), trim))
+    want = oracle.multiscale_forward_crop(blob, xw, trim)
+    assert got.shape == want.shape == (B, 1, e1 - e0 - trim[0] - trim[1], H, W)
+    assert_close_rel(got, want, 1e-5, f"nested crops ({case}) vs the oracle's")
+    full = oracle.multiscale_forward(blob, x, True)
+    lo = e0 + trim[0]
+    assert_close_rel(got[:, :, own[0] - lo:own[1] - lo], full[:, :, own[0]:own[1]], 1e-5, f"nested crops ({case}): owned planes vs the whole domain")
+    if case == "middle":
+        assert_bitexact(N(net.multiScale(T(xw, dev), [0, 0, 0, 0])), N(net.multiScale(T(xw, dev))), "no trim = the plain pass")
+        for bad in ([40, 40, 22, 24], [40, 40, 44, 24], [-4, 40, 0, 24], [56, 56, 24, 24]):
+            with pytest.raises(RuntimeError):
+                net.multiScale(T(xw, dev), bad)
+
+
 def test_fluidnet_built_like_the_reference_driver(dev, golden):
     """plume.py:119-123 verbatim: FluidNet(mconf, dropout=False) -> .cuda() -> .load_state_dict(state['state_dict']) ->
     forward; and a net moved / reloaded after its first forward repacks its weights."""

@@ -108,8 +108,8 @@ class OracleOps:
     def occupancy(self, flags):
         return torch.from_numpy(self.O.flags_to_occupancy(flags.numpy()))
 
-    def multiscale(self, net, x):
-        return torch.from_numpy(net(x.numpy()))
+    def multiscale(self, net, x, trim=None):
+        return torch.from_numpy(net(x.numpy(), trim) if trim is not None and any(trim) else net(x.numpy()))
 
     def convnet_post(self, pn, Un, s, st):
         O = self.O
@@ -277,7 +277,40 @@ def _cnn_reference(gs, nsteps):
     st = dict(gs)
     for _ in range(nsteps):
         st = O.simulate_step(st, CNN_CFG, "convnet", blob)
-    return st, (lambda x: O.multiscale_forward(blob, x, True))
+    # (a rank's window: the nested crops of SlabSimulator._convnet_projection through the oracle's own towers)
+    return st, (lambda x, trim=None: O.multiscale_forward_crop(blob, x, trim) if trim is not None else O.multiscale_forward(blob, x, True))
+
+
+def test_nested_crop_margins_are_exact_and_tight_cpu():
+    """SlabSimulator.NET_MARGIN / NET_MARGIN_HALF / NET_MARGIN_FULL (= FNX_SLAB_NET_MARGIN*): on a rank's window of owned +- 48 planes
+    with the half- / full-resolution towers on owned +- 24 / 8, the oracle's towers give the single-domain pressure on every
+    owned plane BIT FOR BIT (direct convolutions: same sums) -- and one step less of either margin does not."""
+    from oracle import oracle as O
+    from fluidnet_cxx_amd.slab import SlabSimulator as S
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    O.build()
+    blob = O.pack_weights(make_scalenet_weights(0, ndim=3), 3)
+    rng = np.random.default_rng(0)
+    D, H, W, G = 144, 8, 12, S.NET_MARGIN
+    x = rng.standard_normal((1, 2, D, H, W)).astype(np.float32)
+    x[:, 1] = (rng.random((1, D, H, W)) < 0.1)                         # an occupancy channel
+    full = O.multiscale_forward(blob, x, True)
+    own = (56, 88)
+    e0, e1 = own[0] - G, own[1] + G
+    xw = np.ascontiguousarray(x[:, :, e0:e1])
+
+    def owned_exact(mf, mh):
+        trim = [G - mf, G - mf, G - mh, G - mh]
+        pc = O.multiscale_forward_crop(blob, xw, trim)
+        lo = e0 + trim[0]
+        return np.array_equal(pc[:, :, own[0] - lo:own[1] - lo].view(np.int32), full[:, :, own[0]:own[1]].view(np.int32))
+    assert owned_exact(S.NET_MARGIN_FULL, S.NET_MARGIN_HALF)
+    assert not owned_exact(S.NET_MARGIN_FULL - 4, S.NET_MARGIN_HALF)
+    assert not owned_exact(S.NET_MARGIN_FULL, S.NET_MARGIN_HALF - 4)
+    # at a domain face nothing is trimmed on that side: rank 0's window [0, owned + 48)
+    xw0 = np.ascontiguousarray(x[:, :, :32 + G])
+    p0 = O.multiscale_forward_crop(blob, xw0, [0, G - S.NET_MARGIN_FULL, 0, G - S.NET_MARGIN_HALF])
+    assert np.array_equal(p0[:, :, :32].view(np.int32), full[:, :, :32].view(np.int32))
 
 
 def _check_cnn_owned(st, ref, layout, what, density_exact=True):
