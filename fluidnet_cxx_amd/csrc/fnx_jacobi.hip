@@ -98,6 +98,51 @@ __device__ __forceinline__ void jacobi_rows(float (&p)[V], const float (&d)[V], 
   for (int n = 0; n < N; ++n) { delta[n] = v[n] - pc[n]; p[R0 + n] = v[n]; }
 }
 
+// The obstacle-aware update with the five masks of a row as LANE MASKS (one bool per row and mask: an SGPR pair each, the select a
+// single v_cndmask) instead of bits of a per-lane word (v_bfe + v_bfi per select): for the 4-row waves of the deep launches, where
+// 20 masks fit the scalar registers -- small grids run the masked path on every tile that touches the domain wall (85 -> 57 VALU
+// instructions per sweep of a wave's four rows; the plain path has 28).  Same operations on the same operands: same bits.
+template <int V> struct LaneMasks { bool L[V], R[V], D[V], U[V], C[V]; };
+template <int V, int R0, int N>
+__device__ __forceinline__ void jacobi_rows_lm(float (&p)[V], const float (&d)[V], float& carry, const LaneMasks<V>& m, float top) {
+  float pc[N], pl[N], pr[N], sum[N], v[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) pc[n] = p[R0 + n];
+  const float up_last = (R0 + N < V) ? p[(R0 + N < V) ? R0 + N : 0] : top;
+#pragma unroll
+  for (int n = 0; n < N; ++n) pl[n] = dpp_from_left(pc[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) pr[n] = dpp_from_right(pc[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) pl[n] = m.L[R0 + n] ? pc[n] : pl[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) pr[n] = m.R[R0 + n] ? pc[n] : pr[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) sum[n] = pl[n] + pr[n];
+  float dn[N], un[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) { dn[n] = n == 0 ? carry : pc[n > 0 ? n - 1 : 0]; un[n] = n == N - 1 ? up_last : pc[n < N - 1 ? n + 1 : 0]; }
+#pragma unroll
+  for (int n = 0; n < N; ++n) dn[n] = m.D[R0 + n] ? pc[n] : dn[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) un[n] = m.U[R0 + n] ? pc[n] : un[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) sum[n] = sum[n] + dn[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) sum[n] = sum[n] + un[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) sum[n] = sum[n] + 0.f;           // (see jacobi_rows)
+#pragma unroll
+  for (int n = 0; n < N; ++n) sum[n] = sum[n] + d[R0 + n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = sum[n] / 4.f;
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = m.C[R0 + n] ? v[n] : 0.f;
+  carry = pc[N - 1];
+#pragma unroll
+  for (int n = 0; n < N; ++n) p[R0 + n] = v[n];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 2D, workgroup tiles: NW waves stacked in y form ONE tile of 64 x (NW*RW) cells and hand each other their edge rows
 // through LDS once per sweep (one barrier per sweep, two LDS row images alternating), so only the workgroup's outer ring
@@ -189,6 +234,13 @@ __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const 
   if (w == NW - 1) cont &= ~(1u << (V - 1));
   if (lane == 0 || lane == 63) cont = 0;
   unsigned mL[2] = {obL, 0}, mR[2] = {obR, 0}, mD[2] = {obD, 0}, mU[2] = {obU, 0}, mC[2] = {cont, 0};
+  LaneMasks<(V <= 4 ? V : 1)> lm;
+  if constexpr (V <= 4) {
+#pragma unroll
+    for (int r = 0; r < V; ++r) {
+      lm.L[r] = (obL >> r) & 1u; lm.R[r] = (obR >> r) & 1u; lm.D[r] = (obD >> r) & 1u; lm.U[r] = (obU >> r) & 1u; lm.C[r] = (cont >> r) & 1u;
+    }
+  }
   // output rows of this wave: tile rows [K, NW*RW - K) that lie in the grid
   int out_lo = K - w * RW, out_hi = NW * RW - K - w * RW;
   if (out_lo < 0) out_lo = 0;
@@ -213,7 +265,11 @@ __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const 
     // (K = 28) skips 40 % of its row updates, a K = 8 launch the outer groups of its first and last wave.
     const int tr0 = w * RW;                                // first tile row of this wave
     if (all_plain) wg_sweep_live<V, 0, NI, false>(p, d, carry, top, mL, mR, mD, mU, mC, tr0, s, NW * RW);
-    else {
+    else if constexpr (V <= 4) {
+      // (a wave of <= 4 rows is one row group: stale exactly when wg_sweep_live would skip it)
+      const bool stale = (tr0 + V - 1 < s + 1) | (tr0 > NW * RW - 2 - s);
+      if (!stale) jacobi_rows_lm<V, 0, V>(p, d, carry, lm, top);
+    } else {
       asm volatile("" : "+v"(mL[0]), "+v"(mR[0]), "+v"(mD[0]), "+v"(mU[0]), "+v"(mC[0]));
       wg_sweep_live<V, 0, NI, true>(p, d, carry, top, mL, mR, mD, mU, mC, tr0, s, NW * RW);
     }
@@ -787,7 +843,7 @@ void launch_tiles(const GridDims& g, const float* flags, const float* div, const
   const long cells = (long)g.W * g.H * g.B;
   if (K <= 8 && cells <= (160l << 10)) { launch_wg<8, 4>(g, flags, div, p_in, p_out, from_zero, K, s); return; }
   // deep launches (small grids, one tile per CU): a sweep costs a wave the chain over its rows, so 4 rows x 16 waves per tile
-  // (128^2 x 28 in one launch: 24.0 -> 22.6 us, step 42 -> 40 us; same bits)
+  // (128^2 x 28 in one launch: 24.0 -> 22.6 us, step 42 -> 40 us; with the lane masks of jacobi_rows_lm 19.0 us, step 36 us; same bits)
   if (K > 10) { launch_wg<4, 16>(g, flags, div, p_in, p_out, from_zero, K, s); return; }
   launch_wg<8, 8>(g, flags, div, p_in, p_out, from_zero, K, s);
 }
