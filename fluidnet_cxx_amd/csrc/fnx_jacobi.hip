@@ -101,8 +101,10 @@ __device__ __forceinline__ void jacobi_rows(float (&p)[V], const float (&d)[V], 
 // The obstacle-aware update with the five masks of a row as LANE MASKS (one bool per row and mask: an SGPR pair each, the select a
 // single v_cndmask) instead of bits of a per-lane word (v_bfe + v_bfi per select): for the 4-row waves of the deep launches, where
 // 20 masks fit the scalar registers -- small grids run the masked path on every tile that touches the domain wall (85 -> 57 VALU
-// instructions per sweep of a wave's four rows; the plain path has 28).  Same operations on the same operands: same bits.
-template <int V> struct LaneMasks { bool L[V], R[V], D[V], U[V], C[V]; };
+// instructions per sweep of a wave's four rows, ~45 with the unused select groups skipped; the plain path has 28).  Same operations on the same operands: same bits.
+// anyL .. anyU (wave-uniform): does any live cell of the wave take that substitution at all?  A wave beside the left wall only has
+// left-neighbour substitutions: the other three groups of selects are skipped by scalar branches.
+template <int V> struct LaneMasks { bool L[V], R[V], D[V], U[V], C[V]; bool anyL, anyR, anyD, anyU; };
 template <int V, int R0, int N>
 __device__ __forceinline__ void jacobi_rows_lm(float (&p)[V], const float (&d)[V], float& carry, const LaneMasks<V>& m, float top) {
   float pc[N], pl[N], pr[N], sum[N], v[N];
@@ -113,19 +115,27 @@ __device__ __forceinline__ void jacobi_rows_lm(float (&p)[V], const float (&d)[V
   for (int n = 0; n < N; ++n) pl[n] = dpp_from_left(pc[n]);
 #pragma unroll
   for (int n = 0; n < N; ++n) pr[n] = dpp_from_right(pc[n]);
+  if (m.anyL) {
 #pragma unroll
-  for (int n = 0; n < N; ++n) pl[n] = m.L[R0 + n] ? pc[n] : pl[n];
+    for (int n = 0; n < N; ++n) pl[n] = m.L[R0 + n] ? pc[n] : pl[n];
+  }
+  if (m.anyR) {
 #pragma unroll
-  for (int n = 0; n < N; ++n) pr[n] = m.R[R0 + n] ? pc[n] : pr[n];
+    for (int n = 0; n < N; ++n) pr[n] = m.R[R0 + n] ? pc[n] : pr[n];
+  }
 #pragma unroll
   for (int n = 0; n < N; ++n) sum[n] = pl[n] + pr[n];
   float dn[N], un[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) { dn[n] = n == 0 ? carry : pc[n > 0 ? n - 1 : 0]; un[n] = n == N - 1 ? up_last : pc[n < N - 1 ? n + 1 : 0]; }
+  if (m.anyD) {
 #pragma unroll
-  for (int n = 0; n < N; ++n) dn[n] = m.D[R0 + n] ? pc[n] : dn[n];
+    for (int n = 0; n < N; ++n) dn[n] = m.D[R0 + n] ? pc[n] : dn[n];
+  }
+  if (m.anyU) {
 #pragma unroll
-  for (int n = 0; n < N; ++n) un[n] = m.U[R0 + n] ? pc[n] : un[n];
+    for (int n = 0; n < N; ++n) un[n] = m.U[R0 + n] ? pc[n] : un[n];
+  }
 #pragma unroll
   for (int n = 0; n < N; ++n) sum[n] = sum[n] + dn[n];
 #pragma unroll
@@ -240,6 +250,9 @@ __global__ __launch_bounds__(64 * NW) void jacobi2d_wg_kernel(GridDims g, const 
     for (int r = 0; r < V; ++r) {
       lm.L[r] = (obL >> r) & 1u; lm.R[r] = (obR >> r) & 1u; lm.D[r] = (obD >> r) & 1u; lm.U[r] = (obU >> r) & 1u; lm.C[r] = (cont >> r) & 1u;
     }
+    // (a cell that is not updated -- cont clear: its value is forced to 0 -- does not care which neighbours it would have read)
+    lm.anyL = __any((obL & cont) != 0); lm.anyR = __any((obR & cont) != 0);
+    lm.anyD = __any((obD & cont) != 0); lm.anyU = __any((obU & cont) != 0);
   }
   // output rows of this wave: tile rows [K, NW*RW - K) that lie in the grid
   int out_lo = K - w * RW, out_hi = NW * RW - K - w * RW;
@@ -843,7 +856,7 @@ void launch_tiles(const GridDims& g, const float* flags, const float* div, const
   const long cells = (long)g.W * g.H * g.B;
   if (K <= 8 && cells <= (160l << 10)) { launch_wg<8, 4>(g, flags, div, p_in, p_out, from_zero, K, s); return; }
   // deep launches (small grids, one tile per CU): a sweep costs a wave the chain over its rows, so 4 rows x 16 waves per tile
-  // (128^2 x 28 in one launch: 24.0 -> 22.6 us, step 42 -> 40 us; with the lane masks of jacobi_rows_lm 19.0 us, step 36 us; same bits)
+  // (128^2 x 28 in one launch: 24.0 -> 22.6 us, step 42 -> 40 us; with the lane masks of jacobi_rows_lm 17.6 us, step 35.6 us; same bits)
   if (K > 10) { launch_wg<4, 16>(g, flags, div, p_in, p_out, from_zero, K, s); return; }
   launch_wg<8, 8>(g, flags, div, p_in, p_out, from_zero, K, s);
 }
