@@ -5,7 +5,7 @@ One 512 x 512 x (64 + 2*6) slab (rank 1 of 3: the per-GPU shape of bench.py --gp
 communicator of the C ABI (fnx_slab_comm_link_model): every ghost exchange occupies the communication stream for
 latency + bytes / bandwidth and then fills the ghost planes from the slab's own edge planes.  Reported per schedule and link:
 ms per step, eager and as a HIP-graph replay, next to the ghost-free single slab (rank 0 of 1).
-usage: slab_native_model.py [schedules=deep_first,deep_beside] [w=6]      env MODEL_LINKS="0:0,20:75" MODEL_STEPS=20"""
+usage: slab_native_model.py [schedules=deep_first,deep_beside] [w=6] [halo=max(6, w)]      env MODEL_LINKS="0:0,20:75" MODEL_STEPS=20"""
 import os, sys, time, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -31,20 +31,21 @@ def timed(step, n):
 def main():
     schedules = (sys.argv[1] if len(sys.argv) > 1 else "deep_first,deep_beside").split(",")
     wsw = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    halo = int(sys.argv[3]) if len(sys.argv) > 3 else max(6, wsw)
     n = int(os.environ.get("MODEL_STEPS", 20))
     w = bench.WORKLOADS["plume3d_slab_jacobi"]; m = bench.mconf_for(w)
     cfgs = ((0, 0), (15, 150), (20, 75), (25, 55), (30, 40))
     if os.environ.get("MODEL_LINKS"):
         cfgs = tuple(tuple(int(v) for v in c.split(":")) for c in os.environ["MODEL_LINKS"].split(","))
     # the ghost-free slab
-    l1 = SlabLayout(64, 1, 0, 6)
+    l1 = SlabLayout(64, 1, 0, halo)
     st = bench.plume_state_torch(512, l1.D_local, dev, 0, 64)
     sim = NativeSlabSimulator(l1, m, comm=None, sweeps_per_exchange=wsw, static_flags=True, cfl_check_every=0)
     for _ in range(30):
         sim.step(st)
     base = timed(lambda: sim.step(st), n)
     print(f"ghost-free slab (1 rank): {base:.3f} ms/step", flush=True)
-    layout = SlabLayout(64 * 3, 3, 1, 6)
+    layout = SlabLayout(64 * 3, 3, 1, halo)
     for schedule in schedules:
         for lat, gbps in cfgs:
             st = bench.plume_state_torch(512, layout.D_local, dev, layout.z_offset, layout.D_global)
@@ -68,7 +69,7 @@ def main():
                     sys.stderr.write(f"graph capture failed: {e}\n")
             gtxt = f", graph replay {graph:.3f}" if graph is not None else ""
             best = min(eager, graph) if graph is not None else eager
-            print(f"{schedule} w={wsw}: link {gbps:4d} GB/s + {lat:2d} us -> eager {eager:.3f} ms/step{gtxt}   "
+            print(f"{schedule} w={wsw} halo={halo}: link {gbps:4d} GB/s + {lat:2d} us -> eager {eager:.3f} ms/step{gtxt}   "
                   f"(ghost-free / middle = {base / best * 100:.1f} %)", flush=True)
             del sim, comm
 
