@@ -319,10 +319,12 @@ struct FnxSlab {
   bool mask_valid = false, cls_valid = false;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_post = nullptr, ev_done = nullptr;
-  // deep_beside: the edge chain's stream, its fork / join events and one event per deep pass of a block
+  // deep_beside: the edge chain's stream (the exchanges of the sweep blocks ride on it too), its fork / join events and one
+  // event per deep pass of a block
   hipStream_t edge_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_deep[FNX_SLAB_MAX_HALO] = {};
   bool pending = false;
+  hipStream_t pending_on = nullptr;   // the pending exchange was enqueued on this stream itself (post_on), not on comm_stream
   float* h_cfl = nullptr;    // pinned host float
   // optional statistics (fnx_slab_stats_enable): bytes posted per neighbour and direction, exchanges, and how long the
   // compute stream stood at each wait -- an event pair around the stream wait, read back in fnx_slab_stats_read
@@ -436,6 +438,27 @@ int post(FnxSlab* s, float* const* fields, float* const* sources, const int* cha
   SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), s->comm_stream));
   SLAB_HIP(hipEventRecord(s->ev_done, s->comm_stream));
   s->pending = true;
+  s->pending_on = nullptr;
+  if (s->stats_on) {
+    size_t b = 0;
+    for (const FnxSlabSeg& g : segs) b += g.bytes;
+    s->stats.bytes_per_neighbour += (double)b;
+    s->stats.exchanges += 1;
+  }
+  return FNX_OK;
+}
+// the same exchange enqueued on `on` itself (work enqueued on `on` afterwards is behind it without an event; any other stream
+// waits for ev_done as for post)
+int post_on(FnxSlab* s, float* const* fields, const int* channels, int nf, int width, hipStream_t on) {
+  if (s->cfg.nranks == 1) return FNX_OK;
+  if (width > s->cfg.halo) return fnx::set_error(FNX_EINVAL, "slab: exchange wider than the halo");
+  if (s->pending) return fnx::set_error(FNX_EINVAL, "slab: two exchanges in flight");
+  std::vector<FnxSlabSeg> segs;
+  build_segs(s, fields, nullptr, channels, nf, width, segs);
+  SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), on));
+  SLAB_HIP(hipEventRecord(s->ev_done, on));
+  s->pending = true;
+  s->pending_on = on;
   if (s->stats_on) {
     size_t b = 0;
     for (const FnxSlabSeg& g : segs) b += g.bytes;
@@ -446,6 +469,11 @@ int post(FnxSlab* s, float* const* fields, float* const* sources, const int* cha
 }
 int wait(FnxSlab* s, hipStream_t stream) {
   if (!s->pending) return FNX_OK;
+  if (s->pending_on && s->pending_on == stream) {          // posted on this very stream (post_on): already ordered
+    s->pending = false; s->pending_on = nullptr;
+    return FNX_OK;
+  }
+  s->pending_on = nullptr;
   hipEvent_t *e0 = nullptr, *e1 = nullptr;
   if (s->stats_on) {
     if (s->wait_used + 2 > s->wait_ev.size()) {
@@ -676,7 +704,7 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   Work W;
   if (!ws || carve(s, ws, &W) > ws_bytes) return fnx::set_error(FNX_EWORKSPACE, "slab_step: workspace too small (%zu < %zu)", ws_bytes, carve(s, nullptr, nullptr));
   hipStream_t stream = (hipStream_t)vstream;
-  s->pending = false;                        // (a step that failed half-way must not block the next one)
+  s->pending = false; s->pending_on = nullptr;   // (a step that failed half-way must not block the next one)
   const int world = s->cfg.nranks, rank = s->cfg.rank, w = s->w;
   const int lo = s->lo, top = s->lo + s->owned, DL = s->D_local;
   const bool has_lo = rank > 0, has_hi = rank < world - 1;
@@ -879,7 +907,9 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
         const float* pin = (zero_in && pi == 0) ? nullptr : src;
         SLAB_OK(pass(pin, dst, n, has_lo ? lo + split[pi] : 0, has_hi ? top - split[pi] : DL, -1, Q));
         SLAB_HIP(hipEventRecord(s->ev_deep[pi], stream));
-        // E_pi behind D_(pi-1); the very first launch of a step may have built the solver's obstacle mask: E_0 behind it
+        // E_pi behind D_(pi-1); the very first launch of a step may have built the solver's obstacle mask: E_0 behind it.
+        // (One wait for the whole deep chain instead -- an event wait costs an in-order stream ~6 us even when the event has long
+        // fired -- was measured: no better with a link, 4.69 against 4.15 ms per step without transfer time.)
         if (pi > 0 || first_launch) SLAB_HIP(hipStreamWaitEvent(es, s->ev_deep[pi > 0 ? pi - 1 : 0], 0));
         first_launch = false;
         if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q, es));
@@ -891,9 +921,13 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       }
       if (src != cur) { float* t = cur; cur = nxt; nxt = t; }
       float* ff[1] = {cur};
-      SLAB_OK(post(s, ff, nullptr, c1, 1, w, es));         // posted behind the edge chain, from its stream
       SLAB_HIP(hipEventRecord(s->ev_join, es));            // join: the next block's D_0 reads what the last edge part wrote
       SLAB_HIP(hipStreamWaitEvent(stream, s->ev_join, 0));
+      // The exchange rides on the EDGE stream itself, behind the edge chain and ahead of the next block's: the serial chain
+      // exchange -> edge chain -> exchange that bounds a block with a real link is then one in-order stream -- no stream hand-over
+      // (an event record + wait costs ~10 us on this runtime) anywhere on it.  The next block's deep chain was released by the
+      // join above and runs beside the transfer: it reads owned planes only, the transfer writes ghost planes.
+      SLAB_OK(post_on(s, ff, c1, 1, w, es));
       zero_in = false;
     }
     SLAB_OK(wait(s, stream));
