@@ -662,6 +662,37 @@ def test_native_driver_step_is_graph_capturable():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["deep_first", "deep_beside"])
+def test_native_driver_middle_rank_step_is_graph_capturable(schedule):
+    """A MIDDLE rank's step -- exchanges, sweep blocks with deep and edge parts, in deep_beside the second stream with the exchanges
+    riding on it -- captured in a HIP graph and replayed: the same bits as eager steps.  The link-model communicator stands in for
+    the neighbours (every exchange occupies its stream for latency + bytes / bandwidth and fills the ghost planes from the slab's
+    own edge planes: deterministic, so eager and replayed steps must agree)."""
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    dev = torch.device("cuda:0")
+    gs = global_state(96, 20, 70, seed=8)
+    l = SlabLayout(96, 3, 1, 6)
+    a, b = local_state(gs, l, dev), local_state(gs, l, dev)
+    cfg = dict(CFG, jacobiIter=20)
+    sa = NativeSlabSimulator(l, cfg, comm=ext.slab_comm_link_model(5.0, 100.0), sweeps_per_exchange=6, static_flags=True, cfl_check_every=0, schedule=schedule)
+    sb = NativeSlabSimulator(l, cfg, comm=ext.slab_comm_link_model(5.0, 100.0), sweeps_per_exchange=6, static_flags=True, cfl_check_every=0, schedule=schedule)
+    for _ in range(2):
+        sa.step(a); sb.step(b)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sa.step(a)
+    for _ in range(3):
+        g.replay()
+        sb.step(b)
+    torch.cuda.synchronize()
+    for k in ("U", "density", "p"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["U"].abs().max()) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tol", [1e9, 1e-30, 0.3, 0.03])
 def test_native_driver_ptol_matches_single_domain(tol):
     """pTol > 0 in the C++ driver: one sweep per ghost exchange, the residual summed over the ranks through the
