@@ -219,49 +219,72 @@ __global__ __launch_bounds__(BX* BY) void post_projection_kernel(GridDims g, con
   if (i >= g.W || j >= g.H) return;
   constexpr int NC = IS3D ? 3 : 2;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
+  // Straight-line like stage3d_kernel: every load is issued up front with an address that is valid for every lane (a missing -1
+  // neighbour reads the cell itself; BC entries are loaded for the whole wave when any lane needs them) and the conditions become
+  // selects.  (Nested in the conditions they were a chain of load -> wait -> branch round trips: 30 waits for 20 loads.)
   const float fc = flags[os], P = p[os];
   const unsigned cl = cls ? cls[os] : 0u;
   const bool border = is_border<IS3D>(g, i, j, k);
   const float sc = SCALE ? scale[b] : 1.f;
+  float fm[NC], Pm[NC], u[NC], bm[NC], bc[NC];
+  size_t ou[NC];
+  const bool need_u = UBC != nullptr && !(cl & 1);
+  const bool load_u = __builtin_amdgcn_ballot_w64(need_u) != 0;
+  const bool do_rho = rho != nullptr && rhoBC != nullptr && !(rho_done && (cl & 2));
+  const bool need_r = do_rho && !(cl & 2);
+  const bool load_rho = __builtin_amdgcn_ballot_w64(do_rho) != 0, load_r = __builtin_amdgcn_ballot_w64(need_r) != 0;
+#pragma unroll
+  for (int a = 0; a < NC; ++a) {
+    ou[a] = ((size_t)b * NC + a) * g.DHW + o;
+    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
+    const int idx = a == 0 ? i : (a == 1 ? j : k);
+    const int offs = idx > 0 ? off : 0;                    // (idx == 0 is a border cell: fm counts as fc, Pm is not used)
+    fm[a] = flags[os - offs];
+    Pm[a] = p[os - offs];
+    u[a] = U[ou[a]];
+    bm[a] = 1.f; bc[a] = 0.f;
+  }
+  if (load_u) {
+#pragma unroll
+    for (int a = 0; a < NC; ++a) { bm[a] = UBCInvMask[ou[a]]; bc[a] = UBC[ou[a]]; }
+  }
+  float r0 = 0.f, rm = 1.f, rc = 0.f;
+  if (load_rho) r0 = rho[os];
+  if (load_r) { rm = rhoBCInvMask[os]; rc = rhoBC[os]; }
   if (SCALE) p_scaled[os] = P * sc;
 #pragma unroll
   for (int a = 0; a < NC; ++a) {
-    const size_t ou = ((size_t)b * NC + a) * g.DHW + o;
-    const int off = a == 0 ? 1 : (a == 1 ? g.W : g.HW);
-    const int idx = a == 0 ? i : (a == 1 ? j : k);
-    const float fm = idx > 0 ? flags[os - off] : fc;
-    float u = U[ou];
-    if (SCALE) u = u / sc;                                 // model.py:129-168: the net saw U / s
-    if (!border) {     // velocity_update.py:47-149
-      const float Pm = p[os - off];
-      const float m_ff = (fc == FNX_FLUID && fm == FNX_FLUID) ? 1.f : 0.f;
+    float v = u[a];
+    if (SCALE) v = v / sc;                                 // model.py:129-168: the net saw U / s
+    {     // velocity_update.py:47-149 (border cells keep their value)
+      const float m_ff = (fc == FNX_FLUID && fm[a] == FNX_FLUID) ? 1.f : 0.f;
+      float w;
       if (!IS3D) {
-        const float m_fe = (fc == FNX_FLUID && fm == FNX_EMPTY) ? 1.f : 0.f;
-        const float m_ef = (fc == FNX_EMPTY && fm == FNX_FLUID) ? 1.f : 0.f;
-        const float m_nf = (fc == FNX_EMPTY && fm == FNX_EMPTY) ? 1.f : 0.f;
-        u = ((m_ff * (u - (P - Pm)) + m_fe * (u - P)) + m_ef * (u + Pm)) + m_nf * 0.f;
+        const float m_fe = (fc == FNX_FLUID && fm[a] == FNX_EMPTY) ? 1.f : 0.f;
+        const float m_ef = (fc == FNX_EMPTY && fm[a] == FNX_FLUID) ? 1.f : 0.f;
+        const float m_nf = (fc == FNX_EMPTY && fm[a] == FNX_EMPTY) ? 1.f : 0.f;
+        w = ((m_ff * (v - (P - Pm[a])) + m_fe * (v - P)) + m_ef * (v + Pm[a])) + m_nf * 0.f;
       } else {
-        u = m_ff * (u - (P - Pm));
+        w = m_ff * (v - (P - Pm[a]));
       }
+      v = border ? v : w;
     }
-    if (SCALE) u = u * sc;                                 // model.py:221-223
-    if (fc == FNX_FLUID || fc == FNX_OBST) {
-      if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
-        if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) u = 0.f;
-      }
+    if (SCALE) v = v * sc;                                 // model.py:221-223
+    {
+      const bool zface = a == 2 && (k + g.zoff == 0 || k == 0);
+      const bool wall = (fc == FNX_FLUID || fc == FNX_OBST) && !zface && (fm[a] == FNX_OBST || (fc == FNX_OBST && fm[a] == FNX_FLUID));
+      v = wall ? 0.f : v;
     }
     if (UBC) {
-      float m = 1.f, c = 0.f;
-      if (!(cl & 1)) { m = UBCInvMask[ou]; c = UBC[ou]; }
-      const float t = u * m; u = t + c;
+      const float m = need_u ? bm[a] : 1.f, c = need_u ? bc[a] : 0.f;
+      const float t = v * m; v = t + c;
     }
-    U[ou] = u;
+    U[ou[a]] = v;
   }
   // (rho_done: the density has been through this setConstVals before and an identity cell would get its own bits back)
-  if (rho && rhoBC && !(rho_done && (cl & 2))) {
-    float m = 1.f, c = 0.f;
-    if (!(cl & 2)) { m = rhoBCInvMask[os]; c = rhoBC[os]; }
-    const float t = rho[os] * m; rho[os] = t + c;
+  if (do_rho) {
+    const float m = need_r ? rm : 1.f, c = need_r ? rc : 0.f;
+    const float t = r0 * m; rho[os] = t + c;
   }
 }
 
