@@ -317,7 +317,8 @@ typedef struct FnxSlabComm {
    * be waiting for it inside exchange() -- return FNX_ECOMM instead of hanging (RCCL: ncclCommAbort; loopback: a group flag). */
   void (*abort)(void* ctx);
 } FnxSlabComm;
-/* Ordering contract of a communicator: fnx_slab_step issues exchange() on its internal communication stream and the
+/* Ordering contract of a communicator: fnx_slab_step issues exchange() on its internal communication stream (the sweep blocks of
+ * FNX_SLAB_DEEP_BESIDE: on its internal edge stream -- a communicator must take the stream it is given) and the
  * control-path all-reduces (CFL guard, pTol residual) on the caller's stream; every rank issues the same calls in the same
  * order (the step is deterministic).  An all-reduce is only issued when no exchange is pending (the caller's stream has
  * been made to wait for the last one) and is followed by a host synchronisation before the next exchange is posted, so the
@@ -353,8 +354,10 @@ void fnx_slab_comm_free(FnxSlabComm* comm);
  *   EDGE_FIRST  the edge parts of all passes first (shrinking plane ranges), their exchange posted, the interior parts behind it
  *   LAST_PASS   whole passes; only the last pass of a block is split into edge and interior
  *   DEEP_BESIDE the parts of DEEP_FIRST, the edge chain of a block on a second stream BESIDE its deep chain (edge part k waits
- *               for deep part k-1 only; that stream also waits for the previous exchange and posts the next one): a block
- *               takes max(deep chain, exchange + edge chain) instead of their sum
+ *               for deep part k-1 only).  The exchanges of the sweep blocks are enqueued on that stream itself -- exchange(ctx, ...,
+ *               stream) is called with the edge stream, behind the block's edge chain and ahead of the next block's -- so the chain
+ *               exchange -> edge chain -> exchange crosses no stream; a block takes max(deep chain, exchange + edge chain) instead
+ *               of their sum.  Pays with links of >= 150 GB/s per direction; a tie with DEEP_FIRST at 75 GB/s
  * Slabs thinner than 4 sweep blocks, solves of at most one block and pTol > 0 always run LAST_PASS. */
 enum { FNX_SLAB_DEEP_FIRST = 0, FNX_SLAB_EDGE_FIRST = 1, FNX_SLAB_LAST_PASS = 2, FNX_SLAB_DEEP_BESIDE = 3 };
 typedef struct FnxSlabConfig {
