@@ -576,7 +576,7 @@ def compact(out):
     mm = out.get("native_driver", {}).get("middle_rank_model")
     if mm:                                   # (short form: the sentence that says what it is stays in the side file)
         line["middle_rank_model"] = {kk: _r(vv) for kk, vv in mm.items() if kk != "what"}
-        line["middle_rank_model"]["note"] = "1 GPU rehearsing rank 1 of 3 with a link-model communicator: a MODEL of N>=3"
+        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model communicator: a MODEL of N>=3"
     line["detail_file"] = "gpurun_out/bench_detail.json"
     return line, out
 
