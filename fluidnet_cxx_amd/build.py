@@ -45,11 +45,12 @@ def _scratch_users(remarks, kernel):
     """[(function, scratch bytes per lane, VGPR spills)] of the instantiations of `kernel` that use scratch, from hipcc's
     -Rpass-analysis=kernel-resource-usage remarks"""
     import re
-    bad = []
+    bad, seen = [], 0
     for m in re.finditer(r"Function Name: (\S*" + re.escape(kernel) + r"\S*).*?ScratchSize \[bytes/lane\]: (\d+).*?VGPRs Spill: (\d+)", remarks, re.S):
+        seen += 1
         if int(m.group(2)) or int(m.group(3)):
             bad.append((m.group(1), int(m.group(2)), int(m.group(3))))
-    return bad
+    return bad, seen
 
 
 def build_lib(force=False, verbose=False):
@@ -76,8 +77,13 @@ def build_lib(force=False, verbose=False):
             failed = True
             sys.stderr.write(f"--- {unit} ---\n{out.decode()}\n")
         elif unit == "fnx_cnn.hip":
-            bad = _scratch_users(out.decode(), "conv3_wbf_kernel")
-            if bad:
+            bad, seen = _scratch_users(out.decode(), "conv3_wbf_kernel")
+            if seen == 0:      # no remark matched (renamed kernel, another hipcc's remark format): the check must not pass unseen
+                failed = True
+                os.remove(os.path.join(HERE, "build", "fnx_cnn.o"))
+                sys.stderr.write("fnx_cnn.hip: no kernel-resource-usage remark for conv3_wbf_kernel was found in hipcc's output -- the "
+                                 "no-scratch check could not run (fluidnet_cxx_amd/build.py:_scratch_users)\n")
+            elif bad:
                 failed = True
                 os.remove(os.path.join(HERE, "build", "fnx_cnn.o"))
                 sys.stderr.write("fnx_cnn.hip: conv3_wbf_kernel must not spill (fnx_cnn_bf16x6.h: the results of its inline-asm LDS reads are "

@@ -732,7 +732,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            "how long a rank waits for a peer before its call fails (the group stays usable); default 120 s")
       .def("reset", [](PyLoopbackGroup& g) { check_status(fnx_slab_loopback_group_reset(g.g)); },
            "clear an abort (no rank may be inside a call of the group)");
-  py::class_<PySlabComm, std::shared_ptr<PySlabComm>>(m, "SlabComm", "ghost-plane communicator of the native z-slab driver (FnxSlabComm)");
+  py::class_<PySlabComm, std::shared_ptr<PySlabComm>>(m, "SlabComm", "ghost-plane communicator of the native z-slab driver (FnxSlabComm)")
+      // the control-path collectives of the table, callable on their own (every rank of the communicator must call them)
+      .def("allreduce_sum_", [](PySlabComm& c, Tensor x) {
+             TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.scalar_type() == at::kFloat, "allreduce: a contiguous fp32 GPU tensor");
+             c10::hip::HIPGuard guard(x.get_device());
+             py::gil_scoped_release nogil;
+             check_status(c.c.allreduce_sum(c.c.ctx, x.data_ptr<float>(), (int)x.numel(), cur_stream(x)));
+           }, py::arg("x"))
+      .def("allreduce_max_", [](PySlabComm& c, Tensor x) {
+             TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.scalar_type() == at::kFloat, "allreduce: a contiguous fp32 GPU tensor");
+             c10::hip::HIPGuard guard(x.get_device());
+             py::gil_scoped_release nogil;
+             check_status(c.c.allreduce_max(c.c.ctx, x.data_ptr<float>(), (int)x.numel(), cur_stream(x)));
+           }, py::arg("x"));
   m.def("slab_rccl_unique_id", &slab_rccl_unique_id);
   m.def("slab_comm_rccl", &slab_comm_rccl, py::arg("rank"), py::arg("nranks"), py::arg("unique_id"));
   m.def("slab_comm_loopback", &slab_comm_loopback, py::arg("group"), py::arg("rank"));

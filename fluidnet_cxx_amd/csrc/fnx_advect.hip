@@ -222,7 +222,7 @@ __device__ __forceinline__ void sl_scalar_bwd_clamp_cell(const GridDims& g, cons
         const int r = cell - kb * g.HW;
         j0 = r / g.W; i0 = r - j0 * g.W;
       } else {
-        j0 = cell >> 16; i0 = cell & 0xffff;
+        j0 = (int)((unsigned)cell >> 16); i0 = cell & 0xffff;   // (unsigned: rows >= 32768 set the sign bit)
       }
       // 2D (9 cells: cheaper than a separate pass), or traced into a plane this slab does not hold: walk the clipped
       // box directly, as the reference does

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g
     float d = f;
     if (fluid) d = f + half_s * (tl[4][rc0] - bwd);        // applied on border cells too (reference :371)
     // clamp: the 3x3 box of the traced cell (j0 << 16 | i0), members inside the grid and -- unless SAMPLE_OUTSIDE -- fluid
-    const int tj = cell[r] >> 16, ti = cell[r] & 0xffff;
+    const int tj = (int)((unsigned)cell[r] >> 16), ti = cell[r] & 0xffff;   // (unsigned: rows >= 32768 set the sign bit)
     const int di = ti - i, dj = tj - j;
     const bool nearc = ((unsigned)(di + 1) <= 2u) & ((unsigned)(dj + 1) <= 2u);
     const int rct = rc0 + (nearc ? dj * T2P + di : 0);

@@ -169,6 +169,7 @@ struct LoopGroup {
   std::vector<LoopPair> pairs;   // pair i: ranks i, i+1
   std::mutex mu; std::condition_variable cv;
   int red_count = 0, red_gen = 0; std::vector<float> red_val, red_out;   // (red_out: a finished round's result, safe from the next round's first arrival)
+  int red_failed_gen = -1;       // the round that was abandoned (a rank timed out in it): every rank of that round fails together
   std::atomic<bool> aborted{false};   // a rank failed: every party waiting for a peer gives up (FNX_ECOMM) instead of hanging
   // a peer that never arrives (it failed before its exchange call) is an error, not a hang; fnx_slab_loopback_group_set_timeout
   std::atomic<int> timeout_ms{120 * 1000};
@@ -260,9 +261,13 @@ int loop_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
     else for (int i = 0; i < n; ++i) g->red_val[i] = sum ? g->red_val[i] + h[i] : (h[i] > g->red_val[i] ? h[i] : g->red_val[i]);
     if (++g->red_count == g->nranks) { g->red_count = 0; g->red_out = g->red_val; ++g->red_gen; g->cv.notify_all(); }
     else if (LoopWait w = loop_wait(g, g->cv, lk, [&] { return g->red_gen != gen; })) {
-      if (g->red_gen == gen && g->red_count > 0) --g->red_count;       // this rank leaves the unfinished round
+      // This rank's value is already folded into red_val and cannot be taken out again: the unfinished round is abandoned as a
+      // whole (a retry starts a fresh one; the ranks still waiting in this round fail with the same error), never resumed --
+      // resuming would add a retrying rank twice.
+      if (g->red_gen == gen) { g->red_count = 0; g->red_failed_gen = gen; ++g->red_gen; g->cv.notify_all(); }
       return loop_gone(g, w);
     }
+    if (g->red_failed_gen == gen) return loop_gone(g, WAIT_TIMEOUT);
     for (int i = 0; i < n; ++i) h[i] = g->red_out[i];
   }
   SLAB_HIP(hipMemcpyAsync(x, h, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -556,7 +561,7 @@ int fnx_slab_loopback_group_reset(void* group) {
   if (!g) return fnx::set_error(FNX_EINVAL, "loopback group is NULL");
   // (the caller's promise: no rank is inside an exchange or all-reduce of this group)
   for (LoopPair& p : g->pairs) { std::lock_guard<std::mutex> lk(p.mu); p.phase = 0; p.rc = FNX_OK; p.segs.clear(); }
-  { std::lock_guard<std::mutex> lk(g->mu); g->red_count = 0; }
+  { std::lock_guard<std::mutex> lk(g->mu); g->red_count = 0; ++g->red_gen; }
   g->aborted.store(false);
   return FNX_OK;
 }
@@ -685,8 +690,17 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
 
 int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* vstream) {
   const int rc = slab_step_body(s, prm, st, ws, ws_bytes, vstream);
-  // a rank that fails must not leave its neighbours waiting in an exchange it will never join
-  if (rc != FNX_OK && rc != FNX_ECFL && s && s->cfg.nranks > 1 && s->comm.abort) s->comm.abort(s->comm.ctx);
+  if (rc != FNX_OK && s && s->cfg.nranks > 1) {
+    // A step that fails half-way may have forked work onto the internal streams (the edge chain of deep_beside, a posted
+    // exchange) that nothing has joined yet: the caller's stream is made to wait for both, so that a graph capture is left with
+    // no unjoined branch and neither the caller nor the next step can touch p / pbuf / the ghost planes while they are written.
+    hipStream_t stream = (hipStream_t)vstream;
+    if (s->edge_stream && s->ev_join && hipEventRecord(s->ev_join, s->edge_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, s->ev_join, 0);
+    if (s->comm_stream && s->ev_done && hipEventRecord(s->ev_done, s->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, s->ev_done, 0);
+    (void)hipGetLastError();
+    // a rank that fails must not leave its neighbours waiting in an exchange it will never join
+    if (rc != FNX_ECFL && s->comm.abort) s->comm.abort(s->comm.ctx);
+  }
   return rc;
 }
 

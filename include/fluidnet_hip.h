@@ -330,9 +330,12 @@ int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* uniqu
 /* In-process communicator for `nranks` slabs driven by `nranks` host threads of one process (one device, or several
  * with peer access: each side of a pair records only its own event on its own stream): device-to-device copies ordered by
  * events.  A rank whose peer does not arrive within the group's timeout (120 s unless set) returns FNX_ECOMM from that call
- * and the group stays usable (a slow peer is not a dead one); a rank whose group was aborted (FnxSlabComm.abort: some rank's
- * step failed) returns FNX_ECOMM until fnx_slab_loopback_group_reset, which the caller may issue once no rank is inside a call
- * of the group.  Create the group once, then one comm per rank. */
+ * and the group stays usable for DIRECT users of the communicator (a slow peer is not a dead one; an all-reduce round in which a
+ * rank timed out is abandoned as a whole -- every rank of it fails, a retry starts a fresh round).  fnx_slab_step cannot resume a
+ * step half-way: it calls abort() on ANY failure, a timeout included, so through the driver a timeout poisons the group like any
+ * other error.  A rank whose group was aborted (FnxSlabComm.abort: some rank's step failed) returns FNX_ECOMM until
+ * fnx_slab_loopback_group_reset, which the caller may issue once no rank is inside a call of the group.  Create the group
+ * once, then one comm per rank. */
 int fnx_slab_loopback_group(void** group, int nranks);
 int fnx_slab_loopback_group_set_timeout(void* group, double seconds);
 int fnx_slab_loopback_group_reset(void* group);
@@ -403,7 +406,9 @@ void fnx_slab_destroy(FnxSlab* s);
  * sweep still has the single-domain bits, but the residual is summed per rank and then over the ranks (fp32 all-reduce), so a
  * tolerance within rounding (~1e-7 relative) of a sweep's residual can stop one sweep earlier or later than fnx_jacobi does.
  * prm->static_flags is ignored (FnxSlabConfig.static_flags).  ws: fnx_slab_workspace_bytes, kept between steps.
- * On failure (other than FNX_ECFL, which every rank reports together) the communicator's abort() is called. */
+ * On failure (other than FNX_ECFL, which every rank reports together) the communicator's abort() is called -- also when the
+ * failure is a peer timeout of the loopback communicator -- and the caller's stream is made to wait for whatever the failed step
+ * had already forked onto the driver's internal streams. */
 int fnx_slab_step(FnxSlab* s, const FnxStepParams* prm, const FnxState* st, void* ws, size_t ws_bytes, void* stream);
 
 /* Communication statistics of a rank (off by default: the event pairs they need cannot be recorded inside a graph capture).
@@ -449,7 +454,7 @@ int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x,
  * trim[3] <= trim[1].  p: (B,1,D - trim[0] - trim[1],H,W), the planes [trim[0], D - trim[1]).  Where a window ends at an artificial
  * face the tower's output is only meaningful beyond its receptive radius from that face (8 / 14 / 16 full-resolution planes for the
  * full / half / quarter tower, + 2 / 4 for the resampling between them): the caller sizes the windows (FNX_SLAB_NET_MARGIN and
- * FNX_SLAB_NET_TRIM_* below).  trim = {0,0,0,0} is fnx_multiscale_forward.  Workspace: as fnx_multiscale_forward for D planes. */
+ * FNX_SLAB_NET_MARGIN_FULL / _HALF above).  trim = {0,0,0,0} is fnx_multiscale_forward.  Workspace: as fnx_multiscale_forward for D planes. */
 int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                                 const int trim[4], void* ws, size_t ws_bytes, void* stream);
 /* input: (B,5|6,D,H,W) = [p, U, flags, density] -> p_out (B,1,..), U_out (B,2|3,..) */

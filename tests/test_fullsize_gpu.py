@@ -71,6 +71,76 @@ def test_benchmark_size_step_vs_oracle(oracle, name):
         assert_bitexact(bd[k].cpu().numpy(), ref[k], f"{name}: {k} after step {DEVELOP + 1} (max |U| dt = {umax:.3f})")
 
 
+@pytest.mark.parametrize("schedule", ["deep_first", "deep_beside"])
+def test_benchmark_size_middle_rank_vs_oracle(oracle, schedule):
+    """The launch plans of a MIDDLE rank at the size they are timed (bench.py's N > 1 slabs: 512 x 512 x 64 per rank, w = 6,
+    static flags): three slabs of a 512 x 512 x 192 plume in lock-step on one device -- the C++ driver (fnx_slab_step), one host
+    thread and stream per rank, the in-process communicator -- against ONE `oracle.simulate_step` of the whole domain from the
+    same developed state (lib/simulate.py:28-171 per owned plane).  Two slab steps are taken: the first builds the solver mask and
+    the BC class map and is compared with the single-domain HIP step; the second runs under the static promise (what bench.py
+    times) and is the one compared with the oracle.  Rank 1 has two internal faces: its edge / deep plane-range launches (two
+    ranges per launch, 2 x 320 tiles, other plane chunks and XCD renumbering than at 20 x 70) are what this pins."""
+    import threading
+    import bench
+    from fluidnet_cxx_amd import simulate
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS["plume3d_slab_jacobi"]
+    m = bench.mconf_for(w)
+    world, res, own = 3, w["res"], w["D"]
+    D = world * own
+    halo = 12 if schedule == "lagged" else 6
+    bd = bench.plume_state_torch(res, D, dev)
+    ws = torch.empty(ext.step_workspace_bytes(1, D, res, res, True), dtype=torch.uint8, device=dev)
+    for n in range(DEVELOP - 1):
+        simulate(m, bd, None, "jacobi", workspace=ws, static_flags=(0, 3, 7)[min(n, 2)])
+    torch.cuda.synchronize()
+    gs = {k: v.cpu() for k, v in bd.items()}
+    umax = float(gs["U"].abs().max()) * float(m["dt"])
+    assert 0.05 < umax <= 1.0, f"the state did not develop, or left the decomposition's CFL range (max |U| dt = {umax})"
+    layouts = [SlabLayout(D, world, r, halo) for r in range(world)]
+    states = [{k: l.scatter(v).to(dev) for k, v in gs.items()} for l in layouts]
+    group = ext.SlabLoopbackGroup(world)
+    sims = [NativeSlabSimulator(l, m, comm=ext.slab_comm_loopback(group, l.rank), sweeps_per_exchange=6, static_flags=True,
+                                cfl_check_every=8, schedule=schedule) for l in layouts]
+
+    def slab_step():
+        errs = []
+
+        def run(r):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    sims[r].step(states[r])
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:  # noqa: BLE001
+                errs.append((r, e))
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ts), "a rank's thread hangs"
+        assert not errs, errs
+        torch.cuda.synchronize()
+
+    def check(ref, what):
+        for l, st in zip(layouts, states):
+            for k in ("U", "density", "p"):
+                a = st[k][:, :, l.owned_slice].cpu().numpy()
+                assert_bitexact(a, ref[k][:, :, l.z_begin:l.z_begin + l.owned], f"{what}: {k}, rank {l.rank} ({schedule})")
+
+    slab_step()                                                   # step DEVELOP: builds mask + class map
+    simulate(m, bd, None, "jacobi", workspace=ws, static_flags=7)
+    torch.cuda.synchronize()
+    st1 = _np_state(bd)
+    check(st1, f"slab step {DEVELOP} vs the single-domain HIP step")
+    del ws
+    slab_step()                                                   # step DEVELOP + 1: the steady state bench.py times
+    ref = oracle.simulate_step(st1, m, "jacobi")
+    check(ref, f"slab step {DEVELOP + 1} vs oracle.simulate_step of the 512 x 512 x 192 domain")
+
+
 @pytest.mark.parametrize("cfl", [0.5, 3.0])
 def test_tile_advection_vs_oracle_large(oracle, cfl):
     """The 3D LDS-tile advection kernels (fnx_advect_step: z-marching tiles + fix-up launches) DIRECTLY against the oracle on a
@@ -93,6 +163,32 @@ def test_tile_advection_vs_oracle_large(oracle, cfl):
         want_u = oracle.advect_vel(dt, s["U"], s["U"], f, "maccormackFluidNet", 1, 0.7)
         assert_bitexact(r.cpu().numpy(), want_r, f"density, CFL {cfl}, sample_outside={so}")
         assert_bitexact(u.cpu().numpy(), want_u, f"U, CFL {cfl}, sample_outside={so}")
+
+
+@pytest.mark.parametrize("plan", ["cells", "tiles"])
+def test_advection_tall_2d_grid_vs_oracle(oracle, plan):
+    """A 2D grid with more than 32 767 rows (40 000 x 64; check_grid admits up to 65 535): the traced cell of the MacCormack clamp
+    travels between the two advection passes packed as (row << 16) | column, whose sign bit is set for rows >= 32 768 -- decoded
+    with an arithmetic shift the row came out negative and the clamp (fluids_init.cpp:224-263, MacCormackClampFluidNet) was
+    silently skipped there.  advectScalar on its own (cell kernels) and the fused advection pair with either kernel family."""
+    from fluidnet_cxx_amd._ext import ext
+    dev = torch.device("cuda:0")
+    B, D, H, W = 1, 1, 40000, 64
+    dt = 0.2
+    s = random_state(B, D, H, W, 1.2, seed=5)                      # ~CFL 1: the correction overshoots and the clamp acts on most cells
+    f = s["flags"]
+    f[:, :, :, 36000:36003, 20:40] = 2                             # an obstacle bar in the upper rows
+    tf, tU, trho = (torch.from_numpy(s[k]).to(dev) for k in ("flags", "U", "rho"))
+    want_r = oracle.advect_scalar(dt, s["rho"], s["U"], f, "maccormackFluidNet", 1, False, 0.8)
+    want_u = oracle.advect_vel(dt, s["U"], s["U"], f, "maccormackFluidNet", 1, 0.8)
+    top = want_r[0, 0, 0, 33000:]                                   # (clamped values stay inside the source's range [0, 1))
+    assert top.min() >= 0.0 and top.max() <= 1.0
+    if plan == "cells":
+        r1 = ext.advect_scalar(dt, trho, tU, tf, "maccormackFluidNet", 1, False, 0.8)
+        assert_bitexact(r1.cpu().numpy(), want_r, "advect_scalar, 40000 x 64")
+    r, u = ext.advect_step(dt, trho, tU, tf, False, 0.8, plan=plan)
+    assert_bitexact(r.cpu().numpy(), want_r, f"density, 40000 x 64, plan={plan}")
+    assert_bitexact(u.cpu().numpy(), want_u, f"U, 40000 x 64, plan={plan}")
 
 
 def _long_state(D, H, W, seed):

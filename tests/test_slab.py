@@ -598,6 +598,119 @@ def test_native_driver_failing_rank_releases_its_neighbour():
 
 
 @pytest.mark.gpu
+def test_loopback_allreduce_timeout_then_retry_three_ranks():
+    """The in-process communicator's all-reduce with a rank that arrives too late: the round in which a rank timed out is abandoned
+    as a whole -- every rank of it fails -- and the group stays usable: the retry of all three ranks gives the exact sum (a resumed
+    round would add the retrying ranks twice; set_timeout is what makes the wait short)."""
+    import threading
+    import time
+    from fluidnet_cxx_amd._ext import ext
+    dev = torch.device("cuda:0")
+    world = 3
+    group = ext.SlabLoopbackGroup(world)
+    group.set_timeout(0.5)
+    comms = [ext.slab_comm_loopback(group, r) for r in range(world)]
+    xs = [torch.tensor([1.0 + r, 10.0 * (r + 1)], device=dev) for r in range(world)]
+    errs, ok = {}, {}
+
+    def run(r, delay):
+        try:
+            time.sleep(delay)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                comms[r].allreduce_sum_(xs[r])
+                torch.cuda.current_stream().synchronize()
+            ok[r] = True
+        except Exception as e:  # noqa: BLE001
+            errs[r] = str(e)
+
+    # round 1: ranks 0 and 1 arrive, rank 2 stays away longer than the timeout -> both fail, nothing is left folded in
+    ts = [threading.Thread(target=run, args=(r, 0.0)) for r in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert not any(t.is_alive() for t in ts)
+    assert set(errs) == {0, 1} and all("timed out" in e for e in errs.values()), errs
+    assert [x.tolist() for x in xs[:2]] == [[1.0, 10.0], [2.0, 20.0]], "a failed all-reduce leaves its operand alone"
+    # round 2: all three retry (staggered, inside the timeout)
+    errs.clear()
+    ts = [threading.Thread(target=run, args=(r, 0.1 * r)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert not any(t.is_alive() for t in ts) and not errs, errs
+    for x in xs:
+        assert x.tolist() == [6.0, 60.0], x.tolist()
+    # max, for completeness
+    ys = [torch.tensor([float(r)], device=dev) for r in range(world)]
+
+    def runmax(r):
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            comms[r].allreduce_max_(ys[r])
+            torch.cuda.current_stream().synchronize()
+    ts = [threading.Thread(target=runmax, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert [y.item() for y in ys] == [2.0, 2.0, 2.0]
+
+
+@pytest.mark.gpu
+def test_native_driver_timeout_aborts_group_and_reset_clears_it():
+    """Through the DRIVER a peer timeout is a failed step: fnx_slab_step aborts the group (a step cannot be resumed half-way), every
+    later call fails with the abort message until SlabLoopbackGroup.reset(), after which two fresh steps of both ranks match the single
+    domain bit for bit."""
+    import threading
+    from fluidnet_cxx_amd import simulate
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    dev = torch.device("cuda:0")
+    world, w, D = 2, 4, 32
+    gs = global_state(D, 20, 70, seed=4)
+    layouts = [SlabLayout(D, world, r, 6) for r in range(world)]
+    states = [local_state(gs, l, dev) for l in layouts]
+    group = ext.SlabLoopbackGroup(world)
+    group.set_timeout(0.5)
+    sims = [NativeSlabSimulator(l, CFG, comm=ext.slab_comm_loopback(group, l.rank), sweeps_per_exchange=w, cfl_check_every=0) for l in layouts]
+    keep = {k: v.clone() for k, v in states[0].items()}
+    with pytest.raises(RuntimeError, match="timed out"):       # rank 1 never shows up
+        sims[0].step(states[0])
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="group aborted"):   # ... and the driver has aborted the group
+        sims[0].step(states[0])
+    torch.cuda.synchronize()
+    group.reset()
+    group.set_timeout(60.0)
+    states[0] = keep                                            # (the failed steps had already advected rank 0's planes)
+    sims = [NativeSlabSimulator(l, CFG, comm=ext.slab_comm_loopback(group, l.rank), sweeps_per_exchange=w, cfl_check_every=0) for l in layouts]
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    for _ in range(2):
+        simulate(CFG, bd, None, "jacobi")
+    ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
+    errs = []
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                for _ in range(2):
+                    sims[r].step(states[r])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts) and not errs, errs
+    torch.cuda.synchronize()
+    for l, st in zip(layouts, states):
+        check_owned(st, ref, l, "after timeout + reset")
+
+
+@pytest.mark.gpu
 def test_native_driver_cfl_guard_and_errors():
     from fluidnet_cxx_amd._ext import ext
     from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
