@@ -1,11 +1,11 @@
-# usage: trace_schedule.sh <schedule> <latency_us:GB/s> [first_row] [rows] [native]  -- kernel timeline of one step of the overlap model
+# usage: trace_schedule.sh <schedule> <latency_us:GB/s> [first_row] [rows] [native] [w] [halo]  -- kernel timeline of one step of the overlap model
 # (5th argument "native": the C++ driver with the link-model communicator, tools/slab_native_model.py)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 S=${1:-deep_first}; L=${2:-0:0}; A=${3:-0}; N=${4:-120}; TOOL=tools/slab_overlap_model.py
 if [ "${5:-}" = native ]; then TOOL=tools/slab_native_model.py; fi
 rm -rf gpurun_out/trace_$S
-MODEL_LINKS="$L" MODEL_STEPS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_$S -o t -- env MODEL_GRAPH=0 python $TOOL $S 6 2>&1 | grep "ms/step"
+MODEL_LINKS="$L" MODEL_STEPS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_$S -o t -- env MODEL_GRAPH=0 python $TOOL $S ${6:-6} ${7:-} 2>&1 | grep "ms/step"
 python - "$S" "$A" "$N" <<'PY'
 import csv, glob, re, sys
 S, A, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
