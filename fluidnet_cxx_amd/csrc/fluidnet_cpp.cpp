@@ -460,10 +460,10 @@ struct PySlab {
          int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule, const std::string& method) : comm(comm_) {
     cfg.B = B; cfg.H = H; cfg.W = W; cfg.D_global = D_global; cfg.rank = rank; cfg.nranks = nranks; cfg.halo = halo;
     cfg.sweeps_per_exchange = sweeps_per_exchange; cfg.static_flags = static_flags ? 1 : 0; cfg.cfl_check_every = cfl_check_every;
-    TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass" || schedule == "deep_beside" || schedule == "lagged",
+    TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass" || schedule == "deep_beside",
                 "unknown z-slab schedule '", schedule, "'");
     cfg.schedule = schedule == "deep_first" ? FNX_SLAB_DEEP_FIRST : (schedule == "edge_first" ? FNX_SLAB_EDGE_FIRST :
-                   (schedule == "deep_beside" ? FNX_SLAB_DEEP_BESIDE : (schedule == "lagged" ? FNX_SLAB_LAGGED : FNX_SLAB_LAST_PASS)));
+                   (schedule == "deep_beside" ? FNX_SLAB_DEEP_BESIDE : FNX_SLAB_LAST_PASS));
     TORCH_CHECK(method == "jacobi" || method == "convnet", "unknown z-slab method '", method, "'");
     cfg.method = method == "convnet" ? 1 : 0;
     check_status(fnx_slab_create(&s, &cfg, comm ? &comm->c : nullptr));

@@ -296,19 +296,6 @@ __global__ void link_model_wait_kernel(unsigned long long ticks) {       // wall
   const unsigned long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
-// "lagged" sweep blocks: the planes a rank sends (w .. 2w planes inside each internal face) are snapshots -- the next block's second
-// pass overwrites them while the transfer is in flight.  One launch copies both faces of every sample into the send buffer:
-// out[(b * 2 + face) * n .. + n) = p[b * vol + off[face] .. + n).  V = float4 where the offsets allow it.
-template <class V>
-__global__ __launch_bounds__(256) void slab_pack_kernel(const V* __restrict__ p, V* __restrict__ out, size_t vol, size_t off_lo, size_t off_hi,
-                                                        size_t n, int has_lo, int has_hi) {
-  const int face = blockIdx.y, b = blockIdx.z;
-  if ((face == 0 && !has_lo) || (face == 1 && !has_hi)) return;
-  const V* src = p + (size_t)b * vol + (face ? off_hi : off_lo);
-  V* dst = out + ((size_t)b * 2 + face) * n;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
-
 int model_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
   ModelCtx* c = (ModelCtx*)vctx;
   hipStream_t s = (hipStream_t)stream;
@@ -341,7 +328,6 @@ struct FnxSlab {
   // event per deep pass of a block
   hipStream_t edge_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_deep[FNX_SLAB_MAX_HALO] = {};
-  hipEvent_t ev_pack = nullptr;      // lagged: the send buffer of a block is packed (recorded on the caller's stream)
   bool pending = false;
   hipStream_t pending_on = nullptr;   // the pending exchange was enqueued on this stream itself (post_on), not on comm_stream
   float* h_cfl = nullptr;    // pinned host float
@@ -363,7 +349,7 @@ int layout_of(const FnxSlabConfig* c, int* owned, int* lo, int* hi, int* zoff) {
   const int ow = c->D_global / c->nranks;
   if (c->nranks > 1 && c->halo < 5) return fnx::set_error(FNX_EINVAL, "slab: advection + projection need 5 valid ghost planes (CFL <= 1)");
   if (c->halo > FNX_SLAB_MAX_HALO) return fnx::set_error(FNX_EINVAL, "slab: halo %d > %d planes is not supported", c->halo, FNX_SLAB_MAX_HALO);
-  if (c->schedule < FNX_SLAB_DEEP_FIRST || c->schedule > FNX_SLAB_LAGGED) return fnx::set_error(FNX_EINVAL, "slab: unknown schedule %d", c->schedule);
+  if (c->schedule < FNX_SLAB_DEEP_FIRST || c->schedule > FNX_SLAB_DEEP_BESIDE) return fnx::set_error(FNX_EINVAL, "slab: unknown schedule %d", c->schedule);
   if (c->nranks > 1 && ow < c->halo) return fnx::set_error(FNX_EINVAL, "slab thinner than its halo");
   if (c->method != 0 && c->method != 1) return fnx::set_error(FNX_EINVAL, "slab: method %d (0: Jacobi, 1: CNN projection)", c->method);
   if (c->method == 1 && c->nranks > 1 && (c->halo < FNX_SLAB_NET_MARGIN + 1 || c->halo % 4 != 0 || ow % 4 != 0))
@@ -374,13 +360,6 @@ int layout_of(const FnxSlabConfig* c, int* owned, int* lo, int* hi, int* zoff) {
   *hi = c->rank < c->nranks - 1 ? c->halo : 0;
   *zoff = c->rank * ow - *lo;
   return FNX_OK;
-}
-
-// sweeps per ghost exchange of p: clipped to the halo; "lagged" blocks need 2w ghost planes
-int block_w(const FnxSlabConfig& c) {
-  const int cap = c.schedule == FNX_SLAB_LAGGED ? c.halo / 2 : c.halo;
-  int w = c.sweeps_per_exchange < cap ? c.sweeps_per_exchange : cap;
-  return w < 1 ? 1 : w;
 }
 
 FnxGrid grid_of(const FnxSlab* s, int kb = 0, int ke = 0) {
@@ -405,7 +384,6 @@ struct Work {                      // the step's scratch, carved from the caller
   void* msws;
   double* part;                                // the residual's fixed-order partial sums (pTol > 0)
   unsigned char* cls;
-  float* sendbuf[2];                           // lagged: the packed planes of a block's message (two blocks alternate)
   void *jac, *adv;
   size_t jac_bytes, adv_bytes;
 };
@@ -421,11 +399,6 @@ size_t carve(const FnxSlab* s, void* ws, Work* w) {
   t.jac_bytes = fnx_workspace_bytes(&g, FNX_OP_JACOBI); t.jac = take(t.jac_bytes);
   t.adv_bytes = fnx_workspace_bytes(&g, FNX_OP_ADVECT_STEP); t.adv = take(t.adv_bytes);
   t.x_local = t.x_crop = t.p_crop = t.red = t.scale = nullptr; t.wpart = nullptr; t.msws = nullptr;
-  t.sendbuf[0] = t.sendbuf[1] = nullptr;
-  if (s->cfg.schedule == FNX_SLAB_LAGGED && s->cfg.nranks > 1) {
-    const int wb = block_w(s->cfg);
-    for (int q = 0; q < 2; ++q) t.sendbuf[q] = (float*)take((size_t)g.B * 2 * wb * g.H * g.W * 4);
-  }
   if (s->cfg.method == 1) {
     int e0, e1;
     net_range(s, &e0, &e1);
@@ -628,7 +601,8 @@ int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* 
   if (rc != FNX_OK) { delete s; return rc; }
   s->cfg = *cfg;
   s->D_local = s->owned + s->lo + s->hi;
-  s->w = block_w(*cfg);
+  s->w = cfg->sweeps_per_exchange < cfg->halo ? cfg->sweeps_per_exchange : cfg->halo;
+  if (s->w < 1) s->w = 1;
   if (cfg->nranks > 1) {
     if (!comm || !comm->exchange || !comm->allreduce_max || !comm->allreduce_sum) { delete s; return fnx::set_error(FNX_EINVAL, "slab_create: nranks > 1 needs a communicator"); }
     if (s->owned < 2 * s->w) { delete s; return fnx::set_error(FNX_EINVAL, "slab too thin for the sweep block"); }
@@ -639,11 +613,10 @@ int fnx_slab_create(FnxSlab** out, const FnxSlabConfig* cfg, const FnxSlabComm* 
       fnx_slab_destroy(s);
       return fnx::set_error(FNX_EHIP, "slab_create: stream / event creation failed");
     }
-    if (cfg->schedule == FNX_SLAB_DEEP_BESIDE || cfg->schedule == FNX_SLAB_LAGGED) {
+    if (cfg->schedule == FNX_SLAB_DEEP_BESIDE) {
       bool ok = hipStreamCreateWithFlags(&s->edge_stream, hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming) == hipSuccess;
+                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
       for (int i = 0; ok && i < (s->w + 1) / 2; ++i) ok = hipEventCreateWithFlags(&s->ev_deep[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { fnx_slab_destroy(s); return fnx::set_error(FNX_EHIP, "slab_create: stream / event creation failed"); }
     }
@@ -666,7 +639,6 @@ void fnx_slab_destroy(FnxSlab* s) {
   if (s->edge_stream) (void)hipStreamDestroy(s->edge_stream);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-  if (s->ev_pack) (void)hipEventDestroy(s->ev_pack);
   for (hipEvent_t e : s->ev_deep) if (e) (void)hipEventDestroy(e);
   if (s->h_cfl) (void)hipHostFree(s->h_cfl);
   for (hipEvent_t e : s->wait_ev) (void)hipEventDestroy(e);
@@ -852,33 +824,19 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
     return FNX_OK;
   }
   // ---- 2. BC / buoyancy / wall stage + divergence on the owned planes
+  {
+    const FnxGrid g = world > 1 ? grid_of(s, lo, top) : grid_of(s);
+    SLAB_OK(fnx_pre_projection(&g, prm, &state, W.U_adv, W.rho_adv, W.div, stream));
+  }
   float* fd[1] = {W.div};
   const int c1[1] = {1};
   // sweep blocks with an exchange between them (else: thin slabs, short solves, pTol: the "last_pass" code below)
   const bool blocked = world > 1 && s->owned >= 4 * w && prm->jacobi_iter > w && !(prm->p_tol > 0.f);
   const bool beside = blocked && s->cfg.schedule == FNX_SLAB_DEEP_BESIDE;
   const bool deep = blocked && (s->cfg.schedule == FNX_SLAB_DEEP_FIRST || beside);
-  const bool lagged = blocked && s->cfg.schedule == FNX_SLAB_LAGGED && s->cfg.halo >= 2 * w && W.sendbuf[0] != nullptr;
-  if (lagged && s->owned >= 4 * w + 8) {
-    // lagged: the band parts of a sweep block work on ghost planes w .. 2w from the face and need div on 2w - 1 ghost planes.  That
-    // exchange (11 planes at w = 6) is hidden behind the staging of the interior: the 2w owned planes next to each internal face are
-    // staged first (a window stages one plane more than it takes the divergence of: the staging is a pure function of the advected
-    // fields, planes staged twice get the same bits), their div posted, the planes between them staged meanwhile.
-    const int ia = has_lo ? lo + 2 * w : 0, ib = has_hi ? top - 2 * w : DL;
-    if (has_lo) { const FnxGrid g = grid_of(s, lo, ia); SLAB_OK(fnx_pre_projection(&g, prm, &state, W.U_adv, W.rho_adv, W.div, stream)); }
-    if (has_hi) { const FnxGrid g = grid_of(s, ib, top); SLAB_OK(fnx_pre_projection(&g, prm, &state, W.U_adv, W.rho_adv, W.div, stream)); }
-    SLAB_OK(post(s, fd, nullptr, c1, 1, 2 * w - 1, stream));
-    { const FnxGrid g = grid_of(s, ia, ib); SLAB_OK(fnx_pre_projection(&g, prm, &state, W.U_adv, W.rho_adv, W.div, stream)); }
-    SLAB_OK(wait(s, stream));
-  } else {
-    {
-      const FnxGrid g = world > 1 ? grid_of(s, lo, top) : grid_of(s);
-      SLAB_OK(fnx_pre_projection(&g, prm, &state, W.U_adv, W.rho_adv, W.div, stream));
-    }
-    // deep_first: the deep parts of the first sweep block read no ghost plane of div, its exchange is in flight behind them
-    if (deep) SLAB_OK(post(s, fd, nullptr, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
-    else SLAB_OK(xchg(s, fd, c1, 1, lagged ? 2 * w - 1 : (w - 1 > 1 ? w - 1 : 1), stream));
-  }
+  // deep_first: the deep parts of the first sweep block read no ghost plane of div, its exchange is in flight behind them
+  if (deep) SLAB_OK(post(s, fd, nullptr, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
+  else SLAB_OK(xchg(s, fd, c1, 1, w - 1 > 1 ? w - 1 : 1, stream));
 
   // ---- 3. Jacobi: blocks of w sweeps between ghost exchanges of p
   const FnxGrid gj = grid_of(s);
@@ -937,80 +895,6 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
     // solver's row-quad layout, which the plane-range passes below do not)
     SLAB_OK(fnx_jacobi_sweeps_ex(&gj, st->flags, W.div, cur, prm->jacobi_iter, W.jac, W.jac_bytes, (s->mask_valid ? 1 : 0) | 2, stream));
     s->mask_valid = true;
-  } else if (lagged) {
-    // "lagged" (slab.py:_jacobi_lagged): 2w ghost planes per face.  The D part of pass k is the whole shrinking range
-    // [lo - w + done_k, top + w - done_k) -- it starts from the w ghost planes next to the face, which the BAND parts of the previous
-    // block produced, and needs no message; the band part of pass k, [lo - 2w + done_k, lo - w + done_k) and its mirror image, runs
-    // beside it on the edge stream (B_k waits for D_(k-1) only) and starts from the PREVIOUS block's message in ghost planes
-    // [lo - 2w, lo - w).  The message of a block -- the owned planes w .. 2w inside each face, which depend on nothing a neighbour sent
-    // for this block -- is packed behind the last D part (snapshots: the next block overwrites them) and posted on the edge stream
-    // behind the band chain; it is first read one block later.  No exchange -> edge chain -> exchange cycle: a block takes
-    // max(D chain, (transfer + band chain + D chain) / 2).
-    hipStream_t es = s->edge_stream;
-    const size_t plane = (size_t)s->cfg.H * s->cfg.W, vol = plane * DL, nmsg = (size_t)w * plane;
-    bool first_launch = true;
-    int blk = 0;
-    while (remaining > w) {
-      remaining -= w;
-      SLAB_HIP(hipEventRecord(s->ev_fork, stream));        // fork: behind the previous block's join (first block: the staging pass)
-      SLAB_HIP(hipStreamWaitEvent(es, s->ev_fork, 0));
-      SLAB_OK(wait(s, es));                                // the previous block's message was posted on the edge stream itself: ordered
-      float *src = cur, *dst = nxt;
-      int done = 0;
-      for (int pi = 0; pi < npass; ++pi) {
-        const int n = passes[pi];
-        done += n;
-        const float* pin = (zero_in && pi == 0) ? nullptr : src;
-        SLAB_OK(pass(pin, dst, n, has_lo ? lo - w + done : 0, has_hi ? top + w - done : DL, -1, Q));
-        SLAB_HIP(hipEventRecord(s->ev_deep[pi], stream));
-        if (pi > 0 || first_launch) SLAB_HIP(hipStreamWaitEvent(es, s->ev_deep[pi > 0 ? pi - 1 : 0], 0));
-        first_launch = false;
-        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - 2 * w + done, lo - w + done, top + w - done, Q, es));
-        else {
-          if (has_lo) SLAB_OK(pass(pin, dst, n, lo - 2 * w + done, lo - w + done, -1, Q, es));
-          if (has_hi) SLAB_OK(pass(pin, dst, n, top + w - done, top + 2 * w - done, -1, Q, es));
-        }
-        float* t = src; src = dst; dst = t;
-      }
-      if (src != cur) { float* t = cur; cur = nxt; nxt = t; }
-      // the message: owned planes [lo + w, lo + 2w) / [top - 2w, top - w) of every sample, packed on the caller's stream behind the last D part
-      float* sb = W.sendbuf[blk & 1];
-      {
-        const dim3 grid(128, 2, s->cfg.B);
-        const size_t off_lo = (size_t)(lo + w) * plane, off_hi = (size_t)(top - 2 * w) * plane;
-        if (plane % 4 == 0 && ((uintptr_t)cur % 16) == 0 && ((uintptr_t)sb % 16) == 0)
-          slab_pack_kernel<float4><<<grid, 256, 0, stream>>>((const float4*)cur, (float4*)sb, vol / 4, off_lo / 4, off_hi / 4, nmsg / 4, has_lo, has_hi);
-        else
-          slab_pack_kernel<float><<<grid, 256, 0, stream>>>(cur, sb, vol, off_lo, off_hi, nmsg, has_lo, has_hi);
-      }
-      SLAB_HIP(hipEventRecord(s->ev_pack, stream));
-      SLAB_HIP(hipEventRecord(s->ev_join, es));            // join: the next block's D parts start from the ghost planes the last band part wrote
-      SLAB_HIP(hipStreamWaitEvent(stream, s->ev_join, 0));
-      // ... and behind the join (the caller's stream does not wait for the transfer) the exchange, on the edge stream: the planes land
-      // in ghost planes [lo - 2w, lo - w) / [top + w, top + 2w) of `cur`, which nothing but the next block's band parts -- enqueued
-      // behind it on this stream -- touches
-      SLAB_HIP(hipStreamWaitEvent(es, s->ev_pack, 0));
-      {
-        if (s->pending) return fnx::set_error(FNX_EINVAL, "slab: two exchanges in flight");
-        std::vector<FnxSlabSeg> segs;
-        for (int b = 0; b < s->cfg.B; ++b) {
-          FnxSlabSeg g{};
-          g.bytes = nmsg * 4;
-          if (has_lo) { g.send_lo = sb + ((size_t)b * 2 + 0) * nmsg; g.recv_lo = cur + (size_t)b * vol + (size_t)(lo - 2 * w) * plane; }
-          if (has_hi) { g.send_hi = sb + ((size_t)b * 2 + 1) * nmsg; g.recv_hi = cur + (size_t)b * vol + (size_t)(top + w) * plane; }
-          segs.push_back(g);
-        }
-        SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), es));
-        SLAB_HIP(hipEventRecord(s->ev_done, es));
-        s->pending = true;
-        s->pending_on = es;
-        if (s->stats_on) { s->stats.bytes_per_neighbour += (double)s->cfg.B * nmsg * 4; s->stats.exchanges += 1; }
-      }
-      zero_in = false;
-      ++blk;
-    }
-    SLAB_OK(wait(s, stream));
-    SLAB_OK(last_block());
   } else if (beside) {
     // "deep_beside" (slab.py:_jacobi_deep_beside): the plane ranges of "deep_first", the edge chain of a block issued on its
     // own stream beside the deep chain: E_k waits for D_(k-1) only (what it reads just inside its split, and the array it

@@ -53,33 +53,30 @@ class SlabComm:
         self.l = layout
         self.group = group
 
-    def start(self, fields, width, sources=None, depth=0):
+    def start(self, fields, width, sources=None):
         """Post the sends/receives of `width` ghost planes of every field; returns a handle for finish().  `sources`
-        (default: the fields themselves) are the arrays whose owned edge planes are sent.  depth > 0 (the "lagged" sweep
-        blocks): the planes `depth` further from the face on both sides -- owned [lo + depth, lo + depth + width) go to the
-        lower neighbour's ghost planes [top + depth, top + depth + width) and so on -- sent as SNAPSHOTS (the sender's next
-        sweep block overwrites them while the transfer is in flight)."""
+        (default: the fields themselves) are the arrays whose owned edge planes are sent."""
         l = self.l
         if l.world == 1:
             return None
-        assert width + depth <= l.halo
+        assert width <= l.halo
         ops, recvs = [], []
         for f, src in zip(fields, sources if sources is not None else fields):
             if l.rank > 0:           # lower neighbour
-                send = src[:, :, l.lo + depth:l.lo + depth + width]
-                recv = f[:, :, l.lo - depth - width:l.lo - depth]
+                send = src[:, :, l.lo:l.lo + width]
+                recv = f[:, :, l.lo - width:l.lo]
                 direct = send.is_contiguous() and recv.is_contiguous()     # one plane block (B = C = 1): no staging copy
-                sb = (send.clone() if depth > 0 else send) if direct else send.contiguous()
+                sb = send if direct else send.contiguous()
                 rb = recv if direct else torch.empty_like(sb)
                 ops += [dist.P2POp(dist.isend, sb, l.rank - 1, self.group), dist.P2POp(dist.irecv, rb, l.rank - 1, self.group)]
                 if not direct:
                     recvs.append((recv, rb))
             if l.rank < l.world - 1:  # upper neighbour
                 top = l.lo + l.owned
-                send = src[:, :, top - depth - width:top - depth]
-                recv = f[:, :, top + depth:top + depth + width]
+                send = src[:, :, top - width:top]
+                recv = f[:, :, top:top + width]
                 direct = send.is_contiguous() and recv.is_contiguous()     # one plane block (B = C = 1): no staging copy
-                sb = (send.clone() if depth > 0 else send) if direct else send.contiguous()
+                sb = send if direct else send.contiguous()
                 rb = recv if direct else torch.empty_like(sb)
                 ops += [dist.P2POp(dist.isend, sb, l.rank + 1, self.group), dist.P2POp(dist.irecv, rb, l.rank + 1, self.group)]
                 if not direct:
@@ -252,7 +249,7 @@ class SlabSimulator:
         raises RuntimeError on EVERY rank when it exceeds 1 cell -- the bound the ghost widths, the advection windows and the
         overlapped U / density exchange rest on (a violation would otherwise read stale ghost planes silently).  Costs one
         pass over U and one 4-byte all-reduce(MAX) on the control path."""
-        assert schedule in ("last_pass", "edge_first", "deep_first", "deep_beside", "lagged")
+        assert schedule in ("last_pass", "edge_first", "deep_first", "deep_beside")
         assert method in ("jacobi", "convnet")
         self.method, self.net = method, net
         if method == "convnet" and layout.world > 1:
@@ -267,7 +264,7 @@ class SlabSimulator:
         self.cfg = mconf
         self.ops = ops if ops is not None else NativeOps()
         self.comm = SlabComm(layout, group)
-        self.w = max(1, min(sweeps_per_exchange, layout.halo // 2 if schedule == "lagged" else layout.halo))     # ("lagged": 2w ghost planes)
+        self.w = min(sweeps_per_exchange, layout.halo)
         self._pbuf = None
         assert layout.world == 1 or layout.owned >= 2 * self.w, "slab too thin for the sweep block"
         assert layout.world == 1 or layout.halo >= 5, "advection + projection need 5 valid ghost planes (CFL <= 1)"
@@ -350,16 +347,12 @@ class SlabSimulator:
             window(0, 0)
         blocked = l.world > 1 and l.owned >= 4 * w and int(cfg["jacobiIter"]) > w and not float(cfg.get("pTol", 0.0)) > 0.0
         deep = self.schedule in ("deep_first", "deep_beside") and blocked
-        lagged = self.schedule == "lagged" and blocked and l.halo >= 2 * w and l.owned >= 2 * w
         # deep_first: the deep parts of the first sweep block read no ghost plane of div: its exchange is in flight behind them
-        # lagged: the band parts of a block run on ghost planes w .. 2w from the face: div on 2w - 1 ghost planes
-        yield ("start" if deep else "xchg"), [div], (2 * w - 1 if lagged else max(w - 1, 1))
+        yield ("start" if deep else "xchg"), [div], max(w - 1, 1)
 
         ops.set_slab(l.z_offset, l.D_global)
         if float(cfg.get("pTol", 0.0)) > 0.0:
             cur = yield from self._jacobi_ptol(st, div)
-        elif lagged:
-            cur = yield from self._jacobi_lagged(st, div)
         elif deep and self.schedule == "deep_beside":
             cur = yield from self._jacobi_deep_beside(st, div)
         elif deep:
@@ -717,103 +710,6 @@ class SlabSimulator:
             cur, nxt = nxt, cur
         return cur
 
-    def _jacobi_lagged(self, st, div):
-        """Jacobi schedule "lagged": 2w ghost planes per face, and the planes a rank sends after a block of w sweeps are the ones
-        w .. 2w planes INSIDE its face -- not the w planes next to it.  Those depend on nothing a neighbour sent for this block (a
-        plane d planes from the face after w sweeps has read no further than plane d - w), so the message of block n leaves as soon
-        as the block's whole-range passes are through, and the chain  exchange -> edge passes -> exchange  of the other blocked
-        schedules -- which puts a transfer AND an edge chain on every block's critical path -- does not exist:
-
-            D part of pass k   [lo - w + done_k, top + w - done_k)       whole shrinking ranges, as "last_pass": reads the w ghost
-                                                                         planes next to the face, which the BAND parts of the
-                                                                         previous block produced -- no message
-            band part of pass k  [lo - 2w + done_k, lo - w + done_k)     (mirror image at the upper face) reads the message of the
-                                                                         PREVIOUS block in ghost planes [lo - 2w, lo - w) and, just
-                                                                         above its band, what D_(k-1) wrote; ends in the ghost planes
-                                                                         [lo - w, lo) the next block's D parts start from
-            message of block n   owned [lo + w, lo + 2w) after the block -> the lower neighbour's ghost planes [top + w, top + 2w)
-
-        The message of block n is first read by the band parts of block n + 1, which have to be through when block n + 2 starts: a block
-        takes max(D chain, (transfer + band chain + D chain) / 2) instead of max(deep chain, transfer + edge chain) -- the transfer is
-        hidden as long as it fits ONE block of sweeps (a 6 MiB message at 55 GB/s: 139 us against ~150), where "deep_beside" starts to
-        stall beyond ~(block - edge chain) = 70 us.  The price is arithmetic: w ghost planes per face more in every pass (at w = 4 and 64
-        owned planes 1.22 x the sweeps of a ghost-free slab; deep_first 1.09 x).  The planes sent are snapshots (the next block's second
-        pass overwrites them); they land in place (nothing else writes ghost planes [lo - 2w, lo - w) of the array a block ends in
-        after that block's first band part).  The first block starts from p = 0 everywhere, ghost planes included: no message."""
-        l, cfg, ops, w = self.l, self.cfg, self.ops, self.w
-        if self._pbuf is None or self._pbuf.shape != st["p"].shape or self._pbuf.device != st["p"].device:
-            self._pbuf = torch.zeros_like(st["p"])
-        cur, nxt = st["p"], self._pbuf
-        fresh = getattr(ops, "zero_start", False)
-        if not fresh:
-            cur.zero_()
-        lo, top = l.lo, l.lo + l.owned
-        has_lo, has_hi = l.rank > 0, l.rank < l.world - 1
-        flags = st["flags"]
-        passes = [1] * (w % 2) + [2] * (w // 2)
-        remaining = int(cfg["jacobiIter"])
-        quad = w % 2 == 0 and remaining % 2 == 0 and hasattr(ops, "quad_ok") and ops.quad_ok(flags)
-        Q = dict(lay=3) if quad else {}
-        zero_in = fresh
-        side = self._side_stream(cur)
-        main = torch.cuda.current_stream(cur.device) if side is not None else None
-        ev_d = [torch.cuda.Event() for _ in passes] if side is not None else None
-        import contextlib
-        on_band = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
-        first_launch, pending = True, False
-        while remaining > w:                 # a block that is followed by another one
-            remaining -= w
-            if side is not None:
-                side.wait_stream(main)       # fork: behind the previous block's join (first block: behind the staging pass)
-            if pending:
-                yield ("wait", side)         # the previous block's message: ghost planes [lo - 2w, lo - w) of `cur` -- the BAND stream waits
-                ops.set_slab(l.z_offset, l.D_global)
-            src, dst, done = cur, nxt, 0
-            for pi, n in enumerate(passes):
-                done += n
-                pin = None if (zero_in and pi == 0) else src
-                ops.jacobi_pass(flags, div, pin, dst, n, lo - w + done if has_lo else 0, top + w - done if has_hi else l.D_local, **Q)
-                if side is not None:
-                    ev_d[pi].record(main)
-                with on_band():
-                    if side is not None and (pi > 0 or first_launch):
-                        # B_pi behind D_(pi-1) (reads its planes just above the band, overwrites what it was still reading below);
-                        # the very first launch of a step may build the solver's obstacle mask: B_0 behind it
-                        side.wait_event(ev_d[pi - 1 if pi > 0 else 0])
-                    if has_lo and has_hi and getattr(ops, "two_ranges", False):       # both faces in one launch
-                        ops.jacobi_pass(flags, div, pin, dst, n, lo - 2 * w + done, lo - w + done, top + w - done, **Q)
-                    else:
-                        if has_lo:
-                            ops.jacobi_pass(flags, div, pin, dst, n, lo - 2 * w + done, lo - w + done, **Q)
-                        if has_hi:
-                            ops.jacobi_pass(flags, div, pin, dst, n, top + w - done, top + 2 * w - done, **Q)
-                first_launch = False
-                src, dst = dst, src
-            if src is not cur:
-                cur, nxt = nxt, cur
-            if side is not None:
-                side.wait_event(ev_d[-1])    # the planes sent are the last D part's
-            yield "start", [cur], w, None, side, w      # snapshots of the planes w .. 2w inside each face, behind the band chain
-            ops.set_slab(l.z_offset, l.D_global)
-            pending = True
-            if side is not None:
-                main.wait_stream(side)       # join: the next block's D parts start from the ghost planes the last band part wrote
-            zero_in = False
-
-        # the last block (<= w sweeps, no exchange after it): whole shrinking ranges
-        if pending:
-            yield ("wait",)
-            ops.set_slab(l.z_offset, l.D_global)
-        done = 0
-        tail = [2] * (remaining // 2) + [1] * (remaining % 2)
-        for ti, n in enumerate(tail):
-            done += n
-            g = max(w - done, 0)
-            kw = (Q if ti < len(tail) - 1 else dict(lay=1)) if quad else {}
-            ops.jacobi_pass(flags, div, cur, nxt, n, lo - g if has_lo else 0, top + g if has_hi else l.D_local, **kw)
-            cur, nxt = nxt, cur
-        return cur
-
     def _jacobi_last_pass(self, st, div):
         """Jacobi schedule "last_pass": blocks of w sweeps between ghost exchanges (temporal blocking in z); the last
         pass of a block first produces the w planes each neighbour needs, posts their exchange, and computes the interior
@@ -906,7 +802,7 @@ class SlabSimulator:
                         req[2][:] = out
                 elif req[0] == "start":
                     with on(req[4] if len(req) > 4 else None):
-                        handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None, req[5] if len(req) > 5 else 0)
+                        handle = self.comm.start(req[1], req[2], req[3] if len(req) > 3 else None)
                 else:
                     with on(req[1] if len(req) > 1 else None):
                         self.comm.finish(handle)
@@ -980,43 +876,21 @@ def lockstep_step(sims, states, defer=False):
     gens = [s.phases(st) for s, st in zip(sims, states)]
     posted = None
 
-    def snapshot(reqs):
-        """the planes a depth > 0 request sends, taken when it is POSTED (they are snapshots: the sender overwrites them next)"""
-        width, depth = reqs[0][2], (reqs[0][5] if len(reqs[0]) > 5 else 0)
-        if depth == 0:
-            return None
-        if any(len(q) > 4 and q[4] is not None for q in reqs):
-            torch.cuda.synchronize()
-        snaps = []
-        for q, sim in zip(reqs, sims):
-            l = sim.l
-            top = l.lo + l.owned
-            snaps.append([(f[:, :, l.lo + depth:l.lo + depth + width].clone(), f[:, :, top - depth - width:top - depth].clone()) for f in q[1]])
-        return snaps
-
-    def serve(reqs, snaps=None):
-        width, depth = reqs[0][2], (reqs[0][5] if len(reqs[0]) > 5 else 0)
+    def serve(reqs):
+        width = reqs[0][2]
         multi = any(len(q) > 4 and q[4] is not None for q in reqs)     # posted from side streams: order the copies by full syncs
         if multi:
             torch.cuda.synchronize()
-        if depth > 0 and snaps is None:
-            snaps = snapshot(reqs)
         for r in range(len(sims) - 1):           # pair (r, r+1)
             lo, hi = sims[r].l, sims[r + 1].l
-            top = lo.lo + lo.owned
-            if depth > 0:                        # the "lagged" sweep blocks: planes depth .. depth + width inside / outside the face
-                for i, (f_lo, f_hi) in enumerate(zip(reqs[r][1], reqs[r + 1][1])):
-                    f_lo[:, :, top + depth:top + depth + width].copy_(snaps[r + 1][i][0])
-                    f_hi[:, :, hi.lo - depth - width:hi.lo - depth].copy_(snaps[r][i][1])
-                continue
             srcs = [q[3] if len(q) > 3 and q[3] is not None else q[1] for q in (reqs[r], reqs[r + 1])]     # arrays the edge planes are sent from
             for f_lo, f_hi, s_lo, s_hi in zip(reqs[r][1], reqs[r + 1][1], *srcs):
+                top = lo.lo + lo.owned
                 f_lo[:, :, top:top + width].copy_(s_hi[:, :, hi.lo:hi.lo + width])
                 f_hi[:, :, hi.lo - width:hi.lo].copy_(s_lo[:, :, top - width:top])
         if multi:
             torch.cuda.synchronize()
 
-    posted_snaps = None
     while True:
         reqs = []
         for g in gens:
@@ -1041,12 +915,12 @@ def lockstep_step(sims, states, defer=False):
             continue
         if reqs[0][0] == "wait":
             if posted is not None:
-                serve(posted, posted_snaps)
-                posted = posted_snaps = None
+                serve(posted)
+                posted = None
             continue
         if reqs[0][0] == "start" and defer:
             assert posted is None, "two exchanges in flight"
-            posted, posted_snaps = reqs, snapshot(reqs)
+            posted = reqs
             continue
         serve(reqs)
     assert posted is None, "an exchange was posted and never waited for"

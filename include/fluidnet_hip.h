@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 17
+#define FNX_ABI_VERSION 16
 
 enum {
   FNX_OK = 0,
@@ -350,7 +350,7 @@ int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_
 void fnx_slab_comm_free(FnxSlabComm* comm);
 
 #define FNX_SLAB_MAX_HALO 64
-/* How a block of sweeps_per_exchange Jacobi sweeps is ordered around its ghost exchange (every schedule gives the same bits):
+/* How a block of sweeps_per_exchange Jacobi sweeps is ordered around its ghost exchange (all three give the same bits):
  *   DEEP_FIRST  every pass is cut a few planes inside each internal face; the deep parts of all passes run first -- they read
  *               no ghost plane, so the previous block's exchange (first block: the exchange of div) is still in flight --,
  *               then the edge parts (short launches), whose last one produces the planes the neighbours need next
@@ -361,16 +361,8 @@ void fnx_slab_comm_free(FnxSlabComm* comm);
  *               stream) is called with the edge stream, behind the block's edge chain and ahead of the next block's -- so the chain
  *               exchange -> edge chain -> exchange crosses no stream; a block takes max(deep chain, exchange + edge chain) instead
  *               of their sum.  Pays with links of >= 150 GB/s per direction; a tie with DEEP_FIRST at 75 GB/s
- *   LAGGED      2w ghost planes per face (sweeps_per_exchange is clipped to halo / 2).  Every pass is the whole shrinking range of
- *               LAST_PASS, started from the w ghost planes next to the face -- which the rank keeps current itself: the BAND part of
- *               pass k, ghost planes w - done_k .. 2w - done_k from the face, runs beside it on a second stream and starts from the
- *               message of the PREVIOUS block.  That message is the owned planes w .. 2w INSIDE the neighbour's face after its block:
- *               they depend on nothing a neighbour sent for that block, so they leave when the block's last whole pass is through
- *               (as a packed snapshot) and are first read one block later -- the chain exchange -> edge chain -> exchange that bounds
- *               the other blocked schedules with a real link does not exist; a block takes max(D chain, (transfer + band chain + D
- *               chain) / 2).  Costs w ghost planes per face more arithmetic in every pass
  * Slabs thinner than 4 sweep blocks, solves of at most one block and pTol > 0 always run LAST_PASS. */
-enum { FNX_SLAB_DEEP_FIRST = 0, FNX_SLAB_EDGE_FIRST = 1, FNX_SLAB_LAST_PASS = 2, FNX_SLAB_DEEP_BESIDE = 3, FNX_SLAB_LAGGED = 4 };
+enum { FNX_SLAB_DEEP_FIRST = 0, FNX_SLAB_EDGE_FIRST = 1, FNX_SLAB_LAST_PASS = 2, FNX_SLAB_DEEP_BESIDE = 3 };
 typedef struct FnxSlabConfig {
   int B, H, W, D_global;    /* the whole domain */
   int rank, nranks;         /* D_global % nranks == 0 */
