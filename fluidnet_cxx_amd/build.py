@@ -27,6 +27,7 @@ HIP_UNITS = {
     # (resource-usage remarks: build_lib checks that conv3_wbf_kernel has no scratch -- its asynchronous LDS reads rely on it)
     "fnx_cnn.hip": ["-Rpass-analysis=kernel-resource-usage"],
     "fnx_slab.hip": [],
+    "fnx_peer.hip": [],
 }
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 adds into v_pk_add_f32 + v_pk_mov shuffles, measured
 # 1.6x slower per op than plain VALU on gfx950 (tools/ubench/dpp_bench.hip).

@@ -429,9 +429,20 @@ struct PyLoopbackGroup {
   explicit PyLoopbackGroup(int n) : nranks(n) { check_status(fnx_slab_loopback_group(&g, n)); }
   ~PyLoopbackGroup() { fnx_slab_loopback_group_free(g); }
 };
+struct PyPeer {                                // a rank's peer-store region (fnx_slab_peer_create)
+  void* p = nullptr;
+  std::string handle;
+  PyPeer(int rank, int nranks, int64_t mailbox_bytes) {
+    char h[FNX_PEER_HANDLE_BYTES];
+    check_status(fnx_slab_peer_create(&p, rank, nranks, (size_t)mailbox_bytes, h));
+    handle.assign(h, FNX_PEER_HANDLE_BYTES);
+  }
+  ~PyPeer() { fnx_slab_peer_free(p); }
+};
 struct PySlabComm {
   FnxSlabComm c{};
   std::shared_ptr<PyLoopbackGroup> keep;      // a loopback comm keeps its group alive
+  std::shared_ptr<PyPeer> keep_peer;          // a peer-store comm its region
   ~PySlabComm() { fnx_slab_comm_free(&c); }
 };
 py::bytes slab_rccl_unique_id() {
@@ -749,6 +760,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("slab_rccl_unique_id", &slab_rccl_unique_id);
   m.def("slab_comm_rccl", &slab_comm_rccl, py::arg("rank"), py::arg("nranks"), py::arg("unique_id"));
   m.def("slab_comm_loopback", &slab_comm_loopback, py::arg("group"), py::arg("rank"));
+  py::class_<PyPeer, std::shared_ptr<PyPeer>>(m, "SlabPeer", "a rank's peer-store region: flags + mailbox its z-neighbours map (fnx_slab_peer_create)")
+      .def(py::init<int, int, int64_t>(), py::arg("rank"), py::arg("nranks"), py::arg("mailbox_bytes"))
+      .def_property_readonly("handle", [](PyPeer& p) { return py::bytes(p.handle); }, "the bytes both neighbours need (FNX_PEER_HANDLE_BYTES)")
+      .def("set_timeout", [](PyPeer& p, double seconds) { check_status(fnx_slab_peer_set_timeout(p.p, seconds)); }, py::arg("seconds"));
+  m.def("slab_comm_peer", [](std::shared_ptr<PyPeer> peer, py::object handle_lo, py::object handle_hi) {
+    std::string lo = handle_lo.is_none() ? std::string() : handle_lo.cast<std::string>();
+    std::string hi = handle_hi.is_none() ? std::string() : handle_hi.cast<std::string>();
+    TORCH_CHECK((lo.empty() || lo.size() == FNX_PEER_HANDLE_BYTES) && (hi.empty() || hi.size() == FNX_PEER_HANDLE_BYTES), "a peer handle has ",
+                FNX_PEER_HANDLE_BYTES, " bytes");
+    auto c = std::make_shared<PySlabComm>();
+    check_status(fnx_slab_comm_peer(&c->c, peer->p, lo.empty() ? nullptr : lo.data(), hi.empty() ? nullptr : hi.data()));
+    c->keep_peer = peer;
+    return c;
+  }, py::arg("peer"), py::arg("handle_lo"), py::arg("handle_hi"), "peer-store communicator: device stores into the neighbours' mapped mailboxes + flags");
   m.def("slab_comm_link_model", [](double latency_us, double gbps) {
     auto c = std::make_shared<PySlabComm>();
     check_status(fnx_slab_comm_link_model(&c->c, latency_us, gbps));

@@ -1,0 +1,370 @@
+// Peer-store communicator of the z-slab driver (include/fluidnet_hip.h, fnx_slab_peer_create / fnx_slab_comm_peer): ghost planes
+// travel as DEVICE STORES into a mailbox the neighbour has mapped (hipIpc handles between processes, the pointer itself inside one
+// process), ordered by flags that live in the same mapping.  No RCCL kernel, no proxy thread, no host round trip on the data path:
+// one short launch per exchange on the stream the driver names, whose first workgroups push this rank's planes over xGMI and whose
+// last workgroups wait (device side) for the neighbours' planes and put them in place.
+//
+//   region of a rank (one uncached device allocation, mapped by both neighbours):
+//     header   flags + the small all-reduce slots                      written remotely, polled locally
+//     mailbox  [side: 0 filled by the lower neighbour, 1 by the upper one][slot: 2 chunks in flight][slot_bytes]
+//
+//   chunk n towards side s (n = 1, 2, ... per direction; both ends count alike, the step is deterministic):
+//     push  waits for credit[s] >= n - 2 in ITS header (the neighbour has emptied the slot), stores the planes into the neighbour's
+//           mailbox[1 - s][n & 1], fences, and sets data_seq[1 - s] = n in the neighbour's header
+//     pull  waits for data_seq[s] >= n in ITS header, copies mailbox[s][n & 1] to where the driver wants the planes, fences, and sets
+//           credit[1 - s] = n in the neighbour's header
+//
+// A wait that lasts longer than the timeout (a dead peer) or sees the abort word gives up, raises the rank's error word (pinned host
+// memory: the next call of the communicator fails with FNX_ECOMM without a synchronisation) and leaves the planes alone -- a spin
+// must never outlive its peer on a GPU other processes share.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/fluidnet_hip.h"
+#include "fnx_kernels.h"
+
+namespace {
+
+#define PEER_HIP(expr)                                                                                     \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess) return fnx::set_error(FNX_EHIP, "HIP error: %s (%s)", hipGetErrorString(e_), #expr); \
+  } while (0)
+
+constexpr int kRedMax = 1024;            // floats per control-path all-reduce
+constexpr int kMaxPieces = 16;           // plane blocks per launch and direction
+constexpr int kBlocksPerRole = 16;       // workgroups per (push | pull) x (lower | upper)
+constexpr size_t kHeaderBytes = 16384;
+
+struct PeerHeader {                      // all words written with system-scope atomics
+  unsigned data_seq[2];                  // [side the data came from]: chunks delivered into mailbox[side]
+  unsigned credit[2];                    // [side I push to]: chunks that neighbour has taken out of the mailbox I fill
+  unsigned abort_word;                   // != 0: every wait gives up
+  unsigned done_count[4];                // workgroups of a role that have finished (this rank's own kernels only)
+  unsigned pad[7];
+  unsigned red_up_seq, red_dn_seq;       // control-path all-reduce: partial result from rank - 1, total from rank + 1
+  float red_up[kRedMax], red_dn[kRedMax];
+};
+static_assert(sizeof(PeerHeader) <= kHeaderBytes, "header");
+
+struct PeerBlob {                        // what a rank publishes (FNX_PEER_HANDLE_BYTES)
+  unsigned magic;
+  int rank, nranks, pid;
+  unsigned long long slot_bytes;
+  unsigned long long raw;                // the region's address in the owner's process
+  hipIpcMemHandle_t ipc;
+};
+static_assert(sizeof(PeerBlob) <= FNX_PEER_HANDLE_BYTES, "handle blob");
+constexpr unsigned kMagic = 0x464e5850u;
+
+struct Peer {
+  int rank = 0, nranks = 1, device = 0;
+  size_t slot_bytes = 0, region_bytes = 0;
+  char* region = nullptr;                // my region
+  char* nb[2] = {nullptr, nullptr};      // the neighbours' regions as mapped here (0: lower, 1: upper)
+  bool nb_ipc[2] = {false, false};       // opened with hipIpcOpenMemHandle (to be closed)
+  unsigned push_seq[2] = {0, 0}, pull_seq[2] = {0, 0};
+  unsigned red_seq = 0;
+  int* h_err = nullptr;                  // pinned host word the kernels raise
+  double timeout_s = 30.0;
+  PeerHeader* hdr() const { return (PeerHeader*)region; }
+  char* mailbox(char* base, int side, int slot) const { return base + kHeaderBytes + ((size_t)side * 2 + slot) * slot_bytes; }
+};
+
+struct Piece { const char* src; char* dst; unsigned long long bytes, off; };       // off: offset in the mailbox slot
+struct XferArgs {
+  Piece push[2][kMaxPieces]; int npush[2];       // [side pushed to]
+  Piece pull[2][kMaxPieces]; int npull[2];       // [side pulled from]: src is filled in by the kernel (the local mailbox)
+  char* remote_slot[2];                          // the neighbour's mailbox slot this launch fills
+  const char* local_slot[2];                     // my mailbox slot this launch empties
+  unsigned* remote_data_seq[2];                  // the neighbour's data_seq[1 - s]
+  unsigned* remote_credit[2];                    // the neighbour's credit[1 - s]
+  unsigned push_n[2], pull_n[2];                 // chunk numbers (0: nothing in that direction)
+  PeerHeader* me;
+  int* h_err;
+  unsigned long long timeout_ticks;              // wall_clock64 ticks (100 MHz)
+};
+
+__device__ __forceinline__ void copy_bytes(const char* __restrict__ src, char* __restrict__ dst, unsigned long long bytes, int part, int parts) {
+  const unsigned tid = threadIdx.x, nt = blockDim.x;
+  if ((((unsigned long long)src | (unsigned long long)dst | bytes) & 15ull) == 0) {
+    const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
+    const unsigned long long n = bytes >> 4;
+    for (unsigned long long i = (unsigned long long)part * nt + tid; i < n; i += (unsigned long long)parts * nt) d[i] = s[i];
+  } else if ((((unsigned long long)src | (unsigned long long)dst | bytes) & 3ull) == 0) {
+    const unsigned* s = (const unsigned*)src; unsigned* d = (unsigned*)dst;
+    const unsigned long long n = bytes >> 2;
+    for (unsigned long long i = (unsigned long long)part * nt + tid; i < n; i += (unsigned long long)parts * nt) d[i] = s[i];
+  } else {
+    for (unsigned long long i = (unsigned long long)part * nt + tid; i < bytes; i += (unsigned long long)parts * nt) dst[i] = src[i];
+  }
+}
+
+// waits until *word >= want (system scope).  false: timed out or aborted (the rank's error word is raised)
+__device__ bool wait_word(const unsigned* word, unsigned want, const XferArgs& a) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    int good = 1;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      if (__hip_atomic_load(&a.me->abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > a.timeout_ticks) {
+        good = 0;
+        __hip_atomic_store(a.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+
+// the role's workgroups have all passed here -> the last one publishes `value` in `flag` (a word of the neighbour's header)
+// (a role is active in every launch of its direction, so after chunk n its counter stands at n * kBlocksPerRole)
+__device__ void finish_role(int role, unsigned* flag, unsigned value, const XferArgs& a) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&a.me->done_count[role], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == value * (unsigned)kBlocksPerRole) {
+      __threadfence_system();
+      __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// gridDim.x = 4 * kBlocksPerRole: roles 0/1 push to the lower/upper neighbour, 2/3 pull from them.  The push roles come first in
+// the dispatch order, so a launch's pulls never keep its own pushes from starting.
+__global__ __launch_bounds__(256) void peer_xfer_kernel(XferArgs a) {
+  const int role = blockIdx.x / kBlocksPerRole, part = blockIdx.x % kBlocksPerRole;
+  const int s = role & 1;
+  if (role < 2) {
+    if (a.push_n[s] == 0) return;
+    // the slot is free once the neighbour has taken chunk n - 2 out of it
+    const bool ok = a.push_n[s] <= 2 || wait_word(&a.me->credit[s], a.push_n[s] - 2, a);
+    if (ok)
+      for (int i = 0; i < a.npush[s]; ++i) copy_bytes(a.push[s][i].src, a.remote_slot[s] + a.push[s][i].off, a.push[s][i].bytes, part, kBlocksPerRole);
+    if (ok) finish_role(role, a.remote_data_seq[s], a.push_n[s], a);
+  } else {
+    if (a.pull_n[s] == 0) return;
+    const bool ok = wait_word(&a.me->data_seq[s], a.pull_n[s], a);
+    if (ok)
+      for (int i = 0; i < a.npull[s]; ++i) copy_bytes(a.local_slot[s] + a.pull[s][i].off, a.pull[s][i].dst, a.pull[s][i].bytes, part, kBlocksPerRole);
+    if (ok) finish_role(role, a.remote_credit[s], a.pull_n[s], a);
+  }
+}
+
+struct PeerComm { Peer* p; };
+
+int peer_failed(Peer* p) {
+  if (p->h_err && *(volatile int*)p->h_err)
+    return fnx::set_error(FNX_ECOMM, "peer-store exchange: a wait for a neighbour timed out (%.0f s) or the group was aborted", p->timeout_s);
+  return FNX_OK;
+}
+
+int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
+  PeerComm* c = (PeerComm*)vctx;
+  Peer* p = c->p;
+  if (int rc = peer_failed(p)) return rc;
+  const bool has[2] = {p->rank > 0, p->rank < p->nranks - 1};
+  // cut the segments into pieces that fit a mailbox slot, then fill launches with up to kMaxPieces pieces and slot_bytes bytes per
+  // direction.  A segment's lower and upper halves have the same size, and both neighbours cut their segments the same way (same
+  // sizes, same order), so piece i of my push towards s is piece i of that neighbour's pull from 1 - s.
+  struct Cut { int seg; size_t at, bytes; };
+  std::vector<Cut> cuts;
+  for (int i = 0; i < nsegs; ++i)
+    for (size_t at = 0; at < segs[i].bytes;) {
+      const size_t n = segs[i].bytes - at < p->slot_bytes ? segs[i].bytes - at : p->slot_bytes;
+      cuts.push_back(Cut{i, at, n});
+      at += n;
+    }
+  size_t k = 0;
+  while (k < cuts.size()) {
+    XferArgs a{};
+    size_t used = 0;
+    int np = 0;
+    Piece pl[kMaxPieces]; int segi[kMaxPieces];
+    while (k < cuts.size() && np < kMaxPieces && used + cuts[k].bytes <= p->slot_bytes) {
+      pl[np] = Piece{nullptr, nullptr, (unsigned long long)cuts[k].bytes, (unsigned long long)used};
+      segi[np] = (int)k;
+      used += (cuts[k].bytes + 255) & ~(size_t)255;
+      ++np; ++k;
+    }
+    for (int s = 0; s < 2; ++s) {
+      if (!has[s]) continue;
+      int nsend = 0, nrecv = 0;
+      for (int i = 0; i < np; ++i) {
+        const Cut& cu = cuts[segi[i]];
+        const FnxSlabSeg& g = segs[cu.seg];
+        const char* snd = (const char*)(s == 0 ? g.send_lo : g.send_hi);
+        char* rcv = (char*)(s == 0 ? g.recv_lo : g.recv_hi);
+        if (snd) a.push[s][nsend++] = Piece{snd + cu.at, nullptr, pl[i].bytes, pl[i].off};
+        if (rcv) a.pull[s][nrecv++] = Piece{nullptr, rcv + cu.at, pl[i].bytes, pl[i].off};
+      }
+      a.npush[s] = nsend; a.npull[s] = nrecv;
+      // (a direction with nothing to send still hands over the chunk: both ends count chunks, not bytes)
+      a.push_n[s] = ++p->push_seq[s];
+      a.pull_n[s] = ++p->pull_seq[s];
+      PeerHeader* nh = (PeerHeader*)p->nb[s];
+      a.remote_slot[s] = p->mailbox(p->nb[s], 1 - s, a.push_n[s] & 1);
+      a.local_slot[s] = p->mailbox(p->region, s, a.pull_n[s] & 1);
+      a.remote_data_seq[s] = &nh->data_seq[1 - s];
+      a.remote_credit[s] = &nh->credit[1 - s];
+    }
+    a.me = p->hdr();
+    a.h_err = p->h_err;
+    a.timeout_ticks = (unsigned long long)(p->timeout_s * 1e8);
+    peer_xfer_kernel<<<4 * kBlocksPerRole, 256, 0, (hipStream_t)stream>>>(a);
+    PEER_HIP(hipGetLastError());
+  }
+  return FNX_OK;
+}
+
+// ---- control path: all-reduce of n floats along the chain of ranks, through the headers, driven by the host (rank 0 -> ... -> last
+// accumulates in rank order, the total travels back down): the same bits on every rank
+int host_write(Peer* p, void* dst, const void* src, size_t bytes) {
+  PEER_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return FNX_OK;
+}
+int host_wait_seq(Peer* p, const unsigned* word, unsigned want) {
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(p->timeout_s);
+  for (;;) {
+    unsigned v = 0, ab = 0;
+    PEER_HIP(hipMemcpy(&v, word, 4, hipMemcpyDeviceToHost));
+    if (v >= want) return FNX_OK;
+    PEER_HIP(hipMemcpy(&ab, &p->hdr()->abort_word, 4, hipMemcpyDeviceToHost));
+    if (ab) return fnx::set_error(FNX_ECOMM, "peer-store all-reduce: the group was aborted");
+    if (std::chrono::steady_clock::now() > deadline) return fnx::set_error(FNX_ECOMM, "peer-store all-reduce: timed out after %.0f s waiting for a neighbour", p->timeout_s);
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+int peer_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
+  Peer* p = ((PeerComm*)vctx)->p;
+  if (int rc = peer_failed(p)) return rc;
+  if (n < 1 || n > kRedMax) return fnx::set_error(FNX_EINVAL, "peer-store all-reduce: n must be in [1, %d]", kRedMax);
+  std::vector<float> acc((size_t)n), in((size_t)n);
+  PEER_HIP(hipMemcpyAsync(acc.data(), x, (size_t)n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  PEER_HIP(hipStreamSynchronize((hipStream_t)stream));
+  const unsigned seq = ++p->red_seq;
+  PeerHeader* me = p->hdr();
+  if (p->rank > 0) {
+    if (int rc = host_wait_seq(p, &me->red_up_seq, seq)) return rc;
+    PEER_HIP(hipMemcpy(in.data(), me->red_up, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) acc[i] = sum ? in[i] + acc[i] : (acc[i] > in[i] ? acc[i] : in[i]);
+  }
+  if (p->rank < p->nranks - 1) {
+    PeerHeader* up = (PeerHeader*)p->nb[1];
+    if (int rc = host_write(p, up->red_up, acc.data(), (size_t)n * 4)) return rc;
+    if (int rc = host_write(p, &up->red_up_seq, &seq, 4)) return rc;
+    if (int rc = host_wait_seq(p, &me->red_dn_seq, seq)) return rc;
+    PEER_HIP(hipMemcpy(acc.data(), me->red_dn, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  if (p->rank > 0) {
+    PeerHeader* dn = (PeerHeader*)p->nb[0];
+    if (int rc = host_write(p, dn->red_dn, acc.data(), (size_t)n * 4)) return rc;
+    if (int rc = host_write(p, &dn->red_dn_seq, &seq, 4)) return rc;
+  }
+  PEER_HIP(hipMemcpyAsync(x, acc.data(), (size_t)n * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+  PEER_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return FNX_OK;
+}
+int peer_allreduce_max(void* c, float* x, int n, void* s) { return peer_allreduce(c, x, n, s, false); }
+int peer_allreduce_sum(void* c, float* x, int n, void* s) { return peer_allreduce(c, x, n, s, true); }
+void peer_comm_destroy(void* vctx) { delete (PeerComm*)vctx; }
+void peer_abort(void* vctx) {
+  Peer* p = ((PeerComm*)vctx)->p;
+  const unsigned one = 1;
+  (void)hipMemcpy(&p->hdr()->abort_word, &one, 4, hipMemcpyHostToDevice);
+  for (int s = 0; s < 2; ++s)
+    if (p->nb[s]) (void)hipMemcpy(&((PeerHeader*)p->nb[s])->abort_word, &one, 4, hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnx_slab_peer_create(void** peer, int rank, int nranks, size_t mailbox_bytes, void* handle_out) {
+  if (!peer || !handle_out || nranks < 1 || rank < 0 || rank >= nranks || mailbox_bytes < 4096)
+    return fnx::set_error(FNX_EINVAL, "slab_peer_create: bad arguments (mailbox_bytes >= 4096)");
+  Peer* p = new (std::nothrow) Peer();
+  if (!p) return fnx::set_error(FNX_EINVAL, "out of host memory");
+  p->rank = rank; p->nranks = nranks;
+  p->slot_bytes = (mailbox_bytes + 255) & ~(size_t)255;
+  p->region_bytes = kHeaderBytes + 4 * p->slot_bytes;
+  hipError_t e = hipGetDevice(&p->device);
+  // uncached: the neighbour's stores must be seen by a kernel that is already running here, and ours by theirs
+  if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&p->region, p->region_bytes, hipDeviceMallocUncached);
+  if (e == hipSuccess) e = hipMemset(p->region, 0, kHeaderBytes);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_err, sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  PeerBlob b{};
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&b.ipc, p->region);
+  if (e != hipSuccess) {
+    const int rc = fnx::set_error(FNX_EHIP, "slab_peer_create: %s", hipGetErrorString(e));
+    fnx_slab_peer_free(p);
+    return rc;
+  }
+  *p->h_err = 0;
+  b.magic = kMagic; b.rank = rank; b.nranks = nranks; b.pid = (int)getpid(); b.slot_bytes = p->slot_bytes;
+  b.raw = (unsigned long long)(uintptr_t)p->region;
+  memset(handle_out, 0, FNX_PEER_HANDLE_BYTES);
+  memcpy(handle_out, &b, sizeof(b));
+  *peer = p;
+  return FNX_OK;
+}
+
+int fnx_slab_peer_set_timeout(void* peer, double seconds) {
+  Peer* p = (Peer*)peer;
+  if (!p || !(seconds > 0.0) || seconds > 3600.0) return fnx::set_error(FNX_EINVAL, "slab_peer_set_timeout: seconds in (0, 3600]");
+  p->timeout_s = seconds;
+  return FNX_OK;
+}
+
+int fnx_slab_comm_peer(FnxSlabComm* out, void* peer, const void* handle_lo, const void* handle_hi) {
+  Peer* p = (Peer*)peer;
+  if (!out || !p) return fnx::set_error(FNX_EINVAL, "slab_comm_peer: NULL argument");
+  const void* hs[2] = {handle_lo, handle_hi};
+  for (int s = 0; s < 2; ++s) {
+    const bool need = s == 0 ? p->rank > 0 : p->rank < p->nranks - 1;
+    if (!need) continue;
+    if (!hs[s]) return fnx::set_error(FNX_EINVAL, "slab_comm_peer: rank %d of %d needs the handle of its %s neighbour", p->rank, p->nranks, s ? "upper" : "lower");
+    if (p->nb[s]) continue;                                  // already attached
+    PeerBlob b;
+    memcpy(&b, hs[s], sizeof(b));
+    if (b.magic != kMagic || b.nranks != p->nranks || b.rank != p->rank + (s ? 1 : -1) || b.slot_bytes != p->slot_bytes)
+      return fnx::set_error(FNX_ECOMM, "slab_comm_peer: the %s handle is not that of rank %d of %d with %zu-byte mailbox slots", s ? "upper" : "lower",
+                            p->rank + (s ? 1 : -1), p->nranks, p->slot_bytes);
+    if (b.pid == (int)getpid()) {
+      p->nb[s] = (char*)(uintptr_t)b.raw;                    // the same address space (slabs driven by threads): no mapping needed
+    } else {
+      void* m = nullptr;
+      const hipError_t e = hipIpcOpenMemHandle(&m, b.ipc, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return fnx::set_error(FNX_ECOMM, "slab_comm_peer: hipIpcOpenMemHandle failed (%s)", hipGetErrorString(e));
+      p->nb[s] = (char*)m; p->nb_ipc[s] = true;
+    }
+  }
+  PeerComm* c = new (std::nothrow) PeerComm{p};
+  if (!c) return fnx::set_error(FNX_EINVAL, "out of host memory");
+  out->ctx = c; out->exchange = peer_exchange; out->allreduce_max = peer_allreduce_max; out->allreduce_sum = peer_allreduce_sum;
+  out->destroy = peer_comm_destroy; out->abort = peer_abort;
+  return FNX_OK;
+}
+
+void fnx_slab_peer_free(void* peer) {
+  Peer* p = (Peer*)peer;
+  if (!p) return;
+  for (int s = 0; s < 2; ++s)
+    if (p->nb[s] && p->nb_ipc[s]) (void)hipIpcCloseMemHandle(p->nb[s]);
+  if (p->region) (void)hipFree(p->region);
+  if (p->h_err) (void)hipHostFree(p->h_err);
+  delete p;
+}
+
+}  // extern "C"

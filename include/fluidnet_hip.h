@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 16
+#define FNX_ABI_VERSION 17
 
 enum {
   FNX_OK = 0,
@@ -347,6 +347,25 @@ void fnx_slab_loopback_group_free(void* group);
  * ordering are those of a real run and the time a schedule leaves exposed for an assumed link can be measured; the field
  * values are those of a periodic stack of this slab.  All-reduces return the rank's own value. */
 int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_per_s);
+/* Peer-store communicator (no RCCL on the data path; the reference is single device, plume.py:131-135: no counterpart).  Every rank
+ * owns a REGION of uncached device memory -- flag words and a mailbox of 2 x 2 slots of `mailbox_bytes` -- that its two z-neighbours
+ * map (hipIpcOpenMemHandle between processes; ranks driven by threads of one process use the address as it is).  An exchange is ONE
+ * short launch on the stream it is given: its first workgroups store this rank's planes straight into the neighbours' mailboxes over
+ * xGMI and raise a flag there, its last workgroups wait -- on the device -- for the neighbours' flags and move the planes that arrived
+ * into place; exchanges larger than a slot are cut into chunks (two may be in flight per direction).  No proxy thread, no host
+ * synchronisation, 64 workgroups of the device while it runs.  The all-reduces of the control path (CFL guard, pTol residual, the CNN
+ * projection's sums) travel along the chain of ranks through the same regions, driven by the host, added in RANK ORDER: the same bits on
+ * every rank.  A wait that outlasts the timeout (30 s unless set) or sees an abort gives up and the communicator's next call
+ * returns FNX_ECOMM.
+ *   1. every rank: fnx_slab_peer_create -> its handle (FNX_PEER_HANDLE_BYTES bytes), to be carried to both neighbours by the caller
+ *      (MPI, torch.distributed, a file ... like the RCCL unique id)
+ *   2. every rank: fnx_slab_comm_peer with the handles of rank - 1 and rank + 1 (NULL at the ends of the chain)
+ * The peer object must outlive the communicator (fnx_slab_comm_free, then fnx_slab_peer_free); all ranks use the same mailbox_bytes. */
+#define FNX_PEER_HANDLE_BYTES 128
+int fnx_slab_peer_create(void** peer, int rank, int nranks, size_t mailbox_bytes, void* handle_out);
+int fnx_slab_peer_set_timeout(void* peer, double seconds);
+int fnx_slab_comm_peer(FnxSlabComm* out, void* peer, const void* handle_lo, const void* handle_hi);
+void fnx_slab_peer_free(void* peer);
 void fnx_slab_comm_free(FnxSlabComm* comm);
 
 #define FNX_SLAB_MAX_HALO 64

@@ -1,0 +1,138 @@
+"""The peer-store communicator (fnx_slab_peer_create / fnx_slab_comm_peer): ghost planes as device stores into mailboxes the
+neighbours have mapped through hipIpc handles, ordered by flags -- no RCCL on the data path.  RCCL refuses two ranks on one device;
+IPC mappings do not, so these are runs of the C++ driver (fnx_slab_step) with ONE PROCESS PER RANK on the one GPU of the box:
+the first real multi-process runs of the decomposition.  Every owned plane must equal the single-domain step bit for bit
+(lib/simulate.py:28-171 per owned plane; the reference itself is single device, plume.py:131-135)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _peer_comm(ext, dist, rank, world, mailbox_bytes, timeout_s=20.0):
+    """one region per rank, the handles all-gathered over the (gloo) process group, the neighbours' two mapped"""
+    peer = ext.SlabPeer(rank, world, mailbox_bytes)
+    peer.set_timeout(timeout_s)
+    handles = [None] * world
+    dist.all_gather_object(handles, peer.handle)
+    return ext.slab_comm_peer(peer, handles[rank - 1] if rank > 0 else None, handles[rank + 1] if rank < world - 1 else None)
+
+
+def _worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    import test_slab as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        D, H, W, halo, w, schedule, iters, ptol, mailbox, nsteps = case
+        cfg = dict(T.CFG, jacobiIter=iters, pTol=ptol)
+        gs = T.global_state(D, H, W, seed=7)
+        layout = SlabLayout(D, world, rank, halo)
+        st = T.local_state(gs, layout, dev)
+        comm = _peer_comm(ext, dist, rank, world, mailbox)
+        sim = NativeSlabSimulator(layout, cfg, comm=comm, sweeps_per_exchange=w, static_flags=True, cfl_check_every=2, schedule=schedule)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            for _ in range(nsteps):
+                sim.step(st)
+            torch.cuda.current_stream().synchronize()
+        # a probe of the transport itself: average ms of a 1 MiB exchange with each neighbour
+        scratch = torch.zeros(4 << 20, dtype=torch.uint8, device=dev)
+        ms = ext.slab_comm_probe(comm, 1 << 20, 20, scratch)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), probe_ms=ms, **{k: st[k][:, :, layout.owned_slice].cpu().numpy() for k in ("U", "density", "p")})
+        dist.barrier()
+        del sim, comm
+    finally:
+        dist.destroy_process_group()
+
+
+# D, H, W, halo, w, schedule, iters, pTol, mailbox bytes, steps
+CASES = {
+    "deep_first":   (48, 20, 70, 6, 6, "deep_first", 20, 0.0, 1 << 20, 3),
+    "deep_beside":  (48, 20, 70, 6, 4, "deep_beside", 14, 0.0, 1 << 20, 3),
+    "chunked":      (32, 20, 70, 6, 4, "edge_first", 11, 0.0, 8192, 2),          # mailbox slots smaller than a plane (5 600 B x w): cut into chunks
+    "ptol":         (32, 20, 70, 6, 4, "last_pass", 30, 0.05, 1 << 20, 2),       # the per-sweep residual all-reduce along the chain
+}
+
+
+@pytest.mark.parametrize("world,name", [(2, "deep_first"), (3, "deep_first"), (2, "deep_beside"), (3, "chunked"), (3, "ptol")])
+def test_peer_store_processes_match_single_domain(tmp_path, world, name):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import test_slab as T
+    from fluidnet_cxx_amd import simulate
+    from fluidnet_cxx_amd.slab import SlabLayout
+    case = CASES[name]
+    D, H, W, halo, w, schedule, iters, ptol, mailbox, nsteps = case
+    D = D // 2 * world if world != 2 else D
+    case = (D,) + case[1:]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    cfg = dict(T.CFG, jacobiIter=iters, pTol=ptol)
+    gs = T.global_state(D, H, W, seed=7)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    for _ in range(nsteps):
+        simulate(cfg, bd, None, "jacobi")
+    ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
+    for r in range(world):
+        l = SlabLayout(D, world, r, halo)
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for k in ("U", "density", "p"):
+            a, b = z[k], ref[k][:, :, l.z_begin:l.z_begin + l.owned]
+            bad = a.view(np.int32) != b.view(np.int32)
+            assert not bad.any(), f"{name}, world {world}: {k} differs on {int(bad.sum())} owned cells of rank {r}"
+        assert 0.0 < float(z["probe_ms"]) < 50.0
+
+
+def _dead_peer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from fluidnet_cxx_amd._ext import ext
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        comm = _peer_comm(ext, dist, rank, world, 1 << 16, timeout_s=1.0)
+        msg = "ok"
+        if rank == 0:                                  # rank 1 never calls: the wait must give up, not hang the GPU
+            scratch = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)
+            try:
+                ext.slab_comm_probe(comm, 4096, 1, scratch)       # warm-up exchange + 1: enqueued, time out on the device
+                torch.cuda.synchronize()
+                ext.slab_comm_probe(comm, 4096, 1, scratch)       # the next call reports it
+                msg = "no error"
+            except RuntimeError as e:
+                msg = str(e)
+        open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(msg)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_store_dead_neighbour_times_out(tmp_path):
+    """a neighbour that never arrives: the device-side wait gives up after the timeout (1 s here) and the communicator's next call
+    fails with FNX_ECOMM -- a spin must not outlive its peer on a shared GPU"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_dead_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    msg = open(tmp_path / "rank0.txt").read()
+    assert "timed out" in msg, msg
