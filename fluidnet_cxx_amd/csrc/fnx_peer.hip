@@ -8,11 +8,12 @@
 //     header   flags + the small all-reduce slots                      written remotely, polled locally
 //     mailbox  [side: 0 filled by the lower neighbour, 1 by the upper one][slot: 2 chunks in flight][slot_bytes]
 //
-//   chunk n towards side s (n = 1, 2, ... per direction; both ends count alike, the step is deterministic):
-//     push  waits for credit[s] >= n - 2 in ITS header (the neighbour has emptied the slot), stores the planes into the neighbour's
-//           mailbox[1 - s][n & 1], fences, and sets data_seq[1 - s] = n in the neighbour's header
-//     pull  waits for data_seq[s] >= n in ITS header, copies mailbox[s][n & 1] to where the driver wants the planes, fences, and sets
-//           credit[1 - s] = n in the neighbour's header
+//   chunk n towards side s (n = 1, 2, ... per direction; both ends count alike, the step is deterministic), cut into sub-chunks
+//   of >= 64 KiB that one workgroup moves on its own:
+//     push  waits for credit[s] >= n - 2 in ITS header (the neighbour has emptied the slot); per sub-chunk j: stores the bytes into the
+//           neighbour's mailbox[1 - s][n & 1], fences, and sets ready[1 - s][n & 1][j] = n in the neighbour's header
+//     pull  per sub-chunk j: waits for ready[s][n & 1][j] >= n in ITS header and copies the bytes from mailbox[s][n & 1] to where the
+//           driver wants the planes; when the whole chunk is out, fences and sets credit[1 - s] = n in the neighbour's header
 //
 // A wait that lasts longer than the timeout (a dead peer) or sees the abort word gives up, raises the rank's error word (pinned host
 // memory: the next call of the communicator fails with FNX_ECOMM without a synchronisation) and leaves the planes alone -- a spin
@@ -39,17 +40,23 @@ namespace {
 
 constexpr int kRedMax = 1024;            // floats per control-path all-reduce
 constexpr int kMaxPieces = 16;           // plane blocks per launch and direction
-constexpr int kBlocksPerRole = 16;       // workgroups per (push | pull) x (lower | upper)
-constexpr size_t kHeaderBytes = 16384;
+constexpr int kBlocksPerRole = 32;       // workgroups per (push | pull) x (lower | upper)
+constexpr int kMaxSub = 1024;            // sub-chunks of a mailbox slot: the unit a push workgroup hands to a pull workgroup
+constexpr size_t kSubMin = 65536;
+constexpr size_t kHeaderBytes = 65536;
 
 struct PeerHeader {                      // all words written with system-scope atomics
-  unsigned data_seq[2];                  // [side the data came from]: chunks delivered into mailbox[side]
+  unsigned reserved0[2];
   unsigned credit[2];                    // [side I push to]: chunks that neighbour has taken out of the mailbox I fill
   unsigned abort_word;                   // != 0: every wait gives up
   unsigned done_count[4];                // workgroups of a role that have finished (this rank's own kernels only)
   unsigned pad[7];
   unsigned red_up_seq, red_dn_seq;       // control-path all-reduce: partial result from rank - 1, total from rank + 1
   float red_up[kRedMax], red_dn[kRedMax];
+  // ready[side the data came from][slot][sub-chunk] = number of the chunk whose bytes of that sub-chunk have arrived: a push
+  // workgroup owns whole sub-chunks and raises each one's word on its own, so the pull of a chunk runs behind its push sub-chunk by
+  // sub-chunk (a 6 MiB message is on its way for 80 us at 75 GB/s: moving it into place must not come on top of that)
+  unsigned ready[2][2][kMaxSub];
 };
 static_assert(sizeof(PeerHeader) <= kHeaderBytes, "header");
 
@@ -71,6 +78,7 @@ struct Peer {
   bool nb_ipc[2] = {false, false};       // opened with hipIpcOpenMemHandle (to be closed)
   unsigned push_seq[2] = {0, 0}, pull_seq[2] = {0, 0};
   unsigned red_seq = 0;
+  size_t sub_bytes = kSubMin;            // (a multiple of 256: pieces start on 256-byte boundaries of a slot)
   int* h_err = nullptr;                  // pinned host word the kernels raise
   double timeout_s = 30.0;
   PeerHeader* hdr() const { return (PeerHeader*)region; }
@@ -83,32 +91,50 @@ struct XferArgs {
   Piece pull[2][kMaxPieces]; int npull[2];       // [side pulled from]: src is filled in by the kernel (the local mailbox)
   char* remote_slot[2];                          // the neighbour's mailbox slot this launch fills
   const char* local_slot[2];                     // my mailbox slot this launch empties
-  unsigned* remote_data_seq[2];                  // the neighbour's data_seq[1 - s]
+  unsigned* remote_ready[2];                     // the neighbour's ready[1 - s][slot]
+  const unsigned* local_ready[2];                // my ready[s][slot]
   unsigned* remote_credit[2];                    // the neighbour's credit[1 - s]
+  unsigned long long used[2];                    // bytes of the slot this launch fills / empties per direction
+  unsigned long long sub_bytes;
   unsigned push_n[2], pull_n[2];                 // chunk numbers (0: nothing in that direction)
   PeerHeader* me;
   int* h_err;
   unsigned long long timeout_ticks;              // wall_clock64 ticks (100 MHz)
 };
 
-__device__ __forceinline__ void copy_bytes(const char* __restrict__ src, char* __restrict__ dst, unsigned long long bytes, int part, int parts) {
+// bytes [r0, r1) of a slot's byte stream, the whole workgroup: slot -> pieces (TO_SLOT false) or pieces -> slot (true).  Four
+// independent 16-byte loads per lane are in flight before the first store (uncached HBM and remote stores have microseconds of latency).
+template <bool TO_SLOT>
+__device__ __forceinline__ void copy_range(const Piece* pc, int np, char* slot, unsigned long long r0, unsigned long long r1) {
   const unsigned tid = threadIdx.x, nt = blockDim.x;
-  if ((((unsigned long long)src | (unsigned long long)dst | bytes) & 15ull) == 0) {
-    const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
-    const unsigned long long n = bytes >> 4;
-    for (unsigned long long i = (unsigned long long)part * nt + tid; i < n; i += (unsigned long long)parts * nt) d[i] = s[i];
-  } else if ((((unsigned long long)src | (unsigned long long)dst | bytes) & 3ull) == 0) {
-    const unsigned* s = (const unsigned*)src; unsigned* d = (unsigned*)dst;
-    const unsigned long long n = bytes >> 2;
-    for (unsigned long long i = (unsigned long long)part * nt + tid; i < n; i += (unsigned long long)parts * nt) d[i] = s[i];
-  } else {
-    for (unsigned long long i = (unsigned long long)part * nt + tid; i < bytes; i += (unsigned long long)parts * nt) dst[i] = src[i];
+  for (int i = 0; i < np; ++i) {
+    const unsigned long long a = pc[i].off > r0 ? pc[i].off : r0, e = pc[i].off + pc[i].bytes < r1 ? pc[i].off + pc[i].bytes : r1;
+    if (a >= e) continue;
+    const char* src = TO_SLOT ? pc[i].src + (a - pc[i].off) : slot + a;
+    char* dst = TO_SLOT ? slot + a : pc[i].dst + (a - pc[i].off);
+    const unsigned long long bytes = e - a;
+    if ((((unsigned long long)src | (unsigned long long)dst | bytes) & 15ull) == 0) {
+      const uint4* sp = (const uint4*)src; uint4* dp = (uint4*)dst;
+      const unsigned long long n = bytes >> 4;
+      unsigned long long q = tid;
+      for (; q + 3ull * nt < n; q += 4ull * nt) {
+        const uint4 v0 = sp[q], v1 = sp[q + nt], v2 = sp[q + 2ull * nt], v3 = sp[q + 3ull * nt];
+        dp[q] = v0; dp[q + nt] = v1; dp[q + 2ull * nt] = v2; dp[q + 3ull * nt] = v3;
+      }
+      for (; q < n; q += nt) dp[q] = sp[q];
+    } else if ((((unsigned long long)src | (unsigned long long)dst | bytes) & 3ull) == 0) {
+      const unsigned* sp = (const unsigned*)src; unsigned* dp = (unsigned*)dst;
+      for (unsigned long long q = tid; q < (bytes >> 2); q += nt) dp[q] = sp[q];
+    } else {
+      for (unsigned long long q = tid; q < bytes; q += nt) dst[q] = src[q];
+    }
   }
 }
 
 // waits until *word >= want (system scope).  false: timed out or aborted (the rank's error word is raised)
 __device__ bool wait_word(const unsigned* word, unsigned want, const XferArgs& a) {
   __shared__ int ok;
+  __syncthreads();                                           // (the previous wait's result has been read by everyone)
   if (threadIdx.x == 0) {
     int good = 1;
     const unsigned long long t0 = wall_clock64();
@@ -118,7 +144,7 @@ __device__ bool wait_word(const unsigned* word, unsigned want, const XferArgs& a
         __hip_atomic_store(a.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(8);
     }
     ok = good;
   }
@@ -126,38 +152,44 @@ __device__ bool wait_word(const unsigned* word, unsigned want, const XferArgs& a
   return ok != 0;
 }
 
-// the role's workgroups have all passed here -> the last one publishes `value` in `flag` (a word of the neighbour's header)
-// (a role is active in every launch of its direction, so after chunk n its counter stands at n * kBlocksPerRole)
-__device__ void finish_role(int role, unsigned* flag, unsigned value, const XferArgs& a) {
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(&a.me->done_count[role], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == value * (unsigned)kBlocksPerRole) {
-      __threadfence_system();
-      __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
 // gridDim.x = 4 * kBlocksPerRole: roles 0/1 push to the lower/upper neighbour, 2/3 pull from them.  The push roles come first in
-// the dispatch order, so a launch's pulls never keep its own pushes from starting.
+// the dispatch order, so a launch's pulls never keep its own pushes from starting.  Workgroup `part` of a role owns the sub-chunks
+// part, part + kBlocksPerRole, ... of the slot.
 __global__ __launch_bounds__(256) void peer_xfer_kernel(XferArgs a) {
   const int role = blockIdx.x / kBlocksPerRole, part = blockIdx.x % kBlocksPerRole;
   const int s = role & 1;
-  if (role < 2) {
-    if (a.push_n[s] == 0) return;
+  const bool push = role < 2;
+  const unsigned n = push ? a.push_n[s] : a.pull_n[s];
+  if (n == 0) return;
+  const unsigned nsub = (unsigned)((a.used[s] + a.sub_bytes - 1) / a.sub_bytes);
+  bool ok = true;
+  if (push) {
     // the slot is free once the neighbour has taken chunk n - 2 out of it
-    const bool ok = a.push_n[s] <= 2 || wait_word(&a.me->credit[s], a.push_n[s] - 2, a);
-    if (ok)
-      for (int i = 0; i < a.npush[s]; ++i) copy_bytes(a.push[s][i].src, a.remote_slot[s] + a.push[s][i].off, a.push[s][i].bytes, part, kBlocksPerRole);
-    if (ok) finish_role(role, a.remote_data_seq[s], a.push_n[s], a);
+    if (n > 2) ok = wait_word(&a.me->credit[s], n - 2, a);
+    for (unsigned j = part; ok && j < nsub; j += kBlocksPerRole) {
+      const unsigned long long r0 = (unsigned long long)j * a.sub_bytes, r1 = r0 + a.sub_bytes < a.used[s] ? r0 + a.sub_bytes : a.used[s];
+      copy_range<true>(a.push[s], a.npush[s], a.remote_slot[s], r0, r1);
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&a.remote_ready[s][j], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   } else {
-    if (a.pull_n[s] == 0) return;
-    const bool ok = wait_word(&a.me->data_seq[s], a.pull_n[s], a);
-    if (ok)
-      for (int i = 0; i < a.npull[s]; ++i) copy_bytes(a.local_slot[s] + a.pull[s][i].off, a.pull[s][i].dst, a.pull[s][i].bytes, part, kBlocksPerRole);
-    if (ok) finish_role(role, a.remote_credit[s], a.pull_n[s], a);
+    for (unsigned j = part; ok && j < nsub; j += kBlocksPerRole) {
+      ok = wait_word(&a.local_ready[s][j], n, a);
+      if (!ok) break;
+      const unsigned long long r0 = (unsigned long long)j * a.sub_bytes, r1 = r0 + a.sub_bytes < a.used[s] ? r0 + a.sub_bytes : a.used[s];
+      copy_range<false>(a.pull[s], a.npull[s], const_cast<char*>(a.local_slot[s]), r0, r1);
+    }
+    if (ok) {
+      // the slot is empty when every pull workgroup is through: the last one hands the credit back.  (The role is active in every
+      // launch of its direction, so after chunk n its counter stands at n * kBlocksPerRole.)
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&a.me->done_count[role], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == n * (unsigned)kBlocksPerRole) __hip_atomic_store(a.remote_credit[s], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -215,9 +247,12 @@ int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
       PeerHeader* nh = (PeerHeader*)p->nb[s];
       a.remote_slot[s] = p->mailbox(p->nb[s], 1 - s, a.push_n[s] & 1);
       a.local_slot[s] = p->mailbox(p->region, s, a.pull_n[s] & 1);
-      a.remote_data_seq[s] = &nh->data_seq[1 - s];
+      a.remote_ready[s] = nh->ready[1 - s][a.push_n[s] & 1];
+      a.local_ready[s] = p->hdr()->ready[s][a.pull_n[s] & 1];
       a.remote_credit[s] = &nh->credit[1 - s];
+      a.used[s] = used;
     }
+    a.sub_bytes = p->sub_bytes;
     a.me = p->hdr();
     a.h_err = p->h_err;
     a.timeout_ticks = (unsigned long long)(p->timeout_s * 1e8);
@@ -298,6 +333,7 @@ int fnx_slab_peer_create(void** peer, int rank, int nranks, size_t mailbox_bytes
   p->rank = rank; p->nranks = nranks;
   p->slot_bytes = (mailbox_bytes + 255) & ~(size_t)255;
   p->region_bytes = kHeaderBytes + 4 * p->slot_bytes;
+  while (p->sub_bytes * kMaxSub < p->slot_bytes) p->sub_bytes *= 2;
   hipError_t e = hipGetDevice(&p->device);
   // uncached: the neighbour's stores must be seen by a kernel that is already running here, and ours by theirs
   if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&p->region, p->region_bytes, hipDeviceMallocUncached);
