@@ -386,7 +386,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                 roofline=roof)
 
 
-def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="deep_first"):
+def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="deep_first", transport="rccl"):
     """The SAME per-GPU slab step through the C++ z-slab driver (fnx_slab_step: launches, RCCL ncclSend/ncclRecv and their
     overlap issued from C++, csrc/fnx_slab.hip), continuing from the state the Python-driver run developed; same bits as the
     Python driver (tests/test_slab.py).  At N > 1 it also returns `comm`: a one-off probe of the communicator (ghost exchanges
@@ -396,9 +396,10 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
     import torch
     import torch.distributed as dist
     from fluidnet_cxx_amd._ext import ext
-    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout, rccl_comm
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout, peer_comm, rccl_comm
     layout = SlabLayout(D * world, world, rank, halo=6)
-    comm = rccl_comm(rank, world) if world > 1 else None
+    # transport "peer": device stores into hipIpc-mapped mailboxes + flags (csrc/fnx_peer.hip) instead of RCCL send/recv
+    comm = (peer_comm(rank, world, 16 << 20) if transport == "peer" else rccl_comm(rank, world)) if world > 1 else None
     sim = NativeSlabSimulator(layout, m, comm=comm, sweeps_per_exchange=6, static_flags=True, cfl_check_every=0, schedule=schedule)
 
     def barrier():
@@ -418,7 +419,8 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
         ms_big, ms_small = (float(x) for x in t.tolist())
         comm_info = dict(probe_6MiB_ms=ms_big, probe_6MiB_GBps_per_direction=(big / (ms_big * 1e-3) / 1e9) if ms_big > 0 else None,
                          probe_4KiB_us=ms_small * 1e3,
-                         probe="max over ranks of the mean of 20 grouped ncclSend/ncclRecv exchanges with each z-neighbour, back to back")
+                         probe="max over ranks of the mean of 20 ghost exchanges with each z-neighbour, back to back (" +
+                               ("peer-store launches" if transport == "peer" else "grouped ncclSend/ncclRecv") + ")")
         del scratch
     for _ in range(max(warmup, 3)):
         sim.step(bd)
@@ -485,7 +487,8 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
     cells = res * res * layout.owned * world
     out = dict(ms_per_step=elapsed / steps * 1e3, value=cells * steps / elapsed / 1e6, unit="Mcells/s", steps=steps, launch=launch,
                schedule=schedule,
-               transport="RCCL ncclSend/ncclRecv issued from C++ (librccl resolved at run time)" if world > 1 else None,
+               transport=(("peer-store: device stores into hipIpc-mapped mailboxes + flags (csrc/fnx_peer.hip), no RCCL on the data path"
+                           if transport == "peer" else "RCCL ncclSend/ncclRecv issued from C++ (librccl resolved at run time)") if world > 1 else None),
                state_finite=bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all()))
     if model:
         out["middle_rank_model"] = model
@@ -570,7 +573,7 @@ def compact(out):
     for k in ("cpu_baseline", "cpu_baseline_cnn"):
         if k in out:
             line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items()}
-    for k in ("native_driver", "python_driver", "comm"):
+    for k in ("native_driver", "native_driver_peer", "native_driver_rccl", "python_driver", "comm", "comm_peer", "comm_rccl"):
         if k in out:
             line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items() if kk != "middle_rank_model"}
     mm = out.get("native_driver", {}).get("middle_rank_model")
@@ -626,6 +629,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations reported under 'also' at N=1")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous, no GPU work")
     ap.add_argument("--no-native", action="store_true", help="skip the C++ z-slab driver leg reported as 'native_driver'")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
+                    help="N > 1: whose time becomes `value` -- the C++ driver over RCCL send/recv (what north_star names; the default) or over "
+                         "the peer-store communicator; both legs are run and printed either way")
     a = ap.parse_args()
     assert a.gpus >= 1
 
@@ -708,6 +714,30 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["native_driver"] = dict(error=f"{type(e).__name__}: {e}")
         dog.cancel()
+        if world > 1:
+            # the same C++ driver over the peer-store transport (hipIpc-mapped mailboxes + flags, no RCCL on the data path), under its
+            # own watchdog: this leg has never met more than one GPU either
+            def bail_peer():
+                out["native_driver_peer"] = dict(error="the peer-store leg did not finish within its time limit")
+                emit()
+                os._exit(0)
+            dog = threading.Timer(180.0, bail_peer)
+            dog.daemon = True
+            dog.start()
+            try:
+                ndp, comm_p = run_native_slab(a.steps, a.warmup, world, rank, dev, bd_s, m_s, WORKLOADS[name]["res"], WORKLOADS[name]["D"],
+                                              a.schedule, transport="peer")
+                out["native_driver_peer"] = ndp
+                if comm_p:
+                    out["comm_peer"] = comm_p
+            except Exception as e:  # noqa: BLE001
+                out["native_driver_peer"] = dict(error=f"{type(e).__name__}: {e}")
+            dog.cancel()
+            ndp = out["native_driver_peer"]
+            if a.transport == "peer" and "error" not in ndp and ndp.get("state_finite"):
+                out["native_driver_rccl"], out["native_driver"] = out["native_driver"], ndp
+                if "comm_peer" in out:
+                    out["comm_rccl"], out["comm"] = out.get("comm"), out["comm_peer"]
         nd = out["native_driver"]
         out["config"]["driver"] = "python (fluidnet_cxx_amd/slab.py over torch.distributed P2P)"
         if world > 1 and "error" not in nd and nd.get("state_finite"):
@@ -717,7 +747,8 @@ def main():
             out["value"], out["ms_per_step"] = nd["value"], nd["ms_per_step"]
             out["steps_per_s"] = 1e3 / nd["ms_per_step"]
             out["step_hbm_frac"] = out["step_hbm_frac"] * out["python_driver"]["ms_per_step"] / nd["ms_per_step"]
-            out["config"]["driver"] = "native (fnx_slab_step: C++ driver, RCCL ncclSend/ncclRecv issued from C++)"
+            out["config"]["driver"] = ("native (fnx_slab_step: C++ driver, " + ("peer-store transport" if "peer-store" in (nd.get("transport") or "")
+                                       else "RCCL ncclSend/ncclRecv issued from C++") + ")")
             out["config"]["launch"] = nd["launch"]
     emit()
     if world > 1:

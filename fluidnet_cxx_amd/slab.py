@@ -867,6 +867,19 @@ def rccl_comm(rank, world, group=None):
     return ext.slab_comm_rccl(rank, world, box[0])
 
 
+def peer_comm(rank, world, mailbox_bytes=16 << 20, group=None, timeout_s=30.0):
+    """A peer-store communicator for the native driver (fnx_slab_peer_create / fnx_slab_comm_peer): every rank allocates its region
+    (flags + mailbox), `torch.distributed` (any backend) carries the handles, each rank maps its two neighbours'.  Ghost planes then
+    travel as device stores into the neighbour's mailbox + flags -- no RCCL on the data path."""
+    from ._ext import ext
+    peer = ext.SlabPeer(rank, world, int(mailbox_bytes))
+    peer.set_timeout(float(timeout_s))
+    handles = [None] * world
+    if world > 1:
+        dist.all_gather_object(handles, peer.handle, group=group)
+    return ext.slab_comm_peer(peer, handles[rank - 1] if rank > 0 else None, handles[rank + 1] if rank < world - 1 else None)
+
+
 def lockstep_step(sims, states, defer=False):
     """Single-process stand-in for n ranks: advances all slabs phase by phase and serves their ghost exchanges with
     direct copies.  Used to validate the decomposition on ONE device (tests); production uses SlabSimulator.step.

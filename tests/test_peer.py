@@ -136,3 +136,42 @@ def test_peer_store_dead_neighbour_times_out(tmp_path):
     mp.spawn(_dead_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     msg = open(tmp_path / "rank0.txt").read()
     assert "timed out" in msg, msg
+
+
+def _bench_leg_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import json
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        from fluidnet_cxx_amd.slab import SlabLayout
+        w = bench.WORKLOADS["plume3d_slab_jacobi"]
+        m = bench.mconf_for(w)
+        layout = SlabLayout(w["D"] * world, world, rank, halo=6)
+        bd = bench.plume_state_torch(w["res"], layout.D_local, dev, layout.z_offset, layout.D_global)
+        out, comm = bench.run_native_slab(4, 12, world, rank, dev, bd, m, w["res"], w["D"], "deep_first", transport="peer")
+        if rank == 0:
+            json.dump(dict(out=out, comm=comm), open(os.path.join(out_dir, "leg.json"), "w"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_peer_leg_two_processes_one_gpu(tmp_path):
+    """bench.py's N > 1 leg over the peer-store transport (`run_native_slab(..., transport="peer")`: communicator probe, timed steps,
+    the driver's statistics), rehearsed with two processes on the one GPU -- the timings mean nothing (two ranks share a device), the
+    point is that the code path the driver's multi-GPU run takes has executed before: bytes per neighbour and step must be the
+    schedule's (4 planes of U and density = 16, 5 of div, 16 x 6 + 1 of p: 118 planes of 1 MiB in 19 exchanges)."""
+    import json
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_bench_leg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = json.load(open(tmp_path / "leg.json"))
+    assert r["out"]["state_finite"] and r["out"]["ms_per_step"] > 0 and "peer-store" in r["out"]["transport"]
+    c = r["comm"]
+    assert c["exchanges_per_step"] == 19 and c["bytes_per_neighbour_per_step"] == (4 * 4 + 5 + 16 * 6 + 1) * (1 << 20), c
+    assert c["probe_6MiB_ms"] > 0 and c["wait_ms_per_step"] >= 0
