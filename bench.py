@@ -468,7 +468,8 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
             stm = plume_state_torch(res, lm.D_local, dev, lm.z_offset, lm.D_global)
             model = dict(what="middle rank of 3 z-slabs on ONE GPU, C++ driver, link-model communicator (a model of N >= 3, not a measurement)",
                          ghost_free_ms=elapsed / steps * 1e3)
-            for lat, gbps in ((20.0, 75.0), (25.0, 55.0)):
+            # (latency 9 us: the peer-store launch between two processes, tools/peer_probe.py; 20-25 us: a grouped RCCL send/recv)
+            for lat, gbps in ((9.0, 75.0), (9.0, 55.0), (20.0, 75.0), (25.0, 55.0)):
                 simm = NativeSlabSimulator(lm, m, comm=ext.slab_comm_link_model(lat, gbps), sweeps_per_exchange=6, static_flags=True,
                                            cfl_check_every=0, schedule=schedule)
                 for _ in range(5):
@@ -480,7 +481,7 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
                 torch.cuda.synchronize()
                 msm = (time.perf_counter() - t1) / 10 * 1e3
                 model[f"ms_at_{int(gbps)}GBps_{int(lat)}us"] = msm
-                model[f"modelled_efficiency_at_{int(gbps)}GBps"] = (elapsed / steps * 1e3) / msm
+                model[f"modelled_efficiency_at_{int(gbps)}GBps_{int(lat)}us"] = (elapsed / steps * 1e3) / msm
                 del simm
         except Exception as e:  # noqa: BLE001
             model = dict(error=f"{type(e).__name__}: {e}")

@@ -292,9 +292,24 @@ void loop_abort(void* vctx) {
 // not).  What it measures is how much of a transfer of an assumed link a schedule hides.
 // ---------------------------------------------------------------------------------------------------------------
 struct ModelCtx { double latency_us, gbps; };
-__global__ void link_model_wait_kernel(unsigned long long ticks) {       // wall_clock64: 100 MHz on gfx950
+// One launch per exchange, like a real transport's: it moves the planes (ghost planes <- the slab's own edge planes) and does not end
+// before latency + bytes per direction / bandwidth have passed on the device's constant-rate clock (wall_clock64: 100 MHz on gfx950).
+// (Until round 4 the wait was a kernel of its own FOLLOWED by device-to-device copies: 15-25 us per exchange that no transport adds.)
+constexpr int kModelSegs = 16;
+struct ModelArgs { const char* src[2 * kModelSegs]; char* dst[2 * kModelSegs]; unsigned long long bytes[2 * kModelSegs]; int n; unsigned long long ticks; };
+__global__ __launch_bounds__(256) void link_model_xfer_kernel(ModelArgs a) {
   const unsigned long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  for (int i = 0; i < a.n; ++i) {
+    const unsigned long long n16 = a.bytes[i] >> 4;
+    if ((((unsigned long long)a.src[i] | (unsigned long long)a.dst[i] | a.bytes[i]) & 15ull) == 0) {
+      const uint4* s = (const uint4*)a.src[i]; uint4* d = (uint4*)a.dst[i];
+      for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < n16; q += (unsigned long long)gridDim.x * 256) d[q] = s[q];
+    } else {
+      for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < a.bytes[i]; q += (unsigned long long)gridDim.x * 256) a.dst[i][q] = a.src[i][q];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    while (wall_clock64() - t0 < a.ticks) __builtin_amdgcn_s_sleep(32);
 }
 int model_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
   ModelCtx* c = (ModelCtx*)vctx;
@@ -302,12 +317,17 @@ int model_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) 
   size_t bytes = 0;
   for (int i = 0; i < nsegs; ++i) bytes += segs[i].bytes;
   const double us = c->gbps > 0.0 ? c->latency_us + (double)bytes / (c->gbps * 1e3) : 0.0;
-  if (us > 0.0) link_model_wait_kernel<<<1, 64, 0, s>>>((unsigned long long)(us * 100.0));
-  for (int i = 0; i < nsegs; ++i) {
-    const FnxSlabSeg& g = segs[i];
-    if (g.recv_lo && g.send_hi) SLAB_HIP(hipMemcpyAsync(g.recv_lo, g.send_hi, g.bytes, hipMemcpyDeviceToDevice, s));
-    if (g.recv_hi && g.send_lo) SLAB_HIP(hipMemcpyAsync(g.recv_hi, g.send_lo, g.bytes, hipMemcpyDeviceToDevice, s));
+  for (int i0 = 0; i0 < nsegs; i0 += kModelSegs) {
+    ModelArgs a{};
+    for (int i = i0; i < nsegs && i < i0 + kModelSegs; ++i) {
+      const FnxSlabSeg& g = segs[i];
+      if (g.recv_lo && g.send_hi) { a.src[a.n] = (const char*)g.send_hi; a.dst[a.n] = (char*)g.recv_lo; a.bytes[a.n++] = g.bytes; }
+      if (g.recv_hi && g.send_lo) { a.src[a.n] = (const char*)g.send_lo; a.dst[a.n] = (char*)g.recv_hi; a.bytes[a.n++] = g.bytes; }
+    }
+    a.ticks = i0 == 0 ? (unsigned long long)(us * 100.0) : 0ull;      // (the whole exchange's time rides on its first launch)
+    link_model_xfer_kernel<<<64, 256, 0, s>>>(a);
   }
+  SLAB_HIP(hipGetLastError());
   return FNX_OK;
 }
 int model_allreduce(void*, float*, int, void*) { return FNX_OK; }        // one rank: its own value

@@ -342,10 +342,11 @@ int fnx_slab_loopback_group_reset(void* group);
 int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank);
 void fnx_slab_loopback_group_free(void* group);
 /* Link-model communicator (a rehearsal aid, not a transport): lets ONE process run the step of a middle rank (rank r of n with
- * 0 < r < n - 1) on one GPU.  An exchange occupies its stream for latency_us + bytes per direction / gbytes_per_s (0 GB/s: no
- * transfer time) and fills the ghost planes from the slab's own edge planes, so launch sequence, message sizes and stream
- * ordering are those of a real run and the time a schedule leaves exposed for an assumed link can be measured; the field
- * values are those of a periodic stack of this slab.  All-reduces return the rank's own value. */
+ * 0 < r < n - 1) on one GPU.  An exchange is one launch that fills the ghost planes from the slab's own edge planes and occupies its
+ * stream for latency_us + bytes per direction / gbytes_per_s (0 GB/s: no transfer time beyond the copy), so launch sequence, message
+ * sizes and stream ordering are those of a real run and the time a schedule leaves exposed for an assumed link can be measured; the
+ * field values are those of a periodic stack of this slab.  All-reduces return the rank's own value.  latency_us is the transport's:
+ * ~20 us for a grouped RCCL send/recv, ~9 us for the peer-store launch (tools/peer_probe.py). */
 int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_per_s);
 /* Peer-store communicator (no RCCL on the data path; the reference is single device, plume.py:131-135: no counterpart).  Every rank
  * owns a REGION of uncached device memory -- flag words and a mailbox of 2 x 2 slots of `mailbox_bytes` -- that its two z-neighbours
