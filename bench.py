@@ -20,11 +20,12 @@ At N = 1 the same JSON line carries, under "also", the other configurations the 
   plume3d_256_cnn      configs[3]: 3D plume 256^3, CNN pressure (Conv3d analogue of ScaleNet on the MFMA)
   plume3d_hbm_jacobi   3D plume 512 x 512 x 256, Jacobi-100: the solver's working set (1.3 GiB) exceeds the 256 MiB
                        Infinity Cache, so its roofline numbers are against HBM proper
+  plume2d_128_jacobi   configs[0]: 2D plume 128^2, Jacobi-28 -- the one configuration the reference itself runs (CPU, plumeConfig.yaml)
   plume2d_128_b32_cnn  the training-shaped call: 32 samples of 128^2 through one `simulate(..., 'convnet')` (the long-term rollout
                        of fluid_net_train.py:349-373 issues such calls under no_grad); also reports samples/s
 `metric_configs` in the printed line repeats, for the two configurations the metric is quoted on (256^3 Jacobi, 1024^2 CNN), the
 workload name, the numbers and that configuration's own roofline block.
-Other names for --workload: plume2d_128_jacobi (configs[0]), plume3d_128_cnn.
+Other names for --workload: plume3d_128_cnn.
 
 State.  Every workload is first advanced by >= 100 untimed steps (`config.developed_steps`) so that a plume exists
 (advection cost is data dependent: zero-velocity cells leave the line trace at once); the CNN workloads are developed with
@@ -39,19 +40,26 @@ C++ driver is (`config.driver` says so; if its leg fails the Python driver's num
 (`python_driver` / `native_driver`), together with `comm`: bytes posted per neighbour and step, the time the compute stream
 waited for exchanges, and a send/recv probe of the neighbour links.
 
-Prints ONE JSON line (rank 0) of < 4 kB: the contract fields, `summary` (per configuration: value, ms_per_step, steps_per_s,
-frac, frac_traffic or mfma_util -- so the metric's 256^3 Jacobi and 1024^2 CNN numbers sit at the front of the line),
-`roofline` and `cpu_baseline` (+ `cpu_baseline_cnn`).  Everything else (per-configuration config / roofline / kernel times,
-prose, PMC detail) goes to the side file named in `detail_file` (gpurun_out/bench_detail.json).
-  roofline.traffic       a RECORDED PMC figure (rocprofv3 --pmc passes of an earlier run of the same kernel; `traffic_source`
-                         names file and commit), not measured in this run: HIP events and PMC passes cannot share a run
-  roofline.frac          SURVEY 8d model: algorithmic bytes (16 B/cell/sweep) / launch time / 8 TB/s.  The solvers run
-                         several sweeps per pass over HBM, so this can exceed 1; it is the contract's figure, not a
-                         utilisation.
-  roofline.frac_traffic  measured HBM-side bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json) / launch time / peak:
-                         the utilisation figure for the stencil kernels
-  roofline.mfma_util     (conv) multiply-add FLOPs actually issued to the matrix cores / time / 157.3 TF -- a Winograd
-                         launch issues 16/36 of the direct convolution's FLOPs, so `frac` (direct-equivalent) overstates it
+Prints ONE JSON line (rank 0) of < 4 kB: the contract fields; `configs` -- one row [ms, Mcells/s, utilisation, which] per
+BASELINE.json configuration, configs[0] (the reference's own 128^2 CPU case) to configs[4]; `metric_configs` -- the metric's 256^3
+Jacobi and 1024^2 CNN with their own roofline blocks; `other` -- the remaining workloads; the headline's `config`, `roofline`,
+`kernel_ms_per_step`, `advect`; `cpu_baseline` (+ `cpu_baseline_cnn`).  Everything else (per-configuration config / roofline /
+kernel times, prose, PMC detail) goes to the side file named in `detail_file` (gpurun_out/bench_detail.json).
+  roofline.traffic          a RECORDED PMC figure (rocprofv3 --pmc passes of an earlier run of the same kernel; `traffic_source`
+                            names file and commit), not measured in this run: HIP events and PMC passes cannot share a run
+  roofline.frac             SURVEY 8d model: algorithmic bytes (16 B/cell/sweep) / launch time / 8 TB/s.  The solvers run
+                            several sweeps per pass over HBM, so this can exceed 1; it is the contract's figure, not a
+                            utilisation -- read frac_compulsory / frac_traffic / mfma_util next to it
+  roofline.frac_compulsory  the bytes one launch cannot avoid at its sweeps per pass (3D: p in, div, p out, mask byte = 13 B/cell per
+                            two-sweep pass; 2D: 16 B/cell per launch) / launch time / peak
+  roofline.frac_traffic     measured HBM-side bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json) / launch time / peak:
+                            the utilisation figure for the stencil kernels
+  roofline.mfma_util        (conv) multiply-add FLOPs actually issued to the matrix cores / time / 157.3 TF -- a Winograd
+                            launch issues 16/36 of the direct convolution's FLOPs, so `frac` (direct-equivalent) overstates it
+  kernel_ms_per_step        HIP-event pairs around every launch of a class: ~2 us per launch above the kernels' own time, so the
+                            classes can add up to more than ms_per_step
+  advect                    the 3D advection launches: ms, fraction of the 120 B/cell model, and the recorded VALU-issue fraction (the
+                            kernels are issue-bound: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x busy cycles))
 """
 import argparse
 import json
@@ -100,8 +108,10 @@ WORKLOADS = {
     "plume2d_1024_cnn_bf16x6": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x6"),
     "plume3d_256_cnn_bf16x6": dict(res=256, D=256, method="convnet", iters=0, kind="plume", precision="bf16x6"),
 }
-ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_cnn",
+ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_128_jacobi", "plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_cnn",
         "plume3d_hbm_jacobi", "plume2d_128_b32_cnn", "plume2d_1024_cnn_bf16x6", "plume3d_256_cnn_bf16x6"]
+# BASELINE.json's configs[0..4] -> the workload that measures each (configs[4]: one z-slab of it per GPU)
+BASELINE_CONFIGS = ["plume2d_128_jacobi", "plume2d_1024_cnn", "rt2d_2048_jacobi", "plume3d_256_cnn", "plume3d_slab_jacobi"]
 METRIC_CONFIGS = ["plume3d_256_jacobi", "plume2d_1024_cnn"]      # the two configurations BASELINE.json's metric is quoted on
 
 
@@ -351,7 +361,13 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                  "pass to pass in the row-quad layout; the first pass of a solve is <true,..>, the last one writes rows)" if is3d
                  else "jacobi2d_wg_kernel<8,8> (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-10 sweeps per launch)")
         avg_ms = tms / max(nl, 1)
+        # what one launch MUST move at its sweeps per pass: 3D, two sweeps per pass: p in + div + p out (4 B each) + the mask byte;
+        # 2D, 7-10 sweeps per launch: p in + div + flags + p out.  frac (SURVEY 8d's 16 B per cell and SWEEP) exceeds 1 by design of
+        # the temporal blocking; frac_compulsory is the fraction of the HBM peak the kernel needs for the bytes it cannot avoid.
+        comp = (13.0 if is3d else 16.0) * cells
         roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    compulsory_bytes_per_launch=comp,
+                    frac_compulsory=(comp / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else None,
                     traffic=traffic, traffic_source=traffic_src,
                     frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                     traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
@@ -361,11 +377,20 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
     else:
         step_bytes = (STEP_BYTES[is3d](0) - (44 if not is3d else 60) + 104) * cells   # advection + CNN glue
+    advect = None
+    if is3d and times.get("advect", (0, 0))[1] > 0:
+        adv_ms = times["advect"][0] / prof_steps
+        rec = (json.load(open(tfile)) if os.path.exists(tfile) else {}).get("advection_3d_512x512x64", {})
+        advect = dict(ms_per_step=adv_ms, model_bytes_per_cell=120,
+                      frac_of_model=(120.0 * cells / (adv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if adv_ms > 0 else None,
+                      valu_issue_frac=rec.get("valu_issue_frac"), valu_source=rec.get("valu_source"),
+                      note="issue-bound (~1 190 VALU instructions per cell); valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE), recorded PMC pass")
     if slab:
         run_workload.slab_state = (bd, m)
-    return dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
+    return dict(advect=advect, metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
                 unit="Mcells/s", steps_per_s=steps / elapsed, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=ms,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32 (bf16x6 products: opt-in mode)" if w.get("precision") == "bf16x6" else "f32", data="synthetic",
                 config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
                             global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]], batch=w.get("batch", 1),
                             cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"], precision=w.get("precision", "fp32"),
@@ -504,20 +529,21 @@ def _r(x, n=4):
 
 
 def _short(res):
-    """one configuration's entry of `summary`"""
+    """one configuration's row of `configs` / `other`: [ms per step, Mcells/s, fraction, which fraction]"""
     rf = res.get("roofline", {})
-    e = dict(value=_r(res["value"], 5), ms_per_step=_r(res["ms_per_step"], 5), steps_per_s=_r(res["steps_per_s"], 5),
-             frac=_r(rf.get("frac")), step_hbm_frac=_r(res.get("step_hbm_frac")))
     if rf.get("bound") == "mfma":
-        e.pop("step_hbm_frac", None)            # (an HBM fraction of a matrix-core-bound step says nothing; the side file has it)
-        e["mfma_util"] = _r(rf.get("mfma_util"))
         if rf.get("bf16x6"):
-            e["precision"] = "bf16x6 (opt-in)"
-            e["bf16_mfma_util"] = _r(rf["bf16x6"]["frac"])
-    e["frac_traffic"] = _r(rf.get("frac_traffic"))
+            frac, what = rf["bf16x6"]["frac"], "bf16 MFMA util (opt-in bf16x6)"
+        else:
+            frac, what = rf.get("mfma_util"), "fp32 MFMA util"
+    else:
+        frac, what = rf.get("frac_traffic"), "PMC bytes/HBM peak"
+        if frac is None:
+            frac, what = rf.get("frac_compulsory"), "compulsory bytes/HBM peak"
+    e = dict(ms=_r(res["ms_per_step"], 5), Mcells_s=_r(res["value"], 5), frac=_r(frac, 3), of=what)
     if res.get("samples_per_s"):
-        e["samples_per_s"] = _r(res["samples_per_s"], 5)
-    return {k: v for k, v in e.items() if v is not None}       # (the line has a 4 kB budget)
+        e["samples_s"] = _r(res["samples_per_s"], 5)
+    return e
 
 
 def pmc_source(summary_file=None):
@@ -533,44 +559,59 @@ def pmc_source(summary_file=None):
         return f"recorded rocprofv3 PMC passes, {src}"
 
 
+def _roof(rf, long=False):
+    """a roofline block of the printed line: `frac` is SURVEY 8d's model figure (16 B per cell and SWEEP / direct-convolution FLOPs:
+    it exceeds 1 where a pass does several sweeps / runs in the Winograd domain); frac_compulsory / mfma_util is the utilisation"""
+    e = dict(bound=rf["bound"], kernel=rf["kernel"].split(" (")[0], achieved=_r(rf["achieved"], 5), peak=rf["peak"], unit=rf["unit"],
+             frac=_r(rf["frac"]), traffic=rf.get("traffic"), frac_traffic=_r(rf.get("frac_traffic")))
+    if rf["bound"] == "mfma":
+        e["mfma_util"] = _r(rf.get("mfma_util"))
+    else:
+        e["frac_compulsory"] = _r(rf.get("frac_compulsory"))
+    if long:
+        e.update(traffic_source=pmc_source(rf.get("traffic_source")) if rf.get("traffic") else None,
+                 launches_per_step=_r(rf.get("launches_per_step")), avg_launch_ms=_r(rf.get("avg_launch_ms")), algorithmic=rf.get("algorithmic"))
+    return e
+
+
 def compact(out):
-    """(the one printed line, the side file's content).  The line: contract fields, `summary` first, a short `config` and
-    `roofline`, the CPU baselines, and at N > 1 the drivers' numbers and `comm`."""
+    """(the one printed line, the side file's content).  The line (4 kB budget): contract fields; `configs` -- one row per
+    BASELINE.json configuration; `metric_configs` -- the two the metric is quoted on, with their rooflines; `other` -- the
+    remaining workloads; the headline's `config` and `roofline`; the CPU baselines; at N > 1 the drivers' numbers and `comm`."""
     name = out["config"]["workload"]
     line = {k: out[k] for k in ("metric",)}
     line.update(value=_r(out["value"], 6), unit=out["unit"], n_gpus=out["n_gpus"], steps=out["steps"], warmup=out["warmup"],
-                ms_per_step=_r(out["ms_per_step"], 6), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                ms_per_step=_r(out["ms_per_step"], 6), higher_is_better=True, scaling="weak", vs_baseline=None, dtype=out.get("dtype", "f32"),
                 data="synthetic", steps_per_s=_r(out["steps_per_s"], 6))
-    summ = {name: _short(out)}
-    for k, v in out.get("also", {}).items():
-        summ[k] = _short(v) if "error" not in v else dict(error=v["error"][:120])
-    line["summary"] = summ
+    every = {name: out}
+    every.update(out.get("also", {}))
+    rows = {k: (_short(v) if "error" not in v else dict(error=v["error"][:100])) for k, v in every.items()}
+    cfgs = {f"configs[{i}]": dict(workload=k, **rows[k]) for i, k in enumerate(BASELINE_CONFIGS) if k in rows}
+    if cfgs:
+        line["configs"] = cfgs
     c = out["config"]
     line["config"] = {k: c.get(k) for k in ("workload", "grid_per_gpu", "global_grid", "method", "jacobi_iters", "parallelism",
                                             "launch", "driver", "developed_steps", "world_size", "backend") if c.get(k) is not None}
     line["config"]["static_flags"] = "flags+BCs static"
     line["config"]["state_finite"] = c.get("state_finite_after_timing")
-    rf = out["roofline"]
-    line["roofline"] = dict(bound=rf["bound"], kernel=rf["kernel"].split(" (")[0], achieved=_r(rf["achieved"], 5), peak=rf["peak"],
-                            unit=rf["unit"], frac=_r(rf["frac"]), traffic=rf.get("traffic"), frac_traffic=_r(rf.get("frac_traffic")),
-                            traffic_source=pmc_source(rf.get("traffic_source")) if rf.get("traffic") else None,
-                            launches_per_step=_r(rf.get("launches_per_step")), avg_launch_ms=_r(rf.get("avg_launch_ms")),
-                            algorithmic=rf.get("algorithmic"))
+    line["roofline"] = _roof(out["roofline"], long=True)
     # the two configurations the metric is quoted on, with their own workload name and roofline in the printed line
     mc = {}
     for k in METRIC_CONFIGS:
-        v = out if k == name else out.get("also", {}).get(k)
+        v = every.get(k)
         if v and "error" not in v:
-            r2 = v["roofline"]
-            e = dict(workload=k, value=_r(v["value"], 5), unit="Mcells/s", ms_per_step=_r(v["ms_per_step"], 5), steps_per_s=_r(v["steps_per_s"], 5),
-                     roofline=dict(bound=r2["bound"], kernel=r2["kernel"].split(" (")[0], achieved=_r(r2["achieved"], 5), peak=r2["peak"],
-                                   unit=r2["unit"], frac=_r(r2["frac"]), traffic=r2.get("traffic"), frac_traffic=_r(r2.get("frac_traffic"))))
-            if r2["bound"] == "mfma":
-                e["roofline"]["mfma_util"] = _r(r2.get("mfma_util"))
-            mc[k] = e
+            mc[k] = dict(value=_r(v["value"], 5), unit="Mcells/s", ms_per_step=_r(v["ms_per_step"], 5), steps_per_s=_r(v["steps_per_s"], 5),
+                         roofline=_roof(v["roofline"]))
     if mc:
         line["metric_configs"] = mc
-    line["kernel_ms_per_step"] = {k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()}
+    other = {k: v for k, v in rows.items() if k not in BASELINE_CONFIGS and k not in METRIC_CONFIGS}
+    if other:
+        line["other"] = other
+    line["kernel_ms_per_step"] = dict({k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()},
+                                      note="HIP-event pairs around every launch of the class (~2 us per launch above the kernels' own time)")
+    if out.get("advect"):
+        ad = out["advect"]
+        line["advect"] = dict(ms=_r(ad["ms_per_step"]), frac_of_120B_model=_r(ad["frac_of_model"], 3), valu_issue_frac=_r(ad.get("valu_issue_frac"), 3))
     for k in ("cpu_baseline", "cpu_baseline_cnn"):
         if k in out:
             line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items()}
@@ -579,8 +620,8 @@ def compact(out):
             line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items() if kk != "middle_rank_model"}
     mm = out.get("native_driver", {}).get("middle_rank_model")
     if mm:                                   # (short form: the sentence that says what it is stays in the side file)
-        line["middle_rank_model"] = {kk: _r(vv) for kk, vv in mm.items() if kk != "what"}
-        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model communicator: a MODEL of N>=3"
+        line["middle_rank_model"] = {kk.replace("modelled_efficiency", "eff"): _r(vv, 3) for kk, vv in mm.items() if kk != "what"}
+        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model communicator (9 us: peer-store, 20-25 us: RCCL): a MODEL of N>=3"
     line["detail_file"] = "gpurun_out/bench_detail.json"
     return line, out
 
@@ -672,7 +713,7 @@ def main():
             try:
                 r = run_workload(other, min(a.steps, 5 if big else 20), min(a.warmup, 2 if big else 5), not a.no_graph, 1, 0, dev)
                 out["also"][other] = {k: r[k] for k in ("value", "unit", "steps_per_s", "samples_per_s", "ms_per_step", "step_hbm_frac", "steps",
-                                                        "config", "roofline", "kernel_ms_per_step")}
+                                                        "config", "roofline", "kernel_ms_per_step", "dtype", "advect")}
             except Exception as e:  # noqa: BLE001  (an "also" line must not take the headline down)
                 out["also"][other] = dict(error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()

@@ -8,7 +8,7 @@ f = glob.glob('gpurun_out/prof_cnn/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last forward: find last 'unscale'
-idx = [i for i, r in enumerate(rows) if 'pack_input' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'pack_div' in r['Kernel_Name'] or 'pack_input' in r['Kernel_Name']]
 a = idx[-1]
 for r in rows[a:a + 40]:
     n = r['Kernel_Name'].replace('void fnx::(anonymous namespace)::', '').replace('fnx::(anonymous namespace)::', '')[:60]
