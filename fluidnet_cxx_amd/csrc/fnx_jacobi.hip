@@ -523,7 +523,7 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 
 // ZERO: p_in is all zeros (first pass of a solve): no p^0 loads, no p^0 halo exchange.
 // LAY: bit 0 = p_in, bit 1 = p_out is in the ROW-QUAD layout p[b][k][j/4][i][j%4] (H % 4 == 0) instead of p[b][k][j][i].
-// The pass is bound by the CU's vector-memory pipeline, whose cost is per instruction: in the quad layout a
+// The pass is bound by the CU's vector-memory pipeline, whose cost is per instruction (docs/history/design_rounds_1-4.md, section 4): in the quad layout a
 // wave's own four rows of a column are one 16-byte access and the two halo rows on either side one 8-byte access each, so a
 // step reads p^0 with 3 instructions instead of 8 and writes its four finished rows with 1 instead of 4.  A plane is the same
 // H*W floats in both layouts (ghost-plane exchanges do not care); the passes of a solve hand the quad layout to each other
