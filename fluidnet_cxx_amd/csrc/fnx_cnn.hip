@@ -118,6 +118,10 @@ __global__ void pack_layer_kernel(const float* __restrict__ w, const float* __re
 struct ConvArgs {
   const float* x; float* y; const float* w; const float* bias;
   int B, cin, cout, D, H, W, relu, groups;
+  // Optional fused tail (conv5_mfma16_kernel PAIR only): a 1x1(x1) convolution cout -> 1 applied in the epilogue -- y then has ONE
+  // channel: y = tail_b[0] + sum_c tail_w[c] * act(conv)[c].  multi_scale_net.py:116: the net's last 5x5 layer (32 -> 8) and its
+  // final 1x1 (8 -> 1); the 8-channel tensor between them is never written.
+  const float* tail_w; const float* tail_b;
 };
 
 // Thin layers (Cin 2-3 or Cout 1-8): direct convolution.  A thread owns a vertical strip of RY output pixels x CO_T
@@ -191,6 +195,59 @@ void launch_conv_k(const ConvArgs& a, hipStream_t s) {
   if (cot == 16) conv_direct_kernel<KS, 16, IS3D, RY><<<grid, block, 0, s>>>(a);
   else if (cot == 8) conv_direct_kernel<KS, 8, IS3D, RY><<<grid, block, 0, s>>>(a);
   else conv_direct_kernel<KS, 1, IS3D, RY><<<grid, block, 0, s>>>(a);
+}
+
+// 3x3(x3) convolution to ONE output channel (the towers' last layers, 32 -> 1, at half and quarter resolution).  In the strip
+// kernel above a thread walks all Cin channels of its 4 output rows alone: 4 chains of 9 Cin dependent FMAs on launches of a few
+// dozen workgroups (256^2: 25.6 us for 37 MFLOP).  Here the block's four waves split the INPUT CHANNELS: wave q accumulates
+// channels q, q + 4, ... of the block's 4 output rows (each input row it loads feeds up to 3 output rows), the partial sums meet in
+// LDS and wave r finishes output row r: sums of the four partials in wave order + bias.  4x the workgroups, chains a quarter as long.
+template <bool IS3D>
+__global__ __launch_bounds__(256) void conv3_to1_kernel(ConvArgs a) {
+  constexpr int KS = 3, KD = IS3D ? KS : 1, PAD = 1, PD = IS3D ? 1 : 0, TAPS = KD * KS * KS, RY = 4;
+  __shared__ float part[4][RY][64];
+  const int lane = threadIdx.x, q = threadIdx.y;
+  const int i = blockIdx.x * 64 + lane, j0 = blockIdx.y * RY;
+  int z = blockIdx.z;
+  const int k = z % a.D; const int b = z / a.D;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
+  float acc[RY] = {0.f, 0.f, 0.f, 0.f};
+  const float* xb = a.x + (size_t)b * a.cin * vol;
+  for (int ci = q; ci < a.cin; ci += 4) {
+    const float* xc = xb + (size_t)ci * vol;
+    const float* wc = a.w + (size_t)ci * TAPS;              // packed [1][Cin][taps][1]
+#pragma unroll
+    for (int dz = 0; dz < KD; ++dz) {
+      const int zz = k + dz - PD;
+      const bool zin = (zz >= 0) & (zz < a.D);
+#pragma unroll
+      for (int row = 0; row < RY + KS - 1; ++row) {
+        const int yy = j0 + row - PAD;
+        const bool yin = zin & (yy >= 0) & (yy < a.H);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          const int xx = i + t - PAD;
+          const bool in = yin & (xx >= 0) & (xx < a.W);
+          const float v = in ? xc[(size_t)(zin ? zz : 0) * plane + (size_t)(yin ? yy : 0) * a.W + (in ? xx : 0)] : 0.f;
+#pragma unroll
+          for (int ry = 0; ry < RY; ++ry) {
+            const int r = row - ry;
+            if (r >= 0 && r < KS) acc[ry] = fmaf(v, wc[(dz * KS + r) * KS + t], acc[ry]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ry = 0; ry < RY; ++ry) part[q][ry][lane] = acc[ry];
+  __syncthreads();
+  const int j = j0 + q;                                     // wave q finishes output row q
+  if (i < a.W && j < a.H) {
+    float v = ((part[0][q][lane] + part[1][q][lane]) + part[2][q][lane]) + part[3][q][lane];
+    v += a.bias[0];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.y[(size_t)b * vol + (size_t)k * plane + (size_t)j * a.W + i] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -942,6 +999,34 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
     stage_body(it, wbuf0, wbuf1);
     if (it + 1 < niter) stage_body(it + 1, wbuf1, wbuf0);
   }
+  if (PAIR && a.tail_w != nullptr) {
+    // fused 1x1 tail: a lane holds channels (4 kq + r) % 8 of pixel x (kq 0, 1) or x + 1 (kq 2, 3); its four weighted values are
+    // summed in the lane, the two halves of a pixel (lanes 16 apart) through a DPP row... the lanes sit in different rows of 16:
+    // ds_swizzle / bpermute; the lane with even kq adds the bias and stores the ONE output channel
+    float tw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tw[r] = a.tail_w[(4 * kq + r) % 8];
+    const float tb = a.tail_b[0];
+#pragma unroll
+    for (int pr = 0; pr < PR; ++pr) {
+      const int y = y0 + wave * PR + pr;
+#pragma unroll
+      for (int nx = 0; nx < NX; ++nx) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[pr][nx][0][r];
+          if (a.relu) v = fmaxf(v, 0.f);
+          sum = fmaf(tw[r], v, sum);
+        }
+        const float other = __shfl_xor(sum, 16);             // (every lane takes part: no early exits above)
+        const int x = x0 + nx * XSEG + XSTEP * seg + (kq >> 1);
+        if ((kq & 1) == 0 && y < a.H && x < a.W)
+          a.y[(size_t)b * vol + (size_t)z * plane + (size_t)y * a.W + x] = (sum + other) + tb;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int pr = 0; pr < PR; ++pr) {
     const int y = y0 + wave * PR + pr;
@@ -1032,9 +1117,15 @@ bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t
 }
 
 // mode: FNX_PRECISION_* (FP32_DIRECT: no Winograd, every layer a direct sum over its taps; BF16X6: conv3_wbf_kernel where it applies)
+// tail: the packed layer of a following 1x1 convolution to one channel that the launch applies in its epilogue (y then has one
+// channel); only for the PAIR 5x5 layer (fuses_tail)
+inline bool fuses_tail(const ConvLayer& L, const ConvLayer& next) {
+  return mfma16_layer(L) && pair_layer(L.cin, L.cout) && L.cout == 8 && next.k == 1 && next.cin == L.cout && next.cout == 1 && !next.relu;
+}
 void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, const PackedLayer& pl, const float* x, float* y,
-                 int B, int D, int H, int W, hipStream_t s) {
-  ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout)};
+                 int B, int D, int H, int W, hipStream_t s, const PackedLayer* tail = nullptr) {
+  ConvArgs a{x, y, packed + pl.w_off, packed + pl.b_off, B, L.cin, L.cout, D, H, W, L.relu, L.cout / co_tile(L.cout),
+             tail ? packed + tail->w_off : nullptr, tail ? packed + tail->b_off : nullptr};
   // (the MFMA kernels address a stage of 8 channel volumes through one 32-bit buffer range: 2^27 cells per sample at
   // most; beyond that -- 137 GB per 128-channel activation -- the direct kernel below still works)
   const bool direct = mode == FNX_PRECISION_FP32_DIRECT;
@@ -1064,6 +1155,11 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
     return;
   }
   ProfScope ps(FNX_PROF_CONV_DIRECT, s);
+  if (L.k == 3 && L.cout == 1 && L.cin % 4 == 0) {          // the towers' last layers: input channels split over the block's waves
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, B * D), block(64, 4);
+    if (is3d) conv3_to1_kernel<true><<<grid, block, 0, s>>>(a); else conv3_to1_kernel<false><<<grid, block, 0, s>>>(a);
+    return;
+  }
   if (is3d) {
     if (L.k == 3) launch_conv_k<3, true>(a, s);
     else if (L.k == 5) launch_conv_k<5, true>(a, s);
@@ -1093,33 +1189,42 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int
 // notional planes [out_off, out_off + Do); a source plane outside x's window is clamped into it (only planes nobody uses read
 // such values).  {Di, 0, Do, 0} = whole tensors.
 struct ZWin { int full_in, in_off, full_out, out_off; };
-__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
-                                                     int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Ctot,
-                                                     int c_off, ZWin zw) {
+// One launch resamples up to TWO sources into consecutive channel ranges of y (the concatenations of multi_scale_net.py:121-125:
+// [x resampled (2 channels), the coarser tower's output resampled (1 channel)]): source 0 fills channels [c_off, c_off + s0.C), source 1
+// the next s1.C (s1.C = 0: one source).
+struct RSrc { const float* x; int C, Di, Hi, Wi; ZWin zw; };
+__global__ __launch_bounds__(256) void resize_kernel(RSrc s0, RSrc s1, float* __restrict__ y, int B, int Do, int Ho, int Wo, int Ctot,
+                                                     int c_off) {
+  const int C = s0.C + s1.C;
   const size_t n = (size_t)B * C * Do * Ho * Wo;
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
     size_t r = q;
     const int i = r % Wo; r /= Wo;
     const int j = r % Ho; r /= Ho;
     const int k = r % Do; r /= Do;
-    const int c = r % C; const int b = r / C;
-    int x0, x1, y0, y1, z0, z1; float s0, s1, t0, t1, f0, f1;
-    src_index(i, Wi, Wo, x0, x1, s0, s1);
+    const int cc = r % C; const int b = r / C;
+    const bool second = cc >= s0.C;                        // (block-uniform except at a channel boundary)
+    const RSrc& S = second ? s1 : s0;
+    const int c = second ? cc - s0.C : cc;
+    const int Di = S.Di, Hi = S.Hi, Wi = S.Wi;
+    const ZWin zw = S.zw;
+    int x0, x1, y0, y1, z0, z1; float sx0, sx1, t0, t1, f0, f1;
+    src_index(i, Wi, Wo, x0, x1, sx0, sx1);
     src_index(j, Hi, Ho, y0, y1, t0, t1);
     src_index(k + zw.out_off, zw.full_in, zw.full_out, z0, z1, f0, f1);
     z0 -= zw.in_off; z1 -= zw.in_off;
     z0 = z0 < 0 ? 0 : (z0 > Di - 1 ? Di - 1 : z0);
     z1 = z1 < 0 ? 0 : (z1 > Di - 1 ? Di - 1 : z1);
-    const float* xi = x + ((size_t)b * C + c) * Di * Hi * Wi;
+    const float* xi = S.x + ((size_t)b * S.C + c) * Di * Hi * Wi;
 #define XI(zz, yy, xx) xi[((size_t)(zz) * Hi + (yy)) * Wi + (xx)]
-    const float lo = t0 * (s0 * XI(z0, y0, x0) + s1 * XI(z0, y0, x1)) + t1 * (s0 * XI(z0, y1, x0) + s1 * XI(z0, y1, x1));
+    const float lo = t0 * (sx0 * XI(z0, y0, x0) + sx1 * XI(z0, y0, x1)) + t1 * (sx0 * XI(z0, y1, x0) + sx1 * XI(z0, y1, x1));
     float v = lo;
     if (zw.full_in > 1 || zw.full_out > 1) {
-      const float hi = t0 * (s0 * XI(z1, y0, x0) + s1 * XI(z1, y0, x1)) + t1 * (s0 * XI(z1, y1, x0) + s1 * XI(z1, y1, x1));
+      const float hi = t0 * (sx0 * XI(z1, y0, x0) + sx1 * XI(z1, y0, x1)) + t1 * (sx0 * XI(z1, y1, x0) + sx1 * XI(z1, y1, x1));
       v = f0 * lo + f1 * hi;
     }
 #undef XI
-    y[(((size_t)b * Ctot + c_off + c) * Do + k) * Ho * Wo + (size_t)j * Wo + i] = v;
+    y[(((size_t)b * Ctot + c_off + cc) * Do + k) * Ho * Wo + (size_t)j * Wo + i] = v;
   }
 }
 
@@ -1129,7 +1234,14 @@ void launch_resize(const float* x, float* y, int B, int C, int Di, int Hi, int W
   size_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   const ZWin whole{Di, 0, Do, 0};
-  resize_kernel<<<(int)blocks, 256, 0, s>>>(x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, Ctot, c_off, zw ? *zw : whole);
+  resize_kernel<<<(int)blocks, 256, 0, s>>>(RSrc{x, C, Di, Hi, Wi, zw ? *zw : whole}, RSrc{nullptr, 0, 1, 1, 1, whole}, y, B, Do, Ho, Wo, Ctot, c_off);
+}
+// two sources -> channels [0, C0 + C1) of y in one launch
+void launch_resize2(const RSrc& s0, const RSrc& s1, float* y, int B, int Do, int Ho, int Wo, hipStream_t s) {
+  const size_t n = (size_t)B * (s0.C + s1.C) * Do * Ho * Wo;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  resize_kernel<<<(int)blocks, 256, 0, s>>>(s0, s1, y, B, Do, Ho, Wo, s0.C + s1.C, 0);
 }
 
 struct Sizes { int Dq, Hq, Wq, Dh, Hh, Wh; };
@@ -1224,8 +1336,12 @@ void multiscale_forward_crop(const GridDims& g, bool is3d, const void* packed, c
   auto tower = [&](int l0, int n, const float* in, float* out, int D, int H, int W) {
     const float* cur = in;
     for (int l = 0; l < n; ++l) {
-      float* dst = (l == n - 1) ? out : ((l & 1) ? bufB : bufA);
-      launch_conv(LAYERS[l0 + l], is3d, mode, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s);
+      // the last 5x5 layer takes the final 1x1 into its epilogue (multi_scale_net.py:116): one launch, no 8-channel tensor
+      const bool fuse = l + 2 == n && fuses_tail(LAYERS[l0 + l], LAYERS[l0 + l + 1]);
+      float* dst = (l == n - 1 || fuse) ? out : ((l & 1) ? bufB : bufA);
+      const PackedLayer tl = fuse ? packed_layer(l0 + l + 1, is3d) : PackedLayer{0, 0};
+      launch_conv(LAYERS[l0 + l], is3d, mode, pk, packed_layer(l0 + l, is3d), cur, dst, g.B, D, H, W, s, fuse ? &tl : nullptr);
+      if (fuse) break;
       cur = dst;
     }
   };
@@ -1236,12 +1352,10 @@ void multiscale_forward_crop(const GridDims& g, bool is3d, const void* packed, c
   launch_resize(x, xq, g.B, 2, g.D, g.H, g.W, z.Dq, z.Hq, z.Wq, 2, 0, s);
   tower(0, 4, xq, c4, z.Dq, z.Hq, z.Wq);
   const ZWin x_to_h{g.D, 0, z.Dh, h_lo}, q_to_h{z.Dq, 0, z.Dh, h_lo};
-  launch_resize(x, in2, g.B, 2, g.D, g.H, g.W, h_n, z.Hh, z.Wh, 3, 0, s, &x_to_h);
-  launch_resize(c4, in2, g.B, 1, z.Dq, z.Hq, z.Wq, h_n, z.Hh, z.Wh, 3, 2, s, &q_to_h);
+  launch_resize2(RSrc{x, 2, g.D, g.H, g.W, x_to_h}, RSrc{c4, 1, z.Dq, z.Hq, z.Wq, q_to_h}, in2, g.B, h_n, z.Hh, z.Wh, s);
   tower(4, 6, in2, c2, h_n, z.Hh, z.Wh);
   const ZWin x_to_f{g.D, 0, g.D, f_lo}, h_to_f{z.Dh, h_lo, g.D, f_lo};
-  launch_resize(x, in1, g.B, 2, g.D, g.H, g.W, f_n, g.H, g.W, 3, 0, s, &x_to_f);
-  launch_resize(c2, in1, g.B, 1, h_n, z.Hh, z.Wh, f_n, g.H, g.W, 3, 2, s, &h_to_f);
+  launch_resize2(RSrc{x, 2, g.D, g.H, g.W, x_to_f}, RSrc{c2, 1, h_n, z.Hh, z.Wh, h_to_f}, in1, g.B, f_n, g.H, g.W, s);
   // convN_1 (6 layers) then final 1x1: 7 convs, the last one writes p
   tower(10, 7, in1, p, f_n, g.H, g.W);
 }
