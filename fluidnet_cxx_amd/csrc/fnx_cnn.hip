@@ -1193,55 +1193,53 @@ struct ZWin { int full_in, in_off, full_out, out_off; };
 // [x resampled (2 channels), the coarser tower's output resampled (1 channel)]): source 0 fills channels [c_off, c_off + s0.C), source 1
 // the next s1.C (s1.C = 0: one source).
 struct RSrc { const float* x; int C, Di, Hi, Wi; ZWin zw; };
-__global__ __launch_bounds__(256) void resize_kernel(RSrc s0, RSrc s1, float* __restrict__ y, int B, int Do, int Ho, int Wo, int Ctot,
-                                                     int c_off) {
-  const int C = s0.C + s1.C;
-  const size_t n = (size_t)B * C * Do * Ho * Wo;
-  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
-    size_t r = q;
-    const int i = r % Wo; r /= Wo;
-    const int j = r % Ho; r /= Ho;
-    const int k = r % Do; r /= Do;
-    const int cc = r % C; const int b = r / C;
-    const bool second = cc >= s0.C;                        // (block-uniform except at a channel boundary)
-    const RSrc& S = second ? s1 : s0;
-    const int c = second ? cc - s0.C : cc;
-    const int Di = S.Di, Hi = S.Hi, Wi = S.Wi;
-    const ZWin zw = S.zw;
-    int x0, x1, y0, y1, z0, z1; float sx0, sx1, t0, t1, f0, f1;
-    src_index(i, Wi, Wo, x0, x1, sx0, sx1);
-    src_index(j, Hi, Ho, y0, y1, t0, t1);
-    src_index(k + zw.out_off, zw.full_in, zw.full_out, z0, z1, f0, f1);
-    z0 -= zw.in_off; z1 -= zw.in_off;
-    z0 = z0 < 0 ? 0 : (z0 > Di - 1 ? Di - 1 : z0);
-    z1 = z1 < 0 ? 0 : (z1 > Di - 1 ? Di - 1 : z1);
-    const float* xi = S.x + ((size_t)b * S.C + c) * Di * Hi * Wi;
-#define XI(zz, yy, xx) xi[((size_t)(zz) * Hi + (yy)) * Wi + (xx)]
-    const float lo = t0 * (sx0 * XI(z0, y0, x0) + sx1 * XI(z0, y0, x1)) + t1 * (sx0 * XI(z0, y1, x0) + sx1 * XI(z0, y1, x1));
+// One thread per output pixel (lanes along x, blockIdx.y = row, blockIdx.z = (sample, plane)): the interpolation indices and weights
+// of a source are computed once and applied to all of its channels (the flat-index version paid an integer division chain and the
+// weights per channel value: 22 us for the 3 M values of the full-resolution concat at 1024^2).
+__device__ __forceinline__ void resize_source(const RSrc& S, float* __restrict__ y, int b, int k, int j, int i, int Do, int Ho, int Wo,
+                                              int Ctot, int c0) {
+  const int Di = S.Di, Hi = S.Hi, Wi = S.Wi;
+  int x0, x1, y0, y1, z0, z1; float sx0, sx1, t0, t1, f0, f1;
+  src_index(i, Wi, Wo, x0, x1, sx0, sx1);
+  src_index(j, Hi, Ho, y0, y1, t0, t1);
+  src_index(k + S.zw.out_off, S.zw.full_in, S.zw.full_out, z0, z1, f0, f1);
+  z0 -= S.zw.in_off; z1 -= S.zw.in_off;
+  z0 = z0 < 0 ? 0 : (z0 > Di - 1 ? Di - 1 : z0);
+  z1 = z1 < 0 ? 0 : (z1 > Di - 1 ? Di - 1 : z1);
+  const bool in_z = S.zw.full_in > 1 || S.zw.full_out > 1;
+  const size_t vin = (size_t)Di * Hi * Wi, vout = (size_t)Do * Ho * Wo;
+  const float* xi = S.x + (size_t)b * S.C * vin;
+  float* yo = y + ((size_t)b * Ctot + c0) * vout + ((size_t)k * Ho + j) * Wo + i;
+  const size_t o00 = ((size_t)z0 * Hi + y0) * Wi, o01 = ((size_t)z0 * Hi + y1) * Wi, o10 = ((size_t)z1 * Hi + y0) * Wi, o11 = ((size_t)z1 * Hi + y1) * Wi;
+  for (int c = 0; c < S.C; ++c, xi += vin, yo += vout) {
+    const float lo = t0 * (sx0 * xi[o00 + x0] + sx1 * xi[o00 + x1]) + t1 * (sx0 * xi[o01 + x0] + sx1 * xi[o01 + x1]);
     float v = lo;
-    if (zw.full_in > 1 || zw.full_out > 1) {
-      const float hi = t0 * (sx0 * XI(z1, y0, x0) + sx1 * XI(z1, y0, x1)) + t1 * (sx0 * XI(z1, y1, x0) + sx1 * XI(z1, y1, x1));
+    if (in_z) {
+      const float hi = t0 * (sx0 * xi[o10 + x0] + sx1 * xi[o10 + x1]) + t1 * (sx0 * xi[o11 + x0] + sx1 * xi[o11 + x1]);
       v = f0 * lo + f1 * hi;
     }
-#undef XI
-    y[(((size_t)b * Ctot + c_off + cc) * Do + k) * Ho * Wo + (size_t)j * Wo + i] = v;
+    *yo = v;
   }
+}
+__global__ __launch_bounds__(256) void resize_kernel(RSrc s0, RSrc s1, float* __restrict__ y, int B, int Do, int Ho, int Wo, int Ctot,
+                                                     int c_off) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const int k = blockIdx.z % Do, b = blockIdx.z / Do;
+  if (i >= Wo || j >= Ho) return;
+  resize_source(s0, y, b, k, j, i, Do, Ho, Wo, Ctot, c_off);
+  if (s1.C > 0) resize_source(s1, y, b, k, j, i, Do, Ho, Wo, Ctot, c_off + s0.C);
 }
 
 void launch_resize(const float* x, float* y, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Ctot,
                    int c_off, hipStream_t s, const ZWin* zw = nullptr) {
-  const size_t n = (size_t)B * C * Do * Ho * Wo;
-  size_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
   const ZWin whole{Di, 0, Do, 0};
-  resize_kernel<<<(int)blocks, 256, 0, s>>>(RSrc{x, C, Di, Hi, Wi, zw ? *zw : whole}, RSrc{nullptr, 0, 1, 1, 1, whole}, y, B, Do, Ho, Wo, Ctot, c_off);
+  const dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, B * Do), block(64, 4);
+  resize_kernel<<<grid, block, 0, s>>>(RSrc{x, C, Di, Hi, Wi, zw ? *zw : whole}, RSrc{nullptr, 0, 1, 1, 1, whole}, y, B, Do, Ho, Wo, Ctot, c_off);
 }
 // two sources -> channels [0, C0 + C1) of y in one launch
 void launch_resize2(const RSrc& s0, const RSrc& s1, float* y, int B, int Do, int Ho, int Wo, hipStream_t s) {
-  const size_t n = (size_t)B * (s0.C + s1.C) * Do * Ho * Wo;
-  size_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  resize_kernel<<<(int)blocks, 256, 0, s>>>(s0, s1, y, B, Do, Ho, Wo, s0.C + s1.C, 0);
+  const dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, B * Do), block(64, 4);
+  resize_kernel<<<grid, block, 0, s>>>(s0, s1, y, B, Do, Ho, Wo, s0.C + s1.C, 0);
 }
 
 struct Sizes { int Dq, Hq, Wq, Dh, Hh, Wh; };
