@@ -107,11 +107,16 @@ WORKLOADS = {
     # product (FNX_PRECISION_BF16X6; same 1e-5 |ref|max tolerance against the oracle as the exact-fp32 modes, tests/)
     "plume2d_1024_cnn_bf16x6": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x6"),
     "plume3d_256_cnn_bf16x6": dict(res=256, D=256, method="convnet", iters=0, kind="plume", precision="bf16x6"),
+    # OPT-IN "accurate bf16" mode (FNX_PRECISION_BF16X3: the three products without a low piece), its own tolerance: 1e-4 |ref|max
+    "plume2d_1024_cnn_bf16x3": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x3"),
+    "plume3d_256_cnn_bf16x3": dict(res=256, D=256, method="convnet", iters=0, kind="plume", precision="bf16x3"),
 }
 ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_128_jacobi", "plume2d_1024_jacobi", "rt2d_2048_jacobi", "plume3d_256_cnn",
-        "plume3d_hbm_jacobi", "plume2d_128_b32_cnn", "plume2d_1024_cnn_bf16x6", "plume3d_256_cnn_bf16x6"]
+        "plume3d_hbm_jacobi", "plume2d_128_b32_cnn", "plume2d_1024_cnn_bf16x6", "plume3d_256_cnn_bf16x6", "plume2d_1024_cnn_bf16x3",
+        "plume3d_256_cnn_bf16x3"]
 # BASELINE.json's configs[0..4] -> the workload that measures each (configs[4]: one z-slab of it per GPU)
 BASELINE_CONFIGS = ["plume2d_128_jacobi", "plume2d_1024_cnn", "rt2d_2048_jacobi", "plume3d_256_cnn", "plume3d_slab_jacobi"]
+BF16_MODES = ("bf16x6", "bf16x3")
 METRIC_CONFIGS = ["plume3d_256_jacobi", "plume2d_1024_cnn"]      # the two configurations BASELINE.json's metric is quoted on
 
 
@@ -324,23 +329,23 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     traffic_src = (traffic_detail or {}).get("source")
     if w["method"] == "convnet":
         tms, nl = times["conv_mfma"]
-        if w.get("precision") == "bf16x6":      # achieved/frac: all the 3x3(x3) MFMA layers, whichever kernel ran them
+        if w.get("precision") in BF16_MODES:      # achieved/frac: all the 3x3(x3) MFMA layers, whichever kernel ran them
             tms, nl = tms + times["conv_bf16"][0], nl + times["conv_bf16"][1]
         flops = mfma_flops_per_cell(is3d) * cells * prof_steps
         ach = flops / (tms * 1e-3) / 1e12 if tms > 0 else 0.0
         util = issued["conv_mfma"] / (tms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if tms > 0 else 0.0
-        if w.get("precision") == "bf16x6":
+        if w.get("precision") in BF16_MODES:
             util = None                          # (two instruction kinds in one figure would mean nothing: see roofline.bf16x6)
         kname = ("conv3_wino3_kernel<2,2," + ("true" if is3d else "false") + "> (+ <1,2,.> for the 32-channel outputs; persistent software pipeline; 3x3" + ("x3" if is3d else "") + " conv in the Winograd F(2x2,3x3) domain" +
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
         avg_ms = tms / max(nl, 1)
-        if w.get("precision") == "bf16x6":
+        if w.get("precision") in BF16_MODES:
             # the opt-in mode: its own kernel, priced against the bf16 MFMA peak on the bf16 FLOPs it issues (six per fp32 product)
             tb, nb = times["conv_bf16"]
             ub = issued["conv_bf16"] / (tb * 1e-3) / 1e12 if tb > 0 else 0.0
-            roof_bf16 = dict(kernel="conv3_wbf_kernel<" + ("true" if is3d else "false") + "> (FNX_PRECISION_BF16X6: Winograd-domain GEMMs as six "
+            roof_bf16 = dict(kernel="conv3_wbf_kernel<" + ("true" if is3d else "false") + (",6" if w["precision"] == "bf16x6" else ",3") + "> (FNX_PRECISION_" + w["precision"].upper() + ": Winograd-domain GEMMs as six / three "
                              "v_mfma_f32_32x32x16_bf16 per fp32 product; the 32-output-channel layers stay on conv3_wino3_kernel)",
                              achieved=ub, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s (bf16 issued)", frac=ub / MFMA_BF16_PEAK_TF,
                              launches_per_step=nb / prof_steps, ms_per_step=tb / prof_steps)
@@ -390,7 +395,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     return dict(advect=advect, metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=mcells,
                 unit="Mcells/s", steps_per_s=steps / elapsed, n_gpus=world, steps=steps, warmup=warmup, ms_per_step=ms,
                 higher_is_better=True, scaling="weak", vs_baseline=None,
-                dtype="f32 (bf16x6 products: opt-in mode)" if w.get("precision") == "bf16x6" else "f32", data="synthetic",
+                dtype=f"f32 ({w['precision']} products: opt-in mode)" if w.get("precision") in BF16_MODES else "f32", data="synthetic",
                 config=dict(workload=name, grid_per_gpu=[layout.owned if slab else w["D"], w["res"], w["res"]],
                             global_grid=[layout.D_global if slab else w["D"], w["res"], w["res"]], batch=w.get("batch", 1),
                             cells_per_gpu=cells, method=w["method"], jacobi_iters=w["iters"], precision=w.get("precision", "fp32"),
@@ -533,7 +538,7 @@ def _short(res):
     rf = res.get("roofline", {})
     if rf.get("bound") == "mfma":
         if rf.get("bf16x6"):
-            frac, what = rf["bf16x6"]["frac"], "bf16 MFMA util (opt-in bf16x6)"
+            frac, what = rf["bf16x6"]["frac"], "bf16 MFMA util (opt-in mode)"
         else:
             frac, what = rf.get("mfma_util"), "fp32 MFMA util"
     else:
@@ -709,7 +714,7 @@ def main():
         # the other configurations the metric / north star name (single-GPU by definition), measured in the same run
         out["also"] = {}
         for other in ALSO:
-            big = other in ("plume3d_256_cnn", "plume3d_hbm_jacobi", "plume3d_256_cnn_bf16x6")
+            big = other in ("plume3d_256_cnn", "plume3d_hbm_jacobi", "plume3d_256_cnn_bf16x6", "plume3d_256_cnn_bf16x3")
             try:
                 r = run_workload(other, min(a.steps, 5 if big else 20), min(a.warmup, 2 if big else 5), not a.no_graph, 1, 0, dev)
                 out["also"][other] = {k: r[k] for k in ("value", "unit", "steps_per_s", "samples_per_s", "ms_per_step", "step_hbm_frac", "steps",

@@ -1129,12 +1129,13 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
   // (the MFMA kernels address a stage of 8 channel volumes through one 32-bit buffer range: 2^27 cells per sample at
   // most; beyond that -- 137 GB per 128-channel activation -- the direct kernel below still works)
   const bool direct = mode == FNX_PRECISION_FP32_DIRECT;
-  if (mode == FNX_PRECISION_BF16X6 && wbf_layer(L, is3d)) {
+  if ((mode == FNX_PRECISION_BF16X6 || mode == FNX_PRECISION_BF16X3) && wbf_layer(L, is3d)) {
     ProfScope ps(FNX_PROF_CONV_BF16, s);
     const size_t nwino = (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
-    if (launch_conv_wbf(a, is3d, (const unsigned*)(packed + pl.w_off + layer_weight_floats(L, is3d) + 2 * nwino), s)) {
-      // six bf16 MFMA products per Winograd-domain multiply (16 per 2x2 outputs and z tap)
-      prof_add_work(FNX_PROF_CONV_BF16, (double)B * D * H * W * 2.0 * L.cin * L.cout * 4.0 * (is3d ? 3 : 1) * 6.0);
+    const int nprod = mode == FNX_PRECISION_BF16X3 ? 3 : 6;
+    if (launch_conv_wbf(a, is3d, (const unsigned*)(packed + pl.w_off + layer_weight_floats(L, is3d) + 2 * nwino), s, nprod)) {
+      // six (three) bf16 MFMA products per Winograd-domain multiply (16 per 2x2 outputs and z tap)
+      prof_add_work(FNX_PROF_CONV_BF16, (double)B * D * H * W * 2.0 * L.cin * L.cout * 4.0 * (is3d ? 3 : 1) * (double)nprod);
       return;
     }
   }
@@ -1656,12 +1657,12 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
 }
 
-static bool bad_precision(int m) { return m < FNX_PRECISION_FP32 || m > FNX_PRECISION_BF16X6; }
+static bool bad_precision(int m) { return m < FNX_PRECISION_FP32 || m > FNX_PRECISION_BF16X3; }
 
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                            size_t ws_bytes, void* stream) {
   if (!g || !packed || !x || !p || !ws) return FNX_EINVAL;
-  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6)", precision_mode);
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, _FP32_DIRECT, _BF16X6 or _BF16X3)", precision_mode);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   fnx::multiscale_forward(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream);
@@ -1671,7 +1672,7 @@ int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x,
 int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                                 const int trim[4], void* ws, size_t ws_bytes, void* stream) {
   if (!g || !packed || !x || !p || !ws || !trim) return FNX_EINVAL;
-  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6)", precision_mode);
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, _FP32_DIRECT, _BF16X6 or _BF16X3)", precision_mode);
   if (!g->is3D && (trim[0] | trim[1] | trim[2] | trim[3])) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: z windows need a 3D grid");
   for (int a = 0; a < 4; ++a)
     if (trim[a] < 0 || trim[a] % 4) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: trim[%d] = %d must be a non-negative multiple of 4", a, trim[a]);
@@ -1687,7 +1688,7 @@ int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const floa
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float thr, float* p_out,
                          float* U_out, int precision_mode, void* ws, size_t ws_bytes, void* stream) {
   if (!g || !packed || !input || !p_out || !U_out || !ws) return FNX_EINVAL;
-  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6)", precision_mode);
+  if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, _FP32_DIRECT, _BF16X6 or _BF16X3)", precision_mode);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
   if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;

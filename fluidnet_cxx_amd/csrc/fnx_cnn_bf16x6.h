@@ -105,8 +105,15 @@ __device__ __forceinline__ f32x2 wb_lds_read64(unsigned addr) {
   return v;
 }
 
-template <bool IS3D>
+// NP = 6: FNX_PRECISION_BF16X6 (all six products).  NP = 3: FNX_PRECISION_BF16X3 -- only ah*bh + ah*bm + am*bh (the three products
+// that do not involve a low piece): the dropped terms are below 2^-15 of |a*b|, an "accurate bf16" mode with its own tolerance
+// (1e-4 |ref|max in the tests; measured error in profiles/r05).  The phase keeps its 24 slots and its filler schedule -- the slots of
+// the three small products issue nothing --, the low pieces are neither stored by the transform nor read (LDS traffic per phase 208 ->
+// 160 KiB) nor loaded as A operands.
+template <bool IS3D, int NP>
 __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u32x4* __restrict__ wq, int ntx, int nty) {
+  static_assert(NP == 6 || NP == 3, "six products, or the three without a low piece");
+  constexpr int NPIECE = NP == 6 ? 3 : 2;
   // (separate __shared__ objects: the compiler cannot tell an LDS-DMA into one copy from the ds_reads of the other when they
   // are one array, and then parks a vmcnt(0) in front of every read)
   __shared__ __attribute__((aligned(16))) float raw0[WB_RAW];
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
   auto load_a = [&](u32x4 (&Aj)[3], int q, int jj) __attribute__((always_inline)) {
     const u32x4* p = wa + (size_t)(q >> 1) * wstage + ((q & 1) * 6 + jj * 3) * 64;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) Aj[i] = p[i * 64];
+    for (int i = 0; i < NPIECE; ++i) Aj[i] = p[i * 64];
   };
   auto load_a1 = [&](u32x4& dst, int q, int jj, int i) __attribute__((always_inline)) {      // one piece
     dst = wa[(size_t)(q >> 1) * wstage + ((q & 1) * 6 + jj * 3 + i) * 64];
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
     wb_split(v[0][k >> 1][k & 1], p0[0], p0[1], p0[2]);
     wb_split(v[1][k >> 1][k & 1], p1[0], p1[1], p1[2]);
 #pragma unroll
-    for (int sp = 0; sp < 3; ++sp) o[(sp * 2 * 64) * 4] = wb_pack(p0[sp], p1[sp]);
+    for (int sp = 0; sp < NPIECE; ++sp) o[(sp * 2 * 64) * 4] = wb_pack(p0[sp], p1[sp]);
   };
 
   // ---- MFMA stream.  acc[position column j][block tile]; B operand sets X and Y alternate between the groups of six MFMAs
@@ -254,6 +261,7 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
   // product i of a group: (al,bh) (ah,bl) (am,bm) (am,bh) (ah,bm) (ah,bh) -- the small terms first
   auto mfma1 = [&](f32x16& c, const u32x4 (&Aj)[3], const u32x4 (&B)[3], int i) __attribute__((always_inline)) {
     const int ia = i == 0 ? 2 : (i == 2 || i == 3 ? 1 : 0), ib = i == 1 ? 2 : (i == 2 || i == 4 ? 1 : 0);
+    if (NP == 3 && i < 3) return;                            // (al,bh) (ah,bl) (am,bm): not in the three-product mode
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aj[ia]), __builtin_bit_cast(bf16x8, B[ib]), c, 0, 0, 0);
   };
 
@@ -292,15 +300,16 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
       // waves then wait at the issue of whatever comes next)
       if (!(WB_ABL & 8)) {
         // piece order of a group's MFMAs: B pieces h, l, m, h, m, h are first needed by products 0, 1, 2 -> read h, l, m
-        if (slot >= 1 && slot <= 3) read_b1(BY[slot == 1 ? 0 : (slot == 2 ? 2 : 1)], vcur, 0, 0, slot == 1 ? 0 : (slot == 2 ? 2 : 1));
-        if (slot >= 7 && slot <= 9) read_b1(BX[slot == 7 ? 0 : (slot == 8 ? 2 : 1)], vcur, 0, 1, slot == 7 ? 0 : (slot == 8 ? 2 : 1));
-        if (slot >= 13 && slot <= 15) read_b1(BY[slot == 13 ? 0 : (slot == 14 ? 2 : 1)], vcur, 1, 0, slot == 13 ? 0 : (slot == 14 ? 2 : 1));
-        if (slot >= 19 && slot <= 21) read_b1(BX[slot == 19 ? 0 : (slot == 20 ? 2 : 1)], vcur, 1, 1, slot == 19 ? 0 : (slot == 20 ? 2 : 1));
+        // (NP == 3: the low piece, slots 2 / 8 / 14 / 20, is not read)
+        if (slot >= 1 && slot <= 3 && (NP == 6 || slot != 2)) read_b1(BY[slot == 1 ? 0 : (slot == 2 ? 2 : 1)], vcur, 0, 0, slot == 1 ? 0 : (slot == 2 ? 2 : 1));
+        if (slot >= 7 && slot <= 9 && (NP == 6 || slot != 8)) read_b1(BX[slot == 7 ? 0 : (slot == 8 ? 2 : 1)], vcur, 0, 1, slot == 7 ? 0 : (slot == 8 ? 2 : 1));
+        if (slot >= 13 && slot <= 15 && (NP == 6 || slot != 14)) read_b1(BY[slot == 13 ? 0 : (slot == 14 ? 2 : 1)], vcur, 1, 0, slot == 13 ? 0 : (slot == 14 ? 2 : 1));
+        if (slot >= 19 && slot <= 21 && (NP == 6 || slot != 20)) read_b1(BX[slot == 19 ? 0 : (slot == 20 ? 2 : 1)], vcur, 1, 1, slot == 19 ? 0 : (slot == 20 ? 2 : 1));
       }
       if (NEXT) {
         if (!(WB_ABL & 16)) {
-          if (slot == 0 || slot == 4 || slot == 5) load_a1(A[1 - HS][0][slot == 0 ? 0 : slot - 3], q + 1, 0, slot == 0 ? 0 : slot - 3);
-          if (slot == 10 || slot == 12 || slot == 16) load_a1(A[1 - HS][1][slot == 10 ? 0 : (slot == 12 ? 1 : 2)], q + 1, 1, slot == 10 ? 0 : (slot == 12 ? 1 : 2));
+          if (slot == 0 || slot == 4 || (slot == 5 && NP == 6)) load_a1(A[1 - HS][0][slot == 0 ? 0 : slot - 3], q + 1, 0, slot == 0 ? 0 : slot - 3);
+          if (slot == 10 || slot == 12 || (slot == 16 && NP == 6)) load_a1(A[1 - HS][1][slot == 10 ? 0 : (slot == 12 ? 1 : 2)], q + 1, 1, slot == 10 ? 0 : (slot == 12 ? 1 : 2));
         }
         if (!(WB_ABL & 2)) {
           if (slot == 0) xf_load(H0{}, rawnext);
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
   fetch(raw1);
   load_a(A[0][0], 0, 0);
   load_a(A[0][1], 0, 1);
-  WB_WAIT_LDS_VM(6 + 12);                                       // stage 0's DMA has landed (stage 1's and A may still be in flight)
+  WB_WAIT_LDS_VM(2 * NPIECE + 12);                              // stage 0's DMA has landed (stage 1's and A may still be in flight)
   __builtin_amdgcn_s_barrier();
   xf_load(H0{}, raw0); xf_combo(H0{}, 0);
   xf_load(H1{}, raw0); xf_combo(H0{}, 1);
@@ -334,11 +343,11 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
   // ---- main loop: two phases per stage.  Even phase (columns 0, 1 of stage s): the transform reads stage s again (columns 2, 3);
   // odd phase: the transform reads stage s+1, and the DMA of stage s+2 goes into the copy stage s has left.  Barriers: LDS writes
   // and reads of the phase are through (lgkmcnt 0); at the END OF AN EVEN phase the DMA issued in the odd phase before it must
-  // have landed -- the only younger VMEM instructions are that even phase's six A loads (vmcnt 6).
+  // have landed -- the only younger VMEM instructions are that even phase's A loads (six, or four without the low pieces).
   auto run = [&](auto late_) __attribute__((always_inline)) {
     // s = 0, even phase: nothing to rotate in
     phase(H0{}, F_{}, T_{}, late_, 0, vbuf0, vbuf1, raw0, raw1);
-    WB_WAIT_LDS_VM(6);
+    WB_WAIT_LDS_VM(2 * NPIECE);
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s + 1 < nstage; ++s) {
       float* rs = (s & 1) ? raw1 : raw0;                         // stage s (free for stage s+2 in the odd phase)
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
       WB_WAIT_LDS_VM(63);
       __builtin_amdgcn_s_barrier();
       phase(H0{}, T_{}, T_{}, late_, 2 * s + 2, vbuf0, vbuf1, rn, rs);
-      WB_WAIT_LDS_VM(6);
+      WB_WAIT_LDS_VM(2 * NPIECE);
       __builtin_amdgcn_s_barrier();
     }
     // the last odd phase: no half-stage behind it
@@ -432,14 +441,17 @@ __global__ __launch_bounds__(WB_NT, 2) void conv3_wbf_kernel(ConvArgs a, const u
 
 // false: nothing launched (shape the kernel does not take, or a launch too small to fill the chip): the caller falls back to
 // the exact-fp32 Winograd / direct kernels
-bool launch_conv_wbf(const ConvArgs& a, bool is3d, const unsigned* wq, hipStream_t s) {
+bool launch_conv_wbf(const ConvArgs& a, bool is3d, const unsigned* wq, hipStream_t s, int nprod = 6) {
   if (a.cin % WB_C != 0 || a.cin < 2 * WB_C || a.cout % 64 != 0) return false;
   if (a.D != 1 && !is3d) return false;
   if ((size_t)WB_C * a.D * a.H * a.W * 4 >= 0xf0000000ull) return false;        // a stage's 16 channel volumes: one 32-bit buffer range
   const int ntx = (a.W + 31) / 32, nty = (a.H + 7) / 8;
   const long nt = (long)ntx * nty * a.B * a.D * (a.cout / 64);
   if (nt < 512 || nt > 0x7fffffffl) return false;
-  if (is3d) conv3_wbf_kernel<true><<<(unsigned)nt, WB_NT, 0, s>>>(a, (const u32x4*)wq, ntx, nty);
-  else conv3_wbf_kernel<false><<<(unsigned)nt, WB_NT, 0, s>>>(a, (const u32x4*)wq, ntx, nty);
+  if (nprod == 3) {
+    if (is3d) conv3_wbf_kernel<true, 3><<<(unsigned)nt, WB_NT, 0, s>>>(a, (const u32x4*)wq, ntx, nty);
+    else conv3_wbf_kernel<false, 3><<<(unsigned)nt, WB_NT, 0, s>>>(a, (const u32x4*)wq, ntx, nty);
+  } else if (is3d) conv3_wbf_kernel<true, 6><<<(unsigned)nt, WB_NT, 0, s>>>(a, (const u32x4*)wq, ntx, nty);
+  else conv3_wbf_kernel<false, 6><<<(unsigned)nt, WB_NT, 0, s>>>(a, (const u32x4*)wq, ntx, nty);
   return true;
 }

@@ -730,7 +730,7 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
   if (prm->method != 0 && prm->method != 1) return fnx::set_error(FNX_EINVAL, "slab_step: unknown method %d", prm->method);
   if (prm->method == 1 && (s->cfg.method != 1 || !st->net))
     return fnx::set_error(FNX_EINVAL, "slab_step: the CNN projection needs a driver created with cfg.method = 1 and st->net (the packed weights)");
-  if (prm->method == 1 && (prm->precision_mode < FNX_PRECISION_FP32 || prm->precision_mode > FNX_PRECISION_BF16X6))
+  if (prm->method == 1 && (prm->precision_mode < FNX_PRECISION_FP32 || prm->precision_mode > FNX_PRECISION_BF16X3))
     return fnx::set_error(FNX_EINVAL, "slab_step: unknown precision_mode %d", prm->precision_mode);
   if (prm->method == 0 && prm->jacobi_iter < 1) return fnx::set_error(FNX_EINVAL, "At least 1 iteration of the solver is needed.");
   if (prm->viscosity != 0.f || prm->gravity_scale != 0.f || prm->correct_scalar || prm->periodic)

@@ -47,6 +47,7 @@ class MultiScaleNet:
         # "fp32": exact-fp32 MFMA arithmetic, 3x3 layers in the Winograd domain where the launch fills the chip;
         # "fp32_direct": every convolution a direct sum over its taps (include/fluidnet_hip.h: FNX_PRECISION_*)
         # "bf16x6" (opt-in): the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32 product
+        # "bf16x3" (opt-in): the same layers with the three products without a low piece (tolerance 1e-4 |ref|max)
         self.precision_mode = precision_mode
         blob = torch.from_numpy(blob_from_state_dict(state_dict, 3 if is3D else 2)).to(device)
         self.packed = ext.scalenet_pack(blob, self.is3D)
@@ -77,7 +78,7 @@ class FluidNet:
         self.inDims = mconf.get("inputDim", 2)
         self.is3D = bool(mconf.get("is3D", False))
         self.threshold = float(mconf.get("normalizeInputThreshold", 1e-5))
-        # not a reference key: "fp32" (default), "fp32_direct" (no Winograd) or "bf16x6" (opt-in), see MultiScaleNet
+        # not a reference key: "fp32" (default), "fp32_direct" (no Winograd), "bf16x6" or "bf16x3" (opt-in), see MultiScaleNet
         self.precision_mode = str(mconf.get("precisionMode", "fp32"))
         self.training = False
         self._ndim = 3 if self.is3D else 2

@@ -224,7 +224,7 @@ typedef struct FnxStepParams {
   int   jacobi_iter;          /* mconf['jacobiIter'] */
   int   method;               /* 0 = 'jacobi', 1 = 'convnet' */
   float normalize_threshold;  /* mconf['normalizeInputThreshold'] (convnet) */
-  int   precision_mode;       /* convnet: FNX_PRECISION_FP32 (0, the default), FNX_PRECISION_FP32_DIRECT or FNX_PRECISION_BF16X6, see fnx_multiscale_forward */
+  int   precision_mode;       /* convnet: FNX_PRECISION_FP32 (0, the default), _FP32_DIRECT, _BF16X6 or _BF16X3, see fnx_multiscale_forward */
   int   static_flags;         /* promises about the previous fnx_simulate_step on this workspace (no reference key; every
                                  reference simulation keeps its flags and BC arrays fixed):
                                  bit 0: `flags` is unchanged -> the 3D Jacobi solver reuses the obstacle mask it left there;
@@ -453,7 +453,7 @@ size_t fnx_scalenet_weight_floats(int is3D);
 size_t fnx_scalenet_packed_bytes(int is3D);
 int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* stream);
 /* precision_mode of the CNN entry points (and FnxStepParams.precision_mode).  The first two are exact-fp32 arithmetic on
- * v_mfma_f32_*_f32; the third is opt-in and carries its own label in every report (bench.py never puts it in the headline):
+ * v_mfma_f32_*_f32; the last two are opt-in and carry their own labels in every report (bench.py never puts them in the headline):
  *   FNX_PRECISION_FP32         the default: 3x3(x3) layers of launches that fill the chip run in the Winograd F(2x2,3x3) domain
  *                              (2.25x fewer multiplies, not the summation order of a direct convolution; within 1e-5 |ref|max of
  *                              the torch reference, tests/test_parity_gpu.py)
@@ -463,8 +463,13 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
  *                              bits), a product evaluated as six bf16 x bf16 MFMAs with fp32 accumulation (the three dropped
  *                              cross terms are below 2^-23 of the product: the size of one fp32 rounding).  Same tolerance as the
  *                              other modes in the tests (1e-5 |ref|max against oracle and goldens); every other layer as in
- *                              FNX_PRECISION_FP32 */
-enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2 };
+ *                              FNX_PRECISION_FP32
+ *   FNX_PRECISION_BF16X3       FNX_PRECISION_BF16X6 with only the three products that involve no low piece (ah*bh + ah*bm + am*bh): half
+ *                              the bf16 MFMAs and two thirds of the operand traffic; what is dropped is below 2^-15 of a product.  Its own
+ *                              label and its own tolerance: 1e-4 |ref|max against oracle and goldens in the tests (measured ~1e-5:
+ *                              profiles/r05).  SURVEY.md section 7's "accurate bf16" mode; the reference's own convolutions run on
+ *                              torch.nn.Conv2d, whose CUDA default admits TF32 (lib/multi_scale_net.py:21-127) */
+enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2, FNX_PRECISION_BF16X3 = 3 };
 /* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                            void* ws, size_t ws_bytes, void* stream);

@@ -286,7 +286,7 @@ def test_convnet_step_vs_oracle(oracle, shape):
         assert_bitexact(got[:, :, :, 0:4], ref["U"][:, :, :, 0:4], f"U on the inflow rows, step {it + 1}")
 
 
-@pytest.mark.parametrize("name", ["plume2d_1024_cnn", "plume3d_256_cnn", "plume2d_1024_cnn_bf16x6"])
+@pytest.mark.parametrize("name", ["plume2d_1024_cnn", "plume3d_256_cnn", "plume2d_1024_cnn_bf16x6", "plume3d_256_cnn_bf16x6", "plume2d_1024_cnn_bf16x3"])
 def test_benchmark_size_convnet_step_vs_oracle(oracle, name):
     """The convnet step bench.py times at 1024^2 (the metric's configs[1]) and 256^3 (configs[3]), from a developed plume, with
     its launch plan (workspace, static_flags, Winograd MFMA layers): every stage AROUND the net bit for bit against the oracle.

@@ -532,6 +532,37 @@ def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 16, 126, 130), (1, 6, 72, 300)])
+def test_cnn_bf16x3_vs_oracle(dev, oracle, shape):
+    """precisionMode 'bf16x3' (FNX_PRECISION_BF16X3: the same layers with the three bf16 products that involve no low piece, ah*bh +
+    ah*bm + am*bh): an "accurate bf16" mode under its OWN label and tolerance -- 1e-4 of |ref|max against the oracle (the exact modes
+    and bf16x6: 1e-5) -- on the shapes of the bf16x6 test; another kernel instantiation than bf16x6's (different bits), and its error
+    stays well inside its tolerance (it measures 1.6e-5 .. 3e-5 of |ref|max: 16 significand bits per product, random signs)."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    B, D, H, W = shape
+    is3d = D > 1
+    nd = 3 if is3d else 2
+    w = make_scalenet_weights(0, ndim=nd)
+    s = random_state(B, D, H, W, 0.5, seed=12)
+    inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
+    po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, nd), inp)
+    outs = {}
+    for mode in ("bf16x3", "bf16x6"):
+        mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                     normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d, precisionMode=mode)
+        net = FluidNet.from_weights(mconf, w, dev)
+        p, U = net(T(inp, dev))
+        outs[mode] = N(p)
+        tol = 1e-4 if mode == "bf16x3" else 1e-5
+        assert_close_rel(N(p), po, tol, f"FluidNet p ({mode})"); assert_close_rel(N(U), Uo, tol, f"FluidNet U ({mode})")
+    assert not np.array_equal(outs["bf16x3"], outs["bf16x6"]), "precisionMode='bf16x3' did not select another kernel"
+    e3 = np.abs(outs["bf16x3"].astype(np.float64) - po).max()
+    assert e3 <= 5e-5 * np.abs(po).max(), f"bf16x3 error {e3:.3e} = {e3 / np.abs(po).max():.2e} of |ref|max: more than the mode should cost"
+    with pytest.raises(RuntimeError, match="precision_mode"):
+        FluidNet.from_weights(dict(mconf, precisionMode="bf16x2"), w, dev)(T(inp, dev))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 16, 126, 130), (1, 6, 72, 300)])
 def test_cnn_bf16x6_vs_oracle(dev, oracle, shape):
     """precisionMode 'bf16x6' (FNX_PRECISION_BF16X6: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
     product, conv3_wbf_kernel) at the SAME tolerance as the exact-fp32 modes -- 1e-5 of |ref|max against the oracle -- on grids
@@ -695,7 +726,11 @@ def test_cnn_benchmark_size(dev, oracle, tmp_path, shape):
     torch.cuda.empty_cache()
     assert not np.array_equal(got, b6), "precision_mode='bf16x6' did not select another kernel"
     assert_close_rel(b6, direct, 1e-5, f"bf16x6 Winograd vs direct MFMA conv at {shape}")
-    del b6
+    # (4) the opt-in bf16x3 mode (the three products without a low piece): its own, looser tolerance
+    b3 = forward(x, precision_mode="bf16x3")
+    torch.cuda.empty_cache()
+    assert not np.array_equal(b3, b6), "precision_mode='bf16x3' did not select another kernel"
+    assert_close_rel(b3, direct, 1e-4, f"bf16x3 Winograd vs direct MFMA conv at {shape}")
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     blob = oracle.pack_weights(make_scalenet_weights(0, ndim=3 if is3d else 2), 3 if is3d else 2)
     M = 48                                                           # margin kept from a crop's artificial edges
@@ -714,11 +749,13 @@ def test_cnn_benchmark_size(dev, oracle, tmp_path, shape):
             hi = a1 if a1 == n else a1 - M
             return lo, hi
         (vz0, vz1), (vy0, vy1), (vx0, vx1) = (valid(z0, z1, D) if is3d else (0, 1)), valid(y0, y1, H), valid(x0, x1, W)
-        a = got[:, :, vz0:vz1, vy0:vy1, vx0:vx1]
         b = po[:, :, vz0 - z0:vz1 - z0, vy0 - y0:vy1 - y0, vx0 - x0:vx1 - x0]
-        assert a.size > 0
-        d = float(np.abs(a.astype(np.float64) - b).max())
-        assert d <= 1e-5 * scale, f"crop z{z0}:{z1} y{y0}:{y1} x{x0}:{x1}: max |d| = {d:.3e} > 1e-5 * {scale:.3e}"
+        # every precision mode DIRECTLY against the oracle (not through another HIP kernel): fp32 and bf16x6 at 1e-5, bf16x3 at 1e-4
+        for what, field, tol in (("fp32", got, 1e-5), ("bf16x6", b6, 1e-5), ("bf16x3", b3, 1e-4)):
+            a = field[:, :, vz0:vz1, vy0:vy1, vx0:vx1]
+            assert a.size > 0
+            d = float(np.abs(a.astype(np.float64) - b).max())
+            assert d <= tol * scale, f"{what}, crop z{z0}:{z1} y{y0}:{y1} x{x0}:{x1}: max |d| = {d:.3e} > {tol:.0e} * {scale:.3e}"
 
 
 def test_sim64_convnet_vs_reference(dev, golden):

@@ -16,7 +16,7 @@ for case in (sys.argv[1:] or ["2d", "3d"]):
     x = np.random.default_rng(3).standard_normal(shape).astype(np.float32)
     ref = O.multiscale_forward(O.pack_weights(w, nd), x)
     outs = {}
-    for mode in ("fp32", "fp32_direct", "bf16x6"):
+    for mode in ("fp32", "fp32_direct", "bf16x6", "bf16x3"):
         mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
                      normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d, precisionMode=mode)
         net = FluidNet.from_weights(mconf, w, dev)
