@@ -40,7 +40,7 @@ C++ driver is (`config.driver` says so; if its leg fails the Python driver's num
 (`python_driver` / `native_driver`), together with `comm`: bytes posted per neighbour and step, the time the compute stream
 waited for exchanges, and a send/recv probe of the neighbour links.
 
-Prints ONE JSON line (rank 0) of < 4 kB: the contract fields; `configs` -- one row [ms, Mcells/s, utilisation, which] per
+Prints ONE JSON line (rank 0) of < 4 kB: the contract fields; `configs` -- one row (ms, Mcells/s, util, of: which utilisation, legend `util_of`) per
 BASELINE.json configuration, configs[0] (the reference's own 128^2 CPU case) to configs[4]; `metric_configs` -- the metric's 256^3
 Jacobi and 1024^2 CNN with their own roofline blocks; `other` -- the remaining workloads; the headline's `config`, `roofline`,
 `kernel_ms_per_step`, `advect`; `cpu_baseline` (+ `cpu_baseline_cnn`).  Everything else (per-configuration config / roofline /
@@ -117,6 +117,7 @@ ALSO = ["plume3d_256_jacobi", "plume2d_1024_cnn", "plume2d_128_jacobi", "plume2d
 # BASELINE.json's configs[0..4] -> the workload that measures each (configs[4]: one z-slab of it per GPU)
 BASELINE_CONFIGS = ["plume2d_128_jacobi", "plume2d_1024_cnn", "rt2d_2048_jacobi", "plume3d_256_cnn", "plume3d_slab_jacobi"]
 BF16_MODES = ("bf16x6", "bf16x3")
+JOB_DOG = []                 # the N > 1 job's watchdog timer (main)
 METRIC_CONFIGS = ["plume3d_256_jacobi", "plume2d_1024_cnn"]      # the two configurations BASELINE.json's metric is quoted on
 
 
@@ -452,8 +453,9 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
                          probe="max over ranks of the mean of 20 ghost exchanges with each z-neighbour, back to back (" +
                                ("peer-store launches" if transport == "peer" else "grouped ncclSend/ncclRecv") + ")")
         del scratch
-    for _ in range(max(warmup, 3)):
+    for _ in range(max(warmup, 3) + (DEVELOP_STEPS if getattr(run_workload, "fresh_state", False) else 0)):
         sim.step(bd)
+    run_workload.fresh_state = False
     step, launch = (lambda: sim.step(bd)), "eager (C++ driver)"
     if world == 1:
         # one rank: the step is a fixed launch sequence on fixed buffers -- capture it once, replay it per step
@@ -538,14 +540,14 @@ def _short(res):
     rf = res.get("roofline", {})
     if rf.get("bound") == "mfma":
         if rf.get("bf16x6"):
-            frac, what = rf["bf16x6"]["frac"], "bf16 MFMA util (opt-in mode)"
+            frac, what = rf["bf16x6"]["frac"], "B"
         else:
-            frac, what = rf.get("mfma_util"), "fp32 MFMA util"
+            frac, what = rf.get("mfma_util"), "M"
     else:
-        frac, what = rf.get("frac_traffic"), "PMC bytes/HBM peak"
+        frac, what = rf.get("frac_traffic"), "P"
         if frac is None:
-            frac, what = rf.get("frac_compulsory"), "compulsory bytes/HBM peak"
-    e = dict(ms=_r(res["ms_per_step"], 5), Mcells_s=_r(res["value"], 5), frac=_r(frac, 3), of=what)
+            frac, what = rf.get("frac_compulsory"), "C"
+    e = dict(ms=_r(res["ms_per_step"], 5), Mcells_s=_r(res["value"], 5), util=_r(frac, 3), of=what)
     if res.get("samples_per_s"):
         e["samples_s"] = _r(res["samples_per_s"], 5)
     return e
@@ -556,7 +558,7 @@ def pmc_source(summary_file=None):
     commit that last changed the table"""
     src = "profiles/pmc_traffic.json"
     if summary_file:
-        return f"recorded rocprofv3 PMC passes, {summary_file} (via {src})"
+        return f"recorded PMC passes: {summary_file}"
     try:
         c = subprocess.run(["git", "log", "-1", "--format=%h", "--", src], cwd=REPO, capture_output=True, text=True, timeout=5).stdout.strip()
         return f"recorded rocprofv3 PMC passes, {src}" + (f" @ {c}" if c else "")
@@ -594,6 +596,8 @@ def compact(out):
     cfgs = {f"configs[{i}]": dict(workload=k, **rows[k]) for i, k in enumerate(BASELINE_CONFIGS) if k in rows}
     if cfgs:
         line["configs"] = cfgs
+        line["util_of"] = dict(P="PMC bytes / time / HBM peak", C="compulsory bytes / time / HBM peak", M="issued FLOPs / time / fp32 MFMA peak",
+                               B="issued bf16 FLOPs / time / bf16 MFMA peak (opt-in precision mode)")
     c = out["config"]
     line["config"] = {k: c.get(k) for k in ("workload", "grid_per_gpu", "global_grid", "method", "jacobi_iters", "parallelism",
                                             "launch", "driver", "developed_steps", "world_size", "backend") if c.get(k) is not None}
@@ -613,7 +617,7 @@ def compact(out):
     if other:
         line["other"] = other
     line["kernel_ms_per_step"] = dict({k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()},
-                                      note="HIP-event pairs around every launch of the class (~2 us per launch above the kernels' own time)")
+                                      note="HIP-event pairs per launch: ~2 us per launch above the kernels' own time")
     if out.get("advect"):
         ad = out["advect"]
         line["advect"] = dict(ms=_r(ad["ms_per_step"]), frac_of_120B_model=_r(ad["frac_of_model"], 3), valu_issue_frac=_r(ad.get("valu_issue_frac"), 3))
@@ -625,8 +629,8 @@ def compact(out):
             line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items() if kk != "middle_rank_model"}
     mm = out.get("native_driver", {}).get("middle_rank_model")
     if mm:                                   # (short form: the sentence that says what it is stays in the side file)
-        line["middle_rank_model"] = {kk.replace("modelled_efficiency", "eff"): _r(vv, 3) for kk, vv in mm.items() if kk != "what"}
-        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model communicator (9 us: peer-store, 20-25 us: RCCL): a MODEL of N>=3"
+        line["middle_rank_model"] = {kk.replace("modelled_efficiency", "eff"): _r(vv, 3) for kk, vv in mm.items() if kk != "what" and not kk.startswith("ms_at_")}
+        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model comm (9 us: peer-store, 20-25 us: RCCL): a MODEL of N>=3"
     line["detail_file"] = "gpurun_out/bench_detail.json"
     return line, out
 
@@ -707,7 +711,43 @@ def main():
     name = a.workload or "plume3d_slab_jacobi"
     if world > 1 and not WORKLOADS[name].get("slab"):
         sys.exit(f"bench: workload {name} does not shard (single-GPU configuration); N > 1 runs plume3d_slab_jacobi")
-    out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev, a.schedule)
+    if world > 1:
+        # A job of more than one rank has never run before the driver's multi-GPU run: whatever happens, rank 0 prints a line.
+        # (a leg that hangs -- a collective nobody joins -- is ended by this timer; legs that raise are caught one by one below)
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps(dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=None,
+                                      unit="Mcells/s", n_gpus=a.gpus, steps=a.steps, warmup=a.warmup, higher_is_better=True, scaling="weak",
+                                      vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=name),
+                                      error="no leg of the N > 1 job finished within 780 s"), separators=(",", ":")), flush=True)
+            os._exit(0)
+        job_dog = threading.Timer(780.0, give_up)
+        job_dog.daemon = True
+        job_dog.start()
+        JOB_DOG.append(job_dog)
+    try:
+        out = run_workload(name, a.steps, a.warmup, not a.no_graph, world, rank, dev, a.schedule)
+    except Exception as e:  # noqa: BLE001
+        if world == 1:
+            raise
+        # the Python driver's leg failed: the C++ driver's legs below still run, from a fresh state they develop themselves
+        w0 = WORKLOADS[name]
+        from fluidnet_cxx_amd.slab import SlabLayout
+        lay = SlabLayout(w0["D"] * world, world, rank, halo=6)
+        run_workload.slab_state = (plume_state_torch(w0["res"], lay.D_local, dev, lay.z_offset, lay.D_global), mconf_for(w0))
+        run_workload.fresh_state = True
+        cells0 = w0["res"] * w0["res"] * w0["D"]
+        out = dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=0.0, unit="Mcells/s",
+                   steps_per_s=0.0, n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=float("inf"), dtype="f32", step_hbm_frac=0.0,
+                   python_driver_error=f"{type(e).__name__}: {e}"[:300],
+                   config=dict(workload=name, grid_per_gpu=[w0["D"], w0["res"], w0["res"]], global_grid=[w0["D"] * world, w0["res"], w0["res"]],
+                               method="jacobi", jacobi_iters=w0["iters"], parallelism=f"{world} z-slabs", launch="eager", developed_steps=0,
+                               state_finite_after_timing=None),
+                   kernel_ms_per_step={},
+                   roofline=dict(bound="hbm", kernel="jacobi3d_march2_kernel<false,false,3>", achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0,
+                                 algorithmic=f"16 B/cell/sweep x {w0['iters']} sweeps x {cells0} owned cells per step"))
     out["config"]["world_size"] = dist.get_world_size() if world > 1 else 1
     out["config"]["backend"] = "nccl (RCCL)" if world > 1 else None
     if world == 1 and a.workload is None and not a.no_also:
@@ -729,6 +769,8 @@ def main():
     done = []
 
     def emit():
+        for t in JOB_DOG:
+            t.cancel()                       # (one line only: the job's watchdog must not add its own behind this one)
         if rank == 0 and not done:
             done.append(1)
             line, detail = compact(out)
@@ -788,12 +830,17 @@ def main():
         nd = out["native_driver"]
         out["config"]["driver"] = "python (fluidnet_cxx_amd/slab.py over torch.distributed P2P)"
         if world > 1 and "error" not in nd and nd.get("state_finite"):
+            if "python_driver_error" in out:
+                out["python_driver"] = dict(error=out.pop("python_driver_error"))
+                out["ms_per_step"] = nd["ms_per_step"]
             # N > 1: the C++ driver is the product path (launches and RCCL calls issued from C++); both drivers issue the same
             # kernels and exchanges (same bits, tests/test_slab.py), the Python driver's time is kept beside it
-            out["python_driver"] = dict(ms_per_step=out["ms_per_step"], value=out["value"], unit="Mcells/s", steps=out["steps"])
+            if "python_driver" not in out:
+                out["python_driver"] = dict(ms_per_step=out["ms_per_step"], value=out["value"], unit="Mcells/s", steps=out["steps"])
+            pyms = out["python_driver"].get("ms_per_step", nd["ms_per_step"])
             out["value"], out["ms_per_step"] = nd["value"], nd["ms_per_step"]
             out["steps_per_s"] = 1e3 / nd["ms_per_step"]
-            out["step_hbm_frac"] = out["step_hbm_frac"] * out["python_driver"]["ms_per_step"] / nd["ms_per_step"]
+            out["step_hbm_frac"] = out["step_hbm_frac"] * pyms / nd["ms_per_step"]
             out["config"]["driver"] = ("native (fnx_slab_step: C++ driver, " + ("peer-store transport" if "peer-store" in (nd.get("transport") or "")
                                        else "RCCL ncclSend/ncclRecv issued from C++") + ")")
             out["config"]["launch"] = nd["launch"]
