@@ -488,12 +488,12 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
                            int reuse_mask, void* stream) {
   if (int rc = check_grid(g)) return rc;
   if (layout < 0 || layout > 3) return fail(FNX_EINVAL, "jacobi_pass: layout must be 0..3");
-  if (layout != 0 && ((nsweeps != 2 && nsweeps != 3) || !g->is3D || !fnx::jacobi3d_quad_ok(dims(g))))
-    return fail(FNX_EINVAL, "jacobi_pass: the row-quad layout needs a two- or three-sweep pass on a grid fnx_jacobi_quad_ok accepts");
+  if (layout != 0 && (nsweeps != 2 || !g->is3D || !fnx::jacobi3d_quad_ok(dims(g))))
+    return fail(FNX_EINVAL, "jacobi_pass: the row-quad layout needs a two-sweep pass on a grid fnx_jacobi_quad_ok accepts");
   if (!flags || !div || !p_out || p_in == p_out) return fail(FNX_EINVAL, "jacobi_pass: NULL or aliased tensor");
   if (!g->is3D) return fail(FNX_EINVAL, "jacobi_pass: 3D only (2D uses fnx_jacobi_sweeps)");
   const bool from_zero = p_in == nullptr;                 // the first pass of a solve: p = 0 everywhere, nothing to read
-  if (nsweeps < 1 || nsweeps > 3) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1, 2 or 3");
+  if (nsweeps < 1 || nsweeps > 2) return fail(FNX_EINVAL, "jacobi_pass: nsweeps must be 1 or 2");
   if (k_begin < 0 || k_end > g->D || (k_end != 0 && k_end <= k_begin)) return fail(FNX_EINVAL, "jacobi_pass: bad plane range");
   if (k_begin2 >= 0) {
     const int n = k_end - k_begin;
@@ -507,23 +507,13 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
   unsigned char* mask = W.mask;
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
-  if (nsweeps == 3) {
-    const int np3 = k_end > k_begin ? k_end - k_begin : g->D;
-    if (!fnx::jacobi3d_x3_ok(d, np3, k_begin2 >= 0))
-      return fail(FNX_EINVAL, "jacobi_pass: a three-sweep pass needs every (tile, plane chunk) wave resident at once (fnx_jacobi_pass3_ok)");
-    fnx::launch_jacobi3d_x3(d, mask, div, p_in, p_out, s, k_begin, k_end, from_zero, k_begin2, layout);
-  } else if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, s, k_begin, k_end, from_zero, k_begin2, layout);
+  if (nsweeps == 2) fnx::launch_jacobi3d_x2(d, mask, div, p_in, p_out, s, k_begin, k_end, from_zero, k_begin2, layout);
   else {
     fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, s, k_begin, k_end);
     if (k_begin2 >= 0) fnx::launch_jacobi3d(d, mask, div, p_in, p_out, from_zero, s, k_begin2, k_begin2 + (k_end - k_begin));
   }
   HIP_OK(hipGetLastError());
   return FNX_OK;
-}
-
-int fnx_jacobi_pass3_ok(const FnxGrid* g, int planes, int two_ranges) {
-  if (check_grid(g) != FNX_OK || !g->is3D) return 0;
-  return fnx::jacobi3d_x3_ok(dims(g), planes > 0 ? planes : g->D, two_ranges != 0) ? 1 : 0;
 }
 
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,

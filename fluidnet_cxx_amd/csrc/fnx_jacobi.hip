@@ -757,206 +757,6 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   }  // segments
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// 3D, THREE sweeps per pass: the march of jacobi3d_march2_kernel with a third ring.  A wave owns 58 output columns (lanes 3..60)
-// x 4 rows and keeps p^0 on rows j0-3..j0+6, p^1 on j0-2..j0+5 and p^2 on j0-1..j0+4 for three planes each; at step t it builds
-// p^1(plane t), p^2(plane t-1) and the finished p^3(plane t-2): 8 + 6 + 4 = 18 row relaxations per 4 x 58 x 3 cell-sweeps = 1.66
-// lane-updates per cell-sweep against the two-sweep pass's 1.33, at 155 VGPRs (three waves per SIMD).  For WHOLE passes that is a
-// loss -- the two-sweep kernel is VALU-issue bound (measured below) -- but the short plane-range launches of the z-slab driver's
-// edge chains are latency-bound (launch + lead-in + a few steps of one wave): there a block of 6 sweeps as two launches instead of
-// three is what counts (fnx_slab.hip).  Same per-cell arithmetic (relax3 / div6_*): same bits.  Resident-set launches only
-// (every (tile, chunk) wave at once; grids with more tiles than wave slots keep the two-sweep passes).
-// ---------------------------------------------------------------------------------------------------
-constexpr int Z3WPS = 3;       // 155 VGPRs
-template <bool ZERO, int LAY>
-__global__ __launch_bounds__(64, Z3WPS) void jacobi3d_march3_kernel(GridDims g, const unsigned* __restrict__ maskq,
-                                                                    const float* __restrict__ div, const float* __restrict__ p_in,
-                                                                    float* __restrict__ p_out, int nxt, int nyt, int zchunk, int kb,
-                                                                    int ke, int kb2) {
-  constexpr int R0 = Z2R + 6, R1 = Z2R + 4, R2 = Z2R + 2;
-  static_assert(Z2R == 4 && Z2NW == 1, "a mask word holds the rows of a 4-row tile");
-  const int lane = threadIdx.x;
-  const int G = gridDim.x, np = ke - kb;
-  const int gid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int ntiles = nxt * nyt * g.B;
-  int zc = gid / ntiles;
-  const int tl = gid - zc * ntiles;
-  int kbase = kb;
-  if (kb2 >= 0) {
-    const int nzc1 = (np + zchunk - 1) / zchunk;
-    if (zc >= nzc1) { zc -= nzc1; kbase = kb2; }
-  }
-  if (zc * zchunk >= np) return;                           // padding block
-  const int pk = zc * zchunk, seg = min(zchunk, np - pk);
-  const int bx = tl % nxt, l1 = tl / nxt;
-  const int by = l1 % nyt, b = l1 / nyt;
-  const int x = bx * 58 - 3 + lane;
-  const int j0 = by * Z2R;
-  const int k_lo = kbase + pk, k_hi = k_lo + seg;
-  const bool xin = (x >= 0) & (x < g.W);
-  const int xc = x < 0 ? 0 : (x > g.W - 1 ? g.W - 1 : x);
-  const size_t base = (size_t)b * g.DHW;
-  auto clampk = [&](int k) { return k < 0 ? 0 : (k > g.D - 1 ? g.D - 1 : k); };
-  unsigned rowb[R0];                                       // row slot rr <-> j = j0 - 3 + rr (clamped into the grid: border rows have mask 0)
-#pragma unroll
-  for (int rr = 0; rr < R0; ++rr) {
-    const int j = j0 - 3 + rr;
-    rowb[rr] = (unsigned)((j < 0 ? 0 : (j > g.H - 1 ? g.H - 1 : j)) * g.W);
-  }
-  const int k0 = clampk(k_lo - 3);
-  auto planeoff = [&](int k) { return (unsigned)((clampk(k) - k0) * g.HW); };
-  const unsigned xoff = (unsigned)xc * 4u;
-  const size_t seg0 = base + (size_t)k0 * g.HW;
-  const size_t left = (size_t)(g.D - k0) * g.HW;
-  const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
-  const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
-  const BufRsrc r_o = make_rsrc(p_out + seg0, ncell * 4u);
-  const int HqM = (g.H + 3) >> 2, HqW = HqM * g.W;
-  const size_t leftq = (size_t)(g.D - k0) * HqW;
-  const BufRsrc r_m = make_rsrc(maskq + ((size_t)b * g.D + k0) * HqW, (leftq > 0x3fffffffu ? 0x3fffffffu : (unsigned)leftq) * 4u);
-  const unsigned mq_c = (unsigned)(by * g.W) * 4u, mq_m = (unsigned)((by > 0 ? by - 1 : 0) * g.W) * 4u,
-                 mq_p = (unsigned)((by + 1 < HqM ? by + 1 : HqM - 1) * g.W) * 4u;
-  const bool has_m = by > 0, has_p = by + 1 < HqM;
-  // mask of the 8 rows j0-2 .. j0+5: `lo` = bytes 2, 3 of the group below, `own`, `hi` = bytes 0, 1 of the group above
-  struct Mask3 { unsigned own, lo, hi; };
-  auto ldm = [&](int k) {
-    const unsigned po = (unsigned)((clampk(k) - k0) * HqW) * 4u;
-    Mask3 m;
-    m.own = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r_m, xoff, po + mq_c, 0);
-    m.lo = has_m ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r_m, xoff + 2u, po + mq_m, 0) & 0xffffu : 0u;
-    m.hi = has_p ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r_m, xoff, po + mq_p, 0) & 0xffffu : 0u;
-    return m;
-  };
-  auto ldf = [&](const BufRsrc& r, unsigned cell) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff, cell * 4u, 0));
-  };
-  const int Hq = g.H >> 2;
-  const unsigned xoff4 = (unsigned)xc * 16u;
-  const unsigned gq_c = (unsigned)(by * 4 * g.W), gq_m = (unsigned)((by > 0 ? by - 1 : 0) * 4 * g.W),
-                 gq_p = (unsigned)((by + 1 < Hq ? by + 1 : Hq - 1) * 4 * g.W);
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  // the 10 rows j0-3 .. j0+6 of plane offset `po` into dst[0..10)
-  auto load_p0 = [&](float* dst, unsigned po) __attribute__((always_inline)) {
-    if (ZERO) {
-#pragma unroll
-      for (int rr = 0; rr < R0; ++rr) dst[rr] = 0.f;
-    } else if (LAY & 1) {
-      const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_p, xoff4, (po + gq_m) * 4u, 0));
-      const f32x4 mid = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_p, xoff4, (po + gq_c) * 4u, 0));
-      const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_p, xoff4, (po + gq_p) * 4u, 0));
-      dst[0] = lo.y; dst[1] = lo.z; dst[2] = lo.w; dst[3] = mid.x; dst[4] = mid.y; dst[5] = mid.z; dst[6] = mid.w;
-      dst[7] = hi.x; dst[8] = hi.y; dst[9] = hi.z;
-    } else {
-#pragma unroll
-      for (int rr = 0; rr < R0; ++rr) dst[rr] = ldf(r_p, po + rowb[rr]);
-    }
-  };
-  float P0[4][R0], P1[4][R1], P2[4][R2], AD[4][R1];
-  Mask3 AM[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int rr = 0; rr < R0; ++rr) P0[q][rr] = 0.f;
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) { P1[q][rr] = 0.f; AD[q][rr] = 0.f; }
-#pragma unroll
-    for (int rr = 0; rr < R2; ++rr) P2[q][rr] = 0.f;
-    AM[q] = Mask3{0u, 0u, 0u};
-  }
-  int t = k_lo - 2;
-  {
-    const unsigned pm = planeoff(t - 1), pc = planeoff(t), pp = planeoff(t + 1);
-    load_p0(P0[3], pm); load_p0(P0[0], pc); load_p0(P0[1], pp);
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) AD[0][rr] = ldf(r_d, pc + rowb[rr + 1]);
-    AM[0] = ldm(t);
-  }
-  const bool lane_out = (lane >= 3) & (lane <= 60) & xin;
-  int sel_m1 = 2, sel_m2 = 2;                              // select path of planes t-1, t-2
-
-  // one sweep over N rows, row r = slot OFF + r of the 8-row window (slots 0, 1: lo bytes; 2..5: own bytes; 6, 7: hi bytes)
-  auto sweep = [&](auto nn, auto off, int sel, const Mask3 M, const float* Cm1, const float* B, const float* F, const float* DV,
-                   float* out) __attribute__((always_inline)) {
-    constexpr int N = decltype(nn)::value, OFF = decltype(off)::value;
-    auto mword = [&](int r) { return (OFF + r) < 2 ? M.lo : ((OFF + r) >= 6 ? M.hi : M.own); };
-    auto mshift = [&](int r) { return (OFF + r) < 2 ? 8 * (OFF + r) : ((OFF + r) >= 6 ? 8 * (OFF + r - 6) : 8 * (OFF + r - 2)); };
-    float xs[N];
-    bool bad = false;
-    if (sel == 0) {
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const float c = Cm1[r + 1];
-        out[r] = relax3<0>(mword(r), mshift(r), c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
-        bad |= __builtin_amdgcn_classf(out[r], 0x90);
-      }
-    } else if (sel == 1) {
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const float c = Cm1[r + 1];
-        out[r] = relax3<1>(mword(r), mshift(r), c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
-        bad |= __builtin_amdgcn_classf(out[r], 0x90);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const float c = Cm1[r + 1];
-        out[r] = relax3<2>(mword(r), mshift(r), c, dpp_from_left(c), dpp_from_right(c), Cm1[r], Cm1[r + 2], B[r], F[r], DV[r], xs[r]);
-        bad |= __builtin_amdgcn_classf(out[r], 0x90);
-      }
-    }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
-#pragma unroll
-      for (int r = 0; r < N; ++r)
-        if (__builtin_amdgcn_classf(out[r], 0x90)) out[r] = div6_tiny(xs[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < N; ++r)
-      out[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, out[r]) & __builtin_amdgcn_sbfe((int)mword(r), mshift(r), 1));
-  };
-
-  auto step = [&](auto ph, int t) __attribute__((always_inline)) {
-    constexpr int PH = decltype(ph)::value;
-    constexpr int SM = (PH + 3) & 3, SC = PH, SP = (PH + 1) & 3, SN = (PH + 2) & 3;      // planes t-1, t, t+1 (and t-3), t+2 (and t-2)
-    const unsigned p2 = planeoff(t + 2), p1 = planeoff(t + 1);
-    load_p0(P0[SN], p2);
-#pragma unroll
-    for (int rr = 0; rr < R1; ++rr) AD[SP][rr] = ldf(r_d, p1 + rowb[rr + 1]);
-    AM[SP] = ldm(t + 1);
-    // ---- sweep 1 on plane t, rows j0-2 .. j0+5
-    const unsigned ob = AM[SC].own | AM[SC].lo | AM[SC].hi;
-    const int sel1 = __builtin_amdgcn_ballot_w64((ob & 0x78787878u) != 0) != 0 ? 2 : (__builtin_amdgcn_ballot_w64((ob & 0x06060606u) != 0) != 0 ? 1 : 0);
-    sweep(IC<R1>{}, IC<0>{}, sel1, AM[SC], P0[SC], &P0[SM][1], &P0[SP][1], AD[SC], P1[SC]);
-    // ---- sweep 2 on plane t-1, rows j0-1 .. j0+4 (p^1 of planes t-2, t-1, t = slots SN, SM, SC)
-    if (t - 1 >= k_lo - 1) sweep(IC<R2>{}, IC<1>{}, sel_m1, AM[SM], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], P2[SM]);
-    // ---- sweep 3 on plane t-2, rows j0 .. j0+3 (p^2 of planes t-3, t-2, t-1 = slots SP, SN, SM)
-    if (t - 2 >= k_lo) {
-      float v[Z2R];
-      sweep(IC<Z2R>{}, IC<2>{}, sel_m2, AM[SN], P2[SN], &P2[SP][1], &P2[SM][1], &AD[SN][2], v);
-      const unsigned ok = (unsigned)((t - 2 - k0) * g.HW + j0 * g.W) * 4u;
-      if (LAY & 2) {
-        if (lane_out) {
-          const f32x4 o = {v[0], v[1], v[2], v[3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_o, xoff4, ok, 0);
-        }
-      } else
-#pragma unroll
-      for (int r = 0; r < Z2R; ++r) {
-        if (lane_out && j0 + r < g.H)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
-      }
-    }
-    sel_m2 = sel_m1; sel_m1 = sel1;
-  };
-  while (true) {
-    step(IC<0>{}, t); if (++t > k_hi + 1) break;
-    step(IC<1>{}, t); if (++t > k_hi + 1) break;
-    step(IC<2>{}, t); if (++t > k_hi + 1) break;
-    step(IC<3>{}, t); if (++t > k_hi + 1) break;
-  }
-}
-
 constexpr int BX = 64, BY = 4;
 
 // 2D, one sweep per launch, one thread per cell: the pTol > 0 solve (the reference's per-sweep convergence test needs every
@@ -1174,46 +974,6 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   else J3Q_S(false, 1);
 #undef J3Q_S
 #undef J3Q
-}
-
-// can this plane range (or pair of ranges) run as ONE resident set of three-sweep waves?  (tiles of 58 columns x 4 rows)
-bool jacobi3d_x3_ok(const GridDims& g, int np, bool two_ranges) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long slots = (long)Z3WPS * 4 * cus;
-  const long ntiles = (long)((g.W + 57) / 58) * ((g.H + Z2R - 1) / Z2R) * g.B;
-  return Z2R == 4 && Z2NW == 1 && np >= 1 && ntiles * (two_ranges ? 2 : 1) <= slots && (size_t)(np + 8) * g.HW < 0x3fffffffu;
-}
-
-// three sweeps in one pass: p_in = p^n, p_out = p^{n+3}; lay as launch_jacobi3d_x2.  Output planes [kb, ke) (and [kb2, kb2 + ke - kb));
-// reads planes kb - 3 .. ke + 2.  Caller checks jacobi3d_x3_ok.
-void launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay) {
-  if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
-  static const int slots = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return Z3WPS * 4 * cus;
-  }();
-  constexpr int zmin = 2;
-  const int nxt = (g.W + 57) / 58, nyt = (g.H + Z2R - 1) / Z2R;
-  const int np = ke - kb, ntiles = nxt * nyt * g.B;
-  int nzc = slots / ntiles;
-  if (kb2 >= 0) nzc /= 2;
-  if (nzc < 1) nzc = 1;
-  int zchunk = (np + nzc - 1) / nzc;
-  if (zchunk < zmin) zchunk = zmin;
-  long long G = (long long)ntiles * ((np + zchunk - 1) / zchunk) * (kb2 >= 0 ? 2 : 1);
-  G = ((G + 7) / 8) * 8;
-  const dim3 grid((unsigned)G), block(64);
-  const unsigned* maskq = (const unsigned*)(mask + maskq_offset(g));
-#define J3T(Z, L) jacobi3d_march3_kernel<Z, L><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2)
-  if (from_zero) lay &= 2;
-  if (lay == 0) { if (from_zero) J3T(true, 0); else J3T(false, 0); }
-  else if (lay == 2) { if (from_zero) J3T(true, 2); else J3T(false, 2); }
-  else if (lay == 3) J3T(false, 3);
-  else J3T(false, 1);
-#undef J3T
 }
 
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,

@@ -98,10 +98,6 @@ void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* 
                      bool from_zero, hipStream_t s, int kb = 0, int ke = 0);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                         hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0);
-// three sweeps per pass (resident-set launches only: jacobi3d_x3_ok)
-bool jacobi3d_x3_ok(const GridDims& g, int np, bool two_ranges);
-void launch_jacobi3d_x3(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay);
 bool jacobi3d_quad_ok(const GridDims& g);   // may two-sweep passes hand each other p in the row-quad layout (lay bits 0 / 1 = p_in / p_out)?
 // Reproducible residual (no atomics): per sample b the squared differences of a[b*per_sample + first + q] - b[...] (b == null:
 // zeros), q < count, summed in a fixed order in fp64 through `partials` (residual_scratch_bytes(B)); sumsq (B floats, may be

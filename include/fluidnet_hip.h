@@ -151,11 +151,6 @@ int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, con
  * other this layout; the first pass of a solve has no input, the last one writes rows (layout 1).  fnx_jacobi and
  * fnx_jacobi_sweeps do this internally. */
 int fnx_jacobi_quad_ok(const FnxGrid* g);
-/* nsweeps = 3 of the pass entry points: THREE sweeps per pass (reads planes k_begin - 3 .. k_end + 2 of p_in).  For short plane ranges --
- * the edge chains of the z-slab driver, which are latency-bound: two launches per block of six sweeps instead of three; a whole pass is
- * slower than the two-sweep one (1.24 x the VALU work of a kernel that is VALU-issue bound).  Only where every (tile, plane chunk) wave of
- * the launch is resident at once: fnx_jacobi_pass3_ok(g, planes per range, two ranges?) says so. */
-int fnx_jacobi_pass3_ok(const FnxGrid* g, int planes, int two_ranges);
 int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                            int nsweeps, int k_begin, int k_end, int k_begin2, int layout, void* ws, size_t ws_bytes,
                            int reuse_mask, void* stream);

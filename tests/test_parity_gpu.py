@@ -333,53 +333,6 @@ def test_jacobi_quad_handover_more_tiles_than_waves(dev, fl, oracle):
         assert_bitexact(N(pg), po, f"jacobi {n} sweeps on {D}x{H}x{W}")
 
 
-@pytest.mark.parametrize("shape", [(1, 24, 20, 70), (2, 16, 36, 132), (1, 14, 22, 61), (1, 40, 512, 512)])
-def test_jacobi_three_sweep_pass_vs_oracle(dev, ext, oracle, shape):
-    """fnx_jacobi_pass with nsweeps = 3 (jacobi3d_march3_kernel: three sweeps per pass, for the z-slab driver's edge chains): whole
-    domain, plane ranges, two ranges in one launch, from p and from zero, rows and the row-quad layout, obstacles, several tiles in x
-    (58 output columns per wave), H % 4 != 0 -- the bits of the oracle's three sweeps (cpp/fluids_init.cpp:858-994)."""
-    B, D, H, W = shape
-    rng = np.random.default_rng(7)
-    flags = make_flags(B, D, H, W, boxes=True)
-    flags[:, :, D // 2, 5:9, 3:W - 3] = 2                                       # a bar across the x tiles
-    div = rng.standard_normal((B, 1, D, H, W)).astype(np.float32)
-    p0 = rng.standard_normal((B, 1, D, H, W)).astype(np.float32)
-    p0[flags == 2] = 0.0
-    p0[:, :, 0] = 0; p0[:, :, -1] = 0; p0[:, :, :, 0] = 0; p0[:, :, :, -1] = 0; p0[:, :, :, :, 0] = 0; p0[:, :, :, :, -1] = 0
-    tf, td, tp = T(flags, dev), T(div, dev), T(p0, dev)
-    ws = torch.empty(ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=dev)
-    want = oracle.jacobi_sweeps(flags, div, p0, True, 3)
-    want0, _, _ = oracle.jacobi(flags, div, True, 0.0, 3)
-    out = torch.full_like(tp, float("nan"))
-    ext.jacobi_pass_(tf, td, tp, out, 3, 0, 0, ws, False)
-    assert_bitexact(N(out), want, f"three sweeps, whole domain {shape}")
-    out.fill_(float("nan"))
-    ext.jacobi_pass_(tf, td, None, out, 3, 0, 0, ws, True)
-    assert_bitexact(N(out), want0, f"three sweeps from zero {shape}")
-    # plane ranges (the result of a range is the whole-domain result on its planes; nothing else is written)
-    for (a, b, a2) in ((3, 9, -1), (0, 5, -1), (D - 6, D, -1), (3, 7, D - 7), (2, 8, 8)):
-        out.fill_(7.0)
-        ext.jacobi_pass_(tf, td, tp, out, 3, a, b, ws, True, a2)
-        got = N(out)
-        sel = np.zeros(D, bool); sel[a:b] = True
-        if a2 >= 0:
-            sel[a2:a2 + b - a] = True
-        assert_bitexact(got[:, :, sel], want[:, :, sel], f"three sweeps, planes {a}:{b} (+{a2}) of {shape}")
-        assert (got[:, :, ~sel] == 7.0).all(), "a plane outside the requested ranges was written"
-    if ext.jacobi_quad_ok(B, D, H, W):
-        # rows -> quad (2 sweeps), quad -> quad (3 sweeps), quad -> rows (2 sweeps) == 7 sweeps
-        a = torch.full_like(tp, float("nan")); b = torch.full_like(tp, float("nan"))
-        ext.jacobi_pass_(tf, td, tp, a, 2, 0, 0, ws, True, layout=2)
-        ext.jacobi_pass_(tf, td, a, b, 3, 0, 0, ws, True, layout=3)
-        ext.jacobi_pass_(tf, td, b, a, 2, 0, 0, ws, True, layout=1)
-        assert_bitexact(N(a), oracle.jacobi_sweeps(flags, div, p0, True, 7), "2 + 3 + 2 sweeps through the row-quad layout")
-        # from zero, quad out; quad in, rows out
-        ext.jacobi_pass_(tf, td, None, a, 3, 0, 0, ws, True, layout=2)
-        ext.jacobi_pass_(tf, td, a, b, 3, 0, 0, ws, True, layout=1)
-        want6, _, _ = oracle.jacobi(flags, div, True, 0.0, 6)
-        assert_bitexact(N(b), want6, "3 + 3 sweeps from zero through the row-quad layout")
-
-
 def test_jacobi_pass_layout_chain_and_errors(dev, ext, oracle):
     """fnx_jacobi_pass_layout: a chain of two-sweep passes that hand each other p in the row-quad layout (first pass from
     zero, last pass writes rows) has the bits of the oracle; the layout is refused for one-sweep passes and for grids
