@@ -500,21 +500,35 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
             stm = plume_state_torch(res, lm.D_local, dev, lm.z_offset, lm.D_global)
             model = dict(what="middle rank of 3 z-slabs on ONE GPU, C++ driver, link-model communicator (a model of N >= 3, not a measurement)",
                          ghost_free_ms=elapsed / steps * 1e3)
-            # (latency 9 us: the peer-store launch between two processes, tools/peer_probe.py; 20-25 us: a grouped RCCL send/recv)
-            for lat, gbps in ((9.0, 75.0), (9.0, 55.0), (20.0, 75.0), (25.0, 55.0)):
+            # (latency 9 us: the peer-store launch between two processes, tools/peer_probe.py; 20-25 us: a grouped RCCL send/recv.
+            #  deep_beside takes the communicator's direct sends: the last edge part of a block stores into the neighbour's mailbox itself)
+            def model_ms(sched, lat, gbps):
                 simm = NativeSlabSimulator(lm, m, comm=ext.slab_comm_link_model(lat, gbps), sweeps_per_exchange=6, static_flags=True,
-                                           cfl_check_every=0, schedule=schedule)
+                                           cfl_check_every=0, schedule=sched)
                 for _ in range(5):
                     simm.step(stm)
+                stepm = lambda: simm.step(stm)      # noqa: E731
+                try:                                 # the step is a fixed launch sequence: replay it as a HIP graph, as at N = 1
+                    torch.cuda.synchronize()
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm):
+                        simm.step(stm)
+                    gm.replay(); torch.cuda.synchronize()
+                    stepm = gm.replay
+                except Exception:  # noqa: BLE001
+                    pass
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(10):
-                    simm.step(stm)
+                    stepm()
                 torch.cuda.synchronize()
-                msm = (time.perf_counter() - t1) / 10 * 1e3
-                model[f"ms_at_{int(gbps)}GBps_{int(lat)}us"] = msm
-                model[f"modelled_efficiency_at_{int(gbps)}GBps_{int(lat)}us"] = (elapsed / steps * 1e3) / msm
-                del simm
+                return (time.perf_counter() - t1) / 10 * 1e3
+            for sched, lat, gbps in ((schedule, 9.0, 75.0), (schedule, 9.0, 55.0), (schedule, 20.0, 75.0), (schedule, 25.0, 55.0),
+                                     ("deep_beside", 9.0, 75.0), ("deep_beside", 9.0, 55.0)):
+                msm = model_ms(sched, lat, gbps)
+                tag = ("beside_" if sched == "deep_beside" and sched != schedule else "") + f"{int(gbps)}GBps_{int(lat)}us"
+                model[f"ms_at_{tag}"] = msm
+                model[f"modelled_efficiency_at_{tag}"] = (elapsed / steps * 1e3) / msm
         except Exception as e:  # noqa: BLE001
             model = dict(error=f"{type(e).__name__}: {e}")
     cells = res * res * layout.owned * world
@@ -630,7 +644,7 @@ def compact(out):
     mm = out.get("native_driver", {}).get("middle_rank_model")
     if mm:                                   # (short form: the sentence that says what it is stays in the side file)
         line["middle_rank_model"] = {kk.replace("modelled_efficiency", "eff"): _r(vv, 3) for kk, vv in mm.items() if kk != "what" and not kk.startswith("ms_at_")}
-        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model comm (9 us: peer-store, 20-25 us: RCCL): a MODEL of N>=3"
+        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model comm (9 us: peer-store, 20-25 us: RCCL; beside_: deep_beside + direct sends): a MODEL of N>=3"
     line["detail_file"] = "gpurun_out/bench_detail.json"
     return line, out
 

@@ -469,7 +469,7 @@ struct PySlab {
   FnxSlabConfig cfg{};
   std::shared_ptr<PySlabComm> comm;
   PySlab(int B, int H, int W, int D_global, int rank, int nranks, int halo, int sweeps_per_exchange, bool static_flags,
-         int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule, const std::string& method) : comm(comm_) {
+         int cfl_check_every, std::shared_ptr<PySlabComm> comm_, const std::string& schedule, const std::string& method, const std::string& direct_sends) : comm(comm_) {
     cfg.B = B; cfg.H = H; cfg.W = W; cfg.D_global = D_global; cfg.rank = rank; cfg.nranks = nranks; cfg.halo = halo;
     cfg.sweeps_per_exchange = sweeps_per_exchange; cfg.static_flags = static_flags ? 1 : 0; cfg.cfl_check_every = cfl_check_every;
     TORCH_CHECK(schedule == "deep_first" || schedule == "edge_first" || schedule == "last_pass" || schedule == "deep_beside",
@@ -478,6 +478,8 @@ struct PySlab {
                    (schedule == "deep_beside" ? FNX_SLAB_DEEP_BESIDE : FNX_SLAB_LAST_PASS));
     TORCH_CHECK(method == "jacobi" || method == "convnet", "unknown z-slab method '", method, "'");
     cfg.method = method == "convnet" ? 1 : 0;
+    TORCH_CHECK(direct_sends == "auto" || direct_sends == "never" || direct_sends == "always", "direct_sends: 'auto', 'never' or 'always'");
+    cfg.direct_sends = direct_sends == "auto" ? 0 : (direct_sends == "never" ? 1 : 2);
     check_status(fnx_slab_create(&s, &cfg, comm ? &comm->c : nullptr));
   }
   ~PySlab() { fnx_slab_destroy(s); }
@@ -791,10 +793,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   }, py::arg("comm"), py::arg("bytes"), py::arg("reps"), py::arg("scratch"),
         "average ms of one ghost exchange of `bytes` bytes with each neighbour (every rank must call it)");
   py::class_<PySlab>(m, "SlabDriver", "native z-slab driver of the 3D Jacobi step (fnx_slab_create / fnx_slab_step)")
-      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>, const std::string&, const std::string&>(), py::arg("B"), py::arg("H"),
+      .def(py::init<int, int, int, int, int, int, int, int, bool, int, std::shared_ptr<PySlabComm>, const std::string&, const std::string&, const std::string&>(), py::arg("B"), py::arg("H"),
            py::arg("W"), py::arg("D_global"), py::arg("rank"), py::arg("nranks"), py::arg("halo"), py::arg("sweeps_per_exchange"),
            py::arg("static_flags") = false, py::arg("cfl_check_every") = 0, py::arg("comm") = nullptr, py::arg("schedule") = "deep_first",
-           py::arg("method") = "jacobi")
+           py::arg("method") = "jacobi", py::arg("direct_sends") = "auto")
       .def("stats_enable", &PySlab::stats_enable, py::arg("on"))
       .def("stats_read", &PySlab::stats_read, "dict(bytes_per_neighbour, wait_ms, exchanges) since stats_enable(True); synchronises")
       .def("layout", &PySlab::layout, "(owned planes, ghost planes below, above, global plane of local plane 0)")

@@ -516,6 +516,38 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
   return FNX_OK;
 }
 
+int fnx_jacobi_pass_mirror_ok(const FnxGrid* g, int planes, int two_ranges, int layout) {
+  if (check_grid(g) != FNX_OK || !g->is3D || planes < 1) return 0;
+  return fnx::jacobi3d_mirror_ok(dims(g), planes, two_ranges != 0, false, layout) ? 1 : 0;
+}
+
+int fnx_jacobi_pass_mirror(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out, int k_begin,
+                           int k_end, int k_begin2, int layout, const FnxPlaneMirror* mirror, void* ws, size_t ws_bytes,
+                           int reuse_mask, void* stream) {
+  if (int rc = check_grid(g)) return rc;
+  if (!g->is3D || !flags || !div || !p_in || !p_out || p_in == p_out || !mirror) return fail(FNX_EINVAL, "jacobi_pass_mirror: NULL or aliased argument");
+  if (k_begin < 0 || k_end > g->D || k_end <= k_begin) return fail(FNX_EINVAL, "jacobi_pass_mirror: bad plane range");
+  const int np = k_end - k_begin;
+  if (k_begin2 >= 0 && (k_begin2 + np > g->D || (k_begin2 < k_end && k_begin < k_begin2 + np)))
+    return fail(FNX_EINVAL, "jacobi_pass_mirror: bad or overlapping second plane range");
+  if ((layout != 0 && layout != 3) || (layout == 3 && !fnx::jacobi3d_quad_ok(dims(g))) || !fnx::jacobi3d_mirror_ok(dims(g), np, k_begin2 >= 0, false, layout))
+    return fail(FNX_EINVAL, "jacobi_pass_mirror: this launch cannot mirror its output (fnx_jacobi_pass_mirror_ok)");
+  if (mirror->planes < 1 || !mirror->out[0] || (k_begin2 >= 0 && !mirror->out[1]))
+    return fail(FNX_EINVAL, "jacobi_pass_mirror: bad mirror");
+  hipStream_t s = (hipStream_t)stream;
+  const GridDims d = dims(g);
+  JacobiWs W; size_t need;
+  if (!carve_jacobi(g, ws, ws_bytes, &W, &need)) return fail(FNX_EWORKSPACE, "jacobi_pass_mirror: workspace too small (%zu < %zu)", ws_bytes, need);
+  if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, W.mask, s);
+  fnx::ProfScope ps(FNX_PROF_JACOBI, s);
+  fnx::JacobiMirror m{};
+  m.out[0] = mirror->out[0]; m.out[1] = mirror->out[1]; m.k[0] = mirror->k_first[0]; m.k[1] = mirror->k_first[1]; m.n = mirror->planes;
+  m.bstride = mirror->sample_stride; m.clock = mirror->start_clock;
+  fnx::launch_jacobi3d_x2(d, W.mask, div, p_in, p_out, s, k_begin, k_end, false, k_begin2, layout, &m);
+  HIP_OK(hipGetLastError());
+  return FNX_OK;
+}
+
 int fnx_jacobi_pass(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                     int nsweeps, int k_begin, int k_end, void* ws, size_t ws_bytes, int reuse_mask, void* stream) {
   return fnx_jacobi_pass2(g, flags, div, p_in, p_out, nsweeps, k_begin, k_end, -1, ws, ws_bytes, reuse_mask, stream);

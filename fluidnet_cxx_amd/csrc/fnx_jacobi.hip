@@ -528,15 +528,22 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 // step reads p^0 with 3 instructions instead of 8 and writes its four finished rows with 1 instead of 4.  A plane is the same
 // H*W floats in both layouts (ghost-plane exchanges do not care); the passes of a solve hand the quad layout to each other
 // and only the last one writes rows.
-template <bool ZERO, bool SPLIT, int LAY>
+// MIR: the launch ALSO stores the finished planes [mir.k[r], mir.k[r] + mir.n) of plane range r (0: [kb, ke), 1: the second range) to
+// mir.out[r] + sample * mir.bstride -- the same values, the same layout within a plane.  The z-slab driver's last edge part of a sweep
+// block writes the planes its neighbours need next straight into their mapped mailboxes (peer-store communicator) as the march
+// finishes them: no transport launch copies them afterwards.  The extra store is issued by every step and dropped by the buffer range
+// check outside the mirrored planes (an offset below the range wraps around, one above it is out of range): no branch.
+struct MirrorArgs { float* out[2]; int k[2]; int n; unsigned long long bstride; unsigned long long* clock; };
+template <bool ZERO, bool SPLIT, int LAY, bool MIR = false>
 __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned* __restrict__ maskq,
                                                                       const float* __restrict__ div,
                                                                       const float* __restrict__ p_in,
                                                                       float* __restrict__ p_out, int nxt, int nyt,
-                                                                      int zchunk, int kb, int ke, int kb2) {
+                                                                      int zchunk, int kb, int ke, int kb2, MirrorArgs mir = MirrorArgs{}) {
   constexpr int R0 = Z2R + 4, R1 = Z2R + 2;
   const int lane = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (MIR && mir.clock && blockIdx.x == 0 && lane == 0) *mir.clock = wall_clock64();     // when the mirrored stores begin (FnxPlaneMirror.start_clock)
   // One resident set of waves.  !SPLIT: every tile is cut into the same plane chunks and a wave takes one
   // (tile, chunk); all waves of a chunk start together and march the same planes at the same pace, so the halo
   // columns/rows two neighbouring tiles both touch are fetched from HBM once and hit in L2 the second time.  Workgroup
@@ -601,6 +608,10 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   const unsigned ncell = left > 0x3fffffffu ? 0x3fffffffu : (unsigned)left;
   const BufRsrc r_p = make_rsrc(p_in + seg0, ncell * 4u), r_d = make_rsrc(div + seg0, ncell * 4u);
   const BufRsrc r_o = make_rsrc(p_out + seg0, ncell * 4u);
+  // MIR: the mirror of this segment's plane range (byte offsets relative to its first mirrored plane)
+  const int mri = (MIR && kbase != kb) ? 1 : 0;
+  const BufRsrc r_x = make_rsrc(MIR ? mir.out[mri] + (size_t)b * mir.bstride : p_out, MIR ? (unsigned)((size_t)mir.n * g.HW * 4u) : 0u);
+  const int mk0 = MIR ? mir.k[mri] : 0;
   // Mask bytes in row groups of four, maskq[b][k][j/4][i] = the bytes of rows 4(j/4) .. +3 of column i (jacobi3d_maskq_kernel):
   // the tile's own four rows are ONE dword load, the halo rows j0-1 / j0+4 byte 3 / byte 0 of the groups below / above (taking
   // them from the byte mask's 64-B rows instead was measured: slower) -- 3 vector-memory instructions and registers per plane
@@ -733,16 +744,20 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
       float v[Z2R];
       sweep(IC<Z2R>{}, IC<1>{}, prev_sel, AM[SM], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
       const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
+      const unsigned okx = (unsigned)((t - 1 - mk0) * g.HW + j0 * g.W) * 4u;      // (MIR) wraps out of range below the mirrored planes
       if (LAY & 2) {                                       // j0 * W floats into the plane is the tile's row group in both layouts
         if (lane_out) {
           const f32x4 o = {v[0], v[1], v[2], v[3]};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_o, xoff4, ok, 0);
+          if (MIR) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_x, xoff4, okx, 0);
         }
       } else
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
-        if (lane_out && j0 + r < g.H)
+        if (lane_out && j0 + r < g.H) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
+          if (MIR) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_x, xoff, okx + (unsigned)(r * g.W) * 4u, 0);
+        }
       }
     }
     prev_sel = sel1;
@@ -925,9 +940,19 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 // can the two-sweep passes of this grid hand each other p in the row-quad layout (`lay` of launch_jacobi3d_x2)?
 bool jacobi3d_quad_ok(const GridDims& g) { return g.H % 4 == 0 && Z2R == 4 && Z2NW == 1; }
 
+// may a two-sweep launch of these plane ranges mirror its output (launch_jacobi3d_x2's `mirror`)?  One resident set of waves, both
+// arrays in the same layout, not the from-zero pass
+bool jacobi3d_mirror_ok(const GridDims& g, int np, bool two_ranges, bool from_zero, int lay) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long slots = (long)(Z2WPS * 4 / Z2NW) * cus;
+  const long ntiles = (long)((g.W + 59) / 60) * ((g.H + Z2NW * Z2R - 1) / (Z2NW * Z2R)) * g.B;
+  return !from_zero && (lay == 0 || lay == 3) && np >= 1 && ntiles * (two_ranges ? 2 : 1) <= slots && (size_t)(np + 4) * g.HW < 0x3fffffffu;
+}
+
 // two sweeps in one pass: p_in = p^n, p_out = p^{n+2}.  lay: bit 0 = p_in, bit 1 = p_out in the row-quad layout
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay) {
+                        hipStream_t s, int kb, int ke, bool from_zero, int kb2, int lay, const JacobiMirror* mirror) {
   if (ke <= kb) { kb = 0; ke = g.D; kb2 = -1; }
   static const int slots = [] {                          // resident waves: Z2WPS per SIMD (<= 128 VGPRs each)
     int dev = 0, cus = 256;
@@ -949,8 +974,8 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   if (ntiles > slots) zchunk = 0;                        // more tiles than slots: even split of the (tile, plane) space
   if (zchunk == 0 && (size_t)(np + 4) * g.HW >= 0x3fffffffu) zchunk = 64;   // keep a segment's 32-bit offsets below 4 GB
   if (kb2 >= 0 && (zchunk <= 0 || 2 * ntiles > slots)) {   // no room for both ranges at once: one after the other
-    launch_jacobi3d_x2(g, mask, div, p_in, p_out, s, kb, ke, from_zero, -1, lay);
-    launch_jacobi3d_x2(g, mask, div, p_in, p_out, s, kb2, kb2 + np, from_zero, -1, lay);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, s, kb, ke, from_zero, -1, lay, nullptr);
+    launch_jacobi3d_x2(g, mask, div, p_in, p_out, s, kb2, kb2 + np, from_zero, -1, lay, nullptr);
     return;
   }
   long long G;
@@ -965,6 +990,14 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   }
   const dim3 grid((unsigned)G), block(64, Z2NW);
   const unsigned* maskq = (const unsigned*)(mask + maskq_offset(g));
+  if (mirror) {                                            // (jacobi3d_mirror_ok has been checked: resident set, not from zero, lay 0 or 3)
+    MirrorArgs m{};
+    m.out[0] = mirror->out[0]; m.out[1] = mirror->out[1]; m.k[0] = mirror->k[0]; m.k[1] = mirror->k[1]; m.n = mirror->n;
+    m.bstride = mirror->bstride; m.clock = mirror->clock;
+    if (lay == 3) jacobi3d_march2_kernel<false, false, 3, true><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2, m);
+    else jacobi3d_march2_kernel<false, false, 0, true><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2, m);
+    return;
+  }
 #define J3Q(Z, S, L) jacobi3d_march2_kernel<Z, S, L><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2)
 #define J3Q_S(Z, L) do { if (zchunk > 0) J3Q(Z, false, L); else J3Q(Z, true, L); } while (0)
   if (from_zero) lay &= 2;                                 // no input: its layout does not matter

@@ -96,8 +96,12 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 // kb/ke: restrict the OUTPUT to planes [kb, ke) (0,0 = all planes); inputs are read from kb-1 (kb-2 for x2) on
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                      bool from_zero, hipStream_t s, int kb = 0, int ke = 0);
+// mirror of a two-sweep launch's output: planes [k[r], k[r] + n) of plane range r also go to out[r] + sample * bstride (floats)
+struct JacobiMirror { float* out[2]; int k[2]; int n; unsigned long long bstride; unsigned long long* clock; };
+bool jacobi3d_mirror_ok(const GridDims& g, int np, bool two_ranges, bool from_zero, int lay);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
-                        hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0);
+                        hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0,
+                        const JacobiMirror* mirror = nullptr);
 bool jacobi3d_quad_ok(const GridDims& g);   // may two-sweep passes hand each other p in the row-quad layout (lay bits 0 / 1 = p_in / p_out)?
 // Reproducible residual (no atomics): per sample b the squared differences of a[b*per_sample + first + q] - b[...] (b == null:
 // zeros), q < count, summed in a fixed order in fp64 through `partials` (residual_scratch_bytes(B)); sumsq (B floats, may be

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void peer_xfer_kernel(XferArgs a) {
     if (n > 2) ok = wait_word(&a.me->credit[s], n - 2, a);
     for (unsigned j = part; ok && j < nsub; j += kBlocksPerRole) {
       const unsigned long long r0 = (unsigned long long)j * a.sub_bytes, r1 = r0 + a.sub_bytes < a.used[s] ? r0 + a.sub_bytes : a.used[s];
-      copy_range<true>(a.push[s], a.npush[s], a.remote_slot[s], r0, r1);
+      // npush < 0: a DIRECT send -- the kernel that produced the planes has stored them into the slot itself (it ran before this
+      // launch on the stream: its stores are complete); only the ready words remain to be raised
+      if (a.npush[s] >= 0) copy_range<true>(a.push[s], a.npush[s], a.remote_slot[s], r0, r1);
       __threadfence_system();
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(&a.remote_ready[s][j], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -201,7 +203,26 @@ int peer_failed(Peer* p) {
   return FNX_OK;
 }
 
-int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
+int peer_exchange_impl(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream, bool direct);
+int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) { return peer_exchange_impl(vctx, segs, nsegs, stream, false); }
+// DIRECT sends (FnxSlabComm.direct_begin / direct_exchange): the next chunk's slot in each neighbour's mailbox, segment i at i * stride.
+// The slot is free without a wait: this rank's previous exchange launch has completed (stream order) and saw the neighbour's chunk
+// n - 1 arrive, which that neighbour pushed behind ITS launch n - 2, whose pull emptied the slot chunk n goes into.
+int peer_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2], size_t* seg_stride, void** start_clock, void* /*stream*/) {
+  Peer* p = ((PeerComm*)vctx)->p;
+  if (int rc = peer_failed(p)) return rc;
+  const size_t stride = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0 || nsegs < 1 || nsegs > kMaxPieces || stride * (size_t)nsegs > p->slot_bytes)
+    return fnx::set_error(FNX_EINVAL, "peer-store direct send: %d segments of %zu bytes do not fit a mailbox slot", nsegs, bytes);
+  dst[0] = p->rank > 0 ? (void*)p->mailbox(p->nb[0], 1, (p->push_seq[0] + 1) & 1) : nullptr;
+  dst[1] = p->rank < p->nranks - 1 ? (void*)p->mailbox(p->nb[1], 0, (p->push_seq[1] + 1) & 1) : nullptr;
+  *seg_stride = stride;
+  if (start_clock) *start_clock = nullptr;
+  return FNX_OK;
+}
+int peer_direct_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) { return peer_exchange_impl(vctx, segs, nsegs, stream, true); }
+
+int peer_exchange_impl(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream, bool direct) {
   PeerComm* c = (PeerComm*)vctx;
   Peer* p = c->p;
   if (int rc = peer_failed(p)) return rc;
@@ -217,6 +238,8 @@ int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
       cuts.push_back(Cut{i, at, n});
       at += n;
     }
+  if (direct && (cuts.size() != (size_t)nsegs || nsegs > kMaxPieces))
+    return fnx::set_error(FNX_EINVAL, "peer-store direct exchange: the segments are not the ones direct_begin sized");
   size_t k = 0;
   while (k < cuts.size()) {
     XferArgs a{};
@@ -240,7 +263,7 @@ int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
         if (snd) a.push[s][nsend++] = Piece{snd + cu.at, nullptr, pl[i].bytes, pl[i].off};
         if (rcv) a.pull[s][nrecv++] = Piece{nullptr, rcv + cu.at, pl[i].bytes, pl[i].off};
       }
-      a.npush[s] = nsend; a.npull[s] = nrecv;
+      a.npush[s] = direct ? -1 : nsend; a.npull[s] = nrecv;
       // (a direction with nothing to send still hands over the chunk: both ends count chunks, not bytes)
       a.push_n[s] = ++p->push_seq[s];
       a.pull_n[s] = ++p->pull_seq[s];
@@ -390,6 +413,7 @@ int fnx_slab_comm_peer(FnxSlabComm* out, void* peer, const void* handle_lo, cons
   if (!c) return fnx::set_error(FNX_EINVAL, "out of host memory");
   out->ctx = c; out->exchange = peer_exchange; out->allreduce_max = peer_allreduce_max; out->allreduce_sum = peer_allreduce_sum;
   out->destroy = peer_comm_destroy; out->abort = peer_abort;
+  out->direct_begin = peer_direct_begin; out->direct_exchange = peer_direct_exchange;
   return FNX_OK;
 }
 

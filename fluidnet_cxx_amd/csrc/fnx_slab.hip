@@ -291,14 +291,21 @@ void loop_abort(void* vctx) {
 // planes: a periodic stack of this slab -- the launch sequence, sizes and stream ordering are the real ones, the physics is
 // not).  What it measures is how much of a transfer of an assumed link a schedule hides.
 // ---------------------------------------------------------------------------------------------------------------
-struct ModelCtx { double latency_us, gbps; };
+struct ModelCtx {
+  double latency_us, gbps;
+  // direct sends (direct_begin / direct_exchange): the producing kernel stores into these buffers; the exchange's launch moves them into
+  // the ghost planes and lasts until latency + bytes / bandwidth have passed SINCE THE PRODUCING KERNEL STARTED (a clock
+  // word the kernel itself writes when it starts): stores that leave as the march produces them overlap the kernel that issues them
+  char* buf[2] = {nullptr, nullptr}; size_t cap = 0, stride = 0; unsigned long long* stamp = nullptr;
+};
 // One launch per exchange, like a real transport's: it moves the planes (ghost planes <- the slab's own edge planes) and does not end
 // before latency + bytes per direction / bandwidth have passed on the device's constant-rate clock (wall_clock64: 100 MHz on gfx950).
 // (Until round 4 the wait was a kernel of its own FOLLOWED by device-to-device copies: 15-25 us per exchange that no transport adds.)
 constexpr int kModelSegs = 16;
-struct ModelArgs { const char* src[2 * kModelSegs]; char* dst[2 * kModelSegs]; unsigned long long bytes[2 * kModelSegs]; int n; unsigned long long ticks; };
+struct ModelArgs { const char* src[2 * kModelSegs]; char* dst[2 * kModelSegs]; unsigned long long bytes[2 * kModelSegs]; int n; unsigned long long ticks;
+                   const unsigned long long* since; };
 __global__ __launch_bounds__(256) void link_model_xfer_kernel(ModelArgs a) {
-  const unsigned long long t0 = wall_clock64();
+  const unsigned long long t0 = a.since ? *a.since : wall_clock64();
   for (int i = 0; i < a.n; ++i) {
     const unsigned long long n16 = a.bytes[i] >> 4;
     if ((((unsigned long long)a.src[i] | (unsigned long long)a.dst[i] | a.bytes[i]) & 15ull) == 0) {
@@ -330,8 +337,48 @@ int model_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) 
   SLAB_HIP(hipGetLastError());
   return FNX_OK;
 }
+int model_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2], size_t* seg_stride, void** start_clock, void* /*stream*/) {
+  ModelCtx* c = (ModelCtx*)vctx;
+  const size_t stride = (bytes + 255) & ~(size_t)255, need = stride * (size_t)nsegs;
+  if (bytes == 0 || nsegs < 1 || nsegs > kModelSegs) return fnx::set_error(FNX_EINVAL, "link model direct send: bad segments");
+  if (need > c->cap) {
+    for (int d = 0; d < 2; ++d) { if (c->buf[d]) (void)hipFree(c->buf[d]); c->buf[d] = nullptr; }
+    for (int d = 0; d < 2; ++d) SLAB_HIP(hipMalloc((void**)&c->buf[d], need));
+    c->cap = need;
+  }
+  if (!c->stamp) SLAB_HIP(hipMalloc((void**)&c->stamp, sizeof(unsigned long long)));
+  c->stride = stride;
+  dst[0] = c->buf[0]; dst[1] = c->buf[1];
+  *seg_stride = stride;
+  if (start_clock) *start_clock = c->stamp;                 // the producing kernel stamps its own start: no launch of ours in front of it
+  return FNX_OK;
+}
+// what went "down" (buf[0]) arrives in this slab's ghost planes ABOVE (a periodic stack of this slab), and the other way round
+int model_direct_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
+  ModelCtx* c = (ModelCtx*)vctx;
+  if (nsegs > kModelSegs || !c->buf[0]) return fnx::set_error(FNX_EINVAL, "link model direct exchange without direct_begin");
+  size_t bytes = 0;
+  ModelArgs a{};
+  for (int i = 0; i < nsegs; ++i) {
+    const FnxSlabSeg& g = segs[i];
+    bytes += g.bytes;
+    if (g.recv_hi) { a.src[a.n] = c->buf[0] + (size_t)i * c->stride; a.dst[a.n] = (char*)g.recv_hi; a.bytes[a.n++] = g.bytes; }
+    if (g.recv_lo) { a.src[a.n] = c->buf[1] + (size_t)i * c->stride; a.dst[a.n] = (char*)g.recv_lo; a.bytes[a.n++] = g.bytes; }
+  }
+  const double us = c->gbps > 0.0 ? c->latency_us + (double)bytes / (c->gbps * 1e3) : 0.0;
+  a.ticks = (unsigned long long)(us * 100.0);
+  a.since = c->stamp;
+  link_model_xfer_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a);
+  SLAB_HIP(hipGetLastError());
+  return FNX_OK;
+}
 int model_allreduce(void*, float*, int, void*) { return FNX_OK; }        // one rank: its own value
-void model_destroy(void* vctx) { delete (ModelCtx*)vctx; }
+void model_destroy(void* vctx) {
+  ModelCtx* c = (ModelCtx*)vctx;
+  for (int d = 0; d < 2; ++d) if (c->buf[d]) (void)hipFree(c->buf[d]);
+  if (c->stamp) (void)hipFree(c->stamp);
+  delete c;
+}
 
 }  // namespace
 
@@ -452,7 +499,7 @@ int build_segs(const FnxSlab* s, float* const* fields, float* const* sources, co
   return FNX_OK;
 }
 // post on the communication stream behind everything `stream` has been given so far
-int post(FnxSlab* s, float* const* fields, float* const* sources, const int* channels, int nf, int width, hipStream_t stream) {
+int post(FnxSlab* s, float* const* fields, float* const* sources, const int* channels, int nf, int width, hipStream_t stream, bool direct = false) {
   if (s->cfg.nranks == 1) return FNX_OK;
   if (width > s->cfg.halo) return fnx::set_error(FNX_EINVAL, "slab: exchange wider than the halo");
   if (s->pending) return fnx::set_error(FNX_EINVAL, "slab: two exchanges in flight");
@@ -460,7 +507,8 @@ int post(FnxSlab* s, float* const* fields, float* const* sources, const int* cha
   build_segs(s, fields, sources, channels, nf, width, segs);
   SLAB_HIP(hipEventRecord(s->ev_post, stream));
   SLAB_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_post, 0));
-  SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), s->comm_stream));
+  // direct: the send sides are already where the communicator wants them (the producing kernel mirrored them there)
+  SLAB_OK((direct ? s->comm.direct_exchange : s->comm.exchange)(s->comm.ctx, segs.data(), (int)segs.size(), s->comm_stream));
   SLAB_HIP(hipEventRecord(s->ev_done, s->comm_stream));
   s->pending = true;
   s->pending_on = nullptr;
@@ -474,13 +522,13 @@ int post(FnxSlab* s, float* const* fields, float* const* sources, const int* cha
 }
 // the same exchange enqueued on `on` itself (work enqueued on `on` afterwards is behind it without an event; any other stream
 // waits for ev_done as for post)
-int post_on(FnxSlab* s, float* const* fields, const int* channels, int nf, int width, hipStream_t on) {
+int post_on(FnxSlab* s, float* const* fields, const int* channels, int nf, int width, hipStream_t on, bool direct = false) {
   if (s->cfg.nranks == 1) return FNX_OK;
   if (width > s->cfg.halo) return fnx::set_error(FNX_EINVAL, "slab: exchange wider than the halo");
   if (s->pending) return fnx::set_error(FNX_EINVAL, "slab: two exchanges in flight");
   std::vector<FnxSlabSeg> segs;
   build_segs(s, fields, nullptr, channels, nf, width, segs);
-  SLAB_OK(s->comm.exchange(s->comm.ctx, segs.data(), (int)segs.size(), on));
+  SLAB_OK((direct ? s->comm.direct_exchange : s->comm.exchange)(s->comm.ctx, segs.data(), (int)segs.size(), on));
   SLAB_HIP(hipEventRecord(s->ev_done, on));
   s->pending = true;
   s->pending_on = on;
@@ -546,15 +594,18 @@ int fnx_slab_comm_rccl(FnxSlabComm* out, int rank, int nranks, const void* uniqu
   const int r = api->CommInitRank(&c->comm, nranks, id, rank);
   if (r != 0) { delete c; return fnx::set_error(FNX_ECOMM, "ncclCommInitRank failed (%d: %s)", r, api->GetErrorString ? api->GetErrorString(r) : "?"); }
   out->ctx = c; out->exchange = rccl_exchange; out->allreduce_max = rccl_allreduce_max; out->allreduce_sum = rccl_allreduce_sum; out->destroy = rccl_destroy;
-  out->abort = rccl_abort;
+  out->abort = rccl_abort; out->direct_begin = nullptr; out->direct_exchange = nullptr;
   return FNX_OK;
 }
 
 int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_per_s) {
   if (!out || latency_us < 0.0 || gbytes_per_s < 0.0) return fnx::set_error(FNX_EINVAL, "slab_comm_link_model: bad arguments");
-  out->ctx = new ModelCtx{latency_us, gbytes_per_s};
+  ModelCtx* mc = new ModelCtx();
+  mc->latency_us = latency_us; mc->gbps = gbytes_per_s;
+  out->ctx = mc;
   out->exchange = model_exchange; out->allreduce_max = model_allreduce; out->allreduce_sum = model_allreduce;
   out->destroy = model_destroy; out->abort = nullptr;
+  out->direct_begin = model_direct_begin; out->direct_exchange = model_direct_exchange;
   return FNX_OK;
 }
 
@@ -567,7 +618,7 @@ int fnx_slab_comm_loopback(FnxSlabComm* out, void* group, int rank) {
   LoopGroup* g = (LoopGroup*)group;
   if (!out || !g || rank < 0 || rank >= g->nranks) return fnx::set_error(FNX_EINVAL, "loopback comm: bad arguments");
   out->ctx = new LoopCtx{g, rank}; out->exchange = loop_exchange; out->allreduce_max = loop_allreduce_max; out->allreduce_sum = loop_allreduce_sum; out->destroy = loop_destroy;
-  out->abort = loop_abort;
+  out->abort = loop_abort; out->direct_begin = nullptr; out->direct_exchange = nullptr;
   return FNX_OK;
 }
 int fnx_slab_loopback_group_set_timeout(void* group, double seconds) {
@@ -593,7 +644,8 @@ void fnx_slab_loopback_group_free(void* group) {
 }
 void fnx_slab_comm_free(FnxSlabComm* comm) {
   if (comm && comm->destroy && comm->ctx) comm->destroy(comm->ctx);
-  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->allreduce_sum = nullptr; comm->destroy = nullptr; comm->abort = nullptr; }
+  if (comm) { comm->ctx = nullptr; comm->exchange = nullptr; comm->allreduce_max = nullptr; comm->allreduce_sum = nullptr; comm->destroy = nullptr; comm->abort = nullptr;
+              comm->direct_begin = nullptr; comm->direct_exchange = nullptr; }
 }
 
 int fnx_slab_layout(const FnxSlabConfig* cfg, int* owned, int* ghost_lo, int* ghost_hi, int* z_offset) {
@@ -867,6 +919,39 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
     if (rc == FNX_OK) s->mask_valid = true;     // (a failed call may not have built the mask)
     return rc;
   };
+  // The LAST edge part of a sweep block, with the w planes each neighbour needs next mirrored into the communicator's direct-send
+  // windows (FnxSlabComm.direct_begin: the peer-store communicator's mailbox slots on the neighbours): the march stores them there
+  // as it finishes them and the exchange that follows has nothing to copy on the sending side -- the transport's launch and this
+  // part's own run time leave the chain exchange -> edge chain -> exchange.  *sent: the exchange must be posted as direct.  Falls back
+  // to the plain part (communicator without direct sends, launch shape, single-sweep last part).
+  auto edge_last = [&](const float* pin, float* pout, int n, int done, int sp, int lay, hipStream_t on, bool* sent) {
+    *sent = false;
+    hipStream_t q = on ? on : stream;
+    const int len = w - done + sp;                            // planes of one face's part: [face - w + done, face + sp)
+    const bool both = has_lo && has_hi;
+    const bool wanted = s->cfg.direct_sends == 2 || (s->cfg.direct_sends == 0 && s->cfg.schedule == FNX_SLAB_DEEP_BESIDE);
+    const bool can = wanted && s->comm.direct_begin && s->comm.direct_exchange && n == 2 && pin && (lay == 0 || lay == 3) &&
+                     s->mask_valid && fnx_jacobi_pass_mirror_ok(&gj, len, both ? 1 : 0, lay) != 0;
+    void* dst[2] = {nullptr, nullptr};
+    size_t stride = 0;
+    const size_t plane = (size_t)s->cfg.H * s->cfg.W;
+    void* clk = nullptr;
+    if (can && s->comm.direct_begin(s->comm.ctx, (size_t)w * plane * 4, s->cfg.B, dst, &stride, &clk, q) == FNX_OK) {
+      FnxPlaneMirror m{};
+      m.planes = w; m.sample_stride = stride / 4; m.start_clock = (unsigned long long*)clk;
+      int r = 0;
+      if (has_lo) { m.out[r] = (float*)dst[0]; m.k_first[r] = lo; ++r; }
+      if (has_hi) { m.out[r] = (float*)dst[1]; m.k_first[r] = top - w; ++r; }
+      const int kb = has_lo ? lo - w + done : top - sp;
+      SLAB_OK(fnx_jacobi_pass_mirror(&gj, st->flags, W.div, pin, pout, kb, kb + len, both ? top - sp : -1, lay, &m, W.jac, W.jac_bytes, 1, q));
+      *sent = true;
+      return (int)FNX_OK;
+    }
+    if (both) return pass(pin, pout, n, lo - w + done, lo + sp, top - sp, lay, on);
+    if (has_lo) SLAB_OK(pass(pin, pout, n, lo - w + done, lo + sp, -1, lay, on));
+    if (has_hi) SLAB_OK(pass(pin, pout, n, top - sp, top + w - done, -1, lay, on));
+    return (int)FNX_OK;
+  };
   float *cur = st->p, *nxt = W.pbuf;
   int remaining = prm->jacobi_iter;
   bool zero_in = true;                       // the solve starts from p = 0 everywhere: the first pass reads nothing
@@ -935,6 +1020,7 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       SLAB_OK(wait(s, es));                                // the ghost planes of `cur` (first block: of div): the EDGE stream waits
       float *src = cur, *dst = nxt;
       int done = 0;
+      bool sent = false;
       for (int pi = 0; pi < npass; ++pi) {
         const int n = passes[pi];
         done += n;
@@ -946,7 +1032,8 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
         // fired -- was measured: no better with a link, 4.69 against 4.15 ms per step without transfer time.)
         if (pi > 0 || first_launch) SLAB_HIP(hipStreamWaitEvent(es, s->ev_deep[pi > 0 ? pi - 1 : 0], 0));
         first_launch = false;
-        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q, es));
+        if (pi == npass - 1) SLAB_OK(edge_last(pin, dst, n, done, split[pi], Q, es, &sent));
+        else if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q, es));
         else {
           if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], -1, Q, es));
           if (has_hi) SLAB_OK(pass(pin, dst, n, top - split[pi], top + w - done, -1, Q, es));
@@ -961,7 +1048,7 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       // exchange -> edge chain -> exchange that bounds a block with a real link is then one in-order stream -- no stream hand-over
       // (an event record + wait costs ~10 us on this runtime) anywhere on it.  The next block's deep chain was released by the
       // join above and runs beside the transfer: it reads owned planes only, the transfer writes ghost planes.
-      SLAB_OK(post_on(s, ff, c1, 1, w, es));
+      SLAB_OK(post_on(s, ff, c1, 1, w, es, sent));
       zero_in = false;
     }
     SLAB_OK(wait(s, stream));
@@ -986,11 +1073,13 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       SLAB_OK(wait(s, stream));              // the ghost planes of `cur` (first block: of div)
       src = cur; dst = nxt;
       int done = 0;
+      bool sent = false;
       for (int pi = 0; pi < npass; ++pi) {
         const int n = passes[pi];
         done += n;
         const float* pin = (zero_in && pi == 0) ? nullptr : src;
-        if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q));
+        if (pi == npass - 1) SLAB_OK(edge_last(pin, dst, n, done, split[pi], Q, nullptr, &sent));
+        else if (has_lo && has_hi) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], top - split[pi], Q));
         else {
           if (has_lo) SLAB_OK(pass(pin, dst, n, lo - w + done, lo + split[pi], -1, Q));
           if (has_hi) SLAB_OK(pass(pin, dst, n, top - split[pi], top + w - done, -1, Q));
@@ -999,7 +1088,7 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
       }
       if (src != cur) { float* t = cur; cur = nxt; nxt = t; }
       float* ff[1] = {cur};
-      SLAB_OK(post(s, ff, nullptr, c1, 1, w, stream));
+      SLAB_OK(post(s, ff, nullptr, c1, 1, w, stream, sent));
       zero_in = false;
     }
     SLAB_OK(wait(s, stream));

@@ -822,14 +822,17 @@ class NativeSlabSimulator:
     comm: an `ext.SlabComm` (`rccl_comm(...)` below, or `ext.slab_comm_loopback(group, rank)`); None for one rank."""
 
     def __init__(self, layout, mconf, comm=None, sweeps_per_exchange=4, static_flags=False, cfl_check_every=8, batch=1,
-                 H=None, W=None, schedule="deep_first", method="jacobi", net=None):
+                 H=None, W=None, schedule="deep_first", method="jacobi", net=None, direct_sends="auto"):
         """method 'convnet' (with net = a FluidNet): the CNN projection on z-slabs, fnx_slab_step with prm.method 1 -- needs
         layout.halo >= 49 (a multiple of 4) and owned planes a multiple of 4 (include/fluidnet_hip.h)."""
         from ._ext import ext
         assert method in ("jacobi", "convnet") and (method == "jacobi" or net is not None)
         self.ext, self.l, self.cfg, self.comm = ext, layout, mconf, comm
         self.method, self.net = method, net
-        self._args = (int(sweeps_per_exchange), bool(static_flags), int(cfl_check_every), str(schedule))
+        # direct_sends "auto" | "never" | "always": where the communicator offers them (peer-store, link model) a sweep block's last edge
+        # part stores the planes the neighbours need next straight into their windows (FnxSlabConfig.direct_sends; auto: in deep_beside);
+        # same bits either way
+        self._args = (int(sweeps_per_exchange), bool(static_flags), int(cfl_check_every), str(schedule), str(direct_sends))
         self._drv = None
         self._ws = None
 
@@ -838,7 +841,7 @@ class NativeSlabSimulator:
             B, _, D, H, W = st["flags"].shape
             l = self.l
             self._drv = self.ext.SlabDriver(B, H, W, l.D_global, l.rank, l.world, l.halo, self._args[0], self._args[1],
-                                            self._args[2], self.comm, self._args[3], self.method)
+                                            self._args[2], self.comm, self._args[3], self.method, self._args[4])
             assert self._drv.layout() == [l.owned, l.lo, l.hi, l.z_offset] and D == l.D_local
             self._ws = torch.empty(self._drv.workspace_bytes(), dtype=torch.uint8, device=st["flags"].device)
         return self._drv

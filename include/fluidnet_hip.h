@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 17
+#define FNX_ABI_VERSION 18
 
 enum {
   FNX_OK = 0,
@@ -153,6 +153,21 @@ int fnx_jacobi_pass2(const FnxGrid* g, const float* flags, const float* div, con
 int fnx_jacobi_quad_ok(const FnxGrid* g);
 int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out,
                            int nsweeps, int k_begin, int k_end, int k_begin2, int layout, void* ws, size_t ws_bytes,
+                           int reuse_mask, void* stream);
+
+/* A two-sweep pass that ALSO stores some of the planes it finishes to a second destination ("mirror"): the planes
+ * [k_first[r], k_first[r] + planes) of plane range r (0: [k_begin, k_end); 1: the second range) go to out[r] + sample * sample_stride
+ * floats, plane after plane, each in the layout of p_out.  What the z-slab driver's last edge part of a sweep block uses to write the
+ * planes its neighbours need next straight into their mapped mailboxes (FnxSlabComm.direct_begin): the transport then has nothing left
+ * to copy on the sending side.  layout 0 (rows in and out) or 3 (row-quad in and out); p_in != NULL; only launches
+ * fnx_jacobi_pass_mirror_ok accepts (every (tile, plane chunk) wave resident at once). */
+typedef struct FnxPlaneMirror {
+  float* out[2]; int k_first[2]; int planes; size_t sample_stride;
+  unsigned long long* start_clock;   /* optional DEVICE word: the launch stores the device clock (wall_clock64) there when it starts */
+} FnxPlaneMirror;
+int fnx_jacobi_pass_mirror_ok(const FnxGrid* g, int planes_per_range, int two_ranges, int layout);
+int fnx_jacobi_pass_mirror(const FnxGrid* g, const float* flags, const float* div, const float* p_in, float* p_out, int k_begin,
+                           int k_end, int k_begin2, int layout, const FnxPlaneMirror* mirror, void* ws, size_t ws_bytes,
                            int reuse_mask, void* stream);
 
 /* velocityUpdate (in place on U), lib/fluid/velocity_update.py:6-162 */
@@ -316,6 +331,15 @@ typedef struct FnxSlabComm {
   /* Optional (may be NULL): called by fnx_slab_step on the rank whose step FAILED, so that its neighbours -- which may already
    * be waiting for it inside exchange() -- return FNX_ECOMM instead of hanging (RCCL: ncclCommAbort; loopback: a group flag). */
   void (*abort)(void* ctx);
+  /* Optional pair (both NULL or both set): DIRECT sends.  direct_begin(ctx, bytes, nsegs, dst, seg_stride, stream) names where the
+   * producing kernel may store the NEXT exchange's outgoing planes itself: dst[0] towards rank - 1, dst[1] towards rank + 1 (NULL at the
+   * ends of the chain), segment i of `bytes` bytes at dst[d] + i * *seg_stride bytes; FNX_EINVAL when that exchange does not fit (the
+   * driver then sends it the ordinary way).  direct_exchange(ctx, segs, nsegs, stream), enqueued behind the producing kernel on the same
+   * stream, is exchange() for segments whose send sides are already in place: it publishes them and receives.  *start_clock (may come
+   * back NULL): a device word the producing kernel is asked to store its start time in (FnxPlaneMirror.start_clock).  The peer-store
+   * communicator hands out its neighbours' mailbox slots; the link model buffers of its own, and times the transfer from that clock. */
+  int (*direct_begin)(void* ctx, size_t bytes, int nsegs, void* dst[2], size_t* seg_stride, void** start_clock, void* stream);
+  int (*direct_exchange)(void* ctx, const FnxSlabSeg* segs, int nsegs, void* stream);
 } FnxSlabComm;
 /* Ordering contract of a communicator: fnx_slab_step issues exchange() on its internal communication stream (the sweep blocks of
  * FNX_SLAB_DEEP_BESIDE: on its internal edge stream -- a communicator must take the stream it is given) and the
@@ -396,6 +420,12 @@ typedef struct FnxSlabConfig {
                                fnx_slab_step): needs halo >= FNX_SLAB_NET_MARGIN + 1, halo % 4 == 0, D_global / nranks % 4 == 0
                                when nranks > 1, and a workspace that holds the net's activations for owned + 2 x 48 planes (sized for the
                                untrimmed window; the towers run on nested crops of it, see FNX_SLAB_NET_MARGIN_FULL) */
+  int direct_sends;         /* where the communicator offers direct sends (FnxSlabComm.direct_begin), the last edge part of a sweep block
+                               can store the planes the neighbours need next straight into their windows (fnx_jacobi_pass_mirror) and the
+                               exchange is then posted as direct_exchange.  0 (default): in DEEP_BESIDE, whose cycle exchange -> edge chain
+                               the transport's launch and that part's run time then leave (middle rank modelled at 75 GB/s: 74 -> 78 % of a
+                               ghost-free slab); not in DEEP_FIRST, which hides the exchange behind the deep chain anyway and only pays the
+                               mirrored stores.  1: never.  2: in both.  Same bits in every case */
 } FnxSlabConfig;
 /* ghost planes of the MultiScaleNet's input a rank evaluates beyond its owned planes: the net's receptive field (< 48 cells at
  * full resolution), a multiple of 4 so that the rank's quarter- and half-resolution grids coincide with the global ones */

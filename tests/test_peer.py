@@ -42,13 +42,14 @@ def _worker(rank, world, port, case, out_dir):
     try:
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        D, H, W, halo, w, schedule, iters, ptol, mailbox, nsteps = case
+        D, H, W, halo, w, schedule, iters, ptol, mailbox, nsteps, direct = case
         cfg = dict(T.CFG, jacobiIter=iters, pTol=ptol)
         gs = T.global_state(D, H, W, seed=7)
         layout = SlabLayout(D, world, rank, halo)
         st = T.local_state(gs, layout, dev)
         comm = _peer_comm(ext, dist, rank, world, mailbox)
-        sim = NativeSlabSimulator(layout, cfg, comm=comm, sweeps_per_exchange=w, static_flags=True, cfl_check_every=2, schedule=schedule)
+        sim = NativeSlabSimulator(layout, cfg, comm=comm, sweeps_per_exchange=w, static_flags=True, cfl_check_every=2, schedule=schedule,
+                                  direct_sends=direct)
         with torch.cuda.stream(torch.cuda.Stream(device=dev)):
             for _ in range(nsteps):
                 sim.step(st)
@@ -63,16 +64,22 @@ def _worker(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-# D, H, W, halo, w, schedule, iters, pTol, mailbox bytes, steps
+# D, H, W, halo, w, schedule, iters, pTol, mailbox bytes, steps, direct sends ('auto': in deep_beside; 'never'; 'always')
+# (direct: the last edge part of a sweep block stores the planes the neighbours need next straight into their mailbox slots,
+#  fnx_jacobi_pass_mirror + FnxSlabComm.direct_exchange; the default where the communicator offers it)
 CASES = {
-    "deep_first":   (48, 20, 70, 6, 6, "deep_first", 20, 0.0, 1 << 20, 3),
-    "deep_beside":  (48, 20, 70, 6, 4, "deep_beside", 14, 0.0, 1 << 20, 3),
-    "chunked":      (32, 20, 70, 6, 4, "edge_first", 11, 0.0, 8192, 2),          # mailbox slots smaller than a plane (5 600 B x w): cut into chunks
-    "ptol":         (32, 20, 70, 6, 4, "last_pass", 30, 0.05, 1 << 20, 2),       # the per-sweep residual all-reduce along the chain
+    "deep_first":   (48, 20, 70, 6, 6, "deep_first", 20, 0.0, 1 << 20, 3, "always"),
+    "deep_beside":  (48, 20, 70, 6, 4, "deep_beside", 14, 0.0, 1 << 20, 3, "auto"),
+    "no_direct":    (48, 20, 70, 6, 6, "deep_beside", 20, 0.0, 1 << 20, 3, "never"),     # the same exchanges through the push copies
+    "odd_block":    (40, 20, 70, 6, 5, "deep_beside", 16, 0.0, 1 << 20, 2, "auto"),      # blocks of 1 + 2 + 2 sweeps, rows (no row-quad hand-over)
+    "small_slots":  (48, 20, 70, 6, 6, "deep_beside", 20, 0.0, 16384, 2, "always"),      # 6 planes (33 600 B) do not fit a slot: direct_begin declines, chunked pushes
+    "chunked":      (32, 20, 70, 6, 4, "edge_first", 11, 0.0, 8192, 2, "auto"),          # mailbox slots smaller than a plane (5 600 B x w): cut into chunks
+    "ptol":         (32, 20, 70, 6, 4, "last_pass", 30, 0.05, 1 << 20, 2, "auto"),       # the per-sweep residual all-reduce along the chain
 }
 
 
-@pytest.mark.parametrize("world,name", [(2, "deep_first"), (3, "deep_first"), (2, "deep_beside"), (3, "chunked"), (3, "ptol")])
+@pytest.mark.parametrize("world,name", [(2, "deep_first"), (3, "deep_first"), (2, "deep_beside"), (3, "deep_beside"), (2, "no_direct"),
+                                        (2, "odd_block"), (2, "small_slots"), (3, "chunked"), (3, "ptol")])
 def test_peer_store_processes_match_single_domain(tmp_path, world, name):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -80,7 +87,7 @@ def test_peer_store_processes_match_single_domain(tmp_path, world, name):
     from fluidnet_cxx_amd import simulate
     from fluidnet_cxx_amd.slab import SlabLayout
     case = CASES[name]
-    D, H, W, halo, w, schedule, iters, ptol, mailbox, nsteps = case
+    D, H, W, halo, w, schedule, iters, ptol, mailbox, nsteps, _direct = case
     D = D // 2 * world if world != 2 else D
     case = (D,) + case[1:]
     port = _free_port()

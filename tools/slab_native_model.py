@@ -5,7 +5,7 @@ One 512 x 512 x (64 + 2*6) slab (rank 1 of 3: the per-GPU shape of bench.py --gp
 communicator of the C ABI (fnx_slab_comm_link_model): every ghost exchange occupies the communication stream for
 latency + bytes / bandwidth and then fills the ghost planes from the slab's own edge planes.  Reported per schedule and link:
 ms per step, eager and as a HIP-graph replay, next to the ghost-free single slab (rank 0 of 1).
-usage: slab_native_model.py [schedules=deep_first,deep_beside] [w=6] [halo=max(6, w)]      env MODEL_LINKS="0:0,20:75" MODEL_STEPS=20"""
+usage: slab_native_model.py [schedules=deep_first,deep_beside] [w=6] [halo=max(6, w)]      env MODEL_LINKS="0:0,20:75" MODEL_STEPS=20 MODEL_DIRECT=auto|never|always"""
 import os, sys, time, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -50,7 +50,9 @@ def main():
         for lat, gbps in cfgs:
             st = bench.plume_state_torch(512, layout.D_local, dev, layout.z_offset, layout.D_global)
             comm = ext.slab_comm_link_model(float(lat), float(gbps))
-            sim = NativeSlabSimulator(layout, m, comm=comm, sweeps_per_exchange=wsw, static_flags=True, cfl_check_every=0, schedule=schedule)
+            direct = os.environ.get("MODEL_DIRECT", "auto")      # direct sends from the last edge part of a block: auto | never | always
+            sim = NativeSlabSimulator(layout, m, comm=comm, sweeps_per_exchange=wsw, static_flags=True, cfl_check_every=0, schedule=schedule,
+                                      direct_sends=direct)
             for _ in range(10):
                 sim.step(st)
             eager = timed(lambda: sim.step(st), n)
@@ -70,7 +72,7 @@ def main():
                     sys.stderr.write(f"graph capture failed: {e}\n")
             gtxt = f", graph replay {graph:.3f}" if graph is not None else ""
             best = min(eager, graph) if graph is not None else eager
-            print(f"{schedule} w={wsw} halo={halo}: link {gbps:4d} GB/s + {lat:2d} us -> eager {eager:.3f} ms/step{gtxt}   "
+            print(f"{schedule} (direct sends: {direct}) w={wsw} halo={halo}: link {gbps:4d} GB/s + {lat:2d} us -> eager {eager:.3f} ms/step{gtxt}   "
                   f"(ghost-free / middle = {base / best * 100:.1f} %)", flush=True)
             del sim, comm
 
