@@ -457,8 +457,10 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
         sim.step(bd)
     run_workload.fresh_state = False
     step, launch = (lambda: sim.step(bd)), "eager (C++ driver)"
-    if world == 1:
-        # one rank: the step is a fixed launch sequence on fixed buffers -- capture it once, replay it per step
+    if world == 1 or transport == "peer":
+        # one rank: the step is a fixed launch sequence on fixed buffers -- capture it once, replay it per step.  The peer-store
+        # transport too: its chunk counters live on the device, nothing in a captured step depends on how many exchanges came before
+        # (tests/test_peer.py::test_peer_store_step_replays_as_hip_graph); RCCL calls are left eager
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -694,6 +696,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations reported under 'also' at N=1")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous, no GPU work")
     ap.add_argument("--no-native", action="store_true", help="skip the C++ z-slab driver leg reported as 'native_driver'")
+    ap.add_argument("--peer-schedule", default="deep_beside", choices=["deep_first", "deep_beside", "edge_first", "last_pass"],
+                    help="N > 1: the sweep-block schedule of the peer-store leg (deep_beside takes the transport's direct sends)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
                     help="N > 1: whose time becomes `value` -- the C++ driver over RCCL send/recv (what north_star names; the default) or over "
                          "the peer-store communicator; both legs are run and printed either way")
@@ -829,7 +833,7 @@ def main():
             dog.start()
             try:
                 ndp, comm_p = run_native_slab(a.steps, a.warmup, world, rank, dev, bd_s, m_s, WORKLOADS[name]["res"], WORKLOADS[name]["D"],
-                                              a.schedule, transport="peer")
+                                              a.peer_schedule, transport="peer")
                 out["native_driver_peer"] = ndp
                 if comm_p:
                     out["comm_peer"] = comm_p

@@ -532,7 +532,8 @@ int fnx_jacobi_pass_mirror(const FnxGrid* g, const float* flags, const float* di
     return fail(FNX_EINVAL, "jacobi_pass_mirror: bad or overlapping second plane range");
   if ((layout != 0 && layout != 3) || (layout == 3 && !fnx::jacobi3d_quad_ok(dims(g))) || !fnx::jacobi3d_mirror_ok(dims(g), np, k_begin2 >= 0, false, layout))
     return fail(FNX_EINVAL, "jacobi_pass_mirror: this launch cannot mirror its output (fnx_jacobi_pass_mirror_ok)");
-  if (mirror->planes < 1 || !mirror->out[0] || (k_begin2 >= 0 && !mirror->out[1]))
+  if (mirror->planes < 1 || !mirror->out[0][0] || (mirror->slot_select[0] && !mirror->out[0][1]) ||
+      (k_begin2 >= 0 && (!mirror->out[1][0] || (mirror->slot_select[1] && !mirror->out[1][1]))))
     return fail(FNX_EINVAL, "jacobi_pass_mirror: bad mirror");
   hipStream_t s = (hipStream_t)stream;
   const GridDims d = dims(g);
@@ -541,7 +542,8 @@ int fnx_jacobi_pass_mirror(const FnxGrid* g, const float* flags, const float* di
   if (!reuse_mask) fnx::launch_jacobi3d_mask(d, quirks(g), flags, W.mask, s);
   fnx::ProfScope ps(FNX_PROF_JACOBI, s);
   fnx::JacobiMirror m{};
-  m.out[0] = mirror->out[0]; m.out[1] = mirror->out[1]; m.k[0] = mirror->k_first[0]; m.k[1] = mirror->k_first[1]; m.n = mirror->planes;
+  for (int r = 0; r < 2; ++r) { m.out[r][0] = mirror->out[r][0]; m.out[r][1] = mirror->out[r][1]; m.sel[r] = mirror->slot_select[r]; }
+  m.k[0] = mirror->k_first[0]; m.k[1] = mirror->k_first[1]; m.n = mirror->planes;
   m.bstride = mirror->sample_stride; m.clock = mirror->start_clock;
   fnx::launch_jacobi3d_x2(d, W.mask, div, p_in, p_out, s, k_begin, k_end, false, k_begin2, layout, &m);
   HIP_OK(hipGetLastError());

@@ -529,11 +529,12 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* p, unsigned bytes) {
 // H*W floats in both layouts (ghost-plane exchanges do not care); the passes of a solve hand the quad layout to each other
 // and only the last one writes rows.
 // MIR: the launch ALSO stores the finished planes [mir.k[r], mir.k[r] + mir.n) of plane range r (0: [kb, ke), 1: the second range) to
-// mir.out[r] + sample * mir.bstride -- the same values, the same layout within a plane.  The z-slab driver's last edge part of a sweep
+// mir.out[r][q] + sample * mir.bstride, q = (*mir.sel[r] + 1) & 1 read on the device when the launch starts (a double-buffered
+// destination whose turn a device counter tells; sel NULL: q = 0) -- the same values, the same layout within a plane.  The z-slab driver's last edge part of a sweep
 // block writes the planes its neighbours need next straight into their mapped mailboxes (peer-store communicator) as the march
 // finishes them: no transport launch copies them afterwards.  The extra store is issued by every step and dropped by the buffer range
 // check outside the mirrored planes (an offset below the range wraps around, one above it is out of range): no branch.
-struct MirrorArgs { float* out[2]; int k[2]; int n; unsigned long long bstride; unsigned long long* clock; };
+struct MirrorArgs { float* out[2][2]; const unsigned* sel[2]; int k[2]; int n; unsigned long long bstride; unsigned long long* clock; };
 template <bool ZERO, bool SPLIT, int LAY, bool MIR = false>
 __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridDims g, const unsigned* __restrict__ maskq,
                                                                       const float* __restrict__ div,
@@ -610,7 +611,8 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
   const BufRsrc r_o = make_rsrc(p_out + seg0, ncell * 4u);
   // MIR: the mirror of this segment's plane range (byte offsets relative to its first mirrored plane)
   const int mri = (MIR && kbase != kb) ? 1 : 0;
-  const BufRsrc r_x = make_rsrc(MIR ? mir.out[mri] + (size_t)b * mir.bstride : p_out, MIR ? (unsigned)((size_t)mir.n * g.HW * 4u) : 0u);
+  const int mq = (MIR && mir.sel[mri]) ? (int)((__hip_atomic_load(mir.sel[mri], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 1u) : 0;
+  const BufRsrc r_x = make_rsrc(MIR ? mir.out[mri][mq] + (size_t)b * mir.bstride : p_out, MIR ? (unsigned)((size_t)mir.n * g.HW * 4u) : 0u);
   const int mk0 = MIR ? mir.k[mri] : 0;
   // Mask bytes in row groups of four, maskq[b][k][j/4][i] = the bytes of rows 4(j/4) .. +3 of column i (jacobi3d_maskq_kernel):
   // the tile's own four rows are ONE dword load, the halo rows j0-1 / j0+4 byte 3 / byte 0 of the groups below / above (taking
@@ -992,7 +994,8 @@ void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const floa
   const unsigned* maskq = (const unsigned*)(mask + maskq_offset(g));
   if (mirror) {                                            // (jacobi3d_mirror_ok has been checked: resident set, not from zero, lay 0 or 3)
     MirrorArgs m{};
-    m.out[0] = mirror->out[0]; m.out[1] = mirror->out[1]; m.k[0] = mirror->k[0]; m.k[1] = mirror->k[1]; m.n = mirror->n;
+    for (int r = 0; r < 2; ++r) { m.out[r][0] = mirror->out[r][0]; m.out[r][1] = mirror->out[r][1]; m.sel[r] = mirror->sel[r]; }
+    m.k[0] = mirror->k[0]; m.k[1] = mirror->k[1]; m.n = mirror->n;
     m.bstride = mirror->bstride; m.clock = mirror->clock;
     if (lay == 3) jacobi3d_march2_kernel<false, false, 3, true><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2, m);
     else jacobi3d_march2_kernel<false, false, 0, true><<<grid, block, 0, s>>>(g, maskq, div, p_in, p_out, nxt, nyt, zchunk, kb, ke, kb2, m);

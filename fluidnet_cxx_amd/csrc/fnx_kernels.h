@@ -96,8 +96,9 @@ void launch_jacobi3d_mask(const GridDims& g, bool quirks, const float* flags, un
 // kb/ke: restrict the OUTPUT to planes [kb, ke) (0,0 = all planes); inputs are read from kb-1 (kb-2 for x2) on
 void launch_jacobi3d(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                      bool from_zero, hipStream_t s, int kb = 0, int ke = 0);
-// mirror of a two-sweep launch's output: planes [k[r], k[r] + n) of plane range r also go to out[r] + sample * bstride (floats)
-struct JacobiMirror { float* out[2]; int k[2]; int n; unsigned long long bstride; unsigned long long* clock; };
+// mirror of a two-sweep launch's output: planes [k[r], k[r] + n) of plane range r also go to out[r][q] + sample * bstride (floats),
+// q = (*sel[r] + 1) & 1 read on the device (sel NULL: q = 0)
+struct JacobiMirror { float* out[2][2]; const unsigned* sel[2]; int k[2]; int n; unsigned long long bstride; unsigned long long* clock; };
 bool jacobi3d_mirror_ok(const GridDims& g, int np, bool two_ranges, bool from_zero, int lay);
 void launch_jacobi3d_x2(const GridDims& g, const unsigned char* mask, const float* div, const float* p_in, float* p_out,
                         hipStream_t s, int kb = 0, int ke = 0, bool from_zero = false, int kb2 = -1, int lay = 0,

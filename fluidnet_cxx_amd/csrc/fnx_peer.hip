@@ -50,7 +50,11 @@ struct PeerHeader {                      // all words written with system-scope 
   unsigned credit[2];                    // [side I push to]: chunks that neighbour has taken out of the mailbox I fill
   unsigned abort_word;                   // != 0: every wait gives up
   unsigned done_count[4];                // workgroups of a role that have finished (this rank's own kernels only)
-  unsigned pad[7];
+  // Chunk counters per role (push lower / upper, pull lower / upper), kept ON THE DEVICE: a launch reads its chunk number n = seq + 1
+  // when it starts and its last workgroup stores it back -- no launch argument depends on how many exchanges came before, so a step
+  // with its exchanges can be captured in a HIP graph and replayed (both ends count alike: the step is deterministic).
+  unsigned seq[4];
+  unsigned pad[3];
   unsigned red_up_seq, red_dn_seq;       // control-path all-reduce: partial result from rank - 1, total from rank + 1
   float red_up[kRedMax], red_dn[kRedMax];
   // ready[side the data came from][slot][sub-chunk] = number of the chunk whose bytes of that sub-chunk have arrived: a push
@@ -76,7 +80,6 @@ struct Peer {
   char* region = nullptr;                // my region
   char* nb[2] = {nullptr, nullptr};      // the neighbours' regions as mapped here (0: lower, 1: upper)
   bool nb_ipc[2] = {false, false};       // opened with hipIpcOpenMemHandle (to be closed)
-  unsigned push_seq[2] = {0, 0}, pull_seq[2] = {0, 0};
   unsigned red_seq = 0;
   size_t sub_bytes = kSubMin;            // (a multiple of 256: pieces start on 256-byte boundaries of a slot)
   int* h_err = nullptr;                  // pinned host word the kernels raise
@@ -89,14 +92,14 @@ struct Piece { const char* src; char* dst; unsigned long long bytes, off; };    
 struct XferArgs {
   Piece push[2][kMaxPieces]; int npush[2];       // [side pushed to]
   Piece pull[2][kMaxPieces]; int npull[2];       // [side pulled from]: src is filled in by the kernel (the local mailbox)
-  char* remote_slot[2];                          // the neighbour's mailbox slot this launch fills
-  const char* local_slot[2];                     // my mailbox slot this launch empties
-  unsigned* remote_ready[2];                     // the neighbour's ready[1 - s][slot]
-  const unsigned* local_ready[2];                // my ready[s][slot]
+  char* remote_slot[2][2];                       // [side][chunk parity]: the neighbour's mailbox slots this rank fills
+  const char* local_slot[2][2];                  // my mailbox slots this rank empties
+  unsigned* remote_ready[2][2];                  // the neighbour's ready[1 - s][slot]
+  const unsigned* local_ready[2][2];             // my ready[s][slot]
   unsigned* remote_credit[2];                    // the neighbour's credit[1 - s]
+  int active[2];                                 // a neighbour on that side
   unsigned long long used[2];                    // bytes of the slot this launch fills / empties per direction
   unsigned long long sub_bytes;
-  unsigned push_n[2], pull_n[2];                 // chunk numbers (0: nothing in that direction)
   PeerHeader* me;
   int* h_err;
   unsigned long long timeout_ticks;              // wall_clock64 ticks (100 MHz)
@@ -159,8 +162,11 @@ __global__ __launch_bounds__(256) void peer_xfer_kernel(XferArgs a) {
   const int role = blockIdx.x / kBlocksPerRole, part = blockIdx.x % kBlocksPerRole;
   const int s = role & 1;
   const bool push = role < 2;
-  const unsigned n = push ? a.push_n[s] : a.pull_n[s];
-  if (n == 0) return;
+  if (!a.active[s]) return;
+  // this launch's chunk number: the role's device counter + 1 (stored back by the role's last workgroup, below: every workgroup of
+  // the role has read it by then -- it counts itself done only after its work)
+  const unsigned n = __hip_atomic_load(&a.me->seq[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const unsigned par = n & 1u;
   const unsigned nsub = (unsigned)((a.used[s] + a.sub_bytes - 1) / a.sub_bytes);
   bool ok = true;
   if (push) {
@@ -170,26 +176,29 @@ __global__ __launch_bounds__(256) void peer_xfer_kernel(XferArgs a) {
       const unsigned long long r0 = (unsigned long long)j * a.sub_bytes, r1 = r0 + a.sub_bytes < a.used[s] ? r0 + a.sub_bytes : a.used[s];
       // npush < 0: a DIRECT send -- the kernel that produced the planes has stored them into the slot itself (it ran before this
       // launch on the stream: its stores are complete); only the ready words remain to be raised
-      if (a.npush[s] >= 0) copy_range<true>(a.push[s], a.npush[s], a.remote_slot[s], r0, r1);
+      if (a.npush[s] >= 0) copy_range<true>(a.push[s], a.npush[s], a.remote_slot[s][par], r0, r1);
       __threadfence_system();
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&a.remote_ready[s][j], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) __hip_atomic_store(&a.remote_ready[s][par][j], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   } else {
     for (unsigned j = part; ok && j < nsub; j += kBlocksPerRole) {
-      ok = wait_word(&a.local_ready[s][j], n, a);
+      ok = wait_word(&a.local_ready[s][par][j], n, a);
       if (!ok) break;
       const unsigned long long r0 = (unsigned long long)j * a.sub_bytes, r1 = r0 + a.sub_bytes < a.used[s] ? r0 + a.sub_bytes : a.used[s];
-      copy_range<false>(a.pull[s], a.npull[s], const_cast<char*>(a.local_slot[s]), r0, r1);
+      copy_range<false>(a.pull[s], a.npull[s], const_cast<char*>(a.local_slot[s][par]), r0, r1);
     }
-    if (ok) {
-      // the slot is empty when every pull workgroup is through: the last one hands the credit back.  (The role is active in every
-      // launch of its direction, so after chunk n its counter stands at n * kBlocksPerRole.)
-      __threadfence_system();
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&a.me->done_count[role], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == n * (unsigned)kBlocksPerRole) __hip_atomic_store(a.remote_credit[s], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (ok) {
+    // the role's last workgroup: stores the chunk number back and -- pull -- hands the credit for the emptied slot to the neighbour.
+    // (The role is active in every launch of its direction, so after chunk n its counter stands at n * kBlocksPerRole.)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&a.me->done_count[role], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == n * (unsigned)kBlocksPerRole) {
+        __hip_atomic_store(&a.me->seq[role], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!push) __hip_atomic_store(a.remote_credit[s], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
@@ -208,14 +217,19 @@ int peer_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) {
 // DIRECT sends (FnxSlabComm.direct_begin / direct_exchange): the next chunk's slot in each neighbour's mailbox, segment i at i * stride.
 // The slot is free without a wait: this rank's previous exchange launch has completed (stream order) and saw the neighbour's chunk
 // n - 1 arrive, which that neighbour pushed behind ITS launch n - 2, whose pull emptied the slot chunk n goes into.
-int peer_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2], size_t* seg_stride, void** start_clock, void* /*stream*/) {
+int peer_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2][2], const unsigned* select[2], size_t* seg_stride,
+                      void** start_clock, void* /*stream*/) {
   Peer* p = ((PeerComm*)vctx)->p;
   if (int rc = peer_failed(p)) return rc;
   const size_t stride = (bytes + 255) & ~(size_t)255;
   if (bytes == 0 || nsegs < 1 || nsegs > kMaxPieces || stride * (size_t)nsegs > p->slot_bytes)
     return fnx::set_error(FNX_EINVAL, "peer-store direct send: %d segments of %zu bytes do not fit a mailbox slot", nsegs, bytes);
-  dst[0] = p->rank > 0 ? (void*)p->mailbox(p->nb[0], 1, (p->push_seq[0] + 1) & 1) : nullptr;
-  dst[1] = p->rank < p->nranks - 1 ? (void*)p->mailbox(p->nb[1], 0, (p->push_seq[1] + 1) & 1) : nullptr;
+  // both slots of each neighbour's mailbox; the producing kernel takes the one of chunk *select + 1 (the push counter of that side)
+  for (int s = 0; s < 2; ++s) {
+    const bool has = s == 0 ? p->rank > 0 : p->rank < p->nranks - 1;
+    for (int par = 0; par < 2; ++par) dst[s][par] = has ? (void*)p->mailbox(p->nb[s], 1 - s, par) : nullptr;
+    select[s] = has ? &p->hdr()->seq[s] : nullptr;
+  }
   *seg_stride = stride;
   if (start_clock) *start_clock = nullptr;
   return FNX_OK;
@@ -265,13 +279,14 @@ int peer_exchange_impl(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stre
       }
       a.npush[s] = direct ? -1 : nsend; a.npull[s] = nrecv;
       // (a direction with nothing to send still hands over the chunk: both ends count chunks, not bytes)
-      a.push_n[s] = ++p->push_seq[s];
-      a.pull_n[s] = ++p->pull_seq[s];
       PeerHeader* nh = (PeerHeader*)p->nb[s];
-      a.remote_slot[s] = p->mailbox(p->nb[s], 1 - s, a.push_n[s] & 1);
-      a.local_slot[s] = p->mailbox(p->region, s, a.pull_n[s] & 1);
-      a.remote_ready[s] = nh->ready[1 - s][a.push_n[s] & 1];
-      a.local_ready[s] = p->hdr()->ready[s][a.pull_n[s] & 1];
+      a.active[s] = 1;
+      for (int par = 0; par < 2; ++par) {
+        a.remote_slot[s][par] = p->mailbox(p->nb[s], 1 - s, par);
+        a.local_slot[s][par] = p->mailbox(p->region, s, par);
+        a.remote_ready[s][par] = nh->ready[1 - s][par];
+        a.local_ready[s][par] = p->hdr()->ready[s][par];
+      }
       a.remote_credit[s] = &nh->credit[1 - s];
       a.used[s] = used;
     }

@@ -337,7 +337,8 @@ int model_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* stream) 
   SLAB_HIP(hipGetLastError());
   return FNX_OK;
 }
-int model_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2], size_t* seg_stride, void** start_clock, void* /*stream*/) {
+int model_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2][2], const unsigned* select[2], size_t* seg_stride, void** start_clock,
+                       void* /*stream*/) {
   ModelCtx* c = (ModelCtx*)vctx;
   const size_t stride = (bytes + 255) & ~(size_t)255, need = stride * (size_t)nsegs;
   if (bytes == 0 || nsegs < 1 || nsegs > kModelSegs) return fnx::set_error(FNX_EINVAL, "link model direct send: bad segments");
@@ -348,7 +349,7 @@ int model_direct_begin(void* vctx, size_t bytes, int nsegs, void* dst[2], size_t
   }
   if (!c->stamp) SLAB_HIP(hipMalloc((void**)&c->stamp, sizeof(unsigned long long)));
   c->stride = stride;
-  dst[0] = c->buf[0]; dst[1] = c->buf[1];
+  for (int d = 0; d < 2; ++d) { dst[d][0] = c->buf[d]; dst[d][1] = nullptr; select[d] = nullptr; }
   *seg_stride = stride;
   if (start_clock) *start_clock = c->stamp;                 // the producing kernel stamps its own start: no launch of ours in front of it
   return FNX_OK;
@@ -932,16 +933,17 @@ static int slab_step_body(FnxSlab* s, const FnxStepParams* prm, const FnxState* 
     const bool wanted = s->cfg.direct_sends == 2 || (s->cfg.direct_sends == 0 && s->cfg.schedule == FNX_SLAB_DEEP_BESIDE);
     const bool can = wanted && s->comm.direct_begin && s->comm.direct_exchange && n == 2 && pin && (lay == 0 || lay == 3) &&
                      s->mask_valid && fnx_jacobi_pass_mirror_ok(&gj, len, both ? 1 : 0, lay) != 0;
-    void* dst[2] = {nullptr, nullptr};
+    void* dst[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    const unsigned* sel[2] = {nullptr, nullptr};
     size_t stride = 0;
     const size_t plane = (size_t)s->cfg.H * s->cfg.W;
     void* clk = nullptr;
-    if (can && s->comm.direct_begin(s->comm.ctx, (size_t)w * plane * 4, s->cfg.B, dst, &stride, &clk, q) == FNX_OK) {
+    if (can && s->comm.direct_begin(s->comm.ctx, (size_t)w * plane * 4, s->cfg.B, dst, sel, &stride, &clk, q) == FNX_OK) {
       FnxPlaneMirror m{};
       m.planes = w; m.sample_stride = stride / 4; m.start_clock = (unsigned long long*)clk;
       int r = 0;
-      if (has_lo) { m.out[r] = (float*)dst[0]; m.k_first[r] = lo; ++r; }
-      if (has_hi) { m.out[r] = (float*)dst[1]; m.k_first[r] = top - w; ++r; }
+      if (has_lo) { m.out[r][0] = (float*)dst[0][0]; m.out[r][1] = (float*)dst[0][1]; m.slot_select[r] = sel[0]; m.k_first[r] = lo; ++r; }
+      if (has_hi) { m.out[r][0] = (float*)dst[1][0]; m.out[r][1] = (float*)dst[1][1]; m.slot_select[r] = sel[1]; m.k_first[r] = top - w; ++r; }
       const int kb = has_lo ? lo - w + done : top - sp;
       SLAB_OK(fnx_jacobi_pass_mirror(&gj, st->flags, W.div, pin, pout, kb, kb + len, both ? top - sp : -1, lay, &m, W.jac, W.jac_bytes, 1, q));
       *sent = true;

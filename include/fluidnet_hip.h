@@ -156,13 +156,15 @@ int fnx_jacobi_pass_layout(const FnxGrid* g, const float* flags, const float* di
                            int reuse_mask, void* stream);
 
 /* A two-sweep pass that ALSO stores some of the planes it finishes to a second destination ("mirror"): the planes
- * [k_first[r], k_first[r] + planes) of plane range r (0: [k_begin, k_end); 1: the second range) go to out[r] + sample * sample_stride
- * floats, plane after plane, each in the layout of p_out.  What the z-slab driver's last edge part of a sweep block uses to write the
- * planes its neighbours need next straight into their mapped mailboxes (FnxSlabComm.direct_begin): the transport then has nothing left
- * to copy on the sending side.  layout 0 (rows in and out) or 3 (row-quad in and out); p_in != NULL; only launches
- * fnx_jacobi_pass_mirror_ok accepts (every (tile, plane chunk) wave resident at once). */
+ * [k_first[r], k_first[r] + planes) of plane range r (0: [k_begin, k_end); 1: the second range) go to out[r][q] + sample * sample_stride
+ * floats, plane after plane, each in the layout of p_out.  The destination is double buffered: q = (*slot_select[r] + 1) & 1, read ON
+ * THE DEVICE when the launch starts (slot_select[r] NULL: q = 0) -- whose turn it is may depend on how often a captured graph has been
+ * replayed.  What the z-slab driver's last edge part of a sweep block uses to write the planes its neighbours need next straight into
+ * their mapped mailboxes (FnxSlabComm.direct_begin): the transport then has nothing left to copy on the sending side.  layout 0 (rows in
+ * and out) or 3 (row-quad in and out); p_in != NULL; only launches fnx_jacobi_pass_mirror_ok accepts (every (tile, plane chunk) wave
+ * resident at once). */
 typedef struct FnxPlaneMirror {
-  float* out[2]; int k_first[2]; int planes; size_t sample_stride;
+  float* out[2][2]; const unsigned* slot_select[2]; int k_first[2]; int planes; size_t sample_stride;
   unsigned long long* start_clock;   /* optional DEVICE word: the launch stores the device clock (wall_clock64) there when it starts */
 } FnxPlaneMirror;
 int fnx_jacobi_pass_mirror_ok(const FnxGrid* g, int planes_per_range, int two_ranges, int layout);
@@ -331,14 +333,17 @@ typedef struct FnxSlabComm {
   /* Optional (may be NULL): called by fnx_slab_step on the rank whose step FAILED, so that its neighbours -- which may already
    * be waiting for it inside exchange() -- return FNX_ECOMM instead of hanging (RCCL: ncclCommAbort; loopback: a group flag). */
   void (*abort)(void* ctx);
-  /* Optional pair (both NULL or both set): DIRECT sends.  direct_begin(ctx, bytes, nsegs, dst, seg_stride, stream) names where the
-   * producing kernel may store the NEXT exchange's outgoing planes itself: dst[0] towards rank - 1, dst[1] towards rank + 1 (NULL at the
-   * ends of the chain), segment i of `bytes` bytes at dst[d] + i * *seg_stride bytes; FNX_EINVAL when that exchange does not fit (the
-   * driver then sends it the ordinary way).  direct_exchange(ctx, segs, nsegs, stream), enqueued behind the producing kernel on the same
-   * stream, is exchange() for segments whose send sides are already in place: it publishes them and receives.  *start_clock (may come
-   * back NULL): a device word the producing kernel is asked to store its start time in (FnxPlaneMirror.start_clock).  The peer-store
-   * communicator hands out its neighbours' mailbox slots; the link model buffers of its own, and times the transfer from that clock. */
-  int (*direct_begin)(void* ctx, size_t bytes, int nsegs, void* dst[2], size_t* seg_stride, void** start_clock, void* stream);
+  /* Optional pair (both NULL or both set): DIRECT sends.  direct_begin(ctx, bytes, nsegs, dst, select, seg_stride, start_clock, stream)
+   * names where the producing kernel may store the NEXT exchange's outgoing planes itself: towards rank - 1 (d = 0) / rank + 1 (d = 1;
+   * NULL at the ends of the chain) into dst[d][q], q = (*select[d] + 1) & 1 read on the device (FnxPlaneMirror.slot_select; select[d]
+   * NULL: q = 0), segment i of `bytes` bytes at + i * *seg_stride bytes; FNX_EINVAL when that exchange does not fit (the driver then
+   * sends it the ordinary way).  direct_exchange(ctx, segs, nsegs, stream), enqueued behind the producing kernel, is exchange() for
+   * segments whose send sides are already in place: it publishes them and receives.  *start_clock (may come back NULL): a device word
+   * the producing kernel is asked to store its start time in (FnxPlaneMirror.start_clock).  The peer-store communicator hands out its
+   * neighbours' mailbox slots (two per side, told apart by its device-side chunk counter: nothing in a captured step depends on how
+   * many exchanges came before); the link model buffers of its own, and times the transfer from that clock. */
+  int (*direct_begin)(void* ctx, size_t bytes, int nsegs, void* dst[2][2], const unsigned* select[2], size_t* seg_stride,
+                      void** start_clock, void* stream);
   int (*direct_exchange)(void* ctx, const FnxSlabSeg* segs, int nsegs, void* stream);
 } FnxSlabComm;
 /* Ordering contract of a communicator: fnx_slab_step issues exchange() on its internal communication stream (the sweep blocks of

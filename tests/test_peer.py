@@ -160,7 +160,7 @@ def _bench_leg_worker(rank, world, port, out_dir):
         m = bench.mconf_for(w)
         layout = SlabLayout(w["D"] * world, world, rank, halo=6)
         bd = bench.plume_state_torch(w["res"], layout.D_local, dev, layout.z_offset, layout.D_global)
-        out, comm = bench.run_native_slab(4, 12, world, rank, dev, bd, m, w["res"], w["D"], "deep_first", transport="peer")
+        out, comm = bench.run_native_slab(4, 12, world, rank, dev, bd, m, w["res"], w["D"], "deep_beside", transport="peer")
         if rank == 0:
             json.dump(dict(out=out, comm=comm), open(os.path.join(out_dir, "leg.json"), "w"))
         dist.barrier()
@@ -179,6 +179,77 @@ def test_bench_peer_leg_two_processes_one_gpu(tmp_path):
     mp.spawn(_bench_leg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r = json.load(open(tmp_path / "leg.json"))
     assert r["out"]["state_finite"] and r["out"]["ms_per_step"] > 0 and "peer-store" in r["out"]["transport"]
+    assert "graph" in r["out"]["launch"], r["out"]["launch"]        # the peer-store leg replays the captured step
     c = r["comm"]
     assert c["exchanges_per_step"] == 19 and c["bytes_per_neighbour_per_step"] == (4 * 4 + 5 + 16 * 6 + 1) * (1 << 20), c
     assert c["probe_6MiB_ms"] > 0 and c["wait_ms_per_step"] >= 0
+
+
+def _graph_worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    import test_slab as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        D, H, W, halo, w, schedule, iters, nreplay = case
+        cfg = dict(T.CFG, jacobiIter=iters)
+        gs = T.global_state(D, H, W, seed=9)
+        layout = SlabLayout(D, world, rank, halo)
+        st = T.local_state(gs, layout, dev)
+        comm = _peer_comm(ext, dist, rank, world, 1 << 20)
+        sim = NativeSlabSimulator(layout, cfg, comm=comm, sweeps_per_exchange=w, static_flags=True, cfl_check_every=0, schedule=schedule)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            for _ in range(2):                              # (the second step builds the BC class map the captured step reuses)
+                sim.step(st)
+            side.synchronize()
+            dist.barrier()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                sim.step(st)                                # captured: 19-odd exchanges per step -- the mailbox slots' turn differs from replay to replay
+            dist.barrier()
+            for _ in range(nreplay):
+                g.replay()
+            side.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: st[k][:, :, layout.owned_slice].cpu().numpy() for k in ("U", "density", "p")})
+        dist.barrier()
+        del g, sim, comm
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("schedule", ["deep_beside", "deep_first"])
+def test_peer_store_step_replays_as_hip_graph(tmp_path, schedule):
+    """The C++ driver's step over the peer-store transport captured in a HIP graph on each of two processes and replayed: the chunk
+    counters of the transport live on the device (and the direct sends' mailbox slot is chosen there), so no launch argument depends on
+    how many exchanges came before -- 2 eager steps + 3 replays equal 5 single-domain steps bit for bit (an odd number of exchanges per
+    step: every replay uses the other slot of each mailbox than the one before)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import test_slab as T
+    from fluidnet_cxx_amd import simulate
+    from fluidnet_cxx_amd.slab import SlabLayout
+    world, nreplay = 2, 3
+    case = (48, 20, 70, 6, 6, schedule, 20, nreplay)
+    port = _free_port()
+    mp.spawn(_graph_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    D, H, W, halo = case[:4]
+    cfg = dict(T.CFG, jacobiIter=case[6])
+    gs = T.global_state(D, H, W, seed=9)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    for _ in range(2 + nreplay):
+        simulate(cfg, bd, None, "jacobi")
+    ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
+    for r in range(world):
+        l = SlabLayout(D, world, r, halo)
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for k in ("U", "density", "p"):
+            a, b = z[k], ref[k][:, :, l.z_begin:l.z_begin + l.owned]
+            bad = a.view(np.int32) != b.view(np.int32)
+            assert not bad.any(), f"{schedule}: {k} differs on {int(bad.sum())} owned cells of rank {r} after graph replays"
