@@ -8,12 +8,18 @@
 //     header   flags + the small all-reduce slots                      written remotely, polled locally
 //     mailbox  [side: 0 filled by the lower neighbour, 1 by the upper one][slot: 2 chunks in flight][slot_bytes]
 //
-//   chunk n towards side s (n = 1, 2, ... per direction; both ends count alike, the step is deterministic), cut into sub-chunks
+//   chunk n towards side s (n = 1, 2, ... per direction; both ends count alike, the step is deterministic; the counters live in the
+//   header, on the device: a launch reads n = seq + 1 and its last workgroup stores it back, so that no launch argument depends on
+//   how many exchanges came before and a step with its exchanges can be replayed as a HIP graph), cut into sub-chunks
 //   of >= 64 KiB that one workgroup moves on its own:
 //     push  waits for credit[s] >= n - 2 in ITS header (the neighbour has emptied the slot); per sub-chunk j: stores the bytes into the
 //           neighbour's mailbox[1 - s][n & 1], fences, and sets ready[1 - s][n & 1][j] = n in the neighbour's header
 //     pull  per sub-chunk j: waits for ready[s][n & 1][j] >= n in ITS header and copies the bytes from mailbox[s][n & 1] to where the
 //           driver wants the planes; when the whole chunk is out, fences and sets credit[1 - s] = n in the neighbour's header
+//
+// DIRECT sends (direct_begin / direct_exchange): the kernel that produces the planes stores them into the neighbour's slot itself (the
+// z-slab driver's last edge part of a sweep block, fnx_jacobi_pass_mirror; the slot's turn read from the push counter) and the
+// exchange's push workgroups only raise the ready words.
 //
 // A wait that lasts longer than the timeout (a dead peer) or sees the abort word gives up, raises the rank's error word (pinned host
 // memory: the next call of the communicator fails with FNX_ECOMM without a synchronisation) and leaves the planes alone -- a spin
