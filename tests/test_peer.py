@@ -253,3 +253,72 @@ def test_peer_store_step_replays_as_hip_graph(tmp_path, schedule):
             a, b = z[k], ref[k][:, :, l.z_begin:l.z_begin + l.owned]
             bad = a.view(np.int32) != b.view(np.int32)
             assert not bad.any(), f"{schedule}: {k} differs on {int(bad.sum())} owned cells of rank {r} after graph replays"
+
+
+def _cnn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd._ext import ext
+    from fluidnet_cxx_amd.slab import NativeSlabSimulator, SlabLayout
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    import test_slab as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        D, H, W, halo = 64 * world, 40, 72, 52
+        gs = T.global_state(D, H, W, seed=6)
+        gs["U"] = (gs["U"] * 0.4).astype(np.float32)
+        net = FluidNet.from_weights(T.CNN_CFG, make_scalenet_weights(0, ndim=3), dev)
+        layout = SlabLayout(D, world, rank, halo)
+        st = T.local_state(gs, layout, dev)
+        # 64 KiB mailbox slots: the 49 ghost planes of U (3 x 49 x 11 520 B) travel in chunks
+        comm = _peer_comm(ext, dist, rank, world, 1 << 16)
+        sim = NativeSlabSimulator(layout, T.CNN_CFG, comm=comm, static_flags=True, cfl_check_every=2, method="convnet", net=net)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            for n in range(2):
+                sim.step(st)
+                torch.cuda.current_stream().synchronize()
+                np.savez(os.path.join(out_dir, f"rank{rank}_step{n}.npz"),
+                         **{k: st[k][:, :, layout.owned_slice].cpu().numpy() for k in ("U", "density", "p")})
+        dist.barrier()
+        del sim, comm
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_store_convnet_projection_two_processes(tmp_path):
+    """The CNN projection on z-slabs (fnx_slab_step, prm.method 1) over the peer-store transport, two processes on one GPU: the std's
+    sums travel along the chain of ranks (the float all-reduce that is an exact all-gather), the 49 ghost planes of U in chunks through
+    64-KiB mailbox slots, the one plane of p -- against the single-domain `simulate(..., 'convnet')`: p, U within 1e-5 of |ref|max, the
+    first step's density bit for bit (lib/model.py:118-227, lib/simulate.py:96-168)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import test_slab as T
+    from fluidnet_cxx_amd import FluidNet, simulate
+    from fluidnet_cxx_amd.slab import SlabLayout
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    world = 2
+    port = _free_port()
+    mp.spawn(_cnn_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    D, H, W, halo = 64 * world, 40, 72, 52
+    gs = T.global_state(D, H, W, seed=6)
+    gs["U"] = (gs["U"] * 0.4).astype(np.float32)
+    net = FluidNet.from_weights(T.CNN_CFG, make_scalenet_weights(0, ndim=3), dev)
+    bd = {k: torch.from_numpy(v).to(dev) for k, v in gs.items()}
+    for n in range(2):
+        simulate(T.CNN_CFG, bd, net, "convnet")
+        ref = {k: bd[k].cpu().numpy() for k in ("U", "density", "p")}
+        for r in range(world):
+            l = SlabLayout(D, world, r, halo)
+            z = np.load(tmp_path / f"rank{r}_step{n}.npz")
+            own = slice(l.z_begin, l.z_begin + l.owned)
+            if n == 0:
+                assert np.array_equal(z["density"].view(np.int32), ref["density"][:, :, own].view(np.int32)), f"density, rank {r}"
+            for k in ("p", "U"):
+                scale = float(np.abs(ref[k]).max())
+                d = float(np.abs(z[k].astype(np.float64) - ref[k][:, :, own]).max())
+                assert d <= 1e-5 * scale, f"step {n + 1}: {k} on rank {r}: max |d| = {d:.3e} > 1e-5 * {scale:.3e}"
