@@ -471,6 +471,9 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 // tile period, so about half of the transformed-weight reads miss it and are served by the Infinity Cache -- that, not
 // HBM, is the "traffic beyond the activations" FETCH_SIZE shows for these launches (it counts Infinity-Cache hits).
 #define W3_ST(p, v) do { const float2 v_ = (v); __builtin_nontemporal_store((f32x2){v_.x, v_.y}, (f32x2*)(p)); } while (0)
+#ifndef W3_ABL
+#define W3_ABL 0
+#endif
 constexpr int WCOLS = 34;                              // halo tile row: 32 pixels + halo
 constexpr int W3C = 4;                                 // input channels per stage of conv3_wino3_kernel
 inline int wino3_rw(int cout) { return cout % 64 == 0 ? 64 : 32; }   // its output channels per workgroup
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   constexpr int NB = 32 * NPG;
   constexpr int RW = 32 * NCG;
   constexpr int WROWS = 16 * C;
+  constexpr int WD = NCG * NPG == 4 ? 2 : 1;             // stages the weight DMA runs ahead (two 4-wave workgroups per CU: no room for four copies)
   constexpr int NWI = WROWS * RW / 256, NDMA = NWI / NWV;       // 1-KiB DMA instructions per stage / per wave
   constexpr int NEL = C * ROWS * WCOLS, NLD = (NEL + NT - 1) / NT;
   constexpr int NUNIT = 2 * C * NB, UPT = NUNIT / NT;          // half patches per stage / per thread
@@ -494,6 +498,8 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   __shared__ __attribute__((aligned(16))) float xt1[16 * C * NB];
   __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];
   __shared__ __attribute__((aligned(16))) float wbuf1[WROWS * RW];
+  __shared__ __attribute__((aligned(16))) float wbuf2[WD == 2 ? WROWS * RW : 4];
+  __shared__ __attribute__((aligned(16))) float wbuf3[WD == 2 ? WROWS * RW : 4];
   __shared__ __attribute__((aligned(16))) float exch[NWV * 16 * 64];   // epilogue: 4 registers x 4 outputs x 64 lanes per wave
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
   const unsigned stage_bytes = (unsigned)((size_t)C * vol * 4 - 1) + 1u;
   const int tstep = gridDim.x;
+  const float relu_lo = a.relu ? 0.f : -__builtin_inff();   // max(v, -inf) == v: the ReLU without a select per value
 
   // Tiles are numbered x fastest, then y, output-channel group, z, sample.  A workgroup's tiles are blockIdx.x + k*gridDim.x:
   // the tile's digits are advanced by the digits of the step with carries (one integer division chain per workgroup, not
@@ -573,20 +580,26 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   };
   // ---- weight stream (one stage ahead): the stage's [16][C][RW] image is one contiguous block of the packed weights
   // ([dz][Cin/C][Cout/RW] blocks); DMA instruction q of this wave moves its floats [wi*256, (wi+1)*256), wi = wave + NWV*q
-  const float* wW;                                      // block (dz 0, chunk 0) of the stream's output-channel group
+  // (buffer_load_dwordx4 ... lds, not global_load_lds: the compiler counts a FLAT-encoded DMA as a flat access that may return
+  // out of order and turns every later wait -- the halo registers, the transform's LDS reads -- into a wait for ALL of them)
+  typedef __attribute__((address_space(3))) void* W3Lds;
+  typedef __attribute__((address_space(3))) float* W3LdsF;
+  const BufRsrcC wrs = make_rsrc_c(wt, 0x7ffffff0u);
+  const unsigned wlane = (unsigned)(wave * 256 + lane * 4) * 4u;   // per-lane byte offset inside a DMA instruction's 1 KiB x NWV
+  unsigned wgrp;                                        // byte offset of block (dz 0, chunk 0) of the stream's output-channel group
   int wblk;                                             // (dz, chunk) block index of the cursor
-  const size_t wstep = (size_t)ngrp * (16 * C * RW);
+  const unsigned wstep = (unsigned)ngrp * (16 * C * RW) * 4u;
   auto enter_W = [&](const Tile& T) __attribute__((always_inline)) {
-    wW = wt + (size_t)T.grp * (16 * C * RW) + (size_t)wave * 256 + lane * 4; wblk = dz_lo_of(T) * nchunk;
+    wgrp = (unsigned)T.grp * (16 * C * RW) * 4u; wblk = dz_lo_of(T) * nchunk;
     __builtin_amdgcn_sched_barrier(0);
   };
   enter_W(T0);
   auto stage_weights = [&](float* wdst) __attribute__((always_inline)) {
-    const float* sb = wW + (size_t)wblk * wstep;
+    const unsigned sb = wgrp + (unsigned)wblk * wstep;
 #pragma unroll
     for (int q = 0; q < NDMA; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (size_t)NWV * 256 * q),
-                                       (__attribute__((address_space(3))) void*)(&wdst[(wave + NWV * q) * 256]), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (W3Lds)((W3LdsF)&wdst[0] + (wave + NWV * q) * 256), 16, wlane,
+                                               sb + (unsigned)(NWV * 256 * q) * 4u, 0, 0);
     ++wblk;
   };
   // ---- input transform.  Half patch u = threadIdx.x + NT*i: block n = u % NB, channel c = (u / NB) % C, row half
@@ -615,13 +628,14 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
       e[j][0] = *(const float2*)(rawsrc + rd_off[i][j]); e[j][1] = *(const float2*)(rawsrc + rd_off[i][j] + 2);
     }
   };
-  auto xf_cols = [&](int i) __attribute__((always_inline)) {
+  // hpk: the row half where the caller knows it at compile time (0 / 1: a plain add or subtract), 2: by the sign mask
+  auto xf_cols = [&](int i, int hpk = 2) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float P = s & 1 ? e[0][s >> 1].y : e[0][s >> 1].x, Q = s & 1 ? e[1][s >> 1].y : e[1][s >> 1].x;
       const float R = s & 1 ? e[2][s >> 1].y : e[2][s >> 1].x, S = s & 1 ? e[3][s >> 1].y : e[3][s >> 1].x;
       tc[0][s] = P - Q;
-      tc[1][s] = R + __builtin_bit_cast(float, __builtin_bit_cast(unsigned, S) ^ sgn[i]);
+      tc[1][s] = hpk == 0 ? R + S : hpk == 1 ? R - S : R + __builtin_bit_cast(float, __builtin_bit_cast(unsigned, S) ^ sgn[i]);
     }
   };
   auto xf_rows_store = [&](int i, float* xtdst) __attribute__((always_inline)) {
@@ -636,12 +650,14 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   // ---- prologue (first tile of the workgroup only): halo tiles of stages 0 and 1, weights of stage 0, transform of stage 0
   prefetch();
   stage_weights(wbuf0);
+  if (WD == 2) stage_weights(wbuf1);
   store_raw(raw0);
   prefetch();
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < UPT; ++i) { xf_load(i, raw0); xf_cols(i); xf_rows_store(i, xt0); }
   store_raw(raw1);
+  prefetch();
   __syncthreads();
 
   // ---- MFMA stream ----
@@ -661,17 +677,18 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   // k-step is issued first; without it the accumulators start from zero).  The weight/transform stream (stage s+1) and the
   // halo stream (stage s+2) are always live: behind a workgroup's last tile they run on a stand-in tile whose results
   // nobody reads, which keeps every phase the same straight-line code.
-  auto phase_sched = [&](auto m0, auto late_, const float* wcur, float* wnext, const float* xcur, float* xnext,
+  auto phase_sched = [&](auto m0, auto late_, auto hpw_, const float* wcur, float* wnext, const float* xcur, float* xnext,
                          const float* rawnext, float* rawfree) __attribute__((always_inline)) {
     constexpr bool M0 = decltype(m0)::value;
-    constexpr bool LATE = decltype(late_)::value;         // the second wave of each SIMD runs its fillers half a phase later
+    constexpr bool LATE = decltype(late_)::value;
+    constexpr int HPW = decltype(hpw_)::value;            // the row half of this wave's half patches (UPT == 1); with UPT == 2 it is i         // the second wave of each SIMD runs its fillers half a phase later
     // (the fetches of the phase are issued BEHIND its first MFMAs, whose operands are already in registers: the matrix
     // pipe restarts right behind the barrier instead of idling through ~40 address/VMEM/LDS instructions per wave)
     constexpr int S_XF = LATE ? 4 : 0, S_DMA = LATE ? 5 : 1, S_K0 = LATE ? 6 : 2, S_K1 = LATE ? 11 : 7, S_RAW = LATE ? 14 : 13;
 #pragma unroll
     for (int slot = 0; slot < 16; ++slot) {
       const int ks = slot < 8 ? 1 : 0, p = slot & 7;
-      if (slot >= 8 || M0) {
+      if (!(W3_ABL & 2) && (slot >= 8 || M0)) {
         if (slot >= 8 && !M0) {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][p], bv[ks][p], zero, 0, 0, 0);
@@ -679,23 +696,29 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
           acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][p], bv[ks][p], acc[p], 0, 0, 0);
         }
       }
+      if ((W3_ABL & 2) && (slot >= 8 || M0)) asm volatile("; keep" :: "v"(av[ks][p]), "v"(bv[ks][p]));
       __builtin_amdgcn_sched_barrier(0);
-      if (slot == 0) prefetch();
-      if (slot == S_XF) xf_load(0, rawnext);
-      if (slot == S_DMA) stage_weights(wnext);
-      if (slot == S_K0) load_k(0, wcur, xcur);
+      if (!(W3_ABL & 4) && slot == S_XF) xf_load(0, rawnext);
+      if (!(W3_ABL & 16) && slot == S_DMA) stage_weights(wnext);
+      if (!(W3_ABL & 8) && slot == S_DMA + 1) { store_raw(rawfree); prefetch(); }   // the halo tile fetched one phase ago; then the next one
+      if (!(W3_ABL & 32) && slot == S_K0) load_k(0, wcur, xcur);
       // half patch i: loaded at slot S_XF + 4i, columns 3 slots later, rows + stores 4 slots later
       const int rel = slot - S_XF, ui = rel / 4, us = rel % 4;
-      if (rel >= 0) {
+      if (!(W3_ABL & 4) && rel >= 0) {
         if (us == 0 && ui > 0 && ui < UPT) xf_load(ui, rawnext);
-        if (us == 3 && ui < UPT) xf_cols(ui);
+        if (us == 3 && ui < UPT) xf_cols(ui, UPT == 2 ? ui : HPW);
         if (us == 0 && ui > 0 && ui - 1 < UPT) xf_rows_store(ui - 1, xnext);
       }
-      if (slot == S_K1) load_k(1, wcur, xcur);             // the registers of k-step 1 are free: its MFMAs have all been issued
-      if (slot == S_RAW) store_raw(rawfree);
+      if (!(W3_ABL & 32) && slot == S_K1) load_k(1, wcur, xcur);             // the registers of k-step 1 are free: its MFMAs have all been issued
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    // the phase's own weight DMA (stage s+2) may still be in flight; everything older -- the DMA of stage s+1, the halo loads --
+    // has landed: vmcnt(NDMA), lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    constexpr int NFLY = NLD + (WD == 2 ? NDMA : 0);
+    __builtin_amdgcn_s_waitcnt((NFLY & 15) | ((NFLY >> 4) << 14) | 0x70);
+    if (!(W3_ABL & 1)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
@@ -706,10 +729,10 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   // spill 600 registers at the joins).
   // (2D only: with the 3D layers' 48 stages per tile the late schedule measured 5 % slower, 82 -> 86 ms at 256^3)
   constexpr bool STAGGER = NWV == 8 && UPT == 1 && !IS3D;
-  auto run = [&](auto late_) __attribute__((always_inline)) {
+  auto run = [&](auto late_, auto hpw_) __attribute__((always_inline)) {
     auto phase = [&](auto m0, const float* wcur, float* wnext, const float* xcur, float* xnext, const float* rawnext,
                      float* rawfree) __attribute__((always_inline)) {
-      phase_sched(m0, late_, wcur, wnext, xcur, xnext, rawnext, rawfree);
+      phase_sched(m0, late_, hpw_, wcur, wnext, xcur, xnext, rawnext, rawfree);
     };
     int tM = blockIdx.x;
     Tile TM = T0;
@@ -717,17 +740,27 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
       const int niter = (dz_hi_of(TM) - dz_lo_of(TM)) * nchunk;   // even, >= 4 (the host checks Cin % (4 C))
       const bool more = tM + tstep < ntiles;
       const Tile TN = more ? next_tile(TM) : TM;          // the streams' next tile (stand-in behind the last one: this tile again)
-      phase(F_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);    // stage 0
-      for (int it = 1; it + 1 < niter; it += 2) {
-        phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);  // stage it (odd)
-        if (it + 3 == niter) enter_R(TN);         // stage niter-2 fetches the halo tile of the next tile's stage 0
-        phase(T_{}, wbuf0, wbuf1, xt0, xt1, raw1, raw0);  // stage it+1 (even)
-      }
-      enter_W(TN);                                        // stage niter-1 fetches the weights of the next tile's stage 0
-      phase(T_{}, wbuf1, wbuf0, xt1, xt0, raw0, raw1);
+      // four stages per round: stage s computes on weight copy s % 4 and DMAs stage s+2 into copy (s+2) % 4
+      auto group = [&](auto m0, bool last) __attribute__((always_inline)) {
+        phase(m0, wbuf0, WD == 2 ? wbuf2 : wbuf1, xt0, xt1, raw1, raw0);
+        if (last) enter_R(TN);                            // stage niter-3 fetches the halo tile of the next tile's stage 0
+        phase(T_{}, wbuf1, WD == 2 ? wbuf3 : wbuf0, xt1, xt0, raw0, raw1);
+        if (last && WD == 2) enter_W(TN);                 // ... and stage niter-WD its weights
+        phase(T_{}, WD == 2 ? wbuf2 : wbuf0, WD == 2 ? wbuf0 : wbuf1, xt0, xt1, raw1, raw0);
+        if (last && WD == 1) enter_W(TN);
+        phase(T_{}, WD == 2 ? wbuf3 : wbuf1, WD == 2 ? wbuf1 : wbuf0, xt1, xt0, raw0, raw1);
+      };
+      group(F_{}, niter == 4);
+      for (int it = 4; it < niter; it += 4) group(T_{}, it + 4 == niter);
       // the second k-step of the last stage
 #pragma unroll
       for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][p], bv[1][p], acc[p], 0, 0, 0);
+      if (W3_ABL & 64) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) asm volatile("; keep" :: "v"(acc[p]));
+        if (!more) break;
+        tM += tstep; TM = TN; continue;
+      }
 
       // Output transform A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]); this wave holds rows 2h, 2h+1 of M (acc[4*(row-2h) + s]):
       //   h = 0:  t0 = M0 + M1, t1 = M1          h = 1:  t0 = M2, t1 = -M2 - M3
@@ -747,6 +780,13 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
 #pragma unroll
           for (int j = 0; j < 2; ++j) bias2[round][j] = *(const f32x2*)&a.bias[co_own + 8 * round + 2 * j];
         float* obase = a.y + ((size_t)TM.b * a.cout + co_own) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x;
+        // full tiles store through a buffer resource on the wave's 16 channels: one 32-bit lane offset per pixel row (the
+        // channel quad of the lane's half included) and the channel in the scalar offset -- no 64-bit address arithmetic on
+        // the vector ALU, which runs in the matrix pipe's time (tools/ubench/mfma_coexec.hip)
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const BufRsrcC yrs = make_rsrc_c(a.y + ((size_t)TM.b * a.cout + TM.grp * RW + cg * 32 + 16 * h) * vol, (unsigned)(16 * vol * 4 - 1) + 1u);
+        const unsigned yoff0 = (unsigned)(((size_t)(4 * half) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x) * 4), yoff1 = yoff0 + (unsigned)a.W * 4u;
+        const unsigned chan_bytes = (unsigned)(vol * 4);
         const bool inx = x < a.W, iny = y < a.H, inx1 = x + 1 < a.W, iny1 = y + 1 < a.H;
         const bool full = (tx0 + 32 <= a.W) & (ty0 + 4 * NPG <= a.H);       // (wave-uniform) no clipped pixel in the tile
         f32x2* ex_out = (f32x2*)&exch[wave * 16 * 64] + lane;
@@ -782,13 +822,16 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               v[q] = (pt[q] + ex_in[(j * 4 + q) * 64]) + bias2[round][j];
-              if (a.relu) v[q] = __builtin_elementwise_max(v[q], (f32x2){0.f, 0.f});
+              v[q] = __builtin_elementwise_max(v[q], (f32x2){relu_lo, relu_lo});
             }
             float* o0 = obase + (size_t)(8 * round + 2 * j) * vol;
             float* o1 = o0 + vol;
             if (full) {
-              W3_ST((float2*)o0, make_float2(v[0].x, v[1].x)); W3_ST((float2*)(o0 + a.W), make_float2(v[2].x, v[3].x));
-              W3_ST((float2*)o1, make_float2(v[0].y, v[1].y)); W3_ST((float2*)(o1 + a.W), make_float2(v[2].y, v[3].y));
+              const unsigned c0 = (unsigned)(8 * round + 2 * j) * chan_bytes, c1 = c0 + chan_bytes;
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v[0].x, v[1].x}), yrs, yoff0, c0, 2);   // (aux 2: non-temporal)
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v[2].x, v[3].x}), yrs, yoff1, c0, 2);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v[0].y, v[1].y}), yrs, yoff0, c1, 2);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v[2].y, v[3].y}), yrs, yoff1, c1, 2);
             } else if (inx & iny) {
               if (inx1) {
                 *(float2*)o0 = make_float2(v[0].x, v[1].x); *(float2*)o1 = make_float2(v[0].y, v[1].y);
@@ -815,8 +858,11 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
       tM += tstep; TM = TN;
     }
   };
-  if (STAGGER && wave >= NWV / 2) run(std::integral_constant<bool, STAGGER>{});
-  else run(std::integral_constant<bool, false>{});
+  // (the same split serves the input transform: with one half patch per thread the upper half of the waves has the rows 2, 3
+  // of B^T d B, and each copy of the loop knows its half at compile time)
+  static_assert(UPT == 2 || NB * C == NT / 2, "row half = upper half of the waves");
+  if (UPT == 1 && wave >= NWV / 2) run(std::integral_constant<bool, STAGGER>{}, std::integral_constant<int, 1>{});
+  else run(std::integral_constant<bool, false>{}, std::integral_constant<int, 0>{});
 }
 
 // blob: (Cout,Cin,3x3) -> G g G^T as [16][Cin][Cout], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
@@ -1092,6 +1138,7 @@ void launch_conv_mfma(const ConvArgs& a, bool is3d, hipStream_t s) {
 bool launch_conv_wino(const ConvArgs& a, bool is3d, const float* wt, hipStream_t s) {
   if (a.cin % (4 * W3C) != 0 || a.cout % 32 != 0) return false;
   if (a.D != 1 && !is3d) return false;
+  if ((size_t)16 * a.D * a.H * a.W * 4 >= 0xfffffff0u) return false;   // the epilogue's 32-bit offsets span a wave's 16 output channels
   // 64 output channels per workgroup where Cout allows it; 8-wave workgroups (two pixel groups share a stage's weights)
   // when the launch is large enough (measured at 1024^2: 64->32 297 -> 274 us against 4-wave workgroups)
   const int ncg = a.cout % 64 == 0 ? 2 : 1;

@@ -23,12 +23,13 @@ for case in [c for c in sys.argv[1:] if c in ("2d", "3d")] or ["2d", "3d"]:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         ext.profile_enable(True)
-        for _ in range(2): net.multiScale(x)
+        npf = 2 if is3d else 10
+        for _ in range(npf): net.multiScale(x)
         torch.cuda.synchronize()
         tm = {k: ext.profile_read(v) for k, v in PROF.items()}
         wk = {k: ext.profile_read_work(v) for k, v in PROF.items()}
         ext.profile_enable(False)
-        txt = ", ".join(f"{k} {t / 2:.3f} ms/{c // 2}" for k, (t, c) in tm.items() if c)
+        txt = ", ".join(f"{k} {t / npf:.3f} ms/{c // npf}" for k, (t, c) in tm.items() if c)
         util = wk["conv_bf16"] / (tm["conv_bf16"][0] * 1e-3) / 2.5e15 if tm["conv_bf16"][1] else 0
         print(f"{case} {mode}: forward {ms:.3f} ms; {txt}; bf16 MFMA util {util:.3f}", flush=True)
         del net
