@@ -567,9 +567,11 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   float stage[NLD];
   auto prefetch = [&]() __attribute__((always_inline)) {
     const int zz = IS3D ? rz + rdz - 1 : 0;
-    const BufRsrcC r = make_rsrc_c(xR + (size_t)rc0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
+    const BufRsrcC r = (W3_ABL & 128) ? make_rsrc_c(a.x, 1u << 20)
+                                      : make_rsrc_c(xR + (size_t)rc0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
 #pragma unroll
-    for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
+    for (int t = 0; t < NLD; ++t)
+      stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (W3_ABL & 128) ? (unsigned)(threadIdx.x * 4 + t * 2048) : uoff[t], 0, 0));
     rc0 += C;
     if (rc0 >= a.cin) { rc0 = 0; ++rdz; }
   };
@@ -784,9 +786,11 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
         // channel quad of the lane's half included) and the channel in the scalar offset -- no 64-bit address arithmetic on
         // the vector ALU, which runs in the matrix pipe's time (tools/ubench/mfma_coexec.hip)
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const BufRsrcC yrs = make_rsrc_c(a.y + ((size_t)TM.b * a.cout + TM.grp * RW + cg * 32 + 16 * h) * vol, (unsigned)(16 * vol * 4 - 1) + 1u);
-        const unsigned yoff0 = (unsigned)(((size_t)(4 * half) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x) * 4), yoff1 = yoff0 + (unsigned)a.W * 4u;
-        const unsigned chan_bytes = (unsigned)(vol * 4);
+        const BufRsrcC yrs = (W3_ABL & 256) ? make_rsrc_c(a.y + (size_t)blockIdx.x * 65536, 1u << 20)
+                                            : make_rsrc_c(a.y + ((size_t)TM.b * a.cout + TM.grp * RW + cg * 32 + 16 * h) * vol, (unsigned)(16 * vol * 4 - 1) + 1u);
+        const unsigned yoff0 = (W3_ABL & 256) ? threadIdx.x * 8u : (unsigned)(((size_t)(4 * half) * vol + (size_t)TM.z * plane + (size_t)y * a.W + x) * 4),
+                       yoff1 = (W3_ABL & 256) ? yoff0 + 4096u : yoff0 + (unsigned)a.W * 4u;
+        const unsigned chan_bytes = (W3_ABL & 256) ? 8192u : (unsigned)(vol * 4);
         const bool inx = x < a.W, iny = y < a.H, inx1 = x + 1 < a.W, iny1 = y + 1 < a.H;
         const bool full = (tx0 + 32 <= a.W) & (ty0 + 4 * NPG <= a.H);       // (wave-uniform) no clipped pixel in the tile
         f32x2* ex_out = (f32x2*)&exch[wave * 16 * 64] + lane;

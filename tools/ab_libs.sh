@@ -2,7 +2,7 @@
 # A/B of two builds of libfluidnet_hip.so on ONE box (boxes differ by a few per cent, so do runs minutes apart):
 #   here:     tools/ab_libs.sh build <name> [git-rev]   -> variants/libfluidnet_hip_<name>.so from the working tree's (or the
 #                                                           revision's) fnx_cnn.hip and the other objects of the current build
-#   GPU box:  tools/ab_libs.sh run <nameA> <nameB> <rounds> -- <command>     (alternates A, B; prints the command's output)
+#   GPU box:  tools/ab_libs.sh run <rounds> <name>... -- <command>     (round-robin over the builds; prints the command's output)
 set -u
 cd "$(dirname "$0")/.."
 V=variants
@@ -16,10 +16,13 @@ if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libfluidnet_hip_$2.so $objs $V/fnx_cnn_$2.o && echo built $2
   rm -f $V/fnx_cnn_$2.o fluidnet_cxx_amd/csrc/.ab_$2.hip
 else
-  A=$2; B=$3; n=$4; shift 5
+  n=$2; shift 2
+  names=()
+  while [ "$1" != "--" ]; do names+=("$1"); shift; done
+  shift
   cp fluidnet_cxx_amd/libfluidnet_hip.so /tmp/libfluidnet_hip.keep
   for i in $(seq $n); do
-    for v in $A $B; do
+    for v in "${names[@]}"; do
       cp $V/libfluidnet_hip_$v.so fluidnet_cxx_amd/libfluidnet_hip.so
       echo -n "$v: "; "$@" 2>&1 | tail -n +1
     done

@@ -19,6 +19,13 @@ __global__ __launch_bounds__(512, 2) void burn(float* out, int iters) {
   for (int j = 0; j < 16; ++j) { x[j] = j; y[j] = (f32x2){(float)j, 1.f}; z[j] = y[j]; }
   const f32x2 c2 = {c, c};
   const float* lp = lds + (threadIdx.x & 63) * 2 + (threadIdx.x >> 6) * 128;
+  const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)lp;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 q4[4] = {};
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out, (short)0, 256 * 512 * 4, 0x00020000);
+  const unsigned goff = (blockIdx.x * 512 + threadIdx.x) * 4u, goff4 = (blockIdx.x * 512 + (threadIdx.x & ~3u)) * 4u;
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 16384u * 4u + (threadIdx.x >> 6) * 1024u);
+  int sreg = 1;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -29,15 +36,27 @@ __global__ __launch_bounds__(512, 2) void burn(float* out, int iters) {
         const int j = (i * K + k) & 15;
         if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[j]) : "v"(c));
         if (KIND == 1) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[j]) : "v"(c2));
-        if (KIND == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(z[j]) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)lp), "n"(0));
+        if (KIND == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(z[j]) : "v"(la), "n"(0));
+        if (KIND == 3) asm volatile("ds_write_b32 %0, %1" :: "v"(la), "v"(x[j]) : "memory");
+        if (KIND == 4) asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(y[j]) : "memory");
+        if (KIND == 5) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(x[j]) : "v"(goff), "s"(rs) : "memory");
+        if (KIND == 6) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q4[j & 3]) : "v"(goff4), "s"(rs) : "memory");
+        if (KIND == 7) asm volatile("ds_read2st64_b64 %0, %1 offset1:4" : "=v"(q4[j & 3]) : "v"(la));
+        if (KIND == 8) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[j]) : "v"(c));
+        if (KIND == 9) asm volatile("v_max_i32 %0, %0, %1" : "+v"(x[j]) : "v"(c));
+        if (KIND == 10) asm volatile("s_mov_b32 m0, %2\n s_nop 0\n buffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(goff4), "s"(rs), "s"(m0v) : "memory");
+        if (KIND == 11) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(sreg));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (KIND == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (KIND == 2 || KIND == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (KIND == 5 || KIND == 6 || KIND == 10) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   float r = 0.f;
   for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) r += acc[i][j];
   for (int j = 0; j < 16; ++j) r += x[j] + y[j].x + y[j].y + z[j].x + z[j].y;
+  for (int j = 0; j < 4; ++j) r += q4[j].x + q4[j].w;
+  r += sreg;
   out[blockIdx.x * 512 + threadIdx.x] = r;
 }
 
@@ -68,5 +87,13 @@ int main() {
   run<1, 8, false>(out, "v_pk_add_f32");
   run<2, 1, true>(out, "ds_read_b64"); run<2, 2, true>(out, "ds_read_b64"); run<2, 4, true>(out, "ds_read_b64");
   run<2, 4, false>(out, "ds_read_b64");
+  run<7, 1, true>(out, "ds_read2st64"); run<7, 2, true>(out, "ds_read2st64"); run<7, 2, false>(out, "ds_read2st64");
+  run<3, 1, true>(out, "ds_write_b32"); run<3, 4, true>(out, "ds_write_b32"); run<3, 4, false>(out, "ds_write_b32");
+  run<4, 1, true>(out, "ds_write_b64"); run<4, 4, true>(out, "ds_write_b64");
+  run<5, 1, true>(out, "buf_load_b32"); run<5, 2, true>(out, "buf_load_b32"); run<5, 2, false>(out, "buf_load_b32");
+  run<6, 1, true>(out, "buf_load_b128"); run<6, 1, false>(out, "buf_load_b128");
+  run<10, 1, true>(out, "buf_b128_lds"); run<10, 1, false>(out, "buf_b128_lds");
+  run<8, 4, true>(out, "v_max_f32"); run<9, 4, true>(out, "v_max_i32");
+  run<11, 8, true>(out, "s_mul_i32");
   return 0;
 }

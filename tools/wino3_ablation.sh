@@ -1,6 +1,8 @@
 #!/bin/bash
 # Timing probes of conv3_wino3_kernel: variants of libfluidnet_hip.so with pieces of the kernel's phase compiled out
-# (-DW3_ABL=bits: 1 phase barrier, 2 MFMAs, 4 input transform, 8 halo fetch + store, 16 weight DMA, 32 operand reads, 64 epilogue).
+# (-DW3_ABL=bits: 1 phase barrier, 2 MFMAs, 4 input transform, 8 halo fetch + store, 16 weight DMA, 32 operand reads, 64 epilogue;
+# 128 every halo load from one cache-resident 8 KB, 256 every full-tile store into 64 KB per workgroup -- the same instructions
+# without their memory traffic; bits 2 and 32 leave the MFMA operands undefined and the compiler then drops MFMAs: not usable).
 #   here (no GPU):   tools/wino3_ablation.sh build 0 1 2 ...      -> variants/libfluidnet_hip_w3_<bits>.so
 #   GPU box:         tools/wino3_ablation.sh run 2d|3d            -> one line per variant
 set -u
