@@ -270,6 +270,13 @@ typedef __amdgpu_buffer_rsrc_t BufRsrcC;
 __device__ __forceinline__ BufRsrcC make_rsrc_c(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
+// 16 bytes per lane global -> LDS (buffer_load_dwordx4 ... lds: the wave's 1 KiB lands at `dst`, wave-uniform).  In a __device__
+// function of its own: called from a __global__ template directly, the 16-byte form fails the builtin's size check in the HOST
+// pass (no gfx950 there), silently, and the kernel's host stub is then never emitted (undefined symbol at load time).
+typedef __attribute__((address_space(3))) float* LdsF;
+__device__ __forceinline__ void dma16_to_lds(const BufRsrcC r, LdsF dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
 
 template <int CB, int PR, bool IS3D, int CH = MF_CHUNK, int WPS = 2>
 __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
@@ -337,20 +344,27 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
   };
-  // Weights of one stage go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs),
-  // one stage ahead of their use; the A operand is then a conflict-free ds_read_b32.
-  auto stage_weights = [&](int dz, int c0, float* wdst) {
+  // Weights of one stage go global -> LDS directly (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no VGPRs),
+  // one stage ahead of their use; the A operand is then a conflict-free ds_read_b32.  (A buffer load, not global_load_lds:
+  // behind the FLAT-encoded DMA the compiler turns every later wait into a wait for everything -- the operand reads of the
+  // next MFMA group, just issued, included; docs/history/r05_wino3_pipeline.md.)  The lane's part of the offset is fixed,
+  // the stage's part is scalar: no address arithmetic on the vector ALU per stage.
+  const BufRsrcC wrs = make_rsrc_c(a.w, 0x7ffffff0u);
+  constexpr int NWQ = (NWI + 3) / 4;
+  unsigned wvoff[NWQ];
 #pragma unroll
-    for (int q = 0; q < (NWI + 3) / 4; ++q) {
+  for (int q = 0; q < NWQ; ++q) {
+    int row = (wave + 4 * q) * RPI + lane / LPR;
+    if (row > WROWS - 1) row = WROWS - 1;               // tail lanes re-read the last row (their LDS slots are never used)
+    const int tap = row / CH, ci = row - tap * CH;
+    wvoff[q] = (unsigned)(((size_t)tap * a.cin + ci) * a.cout + cout0 + (lane % LPR) * 4) * 4u;
+  }
+  auto stage_weights = [&](int dz, int c0, float* wdst) {
+    const unsigned soff = (unsigned)(((size_t)dz * 9 * a.cin + c0) * a.cout) * 4u;
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
       const int wi = wave + 4 * q;                      // wave-uniform
-      if (wi < NWI) {
-        int row = wi * RPI + lane / LPR;
-        if (row > WROWS - 1) row = WROWS - 1;           // tail lanes re-read the last row (their LDS slots are never used)
-        const int tap = row / CH, ci = row - tap * CH;
-        const float* src = a.w + ((size_t)(dz * 9 + tap) * a.cin + c0 + ci) * a.cout + cout0 + (lane % LPR) * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
-      }
+      if (wi < NWI) dma16_to_lds(wrs, (LdsF)&wdst[0] + wi * 256, wvoff[q], soff);
     }
   };
   // iteration space: (dz, c0) pairs with an in-range z plane
@@ -431,9 +445,9 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 // 16 multiplies per 4 outputs instead of 36: the contraction over input channels becomes 16 independent GEMMs (one per
 // position p of the 4x4 transform domain)
 //   D_p[cout 32][block 32] += Wt_p[cout][k] * Xt_p[k][block],   k = two consecutive input channels
-//   raw halo tile  global -> registers (prefetched two stages ahead) -> LDS
+//   raw halo tile  global -> registers (fetched three stages ahead) -> LDS at the start of the next phase
 //   B^T d B        per (channel, block) half patch by all threads, LDS -> LDS [position pair][c][block][2]
-//   G g G^T        precomputed at pack time; the stage's slice goes global -> LDS by global_load_lds (DMA, one stage ahead)
+//   G g G^T        precomputed at pack time; the stage's slice goes global -> LDS by buffer_load_dwordx4 ... lds (DMA, one stage ahead)
 // and the epilogue applies A^T . A per output channel register, adds the bias, clamps (ReLU) and stores pixel pairs.
 // The 16 positions of a (32 output channels x 32 blocks) tile are split over TWO waves (8 positions = 128 accumulator
 // registers each), so that a wave fits a 256-register budget and two waves share a SIMD: while one is between its barriers
@@ -450,14 +464,16 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 // transform, barrier, operand reads, MFMAs -- and paid a full prologue and epilogue per 256-pixel tile: time = rounds x
 // (5.5 us + stages x 1.31 us) against 0.91 us of MFMA work per stage, 47 % of the MFMA peak at 1024^2):
 //  * every LDS image has two copies and a phase has ONE barrier.  Between two barriers a wave issues
-//      global -> registers   halo tile of stage s+2          (first; lands during the MFMAs)
+//      registers -> LDS      halo tile of stage s+2, fetched during the phase before (into the copy the transform of stage s read
+//                            one phase ago), then
+//      global -> registers   halo tile of stage s+3          (it has until this point of the NEXT phase to land; the barrier
+//                            in between waits for vmcnt(NLD): these loads stay in flight, the weight DMA issued before them lands)
 //      global -> LDS (DMA)   transformed weights of stage s+1
 //      LDS -> LDS            input transform of stage s+1 (halo tile s+1 -> xt[s+1]) in the gaps of the MFMA stream
 //      16 MFMAs              second k-step of stage s-1, then first k-step of stage s: the stream is rotated by half a
 //                            stage against the barriers and each k-step's operands are read half a phase before its
 //                            MFMAs, so a wave leaves a barrier with its next 8 MFMAs' operands already in registers
-//      registers -> LDS      halo tile of stage s+2 (into the copy the transform of stage s read one phase ago)
-//  * a workgroup walks over tiles (tile = blockIdx.x, += gridDim.x) and the three streams -- halo fetch (two stages ahead),
+//  * a workgroup walks over tiles (tile = blockIdx.x, += gridDim.x) and the three streams -- halo fetch (three stages ahead),
 //    weights + transform (one ahead), MFMAs -- each carry their own tile: the fetches run on into the next tile while the
 //    MFMAs finish the current one, so only the first tile of a workgroup pays a prologue.  Between tiles: the last
 //    k-step, the output transform + half-exchange (its own LDS buffer: the xt copies already hold the next tile), stores.
@@ -536,7 +552,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   auto dz_lo_of = [&](const Tile& T) __attribute__((always_inline)) { return IS3D && T.z == 0 ? 1 : 0; };
   auto dz_hi_of = [&](const Tile& T) __attribute__((always_inline)) { return IS3D ? (T.z == a.D - 1 ? 2 : 3) : 1; };
 
-  // ---- halo-fetch stream (two stages ahead of the MFMAs): its tile is (xR, rz), cursor (rdz, rc0) ----
+  // ---- halo-fetch stream (three stages ahead of the MFMAs): its tile is (xR, rz), cursor (rdz, rc0) ----
   const float* xR;                                      // sample base of the stream's tile
   int rz, rdz, rc0 = 0;
   // per-thread slots of the [C][ROWS][34] halo tile: the tile-independent part of the byte offset and (row, col); a slot
@@ -584,8 +600,6 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   // ([dz][Cin/C][Cout/RW] blocks); DMA instruction q of this wave moves its floats [wi*256, (wi+1)*256), wi = wave + NWV*q
   // (buffer_load_dwordx4 ... lds, not global_load_lds: the compiler counts a FLAT-encoded DMA as a flat access that may return
   // out of order and turns every later wait -- the halo registers, the transform's LDS reads -- into a wait for ALL of them)
-  typedef __attribute__((address_space(3))) void* W3Lds;
-  typedef __attribute__((address_space(3))) float* W3LdsF;
   const BufRsrcC wrs = make_rsrc_c(wt, 0x7ffffff0u);
   const unsigned wlane = (unsigned)(wave * 256 + lane * 4) * 4u;   // per-lane byte offset inside a DMA instruction's 1 KiB x NWV
   unsigned wgrp;                                        // byte offset of block (dz 0, chunk 0) of the stream's output-channel group
@@ -600,8 +614,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
     const unsigned sb = wgrp + (unsigned)wblk * wstep;
 #pragma unroll
     for (int q = 0; q < NDMA; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (W3Lds)((W3LdsF)&wdst[0] + (wave + NWV * q) * 256), 16, wlane,
-                                               sb + (unsigned)(NWV * 256 * q) * 4u, 0, 0);
+      dma16_to_lds(wrs, (LdsF)&wdst[0] + (wave + NWV * q) * 256, wlane, sb + (unsigned)(NWV * 256 * q) * 4u);
     ++wblk;
   };
   // ---- input transform.  Half patch u = threadIdx.x + NT*i: block n = u % NB, channel c = (u / NB) % C, row half
@@ -677,7 +690,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   };
   // One phase (between two barriers), stage s of the MFMA stream's tile.  M0: a stage s-1 exists in this tile (its second
   // k-step is issued first; without it the accumulators start from zero).  The weight/transform stream (stage s+1) and the
-  // halo stream (stage s+2) are always live: behind a workgroup's last tile they run on a stand-in tile whose results
+  // halo stream (stage s+3) are always live: behind a workgroup's last tile they run on a stand-in tile whose results
   // nobody reads, which keeps every phase the same straight-line code.
   auto phase_sched = [&](auto m0, auto late_, auto hpw_, const float* wcur, float* wnext, const float* xcur, float* xnext,
                          const float* rawnext, float* rawfree) __attribute__((always_inline)) {
@@ -686,7 +699,7 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
     constexpr int HPW = decltype(hpw_)::value;            // the row half of this wave's half patches (UPT == 1); with UPT == 2 it is i         // the second wave of each SIMD runs its fillers half a phase later
     // (the fetches of the phase are issued BEHIND its first MFMAs, whose operands are already in registers: the matrix
     // pipe restarts right behind the barrier instead of idling through ~40 address/VMEM/LDS instructions per wave)
-    constexpr int S_XF = LATE ? 4 : 0, S_DMA = LATE ? 5 : 1, S_K0 = LATE ? 6 : 2, S_K1 = LATE ? 11 : 7, S_RAW = LATE ? 14 : 13;
+    constexpr int S_XF = LATE ? 4 : 0, S_DMA = LATE ? 5 : 1, S_K0 = LATE ? 6 : 2, S_K1 = LATE ? 11 : 7;
 #pragma unroll
     for (int slot = 0; slot < 16; ++slot) {
       const int ks = slot < 8 ? 1 : 0, p = slot & 7;
@@ -990,17 +1003,22 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
 #pragma unroll
     for (int t = 0; t < NLD; ++t) stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, uoff[t], 0, 0));
   };
-  auto stage_weights = [&](int dz, int c0, float* wdst) {
+  // (weights by buffer_load_dwordx4 ... lds with a fixed lane offset and the stage in the scalar offset: see conv3_mfma_kernel)
+  const BufRsrcC wrs = make_rsrc_c(a.w, 0x7ffffff0u);
+  constexpr int NWQ = (NWI + 3) / 4;
+  unsigned wvoff[NWQ];
 #pragma unroll
-    for (int q = 0; q < (NWI + 3) / 4; ++q) {
+  for (int q = 0; q < NWQ; ++q) {
+    int tap = TPI * (wave + 4 * q) + lane / LPT;
+    if (tap > NTAP - 1) tap = NTAP - 1;                   // the tail re-reads the last tap into slots nobody reads
+    wvoff[q] = (unsigned)((size_t)tap * cin_pad * CO + (lane % LPT) * 4) * 4u;
+  }
+  auto stage_weights = [&](int dz, int c0, float* wdst) {
+    const unsigned soff = (unsigned)(((size_t)dz * NTAP * cin_pad + c0) * CO) * 4u;
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
       const int wi = wave + 4 * q;                        // wave-uniform
-      if (wi < NWI) {
-        int tap = TPI * wi + lane / LPT;
-        if (tap > NTAP - 1) tap = NTAP - 1;               // the tail re-reads the last tap into slots nobody reads
-        const float* src = a.w + ((size_t)(dz * NTAP + tap) * cin_pad + c0) * CO + (lane % LPT) * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(&wdst[wi * 256]), 16, 0, 0);
-      }
+      if (wi < NWI) dma16_to_lds(wrs, (LdsF)&wdst[0] + wi * 256, wvoff[q], soff);
     }
   };
   const int nchunk = cin_pad / CHS;
