@@ -1,20 +1,22 @@
 #!/bin/bash
 # A/B of two builds of libfluidnet_hip.so on ONE box (boxes differ by a few per cent, so do runs minutes apart):
-#   here:     tools/ab_libs.sh build <name> [git-rev]   -> variants/libfluidnet_hip_<name>.so from the working tree's (or the
-#                                                           revision's) fnx_cnn.hip and the other objects of the current build
+#   here:     [UNIT=fnx_jacobi] tools/ab_libs.sh build <name> [git-rev]   -> variants/libfluidnet_hip_<name>.so from the working
+#             tree's (or the revision's) csrc/$UNIT.hip (default fnx_cnn) and the other objects of the current build
 #   GPU box:  tools/ab_libs.sh run <rounds> <name>... -- <command>     (round-robin over the builds; prints the command's output)
 set -u
 cd "$(dirname "$0")/.."
 V=variants
 if [ "$1" = build ]; then
   mkdir -p $V
-  src=fluidnet_cxx_amd/csrc/fnx_cnn.hip
+  U=${UNIT:-fnx_cnn}
+  extra=""; [ $U != fnx_cnn ] && [ $U != fnx_slab ] && [ $U != fnx_peer ] && extra="-ffp-contract=off"    # (build.py's per-unit flags)
+  src=fluidnet_cxx_amd/csrc/$U.hip
   if [ $# -ge 3 ]; then git show $3:$src > fluidnet_cxx_amd/csrc/.ab_$2.hip; src=fluidnet_cxx_amd/csrc/.ab_$2.hip; fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -fno-slp-vectorize -Wno-unused-value \
-      -c $src -o $V/fnx_cnn_$2.o 2>/dev/null &&
-  objs=$(ls fluidnet_cxx_amd/build/*.o | grep -v "fnx_cnn.o" | grep -v "hip-amdgcn\|host-x86") &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libfluidnet_hip_$2.so $objs $V/fnx_cnn_$2.o && echo built $2
-  rm -f $V/fnx_cnn_$2.o fluidnet_cxx_amd/csrc/.ab_$2.hip
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -fno-slp-vectorize -Wno-unused-value $extra \
+      -c $src -o $V/${U}_$2.o 2>/dev/null &&
+  objs=$(ls fluidnet_cxx_amd/build/*.o | grep -v "/$U.o" | grep -v "hip-amdgcn\|host-x86") &&
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libfluidnet_hip_$2.so $objs $V/${U}_$2.o && echo built $2
+  rm -f $V/${U}_$2.o fluidnet_cxx_amd/csrc/.ab_$2.hip
 else
   n=$2; shift 2
   names=()
