@@ -467,7 +467,7 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
             with torch.cuda.graph(g):
                 sim.step(bd)
             g.replay(); torch.cuda.synchronize()
-            step, launch = g.replay, "hip-graph replay of the C++ driver's step"
+            step, launch = g.replay, "hip-graph replay"
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f"bench: native slab step not captured ({e}); running eagerly\n")
     barrier()
@@ -633,7 +633,7 @@ def compact(out):
     if other:
         line["other"] = other
     line["kernel_ms_per_step"] = dict({k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()},
-                                      note="HIP-event pairs per launch: ~2 us per launch above the kernels' own time")
+                                      note="HIP-event pairs: ~2 us per launch above kernel time")
     if out.get("advect"):
         ad = out["advect"]
         line["advect"] = dict(ms=_r(ad["ms_per_step"]), frac_of_120B_model=_r(ad["frac_of_model"], 3), valu_issue_frac=_r(ad.get("valu_issue_frac"), 3))
@@ -646,7 +646,7 @@ def compact(out):
     mm = out.get("native_driver", {}).get("middle_rank_model")
     if mm:                                   # (short form: the sentence that says what it is stays in the side file)
         line["middle_rank_model"] = {kk.replace("modelled_efficiency", "eff"): _r(vv, 3) for kk, vv in mm.items() if kk != "what" and not kk.startswith("ms_at_")}
-        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model comm (9 us: peer-store, 20-25 us: RCCL; beside_: deep_beside + direct sends): a MODEL of N>=3"
+        line["middle_rank_model"]["note"] = "1 GPU as rank 1 of 3, link-model comm (9 us: peer-store, 20-25: RCCL; beside_: deep_beside + direct sends): a MODEL"
     line["detail_file"] = "gpurun_out/bench_detail.json"
     return line, out
 
@@ -846,7 +846,7 @@ def main():
                 if "comm_peer" in out:
                     out["comm_rccl"], out["comm"] = out.get("comm"), out["comm_peer"]
         nd = out["native_driver"]
-        out["config"]["driver"] = "python (fluidnet_cxx_amd/slab.py over torch.distributed P2P)"
+        out["config"]["driver"] = "python (slab.py over torch.distributed P2P)"
         if world > 1 and "error" not in nd and nd.get("state_finite"):
             if "python_driver_error" in out:
                 out["python_driver"] = dict(error=out.pop("python_driver_error"))
