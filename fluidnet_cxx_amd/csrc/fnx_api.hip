@@ -751,17 +751,18 @@ int fnx_pre_projection(const FnxGrid* g, const FnxStepParams* prm, const FnxStat
   const bool periodic = wall && (prm->periodic & 1);
   const bool second_bcs = !(prm->method == 1 && st->flags_stick);
   fnx::ProfScope ps(FNX_PROF_STAGE, (hipStream_t)stream);
-  // 3D: the fused kernel re-derives three neighbour velocities per cell (~54 loads); staging then a plain divergence
-  // pass is faster there (measured 0.67 -> 0.59 ms at 256^3).  2D keeps the single fused pass, unless the periodic patches
-  // have to go between the stages and the divergence.
-  const bool split = g->is3D != 0 || periodic;
-  // split: the divergence pass reads the staged U of the +1 neighbours, so the staging pass covers one more plane
+  // One fused pass writes the staged fields and the divergence (each cell re-derives the staged component of its +1 neighbours),
+  // unless the periodic patches have to go between the stages and the divergence: then staging, patches, a divergence pass.
+  const bool split = periodic;
+  // the staging covers one plane more than the divergences asked for where there is one (3D ranges): the divergence of the last
+  // plane reads the advected fields of that plane, and the callers of plane ranges expect it staged as well
   GridDims ds = dims(g);
-  if (split && div && ds.K0 + ds.KN < ds.D) ds.KN += 1;
+  const int div_k_end = ds.K0 + ds.KN;
+  if (g->is3D && div && ds.K0 + ds.KN < ds.D) ds.KN += 1;
   fnx::launch_pre_projection(ds, g->is3D, quirks(g), U_adv, rho_adv, st->flags, ubc ? st->UBC : nullptr,
                              ubc ? st->UBCInvMask : nullptr, rbc ? st->densityBC : nullptr,
                              rbc ? st->densityBCInvMask : nullptr, st->U, st->density, (split && div) ? nullptr : div, buoy, sx, sy, sz,
-                             prm->operating_density, wall, (hipStream_t)stream, st->bc_class, grav ? gv : nullptr, second_bcs);
+                             prm->operating_density, wall, (hipStream_t)stream, st->bc_class, grav ? gv : nullptr, second_bcs, div_k_end);
   if (periodic)
     fnx::launch_periodic_pre(ds, g->is3D, U_adv, ubc ? st->UBC : nullptr, ubc ? st->UBCInvMask : nullptr, st->U,
                              (prm->periodic & 2) != 0, (prm->periodic & 4) != 0, (hipStream_t)stream);

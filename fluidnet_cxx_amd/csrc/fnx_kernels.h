@@ -67,8 +67,11 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
                            float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s,
-                           const unsigned char* cls = nullptr, const float* gravity = nullptr, bool second_bcs = true);
-// gravity: 3 host floats (gravity * dt) or null; second_bcs = false leaves out the setConstVals of simulate.py:133
+                           const unsigned char* cls = nullptr, const float* gravity = nullptr, bool second_bcs = true,
+                           int div_k_end = 0);
+// gravity: 3 host floats (gravity * dt) or null; second_bcs = false leaves out the setConstVals of simulate.py:133; 3D with `div`:
+// the divergence of the staged field is written for the planes [g.K0, div_k_end) of the staged range (the staged value of a cell's
+// +1 neighbours is re-derived in the same pass; their advected inputs must be valid)
 // periodic patches of the Jacobi branch (simulate.py:121-128, :157-164); `save`: periodic_save_bytes(g), mode 0 = save the
 // source row / column before the post-projection pass, 1 = write the destinations after it
 void launch_periodic_pre(const GridDims& g, bool is3d, const float* U_adv, const float* UBC, const float* UBCInvMask, float* U,

@@ -5,8 +5,8 @@
 //   stage2d_div_kernel    : U_adv, rho_adv (advection outputs) -> U, rho (BCs, buoyancy, wall BCs applied) and div; each
 //                           thread produces its own cell and re-derives the +1 neighbours' velocity components the
 //                           divergence needs (radius-1 recompute instead of a second pass over HBM)
-//   stage3d_kernel        : the same stages in 3D without the divergence (the recompute would cost ~54 loads per cell; a
-//                           plain divergence pass follows: 0.67 -> 0.59 ms at 256^3)
+//   stage3d_kernel        : the same in 3D (round 5; until then staging only, followed by a plain divergence pass: as a branchy
+//                           kernel the recompute's 54 dependent loads per cell had measured slower)
 //   post_projection_kernel: U -= grad p, wall BCs, BCs                      (simulate.py:154-168)
 // Per-cell arithmetic is exactly the sequence of the separate operators (fnx_stencils.hip), so results are bit-identical
 // to the unfused path.  The stages of one velocity component `a` of a cell, in order (what the comments below call "the
@@ -37,26 +37,62 @@ __device__ __forceinline__ bool gravity_applies(float fc, float fm) {
   return (fc == FNX_FLUID || fc == FNX_EMPTY) && (fm == FNX_FLUID || (fm == FNX_EMPTY && fc == FNX_FLUID));
 }
 
+// The stage sequence of component `a` of one 3D cell: u its advected value, (um, uc) its velocity-BC entry, fc / fm the flags of
+// the cell and of its -1 neighbour along a (the cell's own where that neighbour does not exist), r0 / r1 their densities with
+// the BC entries (rm0, rc0) / (rm1, rc1), kg = k + zoff the cell's global plane, k its local one.
+template <bool QUIRKS, bool WALL>
+__device__ __forceinline__ float stage_eval3d(int a, float v, bool ubc, float um, float uc, float fc, float fm, bool border, bool buoy,
+                                              float r0, float r1, bool rbc, float rm0, float rc0, float rm1, float rc1, float s_a,
+                                              float rho_star, bool grav, float g_a, bool bc2, int kg, int k) {
+  if (ubc) { const float t = v * um; v = t + uc; }                                         // simulate.py:96
+  if (buoy && !border && fc == FNX_FLUID && fm == FNX_FLUID) {                              // source_terms.py
+    float q0 = r0, q1 = r1;
+    if (rbc) { float t = q0 * rm0; q0 = t + rc0; t = q1 * rm1; q1 = t + rc1; }
+    if (a == 2 && QUIRKS) v = v + s_a * (0.5f * (q0 + (kg <= 1 ? 0.f : q1)));
+    else v = v + s_a * ((0.5f * (q0 + q1)) - rho_star);
+  }
+  if (grav && !border && gravity_applies(fc, fm)) v = v + g_a;                             // source_terms.py:122-219
+  if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {                                        // set_wall_bcs.py:45-84
+    if (!(a == 2 && (kg == 0 || k == 0))) {
+      if (fm == FNX_OBST || (fc == FNX_OBST && fm == FNX_FLUID)) v = 0.f;
+    }
+  }
+  if (ubc && bc2) { const float t = v * um; v = t + uc; }                                  // simulate.py:133
+  return v;
+}
+
 // The 3D staging pass as straight-line code: every load of a cell -- its three advected velocity components, the density
 // and the flags of the cell and of its three -1 neighbours, and, unless the whole wave is in identity BC cells, the BC
 // arrays of those cells -- is issued unconditionally up front (a -1 neighbour that does not exist reads the cell itself)
 // and the stage conditions become selects.  (With the loads nested inside the conditions the kernel was a chain of load ->
 // wait -> branch round trips: 58 waits, 257 us at 512x512x64 whether or not the BC loads were skipped; now 120 us.)
-template <bool QUIRKS, bool WALL>
+// DIV: the pass also writes velocityDivergence of the staged field (velocity_divergence.py:46-74; divergence_kernel's
+// expression) for the planes below `kdiv`: the cell re-derives the staged component a of its +1 neighbour along a -- that
+// neighbour's advected value, flags, density and BC entry are the nine to fifteen extra loads, all of them lines some
+// neighbouring thread loads as its own -- instead of a second pass reading the staged field back (round 1 measured the fused
+// form slower, 0.67 against 0.59 ms at 256^3: that was the branchy kernel with 54 dependent loads; in the straight-line form
+// the divergence pass's 75 us at 512x512x64 become ~15).
+template <bool QUIRKS, bool WALL, bool DIV>
 __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P, int buoy, float sx, float sy, float sz,
-                                                         float rho_star) {
+                                                         float rho_star, int kdiv) {
   const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
   const int bk = blockIdx.z;
   const int b = bk / g.KN, k = g.K0 + (bk - b * g.KN);
   if (i >= g.W || j >= g.H) return;
   const size_t o = (size_t)k * g.HW + j * g.W + i, os = (size_t)b * g.DHW + o;
   const int off[3] = { i > 0 ? 1 : 0, j > 0 ? g.W : 0, k > 0 ? g.HW : 0 };     // 0: "the cell itself" (a missing neighbour counts as the cell's own type)
+  const bool want_div = DIV && k < kdiv;                                        // (block-uniform)
+  const int offp[3] = { i + 1 < g.W ? 1 : 0, j + 1 < g.H ? g.W : 0, k + 1 < g.D ? g.HW : 0 };   // +1 neighbours (DIV); 0 where there is none: never used
   const bool has_rho = P.rho_adv != nullptr, ubc = P.UBC != nullptr, rbc = P.rhoBC != nullptr;
   bool ident = false;
   if (P.cls) {
     bool mine = P.cls[os] == 3;
 #pragma unroll
     for (int a = 0; a < 3; ++a) mine = mine & ((P.cls[os - off[a]] & 2) != 0);
+    if (want_div) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) mine = mine & (P.cls[os + offp[a]] == 3);
+    }
     ident = __builtin_amdgcn_ballot_w64(!mine) == 0;
   }
   // ---- loads
@@ -69,42 +105,46 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
 #pragma unroll
     for (int a = 0; a < 3; ++a) r1[a] = P.rho_adv[os - off[a]];
   }
+  float fp[3] = { 0.f, 0.f, 0.f }, up[3] = { 0.f, 0.f, 0.f }, rp[3] = { 0.f, 0.f, 0.f };
+  if (want_div) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { fp[a] = P.flags[os + offp[a]]; up[a] = P.U_adv[((size_t)b * 3 + a) * g.DHW + o + offp[a]]; }
+    if (has_rho) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) rp[a] = P.rho_adv[os + offp[a]];
+    }
+  }
   float um[3] = { 1.f, 1.f, 1.f }, uc[3] = { 0.f, 0.f, 0.f }, rm0 = 1.f, rc0 = 0.f, rm1[3] = { 1.f, 1.f, 1.f }, rc1[3] = { 0.f, 0.f, 0.f };
+  float ump[3] = { 1.f, 1.f, 1.f }, ucp[3] = { 0.f, 0.f, 0.f }, rmp[3] = { 1.f, 1.f, 1.f }, rcp[3] = { 0.f, 0.f, 0.f };
   if (!ident) {
     if (ubc) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) { um[a] = P.UBCInvMask[((size_t)b * 3 + a) * g.DHW + o]; uc[a] = P.UBC[((size_t)b * 3 + a) * g.DHW + o]; }
+      if (want_div) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ump[a] = P.UBCInvMask[((size_t)b * 3 + a) * g.DHW + o + offp[a]]; ucp[a] = P.UBC[((size_t)b * 3 + a) * g.DHW + o + offp[a]]; }
+      }
     }
     if (rbc && has_rho) {
       rm0 = P.rhoBCInvMask[os]; rc0 = P.rhoBC[os];
 #pragma unroll
       for (int a = 0; a < 3; ++a) { rm1[a] = P.rhoBCInvMask[os - off[a]]; rc1[a] = P.rhoBC[os - off[a]]; }
+      if (want_div) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { rmp[a] = P.rhoBCInvMask[os + offp[a]]; rcp[a] = P.rhoBC[os + offp[a]]; }
+      }
     }
   }
   // ---- the stage sequence, per component
   const bool border = is_border<true>(g, i, j, k);
   const float sa[3] = { sx, sy, sz };
   const float ga[3] = { P.gx, P.gy, P.gz };
+  const bool by = buoy && has_rho, gr = P.grav && has_rho, rb = rbc && has_rho;
   float un[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float v = u[a];
-    if (ubc) { const float t = v * um[a]; v = t + uc[a]; }                                   // simulate.py:96
-    if (buoy && has_rho && !border && fc == FNX_FLUID && fm[a] == FNX_FLUID) {                // source_terms.py
-      float q0 = r0, q1 = r1[a];
-      if (rbc) { float t = q0 * rm0; q0 = t + rc0; t = q1 * rm1[a]; q1 = t + rc1[a]; }
-      if (a == 2 && QUIRKS) v = v + sa[a] * (0.5f * (q0 + (k + g.zoff <= 1 ? 0.f : q1)));
-      else v = v + sa[a] * ((0.5f * (q0 + q1)) - rho_star);
-    }
-    if (P.grav && has_rho && !border && gravity_applies(fc, fm[a])) v = v + ga[a];          // source_terms.py:122-219
-    if (WALL && (fc == FNX_FLUID || fc == FNX_OBST)) {                                        // set_wall_bcs.py:45-84
-      if (!(a == 2 && (k + g.zoff == 0 || k == 0))) {
-        if (fm[a] == FNX_OBST || (fc == FNX_OBST && fm[a] == FNX_FLUID)) v = 0.f;
-      }
-    }
-    if (ubc && P.bc2) { const float t = v * um[a]; v = t + uc[a]; }                          // simulate.py:133
-    un[a] = v;
-  }
+  for (int a = 0; a < 3; ++a)
+    un[a] = stage_eval3d<QUIRKS, WALL>(a, u[a], ubc, um[a], uc[a], fc, fm[a], border, by, r0, r1[a], rb, rm0, rc0, rm1[a], rc1[a], sa[a],
+                                       rho_star, gr, ga[a], P.bc2 != 0, k + g.zoff, k);
   float rnew = r0;
   if (has_rho && rbc) {
     float t = rnew * rm0; rnew = t + rc0;       // simulate.py:96
@@ -113,6 +153,23 @@ __global__ __launch_bounds__(BX* BY) void stage3d_kernel(GridDims g, StepPtrs P,
 #pragma unroll
   for (int a = 0; a < 3; ++a) P.U[((size_t)b * 3 + a) * g.DHW + o] = un[a];
   if (has_rho) P.rho[os] = rnew;
+  if (want_div) {
+    float d = 0.f;
+    if (!border) {
+      // the staged component a of the +1 neighbour along a: its -1 neighbour along a is this cell
+      float vp[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const bool bp = is_border<true>(g, i + (a == 0), j + (a == 1), k + (a == 2));
+        vp[a] = stage_eval3d<QUIRKS, WALL>(a, up[a], ubc, ump[a], ucp[a], fp[a], fc, bp, by, rp[a], r0, rb, rmp[a], rcp[a], rm0, rc0, sa[a],
+                                           rho_star, gr, ga[a], P.bc2 != 0, k + (a == 2) + g.zoff, k + (a == 2));
+      }
+      d = ((un[0] - vp[0]) + un[1]) - vp[1];
+      d = d + (un[2] - vp[2]);
+    }
+    if (fc == FNX_OBST) d = 0.f;
+    P.div[os] = d;
+  }
 }
 
 // The 2D fused stage (BCs, buoyancy, wall BCs, BCs and -div in one pass) the same way: the cell needs the staged
@@ -367,7 +424,7 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
                            const float* flags, const float* UBC, const float* UBCInvMask, const float* rhoBC,
                            const float* rhoBCInvMask, float* U, float* rho, float* div, bool buoyancy, float sx,
                            float sy, float sz, float rho_star, bool wall_bcs, hipStream_t s, const unsigned char* cls,
-                           const float* gravity, bool second_bcs) {
+                           const float* gravity, bool second_bcs, int div_k_end) {
   StepPtrs P{U_adv, rho_adv, flags, UBC, UBCInvMask, rhoBC, rhoBCInvMask, U, rho, div, cls,
              gravity ? 1 : 0, gravity ? gravity[0] : 0.f, gravity ? gravity[1] : 0.f, gravity ? gravity[2] : 0.f, second_bcs ? 1 : 0};
   const dim3 grid = cell_grid(g), block(BX, BY);
@@ -376,11 +433,18 @@ void launch_pre_projection(const GridDims& g, bool is3d, bool quirks, const floa
     else stage2d_div_kernel<false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, rho_star);
     return;
   }
-  // 3D: staging only (div must be null: fnx_pre_projection follows it with a divergence pass)
-  if (quirks) { if (wall_bcs) stage3d_kernel<true, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
-                else stage3d_kernel<true, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
-  else        { if (wall_bcs) stage3d_kernel<false, true><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star);
-                else stage3d_kernel<false, false><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star); }
+  // 3D: `div` non-null: the fused form, divergence for the planes below div_k_end (the caller stages one plane more than it wants
+  // divergences of where there is one); null: staging only
+  const int kdiv = div ? div_k_end : 0;
+#define STAGE3D(Q, W_, D_) stage3d_kernel<Q, W_, D_><<<grid, block, 0, s>>>(g, P, buoyancy, sx, sy, sz, rho_star, kdiv)
+  if (div) {
+    if (quirks) { if (wall_bcs) STAGE3D(true, true, true); else STAGE3D(true, false, true); }
+    else        { if (wall_bcs) STAGE3D(false, true, true); else STAGE3D(false, false, true); }
+  } else {
+    if (quirks) { if (wall_bcs) STAGE3D(true, true, false); else STAGE3D(true, false, false); }
+    else        { if (wall_bcs) STAGE3D(false, true, false); else STAGE3D(false, false, false); }
+  }
+#undef STAGE3D
 }
 
 void launch_post_projection(const GridDims& g, bool is3d, const float* p, float* U, float* rho, const float* flags,
