@@ -465,10 +465,14 @@ void launch_flags_to_occupancy(size_t n, const float* flags, float* occ, hipStre
 __global__ __launch_bounds__(256) void max_abs_kernel(size_t n4, size_t n, const float* __restrict__ x, unsigned* __restrict__ out) {
   float m = 0.f;
   const float4* x4 = (const float4*)x;
-  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
-    const float4 v = x4[q];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  auto amax4 = [](const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  for (; q + 3 * stride < n4; q += 4 * stride) {          // four loads in flight per thread (a maximum does not care about the order)
+    const float4 a = x4[q], b = x4[q + stride], c = x4[q + 2 * stride], d = x4[q + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(amax4(a), amax4(b)), fmaxf(amax4(c), amax4(d))));
   }
+  for (; q < n4; q += stride) m = fmaxf(m, amax4(x4[q]));
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
