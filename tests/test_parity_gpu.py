@@ -1134,12 +1134,17 @@ def test_jacobi_sweeps_continue(fl, ext, dev, oracle, shape):
         assert_bitexact(N(p), po, f"{first}+{more} sweeps vs oracle")
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 33, 70), (1, 9, 14, 66)])
-def test_fused_stages_equal_operator_sequence(fl, ext, dev, shape):
+@pytest.mark.parametrize("shape,quirks", [((2, 1, 33, 70), False), ((1, 9, 14, 66), False), ((2, 7, 13, 67), True)],
+                         ids=["2d", "3d", "3d-quirks"])
+def test_fused_stages_equal_operator_sequence(fl, ext, dev, shape, quirks):
     """pre_projection_ / post_projection_ == setConstVals, addBuoyancy, setWallBcs, setConstVals, velocityDivergence /
-    velocityUpdate, setWallBcs, setConstVals applied one by one (simulate.py:96-168), bit for bit."""
+    velocityUpdate, setWallBcs, setConstVals applied one by one (simulate.py:96-168), bit for bit -- in 3D the staging pass
+    writes the divergence too (stage3d_kernel<.,.,DIV>: the staged components of the +1 neighbours re-derived per cell), with
+    random BC masks (no identity-BC shortcut) and, third case, in the reference's 3D quirks mode."""
     B, D, H, W = shape
     is3d = D > 1
+    geom = ext.Geom(ref_quirks=True) if quirks else None
+    kw = dict(geom=geom) if quirks else {}
     s = random_state(B, D, H, W, 2.0, seed=9)
     rng = np.random.default_rng(1)
     nc = 3 if is3d else 2
@@ -1152,18 +1157,18 @@ def test_fused_stages_equal_operator_sequence(fl, ext, dev, shape):
     # operator sequence
     U, rho, p = T(s["U"], dev), T(s["rho"], dev), T(s["p"], dev)
     fl.setConstVals(dict(bd), p, U, tf, rho)
-    fl.addBuoyancy(U, tf, rho, [0.1, -0.25, 0.05], 0.02, 0.1)
-    fl.setWallBcs(U, tf)
+    fl.addBuoyancy(U, tf, rho, [0.1, -0.25, 0.05], 0.02, 0.1, **kw)
+    fl.setWallBcs(U, tf, **kw)
     fl.setConstVals(dict(bd), p, U, tf, rho)
-    div_ref = fl.velocityDivergence(U, tf)
+    div_ref = fl.velocityDivergence(U, tf, **kw)
     # fused
     U2, rho2 = torch.empty_like(U), torch.empty_like(rho)
     div = ext.pre_projection_(T(s["U"], dev), T(s["rho"], dev), p, U2, tf, rho2, bd["UBC"], bd["UBCInvMask"], bd["densityBC"],
-                              bd["densityBCInvMask"], 0.1, 1.0, [-0.1, 0.25, -0.05], 0.02, True)
+                              bd["densityBCInvMask"], 0.1, 1.0, [-0.1, 0.25, -0.05], 0.02, True, **kw)
     assert_bitexact(N(U2), N(U), "pre_projection U"); assert_bitexact(N(rho2), N(rho), "pre_projection rho")
     assert_bitexact(N(div), N(div_ref), "pre_projection div")
-    fl.velocityUpdate(p, U, tf); fl.setWallBcs(U, tf); fl.setConstVals(dict(bd), p, U, tf, rho)
-    ext.post_projection_(p, U2, tf, rho2, bd["UBC"], bd["UBCInvMask"], bd["densityBC"], bd["densityBCInvMask"])
+    fl.velocityUpdate(p, U, tf, **kw); fl.setWallBcs(U, tf, **kw); fl.setConstVals(dict(bd), p, U, tf, rho)
+    ext.post_projection_(p, U2, tf, rho2, bd["UBC"], bd["UBCInvMask"], bd["densityBC"], bd["densityBCInvMask"], **kw)
     assert_bitexact(N(U2), N(U), "post_projection U"); assert_bitexact(N(rho2), N(rho), "post_projection rho")
 
 
