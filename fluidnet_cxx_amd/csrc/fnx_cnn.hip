@@ -274,6 +274,9 @@ __device__ __forceinline__ BufRsrcC make_rsrc_c(const void* p, unsigned bytes) {
 // function of its own: called from a __global__ template directly, the 16-byte form fails the builtin's size check in the HOST
 // pass (no gfx950 there), silently, and the kernel's host stub is then never emitted (undefined symbol at load time).
 typedef __attribute__((address_space(3))) float* LdsF;
+__device__ __forceinline__ void dma4_to_lds(const BufRsrcC r, LdsF dst, unsigned voff) {      // 4 bytes per lane: 64 consecutive floats at `dst`
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 4, voff, 0, 0, 0);
+}
 __device__ __forceinline__ void dma16_to_lds(const BufRsrcC r, LdsF dst, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
@@ -490,6 +493,9 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 #ifndef W3_ABL
 #define W3_ABL 0
 #endif
+#ifndef W3_HDMA
+#define W3_HDMA 1
+#endif
 constexpr int WCOLS = 34;                              // halo tile row: 32 pixels + halo
 constexpr int W3C = 4;                                 // input channels per stage of conv3_wino3_kernel
 inline int wino3_rw(int cout) { return cout % 64 == 0 ? 64 : 32; }   // its output channels per workgroup
@@ -508,8 +514,14 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   constexpr int NUNIT = 2 * C * NB, UPT = NUNIT / NT;          // half patches per stage / per thread
   static_assert(NUNIT % NT == 0 && (C * NB) % 64 == 0, "half patches must deal out evenly, wave-uniform in the half");
   static_assert(NWI % NWV == 0 && UPT <= 4, "stage shape");
-  __shared__ __attribute__((aligned(16))) float raw0[NEL];
-  __shared__ __attribute__((aligned(16))) float raw1[NEL];
+  // HDMA (the 8-wave variant: one workgroup per CU has the LDS): the halo tile goes global -> LDS by DMA into a ring of four copies;
+  // the 4-wave variants (two workgroups per CU, 80 KB each) take it through registers into two
+  constexpr bool HDMA = W3_HDMA && NCG * NPG == 4;
+  constexpr int RAWN = HDMA ? NLD * NT : NEL;            // (DMA: the lanes of the last instruction beyond the tile land in the padding)
+  __shared__ __attribute__((aligned(16))) float raw0[RAWN];
+  __shared__ __attribute__((aligned(16))) float raw1[RAWN];
+  __shared__ __attribute__((aligned(16))) float raw2[HDMA ? RAWN : 4];
+  __shared__ __attribute__((aligned(16))) float raw3[HDMA ? RAWN : 4];
   __shared__ __attribute__((aligned(16))) float xt0[16 * C * NB];
   __shared__ __attribute__((aligned(16))) float xt1[16 * C * NB];
   __shared__ __attribute__((aligned(16))) float wbuf0[WROWS * RW];
@@ -581,13 +593,18 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   };
   enter_R(T0);
   float stage[NLD];
-  auto prefetch = [&]() __attribute__((always_inline)) {
+  // HDMA: straight into `rawdst` (buffer_load_dword ... lds: 64 consecutive floats per wave instruction, zeros for the out-of-range
+  // offsets) -- no registers, no LDS store, and nothing waits for it before the barrier of the NEXT phase
+  auto prefetch = [&](float* rawdst = nullptr) __attribute__((always_inline)) {
     const int zz = IS3D ? rz + rdz - 1 : 0;
     const BufRsrcC r = (W3_ABL & 128) ? make_rsrc_c(a.x, 1u << 20)
                                       : make_rsrc_c(xR + (size_t)rc0 * vol + (size_t)zz * plane, stage_bytes - (unsigned)((size_t)zz * plane * 4));
 #pragma unroll
-    for (int t = 0; t < NLD; ++t)
-      stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (W3_ABL & 128) ? (unsigned)(threadIdx.x * 4 + t * 2048) : uoff[t], 0, 0));
+    for (int t = 0; t < NLD; ++t) {
+      const unsigned vo = (W3_ABL & 128) ? (unsigned)(threadIdx.x * 4 + t * 2048) : uoff[t];
+      if (HDMA) dma4_to_lds(r, (LdsF)&rawdst[0] + wave * 64 + NT * t, vo);
+      else stage[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, 0, 0));
+    }
     rc0 += C;
     if (rc0 >= a.cin) { rc0 = 0; ++rdz; }
   };
@@ -663,17 +680,29 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
   };
 
   // ---- prologue (first tile of the workgroup only): halo tiles of stages 0 and 1, weights of stage 0, transform of stage 0
-  prefetch();
-  stage_weights(wbuf0);
-  if (WD == 2) stage_weights(wbuf1);
-  store_raw(raw0);
-  prefetch();
-  __syncthreads();
+  if (HDMA) {
+    prefetch(raw0);
+    stage_weights(wbuf0);
+    if (WD == 2) stage_weights(wbuf1);
+    prefetch(raw1);
+    prefetch(raw2);
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < UPT; ++i) { xf_load(i, raw0); xf_cols(i); xf_rows_store(i, xt0); }
-  store_raw(raw1);
-  prefetch();
-  __syncthreads();
+    for (int i = 0; i < UPT; ++i) { xf_load(i, raw0); xf_cols(i); xf_rows_store(i, xt0); }
+    __syncthreads();
+  } else {
+    prefetch();
+    stage_weights(wbuf0);
+    if (WD == 2) stage_weights(wbuf1);
+    store_raw(raw0);
+    prefetch();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) { xf_load(i, raw0); xf_cols(i); xf_rows_store(i, xt0); }
+    store_raw(raw1);
+    prefetch();
+    __syncthreads();
+  }
 
   // ---- MFMA stream ----
   f32x16 acc[8];
@@ -715,7 +744,10 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
       __builtin_amdgcn_sched_barrier(0);
       if (!(W3_ABL & 4) && slot == S_XF) xf_load(0, rawnext);
       if (!(W3_ABL & 16) && slot == S_DMA) stage_weights(wnext);
-      if (!(W3_ABL & 8) && slot == S_DMA + 1) { store_raw(rawfree); prefetch(); }   // the halo tile fetched one phase ago; then the next one
+      if (!(W3_ABL & 8) && slot == S_DMA + 1) {
+        if (HDMA) prefetch(rawfree);                      // (behind the weights: the barrier waits for those, not for these)
+        else { store_raw(rawfree); prefetch(); }          // the halo tile fetched one phase ago; then the next one
+      }
       if (!(W3_ABL & 32) && slot == S_K0) load_k(0, wcur, xcur);
       // half patch i: loaded at slot S_XF + 4i, columns 3 slots later, rows + stores 4 slots later
       const int rel = slot - S_XF, ui = rel / 4, us = rel % 4;
@@ -757,13 +789,15 @@ __global__ __launch_bounds__(128 * NCG * NPG, 2) void conv3_wino3_kernel(ConvArg
       const Tile TN = more ? next_tile(TM) : TM;          // the streams' next tile (stand-in behind the last one: this tile again)
       // four stages per round: stage s computes on weight copy s % 4 and DMAs stage s+2 into copy (s+2) % 4
       auto group = [&](auto m0, bool last) __attribute__((always_inline)) {
-        phase(m0, wbuf0, WD == 2 ? wbuf2 : wbuf1, xt0, xt1, raw1, raw0);
+        // (halo copies: stage s transforms copy (s+1) % 4 and DMAs the tile of stage s+3 into copy (s+3) % 4; through registers:
+        // transforms copy (s+1) % 2 and stores the tile of stage s+2 into copy s % 2)
+        phase(m0, wbuf0, WD == 2 ? wbuf2 : wbuf1, xt0, xt1, raw1, HDMA ? raw3 : raw0);
         if (last) enter_R(TN);                            // stage niter-3 fetches the halo tile of the next tile's stage 0
-        phase(T_{}, wbuf1, WD == 2 ? wbuf3 : wbuf0, xt1, xt0, raw0, raw1);
+        phase(T_{}, wbuf1, WD == 2 ? wbuf3 : wbuf0, xt1, xt0, HDMA ? raw2 : raw0, HDMA ? raw0 : raw1);
         if (last && WD == 2) enter_W(TN);                 // ... and stage niter-WD its weights
-        phase(T_{}, WD == 2 ? wbuf2 : wbuf0, WD == 2 ? wbuf0 : wbuf1, xt0, xt1, raw1, raw0);
+        phase(T_{}, WD == 2 ? wbuf2 : wbuf0, WD == 2 ? wbuf0 : wbuf1, xt0, xt1, HDMA ? raw3 : raw1, HDMA ? raw1 : raw0);
         if (last && WD == 1) enter_W(TN);
-        phase(T_{}, WD == 2 ? wbuf3 : wbuf1, WD == 2 ? wbuf1 : wbuf0, xt1, xt0, raw0, raw1);
+        phase(T_{}, WD == 2 ? wbuf3 : wbuf1, WD == 2 ? wbuf1 : wbuf0, xt1, xt0, raw0, HDMA ? raw2 : raw1);
       };
       group(F_{}, niter == 4);
       for (int it = 4; it < niter; it += 4) group(T_{}, it + 4 == niter);
