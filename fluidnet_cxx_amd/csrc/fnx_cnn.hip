@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
 // position p of the 4x4 transform domain)
 //   D_p[cout 32][block 32] += Wt_p[cout][k] * Xt_p[k][block],   k = two consecutive input channels
 //   raw halo tile  global -> registers (fetched three stages ahead) -> LDS at the start of the next phase
+//                  (8-wave variant: global -> LDS by DMA into a ring of four copies, HDMA below)
 //   B^T d B        per (channel, block) half patch by all threads, LDS -> LDS [position pair][c][block][2]
 //   G g G^T        precomputed at pack time; the stage's slice goes global -> LDS by buffer_load_dwordx4 ... lds (DMA, one stage ahead)
 // and the epilogue applies A^T . A per output channel register, adds the bias, clamps (ReLU) and stores pixel pairs.
