@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-tag=r05s
+tag=${1:-r05t}
 mkdir -p gpurun_out/prof_$tag
 timeout 900 python bench.py > gpurun_out/prof_$tag/bench_default.log 2>&1
 grep "^{\"metric\"" gpurun_out/prof_$tag/bench_default.log | tail -1 > gpurun_out/prof_$tag/bench_default.json
