@@ -968,7 +968,7 @@ __global__ void repack_wino3_kernel(const float* __restrict__ src, float* __rest
 //   D: lane holds pixel (lane&15) and output channels 4*(lane>>4)..+3
 // Workgroup = 4 waves stacked in y; wave tile = 64 px (4 segments of 16) x 2 rows x MB*16 output channels.  A stage
 // is one z plane x CHS input channels: the halo tile goes global -> registers -> LDS (prefetched during the previous
-// stage's MFMAs), the stage's 25 x CHS x CO weights go global -> LDS by global_load_lds_dwordx4; both double-buffered,
+// stage's MFMAs), the stage's 25 x CHS x CO weights go global -> LDS by buffer_load_dwordx4 ... lds; both double-buffered,
 // one barrier per stage (25*CHS/4*8*MB MFMAs per wave between barriers).  Padded output channels (32->8 uses half
 // of the 16-row M block) cost MFMA cycles, not memory traffic.
 // ---------------------------------------------------------------------------------------------------
