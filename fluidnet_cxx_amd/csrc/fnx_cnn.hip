@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, WPS) void conv3_mfma_kernel(ConvArgs a) {
   constexpr int RW = CB * 32;                    // output channels (floats) per weight row
   constexpr int WROWS = 9 * CH;            // (tap, cin) rows per stage
   constexpr int LPR = RW / 4;                    // lanes per row at 16 B per lane
-  constexpr int RPI = 64 / LPR;                  // rows per wave-wide global_load_lds
+  constexpr int RPI = 64 / LPR;                  // rows per wave-wide LDS DMA instruction
   constexpr int NWI = (WROWS + RPI - 1) / RPI;   // wave-instructions per stage
   __shared__ __attribute__((aligned(16))) float tile2[2][CH * ROWS * MF_COLS];     // halo tile, double-buffered
   // weights of the stage, [tap][cin][cout], double-buffered in two SEPARATE arrays: the compiler then knows that the DMA
