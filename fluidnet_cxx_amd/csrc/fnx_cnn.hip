@@ -83,6 +83,24 @@ __global__ void pack_layer_mfma16_kernel(const float* __restrict__ w, const floa
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
 }
 
+// Cin of 2 or 3 (the first layer of a scale): the MFMA K runs over (tap, channel) pairs of a z plane, k = tap * Cin + channel,
+// padded to a multiple of 4 -- 13 / 19 K-groups of four per plane instead of 25 with one or two empty channels each
+// (conv5_mfma16_kernel<4, 2, ., false, KPC>).  0: the layer does not take that form.
+inline int kpack_cin(int cin, int cout) { return (cin == 2 || cin == 3) && cout > 16 && cout <= 32 ? cin : 0; }   // (Cout padded to 32: MB = 2)
+// blob: (Cout,Cin 2|3,taps 5x5[x5]) -> packed [dz][k = (r*5+s)*Cin + ci, padded to 4][Cout padded to 32], zeros in the padding
+__global__ void pack_layer_kpack_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ pw,
+                                        float* __restrict__ pb, int cin, int cout, int kd, int cout_pad) {
+  const int krows = (25 * cin + 3) / 4 * 4;
+  const int n = kd * krows * cout_pad;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int co = q % cout_pad, r1 = q / cout_pad;
+    const int k = r1 % krows, dz = r1 / krows;
+    const int tap = k / cin, ci = k - tap * cin;
+    pw[q] = (co < cout && tap < 25) ? w[((size_t)co * cin + ci) * (kd * 25) + dz * 25 + tap] : 0.f;
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cout; q += gridDim.x * blockDim.x) pb[q] = bias[q];
+}
+
 // blob: (Cout<=8,Cin,taps 5x5[x5]) -> packed [dz][r][wx 0..5][Cin padded to 4][dx*8 + cout]: the weight of tap (r, wx-dx)
 // for output pixel dx of a pair, zero where wx-dx is not one of the 5 taps
 __global__ void pack_layer_pair_kernel(const float* __restrict__ w, const float* __restrict__ bias,
@@ -977,9 +995,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // PAIR (Cout <= 8): the 16 rows of the M block are (dx, cout) for TWO x-adjacent output pixels, the 16 columns are pixel
 // pairs, and k runs over a 6-wide window per tap row (weights zero where the tap falls outside an output's 5): 30
 // k-positions per row-plane instead of 2 x 25 half-empty ones -- 0.6x the MFMAs of the plain mapping for 32->8.
-template <int CHS, int MB, bool IS3D, bool PAIR>
+// KPC (2 or 3 = Cin; 0: off): K packed over (tap, channel), see kpack_cin.
+template <int CHS, int MB, bool IS3D, bool PAIR, int KPC = 0>
 __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int cin_pad) {
   constexpr int KS = 5, PAD = 2, PR = 2;
+  static_assert(KPC == 0 || (CHS == 4 && !PAIR), "packed K: one stage per z plane, all (<= 3) channels in it");
+  constexpr int NKP = (25 * KPC + 3) / 4, KROWS = NKP * 4;           // K-groups of four / weight rows per plane (KPC)
   constexpr int NX = PAIR ? 2 : 4;                                    // MFMA column blocks per wave row (64 px either way)
   constexpr int KW = PAIR ? KS + 1 : KS;                              // k positions along x per tap row
   constexpr int XSEG = PAIR ? 32 : 16, XSTEP = PAIR ? 2 : 1;          // pixels per column block, pixel stride of a lane
@@ -991,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
   static_assert(TAPF == 128 || TAPF == 64, "a wave-wide 16-byte load covers 2 or 4 taps");
   constexpr int TPI = 256 / TAPF, LPT = 64 / TPI;                     // taps per wave-instruction, lanes per tap
   constexpr int NTAP = KS * KW;                                       // k positions per plane (25, or 30 for PAIR)
-  constexpr int NWI = (NTAP + TPI - 1) / TPI;                         // wave-instructions per stage
+  constexpr int NWI = KPC ? (KROWS * CO + 255) / 256 : (NTAP + TPI - 1) / TPI;   // wave-instructions per stage
   __shared__ __attribute__((aligned(16))) float tile2[2][NEL];
   __shared__ __attribute__((aligned(16))) float wbuf0[NWI * 256];       // (two separate arrays and out-of-range-zero buffer
   __shared__ __attribute__((aligned(16))) float wbuf1[NWI * 256];       //  loads: see conv3_mfma_kernel)
@@ -1044,12 +1065,28 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
   unsigned wvoff[NWQ];
 #pragma unroll
   for (int q = 0; q < NWQ; ++q) {
-    int tap = TPI * (wave + 4 * q) + lane / LPT;
-    if (tap > NTAP - 1) tap = NTAP - 1;                   // the tail re-reads the last tap into slots nobody reads
-    wvoff[q] = (unsigned)((size_t)tap * cin_pad * CO + (lane % LPT) * 4) * 4u;
+    if (KPC) {                                            // the plane's KROWS x CO floats are one linear block
+      int f = (wave + 4 * q) * 256 + lane * 4;
+      if (f > KROWS * CO - 4) f = KROWS * CO - 4;         // (the tail re-reads the last floats into slots nobody reads)
+      wvoff[q] = (unsigned)f * 4u;
+    } else {
+      int tap = TPI * (wave + 4 * q) + lane / LPT;
+      if (tap > NTAP - 1) tap = NTAP - 1;                 // the tail re-reads the last tap into slots nobody reads
+      wvoff[q] = (unsigned)((size_t)tap * cin_pad * CO + (lane % LPT) * 4) * 4u;
+    }
+  }
+  // packed K: the lane's element of K-group m is k = 4 m + kq = (tap, channel); its offset in the halo tile
+  int boff[KPC ? NKP : 1];
+  if (KPC) {
+#pragma unroll
+    for (int m = 0; m < NKP; ++m) {
+      const int k = 4 * m + kq, tap = k / (KPC ? KPC : 1), ci = k - tap * KPC;
+      const int r = tap / KS, sx = tap - r * KS;
+      boff[m] = tap < 25 ? ci * ROWS * COLS + r * COLS + sx : 0;      // (padding: zero weights on a valid address)
+    }
   }
   auto stage_weights = [&](int dz, int c0, float* wdst) {
-    const unsigned soff = (unsigned)(((size_t)dz * NTAP * cin_pad + c0) * CO) * 4u;
+    const unsigned soff = KPC ? (unsigned)((size_t)dz * KROWS * CO) * 4u : (unsigned)(((size_t)dz * NTAP * cin_pad + c0) * CO) * 4u;
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
       const int wi = wave + 4 * q;                        // wave-uniform
@@ -1073,6 +1110,27 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma16_kernel(ConvArgs a, int ci
     }
     const float* wl = &wcur[kq * CO + seg];
     const float* tl = &tile[kq * ROWS * COLS + (wave * PR) * COLS + XSTEP * seg];
+    if (KPC) {
+      const float* tb = &tile[(wave * PR) * COLS + XSTEP * seg];
+#pragma unroll
+      for (int m = 0; m < NKP; ++m) {
+        float av[MB], bv[PR][NX];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = wl[(4 * m) * CO + mb * 16];
+#pragma unroll
+        for (int pr = 0; pr < PR; ++pr)
+#pragma unroll
+          for (int nx = 0; nx < NX; ++nx) bv[pr][nx] = tb[boff[m] + pr * COLS + nx * XSEG];
+#pragma unroll
+        for (int pr = 0; pr < PR; ++pr)
+#pragma unroll
+          for (int nx = 0; nx < NX; ++nx)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+              acc[pr][nx][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[pr][nx], acc[pr][nx][mb], 0, 0, 0);
+      }
+      return;
+    }
     // (an explicit operand pipeline as in conv3_mfma_kernel measured slower here: 2.27 -> 2.74 ms at 128^3)
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
@@ -1163,6 +1221,12 @@ void launch_conv_mfma16(const ConvArgs& a, bool is3d, hipStream_t s) {
   } else if (a.cin % 8 == 0 && a.cout <= 16) {
     if (is3d) conv5_mfma16_kernel<8, 1, true, false><<<grid, 256, 0, s>>>(a, cin_pad);
     else conv5_mfma16_kernel<8, 1, false, false><<<grid, 256, 0, s>>>(a, cin_pad);
+  } else if (kpack_cin(a.cin, a.cout) == 3) {
+    if (is3d) conv5_mfma16_kernel<4, 2, true, false, 3><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<4, 2, false, false, 3><<<grid, 256, 0, s>>>(a, cin_pad);
+  } else if (kpack_cin(a.cin, a.cout) == 2) {
+    if (is3d) conv5_mfma16_kernel<4, 2, true, false, 2><<<grid, 256, 0, s>>>(a, cin_pad);
+    else conv5_mfma16_kernel<4, 2, false, false, 2><<<grid, 256, 0, s>>>(a, cin_pad);
   } else {
     if (is3d) conv5_mfma16_kernel<4, 2, true, false><<<grid, 256, 0, s>>>(a, cin_pad);
     else conv5_mfma16_kernel<4, 2, false, false><<<grid, 256, 0, s>>>(a, cin_pad);
@@ -1391,6 +1455,9 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
       pack_layer_pair_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                 is3d ? 5 : 1, pad_to(L.cin, 4));
+    else if (mfma16_layer(L) && kpack_cin(L.cin, L.cout))
+      pack_layer_kpack_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
+                                                 is3d ? 5 : 1, pad_to(L.cout, 16));
     else if (mfma16_layer(L))
       pack_layer_mfma16_kernel<<<64, 256, 0, s>>>(blob + off, blob + off + nw, pk + pl.w_off, pk + pl.b_off, L.cin, L.cout,
                                                   layer_taps(L, is3d), pad_to(L.cin, 4), pad_to(L.cout, 16));
