@@ -6,11 +6,21 @@ batch_dict, same mconf keys).  Two execution modes:
               Python between kernels);
   fused=False: operator by operator through the `fluid.*` surface in the reference's order (what the
               parity tests use to compare stage by stage).
-`workspace` (a uint8 tensor of ext.step_workspace_bytes) avoids a per-step allocation; with it, `static_flags=True`
-promises that batch_dict['flags'] has not changed since the previous call on that workspace (3D Jacobi then reuses
-its obstacle mask).  `static_flags` may also be the C ABI's bit set (FnxStepParams.static_flags): 1 = flags unchanged,
-2 = the four BC arrays unchanged (the BC stages then go by a 1-byte class map kept in the workspace), 4 = that map was
-already built by an earlier call with bit 2 -- e.g. 0 for the first step, 3 for the second, 7 from the third on.
+The reference's own call -- `simulate(mconf, batch_dict, net, sim_method)`, four arguments (plume.py:237) -- gets the static
+path by itself: the layer keeps one step workspace per (device, grid shape) and looks at `(data_ptr, _version, shape, stride)` of
+`flags` and of the four BC arrays (torch bumps `_version` on every in-place write, and so do this package's own in-place
+operators).  While they are the tensors of the previous call, unwritten, the step reuses what it derived from them (the 3D
+solver's obstacle mask; the 1-byte class map of the BC stages, built on the second such call); any change -- a new tensor, an
+in-place write, another shape -- drops back to deriving everything again for that call.  The cache holds a reference to those
+five tensors, so their addresses cannot be recycled while it trusts them.  What torch's counter does not see: writes through
+`.data`, a numpy / dlpack alias or a raw pointer -- after one of those call `forget_static_inputs()` (or pass `static_flags=0`).
+`release_workspaces()` frees the cached workspaces (the CNN's is ~1 KB per cell).
+
+Explicit control, as before: `workspace` (a uint8 tensor of ext.step_workspace_bytes) with `static_flags` = True / the C ABI's
+bit set (FnxStepParams.static_flags): 1 = flags unchanged since the previous call on that workspace (the 3D Jacobi reuses its
+obstacle mask), 2 = the four BC arrays unchanged (the BC stages then go by a 1-byte class map kept in the workspace), 4 = that
+map was already built by an earlier call with bit 2 -- e.g. 0 for the first step, 3 for the second, 7 from the third on.
+`static_flags=None` (the default) with no `workspace` is the automatic mode above; with a caller's workspace it means 0.
 `geom` (an `ext.Geom`, 3D only) selects the reference-quirk mode / a z-slab view for this call; it is per call, the
 extension keeps no state.
 """
@@ -29,7 +39,80 @@ def _gravity(mconf, scale):
     return [float(gv["x"]), float(gv["y"]), float(gv["z"])], float(scale)
 
 
-def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None, static_flags=False,
+_BC_KEYS = ("UBC", "UBCInvMask", "densityBC", "densityBCInvMask")
+_AUTO = {}            # (device index, B, D, H, W, is3D) -> _AutoStep
+_AUTO_MAX = 4         # grid shapes kept (least recently used goes first)
+
+
+def _ident(t):
+    """what identifies a tensor's CONTENT between two calls, or None when torch cannot say (inference tensors have no counter)"""
+    if t is None:
+        return ()
+    try:
+        return (t.data_ptr(), t._version, tuple(t.shape), t.stride())
+    except RuntimeError:
+        return None
+
+
+class _AutoStep:
+    """the step workspace of one grid shape + what it holds that was derived from flags / the BC arrays"""
+
+    def __init__(self, nbytes, like):
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+        self.forget()
+
+    def forget(self):
+        self.flags_id = self.bc_id = None     # identities at the previous call
+        self.mask_id = None                   # flags identity the kept 3D obstacle mask was built from
+        self.cls_id = None                    # BC identity the kept class map was built from
+        self.held = None                      # the five tensors themselves: alive -> their addresses cannot be reused
+
+    def static_bits(self, batch_dict, flags, is3D, jacobi):
+        fid = _ident(flags)
+        bcs = [batch_dict.get(k) for k in _BC_KEYS]
+        bid = None if any(_ident(t) is None for t in bcs) else tuple(_ident(t) for t in bcs)
+        bits = 0
+        if fid is not None and fid == self.flags_id and (not (is3D and jacobi) or self.mask_id == fid):
+            bits |= 1                         # flags unchanged (and, where a mask is used, the kept one is theirs)
+        if bid is not None and bid == self.bc_id:
+            bits |= 2                         # BC arrays unchanged since the previous call: go by the class map ...
+            if self.cls_id == bid:
+                bits |= 4                     # ... which an earlier call already built
+            self.cls_id = bid
+        else:
+            self.cls_id = None
+        if is3D and jacobi:
+            self.mask_id = fid                # this call leaves the mask of these flags behind (built now, or reused)
+        self.flags_id, self.bc_id = fid, bid
+        self.held = (flags, bcs)
+        return bits
+
+
+def _auto_step(flags, is3D):
+    dev = flags.device.index if flags.device.index is not None else torch.cuda.current_device()
+    key = (dev,) + tuple(int(flags.size(i)) for i in (0, 2, 3, 4)) + (bool(is3D),)
+    a = _AUTO.pop(key, None)
+    if a is None:
+        while len(_AUTO) >= _AUTO_MAX:
+            _AUTO.pop(next(iter(_AUTO)))
+        a = _AutoStep(ext.step_workspace_bytes(key[1], key[2], key[3], key[4], key[5]), flags)
+    _AUTO[key] = a                            # (re-inserted: most recently used last)
+    return a
+
+
+def forget_static_inputs():
+    """the next simulate() call of every grid shape derives everything from flags / the BC arrays again (after a write torch's
+    version counter cannot see: `.data`, a numpy / dlpack alias, a raw pointer)"""
+    for a in _AUTO.values():
+        a.forget()
+
+
+def release_workspaces():
+    """free the step workspaces the automatic mode keeps (one per grid shape seen, at most four)"""
+    _AUTO.clear()
+
+
+def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, workspace=None, static_flags=None,
              geom=None):
     assert sim_method in ("convnet", "jacobi"), "Simulation method not supported. Choose either convnet or jacobi."
     dt = float(mconf["dt"])
@@ -58,6 +141,12 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
         gvec = _gravity(mconf, 1.0)[0] if want_gvec else [0.0, 0.0, 0.0]
         density = batch_dict["density"] if has_density else None
         packed = net.packed_for(U.device) if (sim_method == "convnet") else None
+        if workspace is None and static_flags is None and flags.is_cuda and geom is None:
+            # the reference's four-argument call: the layer's own workspace, static inputs detected (module docstring)
+            auto = _auto_step(flags, is3D)
+            workspace, static_flags = auto.workspace, auto.static_bits(batch_dict, flags, is3D, sim_method == "jacobi")
+        elif static_flags is None:
+            static_flags = 0
         ext.simulate_step_(p, U, flags, density, batch_dict.get("UBC"), batch_dict.get("UBCInvMask"),
                            batch_dict.get("densityBC"), batch_dict.get("densityBCInvMask"), packed, dt,
                            float(maccormackStrength), bool(sampleOutsideFluid), float(buoyancyScale), gvec,

@@ -72,6 +72,13 @@ struct Workspace {
   }
 };
 
+// In-place entry points bump the written tensor's version counter like torch's own in-place operators do: autograd's
+// saved-tensor checks and simulate()'s "have flags / the BC arrays changed since the last step?" test (_simulate.py) rely on it.
+void wrote(const Tensor& t) {
+  if (t.defined() && !t.is_inference()) t.unsafeGetTensorImpl()->bump_version();
+}
+void wrote(const c10::optional<Tensor>& t) { if (t.has_value()) wrote(*t); }
+
 void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
 
 int method_of(const std::string& m) {
@@ -85,9 +92,14 @@ int method_of(const std::string& m) {
 // ---- the reference's three entry points -------------------------------------------------------------
 // `out` (not in the reference): write into an existing tensor -- with a compute window (set_window) the z-slab driver
 // fills one advected field from several calls.
+int plan_of(const std::string& plan) {
+  TORCH_CHECK(plan == "auto" || plan == "tiles" || plan == "cells", "plan must be 'auto', 'tiles' or 'cells'");
+  return plan == "tiles" ? FNX_ADVECT_PLAN_TILES : (plan == "cells" ? FNX_ADVECT_PLAN_CELLS : FNX_ADVECT_PLAN_AUTO);
+}
+
 Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::string method, int bnd,
                      const bool sample_outside_fluid, const float maccormack_strength, c10::optional<Tensor> out,
-                     const Geom* geom) {
+                     const Geom* geom, const std::string& plan) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(src, g, "src");
@@ -95,14 +107,14 @@ Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::st
   Tensor dst = (out.has_value() && out->defined()) ? *out : at::empty_like(src);
   check_scalar(dst, g, "out");
   Workspace ws(g, FNX_OP_ADVECT_SCALAR, src);
-  check_status(fnx_advect_scalar(&g, dt, src.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
-                                 dst.data_ptr<float>(), method_of(method), bnd, sample_outside_fluid,
-                                 maccormack_strength, ws.ptr, ws.bytes, cur_stream(src)));
+  check_status(fnx_advect_scalar_plan(&g, dt, src.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                                      dst.data_ptr<float>(), method_of(method), bnd, sample_outside_fluid,
+                                      maccormack_strength, plan_of(plan), ws.ptr, ws.bytes, cur_stream(src)));
   return dst;
 }
 
 Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::string method, int bnd,
-                  const float maccormack_strength, c10::optional<Tensor> out, const Geom* geom) {
+                  const float maccormack_strength, c10::optional<Tensor> out, const Geom* geom, const std::string& plan) {
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_vel(orig, g, "orig");
@@ -110,9 +122,9 @@ Tensor advect_vel(float dt, Tensor orig, Tensor U, Tensor flags, const std::stri
   Tensor dst = (out.has_value() && out->defined()) ? *out : at::empty_like(U);
   check_vel(dst, g, "out");
   Workspace ws(g, FNX_OP_ADVECT_VEL, U);
-  check_status(fnx_advect_vel(&g, dt, orig.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
-                              dst.data_ptr<float>(), method_of(method), bnd, maccormack_strength, ws.ptr, ws.bytes,
-                              cur_stream(U)));
+  check_status(fnx_advect_vel_plan(&g, dt, orig.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
+                                   dst.data_ptr<float>(), method_of(method), bnd, maccormack_strength, plan_of(plan), ws.ptr,
+                                   ws.bytes, cur_stream(U)));
   return dst;
 }
 
@@ -123,8 +135,7 @@ std::vector<Tensor> advect_step(float dt, Tensor density, Tensor U, Tensor flags
   check_field(U, "U");
   FnxGrid g = grid_of(flags, U.size(1) == 3, geom);
   check_vel(U, g, "U"); check_scalar(density, g, "density");
-  TORCH_CHECK(plan == "auto" || plan == "tiles" || plan == "cells", "plan must be 'auto', 'tiles' or 'cells'");
-  const int pl = plan == "tiles" ? FNX_ADVECT_PLAN_TILES : (plan == "cells" ? FNX_ADVECT_PLAN_CELLS : FNX_ADVECT_PLAN_AUTO);
+  const int pl = plan_of(plan);
   c10::hip::HIPGuard guard(flags.get_device());
   Tensor rd = (out_density.has_value() && out_density->defined()) ? *out_density : at::empty_like(density);
   Tensor ud = (out_U.has_value() && out_U->defined()) ? *out_U : at::empty_like(U);
@@ -172,6 +183,7 @@ void velocity_update_(Tensor pressure, Tensor U, Tensor flags, const Geom* geom)
   check_vel(U, g, "U"); check_scalar(pressure, g, "pressure");
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_velocity_update(&g, pressure.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(U)));
+  wrote(U);
 }
 
 void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> gravity, double rho_star, double dt,
@@ -184,6 +196,7 @@ void add_buoyancy_(Tensor U, Tensor flags, Tensor density, std::vector<double> g
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_add_buoyancy(&g, U.data_ptr<float>(), flags.data_ptr<float>(), density.data_ptr<float>(), gv,
                                 (float)rho_star, (float)dt, cur_stream(U)));
+  wrote(U);
 }
 
 void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt, const Geom* geom) {
@@ -194,6 +207,7 @@ void add_gravity_(Tensor U, Tensor flags, std::vector<double> gravity, double dt
   const float gv[3] = {(float)gravity[0], (float)gravity[1], (float)gravity[2]};
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_add_gravity(&g, U.data_ptr<float>(), flags.data_ptr<float>(), gv, (float)dt, cur_stream(U)));
+  wrote(U);
 }
 
 // correctScalar (cpp/advection.py:9-12), in place on src
@@ -203,6 +217,7 @@ void correct_scalar_(double dt, Tensor src, Tensor div, Tensor flags) {
   check_scalar(src, g, "src"); check_scalar(div, g, "div"); check_scalar(flags, g, "flags");
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_correct_scalar(&g, (float)dt, src.data_ptr<float>(), div.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(src)));
+  wrote(src);
 }
 
 void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
@@ -213,6 +228,7 @@ void add_viscosity_(double dt, Tensor U, Tensor flags, double viscosity) {
   Tensor old = U.clone();
   check_status(fnx_add_viscosity(&g, (float)dt, old.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
                                  (float)viscosity, cur_stream(U)));
+  wrote(U);
 }
 
 // set_wall_bcs_stick.py:5-157 (2D; in place on U like the reference)
@@ -225,6 +241,7 @@ void set_wall_bcs_stick_(Tensor U, Tensor flags, Tensor flags_stick) {
   Tensor old = U.clone();
   check_status(fnx_set_wall_bcs_stick(&g, old.data_ptr<float>(), U.data_ptr<float>(), flags.data_ptr<float>(),
                                       flags_stick.data_ptr<float>(), cur_stream(U)));
+  wrote(U);
 }
 
 void set_wall_bcs_(Tensor U, Tensor flags, const Geom* geom) {
@@ -233,6 +250,7 @@ void set_wall_bcs_(Tensor U, Tensor flags, const Geom* geom) {
   check_vel(U, g, "U");
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_set_wall_bcs(&g, U.data_ptr<float>(), flags.data_ptr<float>(), cur_stream(U)));
+  wrote(U);
 }
 
 void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> UBCInvMask, c10::optional<Tensor> density,
@@ -248,6 +266,7 @@ void set_const_vals_(Tensor U, c10::optional<Tensor> UBC, c10::optional<Tensor> 
   c10::hip::HIPGuard guard(U.get_device());
   check_status(fnx_set_const_vals(&g, U.data_ptr<float>(), ptr(UBC, true), ptr(UBCInvMask, true), ptr(density, false),
                                   ptr(densityBC, false), ptr(densityBCInvMask, false), cur_stream(U)));
+  wrote(U); wrote(density);
 }
 
 // max |x| of a 5-D field as a 0-dim device tensor (no host sync) -- CFL guard of the z-slab driver
@@ -272,6 +291,7 @@ void empty_domain_(Tensor flags, int boundary_width, const Geom* geom) {
   FnxGrid g = grid_of(flags, flags.size(2) > 1, geom);
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_empty_domain(&g, flags.data_ptr<float>(), boundary_width, cur_stream(flags)));
+  wrote(flags);
 }
 
 // adjoints of the linear stencil operators (fnx_velocity_divergence_backward, fnx_velocity_update_backward)
@@ -299,12 +319,14 @@ void create_cylinder_(Tensor flags, double center_x, double center_y, double rad
   FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_create_cylinder(&g, flags.data_ptr<float>(), center_x, center_y, radius, cur_stream(flags)));
+  wrote(flags);
 }
 
 void create_box2d_(Tensor flags, double x0, double x1, double y0, double y1) {
   FnxGrid g = grid_of(flags, flags.size(2) > 1, nullptr);
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_create_box2d(&g, flags.data_ptr<float>(), (float)x0, (float)x1, (float)y0, (float)y1, cur_stream(flags)));
+  wrote(flags);
 }
 
 // lib/fluid/grid.py:7-32
@@ -422,6 +444,7 @@ void simulate_step_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> dens
   // the mask lives in the workspace: only a caller-owned workspace carries it from one step to the next
   prm.static_flags = given ? static_flags : 0;      // (promises about the previous step need a caller-owned workspace)
   check_status(fnx_simulate_step(&g, &prm, &st, ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), cur_stream(U)));
+  wrote(p); wrote(U); wrote(density);
 }
 
 // ---- native z-slab driver (fnx_slab_*): communicators and the per-rank driver object ---------------------------
@@ -549,6 +572,7 @@ void jacobi_sweeps_(Tensor flags, Tensor div, Tensor p, bool is3D, int nsweeps, 
   check_status(fnx_jacobi_sweeps_ex(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p.data_ptr<float>(), nsweeps,
                                     ws.data_ptr(), (size_t)ws.numel() * ws.element_size(), (reuse_mask ? 1 : 0) | (from_zero ? 2 : 0),
                                     cur_stream(flags)));
+  wrote(p);
 }
 
 // one pass (1|2 sweeps) p_in -> p_out on the output planes [k_begin, k_end) -- z-slab driver (overlap with exchange)
@@ -562,12 +586,32 @@ void jacobi_pass_(Tensor flags, Tensor div, c10::optional<Tensor> p_in_opt, Tens
   check_status(fnx_jacobi_pass_layout(&g, flags.data_ptr<float>(), div.data_ptr<float>(), zero ? nullptr : p_in.data_ptr<float>(),
                                       p_out.data_ptr<float>(), nsweeps, k_begin, k_end, k_begin2, layout, workspace.data_ptr(),
                                       (size_t)workspace.numel() * workspace.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+  wrote(p_out);
 }
 
 // may two-sweep passes on this 3D grid hand each other the pressure in the row-quad layout (jacobi_pass_'s `layout`)?
 bool jacobi_quad_ok(int B, int D, int H, int W) {
   FnxGrid g{B, D, H, W, 1, 0, 0, 0};
   return fnx_jacobi_quad_ok(&g) != 0;
+}
+
+// fnx_jacobi_pass_mirror: `mirror` / `mirror2` are flat fp32 tensors of B * planes * H * W floats (sample stride planes * H * W)
+void jacobi_pass_mirror_(Tensor flags, Tensor div, Tensor p_in, Tensor p_out, int k_begin, int k_end, Tensor workspace, bool reuse_mask,
+                         Tensor mirror, int k_first, int planes, int k_begin2, c10::optional<Tensor> mirror2, int k_first2, const Geom* geom,
+                         int layout) {
+  FnxGrid g = grid_of(flags, true, geom);
+  check_scalar(div, g, "div"); check_scalar(p_in, g, "p_in"); check_scalar(p_out, g, "p_out");
+  const int64_t need = (int64_t)g.B * planes * g.H * g.W;
+  auto chk = [&](const Tensor& t) { TORCH_CHECK(t.is_cuda() && t.is_contiguous() && t.scalar_type() == at::kFloat && t.numel() >= need, "mirror: a contiguous fp32 GPU tensor of B * planes * H * W floats"); };
+  chk(mirror);
+  FnxPlaneMirror m{};
+  m.out[0][0] = mirror.data_ptr<float>(); m.k_first[0] = k_first; m.planes = planes; m.sample_stride = (size_t)planes * g.H * g.W;
+  if (mirror2.has_value() && mirror2->defined()) { chk(*mirror2); m.out[1][0] = mirror2->data_ptr<float>(); m.k_first[1] = k_first2; }
+  c10::hip::HIPGuard guard(flags.get_device());
+  check_status(fnx_jacobi_pass_mirror(&g, flags.data_ptr<float>(), div.data_ptr<float>(), p_in.data_ptr<float>(), p_out.data_ptr<float>(),
+                                      k_begin, k_end, k_begin2, layout, &m, workspace.data_ptr(),
+                                      (size_t)workspace.numel() * workspace.element_size(), reuse_mask ? 1 : 0, cur_stream(flags)));
+  wrote(p_out); wrote(mirror); wrote(mirror2);
 }
 
 int64_t jacobi_workspace_bytes(int B, int D, int H, int W, bool is3D) {
@@ -655,6 +699,7 @@ void post_projection_(Tensor p, Tensor U, Tensor flags, c10::optional<Tensor> de
   st.density_bc_applied = density_bc_applied ? 1 : 0;
   c10::hip::HIPGuard guard(flags.get_device());
   check_status(fnx_post_projection(&g, &st, cur_stream(U)));
+  wrote(U); wrote(density);
 }
 
 int64_t step_workspace_bytes(int B, int D, int H, int W, bool is3D) {
@@ -685,12 +730,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // optional trailing extras
   m.def("advect_scalar", &advect_scalar, "Advect Scalar", py::arg("dt"), py::arg("src"), py::arg("U"), py::arg("flags"),
         py::arg("method"), py::arg("boundary_width"), py::arg("sample_outside_fluid"), py::arg("maccormack_strength"),
-        py::arg("out") = py::none(), GEOM, NoGil());
+        py::arg("out") = py::none(), GEOM, py::arg("plan") = "auto", NoGil());
   m.def("advect_step", &advect_step, py::arg("dt"), py::arg("density"), py::arg("U"), py::arg("flags"),
         py::arg("sample_outside_fluid"), py::arg("maccormack_strength"), py::arg("out_density") = py::none(),
         py::arg("out_U") = py::none(), GEOM, py::arg("plan") = "auto", NoGil());
   m.def("advect_vel", &advect_vel, "Advect Velocity", py::arg("dt"), py::arg("orig"), py::arg("U"), py::arg("flags"),
-        py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none(), GEOM, NoGil());
+        py::arg("method"), py::arg("boundary_width"), py::arg("maccormack_strength"), py::arg("out") = py::none(), GEOM,
+        py::arg("plan") = "auto", NoGil());
   m.def("solve_linear_system", &solve_linear_system, "Solve Linear System using Jacobi's method", py::arg("flags"),
         py::arg("div"), py::arg("is3D"), py::arg("p_tol"), py::arg("max_iter"), py::arg("verbose"), GEOM, NoGil());
   // operators the reference implements in Python
@@ -731,6 +777,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("jacobi_pass_", &jacobi_pass_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("nsweeps"),
         py::arg("k_begin"), py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("k_begin2") = -1, GEOM,
         py::arg("layout") = 0, NoGil());
+  m.def("jacobi_pass_mirror_", &jacobi_pass_mirror_, py::arg("flags"), py::arg("div"), py::arg("p_in"), py::arg("p_out"), py::arg("k_begin"),
+        py::arg("k_end"), py::arg("workspace"), py::arg("reuse_mask"), py::arg("mirror"), py::arg("k_first"), py::arg("planes"),
+        py::arg("k_begin2") = -1, py::arg("mirror2") = py::none(), py::arg("k_first2") = 0, GEOM, py::arg("layout") = 0, NoGil(),
+        "two sweeps on planes [k_begin, k_end) (+ a second range) whose output planes [k_first, k_first + planes) also go to `mirror` (fnx_jacobi_pass_mirror)");
+  m.def("jacobi_pass_mirror_ok", [](int B, int D, int H, int W, int planes_per_range, bool two_ranges, int layout) {
+    FnxGrid g{}; g.B = B; g.D = D; g.H = H; g.W = W; g.is3D = 1;
+    return fnx_jacobi_pass_mirror_ok(&g, planes_per_range, two_ranges ? 1 : 0, layout) != 0;
+  });
   m.def("jacobi_quad_ok", &jacobi_quad_ok);
   m.def("pre_projection_", &pre_projection_, py::arg("U_adv"), py::arg("rho_adv"), py::arg("p"), py::arg("U"), py::arg("flags"),
         py::arg("density"), py::arg("UBC"), py::arg("UBCInvMask"), py::arg("densityBC"), py::arg("densityBCInvMask"),
@@ -747,6 +801,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("reset", [](PyLoopbackGroup& g) { check_status(fnx_slab_loopback_group_reset(g.g)); },
            "clear an abort (no rank may be inside a call of the group)");
   py::class_<PySlabComm, std::shared_ptr<PySlabComm>>(m, "SlabComm", "ghost-plane communicator of the native z-slab driver (FnxSlabComm)")
+      .def("failed", [](PySlabComm& c) { return c.keep_peer ? fnx_slab_peer_failed(c.keep_peer->p) != FNX_OK : false; },
+           "peer-store: an exchange of this rank timed out / the group was aborted (ask after synchronising; other transports report through their calls)")
       // the control-path collectives of the table, callable on their own (every rank of the communicator must call them)
       .def("allreduce_sum_", [](PySlabComm& c, Tensor x) {
              TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.scalar_type() == at::kFloat, "allreduce: a contiguous fp32 GPU tensor");
@@ -766,7 +822,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   py::class_<PyPeer, std::shared_ptr<PyPeer>>(m, "SlabPeer", "a rank's peer-store region: flags + mailbox its z-neighbours map (fnx_slab_peer_create)")
       .def(py::init<int, int, int64_t>(), py::arg("rank"), py::arg("nranks"), py::arg("mailbox_bytes"))
       .def_property_readonly("handle", [](PyPeer& p) { return py::bytes(p.handle); }, "the bytes both neighbours need (FNX_PEER_HANDLE_BYTES)")
-      .def("set_timeout", [](PyPeer& p, double seconds) { check_status(fnx_slab_peer_set_timeout(p.p, seconds)); }, py::arg("seconds"));
+      .def("set_timeout", [](PyPeer& p, double seconds) { check_status(fnx_slab_peer_set_timeout(p.p, seconds)); }, py::arg("seconds"))
+      .def("failed", [](PyPeer& p) { return fnx_slab_peer_failed(p.p) != FNX_OK; },
+           "a device-side wait of this rank's exchanges has timed out, or the group was aborted (ask after synchronising the stream)");
   m.def("slab_comm_peer", [](std::shared_ptr<PyPeer> peer, py::object handle_lo, py::object handle_hi) {
     std::string lo = handle_lo.is_none() ? std::string() : handle_lo.cast<std::string>();
     std::string hi = handle_hi.is_none() ? std::string() : handle_hi.cast<std::string>();

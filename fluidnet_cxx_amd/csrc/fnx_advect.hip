@@ -666,69 +666,97 @@ static void tile_launch_geometry(const GridDims& g, int& ntx, int& nty, int& zch
   G = (unsigned)(((n + 7) / 8) * 8);
 }
 
-static void launch_fwd_tile(const GridDims& g, bool sample_outside, float dt, const float* rho, const float* U,
+// WHAT-dispatch of the templated tile launches: `K` is a generic lambda taking std::integral_constant<int, WHAT>
+template <class K> static void with_what(int what, K k) {
+  if (what == 3) k(AIC<3>{}); else if (what == 1) k(AIC<1>{}); else k(AIC<2>{});
+}
+
+static void launch_fwd_tile(const GridDims& g, int what, bool sample_outside, float dt, const float* rho, const float* U,
                             const float* flags, float* rho_fwd, int* cell, float* U_fwd, float* box, unsigned long long* fix_s,
                             unsigned long long* fix_v, hipStream_t s) {
   int ntx, nty, zchunk; unsigned G;
   tile_launch_geometry(g, ntx, nty, zchunk, G);
   const unsigned nfix = (unsigned)(((size_t)g.B * g.KN * g.H * ntx + 255) / 256);
-  if (sample_outside) {
-    advect3d_fwd_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, (float2*)box, fix_s, fix_v, ntx, nty, zchunk);
-    advect3d_fwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
-  } else {
-    advect3d_fwd_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, (float2*)box, fix_s, fix_v, ntx, nty, zchunk);
-    advect3d_fwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
-  }
+  with_what(what, [&](auto W) {
+    constexpr int WH = decltype(W)::value;
+    if (sample_outside) {
+      advect3d_fwd_tile_kernel<true, WH><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, (float2*)box, fix_s, fix_v, ntx, nty, zchunk);
+      advect3d_fwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
+    } else {
+      advect3d_fwd_tile_kernel<false, WH><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, (float2*)box, fix_s, fix_v, ntx, nty, zchunk);
+      advect3d_fwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, fix_s, fix_v, ntx);
+    }
+  });
 }
 
-// MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches
+// which plan launch_advect_fused takes for this grid: 2 = the 2D LDS tiles, 3 = the 3D z-marching tiles, 0 = one thread per cell
+// 3D default semantics: the z-marching LDS tile kernels (fnx_advect_march.h); quirks mode and plane ranges beyond the
+// tile kernels' 32-bit offsets: one thread per cell
+// 2D: LDS tile kernels (fnx_advect_tile2d.h) on grids large enough to pay for the two fix-up launches (measured, advection per
+// step, tiles vs one thread per cell: 2048^2 105 vs 129 us, 1024^2 38.6 vs 37.2, 128^2 17.6 vs 12.6), wherever a row offset
+// fits the tiles' 32-bit buffer offsets
+int advect_tile_plan(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, int plan) {
+  const bool want_tiles = plan == 1 || (plan == 0 && (is3d || (size_t)g.HW * g.B >= ((size_t)3 << 19)));
+  if (!want_tiles) return 0;
+  if (!is3d) return (size_t)g.HW < 0x3fffffffu ? 2 : 0;
+  if (quirks) return 0;
+  return ((size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu ? 1 : 0) | ((size_t)(g.KN + 2) * g.HW < 0x3fffffffu ? 4 : 0);   // bit 0: forward, bit 2: backward
+}
+
+// MacCormack self-advection of U plus advection of rho by U, both by the OLD U (simulate.py:75-93), in two launches.
+// `what`: 3 = both (one step's pair), 1 = the density only (stand-alone advectScalar: U_fwd / U_dst unused), 2 = the velocity only
+// (stand-alone advectVel with orig == U: rho / rho_fwd / cell / box / rho_dst unused).  what != 3 needs a tile plan
+// (advect_tile_plan(...) != 0 in 2D, both bits in 3D): the per-cell stand-alone launches are the callers' own.
 void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, bool sample_outside, float dt,
                          float half_s, const float* rho, const float* U, const float* flags, float* rho_fwd, int* cell,
-                         float* U_fwd, float* box, float* rho_dst, float* U_dst, unsigned long long* fix, hipStream_t s, int plan) {
+                         float* U_fwd, float* box, float* rho_dst, float* U_dst, unsigned long long* fix, hipStream_t s, int plan,
+                         int what) {
   // fix-up bitmaps of the tile kernels: 4 x (one 64-bit word per 64-cell row segment): fwd density, fwd velocity,
   // bwd density, bwd velocity
   const size_t nwords = advect_fix_words(g);
   const dim3 block(BX, BY);
+  const bool do_s = what & 1, do_v = what & 2;
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
-  // 3D default semantics: the z-marching LDS tile kernels (fnx_advect_march.h); quirks mode and plane ranges beyond the
-  // tile kernels' 32-bit offsets: one thread per cell
-  // 2D: LDS tile kernels (fnx_advect_tile2d.h) on grids large enough to pay for the two fix-up launches (measured, advection per
-  // step, tiles vs one thread per cell: 2048^2 105 vs 129 us, 1024^2 38.6 vs 37.2, 128^2 17.6 vs 12.6), wherever a row offset
-  // fits the tiles' 32-bit buffer offsets
-  const bool want_tiles = plan == 1 || (plan == 0 && (is3d || (size_t)g.HW * g.B >= ((size_t)3 << 19)));
-  if (!is3d && want_tiles && (size_t)g.HW < 0x3fffffffu) {
+  const int tp = advect_tile_plan(g, gfwd, is3d, quirks, plan);
+  if (!is3d && tp) {
     const int ntx = (g.W + 63) / 64, nty = (g.H + T2R - 1) / T2R;
     const dim3 grid((unsigned)(ntx * nty * g.B));
     const unsigned nfix = (unsigned)(((size_t)g.B * g.H * ntx + 255) / 256);
-    unsigned long long *ff_s = fix, *ff_v = fix + nwords, *fb_s = fix + 2 * nwords, *fb_v = fix + 3 * nwords;
-    if (sample_outside) {
-      advect2d_fwd_tile_kernel<true><<<grid, 64 * T2NW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx, nty);
-      advect2d_fwd_fix_kernel<true><<<nfix, 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx);
-      advect2d_bwd_tile_kernel<true><<<grid, 64 * T2NW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx, nty);
-      advect2d_bwd_fix_kernel<true><<<nfix, 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx);
-    } else {
-      advect2d_fwd_tile_kernel<false><<<grid, 64 * T2NW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx, nty);
-      advect2d_fwd_fix_kernel<false><<<nfix, 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx);
-      advect2d_bwd_tile_kernel<false><<<grid, 64 * T2NW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx, nty);
-      advect2d_bwd_fix_kernel<false><<<nfix, 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx);
-    }
+    unsigned long long *ff_s = do_s ? fix : nullptr, *ff_v = do_v ? fix + nwords : nullptr;
+    unsigned long long *fb_s = do_s ? fix + 2 * nwords : nullptr, *fb_v = do_v ? fix + 3 * nwords : nullptr;
+    with_what(what, [&](auto W) {
+      constexpr int WH = decltype(W)::value;
+      if (sample_outside) {
+        advect2d_fwd_tile_kernel<true, WH><<<grid, 64 * T2NW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx, nty);
+        advect2d_fwd_fix_kernel<true><<<nfix, 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx);
+        advect2d_bwd_tile_kernel<true, WH><<<grid, 64 * T2NW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx, nty);
+        advect2d_bwd_fix_kernel<true><<<nfix, 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx);
+      } else {
+        advect2d_fwd_tile_kernel<false, WH><<<grid, 64 * T2NW, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx, nty);
+        advect2d_fwd_fix_kernel<false><<<nfix, 256, 0, s>>>(g, dt, rho, U, flags, rho_fwd, cell, U_fwd, ff_s, ff_v, ntx);
+        advect2d_bwd_tile_kernel<false, WH><<<grid, 64 * T2NW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx, nty);
+        advect2d_bwd_fix_kernel<false><<<nfix, 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, rho_dst, U_dst, fb_s, fb_v, ntx);
+      }
+    });
     return;
   }
   // (the tile kernel also reduces the clamp bounds of the density step from the rho planes it streams)
-  if (is3d && want_tiles && !quirks && (size_t)(gfwd.KN + 2) * gfwd.HW < 0x3fffffffu) {
-    launch_fwd_tile(gfwd, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, box, fix, fix + nwords, s);
+  if (is3d && (tp & 1)) {
+    launch_fwd_tile(gfwd, what, sample_outside, dt, rho, U, flags, rho_fwd, cell, U_fwd, box, do_s ? fix : nullptr, do_v ? fix + nwords : nullptr, s);
   } else {
     DISPATCH3(is3d, quirks, sample_outside, advect_fwd_kernel, <<<cell_grid(gfwd), block, 0, s>>>(gfwd, dt, rho, U, flags, rho_fwd, cell, U_fwd));
     if (is3d) launch_box_minmax(gfwd, sample_outside, rho, flags, box, s);
   }
-  if (is3d && want_tiles && !quirks && (size_t)(g.KN + 2) * g.HW < 0x3fffffffu) {
+  if (is3d && (tp & 4)) {
     int ntx, nty, zchunk; unsigned G;
     tile_launch_geometry(g, ntx, nty, zchunk, G);
-    unsigned long long* fb_s = fix + 2 * nwords;
-    unsigned long long* fb_v = fix + 3 * nwords;
-    if (sample_outside) advect3d_bwd_scalar_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
-    else advect3d_bwd_scalar_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
-    advect3d_bwd_vel_tile_kernel<<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, U, U_fwd, flags, U_dst, fb_v, ntx, nty, zchunk);
+    unsigned long long* fb_s = do_s ? fix + 2 * nwords : nullptr;
+    unsigned long long* fb_v = do_v ? fix + 3 * nwords : nullptr;
+    if (do_s) {
+      if (sample_outside) advect3d_bwd_scalar_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
+      else advect3d_bwd_scalar_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
+    }
+    if (do_v) advect3d_bwd_vel_tile_kernel<<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, U, U_fwd, flags, U_dst, fb_v, ntx, nty, zchunk);
     const unsigned nfix = (unsigned)(((size_t)g.B * g.KN * g.H * ntx + 255) / 256);
     if (sample_outside) advect3d_bwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx);
     else advect3d_bwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx);

@@ -304,9 +304,10 @@ __device__ __forceinline__ bool atile_trace(float d0, float d1, float d2, float 
 
 // ---------------------------------------------------------------------------------------------------
 // Forward pass: sl_scalar_cell (density) + sl_mac_cell_flat (velocity) for the planes [K0, K0+KN).
-// Ring fields: rho, Ux, Uy, Uz.
+// Ring fields: rho, Ux, Uy, Uz.  WHAT: bit 0 = the density part, bit 1 = the velocity part (3: both advections of a step in one
+// march; 1 / 2: the stand-alone advectScalar / advectVel entry points -- the velocity-only march holds no rho ring).
 // ---------------------------------------------------------------------------------------------------
-template <bool SAMPLE_OUTSIDE>
+template <bool SAMPLE_OUTSIDE, int WHAT>
 __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_kernel(GridDims g, float dt, const float* __restrict__ rho,
                                                                    const float* __restrict__ U,
                                                                    const float* __restrict__ flags,
@@ -316,14 +317,19 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_k
                                                                    unsigned long long* __restrict__ fix_s,
                                                                    unsigned long long* __restrict__ fix_v, int ntx, int nty,
                                                                    int zchunk) {
-  constexpr int NF = 4;
+  constexpr bool DO_S = (WHAT & 1) != 0, DO_V = (WHAT & 2) != 0;
+  constexpr int UO = DO_S ? 1 : 0;                       // ring field of Ux
+  constexpr int NF = 3 + UO;
   ATILE_LDS(NF);
   ATile m;
   if (!atile_setup(m, g, ntx, nty, zchunk)) return;
   const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
   const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
-  const ABuf rs[NF] = { atile_rsrc(m, g, rho + sb1, after1), atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
-                        atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3) };
+  ABuf rs[NF];
+  if constexpr (DO_S) rs[0] = atile_rsrc(m, g, rho + sb1, after1);
+  rs[UO] = atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW);
+  rs[UO + 1] = atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW);
+  rs[UO + 2] = atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3);
   const ABuf rs_f = atile_rsrc(m, g, flags + sb1, after1);
   const int lane = m.lane, w = m.w, i = m.x, hr0 = ATRPW * w + 1, col = lane + m.xs;
   const bool xin = i < g.W;
@@ -362,25 +368,27 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_k
   auto body = [&](int k, unsigned fbm, unsigned fbc, unsigned fbp, const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ],
                   const float (&rP)[NF][AFSZ], auto pre_store) __attribute__((always_inline)) {
     const int kg = k + g.zoff;
-    if (k == m.k_lo) {                                     // first step of the chunk: planes k-1 and k
-      box_plane(rM, fbm, bxmn[0], bxmx[0], bxan[0]);
-      box_plane(rC, fbc, bxmn[1], bxmx[1], bxan[1]);
-    }
-    float bpmn[ATRPW], bpmx[ATRPW]; unsigned bpan;
-    box_plane(rP, fbp, bpmn, bpmx, bpan);
-    const unsigned anyrows = bxan[0] | bxan[1] | bpan;
+    if constexpr (DO_S) {
+      if (k == m.k_lo) {                                   // first step of the chunk: planes k-1 and k
+        box_plane(rM, fbm, bxmn[0], bxmx[0], bxan[0]);
+        box_plane(rC, fbc, bxmn[1], bxmx[1], bxan[1]);
+      }
+      float bpmn[ATRPW], bpmx[ATRPW]; unsigned bpan;
+      box_plane(rP, fbp, bpmn, bpmx, bpan);
+      const unsigned anyrows = bxan[0] | bxan[1] | bpan;
 #pragma unroll
-    for (int r = 0; r < ATRPW; ++r) {
-      float lo = fminf(fminf(bxmn[0][r], bxmn[1][r]), bpmn[r]), hi = fmaxf(fmaxf(bxmx[0][r], bxmx[1][r]), bpmx[r]);
-      const bool any = ((anyrows >> (3 * r)) & 0x49u) != 0;
-      lo = lo != lo ? INFINITY : lo; hi = hi != hi ? -INFINITY : hi;                      // members, but every one a NaN
-      // stored right away (nothing here waits for a store before the next step's wait for its plane)
-      const int j = m.j0 + ATRPW * w + r;
-      if (xin && j < g.H) box[sb1 + (size_t)k * g.HW + (size_t)j * g.W + i] = make_float2(any ? lo : __builtin_nanf(""), hi);
-      bxmn[0][r] = bxmn[1][r]; bxmx[0][r] = bxmx[1][r];
-      bxmn[1][r] = bpmn[r]; bxmx[1][r] = bpmx[r];
+      for (int r = 0; r < ATRPW; ++r) {
+        float lo = fminf(fminf(bxmn[0][r], bxmn[1][r]), bpmn[r]), hi = fmaxf(fmaxf(bxmx[0][r], bxmx[1][r]), bpmx[r]);
+        const bool any = ((anyrows >> (3 * r)) & 0x49u) != 0;
+        lo = lo != lo ? INFINITY : lo; hi = hi != hi ? -INFINITY : hi;                    // members, but every one a NaN
+        // stored right away (nothing here waits for a store before the next step's wait for its plane)
+        const int j = m.j0 + ATRPW * w + r;
+        if (xin && j < g.H) box[sb1 + (size_t)k * g.HW + (size_t)j * g.W + i] = make_float2(any ? lo : __builtin_nanf(""), hi);
+        bxmn[0][r] = bxmn[1][r]; bxmx[0][r] = bxmx[1][r];
+        bxmn[1][r] = bpmn[r]; bxmx[1][r] = bpmx[r];
+      }
+      bxan[0] = bxan[1]; bxan[1] = bpan;
     }
-    bxan[0] = bxan[1]; bxan[1] = bpan;
     const float ctrz = (float)kg + 0.5f;
     const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
     float o_rho[ATRPW], o_u[ATRPW][3]; int o_cell[ATRPW];
@@ -396,62 +404,66 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_k
       // 27 fluid bits of the neighbourhood: bit 9*(dz+1) + 3*(dy+1) + (dx+1)
       const unsigned nb = ((fbm >> (3 * r)) & 0x1ffu) | (((fbc >> (3 * r)) & 0x1ffu) << 9) | (((fbp >> (3 * r)) & 0x1ffu) << 18);
 
-      // ================= density: sl_scalar_cell =================
-      const float x_c = rC[1][rc0], y_c = rC[2][rc0], z_c = rC[3][rc0];
-      const float x_r = rC[1][rc0 + 1], y_u = rC[2][rc0 + ATP], z_f = rP[3][rc0];
-      const float cen0 = 0.5f * (x_c + x_r), cen1 = 0.5f * (y_c + y_u), cen2 = 0.5f * (z_c + z_f);   // get_centered
-      float p0, p1, p2;
-      const bool traced = atile_trace(ndt * cen0, ndt * cen1, ndt * cen2, ctrx, ctry, ctrz, i, j, kg, nb, p0, p1, p2);
-      const ALerp Ls = alerp(p0, p1, p2, fi, fj, fk);
-      float cs[8];
-      atile_corners<NF>(rM, rC, rP, 0, rc0, Ls.nx, Ls.ny, Ls.nz, cs);
-      // wave-uniform shortcut: when every lane that uses its sample has an all-fluid neighbourhood, interpol_with_fluid IS the
-      // plain trilinear expression (every lerp1d_fluid takes its a*ta + b*tb branch): same bits, a third of the work
-      const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb != 0x7ffffffu)) == 0;
-      const float smp = allfluid ? atrilin(cs, Ls) : atrilin_fluid(cs, atile_corner_bits(nb, Ls), Ls);
-      const float rho_c = rC[0][rc0];
-      o_rho[r] = border ? 0.f : (fluid ? smp : rho_c);
-      const bool keep = border | !fluid;                   // p = ctr
-      const float q0 = keep ? ctrx : p0, q1 = keep ? ctry : p1, q2 = keep ? ctrz : p2;
-      const int ci = clampi((int)q0, 0, g.W - 1), cj = clampi((int)q1, 0, g.H - 1);
-      const int ck = clampi((int)q2, 0, g.Dglob - 1) - g.zoff;
-      o_cell[r] = (ck + 1) * g.HW + cj * g.W + ci;
+      const float x_c = rC[UO][rc0], y_c = rC[UO + 1][rc0], z_c = rC[UO + 2][rc0];
+      const float x_r = rC[UO][rc0 + 1], y_u = rC[UO + 1][rc0 + ATP], z_f = rP[UO + 2][rc0];
       const bool live = xin & (j < g.H);
-      ws[r] = __builtin_amdgcn_ballot_w64(live & !keep & (!traced | !Ls.ok));
+      // ================= density: sl_scalar_cell =================
+      if constexpr (DO_S) {
+        const float cen0 = 0.5f * (x_c + x_r), cen1 = 0.5f * (y_c + y_u), cen2 = 0.5f * (z_c + z_f);   // get_centered
+        float p0, p1, p2;
+        const bool traced = atile_trace(ndt * cen0, ndt * cen1, ndt * cen2, ctrx, ctry, ctrz, i, j, kg, nb, p0, p1, p2);
+        const ALerp Ls = alerp(p0, p1, p2, fi, fj, fk);
+        float cs[8];
+        atile_corners<NF>(rM, rC, rP, 0, rc0, Ls.nx, Ls.ny, Ls.nz, cs);
+        // wave-uniform shortcut: when every lane that uses its sample has an all-fluid neighbourhood, interpol_with_fluid IS the
+        // plain trilinear expression (every lerp1d_fluid takes its a*ta + b*tb branch): same bits, a third of the work
+        const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb != 0x7ffffffu)) == 0;
+        const float smp = allfluid ? atrilin(cs, Ls) : atrilin_fluid(cs, atile_corner_bits(nb, Ls), Ls);
+        const float rho_c = rC[0][rc0];
+        o_rho[r] = border ? 0.f : (fluid ? smp : rho_c);
+        const bool keep = border | !fluid;                 // p = ctr
+        const float q0 = keep ? ctrx : p0, q1 = keep ? ctry : p1, q2 = keep ? ctrz : p2;
+        const int ci = clampi((int)q0, 0, g.W - 1), cj = clampi((int)q1, 0, g.H - 1);
+        const int ck = clampi((int)q2, 0, g.Dglob - 1) - g.zoff;
+        o_cell[r] = (ck + 1) * g.HW + cj * g.W + ci;
+        ws[r] = __builtin_amdgcn_ballot_w64(live & !keep & (!traced | !Ls.ok));
+      }
 
       // ================= velocity: sl_mac_cell_flat =================
-      // get_at_mac<true, false, 0/1/2> (fnx_device.h), operand for operand
-      float v0[3], v1[3], v2[3];
-      v0[0] = x_c;
-      v0[1] = 0.25f * (((y_c + rC[2][rc0 - 1]) + y_u) + rC[2][rc0 + ATP - 1]);
-      v0[2] = 0.25f * (((z_c + rC[3][rc0 - 1]) + z_f) + rP[3][rc0 - 1]);
-      v1[0] = 0.25f * (((x_c + rC[1][rc0 - ATP]) + x_r) + rC[1][rc0 - ATP + 1]);
-      v1[1] = y_c;
-      v1[2] = 0.25f * (((z_c + rC[3][rc0 - ATP]) + z_f) + rP[3][rc0 - ATP]);
-      v2[0] = 0.25f * (((x_c + rM[1][rc0]) + x_r) + rM[1][rc0 + 1]);
-      v2[1] = 0.25f * (((y_c + rM[2][rc0]) + y_u) + rM[2][rc0 + ATP]);
-      v2[2] = z_c;
-      bool okv = true;
-      {
-        const ALerp L = alerp(ctrx + v0[0] * ndt, ctry + v0[1] * ndt, ctrz + v0[2] * ndt, fi, fj, fk);
-        float c[8]; atile_corners<NF>(rM, rC, rP, 1, rc0, L.nx, L.ny, L.nz, c);
-        o_u[r][0] = fluid ? atrilin(c, L) : y_c;            // non-fluid cell: channel 1 into channel 0 (:413-416)
-        okv &= L.ok;
+      if constexpr (DO_V) {
+        // get_at_mac<true, false, 0/1/2> (fnx_device.h), operand for operand
+        float v0[3], v1[3], v2[3];
+        v0[0] = x_c;
+        v0[1] = 0.25f * (((y_c + rC[UO + 1][rc0 - 1]) + y_u) + rC[UO + 1][rc0 + ATP - 1]);
+        v0[2] = 0.25f * (((z_c + rC[UO + 2][rc0 - 1]) + z_f) + rP[UO + 2][rc0 - 1]);
+        v1[0] = 0.25f * (((x_c + rC[UO][rc0 - ATP]) + x_r) + rC[UO][rc0 - ATP + 1]);
+        v1[1] = y_c;
+        v1[2] = 0.25f * (((z_c + rC[UO + 2][rc0 - ATP]) + z_f) + rP[UO + 2][rc0 - ATP]);
+        v2[0] = 0.25f * (((x_c + rM[UO][rc0]) + x_r) + rM[UO][rc0 + 1]);
+        v2[1] = 0.25f * (((y_c + rM[UO + 1][rc0]) + y_u) + rM[UO + 1][rc0 + ATP]);
+        v2[2] = z_c;
+        bool okv = true;
+        {
+          const ALerp L = alerp(ctrx + v0[0] * ndt, ctry + v0[1] * ndt, ctrz + v0[2] * ndt, fi, fj, fk);
+          float c[8]; atile_corners<NF>(rM, rC, rP, UO, rc0, L.nx, L.ny, L.nz, c);
+          o_u[r][0] = fluid ? atrilin(c, L) : y_c;          // non-fluid cell: channel 1 into channel 0 (:413-416)
+          okv &= L.ok;
+        }
+        {
+          const ALerp L = alerp(ctrx + v1[0] * ndt, ctry + v1[1] * ndt, ctrz + v1[2] * ndt, fi, fj, fk);
+          float c[8]; atile_corners<NF>(rM, rC, rP, UO + 1, rc0, L.nx, L.ny, L.nz, c);
+          o_u[r][1] = fluid ? atrilin(c, L) : 0.f;
+          okv &= L.ok;
+        }
+        {
+          const ALerp L = alerp(ctrx + v2[0] * ndt, ctry + v2[1] * ndt, ctrz + v2[2] * ndt, fi, fj, fk);
+          float c[8]; atile_corners<NF>(rM, rC, rP, UO + 2, rc0, L.nx, L.ny, L.nz, c);
+          o_u[r][2] = fluid ? atrilin(c, L) : z_c;
+          okv &= L.ok;
+        }
+        wv[r] = __builtin_amdgcn_ballot_w64(live & !border & fluid & !okv);
+        if (border) { o_u[r][0] = 0.f; o_u[r][1] = 0.f; o_u[r][2] = 0.f; }
       }
-      {
-        const ALerp L = alerp(ctrx + v1[0] * ndt, ctry + v1[1] * ndt, ctrz + v1[2] * ndt, fi, fj, fk);
-        float c[8]; atile_corners<NF>(rM, rC, rP, 2, rc0, L.nx, L.ny, L.nz, c);
-        o_u[r][1] = fluid ? atrilin(c, L) : 0.f;
-        okv &= L.ok;
-      }
-      {
-        const ALerp L = alerp(ctrx + v2[0] * ndt, ctry + v2[1] * ndt, ctrz + v2[2] * ndt, fi, fj, fk);
-        float c[8]; atile_corners<NF>(rM, rC, rP, 3, rc0, L.nx, L.ny, L.nz, c);
-        o_u[r][2] = fluid ? atrilin(c, L) : z_c;
-        okv &= L.ok;
-      }
-      wv[r] = __builtin_amdgcn_ballot_w64(live & !border & fluid & !okv);
-      if (border) { o_u[r][0] = 0.f; o_u[r][1] = 0.f; o_u[r][2] = 0.f; }
     }
     pre_store();
 #pragma unroll
@@ -459,14 +471,22 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_FWD) void advect3d_fwd_tile_k
       const int j = m.j0 + ATRPW * w + r;
       if (xin && j < g.H) {
         const size_t o = (size_t)k * g.HW + (size_t)j * g.W + i;
-        rho_fwd[sb1 + o] = o_rho[r];
-        cell_out[sb1 + o] = o_cell[r];
-        U_fwd[sb3 + o] = o_u[r][0];
-        U_fwd[sb3 + g.DHW + o] = o_u[r][1];
-        U_fwd[sb3 + 2 * (size_t)g.DHW + o] = o_u[r][2];
+        if constexpr (DO_S) {
+          rho_fwd[sb1 + o] = o_rho[r];
+          cell_out[sb1 + o] = o_cell[r];
+        }
+        if constexpr (DO_V) {
+          U_fwd[sb3 + o] = o_u[r][0];
+          U_fwd[sb3 + g.DHW + o] = o_u[r][1];
+          U_fwd[sb3 + 2 * (size_t)g.DHW + o] = o_u[r][2];
+        }
       }
       // lanes the neighbourhood path does not cover (|displacement| >= 1 cell, trace into a non-fluid cell) go to the fix-up
-      if (lane == 0 && j < g.H) { const size_t wi = m.word(g, k, j); fix_s[wi] = ws[r]; fix_v[wi] = wv[r]; }
+      if (lane == 0 && j < g.H) {
+        const size_t wi = m.word(g, k, j);
+        if constexpr (DO_S) fix_s[wi] = ws[r];
+        if constexpr (DO_V) fix_v[wi] = wv[r];
+      }
     }
   };
   atile_march<NF>(g, m, rs, rs_f, ring0, ring1, ring2, ring3, fst0, fst1, body);
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(256) void advect3d_fwd_fix_kernel(GridDims g, float
                                                                const unsigned long long* __restrict__ fix_v, int ntx) {
   CellId c; size_t wi;
   if (!afix_decode(g, ntx, (size_t)blockIdx.x * 256 + threadIdx.x, c, wi)) return;
-  unsigned long long ws = fix_s[wi], wv = fix_v[wi];
+  unsigned long long ws = fix_s ? fix_s[wi] : 0ull, wv = fix_v ? fix_v[wi] : 0ull;   // (a stand-alone advection has one bitmap)
   const int i0 = c.i;
   for (unsigned long long a = ws | wv; a != 0; a &= a - 1) {
     const int bit = __builtin_ctzll(a);
@@ -712,7 +732,7 @@ __global__ __launch_bounds__(256) void advect3d_bwd_fix_kernel(GridDims g, float
                                                                const unsigned long long* __restrict__ fix_v, int ntx) {
   CellId c; size_t wi;
   if (!afix_decode(g, ntx, (size_t)blockIdx.x * 256 + threadIdx.x, c, wi)) return;
-  unsigned long long ws = fix_s[wi], wv = fix_v[wi];
+  unsigned long long ws = fix_s ? fix_s[wi] : 0ull, wv = fix_v ? fix_v[wi] : 0ull;
   const int i0 = c.i;
   for (unsigned long long a = ws | wv; a != 0; a &= a - 1) {
     const int bit = __builtin_ctzll(a);

@@ -94,8 +94,9 @@ __device__ __forceinline__ float t2_bilin_fluid(const float (&c)[4], unsigned nb
 
 // ---------------------------------------------------------------------------------------------------
 // Forward pass: sl_scalar_cell<false> (density) + sl_mac_cell_flat<false> (velocity).  LDS fields: rho, Ux, Uy, flags.
+// WHAT: bit 0 = the density part, bit 1 = the velocity part (3: both advections of a step; 1 / 2: stand-alone advectScalar / advectVel).
 // ---------------------------------------------------------------------------------------------------
-template <bool SAMPLE_OUTSIDE>
+template <bool SAMPLE_OUTSIDE, int WHAT>
 __global__ __launch_bounds__(64 * T2NW) void advect2d_fwd_tile_kernel(GridDims g, float dt, const float* __restrict__ rho,
                                                                       const float* __restrict__ U,
                                                                       const float* __restrict__ flags,
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_fwd_tile_kernel(GridDims g
   t2_setup(m, g, ntx, nty);
   const size_t sb1 = (size_t)m.b * g.DHW, sb2 = (size_t)m.b * 2 * g.DHW;
   const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after2 = 2 * after1;
-  t2_load(m, g, rho + sb1, after1, tl[0]);
+  constexpr bool DO_S = (WHAT & 1) != 0, DO_V = (WHAT & 2) != 0;
+  if constexpr (DO_S) t2_load(m, g, rho + sb1, after1, tl[0]);
   t2_load(m, g, U + sb2, after2 + g.DHW, tl[1]);
   t2_load(m, g, U + sb2 + g.DHW, after2, tl[2]);
   t2_load(m, g, flags + sb1, after1, tl[3]);
@@ -126,27 +128,31 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_fwd_tile_kernel(GridDims g
     const int rc0 = (T2HALO + T2RPW * w + r) * T2P + col;
     const unsigned nb9 = t2_fluid9(tl[3], rc0);
     const bool fluid = (nb9 >> 4) & 1u;
-    // ================= density: sl_scalar_cell =================
     const float x_c = tl[1][rc0], y_c = tl[2][rc0], x_r = tl[1][rc0 + 1], y_u = tl[2][rc0 + T2P];
-    const float cen0 = 0.5f * (x_c + x_r), cen1 = 0.5f * (y_c + y_u), cen2 = 0.f;            // get_centered<false>
-    float p0, p1, p2;
-    const bool traced = atile_trace(ndt * cen0, ndt * cen1, ndt * cen2, ctrx, ctry, 0.5f, i, j, 0, nb9 << 9, p0, p1, p2);
-    const ALerp Ls = alerp(p0, p1, 0.5f, fi, fj, 0.f);
-    float cs[4];
-    t2_corners(tl[0], rc0, Ls.nx, Ls.ny, cs);
-    // (wave-uniform shortcut as in the 3D tiles: with an all-fluid neighbourhood interpol_with_fluid IS the plain expression)
-    const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb9 != 0x1ffu)) == 0;
-    const float smp = allfluid ? t2_bilin(cs, Ls) : t2_bilin_fluid(cs, nb9, Ls);
-    const float rho_c = tl[0][rc0];
-    const float o_rho = border ? 0.f : (fluid ? smp : rho_c);
-    const bool keep = border | !fluid;                     // p = ctr
-    const float q0 = keep ? ctrx : p0, q1 = keep ? ctry : p1;
-    const int ci = clampi((int)q0, 0, g.W - 1), cj = clampi((int)q1, 0, g.H - 1);
-    const int o_cell = (cj << 16) | ci;
-    const unsigned long long ws = __builtin_amdgcn_ballot_w64(live & !keep & (!traced | !Ls.ok));
+    // ================= density: sl_scalar_cell =================
+    float o_rho = 0.f; int o_cell = 0; unsigned long long ws = 0ull;
+    if constexpr (DO_S) {
+      const float cen0 = 0.5f * (x_c + x_r), cen1 = 0.5f * (y_c + y_u), cen2 = 0.f;          // get_centered<false>
+      float p0, p1, p2;
+      const bool traced = atile_trace(ndt * cen0, ndt * cen1, ndt * cen2, ctrx, ctry, 0.5f, i, j, 0, nb9 << 9, p0, p1, p2);
+      const ALerp Ls = alerp(p0, p1, 0.5f, fi, fj, 0.f);
+      float cs[4];
+      t2_corners(tl[0], rc0, Ls.nx, Ls.ny, cs);
+      // (wave-uniform shortcut as in the 3D tiles: with an all-fluid neighbourhood interpol_with_fluid IS the plain expression)
+      const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb9 != 0x1ffu)) == 0;
+      const float smp = allfluid ? t2_bilin(cs, Ls) : t2_bilin_fluid(cs, nb9, Ls);
+      const float rho_c = tl[0][rc0];
+      o_rho = border ? 0.f : (fluid ? smp : rho_c);
+      const bool keep = border | !fluid;                   // p = ctr
+      const float q0 = keep ? ctrx : p0, q1 = keep ? ctry : p1;
+      const int ci = clampi((int)q0, 0, g.W - 1), cj = clampi((int)q1, 0, g.H - 1);
+      o_cell = (cj << 16) | ci;
+      ws = __builtin_amdgcn_ballot_w64(live & !keep & (!traced | !Ls.ok));
+    }
     // ================= velocity: sl_mac_cell_flat =================
-    float o_u[2];
+    float o_u[2] = {0.f, 0.f};
     bool okv = true;
+    if constexpr (DO_V) {
     {
       const float v0 = x_c, v1 = 0.25f * (((y_c + tl[2][rc0 - 1]) + y_u) + tl[2][rc0 + T2P - 1]);       // get_at_mac<false, ., 0>
       const ALerp L = alerp(ctrx + v0 * ndt, ctry + v1 * ndt, 0.5f, fi, fj, 0.f);
@@ -161,24 +167,34 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_fwd_tile_kernel(GridDims g
       o_u[1] = fluid ? t2_bilin(c, L) : 0.f;
       okv &= L.ok;
     }
-    const unsigned long long wv = __builtin_amdgcn_ballot_w64(live & !border & fluid & !okv);
+    }
+    const unsigned long long wv = DO_V ? __builtin_amdgcn_ballot_w64(live & !border & fluid & !okv) : 0ull;
     if (border) { o_u[0] = 0.f; o_u[1] = 0.f; }
     if (live) {
       const size_t o = (size_t)j * g.W + i;
-      rho_fwd[sb1 + o] = o_rho;
-      cell_out[sb1 + o] = o_cell;
-      U_fwd[sb2 + o] = o_u[0];
-      U_fwd[sb2 + g.DHW + o] = o_u[1];
+      if constexpr (DO_S) {
+        rho_fwd[sb1 + o] = o_rho;
+        cell_out[sb1 + o] = o_cell;
+      }
+      if constexpr (DO_V) {
+        U_fwd[sb2 + o] = o_u[0];
+        U_fwd[sb2 + g.DHW + o] = o_u[1];
+      }
     }
-    if (lane == 0 && j < g.H) { const size_t wi = m.word(g, j); fix_s[wi] = ws; fix_v[wi] = wv; }
+    if (lane == 0 && j < g.H) {
+      const size_t wi = m.word(g, j);
+      if constexpr (DO_S) fix_s[wi] = ws;
+      if constexpr (DO_V) fix_v[wi] = wv;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Backward pass: sl_scalar_bwd_clamp_cell<false> + sl_mac_bwd_clamp_cell_flat<false> (self-advection: orig == U).
 // LDS fields: rho_fwd, Ux, Uy, flags, rho (the clamp walks the 3x3 box of the traced cell: halo 2), U_fwd x, y.
+// WHAT as in the forward kernel.
 // ---------------------------------------------------------------------------------------------------
-template <bool SAMPLE_OUTSIDE>
+template <bool SAMPLE_OUTSIDE, int WHAT>
 __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g, float dt, float half_s,
                                                                       const float* __restrict__ rho,
                                                                       const float* __restrict__ rho_fwd,
@@ -194,13 +210,16 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g
   t2_setup(m, g, ntx, nty);
   const size_t sb1 = (size_t)m.b * g.DHW, sb2 = (size_t)m.b * 2 * g.DHW;
   const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after2 = 2 * after1;
-  t2_load(m, g, rho_fwd + sb1, after1, tl[0]);
+  constexpr bool DO_S = (WHAT & 1) != 0, DO_V = (WHAT & 2) != 0;
+  if constexpr (DO_S) t2_load(m, g, rho_fwd + sb1, after1, tl[0]);
   t2_load(m, g, U + sb2, after2 + g.DHW, tl[1]);
   t2_load(m, g, U + sb2 + g.DHW, after2, tl[2]);
   t2_load(m, g, flags + sb1, after1, tl[3]);
-  t2_load(m, g, rho + sb1, after1, tl[4]);
-  t2_load(m, g, U_fwd + sb2, after2 + g.DHW, tl[5]);
-  t2_load(m, g, U_fwd + sb2 + g.DHW, after2, tl[6]);
+  if constexpr (DO_S) t2_load(m, g, rho + sb1, after1, tl[4]);
+  if constexpr (DO_V) {
+    t2_load(m, g, U_fwd + sb2, after2 + g.DHW, tl[5]);
+    t2_load(m, g, U_fwd + sb2 + g.DHW, after2, tl[6]);
+  }
   const int lane = m.lane, w = m.w, i = m.x, col = lane + m.xs;
   const bool xin = i < g.W;
   // the traced cells of my rows (per-cell global operands), issued before the barrier
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g
 #pragma unroll
   for (int r = 0; r < T2RPW; ++r) {
     const int j = m.j0 + T2RPW * w + r;
-    cell[r] = cell_in[sb1 + (size_t)(j < g.H ? j : g.H - 1) * g.W + (xin ? i : g.W - 1)];
+    cell[r] = DO_S ? cell_in[sb1 + (size_t)(j < g.H ? j : g.H - 1) * g.W + (xin ? i : g.W - 1)] : 0;
   }
   __syncthreads();
 #pragma unroll
@@ -223,6 +242,8 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g
     const bool fluid = (nb9 >> 4) & 1u;
     const float x_c = tl[1][rc0], y_c = tl[2][rc0], x_r = tl[1][rc0 + 1], y_u = tl[2][rc0 + T2P];
     // ================= density: sl_scalar_bwd_clamp_cell =================
+    float o_d = 0.f; unsigned long long ws = 0ull;
+    if constexpr (DO_S) {
     const float f = tl[0][rc0];
     const float cen0 = 0.5f * (x_c + x_r), cen1 = 0.5f * (y_c + y_u), cen2 = 0.f;
     float p0, p1, p2;                                       // displacement (-ndt) * cen with ndt = -dt
@@ -254,16 +275,18 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g
         any = any | ok;
       }
     const float dc = any ? fmaxf(mn, fminf(mx, d)) : f;
-    const float o_d = border ? d : dc;
-    const unsigned long long ws = __builtin_amdgcn_ballot_w64(live & !border & ((fluid & (!traced | !Ls.ok)) | !nearc));
+    o_d = border ? d : dc;
+    ws = __builtin_amdgcn_ballot_w64(live & !border & ((fluid & (!traced | !Ls.ok)) | !nearc));
+    }
     // ================= velocity: sl_mac_bwd_clamp_cell_flat =================
+    float o_u[2] = {0.f, 0.f};
+    bool ok = true;
+    if constexpr (DO_V) {
     const bool fmx = (nb9 >> 3) & 1u, fmy = (nb9 >> 1) & 1u;             // flags of the -1 neighbours along x, y
     float v[2][2];
     v[0][0] = x_c; v[0][1] = 0.25f * (((y_c + tl[2][rc0 - 1]) + y_u) + tl[2][rc0 + T2P - 1]);
     v[1][0] = 0.25f * (((x_c + tl[1][rc0 - T2P]) + x_r) + tl[1][rc0 - T2P + 1]); v[1][1] = y_c;
     const float fwd0 = tl[5][rc0], fwd1 = tl[6][rc0];
-    float o_u[2];
-    bool ok = true;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const float vd0 = v[a][0] * dt, vd1 = v[a][1] * dt;
@@ -292,14 +315,21 @@ __global__ __launch_bounds__(64 * T2NW) void advect2d_bwd_tile_kernel(GridDims g
       o_u[a] = border ? 0.f : fmaxf(fminf(corr, bmx), bmn);
       ok &= okc & (L.ok | !fluid);
     }
-    const unsigned long long wv = __builtin_amdgcn_ballot_w64(live & !border & !ok);
+    }
+    const unsigned long long wv = DO_V ? __builtin_amdgcn_ballot_w64(live & !border & !ok) : 0ull;
     if (live) {
       const size_t o = (size_t)j * g.W + i;
-      rho_dst[sb1 + o] = o_d;
-      U_dst[sb2 + o] = o_u[0];
-      U_dst[sb2 + g.DHW + o] = o_u[1];
+      if constexpr (DO_S) rho_dst[sb1 + o] = o_d;
+      if constexpr (DO_V) {
+        U_dst[sb2 + o] = o_u[0];
+        U_dst[sb2 + g.DHW + o] = o_u[1];
+      }
     }
-    if (lane == 0 && j < g.H) { const size_t wi = m.word(g, j); fix_s[wi] = ws; fix_v[wi] = wv; }
+    if (lane == 0 && j < g.H) {
+      const size_t wi = m.word(g, j);
+      if constexpr (DO_S) fix_s[wi] = ws;
+      if constexpr (DO_V) fix_v[wi] = wv;
+    }
   }
 }
 
@@ -325,7 +355,7 @@ __global__ __launch_bounds__(256) void advect2d_fwd_fix_kernel(GridDims g, float
                                                                const unsigned long long* __restrict__ fix_v, int ntx) {
   CellId c; size_t wi;
   if (!t2fix_decode(g, ntx, (size_t)blockIdx.x * 256 + threadIdx.x, c, wi)) return;
-  const unsigned long long ws = fix_s[wi], wv = fix_v[wi];
+  const unsigned long long ws = fix_s ? fix_s[wi] : 0ull, wv = fix_v ? fix_v[wi] : 0ull;   // (a stand-alone advection has one bitmap)
   const int i0 = c.i;
   for (unsigned long long a = ws | wv; a != 0; a &= a - 1) {
     const int bit = __builtin_ctzll(a);
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(256) void advect2d_bwd_fix_kernel(GridDims g, float
                                                                const unsigned long long* __restrict__ fix_v, int ntx) {
   CellId c; size_t wi;
   if (!t2fix_decode(g, ntx, (size_t)blockIdx.x * 256 + threadIdx.x, c, wi)) return;
-  const unsigned long long ws = fix_s[wi], wv = fix_v[wi];
+  const unsigned long long ws = fix_s ? fix_s[wi] : 0ull, wv = fix_v ? fix_v[wi] : 0ull;   // (a stand-alone advection has one bitmap)
   const int i0 = c.i;
   for (unsigned long long a = ws | wv; a != 0; a &= a - 1) {
     const int bit = __builtin_ctzll(a);

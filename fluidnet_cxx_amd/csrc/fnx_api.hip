@@ -67,10 +67,13 @@ struct Carver {
   bool ok() const { return base != nullptr && off <= cap; }
 };
 
-size_t ws_advect_scalar(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4) + (g->is3D ? al(ncell(g) * 8) : 0); }   // fwd, traced cell, 3D clamp bounds
-size_t ws_advect_vel(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
+size_t ws_advect_scalar_fields(const FnxGrid* g) { return al(ncell(g) * 4) + al(ncell(g) * 4) + (g->is3D ? al(ncell(g) * 8) : 0); }   // fwd, traced cell, 3D clamp bounds
+size_t ws_advect_vel_fields(const FnxGrid* g) { return al(ncell(g) * 4 * (g->is3D ? 3 : 2)); }
 // fix-up bitmaps of the tile advection kernels (fnx_advect_march.h, fnx_advect_tile2d.h): 4 x one 64-bit word per 64-cell row segment
 size_t ws_advect_fix(const FnxGrid* g) { return al(4 * 8 * (size_t)g->B * g->D * g->H * ((g->W + 63) / 64)); }
+// the stand-alone operators take the tile kernels too (ABI 19): their fields + the bitmaps
+size_t ws_advect_scalar(const FnxGrid* g) { return ws_advect_scalar_fields(g) + ws_advect_fix(g); }
+size_t ws_advect_vel(const FnxGrid* g) { return ws_advect_vel_fields(g) + ws_advect_fix(g); }
 size_t ws_mask(const FnxGrid* g) { return g->is3D ? al(fnx::jacobi3d_mask_bytes(dims(g))) : 0; }   // 3D solver: neighbour-mask bytes, twice (rows / row groups)
 // Jacobi workspace: ping-pong pressure, the residual's fixed-order partial sums, one result float, the 3D neighbour mask
 size_t ws_jacobi(const FnxGrid* g) { return al(ncell(g) * 4) + al(fnx::residual_scratch_bytes(g->B)) + al(4) + ws_mask(g); }
@@ -87,7 +90,7 @@ bool carve_jacobi(const FnxGrid* g, void* ws, size_t ws_bytes, JacobiWs* out, si
 size_t ws_step(const FnxGrid* g) {
   const size_t nc = g->is3D ? 3 : 2;
   // 2D: the fused advection launches keep both forward fields at once
-  size_t adv = ws_advect_scalar(g) + ws_advect_vel(g) + ws_advect_fix(g);
+  size_t adv = ws_advect_scalar_fields(g) + ws_advect_vel_fields(g) + ws_advect_fix(g);
   size_t solve = ws_jacobi(g);
   size_t cnn = fnx::fluidnet_ws_bytes(dims(g), g->is3D);
   size_t tail = adv > solve ? adv : solve;
@@ -226,7 +229,7 @@ size_t fnx_workspace_bytes(const FnxGrid* g, int op) {
     case FNX_OP_JACOBI: return ws_jacobi(g);
     case FNX_OP_STEP: return ws_step(g);
     case FNX_OP_FLUIDNET: return fnx::fluidnet_ws_bytes(dims(g), g->is3D);
-    case FNX_OP_ADVECT_STEP: return ws_advect_scalar(g) + ws_advect_vel(g) + ws_advect_fix(g);
+    case FNX_OP_ADVECT_STEP: return ws_advect_scalar_fields(g) + ws_advect_vel_fields(g) + ws_advect_fix(g);
   }
   fail(FNX_EINVAL, "unknown op %d", op);
   return 0;
@@ -235,7 +238,14 @@ size_t fnx_workspace_bytes(const FnxGrid* g, int op) {
 int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float* U, const float* flags, float* dst,
                       int method, int bnd, int sample_outside, float strength, void* ws, size_t ws_bytes,
                       void* stream) {
+  return fnx_advect_scalar_plan(g, dt, src, U, flags, dst, method, bnd, sample_outside, strength, FNX_ADVECT_PLAN_AUTO, ws, ws_bytes, stream);
+}
+
+int fnx_advect_scalar_plan(const FnxGrid* g, float dt, const float* src, const float* U, const float* flags, float* dst,
+                           int method, int bnd, int sample_outside, float strength, int plan, void* ws, size_t ws_bytes,
+                           void* stream) {
   if (int rc = check_grid(g)) return rc;
+  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_CELLS) return fail(FNX_EINVAL, "advect_scalar: unknown plan %d", plan);
   if (!src || !U || !flags || !dst) return fail(FNX_EINVAL, "advect_scalar: NULL tensor");
   if (dst == src) return fail(FNX_EINVAL, "advect_scalar: dst must not alias src");
   if (method != FNX_ADVECT_EULER && method != FNX_ADVECT_MACCORMACK) return fail(FNX_EMETHOD, "Advection method not supported");
@@ -249,8 +259,19 @@ int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float*
     float* fwd = (float*)c.take(ncell(g) * 4);
     int* cell = (int*)c.take(ncell(g) * 4);
     float* box = g->is3D ? (float*)c.take(ncell(g) * 8) : nullptr;
+    unsigned long long* fix = (unsigned long long*)c.take(ws_advect_fix(g));
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_scalar: workspace too small (%zu < %zu)", ws_bytes, c.off);
     const GridDims dw = widened(d, 2);                  // what the backward pass / clamp read at |U dt| <= 1
+    // the LDS tile kernels of the fused pair, density part only (3D default semantics; 2D from 1.5 M cells): same bits as the
+    // per-cell launches below (fnx_advect_march.h), ~1.5x faster in 3D
+    const int tp = fnx::advect_tile_plan(d, dw, g->is3D, quirks(g), plan);
+    if (g->is3D ? tp == 5 : tp == 2) {
+      fnx::ProfScope ps(FNX_PROF_ADVECT, s);
+      fnx::launch_advect_fused(d, dw, g->is3D, false, sample_outside != 0, dt, strength * 0.5f, src, U, flags, fwd, cell, nullptr, box,
+                               dst, nullptr, fix, s, plan, 1);
+      HIP_OK(hipGetLastError());
+      return FNX_OK;
+    }
     { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_scalar(dw, g->is3D, quirks(g), sample_outside != 0, dt, src, U, flags, fwd, cell, s); }
     if (g->is3D) { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_box_minmax(dw, sample_outside != 0, src, flags, box, s); }
     else box = nullptr;                                  // 2D: the 3x3 clamp box is walked in the backward kernel
@@ -264,7 +285,13 @@ int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float*
 
 int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags, float* dst,
                    int method, int bnd, float strength, void* ws, size_t ws_bytes, void* stream) {
+  return fnx_advect_vel_plan(g, dt, orig, U, flags, dst, method, bnd, strength, FNX_ADVECT_PLAN_AUTO, ws, ws_bytes, stream);
+}
+
+int fnx_advect_vel_plan(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags, float* dst,
+                        int method, int bnd, float strength, int plan, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_grid(g)) return rc;
+  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_CELLS) return fail(FNX_EINVAL, "advect_vel: unknown plan %d", plan);
   if (!orig || !U || !flags || !dst) return fail(FNX_EINVAL, "advect_vel: NULL tensor");
   if (dst == orig || dst == U) return fail(FNX_EINVAL, "advect_vel: dst must not alias orig or U");
   if (method != FNX_ADVECT_EULER && method != FNX_ADVECT_MACCORMACK) return fail(FNX_EMETHOD, "Advection method not supported");
@@ -276,7 +303,17 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
   } else {
     Carver c(ws, ws_bytes);
     float* fwd = (float*)c.take(ncell(g) * 4 * (g->is3D ? 3 : 2));
+    unsigned long long* fix = (unsigned long long*)c.take(ws_advect_fix(g));
     if (!c.ok()) return fail(FNX_EWORKSPACE, "advect_vel: workspace too small (%zu < %zu)", ws_bytes, c.off);
+    // self-advection (orig is U: every call of simulate.py:93 without viscosity): the LDS tile kernels, velocity part only
+    const int tp = orig == U ? fnx::advect_tile_plan(d, widened(d, 2), g->is3D, quirks(g), plan) : 0;
+    if (g->is3D ? tp == 5 : tp == 2) {
+      fnx::ProfScope ps(FNX_PROF_ADVECT, s);
+      fnx::launch_advect_fused(d, widened(d, 2), g->is3D, false, false, dt, strength * 0.5f, nullptr, U, flags, nullptr, nullptr, fwd,
+                               nullptr, nullptr, dst, fix, s, plan, 2);
+      HIP_OK(hipGetLastError());
+      return FNX_OK;
+    }
     { fnx::ProfScope ps(FNX_PROF_ADVECT, s); fnx::launch_sl_mac(widened(d, 2), g->is3D, quirks(g), dt, orig, U, flags, fwd, s); }
     fnx::ProfScope ps2(FNX_PROF_ADVECT, s);
     fnx::launch_sl_mac_bwd_clamp(d, g->is3D, quirks(g), dt, strength * 0.5f, orig, fwd, U, flags, dst, s);

@@ -746,19 +746,23 @@ __global__ __launch_bounds__(64 * Z2NW, Z2WPS) void jacobi3d_march2_kernel(GridD
       float v[Z2R];
       sweep(IC<Z2R>{}, IC<1>{}, prev_sel, AM[SM], P1[SM], &P1[SN][1], &P1[SC][1], &AD[SM][1], v);
       const unsigned ok = (unsigned)((t - 1 - k0) * g.HW + j0 * g.W) * 4u;
-      const unsigned okx = (unsigned)((t - 1 - mk0) * g.HW + j0 * g.W) * 4u;      // (MIR) wraps out of range below the mirrored planes
+      // (MIR) the mirrored planes are [mk0, mk0 + mir.n): a wave-uniform test, not the buffer range check -- the scalar offset of a
+      // buffer instruction is outside that check, and a plane below mk0 would wrap it around 2^32.  Inside the window the plane offset
+      // travels in the bounds-checked vector offset.
+      const bool mir_plane = MIR && (unsigned)(t - 1 - mk0) < (unsigned)mir.n;
+      const unsigned okx = mir_plane ? (unsigned)((t - 1 - mk0) * g.HW + j0 * g.W) * 4u : 0u;
       if (LAY & 2) {                                       // j0 * W floats into the plane is the tile's row group in both layouts
         if (lane_out) {
           const f32x4 o = {v[0], v[1], v[2], v[3]};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_o, xoff4, ok, 0);
-          if (MIR) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_x, xoff4, okx, 0);
+          if (mir_plane) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_x, xoff4 + okx, 0, 0);
         }
       } else
 #pragma unroll
       for (int r = 0; r < Z2R; ++r) {
         if (lane_out && j0 + r < g.H) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_o, xoff, ok + (unsigned)(r * g.W) * 4u, 0);
-          if (MIR) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_x, xoff, okx + (unsigned)(r * g.W) * 4u, 0);
+          if (mir_plane) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), r_x, xoff + okx + (unsigned)(r * g.W) * 4u, 0, 0);
         }
       }
     }

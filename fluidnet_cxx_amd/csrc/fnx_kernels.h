@@ -29,7 +29,10 @@ size_t advect_fix_words(const GridDims& g);
 void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, bool sample_outside, float dt,
                          float half_s, const float* rho, const float* U, const float* flags, float* rho_fwd, int* cell,
                          float* U_fwd, float* box, float* rho_dst, float* U_dst, unsigned long long* fix, hipStream_t s,
-                         int plan = 0);   // plan: FNX_ADVECT_PLAN_*
+                         int plan = 0, int what = 3);   // plan: FNX_ADVECT_PLAN_*; what: 3 both, 1 density only, 2 velocity only (tiles only)
+// which kernels launch_advect_fused takes: 0 = one thread per cell; 2D: 2 = LDS tiles; 3D: bit 0 / bit 2 = z-marching tiles for the
+// forward / backward pass
+int advect_tile_plan(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, int plan);
 void launch_box_minmax(const GridDims& g, bool sample_outside, const float* src, const float* flags, float* box,
                        hipStream_t s);
 void launch_sl_mac(const GridDims& g, bool is3d, bool quirks, float dt, const float* src, const float* U,

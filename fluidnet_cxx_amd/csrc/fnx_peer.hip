@@ -22,13 +22,17 @@
 // exchange's push workgroups only raise the ready words.
 //
 // A wait that lasts longer than the timeout (a dead peer) or sees the abort word gives up, raises the rank's error word (pinned host
-// memory: the next call of the communicator fails with FNX_ECOMM without a synchronisation) and leaves the planes alone -- a spin
-// must never outlive its peer on a GPU other processes share.
+// memory: the next call of the communicator fails with FNX_ECOMM without a synchronisation) AND the rank's own abort word, and leaves
+// the planes alone.  Every exchange launch looks at the abort word when it starts: the launches already queued behind the failed one --
+// the rest of the step, the rest of a replayed graph -- return at once, so a dead neighbour costs ONE time-out, not one per exchange (a
+// spin must never outlive its peer on a GPU other processes share).  A step / replay that ran into this still returns FNX_OK (nothing on
+// the host waited): fnx_slab_peer_failed() after the caller's synchronisation says whether its ghost planes can be trusted.
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <unistd.h>
 
 #include <chrono>
+#include <limits>
 #include <new>
 #include <thread>
 #include <vector>
@@ -150,6 +154,9 @@ __device__ bool wait_word(const unsigned* word, unsigned want, const XferArgs& a
     while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
       if (__hip_atomic_load(&a.me->abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > a.timeout_ticks) {
         good = 0;
+        // this rank's communicator is dead from here on: the abort word makes every workgroup of this launch and every launch already
+        // queued behind it (the rest of the step, the rest of a replayed graph) leave at once instead of spinning for the time-out again
+        __hip_atomic_store(&a.me->abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(a.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -169,6 +176,12 @@ __global__ __launch_bounds__(256) void peer_xfer_kernel(XferArgs a) {
   const int s = role & 1;
   const bool push = role < 2;
   if (!a.active[s]) return;
+  // an earlier wait of this rank timed out, or the group was aborted (peer_abort, a neighbour's failure): nothing is moved, nothing
+  // is waited for, and the host finds the error word raised (one load of a device word per wave)
+  if (__hip_atomic_load(&a.me->abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+    if (threadIdx.x == 0 && part == 0) __hip_atomic_store(a.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   // this launch's chunk number: the role's device counter + 1 (stored back by the role's last workgroup, below: every workgroup of
   // the role has read it by then -- it counts itself done only after its work)
   const unsigned n = __hip_atomic_load(&a.me->seq[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -336,7 +349,8 @@ int peer_allreduce(void* vctx, float* x, int n, void* stream, bool sum) {
   if (p->rank > 0) {
     if (int rc = host_wait_seq(p, &me->red_up_seq, seq)) return rc;
     PEER_HIP(hipMemcpy(in.data(), me->red_up, (size_t)n * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) acc[i] = sum ? in[i] + acc[i] : (acc[i] > in[i] ? acc[i] : in[i]);
+    // max: a NaN on EITHER side wins (a blown-up field must fail the CFL / residual guard whichever rank holds it)
+    for (int i = 0; i < n; ++i) acc[i] = sum ? in[i] + acc[i] : ((acc[i] != acc[i] || in[i] != in[i]) ? std::numeric_limits<float>::quiet_NaN() : (acc[i] > in[i] ? acc[i] : in[i]));
   }
   if (p->rank < p->nranks - 1) {
     PeerHeader* up = (PeerHeader*)p->nb[1];
@@ -398,6 +412,12 @@ int fnx_slab_peer_create(void** peer, int rank, int nranks, size_t mailbox_bytes
   memcpy(handle_out, &b, sizeof(b));
   *peer = p;
   return FNX_OK;
+}
+
+int fnx_slab_peer_failed(void* peer) {
+  Peer* p = (Peer*)peer;
+  if (!p) return fnx::set_error(FNX_EINVAL, "fnx_slab_peer_failed: NULL peer");
+  return peer_failed(p);
 }
 
 int fnx_slab_peer_set_timeout(void* peer, double seconds) {

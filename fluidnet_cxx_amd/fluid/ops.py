@@ -36,8 +36,9 @@ def getCentered(self):
 
 
 def advectScalar(dt, src, U, flags, method="maccormackFluidNet", boundary_width=1, sample_outside_fluid=False,
-                 maccormack_strength=0.75, *, geom=None):
-    """cpp/advection.py:14-66 -> pybind advect_scalar (cpp/fluids_init.cpp:265-382). 3D is supported here."""
+                 maccormack_strength=0.75, *, geom=None, plan="auto"):
+    """cpp/advection.py:14-66 -> pybind advect_scalar (cpp/fluids_init.cpp:265-382). 3D is supported here.
+    `plan` ('auto' | 'tiles' | 'cells'): the kernel family (same bits; 'auto' = LDS tiles in 3D and on 2D grids of >= 1.5 M cells)."""
     _check_advection_method(method)
     _check5(src, U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
@@ -47,12 +48,13 @@ def advectScalar(dt, src, U, flags, method="maccormackFluidNet", boundary_width=
         assert U.size(1) == 2, "2D velocity field must have only 2 channels"
     assert U.size(0) == flags.size(0) and U.shape[2:] == flags.shape[2:], "Size mismatch"
     return ext.advect_scalar(float(dt), src, U, flags, method, int(boundary_width), bool(sample_outside_fluid),
-                             float(maccormack_strength), None, geom)
+                             float(maccormack_strength), None, geom, plan)
 
 
 def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_width=1, maccormack_strength=0.75, *,
-                   geom=None):
-    """cpp/advection.py:68-118 -> pybind advect_vel (cpp/fluids_init.cpp:656-807)."""
+                   geom=None, plan="auto"):
+    """cpp/advection.py:68-118 -> pybind advect_vel (cpp/fluids_init.cpp:656-807).  `plan` as in advectScalar (tiles exist for
+    self-advection, `orig is U`, which is what simulate.py:93 passes unless viscosity > 0)."""
     _check_advection_method(method)
     _check5(orig, U, flags)
     assert flags.size(1) == 1, "flags is not scalar"
@@ -61,21 +63,23 @@ def advectVelocity(dt, orig, U, flags, method="maccormackFluidNet", boundary_wid
         assert flags.size(2) == 1, "2D velocity field but zdepth > 1"
         assert orig.size(1) == 2 and U.size(1) == 2, "2D velocity field must have only 2 channels"
     assert U.shape == orig.shape and U.size(0) == flags.size(0) and U.shape[2:] == flags.shape[2:], "Size mismatch"
-    return ext.advect_vel(float(dt), orig, U, flags, method, int(boundary_width), float(maccormack_strength), None, geom)
+    return ext.advect_vel(float(dt), orig, U, flags, method, int(boundary_width), float(maccormack_strength), None, geom, plan)
 
 
 def correctScalar(dt, src, div, flags):
-    """cpp/advection.py:9-12 (off in all shipped configs): src += dt*0.5*src*div on fluid cells, in place."""
-    native = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 5 for t in (src, div, flags)) \
-        and div.shape == src.shape == flags.shape
-    if native:
-        ext.correct_scalar_(float(dt), src, div, flags)
-        return
-    # the reference's statement (cpp/advection.py:9-12) as written, for what it accepts and the native operator does not:
-    # broadcastable shapes, strided views, other dtypes.  Still on the tensors' own device: CPU tensors raise like every operator.
-    assert src.is_cuda and div.is_cuda and flags.is_cuda, "fluidnet_cxx_amd has no CPU path: tensors must be on the GPU"
-    mask = flags.eq(1)
-    src.copy_(torch.where(mask, src + (dt * 0.5 * src) * div, src))
+    """cpp/advection.py:9-12 (off in all shipped configs): src += dt*0.5*src*div on fluid cells, in place.
+    The reference's statement is plain tensor arithmetic, so it takes strided views and broadcastable `div` / `flags`; here those are
+    brought to the native operator's form (5-D contiguous fp32, one shape) and the result is copied back into `src`'s own storage."""
+    for t, name in ((src, "src"), (div, "div"), (flags, "flags")):
+        assert t.is_cuda, "fluidnet_cxx_amd has no CPU path: tensors must be on the GPU"
+        assert t.dtype == torch.float32, f"{name} must be float32"
+    assert src.dim() == 5, "Dimension mismatch"
+    shape = src.shape
+    assert torch.broadcast_shapes(shape, div.shape, flags.shape) == shape, "Size mismatch"       # (src is written in place: it sets the shape)
+    work = src if src.is_contiguous() else src.contiguous()
+    ext.correct_scalar_(float(dt), work, div.expand(shape).contiguous(), flags.expand(shape).contiguous())
+    if work is not src:
+        src.copy_(work)
 
 
 def solveLinearSystemJacobi(flags, div, is_3d=False, p_tol=1e-5, max_iter=1000, verbose=False, *, geom=None):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FNX_ABI_VERSION 18
+#define FNX_ABI_VERSION 19
 
 enum {
   FNX_OK = 0,
@@ -76,13 +76,16 @@ int fnx_abi_version(void);
 const char* fnx_device_name(void);
 
 /* advectScalar: pybind `advect_scalar`, cpp/fluids_init.cpp:265-382 (wrapper cpp/advection.py:14-66).
- * dst must not alias src. */
+ * dst must not alias src.  MacCormack in 3D default semantics, and in 2D from 1.5 M cells, runs the LDS tile kernels of the fused pair
+ * below with its density part only (ABI 19; FNX_OP_ADVECT_SCALAR grew by the tiles' fix-up bitmaps); quirks mode, Euler and small 2D
+ * grids run one thread per cell.  Same bits either way. */
 int fnx_advect_scalar(const FnxGrid* g, float dt, const float* src, const float* U, const float* flags,
                       float* dst, int method, int bnd, int sample_outside_fluid, float maccormack_strength,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* advectVel: pybind `advect_vel`, cpp/fluids_init.cpp:656-807 (wrapper cpp/advection.py:68-118).
- * orig may alias U (self-advection); dst must alias neither. */
+ * orig may alias U (self-advection); dst must alias neither.  Self-advection (orig == U, what lib/simulate.py:93 passes unless
+ * viscosity > 0) takes the LDS tile kernels under the same conditions as fnx_advect_scalar (ABI 19); same bits either way. */
 int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags,
                    float* dst, int method, int bnd, float maccormack_strength,
                    void* ws, size_t ws_bytes, void* stream);
@@ -100,6 +103,14 @@ enum { FNX_ADVECT_PLAN_AUTO = 0,      /* what fnx_advect_step does: LDS tile ker
 int fnx_advect_step_plan(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
                          float* density_dst, float* U_dst, int sample_outside, float strength, int plan, void* ws,
                          size_t ws_bytes, void* stream);
+/* ... and the stand-alone operators with the kernel family chosen by the caller (ABI 19; TILES is honoured where tiles exist: MacCormack,
+ * default 3D semantics or 2D, fnx_advect_vel with orig == U -- elsewhere the call runs one thread per cell): */
+int fnx_advect_scalar_plan(const FnxGrid* g, float dt, const float* src, const float* U, const float* flags,
+                           float* dst, int method, int bnd, int sample_outside_fluid, float maccormack_strength, int plan,
+                           void* ws, size_t ws_bytes, void* stream);
+int fnx_advect_vel_plan(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags,
+                        float* dst, int method, int bnd, float maccormack_strength, int plan,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* velocityDivergence, lib/fluid/velocity_divergence.py:4-74 */
 int fnx_velocity_divergence(const FnxGrid* g, const float* U, const float* flags, float* div, void* stream);
@@ -394,6 +405,10 @@ int fnx_slab_comm_link_model(FnxSlabComm* out, double latency_us, double gbytes_
 #define FNX_PEER_HANDLE_BYTES 128
 int fnx_slab_peer_create(void** peer, int rank, int nranks, size_t mailbox_bytes, void* handle_out);
 int fnx_slab_peer_set_timeout(void* peer, double seconds);
+/* FNX_ECOMM once a device-side wait of this rank's exchanges has timed out or the group was aborted (ABI 19).  The exchanges are
+ * enqueued, not waited for, so a step or a replayed graph that met a dead neighbour still returns FNX_OK: ask after synchronising the
+ * stream, before trusting the step's ghost planes.  (Every later communicator call fails with FNX_ECOMM by itself.) */
+int fnx_slab_peer_failed(void* peer);
 int fnx_slab_comm_peer(FnxSlabComm* out, void* peer, const void* handle_lo, const void* handle_hi);
 void fnx_slab_peer_free(void* peer);
 void fnx_slab_comm_free(FnxSlabComm* comm);

@@ -43,6 +43,18 @@ def test_no_oracle_in_product(built):
                 assert "import oracle" not in txt and "from oracle" not in txt and "ora_" not in txt, f
 
 
+def test_no_torch_arithmetic_in_the_operator_surface(built):
+    """The operators and the step are the extension's kernels: no torch compute op (where / conv / interpolate / elementwise arithmetic on
+    fields) may stand in for one in the Python surface.  (Allocation, views, copies, the generators' index arithmetic and the autograd
+    glue are plumbing.)"""
+    import re
+    banned = re.compile(r"torch\.where\(|F\.conv|functional\.conv|interpolate\(|torch\.nn\.functional|\.conv[123]d\(")
+    for f in ("fluid/ops.py", "_simulate.py", "model.py"):
+        txt = open(os.path.join(REPO, "fluidnet_cxx_amd", f)).read()
+        code = "\n".join(l.split("#")[0] for l in txt.splitlines())
+        assert not banned.search(code), (f, banned.search(code).group(0))
+
+
 def test_no_environment_switches_in_product(built):
     """Kernel selection is a function of the arguments alone: the library reads no environment variable (round 2 had ~18
     getenv switches selecting variants once per process -- hidden process-global state in a library whose contract says
@@ -74,9 +86,9 @@ def test_extension_entry_points(built):
 def test_python_surface_matches_reference(built):
     import inspect
     from fluidnet_cxx_amd import fluid
-    def positional(sig):          # the reference's parameters; `geom` is the one keyword-only extra (per-call 3D options)
+    def positional(sig):          # the reference's parameters; keyword-only extras: `geom` (per-call 3D options), `plan` (kernel family of the advections)
         extra = [n for n, p in sig.parameters.items() if p.kind is p.KEYWORD_ONLY]
-        assert extra in ([], ["geom"]), extra
+        assert extra in ([], ["geom"], ["geom", "plan"]), extra
         return [n for n, p in sig.parameters.items() if p.kind is not p.KEYWORD_ONLY]
     sig = inspect.signature(fluid.advectScalar)
     assert positional(sig) == ["dt", "src", "U", "flags", "method", "boundary_width", "sample_outside_fluid", "maccormack_strength"]

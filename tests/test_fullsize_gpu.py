@@ -163,6 +163,11 @@ def test_tile_advection_vs_oracle_large(oracle, cfl):
         want_u = oracle.advect_vel(dt, s["U"], s["U"], f, "maccormackFluidNet", 1, 0.7)
         assert_bitexact(r.cpu().numpy(), want_r, f"density, CFL {cfl}, sample_outside={so}")
         assert_bitexact(u.cpu().numpy(), want_u, f"U, CFL {cfl}, sample_outside={so}")
+        # the reference's call pattern, one advection at a time (cpp/advection.py:64,115): the same tile kernels, one part each
+        r1 = ext.advect_scalar(dt, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7)
+        assert_bitexact(r1.cpu().numpy(), want_r, f"advect_scalar alone, CFL {cfl}, sample_outside={so}")
+    u1 = ext.advect_vel(dt, tU, tU, tf, "maccormackFluidNet", 1, 0.7)
+    assert_bitexact(u1.cpu().numpy(), want_u, f"advect_vel alone, CFL {cfl}")
 
 
 @pytest.mark.parametrize("plan", ["cells", "tiles"])
@@ -183,9 +188,10 @@ def test_advection_tall_2d_grid_vs_oracle(oracle, plan):
     want_u = oracle.advect_vel(dt, s["U"], s["U"], f, "maccormackFluidNet", 1, 0.8)
     top = want_r[0, 0, 0, 33000:]                                   # (clamped values stay inside the source's range [0, 1))
     assert top.min() >= 0.0 and top.max() <= 1.0
-    if plan == "cells":
-        r1 = ext.advect_scalar(dt, trho, tU, tf, "maccormackFluidNet", 1, False, 0.8)
-        assert_bitexact(r1.cpu().numpy(), want_r, "advect_scalar, 40000 x 64")
+    r1 = ext.advect_scalar(dt, trho, tU, tf, "maccormackFluidNet", 1, False, 0.8, plan=plan)
+    assert_bitexact(r1.cpu().numpy(), want_r, f"advect_scalar, 40000 x 64, plan={plan}")
+    u1 = ext.advect_vel(dt, tU, tU, tf, "maccormackFluidNet", 1, 0.8, plan=plan)
+    assert_bitexact(u1.cpu().numpy(), want_u, f"advect_vel, 40000 x 64, plan={plan}")
     r, u = ext.advect_step(dt, trho, tU, tf, False, 0.8, plan=plan)
     assert_bitexact(r.cpu().numpy(), want_r, f"density, 40000 x 64, plan={plan}")
     assert_bitexact(u.cpu().numpy(), want_u, f"U, 40000 x 64, plan={plan}")

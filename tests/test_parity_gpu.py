@@ -298,6 +298,56 @@ def test_jacobi_pass_two_ranges(dev, ext, shape):
         ext.jacobi_pass_(flags, div, p, torch.empty_like(p), 2, 3, 17, ws, True, 10)
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_jacobi_pass_mirror_window_inside_and_across_the_range(dev, ext, B):
+    """fnx_jacobi_pass_mirror with a mirror window that is NOT the launch's plane range (the z-slab driver always passes window ==
+    range): a window inside the range, one that starts below it, one that ends above it, one wholly outside, and two ranges with a
+    window each.  p_out is the plain two-sweep pass's, the mirror holds exactly the window's computed planes, and the canary floats
+    around and inside the mirror (planes of the window the launch does not compute) are untouched -- the mirrored store is dropped
+    by a wave-uniform plane test, not by the buffer range check (a plane below the window used to wrap the scalar offset)."""
+    D, H, W = 40, 64, 120
+    if not ext.jacobi_pass_mirror_ok(B, D, H, W, 22, True, 0):
+        pytest.skip("this device holds fewer resident waves than the test grid has tiles")
+    rng = np.random.default_rng(8)
+    flags = T(make_flags(B, D, H, W, boxes=True), dev)
+    div = T(rng.standard_normal((B, 1, D, H, W)).astype(np.float32), dev)
+    p = T(rng.standard_normal((B, 1, D, H, W)).astype(np.float32), dev)
+    ws = torch.empty(ext.jacobi_workspace_bytes(B, D, H, W, True), dtype=torch.uint8, device=dev)
+    want = torch.full_like(p, 7.0)
+    ext.jacobi_pass_(flags, div, p, want, 2, 0, D, ws, False)
+    guard, CAN = 3 * H * W, 777.0
+
+    def run(kb, ke, kf, n, kb2=-1, kf2=0):
+        bufs = [torch.full((2 * guard + B * n * H * W,), CAN, device=dev) for _ in range(2 if kb2 >= 0 else 1)]
+        mir = [b[guard:guard + B * n * H * W] for b in bufs]
+        out = torch.full_like(p, 7.0)
+        ext.jacobi_pass_mirror_(flags, div, p, out, kb, ke, ws, True, mir[0], kf, n, kb2, mir[1] if kb2 >= 0 else None, kf2)
+        torch.cuda.synchronize()
+        ranges = [(kb, ke, kf, 0)] + ([(kb2, kb2 + ke - kb, kf2, 1)] if kb2 >= 0 else [])
+        inside = torch.zeros(D, dtype=torch.bool)
+        for a, b_, f, q in ranges:
+            inside[a:b_] = True
+            assert torch.equal(out[:, :, a:b_], want[:, :, a:b_]), ("p_out", kb, ke, kf, n, q)
+            assert bool((bufs[q][:guard] == CAN).all()) and bool((bufs[q][guard + B * n * H * W:] == CAN).all()), ("canary around the mirror", kb, ke, kf, n, q)
+            m = mir[q].view(B, n, H, W)
+            for i in range(n):
+                k = f + i
+                if a <= k < b_:
+                    assert torch.equal(m[:, i], want[:, 0, k]), ("mirrored plane", k, kb, ke, kf, n, q)
+                else:
+                    assert bool((m[:, i] == CAN).all()), ("plane of the window outside the range must stay untouched", k, kb, ke, kf, n, q)
+        assert bool((out[:, :, ~inside] == 7.0).all()), "planes outside the range untouched"
+
+    run(8, 30, 12, 4)            # window inside the range
+    run(8, 30, 8, 22)            # window == range (what the z-slab driver passes)
+    run(8, 30, 5, 6)             # starts 3 planes below the range
+    run(8, 30, 27, 6)            # ends 3 planes above it
+    run(20, 30, 2, 5)            # wholly below: nothing mirrored
+    run(3, 12, 30, 5)            # wholly above
+    run(2, 12, 4, 3, 25, 22)     # two ranges, a window inside the first and one that starts below the second
+    run(2, 12, 0, 4, 25, 33)     # ... one below the first range's start, one over the second's end
+
+
 @pytest.mark.parametrize("shape,n", [((2, 12, 24, 70), 10), ((1, 9, 21, 66), 7), ((1, 1, 40, 90), 20), ((1, 5, 4, 10), 6), ((2, 3, 8, 130), 8)])
 def test_jacobi_sweeps_from_zero_flag(dev, ext, fl, oracle, shape, n):
     """fnx_jacobi_sweeps_ex with the from-zero bit (what the z-slab drivers run on a single rank): p is not read -- it is
@@ -797,6 +847,65 @@ def test_static_flags_reuses_mask_3d(dev, oracle, ext):
         assert_bitexact(runs[2][k], st[k], f"{k} (mask and BC class map reused)")
 
 
+@pytest.mark.parametrize("D", [14, 1])
+def test_four_argument_simulate_detects_static_inputs(dev, oracle, ext, fl, monkeypatch, D):
+    """The reference's own call -- simulate(mconf, batch_dict, net, method), four arguments (plume.py:237): the layer keeps the step
+    workspace and derives FnxStepParams.static_flags from (data_ptr, _version) of flags and the BC arrays.  The bits climb 0 -> 3 -> 7
+    on untouched inputs and fall back whenever one is written in place: an obstacle inserted between steps 5 and 6 (torch indexing),
+    the inlet velocity changed between steps 7 and 8, flags reset by this package's own in-place generator (emptyDomain) between
+    steps 9 and 10, and a NEW flags tensor with the old one's contents at step 11.  Every step bit-identical to the oracle, which
+    gets the same edits."""
+    from fluidnet_cxx_amd import _simulate, simulate
+    _simulate.release_workspaces()
+    res = 26
+    cfg = dict(PLUME_CFG, jacobiIter=9)
+    st = plume_state(res, D=D)
+    bd = to_dev(st, dev)
+    seen = []
+    real = ext.simulate_step_
+
+    def spy(*a, **k):
+        seen.append(a[20])                                   # the static_flags argument
+        return real(*a, **k)
+    monkeypatch.setattr(_simulate.ext, "simulate_step_", spy)
+    zs = slice(5, 9) if D > 1 else slice(None)
+    for step in range(1, 13):
+        if step == 6:                                        # an obstacle, in place
+            bd["flags"][:, :, zs, 12:16, 9:14] = 2.0
+            st["flags"] = st["flags"].copy(); st["flags"][:, :, zs, 12:16, 9:14] = 2.0
+        if step == 8:                                        # a faster inlet, in place
+            bd["UBC"].mul_(1.5)
+            st["UBC"] = st["UBC"] * np.float32(1.5)
+        if step == 10:                                       # the native in-place generator: the obstacle is gone again
+            fl.emptyDomain(bd["flags"])
+            st["flags"] = make_flags(1, D, res, res, boxes=False)
+        if step == 11:                                       # a new tensor, same contents
+            bd["flags"] = bd["flags"].clone()
+        simulate(cfg, bd, None, "jacobi")
+        st = oracle.simulate_step(st, cfg, "jacobi")
+        for k in ("U", "density", "p"):
+            assert_bitexact(N(bd[k]), st[k], f"{k} after step {step} (D={D})")
+    #        step:  1  2  3  4  5 | 6 obstacle: the BC map stays | 8 inlet: the mask stays, map rebuilt at 9 | 10 flags | 11 new tensor
+    assert seen == [0, 3, 7, 7, 7, 6, 7, 1, 3, 6, 6, 7], seen
+    # an explicit static_flags / workspace still wins, and geom switches the automatic mode off
+    seen.clear()
+    simulate(cfg, bd, None, "jacobi", static_flags=0)
+    ws = torch.empty(ext.step_workspace_bytes(1, D, res, res, D > 1), dtype=torch.uint8, device=dev)
+    simulate(cfg, bd, None, "jacobi", workspace=ws)
+    simulate(cfg, bd, None, "jacobi", workspace=ws, static_flags=True)
+    if D > 1:
+        simulate(cfg, bd, None, "jacobi", geom=ext.Geom())
+    assert seen == [0, 0, 1] + ([0] if D > 1 else []), seen
+    # forget_static_inputs(): after a write torch's counter cannot see (here through .data) the caller says so
+    simulate(cfg, bd, None, "jacobi"); simulate(cfg, bd, None, "jacobi"); simulate(cfg, bd, None, "jacobi")
+    seen.clear()
+    bd["flags"].data[:, :, zs, 6:9, 6:9] = 2.0              # (.data: no version bump)
+    _simulate.forget_static_inputs()
+    simulate(cfg, bd, None, "jacobi")
+    assert seen == [0], seen
+    _simulate.release_workspaces()
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 40, 70), (1, 10, 20, 66)])
 @pytest.mark.parametrize("method", ["jacobi", "convnet"])
 def test_bc_class_map_same_bits(dev, ext, shape, method):
@@ -862,8 +971,8 @@ def test_advect_step_equals_the_two_advections(fl, ext, dev, shape):
     tf, tU, trho = T(s["flags"], dev), T(s["U"], dev), T(s["rho"], dev)
     for so in (False, True):
         r, u = ext.advect_step(0.13, trho, tU, tf, so, 0.7)
-        want_r = N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7))
-        want_u = N(fl.advectVelocity(0.13, tU, tU, tf, "maccormackFluidNet", 1, 0.7))
+        want_r = N(fl.advectScalar(0.13, trho, tU, tf, "maccormackFluidNet", 1, so, 0.7, plan="cells"))
+        want_u = N(fl.advectVelocity(0.13, tU, tU, tf, "maccormackFluidNet", 1, 0.7, plan="cells"))
         assert_bitexact(N(r), want_r, f"density so={so}")
         assert_bitexact(N(u), want_u, f"U so={so}")
         if D >= 9 and sigma * 0.13 * 5 < 1.0:
@@ -880,8 +989,8 @@ def test_advect_step_equals_the_two_advections(fl, ext, dev, shape):
         for sign in (-1.0, 1.0):
             tUn = (tU.abs() * sign).contiguous()
             r, u = ext.advect_step(0.13, trho, tUn, tf, False, 0.7)
-            assert_bitexact(N(r), N(fl.advectScalar(0.13, trho, tUn, tf, "maccormackFluidNet", 1, False, 0.7)), f"density, U sign {sign}")
-            assert_bitexact(N(u), N(fl.advectVelocity(0.13, tUn, tUn, tf, "maccormackFluidNet", 1, 0.7)), f"U, U sign {sign}")
+            assert_bitexact(N(r), N(fl.advectScalar(0.13, trho, tUn, tf, "maccormackFluidNet", 1, False, 0.7, plan="cells")), f"density, U sign {sign}")
+            assert_bitexact(N(u), N(fl.advectVelocity(0.13, tUn, tUn, tf, "maccormackFluidNet", 1, 0.7, plan="cells")), f"U, U sign {sign}")
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 70, 3.0), (1, 96, 200, 0.4), (1, 33, 130, 0.8), (1, 17, 64, 0.0), (2, 64, 129, 6.0), (1, 150, 67, 1.5),
@@ -915,6 +1024,56 @@ def test_advect2d_tile_kernels_equal_the_cell_kernels(fl, ext, dev, oracle, shap
         assert_bitexact(N(ut), N(uc), f"U, U sign {sign}")
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 40, 70, 3.0), (1, 1, 96, 200, 0.4), (3, 1, 35, 258, 1.0), (1, 1, 150, 67, 0.0), (1, 9, 20, 66, 2.0),
+                                   (2, 12, 21, 130, 0.8), (1, 16, 33, 70, 6.0), (1, 7, 9, 11, 1.5), (1, 20, 64, 200, 0.3)])
+def test_standalone_advection_tile_plan(fl, ext, dev, oracle, shape):
+    """The reference's own call pattern -- advect_scalar and advect_vel one at a time (cpp/advection.py:64,115) -- on the LDS tile
+    kernels (the density-only / velocity-only instantiations: 3D default semantics by 'auto', 2D forced with plan='tiles') ==
+    one thread per cell (plan='cells') == the oracle, bit for bit: CFL 0 to mostly-fallback, obstacles and Empty cells, batch 1-3,
+    both sample_outside_fluid settings, compute windows, traces towards the tensors' corners, and orig != U (cells, whatever the plan)."""
+    B, D, H, W, sigma = shape
+    s = random_state(B, D, H, W, sigma, seed=29, empties=True)
+    tf, tU, trho = T(s["flags"], dev), T(s["U"], dev), T(s["rho"], dev)
+    M = "maccormackFluidNet"
+    plans = ("tiles", "auto") if D > 1 else ("tiles",)
+    uc = fl.advectVelocity(0.13, tU, tU, tf, M, 1, 0.7, plan="cells")
+    for so in (False, True):
+        rc = fl.advectScalar(0.13, trho, tU, tf, M, 1, so, 0.7, plan="cells")
+        for plan in plans:
+            assert_bitexact(N(fl.advectScalar(0.13, trho, tU, tf, M, 1, so, 0.7, plan=plan)), N(rc), f"density so={so}: {plan} vs cells")
+        if sigma > 0:   # (sigma 0 is a field of +0 / -0: the sign of the clamp's min / max of equal zeros is the C library's choice on the CPU)
+            assert_bitexact(N(rc), oracle.advect_scalar(0.13, s["rho"], s["U"], s["flags"], M, 1, so, 0.7), f"density so={so} vs oracle")
+    for plan in plans:
+        assert_bitexact(N(fl.advectVelocity(0.13, tU, tU, tf, M, 1, 0.7, plan=plan)), N(uc), f"U: {plan} vs cells")
+    if sigma > 0:
+        assert_bitexact(N(uc), oracle.advect_vel(0.13, s["U"], s["U"], s["flags"], M, 1, 0.7), "U vs oracle")
+    # orig != U (the viscous velocity of simulate.py:66-69): no tiles for it -- 'tiles' must give the cell kernels' bits
+    orig = (tU * 0.9 + 0.01).contiguous()
+    assert_bitexact(N(fl.advectVelocity(0.13, orig, tU, tf, M, 1, 0.7, plan="tiles")), N(fl.advectVelocity(0.13, orig, tU, tf, M, 1, 0.7, plan="cells")), "orig != U")
+    if sigma > 0:
+        assert_bitexact(N(fl.advectVelocity(0.13, orig, tU, tf, M, 1, 0.7)), oracle.advect_vel(0.13, N(orig), s["U"], s["flags"], M, 1, 0.7), "orig != U vs oracle")
+    # Euler and quirks mode keep their kernels under any plan
+    assert_bitexact(N(fl.advectScalar(0.13, trho, tU, tf, "eulerFluidNet", 1, False, 0.7, plan="tiles")), N(fl.advectScalar(0.13, trho, tU, tf, "eulerFluidNet", 1, False, 0.7, plan="cells")), "euler")
+    if D > 1:
+        q = ext.Geom(ref_quirks=True)
+        assert_bitexact(N(fl.advectScalar(0.13, trho, tU, tf, M, 1, False, 0.7, geom=q, plan="tiles")), N(fl.advectScalar(0.13, trho, tU, tf, M, 1, False, 0.7, geom=q, plan="cells")), "quirks")
+    if D >= 9 and sigma * 0.13 * 5 < 1.0:
+        # compute window: planes [3, D-3) only, the rest of `out` untouched
+        ro, uo = torch.full_like(trho, 9.0), torch.full_like(tU, 9.0)
+        gw = ext.Geom(k_begin=3, k_end=D - 3)
+        ext.advect_scalar(0.13, trho, tU, tf, M, 1, False, 0.7, ro, gw, "tiles")
+        ext.advect_vel(0.13, tU, tU, tf, M, 1, 0.7, uo, gw, "tiles")
+        rc = fl.advectScalar(0.13, trho, tU, tf, M, 1, False, 0.7, plan="cells")
+        assert_bitexact(N(ro)[:, :, 3:D - 3], N(rc)[:, :, 3:D - 3], "window density")
+        assert_bitexact(N(uo)[:, :, 3:D - 3], N(uc)[:, :, 3:D - 3], "window U")
+        assert (N(ro)[:, :, :3] == 9.0).all() and (N(ro)[:, :, D - 3:] == 9.0).all() and (N(uo)[:, :, :3] == 9.0).all() and (N(uo)[:, :, D - 3:] == 9.0).all()
+    for sign in (-1.0, 1.0):
+        # every trace towards one corner: the tile loader's 16-byte chunks hang over the end (start) of the tensors there
+        tUn = (tU.abs() * sign).contiguous()
+        assert_bitexact(N(fl.advectScalar(0.13, trho, tUn, tf, M, 1, False, 0.7, plan="tiles")), N(fl.advectScalar(0.13, trho, tUn, tf, M, 1, False, 0.7, plan="cells")), f"density, U sign {sign}")
+        assert_bitexact(N(fl.advectVelocity(0.13, tUn, tUn, tf, M, 1, 0.7, plan="tiles")), N(fl.advectVelocity(0.13, tUn, tUn, tf, M, 1, 0.7, plan="cells")), f"U, U sign {sign}")
+
+
 def test_rollout_batch_of_two(dev, oracle):
     """Long-term loop with batch > 1 (fluid_net_train.py:349-373): every sample evolves exactly as it does alone."""
     from fluidnet_cxx_amd import rollout
@@ -945,6 +1104,29 @@ def test_sim64_optional_stages_vs_reference(dev, golden, fused):
         if it in (1, 3, 6):
             for k in ("U", "density", "p"):
                 assert_bitexact(N(bd[k]), s[f"f2_{k}_{it}"], f"{k} after {it} steps")
+
+
+def test_correct_scalar_strided_and_broadcast_inputs(dev, fl):
+    """correctScalar (cpp/advection.py:9-12) on what the reference's plain tensor statement accepts and the native operator does not take
+    as such: a strided view of a larger tensor as `src` (written in place, the rest of the parent untouched) and broadcast `div` / `flags`
+    (one sample's fields for a batch) -- the native operator's bits, no torch arithmetic."""
+    rng = np.random.default_rng(3)
+    B, D, H, W = 2, 1, 20, 30
+    big = T(rng.random((B, 3, D, H, W)).astype(np.float32), dev)
+    div = T(rng.standard_normal((1, 1, D, H, W)).astype(np.float32), dev)
+    flags = T(make_flags(1, D, H, W, boxes=True), dev)
+    src_view = big[:, 1:2]                                             # non-contiguous for B > 1
+    assert not src_view.is_contiguous()
+    want = src_view.contiguous()
+    fl.correctScalar(0.2, want, div.expand(B, 1, D, H, W).contiguous(), flags.expand(B, 1, D, H, W).contiguous())     # the native form
+    keep0, keep2 = big[:, 0].clone(), big[:, 2].clone()
+    fl.correctScalar(0.2, src_view, div, flags)
+    assert torch.equal(big[:, 1:2], want)
+    assert torch.equal(big[:, 0], keep0) and torch.equal(big[:, 2], keep2)
+    with pytest.raises(AssertionError):
+        fl.correctScalar(0.2, want, div.double(), flags)
+    with pytest.raises(AssertionError):
+        fl.correctScalar(0.2, want[:1], div.expand(B, 1, D, H, W), flags)
 
 
 OPTIONAL_STAGES = [("viscosity", dict(viscosity=0.02)), ("gravity", dict(gravityScale=0.5)), ("correct", dict(correctScalar=True)),
