@@ -230,6 +230,40 @@ def cpu_baseline(w, budget_s=12.0):
                 sample=f"{n} {w['method']} steps on a {D}x{res}x{res} grid, per-cell rate")
 
 
+def jacobi_roofline(name, w, cells, prof_steps, jac, traffic, traffic_src, traffic_detail):
+    """roofline block of the solver's pass kernel from the HIP-event pairs around its launches (`jac` = (ms, launches) over
+    `prof_steps` eager steps of this rank's `cells`)"""
+    is3d = w["D"] > 1
+    tms, nl = jac
+    byts = 16.0 * w["iters"] * cells * prof_steps
+    ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+    kname = ("jacobi3d_march2_kernel<false,false,3> (the steady-state instantiation: z-marching, TWO sweeps per pass, p handed from "
+             "pass to pass in the row-quad layout; the first pass of a solve is <true,..>, the last one writes rows)" if is3d
+             else "jacobi2d_wg_kernel<8,8> (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-10 sweeps per launch)")
+    avg_ms = tms / max(nl, 1)
+    # what one launch MUST move at its sweeps per pass: 3D, two sweeps per pass: p in + div + p out (4 B each) + the mask byte;
+    # 2D, 7-10 sweeps per launch: p in + div + flags + p out.  frac_model (SURVEY 8d's 16 B per cell and SWEEP) exceeds 1 by design of
+    # the temporal blocking; frac_compulsory is the fraction of the HBM peak the kernel needs for the bytes it cannot avoid.
+    comp = (13.0 if is3d else 16.0) * cells
+    return dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                compulsory_bytes_per_launch=comp,
+                frac_compulsory=(comp / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else None,
+                traffic=traffic, traffic_source=traffic_src,
+                frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
+                traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
+                avg_launch_ms=avg_ms,
+                algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} owned cells per step")
+
+
+def recorded_traffic(name):
+    """(bytes per launch, source, detail) of the dominant kernel of workload `name` from the committed PMC table"""
+    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tfile):
+        return None, None, None
+    d = json.load(open(tfile)).get(name)
+    return (d.get("bytes_per_launch") if d else None), (d or {}).get("source"), d
+
+
 def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="deep_first", dropin=False):
     """Develop the state, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then profile
     the dominant kernel class with HIP events.  Returns the JSON-able result dict (without cpu_baseline)."""
@@ -356,13 +390,9 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     times = {k: ext.profile_read(v) for k, v in PROF.items()}
     issued = {k: ext.profile_read_work(v) for k, v in PROF.items()}
     ext.profile_enable(False)
-    traffic = None           # HBM bytes per launch of the roofline kernel (PMC FETCH_SIZE/WRITE_SIZE passes, profiles/)
-    traffic_detail = None
+    # HBM bytes per launch of the roofline kernel (PMC FETCH_SIZE/WRITE_SIZE passes, profiles/)
+    traffic, traffic_src, traffic_detail = recorded_traffic(name)
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        traffic_detail = json.load(open(tfile)).get(name)
-        traffic = traffic_detail.get("bytes_per_launch") if traffic_detail else None
-    traffic_src = (traffic_detail or {}).get("source")
     if w["method"] == "convnet":
         tms, nl = times["conv_mfma"]
         if w.get("precision") in BF16_MODES:      # achieved/frac: all the 3x3(x3) MFMA layers, whichever kernel ran them
@@ -396,25 +426,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                     launches_per_step=nl / prof_steps, avg_launch_ms=avg_ms,
                     algorithmic=f"{mfma_flops_per_cell(is3d):.0f} direct-convolution FLOP/cell in the MFMA conv launches x {cells} cells per step")
     else:
-        tms, nl = times["jacobi"]
-        byts = 16.0 * w["iters"] * cells * prof_steps
-        ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-        kname = ("jacobi3d_march2_kernel<false,false,3> (the steady-state instantiation: z-marching, TWO sweeps per pass, p handed from "
-                 "pass to pass in the row-quad layout; the first pass of a solve is <true,..>, the last one writes rows)" if is3d
-                 else "jacobi2d_wg_kernel<8,8> (register/DPP temporal blocking, 64x64-cell workgroup tiles, 7-10 sweeps per launch)")
-        avg_ms = tms / max(nl, 1)
-        # what one launch MUST move at its sweeps per pass: 3D, two sweeps per pass: p in + div + p out (4 B each) + the mask byte;
-        # 2D, 7-10 sweeps per launch: p in + div + flags + p out.  frac (SURVEY 8d's 16 B per cell and SWEEP) exceeds 1 by design of
-        # the temporal blocking; frac_compulsory is the fraction of the HBM peak the kernel needs for the bytes it cannot avoid.
-        comp = (13.0 if is3d else 16.0) * cells
-        roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    compulsory_bytes_per_launch=comp,
-                    frac_compulsory=(comp / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else None,
-                    traffic=traffic, traffic_source=traffic_src,
-                    frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
-                    traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
-                    avg_launch_ms=avg_ms,
-                    algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} owned cells per step")
+        roof = jacobi_roofline(name, w, cells, prof_steps, times["jacobi"], traffic, traffic_src, traffic_detail)
     if w["method"] == "jacobi":
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
     else:
@@ -543,6 +555,25 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         comm_info.update(wait_ms_per_step=float(t[0]), bytes_per_neighbour_per_step=float(t[1]), exchanges_per_step=st["exchanges"] / n_stat,
                          wait="max over ranks; time the compute stream stood in front of posted ghost exchanges, HIP events, 5 untimed steps")
+    # the dominant kernel through THIS driver: HIP-event pairs around the solver's launches over a few eager steps (outside the timed
+    # region: events cannot be recorded inside a replayed graph).  Partial edge / deep launches of the sweep blocks are in the mean.
+    roof = None
+    try:
+        ext.profile_enable(True)
+        n_prof = 3
+        for _ in range(n_prof):
+            sim.step(bd)
+        torch.cuda.synchronize()
+        jac = ext.profile_read(PROF["jacobi"])
+        ext.profile_enable(False)
+        tr, tsrc, tdet = recorded_traffic("plume3d_slab_jacobi")
+        roof = jacobi_roofline("plume3d_slab_jacobi", WORKLOADS["plume3d_slab_jacobi"], res * res * layout.owned, n_prof, jac,
+                               tr if world == 1 else None, tsrc if world == 1 else None, tdet if world == 1 else None)
+        if world > 1:
+            roof["note"] = "mean over the deep and the (shorter) edge launches of the sweep blocks of this rank"
+    except Exception as e:  # noqa: BLE001
+        roof = None
+        sys.stderr.write(f"bench: no roofline from the native leg ({e})\n")
     model = None
     if world == 1 and hasattr(ext, "slab_comm_link_model"):
         # One GPU rehearses a MIDDLE rank (rank 1 of 3: 64 owned + 2 x 6 ghost planes) through the same C++ driver with the C ABI's
@@ -596,6 +627,8 @@ def run_native_slab(steps, warmup, world, rank, dev, bd, m, res, D, schedule="de
                state_finite=bool(torch.isfinite(bd["U"]).all()) and bool(torch.isfinite(bd["p"]).all()))
     if model:
         out["middle_rank_model"] = model
+    if roof:
+        out["roofline"] = roof
     return out, comm_info
 
 
@@ -727,8 +760,9 @@ def compact(out):
         line["advect"] = dict(ms=_r(ad["ms_per_step"]), frac_of_120B_model=_r(ad["frac_of_model"], 3), valu_issue_frac=_r(ad.get("valu_issue_frac"), 3))
     if "cpu_baseline" in out:
         line["cpu_baseline"] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out["cpu_baseline"].items()}
-    for k in ("native_driver", "native_driver_peer", "native_driver_rccl", "python_driver", "comm", "comm_peer", "comm_rccl"):
-        if k in out:
+    for k in ("native_driver", "native_driver_peer", "native_driver_rccl", "native_driver_rccl_graph", "native_driver_rccl_eager", "python_driver",
+              "comm", "comm_peer", "comm_rccl"):
+        if isinstance(out.get(k), dict):
             line[k] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in out[k].items() if kk != "middle_rank_model"}
     mm = out.get("native_driver", {}).get("middle_rank_model")
     if mm:                                   # (short form: the sentence that says what it is stays in the side file)
@@ -896,7 +930,14 @@ def main():
             t.cancel()                       # (one line only: the job's watchdog must not add its own behind this one)
         if rank == 0 and not done:
             done.append(1)
-            line, detail = compact(out)
+            try:
+                line, detail = compact(out)
+            except Exception as e:  # noqa: BLE001  (whatever a leg left behind: the job still prints its line)
+                line = dict(metric=out.get("metric"), value=out.get("value"), unit=out.get("unit"), n_gpus=out.get("n_gpus"), steps=out.get("steps"),
+                            warmup=out.get("warmup"), ms_per_step=out.get("ms_per_step"), higher_is_better=True, scaling="weak", vs_baseline=None,
+                            dtype="f32", data="synthetic", config=dict(workload=out.get("config", {}).get("workload")),
+                            error=f"compact(): {type(e).__name__}: {e}"[:300])
+                detail = dict(error=line["error"])
             try:
                 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
                 with open(os.path.join(REPO, "gpurun_out", "bench_detail.json"), "w") as f:
@@ -932,6 +973,16 @@ def main():
             out["config"]["driver"] = ("native (fnx_slab_step: C++ driver, " + ("peer-store transport" if "peer-store" in (nd.get("transport") or "")
                                        else "RCCL ncclSend/ncclRecv issued from C++") + ")")
             out["config"]["launch"] = nd["launch"]
+            out["config"]["state_finite_after_timing"] = nd.get("state_finite")
+            if nd.get("roofline"):
+                out["roofline"] = nd["roofline"]       # the dominant kernel as THIS driver launches it
+        for k in ("native_driver", "native_driver_peer", "native_driver_rccl", "native_driver_rccl_graph", "native_driver_rccl_eager"):
+            if isinstance(out.get(k), dict):
+                out[k].pop("roofline", None)
+        if out.get("native_driver") is out.get("native_driver_peer"):
+            out.pop("native_driver_peer", None)        # (`--transport peer`: it IS native_driver)
+        if out.get("comm") is out.get("comm_peer"):
+            out.pop("comm_peer", None)
 
     # the z-slab workload through the C++ driver: the headline at N > 1; at N = 1 a row beside the headline (+ the middle-rank model)
     slab_name = name if WORKLOADS[name].get("slab") else ("plume3d_slab_jacobi" if "plume3d_slab_jacobi" in out.get("also", {})
@@ -984,7 +1035,9 @@ def main():
             if a.transport == "peer" and "error" not in ndp and ndp.get("state_finite"):
                 out["native_driver_rccl"], out["native_driver"] = out["native_driver"], ndp
                 if "comm_peer" in out:
-                    out["comm_rccl"], out["comm"] = out.get("comm"), out["comm_peer"]
+                    if out.get("comm"):
+                        out["comm_rccl"] = out["comm"]
+                    out["comm"] = out["comm_peer"]
         rccl_leg = out.get("native_driver_rccl", out.get("native_driver")) or dict(error="none")
         if world > 1 and not rehearse and "error" not in rccl_leg and not a.no_rccl_graph:
             # LAST (a hang here ends the job with everything above already in the line): the RCCL leg once more with the step -- its

@@ -14,7 +14,8 @@ solver's obstacle mask; the 1-byte class map of the BC stages, built on the seco
 in-place write, another shape -- drops back to deriving everything again for that call.  The cache holds a reference to those
 five tensors, so their addresses cannot be recycled while it trusts them.  What torch's counter does not see: writes through
 `.data`, a numpy / dlpack alias or a raw pointer -- after one of those call `forget_static_inputs()` (or pass `static_flags=0`).
-`release_workspaces()` frees the cached workspaces (the CNN's is ~1 KB per cell).
+`release_workspaces()` frees the cached workspaces (the CNN's is ~1 KB per cell; one per device, stream and grid shape, at most four).
+A call captured in a HIP graph bakes the bits of capture time into the graph: replays do not look at the tensors again.
 
 Explicit control, as before: `workspace` (a uint8 tensor of ext.step_workspace_bytes) with `static_flags` = True / the C ABI's
 bit set (FnxStepParams.static_flags): 1 = flags unchanged since the previous call on that workspace (the 3D Jacobi reuses its
@@ -40,7 +41,7 @@ def _gravity(mconf, scale):
 
 
 _BC_KEYS = ("UBC", "UBCInvMask", "densityBC", "densityBCInvMask")
-_AUTO = {}            # (device index, B, D, H, W, is3D) -> _AutoStep
+_AUTO = {}            # (device index, stream, B, D, H, W, is3D) -> _AutoStep
 _AUTO_MAX = 4         # grid shapes kept (least recently used goes first)
 
 
@@ -89,13 +90,19 @@ class _AutoStep:
 
 
 def _auto_step(flags, is3D):
+    """the cached step state of this (device, stream, grid shape), or None where the layer must not keep one: a first call inside a
+    HIP-graph capture (its allocation would belong to the graph's private pool and die with the graph)"""
     dev = flags.device.index if flags.device.index is not None else torch.cuda.current_device()
-    key = (dev,) + tuple(int(flags.size(i)) for i in (0, 2, 3, 4)) + (bool(is3D),)
+    # per stream: two simulations of one shape on two streams must not share scratch memory, and a workspace is handed back to the
+    # allocator on the stream it was used on
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream) + tuple(int(flags.size(i)) for i in (0, 2, 3, 4)) + (bool(is3D),)
     a = _AUTO.pop(key, None)
     if a is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
         while len(_AUTO) >= _AUTO_MAX:
             _AUTO.pop(next(iter(_AUTO)))
-        a = _AutoStep(ext.step_workspace_bytes(key[1], key[2], key[3], key[4], key[5]), flags)
+        a = _AutoStep(ext.step_workspace_bytes(key[2], key[3], key[4], key[5], key[6]), flags)
     _AUTO[key] = a                            # (re-inserted: most recently used last)
     return a
 
@@ -144,8 +151,9 @@ def simulate(mconf, batch_dict, net, sim_method, output_div=False, fused=True, w
         if workspace is None and static_flags is None and flags.is_cuda and geom is None:
             # the reference's four-argument call: the layer's own workspace, static inputs detected (module docstring)
             auto = _auto_step(flags, is3D)
-            workspace, static_flags = auto.workspace, auto.static_bits(batch_dict, flags, is3D, sim_method == "jacobi")
-        elif static_flags is None:
+            if auto is not None:
+                workspace, static_flags = auto.workspace, auto.static_bits(batch_dict, flags, is3D, sim_method == "jacobi")
+        if static_flags is None:
             static_flags = 0
         ext.simulate_step_(p, U, flags, density, batch_dict.get("UBC"), batch_dict.get("UBCInvMask"),
                            batch_dict.get("densityBC"), batch_dict.get("densityBCInvMask"), packed, dt,

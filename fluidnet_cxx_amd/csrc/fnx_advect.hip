@@ -696,7 +696,7 @@ static void launch_fwd_tile(const GridDims& g, int what, bool sample_outside, fl
 // step, tiles vs one thread per cell: 2048^2 105 vs 129 us, 1024^2 38.6 vs 37.2, 128^2 17.6 vs 12.6), wherever a row offset
 // fits the tiles' 32-bit buffer offsets
 int advect_tile_plan(const GridDims& g, const GridDims& gfwd, bool is3d, bool quirks, int plan) {
-  const bool want_tiles = plan == 1 || (plan == 0 && (is3d || (size_t)g.HW * g.B >= ((size_t)3 << 19)));
+  const bool want_tiles = plan == 1 || plan == 3 || (plan == 0 && (is3d || (size_t)g.HW * g.B >= ((size_t)3 << 19)));
   if (!want_tiles) return 0;
   if (!is3d) return (size_t)g.HW < 0x3fffffffu ? 2 : 0;
   if (quirks) return 0;
@@ -718,6 +718,11 @@ void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, boo
   const bool do_s = what & 1, do_v = what & 2;
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
   const int tp = advect_tile_plan(g, gfwd, is3d, quirks, plan);
+  // FNX_ADVECT_PLAN_TILES_FUSED: the 3D backward pass as ONE march for density and velocity (advect3d_bwd_tile_kernel) instead of two.
+  // Built in round 6, bit-identical, and not faster (512 x 512 x 64 developed plume: 781 us per pair either way): the two marches are
+  // VALU-issue bound and the fused one issues 96 % of their instructions -- what it saves is traffic (U and the flags streamed once)
+  // and a lead-in, which were not the bound; it pays 24 spilled VGPRs at two waves per SIMD.  Kept behind this plan for A/B timing.
+  const bool bwd_fused = plan == 3;
   if (!is3d && tp) {
     const int ntx = (g.W + 63) / 64, nty = (g.H + T2R - 1) / T2R;
     const dim3 grid((unsigned)(ntx * nty * g.B));
@@ -752,11 +757,16 @@ void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, boo
     tile_launch_geometry(g, ntx, nty, zchunk, G);
     unsigned long long* fb_s = do_s ? fix + 2 * nwords : nullptr;
     unsigned long long* fb_v = do_v ? fix + 3 * nwords : nullptr;
+    if (what == 3 && bwd_fused) {
+      if (sample_outside) advect3d_bwd_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx, nty, zchunk);
+      else advect3d_bwd_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx, nty, zchunk);
+    } else {
     if (do_s) {
       if (sample_outside) advect3d_bwd_scalar_tile_kernel<true><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
       else advect3d_bwd_scalar_tile_kernel<false><<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, flags, (const float2*)box, rho_dst, fb_s, ntx, nty, zchunk);
     }
     if (do_v) advect3d_bwd_vel_tile_kernel<<<dim3(G), 64 * ATNW, 0, s>>>(g, dt, half_s, U, U_fwd, flags, U_dst, fb_v, ntx, nty, zchunk);
+    }
     const unsigned nfix = (unsigned)(((size_t)g.B * g.KN * g.H * ntx + 255) / 256);
     if (sample_outside) advect3d_bwd_fix_kernel<true><<<dim3(nfix), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx);
     else advect3d_bwd_fix_kernel<false><<<dim3(nfix), 256, 0, s>>>(g, dt, half_s, rho, rho_fwd, cell, U, U_fwd, flags, (const float2*)box, rho_dst, U_dst, fb_s, fb_v, ntx);

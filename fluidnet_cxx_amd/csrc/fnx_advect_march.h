@@ -284,6 +284,31 @@ __device__ __forceinline__ unsigned atile_corner_bits(unsigned nb, const ALerp& 
          ((q >> 10) & 1u) << 5 | ((q >> 12) & 1u) << 6 | ((q >> 13) & 1u) << 7;
 }
 
+// The three quotients d_i / length of a trace with ONE reciprocal (round 6).  hipcc expands an IEEE fp32 division into v_div_scale x 2,
+// v_rcp, two refinements of the reciprocal, the quotient with two residual corrections, v_div_fmas, v_div_fixup (11 instructions);
+// whenever v_div_scale leaves its operands alone that sequence is plain arithmetic -- r = fma(fma(-b, rcp b, 1), rcp b, rcp b);
+// q = a r; q = fma(fma(-b, q, a), r, q); q = fma(fma(-b, q, a), r, q) -- in which everything up to r depends on the denominator only.
+// Here: 3 + 3 x 5 instructions instead of 33, the same bits wherever they are looked at:
+//   * the quotients are only ever used as ctr + dir * stp (atile_trace), by lanes whose length is > FNX_HIT_MARGIN;
+//   * v_div_scale rescales when the denominator is denormal or >= 2^126 (a wave that holds a length above 2^60 or a NaN takes the
+//     plain divisions: wave-uniform branch), or when the numerator is below 2^-103 / the quotient denormal: then |dir * stp| < 2^-80
+//     against ctr >= 0.5 and the sum is ctr whatever the quotient's last bits (or the sign of a zero quotient, which v_div_fixup
+//     would take from the operands);
+//   * lanes with length <= FNX_HIT_MARGIN (0 included: rcp gives inf, everything NaN) discard the quotients, as they discard 0 / 0 today.
+// tests/test_parity_gpu.py::test_tile_trace_division_extremes runs tiles against the per-cell kernels (plain divisions) on velocity
+// fields of mixed magnitudes (1, 1e-20, denormals, +-0, 1e25).
+__device__ __forceinline__ void adiv3(float a0, float a1, float a2, float b, float& q0, float& q1, float& q2) {
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(b <= 0x1p60f)) != 0, 0)) { q0 = a0 / b; q1 = a1 / b; q2 = a2 / b; return; }
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float r = fmaf(fmaf(-b, r0, 1.f), r0, r0);
+  auto quot = [&](float a) __attribute__((always_inline)) {
+    float q = a * r;
+    q = fmaf(fmaf(-b, q, a), r, q);
+    return fmaf(fmaf(-b, q, a), r, q);
+  };
+  q0 = quot(a0); q1 = quot(a1); q2 = quot(a2);
+}
+
 // line_trace from the centre of a non-border FLUID cell with displacement d (fnx_device.h): either it stays (length <= eps
 // / <= margin) or it is ONE step of length min(|d|, 1) that must end the loop and land in a fluid cell of the
 // neighbourhood (bits nb).  Returns the end point and whether this path covers the trace.
@@ -291,7 +316,8 @@ __device__ __forceinline__ bool atile_trace(float d0, float d1, float d2, float 
                                             unsigned nb, float& p0, float& p1, float& p2) {
   const float length = sqrtf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
   const bool stay = (length <= FNX_EPSILON) | (0.f >= length - FNX_HIT_MARGIN);
-  const float dir0 = d0 / length, dir1 = d1 / length, dir2 = d2 / length;
+  float dir0, dir1, dir2;
+  adiv3(d0, d1, d2, length, dir0, dir1, dir2);
   const float stp = fminf(length - 0.f, 1.f);
   const float n0 = ctrx + dir0 * stp, n1 = ctry + dir1 * stp, n2 = ctrz + dir2 * stp;
   const bool ends = stp >= length - FNX_HIT_MARGIN;                            // the second iteration's exit test
@@ -683,6 +709,175 @@ __global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_BV) void advect3d_bwd_vel_til
         U_dst[sb3 + 2 * (size_t)g.DHW + o] = o_u[r][2];
       }
       if (lane == 0 && j < g.H) fix[m.word(g, k, j)] = ws[r];
+    }
+  };
+  atile_march<NF>(g, m, rs, rs_f, ring0, ring1, ring2, ring3, fst0, fst1, body);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward pass of BOTH advections of a step in one march (round 6): sl_scalar_bwd_clamp_cell<true, false, SO> and
+// sl_mac_bwd_clamp_cell_flat<true> for the planes [K0, K0+KN).  Ring fields: rho_fwd, U_fwd x,y,z, U x,y,z -- 7 of them, 81 600 bytes
+// of LDS with the flags stages: two workgroups per CU, like the velocity kernel alone (163 200 of the CU's 163 840 bytes).  Against the
+// two separate marches: U and the flags are streamed once instead of twice (1.43 -> ~1.0 GB per 16.8 M cells), one lead-in, one
+// barrier / DMA issue / fluid-bit extraction per plane, and the density part's dependent global loads (traced cell -> its clamp bounds)
+// are issued ahead of the velocity part's ~800 instructions instead of being waited for at the top of the step.
+// Every expression is the two kernels' own (and through them the per-cell functions'), operand for operand.
+// ---------------------------------------------------------------------------------------------------
+#ifndef FNX_AT_WPS_B
+#define FNX_AT_WPS_B 2
+#endif
+template <bool SAMPLE_OUTSIDE>
+__global__ __launch_bounds__(64 * ATNW, FNX_AT_WPS_B) void advect3d_bwd_tile_kernel(GridDims g, float dt, float half_s,
+                                                                   const float* __restrict__ rho,
+                                                                   const float* __restrict__ rho_fwd,
+                                                                   const int* __restrict__ cell_in,
+                                                                   const float* __restrict__ U,
+                                                                   const float* __restrict__ U_fwd,
+                                                                   const float* __restrict__ flags,
+                                                                   const float2* __restrict__ box,
+                                                                   float* __restrict__ rho_dst, float* __restrict__ U_dst,
+                                                                   unsigned long long* __restrict__ fix_s,
+                                                                   unsigned long long* __restrict__ fix_v, int ntx, int nty,
+                                                                   int zchunk) {
+  constexpr int NF = 7;
+  constexpr int FW = 1, FU = 4;                           // ring fields of U_fwd x and of U x
+  ATILE_LDS(NF);
+  ATile m;
+  if (!atile_setup(m, g, ntx, nty, zchunk)) return;
+  const size_t sb1 = (size_t)m.b * g.DHW, sb3 = (size_t)m.b * 3 * g.DHW;
+  const size_t after1 = (size_t)(g.B - 1 - m.b) * g.DHW, after3 = 3 * after1;
+  const ABuf rs[NF] = { atile_rsrc(m, g, rho_fwd + sb1, after1),
+                        atile_rsrc(m, g, U_fwd + sb3, after3 + 2 * (size_t)g.DHW), atile_rsrc(m, g, U_fwd + sb3 + g.DHW, after3 + g.DHW),
+                        atile_rsrc(m, g, U_fwd + sb3 + 2 * (size_t)g.DHW, after3), atile_rsrc(m, g, U + sb3, after3 + 2 * (size_t)g.DHW),
+                        atile_rsrc(m, g, U + sb3 + g.DHW, after3 + g.DHW), atile_rsrc(m, g, U + sb3 + 2 * (size_t)g.DHW, after3) };
+  const ABuf rs_f = atile_rsrc(m, g, flags + sb1, after1);
+  const int lane = m.lane, w = m.w, i = m.x, hr0 = ATRPW * w + 1, col = lane + m.xs;
+  const bool xin = i < g.W;
+
+  auto body = [&](int k, unsigned fbm, unsigned fbc, unsigned fbp, const float (&rM)[NF][AFSZ], const float (&rC)[NF][AFSZ],
+                  const float (&rP)[NF][AFSZ], auto pre_store) __attribute__((always_inline)) {
+    const int kg = k + g.zoff;
+    const float ctrz = (float)kg + 0.5f, posz = (float)kg;
+    const bool kbord = (kg < 1) | (kg > g.Dglob - 2) | (k < 1) | (k > g.D - 2);
+    // the density part's traced cells (per-cell global operands; clamped addresses for the lanes that store nothing) are asked for
+    // first and arrive behind the velocity part; what hangs off them -- the clamp bounds -- and rho are fetched at the top of the
+    // density part and arrive behind its traces and samples.  (Two registers live across the velocity part, which needs all 256.)
+    int cell[ATRPW];
+    auto own = [&](int r) __attribute__((always_inline)) {
+      const int j = m.j0 + ATRPW * w + r;
+      return (size_t)k * g.HW + (size_t)(j < g.H ? j : g.H - 1) * g.W + (xin ? i : g.W - 1);
+    };
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) cell[r] = cell_in[sb1 + own(r)];
+    float o_u[ATRPW][3]; unsigned long long wv[ATRPW];
+    // ================= velocity: sl_mac_bwd_clamp_cell_flat (advect3d_bwd_vel_tile_kernel's body) =================
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
+      const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
+      const bool live = xin & (j < g.H);
+      const float fi = (float)i, fj = (float)j, fk = (float)kg;
+      const float ctrx = fi + 0.5f, ctry = fj + 0.5f, posx = fi, posy = fj;
+      const int rc0 = (hr0 + r) * ATP + col;
+      const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
+      const bool fmx = (fbc >> (3 * (r + 1) + 0)) & 1u, fmy = (fbc >> (3 * r + 1)) & 1u, fmz = (fbm >> (3 * (r + 1) + 1)) & 1u;
+      const float x_c = rC[FU][rc0], y_c = rC[FU + 1][rc0], z_c = rC[FU + 2][rc0];
+      const float x_r = rC[FU][rc0 + 1], y_u = rC[FU + 1][rc0 + ATP], z_f = rP[FU + 2][rc0];
+      float v[3][3];
+      v[0][0] = x_c;
+      v[0][1] = 0.25f * (((y_c + rC[FU + 1][rc0 - 1]) + y_u) + rC[FU + 1][rc0 + ATP - 1]);
+      v[0][2] = 0.25f * (((z_c + rC[FU + 2][rc0 - 1]) + z_f) + rP[FU + 2][rc0 - 1]);
+      v[1][0] = 0.25f * (((x_c + rC[FU][rc0 - ATP]) + x_r) + rC[FU][rc0 - ATP + 1]);
+      v[1][1] = y_c;
+      v[1][2] = 0.25f * (((z_c + rC[FU + 2][rc0 - ATP]) + z_f) + rP[FU + 2][rc0 - ATP]);
+      v[2][0] = 0.25f * (((x_c + rM[FU][rc0]) + x_r) + rM[FU][rc0 + 1]);
+      v[2][1] = 0.25f * (((y_c + rM[FU + 1][rc0]) + y_u) + rM[FU + 1][rc0 + ATP]);
+      v[2][2] = z_c;
+      const float fwd0 = rC[FW][rc0], fwd1 = rC[FW + 1][rc0], fwd2 = rC[FW + 2][rc0];
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float vd0 = v[a][0] * dt, vd1 = v[a][1] * dt, vd2 = v[a][2] * dt;
+        const ALerp L = alerp(ctrx + vd0, ctry + vd1, ctrz + vd2, fi, fj, fk);
+        float c[8];
+        atile_corners<NF>(rM, rC, rP, FW + a, rc0, L.nx, L.ny, L.nz, c);
+        const float smp = atrilin(c, L);
+        float mn = INFINITY, mx = -INFINITY;
+        bool okc = true;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {                      // doClampComponentMAC: the boxes at trunc(pos -/+ vd)
+          const int qx = (int)(l == 0 ? posx - vd0 : posx + vd0);
+          const int qy = (int)(l == 0 ? posy - vd1 : posy + vd1);
+          const int qz = (int)(l == 0 ? posz - vd2 : posz + vd2);
+          const int rx = qx - i, ry = qy - j, rz = qz - kg;
+          okc &= ((unsigned)(rx + 1) <= 1u) & ((unsigned)(ry + 1) <= 1u) & ((unsigned)(rz + 1) <= 1u);
+          float e[8];
+          atile_corners<NF>(rM, rC, rP, FU + a, rc0, rx == -1, ry == -1, rz == -1, e);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { mn = fminf(mn, e[q]); mx = fmaxf(mx, e[q]); }
+        }
+        const float fa = a == 0 ? fwd0 : (a == 1 ? fwd1 : fwd2);
+        const float og = a == 0 ? x_c : (a == 1 ? y_c : z_c);
+        const float bwd = fluid ? smp : (a == 0 ? fwd1 : (a == 1 ? 0.f : fa));     // Q1 pass-through of SL(fwd)
+        const bool fm = a == 0 ? fmx : (a == 1 ? fmy : fmz);
+        const bool skip = !fluid | !fm;
+        const float corr = skip ? fa : fa + half_s * (og - bwd);
+        o_u[r][a] = border ? 0.f : fmaxf(fminf(corr, mx), mn);
+        ok &= okc & (L.ok | !fluid);
+      }
+      wv[r] = __builtin_amdgcn_ballot_w64(live & !border & !ok);
+    }
+    // ================= density: sl_scalar_bwd_clamp_cell (advect3d_bwd_scalar_tile_kernel's body) =================
+    float src[ATRPW]; float2 bb[ATRPW]; bool inslab[ATRPW];
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      inslab[r] = (cell[r] >= g.HW) & (cell[r] < g.HW + g.DHW);
+      bb[r] = box[sb1 + (size_t)(inslab[r] ? cell[r] - g.HW : 0)];
+      src[r] = rho[sb1 + own(r)];
+    }
+    float o_d[ATRPW]; unsigned long long ws[ATRPW];
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
+      const bool border = (i < 1) | (i > g.W - 2) | (j < 1) | (j > g.H - 2) | kbord;
+      const bool live = xin & (j < g.H);
+      const float fi = (float)i, fj = (float)j, fk = (float)kg;
+      const float ctrx = fi + 0.5f, ctry = fj + 0.5f;
+      const int rc0 = (hr0 + r) * ATP + col;
+      const bool fluid = (fbc >> (3 * (r + 1) + 1)) & 1u;
+      const unsigned nb = ((fbm >> (3 * r)) & 0x1ffu) | (((fbc >> (3 * r)) & 0x1ffu) << 9) | (((fbp >> (3 * r)) & 0x1ffu) << 18);
+      const float f = rC[0][rc0];
+      const float cen0 = 0.5f * (rC[FU][rc0] + rC[FU][rc0 + 1]);
+      const float cen1 = 0.5f * (rC[FU + 1][rc0] + rC[FU + 1][rc0 + ATP]);
+      const float cen2 = 0.5f * (rC[FU + 2][rc0] + rP[FU + 2][rc0]);
+      float p0, p1, p2;                                               // displacement (-ndt) * cen with ndt = -dt
+      const bool traced = atile_trace(dt * cen0, dt * cen1, dt * cen2, ctrx, ctry, ctrz, i, j, kg, nb, p0, p1, p2);
+      const ALerp Ls = alerp(p0, p1, p2, fi, fj, fk);
+      float cs[8];
+      atile_corners<NF>(rM, rC, rP, 0, rc0, Ls.nx, Ls.ny, Ls.nz, cs);
+      const bool allfluid = SAMPLE_OUTSIDE || __builtin_amdgcn_ballot_w64(!border & fluid & (nb != 0x7ffffffu)) == 0;   // (see the forward kernel)
+      const float smp = allfluid ? atrilin(cs, Ls) : atrilin_fluid(cs, atile_corner_bits(nb, Ls), Ls);
+      const float bwd = border ? 0.f : (fluid ? smp : f);
+      float d = f;
+      if (fluid) d = f + half_s * (src[r] - bwd);          // applied on border cells too (reference :371)
+      const float mn = bb[r].x, mx = bb[r].y;
+      const bool any = !(mn != mn);
+      const float dc = any ? fmaxf(mn, fminf(mx, d)) : f;
+      o_d[r] = border ? d : dc;
+      ws[r] = __builtin_amdgcn_ballot_w64(live & !border & ((fluid & (!traced | !Ls.ok)) | !inslab[r]));
+    }
+    pre_store();
+#pragma unroll
+    for (int r = 0; r < ATRPW; ++r) {
+      const int j = m.j0 + ATRPW * w + r;
+      if (xin && j < g.H) {
+        const size_t o = (size_t)k * g.HW + (size_t)j * g.W + i;
+        rho_dst[sb1 + o] = o_d[r];
+        U_dst[sb3 + o] = o_u[r][0];
+        U_dst[sb3 + g.DHW + o] = o_u[r][1];
+        U_dst[sb3 + 2 * (size_t)g.DHW + o] = o_u[r][2];
+      }
+      if (lane == 0 && j < g.H) { const size_t wi = m.word(g, k, j); fix_s[wi] = ws[r]; fix_v[wi] = wv[r]; }
     }
   };
   atile_march<NF>(g, m, rs, rs_f, ring0, ring1, ring2, ring3, fst0, fst1, body);

@@ -379,7 +379,11 @@ __global__ __launch_bounds__(256) void jacobi3d_march_kernel(GridDims g, const u
   int jr[ZR]; bool jin[ZR];
 #pragma unroll
   for (int r = 0; r < ZR; ++r) { jin[r] = j0 + r < g.H; jr[r] = jin[r] ? j0 + r : g.H - 1; }
-  const int jd = j0 > 0 ? j0 - 1 : 0, ju = j0 + ZR < g.H ? j0 + ZR : g.H - 1;   // halo rows (clamped: masks never select them at the border)
+  // halo rows, clamped into the grid (masks never select them at the border).  A wave whose rows ALL lie beyond H (the last block of
+  // four waves hangs over the grid when H is not a multiple of 4 ZR) stores nothing but still loads: its lower halo row j0 - 1 is
+  // beyond the grid too and must be clamped like the rows themselves -- unclamped it read up to a plane past the tensor on the last
+  // plane (a fault wherever the tensor ends its memory segment; round 6, found under rocgdb)
+  const int jd = j0 > 0 ? (j0 - 1 < g.H ? j0 - 1 : g.H - 1) : 0, ju = j0 + ZR < g.H ? j0 + ZR : g.H - 1;
   const int il = ic > 0 ? ic - 1 : 0, ir = ic < g.W - 1 ? ic + 1 : g.W - 1;
   float pb[ZR], pc[ZR], pf[ZR];                         // planes k-1, k, k+1 of my rows
   auto ld = [&](int k, int j, int x) { return p_in[base + (size_t)k * g.HW + (size_t)j * g.W + x]; };

@@ -1074,6 +1074,36 @@ def test_standalone_advection_tile_plan(fl, ext, dev, oracle, shape):
         assert_bitexact(N(fl.advectVelocity(0.13, tUn, tUn, tf, M, 1, 0.7, plan="tiles")), N(fl.advectVelocity(0.13, tUn, tUn, tf, M, 1, 0.7, plan="cells")), f"U, U sign {sign}")
 
 
+@pytest.mark.parametrize("D", [1, 10])
+def test_tile_trace_division_extremes(fl, ext, dev, oracle, D):
+    """The tile kernels take the three quotients d_i / length of a line trace from ONE refined reciprocal (fnx_advect_march.h: adiv3);
+    the per-cell kernels and the oracle divide.  Velocity fields whose components mix magnitudes -- O(1), 1e-3, 1e-20, 1e-36,
+    denormals, +0 / -0, 1e25 (a wave holding such a length takes the plain divisions), inf -- must give the same bits either way."""
+    B, H, W = 2, 40, 130
+    rng = np.random.default_rng(41)
+    s = random_state(B, D, H, W, 1.0, seed=41, empties=True)
+    scales = np.array([1.0, 1e-3, 1e-20, 1e-36, 1e-40, 0.0, -0.0, 3.0, 1e25], np.float32)
+    pick = rng.integers(0, len(scales) - 1, size=s["U"].shape)          # per component and cell (1e25 only in a patch below)
+    U = (s["U"] * scales[pick]).astype(np.float32)
+    U[:, :, :, 5:8, 70:100] *= np.float32(1e25)                          # huge lengths: the waves there divide
+    U[0, 0, :, 30, 20] = np.inf
+    tf, tU, trho = T(s["flags"], dev), T(U, dev), T(s["rho"], dev)
+    M = "maccormackFluidNet"
+    for dt in (0.13, 1.0):
+        for so in (False, True):
+            a = fl.advectScalar(dt, trho, tU, tf, M, 1, so, 0.7, plan="tiles")
+            b = fl.advectScalar(dt, trho, tU, tf, M, 1, so, 0.7, plan="cells")
+            assert_bitexact(N(a), N(b), f"density, dt {dt}, so {so}: tiles vs cells")
+        rt, ut = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="tiles")
+        rc, uc = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="cells")
+        assert_bitexact(N(rt), N(rc), f"fused density, dt {dt}"); assert_bitexact(N(ut), N(uc), f"fused U, dt {dt}")
+        rs, us = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="tiles_fused")     # (3D: the backward pass as one march)
+        assert_bitexact(N(rs), N(rc), f"fused-backward density, dt {dt}"); assert_bitexact(N(us), N(uc), f"fused-backward U, dt {dt}")
+    Uf = np.where(np.isfinite(U), U, np.float32(0)).astype(np.float32)   # the oracle on the finite part of the field
+    tUf = T(Uf, dev)
+    assert_bitexact(N(fl.advectScalar(0.13, trho, tUf, tf, M, 1, False, 0.7, plan="tiles")), oracle.advect_scalar(0.13, s["rho"], Uf, s["flags"], M, 1, False, 0.7), "vs oracle")
+
+
 def test_rollout_batch_of_two(dev, oracle):
     """Long-term loop with batch > 1 (fluid_net_train.py:349-373): every sample evolves exactly as it does alone."""
     from fluidnet_cxx_amd import rollout
