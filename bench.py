@@ -717,7 +717,7 @@ def compact(out):
     cfgs = {f"configs[{i}]": dict(workload=k, **rows[k]) for i, k in enumerate(BASELINE_CONFIGS) if k in rows}
     if cfgs:
         line["configs"] = cfgs
-        line["util_of"] = "P: PMC bytes/HBM peak, C: compulsory bytes/HBM peak, M: issued FLOPs/fp32 MFMA peak, B: issued bf16 FLOPs/bf16 MFMA peak (opt-in modes)"
+        line["util_of"] = "P: PMC bytes/HBM peak, C: compulsory bytes/HBM peak, M: issued FLOPs/fp32 MFMA peak"
     c = out["config"]
     line["config"] = {k: c.get(k) for k in ("workload", "grid_per_gpu", "global_grid", "method", "jacobi_iters", "parallelism",
                                             "launch", "driver", "developed_steps", "world_size", "backend") if c.get(k) is not None}
@@ -750,7 +750,8 @@ def compact(out):
         for k, v in drops.items():
             d[k] = [v.get("error")[:60]] if "error" in v else [_r(v["tuned_ms"], 4), _r(v["four_arg_ms"], 4), _r(v["operators_ms"], 4)]
         line["config"]["dropin"] = d
-    other = {k: v for k, v in rows.items() if k not in BASELINE_CONFIGS and k not in METRIC_CONFIGS}
+    # (the opt-in bf16 precision modes are never a headline: their rows are in the side file only)
+    other = {k: v for k, v in rows.items() if k not in BASELINE_CONFIGS and k not in METRIC_CONFIGS and not any(k.endswith("_" + b) for b in BF16_MODES)}
     if other:
         line["other"] = other
     line["kernel_ms_per_step"] = dict({k: _r(v) for k, v in out.get("kernel_ms_per_step", {}).items()},

@@ -93,8 +93,8 @@ int method_of(const std::string& m) {
 // `out` (not in the reference): write into an existing tensor -- with a compute window (set_window) the z-slab driver
 // fills one advected field from several calls.
 int plan_of(const std::string& plan) {
-  TORCH_CHECK(plan == "auto" || plan == "tiles" || plan == "cells" || plan == "tiles_fused", "plan must be 'auto', 'tiles', 'cells' or 'tiles_fused'");
-  return plan == "tiles" ? FNX_ADVECT_PLAN_TILES : (plan == "cells" ? FNX_ADVECT_PLAN_CELLS : (plan == "tiles_fused" ? FNX_ADVECT_PLAN_TILES_FUSED : FNX_ADVECT_PLAN_AUTO));
+  TORCH_CHECK(plan == "auto" || plan == "tiles" || plan == "cells" || plan == "tiles_split", "plan must be 'auto', 'tiles', 'cells' or 'tiles_split'");
+  return plan == "tiles" ? FNX_ADVECT_PLAN_TILES : (plan == "cells" ? FNX_ADVECT_PLAN_CELLS : (plan == "tiles_split" ? FNX_ADVECT_PLAN_TILES_SPLIT : FNX_ADVECT_PLAN_AUTO));
 }
 
 Tensor advect_scalar(float dt, Tensor src, Tensor U, Tensor flags, const std::string method, int bnd,

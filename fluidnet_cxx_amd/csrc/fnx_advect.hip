@@ -718,11 +718,11 @@ void launch_advect_fused(const GridDims& g, const GridDims& gfwd, bool is3d, boo
   const bool do_s = what & 1, do_v = what & 2;
   // forward passes and clamp bounds on `gfwd` (the compute window widened by what the backward pass reads)
   const int tp = advect_tile_plan(g, gfwd, is3d, quirks, plan);
-  // FNX_ADVECT_PLAN_TILES_FUSED: the 3D backward pass as ONE march for density and velocity (advect3d_bwd_tile_kernel) instead of two.
-  // Built in round 6, bit-identical, and not faster (512 x 512 x 64 developed plume: 781 us per pair either way): the two marches are
-  // VALU-issue bound and the fused one issues 96 % of their instructions -- what it saves is traffic (U and the flags streamed once)
-  // and a lead-in, which were not the bound; it pays 24 spilled VGPRs at two waves per SIMD.  Kept behind this plan for A/B timing.
-  const bool bwd_fused = plan == 3;
+  // The 3D backward pass of the pair is ONE march for density and velocity (advect3d_bwd_tile_kernel, round 6): 761-769 against 772-775 us
+  // per pair of a developed 512 x 512 x 64 plume in alternating rounds on one box (profiles/r06/b_advect_ab_alternating.txt) -- 1 %: the
+  // marches are VALU-issue bound and the fused one issues 96 % of their instructions; the traffic it saves was not the bound.
+  // FNX_ADVECT_PLAN_TILES_SPLIT keeps the two separate marches (what the stand-alone advections run) for A/B timing.
+  const bool bwd_fused = plan != 3;
   if (!is3d && tp) {
     const int ntx = (g.W + 63) / 64, nty = (g.H + T2R - 1) / T2R;
     const dim3 grid((unsigned)(ntx * nty * g.B));

@@ -245,7 +245,7 @@ int fnx_advect_scalar_plan(const FnxGrid* g, float dt, const float* src, const f
                            int method, int bnd, int sample_outside, float strength, int plan, void* ws, size_t ws_bytes,
                            void* stream) {
   if (int rc = check_grid(g)) return rc;
-  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_TILES_FUSED) return fail(FNX_EINVAL, "advect_scalar: unknown plan %d", plan);
+  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_TILES_SPLIT) return fail(FNX_EINVAL, "advect_scalar: unknown plan %d", plan);
   if (!src || !U || !flags || !dst) return fail(FNX_EINVAL, "advect_scalar: NULL tensor");
   if (dst == src) return fail(FNX_EINVAL, "advect_scalar: dst must not alias src");
   if (method != FNX_ADVECT_EULER && method != FNX_ADVECT_MACCORMACK) return fail(FNX_EMETHOD, "Advection method not supported");
@@ -291,7 +291,7 @@ int fnx_advect_vel(const FnxGrid* g, float dt, const float* orig, const float* U
 int fnx_advect_vel_plan(const FnxGrid* g, float dt, const float* orig, const float* U, const float* flags, float* dst,
                         int method, int bnd, float strength, int plan, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_grid(g)) return rc;
-  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_TILES_FUSED) return fail(FNX_EINVAL, "advect_vel: unknown plan %d", plan);
+  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_TILES_SPLIT) return fail(FNX_EINVAL, "advect_vel: unknown plan %d", plan);
   if (!orig || !U || !flags || !dst) return fail(FNX_EINVAL, "advect_vel: NULL tensor");
   if (dst == orig || dst == U) return fail(FNX_EINVAL, "advect_vel: dst must not alias orig or U");
   if (method != FNX_ADVECT_EULER && method != FNX_ADVECT_MACCORMACK) return fail(FNX_EMETHOD, "Advection method not supported");
@@ -332,7 +332,7 @@ int fnx_advect_step_plan(const FnxGrid* g, float dt, const float* density, const
                          float* density_dst, float* U_dst, int sample_outside, float strength, int plan, void* ws,
                          size_t ws_bytes, void* stream) {
   if (int rc = check_grid(g)) return rc;
-  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_TILES_FUSED) return fail(FNX_EINVAL, "advect_step: unknown plan %d", plan);
+  if (plan < FNX_ADVECT_PLAN_AUTO || plan > FNX_ADVECT_PLAN_TILES_SPLIT) return fail(FNX_EINVAL, "advect_step: unknown plan %d", plan);
   if (!density || !U || !flags || !density_dst || !U_dst) return fail(FNX_EINVAL, "advect_step: NULL tensor");
   if (density_dst == density || U_dst == U) return fail(FNX_EINVAL, "advect_step: dst must not alias the inputs");
   hipStream_t s = (hipStream_t)stream;

@@ -79,8 +79,20 @@ struct PeerBlob {                        // what a rank publishes (FNX_PEER_HAND
   int rank, nranks, pid;
   unsigned long long slot_bytes;
   unsigned long long raw;                // the region's address in the owner's process
+  unsigned long long token;              // drawn per process: a pid alone is not an address space (two containers can share one)
+  int device;                            // the owner's HIP device
   hipIpcMemHandle_t ipc;
 };
+// one token per process (address space): pid, a clock and an address of this library as it is mapped here
+unsigned long long process_token() {
+  static const unsigned long long t = [] {
+    unsigned long long x = (unsigned long long)getpid() * 0x9E3779B97F4A7C15ull;
+    x ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0xBF58476D1CE4E5B9ull;
+    x ^= (unsigned long long)(uintptr_t)&t;
+    return x | 1ull;
+  }();
+  return t;
+}
 static_assert(sizeof(PeerBlob) <= FNX_PEER_HANDLE_BYTES, "handle blob");
 constexpr unsigned kMagic = 0x464e5850u;
 
@@ -408,6 +420,7 @@ int fnx_slab_peer_create(void** peer, int rank, int nranks, size_t mailbox_bytes
   *p->h_err = 0;
   b.magic = kMagic; b.rank = rank; b.nranks = nranks; b.pid = (int)getpid(); b.slot_bytes = p->slot_bytes;
   b.raw = (unsigned long long)(uintptr_t)p->region;
+  b.token = process_token(); b.device = p->device;
   memset(handle_out, 0, FNX_PEER_HANDLE_BYTES);
   memcpy(handle_out, &b, sizeof(b));
   *peer = p;
@@ -441,8 +454,14 @@ int fnx_slab_comm_peer(FnxSlabComm* out, void* peer, const void* handle_lo, cons
     if (b.magic != kMagic || b.nranks != p->nranks || b.rank != p->rank + (s ? 1 : -1) || b.slot_bytes != p->slot_bytes)
       return fnx::set_error(FNX_ECOMM, "slab_comm_peer: the %s handle is not that of rank %d of %d with %zu-byte mailbox slots", s ? "upper" : "lower",
                             p->rank + (s ? 1 : -1), p->nranks, p->slot_bytes);
-    if (b.pid == (int)getpid()) {
-      p->nb[s] = (char*)(uintptr_t)b.raw;                    // the same address space (slabs driven by threads): no mapping needed
+    if (b.pid == (int)getpid() && b.token == process_token()) {
+      // the same address space (slabs driven by threads): no mapping needed -- on the same device.  Two devices of one process would
+      // need peer access enabled, and ranks that share a device queue their spinning exchange launches behind each other on the
+      // process's few hardware queues: neither is a tested configuration, so the pointer is only taken for the owner's device
+      if (b.device != p->device)
+        return fnx::set_error(FNX_ECOMM, "slab_comm_peer: ranks %d and %d live in one process on devices %d and %d; same-process ranks are "
+                              "supported on one device only (use one process per GPU)", p->rank, b.rank, p->device, b.device);
+      p->nb[s] = (char*)(uintptr_t)b.raw;
     } else {
       void* m = nullptr;
       const hipError_t e = hipIpcOpenMemHandle(&m, b.ipc, hipIpcMemLazyEnablePeerAccess);

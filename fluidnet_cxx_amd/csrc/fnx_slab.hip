@@ -303,9 +303,15 @@ struct ModelCtx {
 // (Until round 4 the wait was a kernel of its own FOLLOWED by device-to-device copies: 15-25 us per exchange that no transport adds.)
 constexpr int kModelSegs = 16;
 struct ModelArgs { const char* src[2 * kModelSegs]; char* dst[2 * kModelSegs]; unsigned long long bytes[2 * kModelSegs]; int n; unsigned long long ticks;
-                   const unsigned long long* since; };
+                   const unsigned long long* since; unsigned long long tail_ticks; };
 __global__ __launch_bounds__(256) void link_model_xfer_kernel(ModelArgs a) {
-  const unsigned long long t0 = a.since ? *a.since : wall_clock64();
+  // `since` (a direct send): the transfer is timed from the start of the PRODUCING launch -- its stores leave while it computes -- but
+  // it cannot be through before that launch is (this kernel starts behind it in stream order) plus the link's latency: the ready
+  // flag is raised after the last plane has been stored and nothing overlaps its flight (round 6; until then a producing launch longer
+  // than latency + bytes / bandwidth made the exchange free)
+  const unsigned long long now = wall_clock64();
+  unsigned long long t0 = a.since ? *a.since : now;
+  if (a.since && now + a.tail_ticks > t0 + a.ticks) { t0 = now; a.ticks = a.tail_ticks; }
   for (int i = 0; i < a.n; ++i) {
     const unsigned long long n16 = a.bytes[i] >> 4;
     if ((((unsigned long long)a.src[i] | (unsigned long long)a.dst[i] | a.bytes[i]) & 15ull) == 0) {
@@ -369,6 +375,7 @@ int model_direct_exchange(void* vctx, const FnxSlabSeg* segs, int nsegs, void* s
   const double us = c->gbps > 0.0 ? c->latency_us + (double)bytes / (c->gbps * 1e3) : 0.0;
   a.ticks = (unsigned long long)(us * 100.0);
   a.since = c->stamp;
+  a.tail_ticks = c->gbps > 0.0 ? (unsigned long long)(c->latency_us * 100.0) : 0ull;
   link_model_xfer_kernel<<<64, 256, 0, (hipStream_t)stream>>>(a);
   SLAB_HIP(hipGetLastError());
   return FNX_OK;

@@ -100,8 +100,8 @@ int fnx_advect_step(const FnxGrid* g, float dt, const float* density, const floa
 enum { FNX_ADVECT_PLAN_AUTO = 0,      /* what fnx_advect_step does: LDS tile kernels in 3D and on 2D grids of >= 1.5 M cells */
        FNX_ADVECT_PLAN_TILES = 1,     /* LDS tile kernels + fix-up launches (CFL < 1 is their fast path, any CFL is correct) */
        FNX_ADVECT_PLAN_CELLS = 2,     /* one thread per cell, gathers from global memory */
-       FNX_ADVECT_PLAN_TILES_FUSED = 3 };  /* TILES with the 3D backward pass of fnx_advect_step as ONE march for density and velocity instead of two
-                                              (same bits, measured no faster: a timing aid) */
+       FNX_ADVECT_PLAN_TILES_SPLIT = 3 };  /* TILES with the 3D backward pass of fnx_advect_step as two marches (density, velocity) instead of the
+                                              fused one (same bits, 1 % slower: a timing aid) */
 int fnx_advect_step_plan(const FnxGrid* g, float dt, const float* density, const float* U, const float* flags,
                          float* density_dst, float* U_dst, int sample_outside, float strength, int plan, void* ws,
                          size_t ws_bytes, void* stream);

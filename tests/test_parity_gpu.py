@@ -1097,8 +1097,8 @@ def test_tile_trace_division_extremes(fl, ext, dev, oracle, D):
         rt, ut = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="tiles")
         rc, uc = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="cells")
         assert_bitexact(N(rt), N(rc), f"fused density, dt {dt}"); assert_bitexact(N(ut), N(uc), f"fused U, dt {dt}")
-        rs, us = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="tiles_fused")     # (3D: the backward pass as one march)
-        assert_bitexact(N(rs), N(rc), f"fused-backward density, dt {dt}"); assert_bitexact(N(us), N(uc), f"fused-backward U, dt {dt}")
+        rs, us = ext.advect_step(dt, trho, tU, tf, False, 0.7, plan="tiles_split")     # (3D: the backward pass as two marches)
+        assert_bitexact(N(rs), N(rc), f"split-backward density, dt {dt}"); assert_bitexact(N(us), N(uc), f"split-backward U, dt {dt}")
     Uf = np.where(np.isfinite(U), U, np.float32(0)).astype(np.float32)   # the oracle on the finite part of the field
     tUf = T(Uf, dev)
     assert_bitexact(N(fl.advectScalar(0.13, trho, tUf, tf, M, 1, False, 0.7, plan="tiles")), oracle.advect_scalar(0.13, s["rho"], Uf, s["flags"], M, 1, False, 0.7), "vs oracle")

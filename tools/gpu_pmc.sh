@@ -7,6 +7,6 @@ export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_$tag/$w/$c
   mkdir -p $out
-  rocprofv3 --pmc $c --kernel-trace -d $out -o r --output-format csv -- python bench.py --workload $w --no-cpu-baseline --no-graph "$@" > $out/bench.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $out -o r --output-format csv -- python bench.py --workload $w --no-cpu-baseline --no-graph ${FNX_BENCH_PROFILE_ARGS:-} "$@" > $out/bench.log 2>&1
   rm -f $out/r_kernel_trace.csv
 done
