@@ -109,6 +109,8 @@ WORKLOADS = {
     # `simulate(..., 'convnet')` on the whole batch under no_grad; a step here is one such call on 32 samples
     "plume2d_128_b32_cnn": dict(res=128, D=1, method="convnet", iters=0, kind="plume", batch=32),
     "plume2d_128_b32_jacobi": dict(res=128, D=1, method="jacobi", iters=28, kind="plume", batch=32),   # configs[0]'s step on 32 samples: the lever a 36-us step has
+    # the 64/128-output-channel 3x3 layers in the Winograd F(4x4,3x3) domain (FNX_PRECISION_FP32_F4, exact-fp32 MFMAs; round 6)
+    "plume2d_1024_cnn_f4": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="fp32_f4"),
     # OPT-IN precision mode, never the headline: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
     # product (FNX_PRECISION_BF16X6; same 1e-5 |ref|max tolerance against the oracle as the exact-fp32 modes, tests/)
     "plume2d_1024_cnn_bf16x6": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x6"),

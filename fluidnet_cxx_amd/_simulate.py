@@ -15,7 +15,8 @@ in-place write, another shape -- drops back to deriving everything again for tha
 five tensors, so their addresses cannot be recycled while it trusts them.  What torch's counter does not see: writes through
 `.data`, a numpy / dlpack alias or a raw pointer -- after one of those call `forget_static_inputs()` (or pass `static_flags=0`).
 `release_workspaces()` frees the cached workspaces (the CNN's is ~1 KB per cell; one per device, stream and grid shape, at most four).
-A call captured in a HIP graph bakes the bits of capture time into the graph: replays do not look at the tensors again.
+A call captured in a HIP graph bakes the bits of capture time into the graph: replays do not look at the tensors again (and a graph
+captured over a cached workspace must not be replayed after `release_workspaces()`; a FIRST call inside a capture keeps nothing).
 
 Explicit control, as before: `workspace` (a uint8 tensor of ext.step_workspace_bytes) with `static_flags` = True / the C ABI's
 bit set (FnxStepParams.static_flags): 1 = flags unchanged since the previous call on that workspace (the 3D Jacobi reuses its

@@ -1,0 +1,248 @@
+// 3x3 convolution in the Winograd F(4x4, 3x3) domain, 2D, exact fp32 on v_mfma_f32_16x16x4_f32 (included by fnx_cnn.hip inside
+// namespace fnx, after its DMA helpers).  Round 6; FNX_PRECISION_FP32_F4.
+//
+//   Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A      d = 6x6 input patch of a 4x4 output block (Lavin & Gray, points 0, +-1, +-2, inf)
+//
+// 36 multiplies per 16 outputs instead of 144 (F(2x2): 64): the contraction over input channels is 36 independent GEMMs, one per
+// position p of the 6x6 transform domain,
+//   D_p[cout 16][block 16] += Wt_p[cout][k] * Xt_p[k][block],   k = four consecutive input channels = ONE v_mfma_f32_16x16x4_f32.
+// A wave owns 16 output channels x 16 blocks (= 16 x 16 pixels) and ALL 36 positions: 36 x 4 = 144 accumulator registers, and the
+// output transform A^T M A runs on registers alone -- no exchange between waves (conv3_wino3_kernel splits its 16 positions over
+// two waves and swaps half of its outputs through LDS).  Workgroup = 8 waves = 64 output channels (4 groups of 16) x 32 blocks
+// (2 groups of 16) = a 32 x 16-pixel tile; the four channel groups share the tile's transformed input, the two block groups share
+// the stage's weights.  One workgroup per CU (131 KB of LDS, two waves per SIMD at 256 registers).
+//
+// Stage = 4 input channels:
+//   raw halo tile   4 x 18 x 34 floats, global -> LDS by DMA (buffer_load_dword ... lds; zeros outside the image), one stage ahead
+//   weights         the stage's [36][4 groups][4 k][16] block of G g G^T (packed at pack time, contiguous), global -> LDS by DMA
+//                   (buffer_load_dwordx4 ... lds), one stage ahead
+//   B^T d B         two passes through LDS, all threads: columns (raw -> tmp), barrier, rows (tmp -> xt [36][2 groups][4 k][16])
+//   36 MFMAs        per wave; both operands are ONE conflict-free ds_read_b32 each (64 consecutive floats per wave)
+// Three barriers per stage.  This is a first version: no persistent tile loop, transforms not interleaved with the MFMA stream.
+//
+// Numerics: the transforms are not exact in binary (G has 1/6, 1/24; B^T and A^T multiply by 2, 4, 5, 8): measured 2x the error of
+// F(2x2) against an fp64 evaluation of the net, 0.07 of the tests' 1e-5 |ref|max (tools/wino_f4_error_probe.py).
+constexpr int W4C = 4;                       // input channels per stage
+constexpr int W4_RAW = 4 * 18 * 34;          // 2448 floats of a stage's halo tile
+constexpr int W4_RAWP = 2560;                // padded to 5 DMA instructions of 512 lanes
+constexpr int W4_TP = 37;                    // tmp pitch per patch (odd: conflict-free row reads)
+constexpr int W4_WST = 36 * 4 * 4 * 16;      // 9216 floats of a stage's weights (64 output channels)
+
+// blob (Cout, Cin, 3, 3) -> G g G^T as [Cin/4][Cout/64][36][4 groups of 16 cout][4 k][16], evaluated in fp64, rounded once
+__global__ void pack_layer_wino4_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
+  const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
+                          {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const int n = cin * cout, ngrp = cout / 64;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const int co = q / cin, ci = q - co * cin;
+    const float* g = w + (size_t)q * 9;
+    double t[6][3];
+    for (int i = 0; i < 6; ++i)
+      for (int s = 0; s < 3; ++s) t[i][s] = G[i][0] * g[s] + G[i][1] * g[3 + s] + G[i][2] * g[6 + s];
+    const size_t base = ((size_t)(ci / 4) * ngrp + co / 64) * W4_WST + (size_t)((co % 64) / 16) * 64 + (ci % 4) * 16 + co % 16;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j)
+        pw[base + (size_t)(i * 6 + j) * 256] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+  }
+}
+
+// B^T (6 x 6) applied to d0..d5
+__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&t)[6]) {
+  const float a = fmaf(-4.f, d[2], d[4]), b = fmaf(-4.f, d[1], d[3]);        // d4 - 4 d2,  d3 - 4 d1
+  const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  t[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+  t[1] = a + b; t[2] = a - b;
+  t[3] = c + e; t[4] = c - e;
+  t[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+}
+// A^T (4 x 6) applied to m0..m5
+__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+  const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+  y[0] = (m0 + s1) + s3;
+  y[1] = fmaf(2.f, s4, s2);
+  y[2] = fmaf(4.f, s3, s1);
+  y[3] = fmaf(8.f, s4, s2) + m5;
+}
+
+typedef float w4f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const float* __restrict__ wt, int ntx, int nty) {
+  __shared__ __attribute__((aligned(16))) float raw0[W4_RAWP];
+  __shared__ __attribute__((aligned(16))) float raw1[W4_RAWP];
+  __shared__ __attribute__((aligned(16))) float tmp[128 * W4_TP];
+  __shared__ __attribute__((aligned(16))) float xt[36 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float wb0[W4_WST];
+  __shared__ __attribute__((aligned(16))) float wb1[W4_WST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave & 3, ng = wave >> 2;
+  const int ngrp = a.cout / 64, nchunk = a.cin / W4C;
+  const size_t plane = (size_t)a.H * a.W;
+  int t = blockIdx.x;
+  const int tx = t % ntx; t /= ntx;
+  const int ty = t % nty; t /= nty;
+  const int grp = t % ngrp, b = t / ngrp;
+  const int x0 = tx * 32, y0 = ty * 16;
+
+  // ---- halo-tile DMA: slot idx = q * 512 + tid of the [4][18][34] tile; out of the image (or beyond the tile) -> an offset the range
+  // check refuses (zeros land in LDS)
+  unsigned uoff[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int idx = q * 512 + tid;
+    const int c = idx / (18 * 34), rem = idx - c * (18 * 34);
+    const int row = rem / 34, col = rem - row * 34;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool ok = (idx < W4_RAW) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+    uoff[q] = ok ? (unsigned)(((size_t)c * plane + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
+  }
+  const float* xb = a.x + (size_t)b * a.cin * plane;
+  const unsigned stage_bytes = (unsigned)((size_t)W4C * plane * 4);
+  const BufRsrcC wrs = make_rsrc_c(wt, 0x7ffffff0u);
+  const unsigned wlane = (unsigned)(wave * 256 + lane * 4) * 4u;
+  auto fetch = [&](int chunk, float (&rawdst)[W4_RAWP], float (&wdst)[W4_WST]) __attribute__((always_inline)) {
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)chunk * W4C * plane, stage_bytes);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) dma4_to_lds(r, (LdsF)&rawdst[0] + q * 512 + wave * 64, uoff[q]);
+    const unsigned sb = (unsigned)(((size_t)chunk * ngrp + grp) * W4_WST * 4);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {                       // 36 instructions of 1 KiB: waves 0-3 issue five, waves 4-7 four
+      const int wi = wave + 8 * q;
+      if (wi < 36) dma16_to_lds(wrs, (LdsF)&wdst[0] + wi * 256, wlane, sb + (unsigned)(8 * 256 * q) * 4u);
+    }
+  };
+
+  // ---- transform units: 768 per pass (128 patches x 6 columns / rows); thread tid takes unit tid and, below 256, unit 512 + tid
+  // pass 1 (columns): unit = patch * 6 + j           pass 2 (rows): unit = i * 128 + patch (blocks fastest: conflict-free xt stores)
+  int p1_rd[2], p1_wr[2], p2_rd[2], p2_wr[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int u = h * 512 + tid;
+    {
+      const int patch = u / 6, j = u - patch * 6;
+      const int c = patch >> 5, n = patch & 31, bx = n & 7, by = n >> 3;
+      p1_rd[h] = (c * 18 + 4 * by) * 34 + 4 * bx + j;
+      p1_wr[h] = patch * W4_TP + j;
+    }
+    {
+      const int i = u >> 7, patch = u & 127;
+      const int c = patch >> 5, n = patch & 31;
+      p2_rd[h] = patch * W4_TP + i * 6;
+      p2_wr[h] = ((i * 6) * 2 + (n >> 4)) * 64 + c * 16 + (n & 15);
+    }
+  }
+  auto pass1 = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && tid >= 256) break;
+      float d[6], tt[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i] = rawsrc[p1_rd[h] + i * 34];
+      w4_bt(d, tt);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tmp[p1_wr[h] + i * 6] = tt[i];
+    }
+  };
+  auto pass2 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && tid >= 256) break;
+      float d[6], v[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[j] = tmp[p2_rd[h] + j];
+      w4_bt(d, v);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xt[p2_wr[h] + j * 128] = v[j];
+    }
+  };
+
+  w4f4 acc[36];
+#pragma unroll
+  for (int p = 0; p < 36; ++p) acc[p] = (w4f4){0.f, 0.f, 0.f, 0.f};
+  // 36 MFMAs per stage.  Their operands are read in four groups of nine positions, a group ahead of the MFMAs that use it (left to
+  // itself the compiler reads two positions, waits for the LDS, issues two MFMAs -- 18 exposed LDS latencies per stage): the loads of
+  // group g + 1 are in flight behind the nine MFMAs (288 cycles) of group g.
+  auto mfmas = [&](const float (&wsrc)[W4_WST]) __attribute__((always_inline)) {
+    const float* wa = &wsrc[cg * 64 + lane];
+    const float* xbp = &xt[ng * 64 + lane];
+    float av[2][9], bv[2][9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { av[0][q] = wa[q * 256]; bv[0][q] = xbp[q * 128]; }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { av[(g + 1) & 1][q] = wa[((g + 1) * 9 + q) * 256]; bv[(g + 1) & 1][q] = xbp[((g + 1) * 9 + q) * 128]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[g * 9 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][q], bv[g & 1][q], acc[g * 9 + q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+#ifndef W4_ABL
+#define W4_ABL 0        // timing ablations (results are wrong): 1 no MFMAs, 2 no transforms (and their barriers), 4 no DMA
+#endif
+  auto stage = [&](int s, float (&rawc)[W4_RAWP], float (&wc)[W4_WST], float (&rawn)[W4_RAWP], float (&wn)[W4_WST]) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of stage s has landed (issued a whole stage ago)
+    __syncthreads();                                       // everybody's has; everybody is through with stage s-1's MFMAs
+    if (!(W4_ABL & 4) && s + 1 < nchunk) fetch(s + 1, rawn, wn);
+    if (!(W4_ABL & 2)) {
+      pass1(rawc);
+      __syncthreads();
+      pass2();
+      __syncthreads();
+    }
+    if (!(W4_ABL & 1)) mfmas(wc);
+  };
+  fetch(0, raw0, wb0);
+  for (int s = 0; s < nchunk; s += 2) {
+    stage(s, raw0, wb0, raw1, wb1);
+    if (s + 1 < nchunk) stage(s + 1, raw1, wb1, raw0, wb0);
+  }
+
+  // ---- epilogue: A^T M A per accumulator register (an output channel), bias, ReLU, 4 x 4 pixels per block
+  const int n = ng * 16 + (lane & 15), bx = n & 7, by = n >> 3;
+  const int px = x0 + 4 * bx, py = y0 + 4 * by;
+  const float lo = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = grp * 64 + cg * 16 + 4 * (lane >> 4) + r;
+    float T[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      w4_at(acc[i * 6 + 0][r], acc[i * 6 + 1][r], acc[i * 6 + 2][r], acc[i * 6 + 3][r], acc[i * 6 + 4][r], acc[i * 6 + 5][r], T[i]);
+    const float bias = a.bias[co];
+    float* yo = a.y + ((size_t)b * a.cout + co) * plane;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {                     // output column bb of the block: A^T along i
+      float y[4];
+      w4_at(T[0][bb], T[1][bb], T[2][bb], T[3][bb], T[4][bb], T[5][bb], y);
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa) T[aa][bb] = fmaxf(y[aa] + bias, lo);      // (reuse T[0..3][bb] for the outputs of row aa)
+    }
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+      const int yy = py + aa;
+      if (yy >= a.H) continue;
+      float* row = yo + (size_t)yy * a.W + px;
+      if (px + 3 < a.W && ((a.W & 3) == 0)) *(w4f4*)row = (w4f4){T[aa][0], T[aa][1], T[aa][2], T[aa][3]};
+      else {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+          if (px + bb < a.W) row[bb] = T[aa][bb];
+      }
+    }
+  }
+}
+
+// false: nothing launched (the caller takes the F(2x2) kernel)
+bool launch_conv_wino4(const ConvArgs& a, const float* wt4, hipStream_t s) {
+  if (a.D != 1 || a.cin % 16 != 0 || a.cout % 64 != 0) return false;
+  if ((size_t)W4C * a.H * a.W * 4 >= 0xfffffff0u) return false;
+  const int ntx = (a.W + 31) / 32, nty = (a.H + 15) / 16;
+  const long nt = (long)ntx * nty * a.B * (a.cout / 64);
+  if (nt < 256 || nt > 0x7fffffffl) return false;        // a launch that does not fill the chip stays on the F(2x2) / direct kernels
+  conv3_wino4_kernel<<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty);
+  return true;
+}

@@ -520,8 +520,12 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
  *                              the bf16 MFMAs and two thirds of the operand traffic; what is dropped is below 2^-15 of a product.  Its own
  *                              label and its own tolerance: 1e-4 |ref|max against oracle and goldens in the tests (measured ~1e-5:
  *                              profiles/r05).  SURVEY.md section 7's "accurate bf16" mode; the reference's own convolutions run on
- *                              torch.nn.Conv2d, whose CUDA default admits TF32 (lib/multi_scale_net.py:21-127) */
-enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2, FNX_PRECISION_BF16X3 = 3 };
+ *                              torch.nn.Conv2d, whose CUDA default admits TF32 (lib/multi_scale_net.py:21-127)
+ *   FNX_PRECISION_FP32_F4      (round 6, 2D) FNX_PRECISION_FP32 with the 64- and 128-output-channel 3x3 layers in the Winograd F(4x4,3x3)
+ *                              domain (conv3_wino4_kernel: 36 multiplies per 16 outputs instead of F(2x2)'s 64): exact-fp32 MFMAs, the
+ *                              transforms round more (multipliers 4, 5, 8, 1/6, 1/24) -- measured 2x F(2x2)'s error, 0.07 of the tests'
+ *                              1e-5 |ref|max; 3D nets take FNX_PRECISION_FP32's kernels */
+enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2, FNX_PRECISION_BF16X3 = 3, FNX_PRECISION_FP32_F4 = 4 };
 /* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                            void* ws, size_t ws_bytes, void* stream);

@@ -581,6 +581,42 @@ def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
         assert_close_rel(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 1e-5, "MultiScaleNet")
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 1, 1024, 1024), (3, 1, 130, 700), (1, 16, 126, 130)])
+def test_cnn_f4_vs_oracle(dev, oracle, shape):
+    """FNX_PRECISION_FP32_F4: the 64- / 128-output-channel 3x3 layers of a 2D net in the Winograd F(4x4,3x3) domain (conv3_wino4_kernel,
+    v_mfma_f32_16x16x4_f32; every other layer as in 'fp32') against the oracle at the modes' common tolerance 1e-5 |ref|max: partial
+    tiles in x and y, odd sizes, batch, the benchmark size, and a 3D net (which must give the 'fp32' mode's bits: no F(4x4) there)."""
+    from fluidnet_cxx_amd import FluidNet
+    from fluidnet_cxx_amd.weights import make_scalenet_weights
+    B, D, H, W = shape
+    is3d = D > 1
+    nd = 3 if is3d else 2
+    w = make_scalenet_weights(0, ndim=nd)
+    mconf = dict(model="ScaleNet", inputChannels=dict(div=True, pDiv=False, UDiv=False), normalizeInput=True,
+                 normalizeInputChan="UDiv", normalizeInputThreshold=1e-5, is3D=is3d)
+    net = FluidNet.from_weights(dict(mconf, precisionMode="fp32_f4"), w, dev)
+    x = np.random.default_rng(5).standard_normal((B, 2, D, H, W)).astype(np.float32)
+    got = N(net.multiScale(T(x, dev) if is3d else T(x[:, :, 0], dev))).reshape(B, 1, D, H, W)
+    if is3d:
+        ref32 = FluidNet.from_weights(mconf, w, dev)
+        assert_bitexact(got, N(ref32.multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the fp32 mode's kernels")
+        return
+    if H * W <= 600 * 600:
+        want = oracle.multiscale_forward(oracle.pack_weights(w, 2), x)
+        assert_close_rel(got, want, 1e-5, "MultiScaleNet, F(4x4) layers")
+    else:
+        # benchmark size: against the F(2x2) mode (itself pinned to the oracle at this size by test_cnn_benchmark_size), both within 1e-5
+        ref32 = FluidNet.from_weights(mconf, w, dev)
+        want = N(ref32.multiScale(T(x[:, :, 0], dev))).reshape(B, 1, D, H, W)
+        assert_close_rel(got, want, 2e-5, "MultiScaleNet at 1024^2: F(4x4) against F(2x2)")
+    if shape == (1, 1, 515, 509):
+        s = random_state(B, D, H, W, 0.5, seed=12)
+        inp = np.concatenate([np.zeros_like(s["p"]), s["U"], s["flags"], s["rho"]], 1)
+        p, U = net(T(inp, dev))
+        po, Uo = oracle.fluidnet_forward(oracle.pack_weights(w, nd), inp)
+        assert_close_rel(N(p), po, 1e-5, "FluidNet p"); assert_close_rel(N(U), Uo, 1e-5, "FluidNet U")
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 16, 126, 130), (1, 6, 72, 300)])
 def test_cnn_bf16x3_vs_oracle(dev, oracle, shape):
     """precisionMode 'bf16x3' (FNX_PRECISION_BF16X3: the same layers with the three bf16 products that involve no low piece, ah*bh +
