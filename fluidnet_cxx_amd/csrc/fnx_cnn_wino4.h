@@ -10,7 +10,7 @@
 // output transform A^T M A runs on registers alone -- no exchange between waves (conv3_wino3_kernel splits its 16 positions over
 // two waves and swaps half of its outputs through LDS).  Workgroup = 8 waves = 64 output channels (4 groups of 16) x 32 blocks
 // (2 groups of 16) = a 32 x 16-pixel tile; the four channel groups share the tile's transformed input, the two block groups share
-// the stage's weights.  One workgroup per CU (131 KB of LDS, two waves per SIMD at 256 registers).
+// the stage's weights.  One workgroup per CU (150 KB of LDS, two waves per SIMD at 256 registers).
 //
 // Stage = 4 input channels:
 //   raw halo tile   4 x 18 x 34 floats, global -> LDS by DMA (buffer_load_dword ... lds; zeros outside the image), one stage ahead
@@ -18,7 +18,7 @@
 //                   (buffer_load_dwordx4 ... lds), one stage ahead
 //   B^T d B         two passes through LDS, all threads: columns (raw -> tmp), barrier, rows (tmp -> xt [36][2 groups][4 k][16])
 //   36 MFMAs        per wave; both operands are ONE conflict-free ds_read_b32 each (64 consecutive floats per wave)
-// Three barriers per stage.  This is a first version: no persistent tile loop, transforms not interleaved with the MFMA stream.
+// Two barriers per stage; the transforms of stage s + 1 ride between the MFMA groups of stage s.  No persistent tile loop yet.
 //
 // Numerics: the transforms are not exact in binary (G has 1/6, 1/24; B^T and A^T multiply by 2, 4, 5, 8): measured 2x the error of
 // F(2x2) against an fp64 evaluation of the net, 0.07 of the tests' 1e-5 |ref|max (tools/wino_f4_error_probe.py).
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   __shared__ __attribute__((aligned(16))) float raw0[W4_RAWP];
   __shared__ __attribute__((aligned(16))) float raw1[W4_RAWP];
   __shared__ __attribute__((aligned(16))) float tmp[128 * W4_TP];
-  __shared__ __attribute__((aligned(16))) float xt[36 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float xt0[36 * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float xt1[36 * 2 * 64];
   __shared__ __attribute__((aligned(16))) float wb0[W4_WST];
   __shared__ __attribute__((aligned(16))) float wb1[W4_WST];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,10 +100,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   const unsigned stage_bytes = (unsigned)((size_t)W4C * plane * 4);
   const BufRsrcC wrs = make_rsrc_c(wt, 0x7ffffff0u);
   const unsigned wlane = (unsigned)(wave * 256 + lane * 4) * 4u;
-  auto fetch = [&](int chunk, float (&rawdst)[W4_RAWP], float (&wdst)[W4_WST]) __attribute__((always_inline)) {
+  auto fetch_raw = [&](int chunk, float (&rawdst)[W4_RAWP]) __attribute__((always_inline)) {
     const BufRsrcC r = make_rsrc_c(xb + (size_t)chunk * W4C * plane, stage_bytes);
 #pragma unroll
     for (int q = 0; q < 5; ++q) dma4_to_lds(r, (LdsF)&rawdst[0] + q * 512 + wave * 64, uoff[q]);
+  };
+  auto fetch_w = [&](int chunk, float (&wdst)[W4_WST]) __attribute__((always_inline)) {
     const unsigned sb = (unsigned)(((size_t)chunk * ngrp + grp) * W4_WST * 4);
 #pragma unroll
     for (int q = 0; q < 5; ++q) {                       // 36 instructions of 1 KiB: waves 0-3 issue five, waves 4-7 four
@@ -130,75 +133,106 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
       p2_wr[h] = ((i * 6) * 2 + (n >> 4)) * 64 + c * 16 + (n & 15);
     }
   }
-  auto pass1 = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
+  // The transforms of stage s + 1 ride in the MFMA stream of stage s: each pass is cut into its LDS loads (issued ahead of a group of
+  // nine MFMAs, 288 cycles) and its arithmetic + stores (behind it).
+  float pd[2][6];
+  auto p1_load = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (h == 1 && tid >= 256) break;
-      float d[6], tt[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = rawsrc[p1_rd[h] + i * 34];
-      w4_bt(d, tt);
+      for (int i = 0; i < 6; ++i) pd[h][i] = rawsrc[p1_rd[h] + i * 34];
+    }
+  };
+  auto p1_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && tid >= 256) break;
+      float tt[6];
+      w4_bt(pd[h], tt);
 #pragma unroll
       for (int i = 0; i < 6; ++i) tmp[p1_wr[h] + i * 6] = tt[i];
     }
   };
-  auto pass2 = [&]() __attribute__((always_inline)) {
+  auto p2_load = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (h == 1 && tid >= 256) break;
-      float d[6], v[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) d[j] = tmp[p2_rd[h] + j];
-      w4_bt(d, v);
+      for (int j = 0; j < 6; ++j) pd[h][j] = tmp[p2_rd[h] + j];
+    }
+  };
+  auto p2_store = [&](float (&xtdst)[36 * 2 * 64]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) xt[p2_wr[h] + j * 128] = v[j];
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && tid >= 256) break;
+      float v[6];
+      w4_bt(pd[h], v);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xtdst[p2_wr[h] + j * 128] = v[j];
     }
   };
 
   w4f4 acc[36];
 #pragma unroll
   for (int p = 0; p < 36; ++p) acc[p] = (w4f4){0.f, 0.f, 0.f, 0.f};
-  // 36 MFMAs per stage.  Their operands are read in four groups of nine positions, a group ahead of the MFMAs that use it (left to
-  // itself the compiler reads two positions, waits for the LDS, issues two MFMAs -- 18 exposed LDS latencies per stage): the loads of
-  // group g + 1 are in flight behind the nine MFMAs (288 cycles) of group g.
-  auto mfmas = [&](const float (&wsrc)[W4_WST]) __attribute__((always_inline)) {
+  // 36 MFMAs per stage in four groups of nine positions; a group's operands are read ahead of the MFMAs of the group before (left to
+  // itself the compiler reads two positions, waits for the LDS, issues two MFMAs).
+  float av[2][9], bv[2][9];
+  auto op_load = [&](int g, const float (&wsrc)[W4_WST], const float (&xsrc)[36 * 2 * 64]) __attribute__((always_inline)) {
     const float* wa = &wsrc[cg * 64 + lane];
-    const float* xbp = &xt[ng * 64 + lane];
-    float av[2][9], bv[2][9];
+    const float* xbp = &xsrc[ng * 64 + lane];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) { av[0][q] = wa[q * 256]; bv[0][q] = xbp[q * 128]; }
+    for (int q = 0; q < 9; ++q) { av[g & 1][q] = wa[(g * 9 + q) * 256]; bv[g & 1][q] = xbp[(g * 9 + q) * 128]; }
+  };
+  auto mfma9 = [&](int g) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g < 3) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { av[(g + 1) & 1][q] = wa[((g + 1) * 9 + q) * 256]; bv[(g + 1) & 1][q] = xbp[((g + 1) * 9 + q) * 128]; }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 9; ++q) acc[g * 9 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][q], bv[g & 1][q], acc[g * 9 + q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int q = 0; q < 9; ++q) acc[g * 9 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][q], bv[g & 1][q], acc[g * 9 + q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
 #ifndef W4_ABL
-#define W4_ABL 0        // timing ablations (results are wrong): 1 no MFMAs, 2 no transforms (and their barriers), 4 no DMA
+#define W4_ABL 0        // timing ablations (results are wrong): 1 no MFMAs, 2 no transforms, 4 no DMA
 #endif
-  auto stage = [&](int s, float (&rawc)[W4_RAWP], float (&wc)[W4_WST], float (&rawn)[W4_RAWP], float (&wn)[W4_WST]) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of stage s has landed (issued a whole stage ago)
-    __syncthreads();                                       // everybody's has; everybody is through with stage s-1's MFMAs
-    if (!(W4_ABL & 4) && s + 1 < nchunk) fetch(s + 1, rawn, wn);
-    if (!(W4_ABL & 2)) {
-      pass1(rawc);
-      __syncthreads();
-      pass2();
-      __syncthreads();
+  // Stage s (steady state), buffers by parity: rawN = halo tile of stage s + 1 (landed), rawF = free (tile s was transformed during
+  // stage s - 1): receives tile s + 2; xtC / wC = this stage's operands, xtN / wN = the next stage's.
+  //   B1   everybody's DMA of the previous top has landed; xtC is complete; nobody reads wN, rawF, xtN, tmp any more
+  //   DMA  halo tile s + 2 -> rawF, weights s + 1 -> wN          (a whole stage to land)
+  //   nine MFMAs x 2 with pass 1 of stage s + 1 (rawN -> tmp) between them;  B2 (tmp complete);
+  //   nine MFMAs x 2 with pass 2 of stage s + 1 (tmp -> xtN) between them
+  auto stage = [&](int s, float (&rawN)[W4_RAWP], float (&rawF)[W4_RAWP], float (&xtC)[36 * 2 * 64], float (&xtN)[36 * 2 * 64],
+                   float (&wC)[W4_WST], float (&wN)[W4_WST]) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!(W4_ABL & 4)) {
+      if (s + 2 < nchunk) fetch_raw(s + 2, rawF);
+      if (s + 1 < nchunk) fetch_w(s + 1, wN);
     }
-    if (!(W4_ABL & 1)) mfmas(wc);
+    const bool nxt = !(W4_ABL & 2) && s + 1 < nchunk;
+    const bool mm = !(W4_ABL & 1);
+    if (mm) op_load(0, wC, xtC);
+    if (nxt) p1_load(rawN);
+    if (mm) { op_load(1, wC, xtC); mfma9(0); }
+    if (nxt) p1_store();
+    if (mm) { op_load(2, wC, xtC); mfma9(1); }
+    __syncthreads();
+    if (nxt) p2_load();
+    if (mm) { op_load(3, wC, xtC); mfma9(2); }
+    if (nxt) p2_store(xtN);
+    if (mm) mfma9(3);
   };
-  fetch(0, raw0, wb0);
+  // prologue: tiles 0 and 1 and the weights of stage 0 in flight; tile 0 transformed into xt0
+  fetch_raw(0, raw0); fetch_w(0, wb0);
+  if (nchunk > 1) fetch_raw(1, raw1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  p1_load(raw0); p1_store();
+  __syncthreads();
+  p2_load(); p2_store(xt0);
   for (int s = 0; s < nchunk; s += 2) {
-    stage(s, raw0, wb0, raw1, wb1);
-    if (s + 1 < nchunk) stage(s + 1, raw1, wb1, raw0, wb0);
+    stage(s, raw1, raw0, xt0, xt1, wb0, wb1);
+    if (s + 1 < nchunk) stage(s + 1, raw0, raw1, xt1, xt0, wb1, wb0);
   }
 
   // ---- epilogue: A^T M A per accumulator register (an output channel), bias, ReLU, 4 x 4 pixels per block
