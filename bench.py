@@ -28,7 +28,7 @@ At N = 1 the same JSON line carries the other configurations the metric and the 
 `config.metric_2d` in the printed line holds the metric's 2D configuration (1024^2 CNN) with its own roofline block and CPU baseline;
 `config.dropin` the reference's own call pattern beside the tuned figure, per configuration: [tuned ms, `simulate(mconf, batch_dict,
 net, method)` with four arguments and eager launches (plume.py:237), the same step operator by operator (`fused=False`)].
-Other names for --workload: plume3d_128_cnn.
+Other names for --workload: plume3d_128_cnn, plume2d_1024_cnn_f4 (the opt-in F(4x4) Winograd mode).
 
 State.  Every workload is first advanced by >= 100 untimed steps (`config.developed_steps`) so that a plume exists
 (advection cost is data dependent: zero-velocity cells leave the line trace at once); the CNN workloads are developed with

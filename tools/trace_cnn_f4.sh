@@ -1,0 +1,20 @@
+# Usage (GPU box, repo root): per-launch durations of the last 1024^2 CNN step, F(2x2) default against the opt-in F(4x4) mode
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for w in plume2d_1024_cnn plume2d_1024_cnn_f4; do
+rm -rf gpurun_out/prof_cnn
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_cnn -o t -- python bench.py --workload $w --no-cpu-baseline --no-dropin --steps 3 --warmup 1 --no-graph > /dev/null 2>&1
+echo "== $w"
+python - <<'PY'
+import csv, glob
+f = glob.glob('gpurun_out/prof_cnn/**/*kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'pack_div' in r['Kernel_Name'] or 'pack_input' in r['Kernel_Name']]
+a = idx[-1]
+for r in rows[a:a + 40]:
+    n = r['Kernel_Name'].replace('void fnx::(anonymous namespace)::', '').replace('fnx::(anonymous namespace)::', '')[:48]
+    if 'conv' in n:
+        print(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} us  wgs {int(r.get('Grid_Size_X', 0)) // max(int(r.get('Workgroup_Size_X', 1)), 1):6d}  {n}")
+PY
+done
