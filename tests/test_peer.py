@@ -419,3 +419,25 @@ def test_bench_eight_rank_rehearsal_on_one_gpu(tmp_path):
     c = d["comm"]
     want = (4 * 4 + 5 + 16 * 6 + 1) * (1 << 20)            # (the printed line rounds to four significant digits)
     assert c["exchanges_per_step"] == 19 and abs(c["bytes_per_neighbour_per_step"] - want) <= 1e-3 * want, c
+
+
+def test_bench_fallback_line_when_a_rank_dies_in_a_supplementary_leg(tmp_path):
+    """`bench.py` at N > 1 hands its line as it stands to a monitor process before every leg that has never met a multi-GPU box; when
+    a rank is killed inside such a leg (here: the last rank SIGKILLs itself at the start of the peer-store leg, the launcher then
+    terminates the others) there is still ONE JSON line on stdout -- the armed line from the monitor, marked `fallback`, or the job's
+    final line through the monitor if rank 0 outlived the launcher's SIGTERM long enough to finish -- instead of none or two."""
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=REPO, FNX_BENCH_TEST_CRASH="peer")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-one-gpu", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    # two endings, both ONE line: the launcher's SIGTERM reached rank 0 first (the monitor printed the armed line, marked `fallback`), or
+    # rank 0's own leg noticed the dead rank first, failed, and the job's final line went out with that leg's error in it
+    if "fallback" in d:
+        assert "peer-store" in d["fallback"], d["fallback"]
+    else:
+        assert "error" in d.get("native_driver_peer", d.get("native_driver", {})), d
+    assert d["n_gpus"] == 2 and d["config"]["workload"] == "plume3d_slab_jacobi"
