@@ -28,7 +28,7 @@ At N = 1 the same JSON line carries the other configurations the metric and the 
 `config.metric_2d` in the printed line holds the metric's 2D configuration (1024^2 CNN) with its own roofline block and CPU baseline;
 `config.dropin` the reference's own call pattern beside the tuned figure, per configuration: [tuned ms, `simulate(mconf, batch_dict,
 net, method)` with four arguments and eager launches (plume.py:237), the same step operator by operator (`fused=False`)].
-Other names for --workload: plume3d_128_cnn, plume2d_1024_cnn_f4 (the opt-in F(4x4) Winograd mode).
+Other names for --workload: plume3d_128_cnn, plume2d_1024_cnn_f2 (F(2x2) Winograd everywhere: the default of rounds 2-5).
 
 State.  Every workload is first advanced by >= 100 untimed steps (`config.developed_steps`) so that a plume exists
 (advection cost is data dependent: zero-velocity cells leave the line trace at once); the CNN workloads are developed with
@@ -109,8 +109,9 @@ WORKLOADS = {
     # `simulate(..., 'convnet')` on the whole batch under no_grad; a step here is one such call on 32 samples
     "plume2d_128_b32_cnn": dict(res=128, D=1, method="convnet", iters=0, kind="plume", batch=32),
     "plume2d_128_b32_jacobi": dict(res=128, D=1, method="jacobi", iters=28, kind="plume", batch=32),   # configs[0]'s step on 32 samples: the lever a 36-us step has
-    # the 64/128-output-channel 3x3 layers in the Winograd F(4x4,3x3) domain (FNX_PRECISION_FP32_F4, exact-fp32 MFMAs; round 6)
-    "plume2d_1024_cnn_f4": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="fp32_f4"),
+    # the default of rounds 2-5 for comparison: every Winograd layer in the F(2x2,3x3) domain (FNX_PRECISION_FP32_F2; since round 6 the
+    # default runs the 64/128-output-channel 3x3 layers of a 2D net in the F(4x4,3x3) domain)
+    "plume2d_1024_cnn_f2": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="fp32_f2"),
     # OPT-IN precision mode, never the headline: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
     # product (FNX_PRECISION_BF16X6; same 1e-5 |ref|max tolerance against the oracle as the exact-fp32 modes, tests/)
     "plume2d_1024_cnn_bf16x6": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x6"),
@@ -457,6 +458,12 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
+        if not is3d and w.get("precision", "fp32") in ("fp32", "fp32_f4"):
+            kname = ("conv3_wino4_kernel (round 6: the 64/128-output-channel 3x3 layers of a 2D net that fill the chip -- 6 of the 10 MFMA launches of a 1024^2 forward, "
+                     "0.9 of their time -- in the Winograd F(4x4,3x3) domain: 36 multiplies per 16 outputs instead of 144, v_mfma_f32_16x16x4_f32, one wave = 16 output "
+                     "channels x 16 blocks x all 36 positions) + conv3_wino3_kernel<1,2,false> / <2,2,false> (F(2x2,3x3), v_mfma_f32_32x32x2_f32) for the 32-channel "
+                     "outputs and the quarter-resolution layers; achieved/frac count DIRECT-convolution FLOPs and can exceed the MFMA peak, mfma_util counts the FLOPs "
+                     "actually issued to the matrix cores (F(4x4) issues 0.5625 of F(2x2)'s)")
         avg_ms = tms / max(nl, 1)
         if w.get("precision") in BF16_MODES:
             # the opt-in mode: its own kernel, priced against the bf16 MFMA peak on the bf16 FLOPs it issues (six per fp32 product)
@@ -928,6 +935,13 @@ def main():
                                       vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=name),
                                       error="no leg of the N > 1 job finished within 780 s"), separators=(",", ":")))
             os._exit(0)
+        if rank == 0:
+            # (and if rank 0 DIES before any leg is through -- a GPU fault in the first multi-GPU step of its life -- the monitor says so)
+            FALLBACK.arm(json.dumps(dict(metric="fluid time-step throughput, Mcells/s = cells*steps/s/1e6 (steps/s alongside)", value=None,
+                                         unit="Mcells/s", n_gpus=a.gpus, steps=a.steps, warmup=a.warmup, higher_is_better=True, scaling="weak",
+                                         vs_baseline=None, dtype="f32", data="synthetic", config=dict(workload=name),
+                                         fallback="printed by the monitor process: rank 0 ended before any leg of the N > 1 job had finished"),
+                                    separators=(",", ":")))
         job_dog = threading.Timer(780.0, give_up)
         job_dog.daemon = True
         job_dog.start()

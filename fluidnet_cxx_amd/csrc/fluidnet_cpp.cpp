@@ -354,9 +354,10 @@ Tensor scalenet_pack(Tensor blob, bool is3D) {
 
 // precision_mode: "fp32" (default: Winograd where the launch fills the chip), "fp32_direct", "bf16x6" or "bf16x3" (FNX_PRECISION_*)
 static int precision_of(const std::string& m) {
-  TORCH_CHECK(m == "fp32" || m == "fp32_direct" || m == "bf16x6" || m == "bf16x3" || m == "fp32_f4",
-              "precision_mode must be 'fp32', 'fp32_direct', 'fp32_f4', 'bf16x6' or 'bf16x3', got '", m, "'");
+  TORCH_CHECK(m == "fp32" || m == "fp32_direct" || m == "bf16x6" || m == "bf16x3" || m == "fp32_f4" || m == "fp32_f2",
+              "precision_mode must be 'fp32', 'fp32_direct', 'fp32_f4', 'fp32_f2', 'bf16x6' or 'bf16x3', got '", m, "'");
   if (m == "fp32_f4") return FNX_PRECISION_FP32_F4;
+  if (m == "fp32_f2") return FNX_PRECISION_FP32_F2;
   if (m == "bf16x6") return FNX_PRECISION_BF16X6;
   if (m == "bf16x3") return FNX_PRECISION_BF16X3;
   return m == "fp32_direct" ? FNX_PRECISION_FP32_DIRECT : FNX_PRECISION_FP32;

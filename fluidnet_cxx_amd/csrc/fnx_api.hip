@@ -917,7 +917,7 @@ int fnx_simulate_step(const FnxGrid* g, const FnxStepParams* prm, const FnxState
     // simulate.py:136-142: p, U = net(cat(p, U, flags, density)) -- the net only reads U and flags (model.py:104-126),
     // so the concatenation is not materialised: U is projected in place.
     if (tail_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fail(FNX_EWORKSPACE, "simulate_step: workspace too small for the CNN");
-    if (prm->precision_mode < FNX_PRECISION_FP32 || prm->precision_mode > FNX_PRECISION_FP32_F4)
+    if (prm->precision_mode < FNX_PRECISION_FP32 || prm->precision_mode > FNX_PRECISION_FP32_F2)
       return fail(FNX_EINVAL, "simulate_step: unknown precision_mode %d", prm->precision_mode);
     // without flags_stick the tail of the net's forward and the step's last setConstVals are one pass (fluidnet_core)
     if (int rc = fnx::fluidnet_core(g, st->net, st->flags, prm->normalize_threshold, prm->precision_mode, st->p, st->U, tail, stream,

@@ -33,8 +33,8 @@ inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_
 // FNX_PRECISION_BF16X6 (conv3_wbf_kernel): the wino layers with 64 output channels per workgroup; their transformed weights
 // cut into three bf16 pieces, in the kernel's MFMA operand layout (1.5x the fp32 image), follow the two fp32 images
 inline bool wbf_layer(const ConvLayer& L, bool is3d) { return wino_layer(L, is3d) && L.cin % 16 == 0 && L.cout % 64 == 0; }
-// FNX_PRECISION_FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the 2D wino layers with 64 output channels per workgroup; their
-// F(4x4,3x3) weights G g G^T ([Cin/4][Cout/64][36][4][4][16], 36 Cin Cout floats) follow the bf16 image
+// FNX_PRECISION_FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the 2D wino layers with 64 output channels per workgroup; their nine
+// taps in the kernel's lane order ([Cin/4][Cout/64][9][4][4][16], 9 Cin Cout floats: G g G^T is formed in registers) follow the bf16 image
 inline bool wino4_layer_(const ConvLayer& L, bool is3d) { return !is3d && L.k == 3 && L.cin % 16 == 0 && L.cout % 64 == 0; }
 inline size_t wino4_offset(const ConvLayer& L, bool is3d) {      // floats from the layer's w_off to its F(4x4) image
   const size_t nwino = (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
@@ -44,7 +44,7 @@ inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
   if (wino_layer(L, is3d))
     return layer_weight_floats(L, is3d) + 2 * (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout +
            (wbf_layer(L, is3d) ? (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout * 3 / 2 : 0) +
-           (wino4_layer_(L, is3d) ? (size_t)36 * L.cin * L.cout : 0);
+           (wino4_layer_(L, is3d) ? (size_t)9 * L.cin * L.cout : 0);
   if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
@@ -1319,7 +1319,8 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
-    if (mode == FNX_PRECISION_FP32_F4 && wino4_layer_(L, is3d) && launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), s)) {
+    if ((mode == FNX_PRECISION_FP32 || mode == FNX_PRECISION_FP32_F4) && wino4_layer_(L, is3d) &&
+        launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), s)) {
       prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 2.25);                  // 36 multiplies per 4x4 outputs
       return;
     }
@@ -1463,8 +1464,8 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
         repack_wino3_kernel<<<64, 256, 0, s>>>(w2, w3, L.cin, L.cout, kd, wino3_rw(L.cout));
         if (wbf_layer(L, is3d))                                 // FNX_PRECISION_BF16X6: three bf16 pieces, MFMA operand layout
           pack_wbf_kernel<<<256, 256, 0, s>>>(w2, (unsigned*)(w3 + (size_t)16 * kd * L.cin * L.cout), L.cin, L.cout, kd);
-        if (wino4_layer_(L, is3d))                              // FNX_PRECISION_FP32_F4: G g G^T of F(4x4,3x3), stage-contiguous
-          pack_layer_wino4_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + wino4_offset(L, is3d), L.cin, L.cout);
+        if (wino4_layer_(L, is3d))                              // FNX_PRECISION_FP32_F4: the taps in lane order, stage-contiguous
+          pack_layer_wino4g_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + wino4_offset(L, is3d), L.cin, L.cout);
       }
     }
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))
@@ -1843,7 +1844,7 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
   return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
 }
 
-static bool bad_precision(int m) { return m < FNX_PRECISION_FP32 || m > FNX_PRECISION_FP32_F4; }
+static bool bad_precision(int m) { return m < FNX_PRECISION_FP32 || m > FNX_PRECISION_FP32_F2; }
 
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                            size_t ws_bytes, void* stream) {

@@ -10,14 +10,15 @@
 // output transform A^T M A runs on registers alone -- no exchange between waves (conv3_wino3_kernel splits its 16 positions over
 // two waves and swaps half of its outputs through LDS).  Workgroup = 8 waves = 64 output channels (4 groups of 16) x 32 blocks
 // (2 groups of 16) = a 32 x 16-pixel tile; the four channel groups share the tile's transformed input, the two block groups share
-// the stage's weights.  One workgroup per CU (150 KB of LDS, two waves per SIMD at 256 registers).
+// the stage's weights.  One workgroup per CU (113 KB of LDS, two waves per SIMD at 256 registers).
 //
 // Stage = 4 input channels:
 //   raw halo tile   4 x 18 x 34 floats, global -> LDS by DMA (buffer_load_dword ... lds; zeros outside the image), one stage ahead
-//   weights         the stage's [36][4 groups][4 k][16] block of G g G^T (packed at pack time, contiguous), global -> LDS by DMA
-//                   (buffer_load_dwordx4 ... lds), one stage ahead
+//   weights         the stage's nine taps per (output channel, k) pair, [9][4 groups][4 k][16] = 9 KB, global -> LDS by DMA three stages
+//                   ahead; G g G^T is formed IN REGISTERS, one pair per lane -- the lane that feeds it to the MFMA (90 VALU per stage
+//                   and wave instead of a 36 KB stream per stage and workgroup through L2 and LDS)
 //   B^T d B         two passes through LDS, all threads: columns (raw -> tmp), barrier, rows (tmp -> xt [36][2 groups][4 k][16])
-//   36 MFMAs        per wave; both operands are ONE conflict-free ds_read_b32 each (64 consecutive floats per wave)
+//   36 MFMAs        per wave; A from registers, B ONE conflict-free ds_read_b32 (64 consecutive floats per wave)
 // Two barriers per stage; the transforms of stage s + 1 ride between the MFMA groups of stage s.  No persistent tile loop yet.
 //
 // Numerics: the transforms are not exact in binary (G has 1/6, 1/24; B^T and A^T multiply by 2, 4, 5, 8): measured 2x the error of
@@ -29,24 +30,28 @@ constexpr int W4C = 4;                       // input channels per stage
 constexpr int W4_RAW = 4 * 18 * 34;          // 2448 floats of a stage's halo tile
 constexpr int W4_RAWP = 2560;                // padded to 5 DMA instructions of 512 lanes
 constexpr int W4_TP = 37;                    // tmp pitch per patch (odd: conflict-free row reads)
-constexpr int W4_WST = 36 * 4 * 4 * 16;      // 9216 floats of a stage's weights (64 output channels)
+constexpr int W4_GST = 9 * 4 * 4 * 16;       // 2304 floats of a stage's taps
 
-// blob (Cout, Cin, 3, 3) -> G g G^T as [Cin/4][Cout/64][36][4 groups of 16 cout][4 k][16], evaluated in fp64, rounded once
-__global__ void pack_layer_wino4_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
-  const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
-                          {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+// blob (Cout, Cin, 3, 3) -> the nine taps as [Cin/4][Cout/64][9][4 groups of 16 cout][4 k][16]: what a wave reads as one float per lane and
+// tap (its MFMA A-operand position: lane = k * 16 + cout % 16) to form G g G^T in registers (conv3_wino4_kernel)
+__global__ void pack_layer_wino4g_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
   const int n = cin * cout, ngrp = cout / 64;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
     const int co = q / cin, ci = q - co * cin;
-    const float* g = w + (size_t)q * 9;
-    double t[6][3];
-    for (int i = 0; i < 6; ++i)
-      for (int s = 0; s < 3; ++s) t[i][s] = G[i][0] * g[s] + G[i][1] * g[3 + s] + G[i][2] * g[6 + s];
-    const size_t base = ((size_t)(ci / 4) * ngrp + co / 64) * W4_WST + (size_t)((co % 64) / 16) * 64 + (ci % 4) * 16 + co % 16;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j)
-        pw[base + (size_t)(i * 6 + j) * 256] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+    const size_t base = ((size_t)(ci / 4) * ngrp + co / 64) * (9 * 256) + (size_t)((co % 64) / 16) * 64 + (ci % 4) * 16 + co % 16;
+    for (int t = 0; t < 9; ++t) pw[base + (size_t)t * 256] = w[(size_t)q * 9 + t];
   }
+}
+
+// G (6 x 3) applied to x0..x2: (x0/4, -(x0+x1+x2)/6, -(x0-x1+x2)/6, x0/24 + x1/12 + x2/6, x0/24 - x1/12 + x2/6, x2)
+__device__ __forceinline__ void w4_g(float x0, float x1, float x2, float (&y)[6]) {
+  const float e = (x0 + x2) * (-1.f / 6.f), f = fmaf(x0, 1.f / 24.f, x2 * (1.f / 6.f));
+  y[0] = 0.25f * x0;
+  y[1] = fmaf(x1, -1.f / 6.f, e);
+  y[2] = fmaf(x1, 1.f / 6.f, e);
+  y[3] = fmaf(x1, 1.f / 12.f, f);
+  y[4] = fmaf(x1, -1.f / 12.f, f);
+  y[5] = x2;
 }
 
 // B^T (6 x 6) applied to d0..d5
@@ -68,6 +73,7 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 }
 
 typedef float w4f4 __attribute__((ext_vector_type(4)));
+template <int N> struct AIC4 { static constexpr int value = N; };
 
 __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const float* __restrict__ wt, int ntx, int nty) {
   __shared__ __attribute__((aligned(16))) float raw0[W4_RAWP];
@@ -75,8 +81,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   __shared__ __attribute__((aligned(16))) float tmp[128 * W4_TP];
   __shared__ __attribute__((aligned(16))) float xt0[36 * 2 * 64];
   __shared__ __attribute__((aligned(16))) float xt1[36 * 2 * 64];
-  __shared__ __attribute__((aligned(16))) float wb0[W4_WST];
-  __shared__ __attribute__((aligned(16))) float wb1[W4_WST];
+  __shared__ __attribute__((aligned(16))) float gw0[W4_GST];
+  __shared__ __attribute__((aligned(16))) float gw1[W4_GST];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cg = wave & 3, ng = wave >> 2;
   const int ngrp = a.cout / 64, nchunk = a.cin / W4C;
@@ -111,12 +117,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
       else dma4_to_lds(r, (LdsF)&rawdst[0] + q * 512 + wave * 64, uoff[q]);
     }
   };
-  auto fetch_w = [&](int chunk, float (&wdst)[W4_WST]) __attribute__((always_inline)) {
-    const unsigned sb = (unsigned)(((size_t)chunk * ngrp + grp) * W4_WST * 4);
+  auto fetch_w = [&](int chunk, float (&wdst)[W4_GST]) __attribute__((always_inline)) {
+    const unsigned sb = (unsigned)(((size_t)chunk * ngrp + grp) * W4_GST * 4);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {                       // 36 instructions of 1 KiB: waves 0-3 issue five, waves 4-7 four
+    for (int q = 0; q < 2; ++q) {                       // 9 instructions of 1 KiB: waves 0-7, then wave 0 again
       const int wi = wave + 8 * q;
-      if (wi < 36) dma16_to_lds(wrs, (LdsF)&wdst[0] + wi * 256, wlane, sb + (unsigned)(8 * 256 * q) * 4u);
+      if (wi < 9) dma16_to_lds(wrs, (LdsF)&wdst[0] + wi * 256, wlane, sb + (unsigned)(8 * 256 * q) * 4u);
     }
   };
 
@@ -141,41 +147,43 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   }
   // The transforms of stage s + 1 ride in the MFMA stream of stage s: each pass is cut into its LDS loads (issued ahead of a group of
   // nine MFMAs, 288 cycles) and its arithmetic + stores (behind it).
-  float pd[2][6];
+  // (unit 0 of a thread is cut into loads ahead of nine MFMAs and arithmetic + stores behind them; the second unit of the lower 256
+  //  threads is done in one go behind it: six registers instead of twelve next to 144 accumulators)
+  float pd[6];
   auto p1_load = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1 && tid >= 256) break;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) pd[h][i] = rawsrc[p1_rd[h] + i * 34];
-    }
+    for (int i = 0; i < 6; ++i) pd[i] = rawsrc[p1_rd[0] + i * 34];
   };
-  auto p1_store = [&]() __attribute__((always_inline)) {
+  auto p1_store = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
+    float tt[6];
+    w4_bt(pd, tt);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1 && tid >= 256) break;
-      float tt[6];
-      w4_bt(pd[h], tt);
+    for (int i = 0; i < 6; ++i) tmp[p1_wr[0] + i * 6] = tt[i];
+    if (tid < 256) {
+      float d[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) tmp[p1_wr[h] + i * 6] = tt[i];
+      for (int i = 0; i < 6; ++i) d[i] = rawsrc[p1_rd[1] + i * 34];
+      w4_bt(d, tt);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tmp[p1_wr[1] + i * 6] = tt[i];
     }
   };
   auto p2_load = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1 && tid >= 256) break;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) pd[h][j] = tmp[p2_rd[h] + j];
-    }
+    for (int j = 0; j < 6; ++j) pd[j] = tmp[p2_rd[0] + j];
   };
   auto p2_store = [&](float (&xtdst)[36 * 2 * 64]) __attribute__((always_inline)) {
+    float v[6];
+    w4_bt(pd, v);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1 && tid >= 256) break;
-      float v[6];
-      w4_bt(pd[h], v);
+    for (int j = 0; j < 6; ++j) xtdst[p2_wr[0] + j * 128] = v[j];
+    if (tid < 256) {
+      float d[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) xtdst[p2_wr[h] + j * 128] = v[j];
+      for (int j = 0; j < 6; ++j) d[j] = tmp[p2_rd[1] + j];
+      w4_bt(d, v);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xtdst[p2_wr[1] + j * 128] = v[j];
     }
   };
 
@@ -184,61 +192,93 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   for (int p = 0; p < 36; ++p) acc[p] = (w4f4){0.f, 0.f, 0.f, 0.f};
   // 36 MFMAs per stage in four groups of nine positions; a group's operands are read ahead of the MFMAs of the group before (left to
   // itself the compiler reads two positions, waits for the LDS, issues two MFMAs).
-  float av[2][9], bv[2][9];
-  auto op_load = [&](int g, const float (&wsrc)[W4_WST], const float (&xsrc)[36 * 2 * 64]) __attribute__((always_inline)) {
-    const float* wa = &wsrc[cg * 64 + lane];
+  // A operands: G g G^T of this wave's (output channel, k) pairs -- one pair per lane, lane = k * 16 + cout % 16, exactly the lane that
+  // feeds it to the MFMA -- formed in registers from the nine taps (90 VALU per stage and wave) instead of streaming the 4x larger
+  // transformed image through L2 and LDS (36 KB per stage and workgroup: the first two versions waited 0.47 ms per forward for it)
+  // (half of the 36 at a time -- rows 0-2 ahead of the first eighteen MFMAs, rows 3-5 ahead of the last: 144 accumulators leave no room
+  //  for all of them)
+  float gv[9], U[18], bv[2][9];
+  auto g_load = [&](const float (&gsrc)[W4_GST]) __attribute__((always_inline)) {
+    const float* gp = &gsrc[cg * 64 + lane];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) gv[t9] = gp[t9 * 256];
+  };
+  auto g_xform = [&](auto hsel) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(hsel)::value;
+    float tt[3][3];                                       // (G g)[3 HALF + i][s]
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx) {
+      const float x0 = gv[sidx], x1 = gv[3 + sidx], x2 = gv[6 + sidx];
+      if (HALF == 0) {
+        const float e = (x0 + x2) * (-1.f / 6.f);
+        tt[0][sidx] = 0.25f * x0; tt[1][sidx] = fmaf(x1, -1.f / 6.f, e); tt[2][sidx] = fmaf(x1, 1.f / 6.f, e);
+      } else {
+        const float f = fmaf(x0, 1.f / 24.f, x2 * (1.f / 6.f));
+        tt[0][sidx] = fmaf(x1, 1.f / 12.f, f); tt[1][sidx] = fmaf(x1, -1.f / 12.f, f); tt[2][sidx] = x2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float y[6];
+      w4_g(tt[i][0], tt[i][1], tt[i][2], y);              // (G g) G^T: row 3 HALF + i
+#pragma unroll
+      for (int j = 0; j < 6; ++j) U[i * 6 + j] = y[j];
+    }
+  };
+  auto op_load = [&](int g, const float (&xsrc)[36 * 2 * 64]) __attribute__((always_inline)) {
     const float* xbp = &xsrc[ng * 64 + lane];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) { av[g & 1][q] = wa[(g * 9 + q) * 256]; bv[g & 1][q] = xbp[(g * 9 + q) * 128]; }
+    for (int q = 0; q < 9; ++q) bv[g & 1][q] = xbp[(g * 9 + q) * 128];
   };
   auto mfma9 = [&](int g) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) acc[g * 9 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][q], bv[g & 1][q], acc[g * 9 + q], 0, 0, 0);
+    for (int q = 0; q < 9; ++q) acc[g * 9 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[(g & 1) * 9 + q], bv[g & 1][q], acc[g * 9 + q], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
 #ifndef W4_ABL
 #define W4_ABL 0        // timing ablations (results are wrong): 1 no MFMAs, 2 no transforms, 4 no DMA
 #endif
-  // Stage s (steady state), buffers by parity: rawN = halo tile of stage s + 1 (landed), rawF = free (tile s was transformed during
-  // stage s - 1): receives tile s + 2; xtC / wC = this stage's operands, xtN / wN = the next stage's.
-  //   B1   everybody's DMA of the previous top has landed; xtC is complete; nobody reads wN, rawF, xtN, tmp any more
-  //   DMA  halo tile s + 2 -> rawF, weights s + 1 -> wN          (a whole stage to land)
-  //   nine MFMAs x 2 with pass 1 of stage s + 1 (rawN -> tmp) between them;  B2 (tmp complete);
-  //   nine MFMAs x 2 with pass 2 of stage s + 1 (tmp -> xtN) between them
+  // Stage s (steady state): rawN = halo tile of stage s + 1 (landed), rawF = free (tile s was transformed during stage s - 1): receives
+  // tile s + 2; xtC = this stage's transformed input, xtN = the next stage's; the taps of stage s are in registers (gv, read at the end of
+  // stage s - 1), gN = the taps of stage s + 1 (landed; read into registers at the end of this stage), gF = the slot the taps of stage s
+  // came from: receives the taps of stage s + 2.
+  //   B1   everybody's DMA of the previous top has landed; xtC is complete; nobody reads rawF, xtN, tmp, gF any more
+  //   DMA  halo tile s + 2 -> rawF, taps s + 2 -> gF
+  //   G g G^T rows 0-2 in registers; nine MFMAs x 2 with pass 1 of stage s + 1 (rawN -> tmp) between them;  B2 (tmp complete);
+  //   G g G^T rows 3-5; nine MFMAs x 2 with pass 2 of stage s + 1 (tmp -> xtN) between them; the taps of stage s + 1 into registers
   auto stage = [&](int s, float (&rawN)[W4_RAWP], float (&rawF)[W4_RAWP], float (&xtC)[36 * 2 * 64], float (&xtN)[36 * 2 * 64],
-                   float (&wC)[W4_WST], float (&wN)[W4_WST]) __attribute__((always_inline)) {
+                   float (&gN)[W4_GST], float (&gF)[W4_GST]) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!(W4_ABL & 4)) {
-      if (s + 2 < nchunk) fetch_raw(s + 2, rawF);
-      if (s + 1 < nchunk) fetch_w(s + 1, wN);
-    }
+    if (!(W4_ABL & 4) && s + 2 < nchunk) { fetch_raw(s + 2, rawF); fetch_w(s + 2, gF); }
     const bool nxt = !(W4_ABL & 2) && s + 1 < nchunk;
     const bool mm = !(W4_ABL & 1);
-    if (mm) op_load(0, wC, xtC);
+    if (mm) { op_load(0, xtC); g_xform(AIC4<0>{}); }
     if (nxt) p1_load(rawN);
-    if (mm) { op_load(1, wC, xtC); mfma9(0); }
-    if (nxt) p1_store();
-    if (mm) { op_load(2, wC, xtC); mfma9(1); }
+    if (mm) { op_load(1, xtC); mfma9(0); }
+    if (nxt) p1_store(rawN);
+    if (mm) { op_load(2, xtC); mfma9(1); }
     __syncthreads();
     if (nxt) p2_load();
-    if (mm) { op_load(3, wC, xtC); mfma9(2); }
+    if (mm) { g_xform(AIC4<1>{}); op_load(3, xtC); mfma9(2); }
     if (nxt) p2_store(xtN);
     if (mm) mfma9(3);
+    if (s + 1 < nchunk) g_load(gN);
   };
-  // prologue: tiles 0 and 1 and the weights of stage 0 in flight; tile 0 transformed into xt0
-  fetch_raw(0, raw0); fetch_w(0, wb0);
-  if (nchunk > 1) fetch_raw(1, raw1);
+  // prologue: tiles 0 and 1 and the taps of stages 0 and 1 in flight; tile 0 transformed into xt0; the taps of stage 0 in registers
+  fetch_raw(0, raw0); fetch_w(0, gw0);
+  if (nchunk > 1) { fetch_raw(1, raw1); fetch_w(1, gw1); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  p1_load(raw0); p1_store();
+  p1_load(raw0); p1_store(raw0);
+  g_load(gw0);
   __syncthreads();
   p2_load(); p2_store(xt0);
   for (int s = 0; s < nchunk; s += 2) {
-    stage(s, raw1, raw0, xt0, xt1, wb0, wb1);
-    if (s + 1 < nchunk) stage(s + 1, raw0, raw1, xt1, xt0, wb1, wb0);
+    stage(s, raw1, raw0, xt0, xt1, gw1, gw0);
+    if (s + 1 < nchunk) stage(s + 1, raw0, raw1, xt1, xt0, gw0, gw1);
   }
 
   // ---- epilogue: A^T M A per accumulator register (an output channel), bias, ReLU, 4 x 4 pixels per block

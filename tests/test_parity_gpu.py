@@ -585,7 +585,8 @@ def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
 def test_cnn_f4_vs_oracle(dev, oracle, shape):
     """FNX_PRECISION_FP32_F4: the 64- / 128-output-channel 3x3 layers of a 2D net in the Winograd F(4x4,3x3) domain (conv3_wino4_kernel,
     v_mfma_f32_16x16x4_f32; every other layer as in 'fp32') against the oracle at the modes' common tolerance 1e-5 |ref|max: partial
-    tiles in x and y, odd sizes, batch, the benchmark size, and a 3D net (which must give the 'fp32' mode's bits: no F(4x4) there)."""
+    tiles in x and y, odd sizes, batch, the benchmark size, and a 3D net (which must give the 'fp32_f2' mode's bits: no F(4x4) there).
+    Since round 6 this is what the default mode 'fp32' runs; 'fp32_f2' keeps F(2x2) everywhere."""
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     B, D, H, W = shape
@@ -598,15 +599,17 @@ def test_cnn_f4_vs_oracle(dev, oracle, shape):
     x = np.random.default_rng(5).standard_normal((B, 2, D, H, W)).astype(np.float32)
     got = N(net.multiScale(T(x, dev) if is3d else T(x[:, :, 0], dev))).reshape(B, 1, D, H, W)
     if is3d:
-        ref32 = FluidNet.from_weights(mconf, w, dev)
-        assert_bitexact(got, N(ref32.multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the fp32 mode's kernels")
+        ref32 = FluidNet.from_weights(dict(mconf, precisionMode="fp32_f2"), w, dev)
+        assert_bitexact(got, N(ref32.multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the F(2x2) kernels")
+        assert_bitexact(got, N(FluidNet.from_weights(mconf, w, dev).multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the default")
         return
     if H * W <= 600 * 600:
         want = oracle.multiscale_forward(oracle.pack_weights(w, 2), x)
         assert_close_rel(got, want, 1e-5, "MultiScaleNet, F(4x4) layers")
+        assert_bitexact(got, N(FluidNet.from_weights(mconf, w, dev).multiScale(T(x[:, :, 0], dev))).reshape(B, 1, D, H, W), "the default mode IS fp32_f4")
     else:
-        # benchmark size: against the F(2x2) mode (itself pinned to the oracle at this size by test_cnn_benchmark_size), both within 1e-5
-        ref32 = FluidNet.from_weights(mconf, w, dev)
+        # benchmark size: against the F(2x2) mode, both within 1e-5 of the oracle (test_cnn_benchmark_size pins the default at this size)
+        ref32 = FluidNet.from_weights(dict(mconf, precisionMode="fp32_f2"), w, dev)
         want = N(ref32.multiScale(T(x[:, :, 0], dev))).reshape(B, 1, D, H, W)
         assert_close_rel(got, want, 2e-5, "MultiScaleNet at 1024^2: F(4x4) against F(2x2)")
     if shape == (1, 1, 515, 509):

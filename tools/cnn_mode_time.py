@@ -6,7 +6,7 @@ from fluidnet_cxx_amd._ext import ext
 from fluidnet_cxx_amd.weights import make_scalenet_weights
 dev = torch.device('cuda:0')
 PROF = dict(conv_mfma=1, conv_direct=4, conv_mfma16=5, conv_bf16=6)
-MODES = [m for m in sys.argv[1:] if m in ("fp32", "bf16x6", "bf16x3", "fp32_direct", "fp32_f4")] or ["fp32", "bf16x6", "bf16x3"]
+MODES = [m for m in sys.argv[1:] if m in ("fp32", "bf16x6", "bf16x3", "fp32_direct", "fp32_f4", "fp32_f2")] or ["fp32", "bf16x6", "bf16x3"]
 for case in [c for c in sys.argv[1:] if c in ("2d", "3d")] or ["2d", "3d"]:
     is3d = case == "3d"
     shape = (1, 2, 256, 256, 256) if is3d else (1, 2, 1024, 1024)

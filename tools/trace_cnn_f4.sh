@@ -1,7 +1,7 @@
 # Usage (GPU box, repo root): per-launch durations of the last 1024^2 CNN step, F(2x2) default against the opt-in F(4x4) mode
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for w in plume2d_1024_cnn plume2d_1024_cnn_f4; do
+for w in plume2d_1024_cnn_f2 plume2d_1024_cnn; do
 rm -rf gpurun_out/prof_cnn
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_cnn -o t -- python bench.py --workload $w --no-cpu-baseline --no-dropin --steps 3 --warmup 1 --no-graph > /dev/null 2>&1
 echo "== $w"
