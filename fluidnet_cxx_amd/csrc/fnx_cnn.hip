@@ -33,7 +33,7 @@ inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_
 // FNX_PRECISION_BF16X6 (conv3_wbf_kernel): the wino layers with 64 output channels per workgroup; their transformed weights
 // cut into three bf16 pieces, in the kernel's MFMA operand layout (1.5x the fp32 image), follow the two fp32 images
 inline bool wbf_layer(const ConvLayer& L, bool is3d) { return wino_layer(L, is3d) && L.cin % 16 == 0 && L.cout % 64 == 0; }
-// FNX_PRECISION_FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the 2D wino layers with 64 output channels per workgroup; their nine
+// FNX_PRECISION_FP32 / _FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the 2D wino layers with 64 output channels per workgroup; their nine
 // taps in the kernel's lane order ([Cin/4][Cout/64][9][4][4][16], 9 Cin Cout floats: G g G^T is formed in registers) follow the bf16 image
 inline bool wino4_layer_(const ConvLayer& L, bool is3d) { return !is3d && L.k == 3 && L.cin % 16 == 0 && L.cout % 64 == 0; }
 inline size_t wino4_offset(const ConvLayer& L, bool is3d) {      // floats from the layer's w_off to its F(4x4) image
@@ -1887,5 +1887,9 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
   fnx::launch_gather_input(d, nc, input, U_out, flags, s);
   return fnx::fluidnet_core(g, packed, flags, thr, precision_mode, p_out, U_out, rest, stream);
 }
+
+#ifdef W4_TIMELINE
+int fnx_debug_w4_timeline(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fnx::w4_tl), sizeof(fnx::w4_tl)); }
+#endif
 
 }  // extern "C"

@@ -1,5 +1,8 @@
 // 3x3 convolution in the Winograd F(4x4, 3x3) domain, 2D, exact fp32 on v_mfma_f32_16x16x4_f32 (included by fnx_cnn.hip inside
-// namespace fnx, after its DMA helpers).  Round 6; FNX_PRECISION_FP32_F4.
+// namespace fnx, after its DMA helpers).  Round 6; what FNX_PRECISION_FP32 runs for the 64- / 128-output-channel 3x3 layers of a 2D net
+// whose launch fills the chip (FNX_PRECISION_FP32_F2 keeps them on conv3_wino3_kernel): 5.7 % faster than F(2x2) on the six such
+// launches of a 1024^2 MultiScaleNet forward (1 740 against 1 845 us); docs/history/r06_notes.md section 3 has the eight versions that
+// were measured and the cycle accounting (this file is the third).
 //
 //   Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A      d = 6x6 input patch of a 4x4 output block (Lavin & Gray, points 0, +-1, +-2, inf)
 //
@@ -19,7 +22,7 @@
 //                   and wave instead of a 36 KB stream per stage and workgroup through L2 and LDS)
 //   B^T d B         two passes through LDS, all threads: columns (raw -> tmp), barrier, rows (tmp -> xt [36][2 groups][4 k][16])
 //   36 MFMAs        per wave; A from registers, B ONE conflict-free ds_read_b32 (64 consecutive floats per wave)
-// Two barriers per stage; the transforms of stage s + 1 ride between the MFMA groups of stage s.  No persistent tile loop yet.
+// Two barriers per stage; the transforms of stage s + 1 ride between the MFMA groups of stage s.  No persistent tile loop.
 //
 // Numerics: the transforms are not exact in binary (G has 1/6, 1/24; B^T and A^T multiply by 2, 4, 5, 8): measured 2x the error of
 // F(2x2) against an fp64 evaluation of the net, 0.07 of the tests' 1e-5 |ref|max (tools/wino_f4_error_probe.py).

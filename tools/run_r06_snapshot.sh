@@ -12,5 +12,6 @@ rm -f gpurun_out/${tag}_link_model.txt
 MODEL_DIRECT=auto timeout 900 python tools/slab_native_model.py deep_first,deep_beside 6 6 2>&1 | grep "ms/step" >> gpurun_out/${tag}_link_model.txt
 cat gpurun_out/${tag}_link_model.txt
 timeout 300 python tools/peer_probe.py 2>&1 | grep peer-store > gpurun_out/${tag}_peer_probe.txt; cat gpurun_out/${tag}_peer_probe.txt
+bash tools/trace_cnn_f4.sh > gpurun_out/${tag}_wino4_per_layer_trace.txt 2>&1; cat gpurun_out/${tag}_wino4_per_layer_trace.txt
 timeout 300 python tools/advect_ab.py 512 64 > gpurun_out/${tag}_advect_ab.txt 2>&1; cat gpurun_out/${tag}_advect_ab.txt
 timeout 600 python bench.py --gpus 8 --steps 5 --warmup 2 --rehearse-one-gpu --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > gpurun_out/${tag}_bench_rehearsal_8_ranks_one_gpu.json; wc -c gpurun_out/${tag}_bench_rehearsal_8_ranks_one_gpu.json

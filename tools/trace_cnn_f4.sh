@@ -1,4 +1,5 @@
-# Usage (GPU box, repo root): per-launch durations of the last 1024^2 CNN step, F(2x2) default against the opt-in F(4x4) mode
+# Usage (GPU box, repo root): per-launch durations of the last 1024^2 CNN step, F(2x2) everywhere (fp32_f2) against the default (F(4x4) for the
+# 64- / 128-output-channel 3x3 layers)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for w in plume2d_1024_cnn_f2 plume2d_1024_cnn; do
