@@ -35,7 +35,7 @@ inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_
 inline bool wbf_layer(const ConvLayer& L, bool is3d) { return wino_layer(L, is3d) && L.cin % 16 == 0 && L.cout % 64 == 0; }
 // FNX_PRECISION_FP32 / _FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the 2D wino layers with 64 output channels per workgroup; their nine
 // taps in the kernel's lane order ([Cin/4][Cout/64][9][4][4][16], 9 Cin Cout floats: G g G^T is formed in registers) follow the bf16 image
-inline bool wino4_layer_(const ConvLayer& L, bool is3d) { return !is3d && L.k == 3 && L.cin % 16 == 0 && L.cout % 64 == 0; }
+inline bool wino4_layer_(const ConvLayer& L, bool is3d) { (void)is3d; return L.k == 3 && L.cin % 16 == 0 && L.cout % 64 == 0; }
 inline size_t wino4_offset(const ConvLayer& L, bool is3d) {      // floats from the layer's w_off to its F(4x4) image
   const size_t nwino = (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout;
   return layer_weight_floats(L, is3d) + 2 * nwino + (wbf_layer(L, is3d) ? nwino * 3 / 2 : 0);
@@ -44,7 +44,7 @@ inline size_t packed_weight_floats(const ConvLayer& L, bool is3d) {
   if (wino_layer(L, is3d))
     return layer_weight_floats(L, is3d) + 2 * (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout +
            (wbf_layer(L, is3d) ? (size_t)16 * (is3d ? 3 : 1) * L.cin * L.cout * 3 / 2 : 0) +
-           (wino4_layer_(L, is3d) ? (size_t)9 * L.cin * L.cout : 0);
+           (wino4_layer_(L, is3d) ? (size_t)(is3d ? 27 : 9) * L.cin * L.cout : 0);
   if (mfma16_layer(L) && pair_layer(L.cin, L.cout)) return (size_t)(is3d ? 5 : 1) * 30 * pad_to(L.cin, 4) * 16;
   if (mfma16_layer(L)) return (size_t)layer_taps(L, is3d) * pad_to(L.cin, 4) * pad_to(L.cout, 16);
   return layer_weight_floats(L, is3d);
@@ -1320,8 +1320,8 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
     if ((mode == FNX_PRECISION_FP32 || mode == FNX_PRECISION_FP32_F4) && wino4_layer_(L, is3d) &&
-        launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), s)) {
-      prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 2.25);                  // 36 multiplies per 4x4 outputs
+        launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), is3d, s)) {
+      prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 2.25 * (is3d ? 3 : 1));  // 36 multiplies per 4x4 outputs (per z tap)
       return;
     }
     if (!direct && wino_layer(L, is3d) && launch_conv_wino(a, is3d, packed + pl.w_off + layer_weight_floats(L, is3d), s)) {
@@ -1465,7 +1465,7 @@ void scalenet_pack(bool is3d, const float* blob, void* packed, hipStream_t s) {
         if (wbf_layer(L, is3d))                                 // FNX_PRECISION_BF16X6: three bf16 pieces, MFMA operand layout
           pack_wbf_kernel<<<256, 256, 0, s>>>(w2, (unsigned*)(w3 + (size_t)16 * kd * L.cin * L.cout), L.cin, L.cout, kd);
         if (wino4_layer_(L, is3d))                              // FNX_PRECISION_FP32_F4: the taps in lane order, stage-contiguous
-          pack_layer_wino4g_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + wino4_offset(L, is3d), L.cin, L.cout);
+          pack_layer_wino4g_kernel<<<64, 256, 0, s>>>(blob + off, pk + pl.w_off + wino4_offset(L, is3d), L.cin, L.cout, is3d ? 3 : 1);
       }
     }
     else if (mfma16_layer(L) && pair_layer(L.cin, L.cout))

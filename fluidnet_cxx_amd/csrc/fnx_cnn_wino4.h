@@ -37,12 +37,15 @@ constexpr int W4_GST = 9 * 4 * 4 * 16;       // 2304 floats of a stage's taps
 
 // blob (Cout, Cin, 3, 3) -> the nine taps as [Cin/4][Cout/64][9][4 groups of 16 cout][4 k][16]: what a wave reads as one float per lane and
 // tap (its MFMA A-operand position: lane = k * 16 + cout % 16) to form G g G^T in registers (conv3_wino4_kernel)
-__global__ void pack_layer_wino4g_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout) {
+// (3D, kd = 3: blob (Cout, Cin, 3, 3, 3); one such image per z tap, [dz][Cin/4][Cout/64]...: a stage = four channels of ONE z tap)
+__global__ void pack_layer_wino4g_kernel(const float* __restrict__ w, float* __restrict__ pw, int cin, int cout, int kd) {
   const int n = cin * cout, ngrp = cout / 64;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
     const int co = q / cin, ci = q - co * cin;
-    const size_t base = ((size_t)(ci / 4) * ngrp + co / 64) * (9 * 256) + (size_t)((co % 64) / 16) * 64 + (ci % 4) * 16 + co % 16;
-    for (int t = 0; t < 9; ++t) pw[base + (size_t)t * 256] = w[(size_t)q * 9 + t];
+    for (int dz = 0; dz < kd; ++dz) {
+      const size_t base = (((size_t)dz * (cin / 4) + ci / 4) * ngrp + co / 64) * (9 * 256) + (size_t)((co % 64) / 16) * 64 + (ci % 4) * 16 + co % 16;
+      for (int t = 0; t < 9; ++t) pw[base + (size_t)t * 256] = w[((size_t)q * kd + dz) * 9 + t];
+    }
   }
 }
 
@@ -78,6 +81,9 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
 typedef float w4f4 __attribute__((ext_vector_type(4)));
 template <int N> struct AIC4 { static constexpr int value = N; };
 
+// IS3D: F(4x4) in (y, x), the three z taps as three times the stages (input plane z + dz - 1, the taps image of dz; a tap whose plane is
+// outside the grid is skipped: zero padding)
+template <bool IS3D>
 __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const float* __restrict__ wt, int ntx, int nty) {
   __shared__ __attribute__((aligned(16))) float raw0[W4_RAWP];
   __shared__ __attribute__((aligned(16))) float raw1[W4_RAWP];
@@ -88,12 +94,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   __shared__ __attribute__((aligned(16))) float gw1[W4_GST];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cg = wave & 3, ng = wave >> 2;
-  const int ngrp = a.cout / 64, nchunk = a.cin / W4C;
-  const size_t plane = (size_t)a.H * a.W;
+  const int ngrp = a.cout / 64, nch = a.cin / W4C;
+  const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
   int t = blockIdx.x;
   const int tx = t % ntx; t /= ntx;
   const int ty = t % nty; t /= nty;
+  int z = 0;
+  if (IS3D) { z = t % a.D; t /= a.D; }
   const int grp = t % ngrp, b = t / ngrp;
+  const int dz_lo = IS3D && z == 0 ? 1 : 0, dz_hi = IS3D ? (z == a.D - 1 ? 2 : 3) : 1;
+  const int nchunk = (dz_hi - dz_lo) * nch;                 // stages: (z tap, four input channels), z tap slowest
   const int x0 = tx * 32, y0 = ty * 16;
 
   // ---- halo-tile DMA: slot idx = q * 512 + tid of the [4][18][34] tile; out of the image (or beyond the tile) -> an offset the range
@@ -106,14 +116,15 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     const int row = rem / 34, col = rem - row * 34;
     const int gy = y0 - 1 + row, gx = x0 - 1 + col;
     const bool ok = (idx < W4_RAW) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
-    uoff[q] = ok ? (unsigned)(((size_t)c * plane + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
+    uoff[q] = ok ? (unsigned)(((size_t)c * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
   }
-  const float* xb = a.x + (size_t)b * a.cin * plane;
-  const unsigned stage_bytes = (unsigned)((size_t)W4C * plane * 4);
+  const float* xb = a.x + (size_t)b * a.cin * vol;
+  const unsigned stage_bytes = (unsigned)(((size_t)(W4C - 1) * vol + plane) * 4);
   const BufRsrcC wrs = make_rsrc_c(wt, 0x7ffffff0u);
   const unsigned wlane = (unsigned)(wave * 256 + lane * 4) * 4u;
   auto fetch_raw = [&](int chunk, float (&rawdst)[W4_RAWP]) __attribute__((always_inline)) {
-    const BufRsrcC r = make_rsrc_c(xb + (size_t)chunk * W4C * plane, stage_bytes);
+    const int kz = IS3D ? (chunk >= 2 * nch ? 2 : chunk >= nch ? 1 : 0) : 0;      // stage -> (z tap - dz_lo, channel group)
+    const BufRsrcC r = make_rsrc_c(xb + (size_t)(chunk - kz * nch) * W4C * vol + (size_t)(IS3D ? z + dz_lo + kz - 1 : 0) * plane, stage_bytes);
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       if (W4_NT & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)((LdsF)&rawdst[0] + q * 512 + wave * 64), 4, uoff[q], 0, 0, 2);
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     }
   };
   auto fetch_w = [&](int chunk, float (&wdst)[W4_GST]) __attribute__((always_inline)) {
-    const unsigned sb = (unsigned)(((size_t)chunk * ngrp + grp) * W4_GST * 4);
+    const unsigned sb = (unsigned)(((size_t)(dz_lo * nch + chunk) * ngrp + grp) * W4_GST * 4);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                       // 9 instructions of 1 KiB: waves 0-7, then wave 0 again
       const int wi = wave + 8 * q;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     for (int i = 0; i < 6; ++i)
       w4_at(acc[i * 6 + 0][r], acc[i * 6 + 1][r], acc[i * 6 + 2][r], acc[i * 6 + 3][r], acc[i * 6 + 4][r], acc[i * 6 + 5][r], T[i]);
     const float bias = a.bias[co];
-    float* yo = a.y + ((size_t)b * a.cout + co) * plane;
+    float* yo = a.y + ((size_t)b * a.cout + co) * vol + (size_t)z * plane;
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {                     // output column bb of the block: A^T along i
       float y[4];
@@ -323,12 +334,13 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
 }
 
 // false: nothing launched (the caller takes the F(2x2) kernel)
-bool launch_conv_wino4(const ConvArgs& a, const float* wt4, hipStream_t s) {
-  if (a.D != 1 || a.cin % 16 != 0 || a.cout % 64 != 0) return false;
-  if ((size_t)W4C * a.H * a.W * 4 >= 0xfffffff0u) return false;
+bool launch_conv_wino4(const ConvArgs& a, const float* wt4, bool is3d, hipStream_t s) {
+  if ((!is3d && a.D != 1) || a.cin % 16 != 0 || a.cout % 64 != 0) return false;
+  if ((size_t)W4C * a.D * a.H * a.W * 4 >= 0xfffffff0u) return false;
   const int ntx = (a.W + 31) / 32, nty = (a.H + 15) / 16;
-  const long nt = (long)ntx * nty * a.B * (a.cout / 64);
+  const long nt = (long)ntx * nty * a.D * a.B * (a.cout / 64);
   if (nt < 256 || nt > 0x7fffffffl) return false;        // a launch that does not fill the chip stays on the F(2x2) / direct kernels
-  conv3_wino4_kernel<<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty);
+  if (is3d) conv3_wino4_kernel<true><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty);
+  else conv3_wino4_kernel<false><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty);
   return true;
 }

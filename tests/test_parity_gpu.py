@@ -581,11 +581,12 @@ def test_cnn_winograd_layers_vs_oracle(dev, oracle, shape):
         assert_close_rel(N(net.multiScale(T(x, dev))), oracle.multiscale_forward(oracle.pack_weights(w, 2), x), 1e-5, "MultiScaleNet")
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 1, 1024, 1024), (3, 1, 130, 700), (1, 16, 126, 130)])
+@pytest.mark.parametrize("shape", [(1, 1, 515, 509), (2, 1, 384, 352), (1, 1, 1024, 1024), (3, 1, 130, 700), (1, 16, 126, 130), (2, 5, 200, 96),
+                                   (1, 3, 64, 512)])
 def test_cnn_f4_vs_oracle(dev, oracle, shape):
     """FNX_PRECISION_FP32_F4: the 64- / 128-output-channel 3x3 layers of a 2D net in the Winograd F(4x4,3x3) domain (conv3_wino4_kernel,
     v_mfma_f32_16x16x4_f32; every other layer as in 'fp32') against the oracle at the modes' common tolerance 1e-5 |ref|max: partial
-    tiles in x and y, odd sizes, batch, the benchmark size, and a 3D net (which must give the 'fp32_f2' mode's bits: no F(4x4) there).
+    tiles in x and y, odd sizes, batch, the benchmark size, and 3D nets (F(4x4) in (y, x), the three z taps as stages; boundary planes skip a tap).
     Since round 6 this is what the default mode 'fp32' runs; 'fp32_f2' keeps F(2x2) everywhere."""
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
@@ -599,9 +600,12 @@ def test_cnn_f4_vs_oracle(dev, oracle, shape):
     x = np.random.default_rng(5).standard_normal((B, 2, D, H, W)).astype(np.float32)
     got = N(net.multiScale(T(x, dev) if is3d else T(x[:, :, 0], dev))).reshape(B, 1, D, H, W)
     if is3d:
+        # 3D: F(4x4) in (y, x), the z taps as stages (launches that fill the chip; the coarser scales stay on the F(2x2) / direct kernels)
+        want = oracle.multiscale_forward(oracle.pack_weights(w, 3), x)
+        assert_close_rel(got, want, 1e-5, "3D MultiScaleNet, F(4x4) layers")
+        assert_bitexact(got, N(FluidNet.from_weights(mconf, w, dev).multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the default mode IS fp32_f4")
         ref32 = FluidNet.from_weights(dict(mconf, precisionMode="fp32_f2"), w, dev)
-        assert_bitexact(got, N(ref32.multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the F(2x2) kernels")
-        assert_bitexact(got, N(FluidNet.from_weights(mconf, w, dev).multiScale(T(x, dev))).reshape(B, 1, D, H, W), "3D: the default")
+        assert not np.array_equal(got, N(ref32.multiScale(T(x, dev))).reshape(B, 1, D, H, W)), "3D: the F(4x4) kernel did not run"
         return
     if H * W <= 600 * 600:
         want = oracle.multiscale_forward(oracle.pack_weights(w, 2), x)
