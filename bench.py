@@ -112,6 +112,7 @@ WORKLOADS = {
     # the default of rounds 2-5 for comparison: every Winograd layer in the F(2x2,3x3) domain (FNX_PRECISION_FP32_F2; since round 6 the
     # default runs the 64/128-output-channel 3x3 layers of a 2D net in the F(4x4,3x3) domain)
     "plume2d_1024_cnn_f2": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="fp32_f2"),
+    "plume3d_256_cnn_f2": dict(res=256, D=256, method="convnet", iters=0, kind="plume", precision="fp32_f2"),
     # OPT-IN precision mode, never the headline: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
     # product (FNX_PRECISION_BF16X6; same 1e-5 |ref|max tolerance against the oracle as the exact-fp32 modes, tests/)
     "plume2d_1024_cnn_bf16x6": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="bf16x6"),
@@ -458,12 +459,14 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
-        if not is3d and w.get("precision", "fp32") in ("fp32", "fp32_f4"):
-            kname = ("conv3_wino4_kernel (round 6: the 64/128-output-channel 3x3 layers of a 2D net that fill the chip -- 6 of the 10 MFMA launches of a 1024^2 forward, "
-                     "0.9 of their time -- in the Winograd F(4x4,3x3) domain: 36 multiplies per 16 outputs instead of 144, v_mfma_f32_16x16x4_f32, one wave = 16 output "
-                     "channels x 16 blocks x all 36 positions) + conv3_wino3_kernel<1,2,false> / <2,2,false> (F(2x2,3x3), v_mfma_f32_32x32x2_f32) for the 32-channel "
-                     "outputs and the quarter-resolution layers; achieved/frac count DIRECT-convolution FLOPs and can exceed the MFMA peak, mfma_util counts the FLOPs "
-                     "actually issued to the matrix cores (F(4x4) issues 0.5625 of F(2x2)'s)")
+        if w.get("precision", "fp32") in ("fp32", "fp32_f4"):
+            t3 = "true" if is3d else "false"
+            kname = (f"conv3_wino4_kernel<{t3}> (round 6: the 64/128-output-channel 3x3{'x3' if is3d else ''} layers whose launch fills the chip -- 6 of the 10 MFMA launches of a "
+                     "forward, 0.9 of their time -- in the Winograd F(4x4,3x3) domain" + (" in (y, x), the three z taps as stages" if is3d else "") + ": 36 multiplies per 16 "
+                     "outputs instead of 144, v_mfma_f32_16x16x4_f32, one wave = 16 output channels x 16 blocks x all 36 positions) + "
+                     f"conv3_wino3_kernel<1,2,{t3}> / <2,2,{t3}> (F(2x2,3x3), v_mfma_f32_32x32x2_f32) for the 32-channel outputs and the quarter-resolution layers; "
+                     "achieved/frac count DIRECT-convolution FLOPs and can exceed the MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores "
+                     "(F(4x4) issues 0.5625 of F(2x2)'s)")
         avg_ms = tms / max(nl, 1)
         if w.get("precision") in BF16_MODES:
             # the opt-in mode: its own kernel, priced against the bf16 MFMA peak on the bf16 FLOPs it issues (six per fp32 product)

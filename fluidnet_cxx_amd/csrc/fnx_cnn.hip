@@ -12,6 +12,12 @@
 #include "../../include/fluidnet_hip.h"
 
 namespace fnx {
+// (every error return sets the thread's message: the Python layer raises fnx_last_error(), which would otherwise be an earlier call's text)
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FNX_OK : set_error(FNX_EHIP, "HIP error in a CNN launch: %s (a grid the net cannot take -- 3D: D a multiple of 4?)", hipGetErrorString(e));
+}
+
 
 namespace {
 
@@ -1816,7 +1822,7 @@ int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, floa
     launch_post_projection(d, g->is3D, pnet, U, bcs->density, flags, ubc ? bcs->UBC : nullptr, ubc ? bcs->UBCInvMask : nullptr,
                            rbc ? bcs->densityBC : nullptr, rbc ? bcs->densityBCInvMask : nullptr, s, bcs->bc_class,
                            bcs->density_bc_applied != 0, scale, p_out);          // model.py:213-226, simulate.py:168
-    return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+    return fnx::launch_status();
   }
   if (int rc = fnx_velocity_divergence(g, U, flags, div, stream)) return rc;     // model.py:125-126
   launch_scale_std(d, nc, U, thr, partial, scale, s);                            // model.py:129-144
@@ -1825,7 +1831,7 @@ int fluidnet_core(const FnxGrid* g, const void* packed, const float* flags, floa
   if (int rc = fnx_velocity_update(g, p_out, U, flags, stream)) return rc;       // model.py:213-218
   launch_unscale(d, nc, scale, p_out, U, s);                                     // model.py:221-223
   if (int rc = fnx_set_wall_bcs(g, U, flags, stream)) return rc;                 // model.py:226
-  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+  return fnx::launch_status();
 }
 }  // namespace fnx
 
@@ -1839,26 +1845,28 @@ size_t fnx_scalenet_weight_floats(int is3D) { return fnx::scalenet_weight_floats
 size_t fnx_scalenet_packed_bytes(int is3D) { return fnx::scalenet_packed_bytes(is3D != 0); }
 
 int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* stream) {
-  if (!weights_blob || !packed) return FNX_EINVAL;
+  if (!weights_blob || !packed) return fnx::set_error(FNX_EINVAL, "%s: null argument", __func__);
   fnx::scalenet_pack(is3D != 0, weights_blob, packed, (hipStream_t)stream);
-  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+  return fnx::launch_status();
 }
 
 static bool bad_precision(int m) { return m < FNX_PRECISION_FP32 || m > FNX_PRECISION_FP32_F2; }
 
 int fnx_multiscale_forward(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode, void* ws,
                            size_t ws_bytes, void* stream) {
-  if (!g || !packed || !x || !p || !ws) return FNX_EINVAL;
+  if (!g || !packed || !x || !p || !ws) return fnx::set_error(FNX_EINVAL, "%s: null argument", __func__);
   if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, _FP32_DIRECT, _BF16X6 or _BF16X3)", precision_mode);
+  if (g->H < 4 || g->W < 4 || (g->is3D && g->D < 4))
+    return fnx::set_error(FNX_EINVAL, "%s: the three-scale net needs at least 4 cells per axis (D %d, H %d, W %d)", __func__, g->D, g->H, g->W);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
-  if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
+  if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return fnx::set_error(FNX_EWORKSPACE, "%s: workspace of %zu bytes is too small", __func__, ws_bytes);
   fnx::multiscale_forward(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream);
-  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+  return fnx::launch_status();
 }
 
 int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const float* x, float* p, int precision_mode,
                                 const int trim[4], void* ws, size_t ws_bytes, void* stream) {
-  if (!g || !packed || !x || !p || !ws || !trim) return FNX_EINVAL;
+  if (!g || !packed || !x || !p || !ws || !trim) return fnx::set_error(FNX_EINVAL, "%s: null argument", __func__);
   if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, _FP32_DIRECT, _BF16X6 or _BF16X3)", precision_mode);
   if (!g->is3D && (trim[0] | trim[1] | trim[2] | trim[3])) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: z windows need a 3D grid");
   for (int a = 0; a < 4; ++a)
@@ -1866,18 +1874,22 @@ int fnx_multiscale_forward_crop(const FnxGrid* g, const void* packed, const floa
   if (trim[2] > trim[0] || trim[3] > trim[1]) return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: the half-resolution window must contain the full-resolution one");
   if ((trim[0] | trim[1] | trim[2] | trim[3]) && (g->D % 4 || g->D - trim[0] - trim[1] < 4))
     return fnx::set_error(FNX_EINVAL, "multiscale_forward_crop: D = %d must be a multiple of 4 and leave at least 4 planes (trims %d + %d)", g->D, trim[0], trim[1]);
+  if (g->H < 4 || g->W < 4 || (g->is3D && g->D < 4))
+    return fnx::set_error(FNX_EINVAL, "%s: the three-scale net needs at least 4 cells per axis (D %d, H %d, W %d)", __func__, g->D, g->H, g->W);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
-  if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
+  if (ws_bytes < fnx::multiscale_ws_bytes(d, g->is3D)) return fnx::set_error(FNX_EWORKSPACE, "%s: workspace of %zu bytes is too small", __func__, ws_bytes);
   fnx::multiscale_forward_crop(d, g->is3D, packed, x, p, precision_mode, ws, (hipStream_t)stream, trim);
-  return hipGetLastError() == hipSuccess ? FNX_OK : FNX_EHIP;
+  return fnx::launch_status();
 }
 
 int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* input, float thr, float* p_out,
                          float* U_out, int precision_mode, void* ws, size_t ws_bytes, void* stream) {
-  if (!g || !packed || !input || !p_out || !U_out || !ws) return FNX_EINVAL;
+  if (!g || !packed || !input || !p_out || !U_out || !ws) return fnx::set_error(FNX_EINVAL, "%s: null argument", __func__);
   if (bad_precision(precision_mode)) return fnx::set_error(FNX_EINVAL, "unknown precision_mode %d (FNX_PRECISION_FP32, _FP32_DIRECT, _BF16X6 or _BF16X3)", precision_mode);
+  if (g->H < 4 || g->W < 4 || (g->is3D && g->D < 4))
+    return fnx::set_error(FNX_EINVAL, "%s: the three-scale net needs at least 4 cells per axis (D %d, H %d, W %d)", __func__, g->D, g->H, g->W);
   const GridDims d = make_dims(g->B, g->D, g->H, g->W, g->z_offset, g->D_global);
-  if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return FNX_EWORKSPACE;
+  if (ws_bytes < fnx::fluidnet_ws_bytes(d, g->is3D)) return fnx::set_error(FNX_EWORKSPACE, "%s: workspace of %zu bytes is too small", __func__, ws_bytes);
   hipStream_t s = (hipStream_t)stream;
   const int nc = g->is3D ? 3 : 2;
   const size_t full = (size_t)g->B * d.DHW;

@@ -13,7 +13,7 @@ timeout 300 tools/gpu_profile.sh $tag plume3d_slab_jacobi --steps 20 --warmup 3 
 for w in plume3d_256_jacobi plume2d_1024_cnn plume2d_1024_jacobi rt2d_2048_jacobi plume2d_128_jacobi plume2d_128_b32_cnn plume2d_128_b32_jacobi plume2d_1024_cnn_bf16x6 plume2d_1024_cnn_f2; do
   timeout 300 tools/gpu_profile.sh $tag $w --steps 20 --warmup 3
 done
-for w in plume3d_256_cnn plume3d_hbm_jacobi plume3d_256_cnn_bf16x6; do
+for w in plume3d_256_cnn plume3d_hbm_jacobi plume3d_256_cnn_bf16x6 plume3d_256_cnn_f2; do
   timeout 400 tools/gpu_profile.sh $tag $w --steps 5 --warmup 2
 done
 for w in plume3d_slab_jacobi plume3d_256_jacobi plume2d_1024_cnn rt2d_2048_jacobi plume2d_1024_cnn_bf16x6 plume3d_256_cnn_bf16x6; do

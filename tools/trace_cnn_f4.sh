@@ -2,7 +2,7 @@
 # 64- / 128-output-channel 3x3 layers)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for w in plume2d_1024_cnn_f2 plume2d_1024_cnn; do
+for w in plume2d_1024_cnn_f2 plume2d_1024_cnn plume3d_256_cnn_f2 plume3d_256_cnn; do
 rm -rf gpurun_out/prof_cnn
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_cnn -o t -- python bench.py --workload $w --no-cpu-baseline --no-dropin --steps 3 --warmup 1 --no-graph > /dev/null 2>&1
 echo "== $w"
