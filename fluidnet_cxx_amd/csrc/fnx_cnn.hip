@@ -39,7 +39,7 @@ inline bool wino_layer(const ConvLayer& L, bool is3d) { (void)is3d; return mfma_
 // FNX_PRECISION_BF16X6 (conv3_wbf_kernel): the wino layers with 64 output channels per workgroup; their transformed weights
 // cut into three bf16 pieces, in the kernel's MFMA operand layout (1.5x the fp32 image), follow the two fp32 images
 inline bool wbf_layer(const ConvLayer& L, bool is3d) { return wino_layer(L, is3d) && L.cin % 16 == 0 && L.cout % 64 == 0; }
-// FNX_PRECISION_FP32 / _FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the 2D wino layers with 64 output channels per workgroup; their nine
+// FNX_PRECISION_FP32 (3D) / _FP32_F4 (conv3_wino4_kernel, fnx_cnn_wino4.h): the wino layers with 64 output channels per workgroup; their nine
 // taps in the kernel's lane order ([Cin/4][Cout/64][9][4][4][16], 9 Cin Cout floats: G g G^T is formed in registers) follow the bf16 image
 inline bool wino4_layer_(const ConvLayer& L, bool is3d) { (void)is3d; return L.k == 3 && L.cin % 16 == 0 && L.cout % 64 == 0; }
 inline size_t wino4_offset(const ConvLayer& L, bool is3d) {      // floats from the layer's w_off to its F(4x4) image
@@ -1325,7 +1325,9 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
-    if ((mode == FNX_PRECISION_FP32 || mode == FNX_PRECISION_FP32_F4) && wino4_layer_(L, is3d) &&
+    // F(4x4): the default of 3D nets (256^3 step 92.2 -> 86.3 ms); in 2D only by name -- the 1024^2 step measures 0.3-0.5 % SLOWER with it
+    // (2.292 against 2.285 ms replayed, 2.279 against 2.265 eager) although the six launches alone are 4 % shorter under rocprofv3
+    if ((mode == FNX_PRECISION_FP32_F4 || (mode == FNX_PRECISION_FP32 && is3d)) && wino4_layer_(L, is3d) &&
         launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), is3d, s)) {
       prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 2.25 * (is3d ? 3 : 1));  // 36 multiplies per 4x4 outputs (per z tap)
       return;
