@@ -283,11 +283,38 @@ def cpu_baseline(w, budget_s=12.0):
                 sample=f"{n} {w['method']} steps on a {D}x{res}x{res} grid, per-cell rate")
 
 
-def jacobi_roofline(name, w, cells, prof_steps, jac, traffic, traffic_src, traffic_detail):
-    """roofline block of the solver's pass kernel from the HIP-event pairs around its launches (`jac` = (ms, launches) over
-    `prof_steps` eager steps of this rank's `cells`)"""
+def jacobi_replay_launch_ms(ext, bd, is3d, iters, launches_per_solve):
+    """ms per launch of the solver's pass with its launches back to back in a replayed graph (see the call)"""
+    import torch
+    flags = bd["flags"]
+    div = ext.velocity_divergence(bd["U"], flags, None)
+
+    def solve_ms(n_iter, reps=10):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            keep = ext.solve_linear_system(flags, div, is3d, 0.0, n_iter, False, None)   # noqa: F841  (outputs live in the graph's pool)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    return (solve_ms(2 * iters) - solve_ms(iters)) / launches_per_solve
+
+
+def jacobi_roofline(name, w, cells, prof_steps, jac, traffic, traffic_src, traffic_detail, replay_ms=None):
+    """roofline block of the solver's pass kernel.  `jac` = (ms, launches) of the HIP-event pairs around every launch over `prof_steps`
+    eager steps of this rank's `cells`; `replay_ms`: ms per launch with the launches back to back in a replayed graph -- the figure the
+    fractions use when it is there (how the kernel runs in the timed step; the pairs' figure stays beside it as avg_launch_ms_each)"""
     is3d = w["D"] > 1
     tms, nl = jac
+    each_ms = tms / max(nl, 1)
+    if replay_ms and replay_ms > 0:
+        tms = replay_ms * nl
     byts = 16.0 * w["iters"] * cells * prof_steps
     ach = byts / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
     kname = ("jacobi3d_march2_kernel<false,false,3> (the steady-state instantiation: z-marching, TWO sweeps per pass, p handed from "
@@ -304,7 +331,9 @@ def jacobi_roofline(name, w, cells, prof_steps, jac, traffic, traffic_src, traff
                 traffic=traffic, traffic_source=traffic_src,
                 frac_traffic=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
                 traffic_detail=traffic_detail, launches_per_step=nl / prof_steps,
-                avg_launch_ms=avg_ms,
+                avg_launch_ms=avg_ms, avg_launch_ms_each=each_ms,
+                timing=("HIP events around 10 replays of a graph holding one solve, (T(2 x iters) - T(iters)) / launches; _each: an event pair around "
+                        "every eager launch") if (replay_ms and replay_ms > 0) else "an event pair around every eager launch",
                 algorithmic=f"16 B/cell/sweep x {w['iters']} sweeps x {cells} owned cells per step")
 
 
@@ -443,6 +472,16 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
     times = {k: ext.profile_read(v) for k, v in PROF.items()}
     issued = {k: ext.profile_read_work(v) for k, v in PROF.items()}
     ext.profile_enable(False)
+    # The solver's pass as it runs in the timed step -- launches back to back in a replayed graph: HIP events around ten replays of a graph
+    # that holds ONE solve, at `iters` and at 2 x `iters` sweeps; the difference is the time of the extra launches alone (no mask build,
+    # no first pass).  A pair around every eager launch (above) makes each kernel wait for the one before it to drain and reads ~2 us
+    # long; rocprofv3's average over the same command agrees with the replay figure (profiles/r06/a_*_kernel_stats.csv).
+    replay_ms = None
+    if w["method"] == "jacobi" and world == 1 and times["jacobi"][1] > 0:
+        try:
+            replay_ms = jacobi_replay_launch_ms(ext, bd, is3d, w["iters"], times["jacobi"][1] / prof_steps)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"bench: no replayed-solve timing ({type(e).__name__}: {e})\n")
     # HBM bytes per launch of the roofline kernel (PMC FETCH_SIZE/WRITE_SIZE passes, profiles/)
     traffic, traffic_src, traffic_detail = recorded_traffic(name)
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -487,7 +526,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                     launches_per_step=nl / prof_steps, avg_launch_ms=avg_ms,
                     algorithmic=f"{mfma_flops_per_cell(is3d):.0f} direct-convolution FLOP/cell in the MFMA conv launches x {cells} cells per step")
     else:
-        roof = jacobi_roofline(name, w, cells, prof_steps, times["jacobi"], traffic, traffic_src, traffic_detail)
+        roof = jacobi_roofline(name, w, cells, prof_steps, times["jacobi"], traffic, traffic_src, traffic_detail, replay_ms)
     if w["method"] == "jacobi":
         step_bytes = STEP_BYTES[is3d](w["iters"]) * cells
     else:
@@ -752,7 +791,8 @@ def _roof(rf, long=False):
         e.update(achieved_model=_r(rf["achieved"], 5), frac_model=_r(rf["frac"]), traffic=rf.get("traffic"), frac_compulsory=_r(rf.get("frac_compulsory")))
     if long:
         e.update(traffic_source=pmc_source(rf.get("traffic_source")) if rf.get("traffic") else None,
-                 launches_per_step=_r(rf.get("launches_per_step")), avg_launch_ms=_r(rf.get("avg_launch_ms")), algorithmic=rf.get("algorithmic"))
+                 launches_per_step=_r(rf.get("launches_per_step")), avg_launch_ms=_r(rf.get("avg_launch_ms")),
+                 avg_launch_ms_each=_r(rf.get("avg_launch_ms_each")), algorithmic=rf.get("algorithmic"))
     return e
 
 

@@ -869,7 +869,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("normalize_threshold") = 1e-5, NoGil());
   m.def("device_name", []() { const char* n = fnx_device_name(); return std::string(n ? n : ""); });
   m.def("abi_version", &fnx_abi_version);
-  m.def("profile_enable", [](bool on) { fnx_profile_enable(on ? 1 : 0); });
+  m.def("profile_enable", [](bool on, bool runs) { fnx_profile_enable(on ? (runs ? 2 : 1) : 0); }, py::arg("on"), py::arg("runs") = false);
   m.def("roctx_enable", [](bool on) { check_status(fnx_roctx_enable(on ? 1 : 0)); });
   m.def("profile_read_work", [](int tag) { double w = 0; fnx_profile_read_work(tag, &w); return w; });
   m.def("profile_read", [](int tag) { double ms = 0; int n = 0; fnx_profile_read(tag, &ms, &n); return std::make_pair(ms, n); });

@@ -119,9 +119,12 @@ namespace {
 constexpr int PROF_MAX = 16384;
 struct Prof {
   bool on = false;
+  bool runs = false;               // fnx_profile_enable(2): ONE event pair around a run of consecutive launches of a class on a stream
   int n = 0;
   hipEvent_t ev[PROF_MAX][2];
   int tag[PROF_MAX];
+  int count[PROF_MAX];             // launches between the pair
+  hipStream_t stream[PROF_MAX];
   int created = 0;
   int open_idx[FNX_PROF_NTAGS];
   double work[FNX_PROF_NTAGS];     // what the recorded launches of a class issued (MFMA FLOPs for the conv classes)
@@ -141,12 +144,21 @@ bool prof_begin(int tag, hipStream_t s) {
   const bool pushed = g_roctx.on.load(std::memory_order_acquire);
   if (pushed) g_roctx.push(kProfNames[tag]);
   if (!g_prof.on || g_prof.n >= PROF_MAX) { if (g_prof.on) g_prof.open_idx[tag] = -1; return pushed; }
+  if (g_prof.runs && g_prof.n > 0 && g_prof.tag[g_prof.n - 1] == tag && g_prof.stream[g_prof.n - 1] == s) {
+    // the launch before this one on the stream was of the same class: extend its pair (prof_end records the end event again) -- events between
+    // back-to-back launches keep the next kernel from starting behind the one before it, and each then reads 3-5 % long
+    g_prof.open_idx[tag] = g_prof.n - 1;
+    ++g_prof.count[g_prof.n - 1];
+    return pushed;
+  }
   const int i = g_prof.n++;
   if (i >= g_prof.created) {
     hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]);
     g_prof.created = i + 1;
   }
   g_prof.tag[i] = tag;
+  g_prof.count[i] = 1;
+  g_prof.stream[i] = s;
   g_prof.open_idx[tag] = i;
   hipEventRecord(g_prof.ev[i][0], s);
   return pushed;
@@ -168,6 +180,7 @@ extern "C" {
 
 int fnx_profile_enable(int on) {
   fnx::g_prof.on = on != 0;
+  fnx::g_prof.runs = on == 2;
   if (on) { fnx::g_prof.n = 0; for (int t = 0; t < FNX_PROF_NTAGS; ++t) { fnx::g_prof.open_idx[t] = -1; fnx::g_prof.work[t] = 0.0; } }
   return FNX_OK;
 }
@@ -201,7 +214,7 @@ int fnx_profile_read(int tag, double* total_ms, int* launches) {
     if (fnx::g_prof.tag[i] != tag) continue;
     if (hipEventSynchronize(fnx::g_prof.ev[i][1]) != hipSuccess) continue;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, fnx::g_prof.ev[i][0], fnx::g_prof.ev[i][1]) == hipSuccess) { tot += ms; ++cnt; }
+    if (hipEventElapsedTime(&ms, fnx::g_prof.ev[i][0], fnx::g_prof.ev[i][1]) == hipSuccess) { tot += ms; cnt += fnx::g_prof.count[i]; }
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = cnt;

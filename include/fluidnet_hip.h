@@ -549,7 +549,11 @@ int fnx_fluidnet_forward(const FnxGrid* g, const void* packed, const float* inpu
 /* Optional timing of the dominant kernels with HIP events on the launch stream (used by bench.py for the roofline
  * figures).  While enabled, every launch of the tagged kernel class is bracketed by an event pair (up to 16384 pairs,
  * later launches are not recorded).  fnx_profile_read synchronises the recorded events and returns the summed
- * kernel time and the number of launches of that class; fnx_profile_enable(1) also clears earlier records. */
+ * kernel time and the number of launches of that class; fnx_profile_enable(1) also clears earlier records.
+ * fnx_profile_enable(2) (round 6): ONE pair around each RUN of consecutive launches of a class on a stream (the 50 passes of a
+ * Jacobi-100 solve, the consecutive Winograd layers of a tower) -- the launches then run back to back as they do in a step; a pair
+ * per launch holds each kernel until the one before it has drained and reads 3-10 % long (rocprofv3's per-kernel durations of a
+ * replayed step agree with the run figure: profiles/r06/c_wino4_versions.txt, tools/debug/trace_step_span.sh). */
 enum { FNX_PROF_JACOBI = 0, FNX_PROF_CONV_MFMA = 1, FNX_PROF_ADVECT = 2, FNX_PROF_STAGE = 3, FNX_PROF_CONV_DIRECT = 4,
        FNX_PROF_CONV_MFMA16 = 5, FNX_PROF_CONV_BF16 = 6 /* FNX_PRECISION_BF16X6 launches; work = bf16 MFMA FLOPs issued */, FNX_PROF_NTAGS = 7 };
 int fnx_profile_enable(int on);
