@@ -1325,9 +1325,8 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
-    // F(4x4): the default of 3D nets (256^3 step 92.2 -> 86.3 ms); in 2D only by name -- the 1024^2 step measures 0.3-0.5 % SLOWER with it
-    // (2.292 against 2.285 ms replayed, 2.279 against 2.265 eager) although the six launches alone are 4 % shorter under rocprofv3
-    if ((mode == FNX_PRECISION_FP32_F4 || (mode == FNX_PRECISION_FP32 && is3d)) && wino4_layer_(L, is3d) &&
+    // F(4x4): the default (256^3 step 92.2 -> 84.9 ms; 1024^2 step 2.292 -> 2.252 ms, replayed graphs, three alternating runs)
+    if ((mode == FNX_PRECISION_FP32_F4 || mode == FNX_PRECISION_FP32) && wino4_layer_(L, is3d) &&
         launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), is3d, s)) {
       prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 2.25 * (is3d ? 3 : 1));  // 36 multiplies per 4x4 outputs (per z tap)
       return;

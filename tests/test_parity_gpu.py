@@ -587,7 +587,7 @@ def test_cnn_f4_vs_oracle(dev, oracle, shape):
     """FNX_PRECISION_FP32_F4: the 64- / 128-output-channel 3x3 layers of a 2D net in the Winograd F(4x4,3x3) domain (conv3_wino4_kernel,
     v_mfma_f32_16x16x4_f32; every other layer as in 'fp32') against the oracle at the modes' common tolerance 1e-5 |ref|max: partial
     tiles in x and y, odd sizes, batch, the benchmark size, and 3D nets (F(4x4) in (y, x), the three z taps as stages; boundary planes skip a tap).
-    Since round 6 this is what the default mode 'fp32' runs for 3D nets; 'fp32_f2' keeps F(2x2) everywhere (the 2D default)."""
+    Since round 6 this is what the default mode 'fp32' runs; 'fp32_f2' keeps F(2x2) everywhere."""
     from fluidnet_cxx_amd import FluidNet
     from fluidnet_cxx_amd.weights import make_scalenet_weights
     B, D, H, W = shape
@@ -610,8 +610,8 @@ def test_cnn_f4_vs_oracle(dev, oracle, shape):
     if H * W <= 600 * 600:
         want = oracle.multiscale_forward(oracle.pack_weights(w, 2), x)
         assert_close_rel(got, want, 1e-5, "MultiScaleNet, F(4x4) layers")
+        assert_bitexact(got, N(FluidNet.from_weights(mconf, w, dev).multiScale(T(x[:, :, 0], dev))).reshape(B, 1, D, H, W), "the default mode IS fp32_f4")
         ref32 = FluidNet.from_weights(dict(mconf, precisionMode="fp32_f2"), w, dev)
-        assert_bitexact(N(ref32.multiScale(T(x[:, :, 0], dev))), N(FluidNet.from_weights(mconf, w, dev).multiScale(T(x[:, :, 0], dev))), "2D: the default mode is fp32_f2")
         assert not np.array_equal(got, N(ref32.multiScale(T(x[:, :, 0], dev))).reshape(B, 1, D, H, W)), "2D: the F(4x4) kernel did not run"
     else:
         # benchmark size: against the F(2x2) mode, both within 1e-5 of the oracle (test_cnn_benchmark_size pins the default at this size)
