@@ -27,12 +27,16 @@
 //
 // Numerics: the transforms are not exact in binary (G has 1/6, 1/24; B^T and A^T multiply by 2, 4, 5, 8): measured 2x the error of
 // F(2x2) against an fp64 evaluation of the net, 0.07 of the tests' 1e-5 |ref|max (tools/wino_f4_error_probe.py).
+#ifndef W4_V16
+#define W4_V16 1
+#endif
 #ifndef W4_NT
 #define W4_NT 2         // cache policy: 1 = halo-tile DMA non-temporal (measured 5 % slower), 2 = output stores non-temporal (3 % faster)
 #endif
 constexpr int W4C = 4;                       // input channels per stage
-constexpr int W4_RAW = 4 * 18 * 34;          // 2448 floats of a stage's halo tile
-constexpr int W4_RAWP = 2560;                // padded to 5 DMA instructions of 512 lanes
+constexpr int W4_RAW = 4 * 18 * 34;          // 2448 floats of a stage's halo tile (4 bytes per lane: any W)
+constexpr int W4_RAW16 = 4 * 18 * 10;        // 720 pieces of 16 bytes: rows of 40 floats, columns x0 - 4 .. x0 + 35 (W % 4 == 0)
+constexpr int W4_RAWP = 3072;                // floats per buffer: 8 + 4 DMA instructions of 1 KiB (V16) / 5 of 256 B per wave
 constexpr int W4_TP = 37;                    // tmp pitch per patch (odd: conflict-free row reads)
 constexpr int W4_GST = 9 * 4 * 4 * 16;       // 2304 floats of a stage's taps
 
@@ -84,7 +88,9 @@ template <int N> struct AIC4 { static constexpr int value = N; };
 
 // IS3D: F(4x4) in (y, x), the three z taps as three times the stages (input plane z + dz - 1, the taps image of dz; a tap whose plane is
 // outside the grid is skipped: zero padding)
-template <bool IS3D>
+// V16: the halo tile as 16-byte pieces (W % 4 == 0: a piece is inside the image or outside it) -- 12 DMA instructions per stage instead
+// of 40 (each costs its wave an M0 write, a wait state and the issue)
+template <bool IS3D, bool V16>
 __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const float* __restrict__ wt, int ntx, int nty) {
   __shared__ __attribute__((aligned(16))) float raw0[W4_RAWP];
   __shared__ __attribute__((aligned(16))) float raw1[W4_RAWP];
@@ -107,16 +113,18 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   const int nchunk = (dz_hi - dz_lo) * nch;                 // stages: (z tap, four input channels), z tap slowest
   const int x0 = tx * 32, y0 = ty * 16;
 
-  // ---- halo-tile DMA: slot idx = q * 512 + tid of the [4][18][34] tile; out of the image (or beyond the tile) -> an offset the range
-  // check refuses (zeros land in LDS)
-  unsigned uoff[5];
+  // ---- halo-tile DMA: slot idx = q * 512 + tid of the [4][18][34] tile (V16: piece idx of the [4][18][10] tile, q = 1 is waves 0-3's);
+  // out of the image (or beyond the tile) -> an offset the range check refuses (zeros land in LDS)
+  constexpr int NQ = V16 ? 2 : 5, RP = V16 ? 40 : 34, CO = V16 ? 3 : 0;     // DMA instructions per wave, row pitch, column of x0 - 1
+  unsigned uoff[NQ];
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int idx = q * 512 + tid;
-    const int c = idx / (18 * 34), rem = idx - c * (18 * 34);
-    const int row = rem / 34, col = rem - row * 34;
-    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-    const bool ok = (idx < W4_RAW) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+    const int rowlen = V16 ? 10 : 34;
+    const int c = idx / (18 * rowlen), rem = idx - c * (18 * rowlen);
+    const int row = rem / rowlen, col = rem - row * rowlen;
+    const int gy = y0 - 1 + row, gx = V16 ? x0 - 4 + 4 * col : x0 - 1 + col;
+    const bool ok = (idx < (V16 ? W4_RAW16 : W4_RAW)) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
     uoff[q] = ok ? (unsigned)(((size_t)c * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
   }
   const float* xb = a.x + (size_t)b * a.cin * vol;
@@ -132,14 +140,19 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     (void)chunk;
     const BufRsrcC r = make_rsrc_c(raw_src, stage_bytes);
     if (IS3D && raw_c + 1 == nch) { raw_src += raw_wrap; raw_c = 0; } else { raw_src += raw_step; ++raw_c; }
+    if (V16) {
+      dma16_to_lds(r, (LdsF)&rawdst[0] + wave * 256, uoff[0], 0);
+      if (wave < 4) dma16_to_lds(r, (LdsF)&rawdst[0] + 2048 + wave * 256, uoff[NQ - 1], 0);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      if (W4_NT & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)((LdsF)&rawdst[0] + q * 512 + wave * 64), 4, uoff[q], 0, 0, 2);
-      else dma4_to_lds(r, (LdsF)&rawdst[0] + q * 512 + wave * 64, uoff[q]);
+      for (int q = 0; q < NQ; ++q) dma4_to_lds(r, (LdsF)&rawdst[0] + q * 512 + wave * 64, uoff[q]);
     }
   };
+  unsigned w_next = (unsigned)(((size_t)(dz_lo * nch) * ngrp + grp) * W4_GST * 4);   // (requested in order, like the halo tiles)
   auto fetch_w = [&](int chunk, float (&wdst)[W4_GST]) __attribute__((always_inline)) {
-    const unsigned sb = (unsigned)(((size_t)(dz_lo * nch + chunk) * ngrp + grp) * W4_GST * 4);
+    (void)chunk;
+    const unsigned sb = w_next;
+    w_next += (unsigned)(ngrp * W4_GST * 4);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                       // 9 instructions of 1 KiB: waves 0-7, then wave 0 again
       const int wi = wave + 8 * q;
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     {
       const int patch = u / 6, j = u - patch * 6;
       const int c = patch >> 5, n = patch & 31, bx = n & 7, by = n >> 3;
-      p1_rd[h] = (c * 18 + 4 * by) * 34 + 4 * bx + j;
+      p1_rd[h] = (c * 18 + 4 * by) * RP + 4 * bx + j + CO;
       p1_wr[h] = patch * W4_TP + j;
     }
     {
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   float pd[6];
   auto p1_load = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pd[i] = rawsrc[p1_rd[0] + i * 34];
+    for (int i = 0; i < 6; ++i) pd[i] = rawsrc[p1_rd[0] + i * RP];
   };
   auto p1_store = [&](const float (&rawsrc)[W4_RAWP]) __attribute__((always_inline)) {
     float tt[6];
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     if (IS3D ? tid < 256 : wave < 4) {
       float d[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = rawsrc[p1_rd[1] + i * 34];
+      for (int i = 0; i < 6; ++i) d[i] = rawsrc[p1_rd[1] + i * RP];
       w4_bt(d, tt);
 #pragma unroll
       for (int i = 0; i < 6; ++i) tmp[p1_wr[1] + i * 6] = tt[i];
@@ -359,7 +372,8 @@ bool launch_conv_wino4(const ConvArgs& a, const float* wt4, bool is3d, hipStream
   const int ntx = (a.W + 31) / 32, nty = (a.H + 15) / 16;
   const long nt = (long)ntx * nty * a.D * a.B * (a.cout / 64);
   if (nt < 256 || nt > 0x7fffffffl) return false;        // a launch that does not fill the chip stays on the F(2x2) / direct kernels
-  if (is3d) conv3_wino4_kernel<true><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty);
-  else conv3_wino4_kernel<false><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty);
+  const bool v16 = (a.W & 3) == 0 && W4_V16;
+  if (is3d) { if (v16) conv3_wino4_kernel<true, true><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); else conv3_wino4_kernel<true, false><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); }
+  else { if (v16) conv3_wino4_kernel<false, true><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); else conv3_wino4_kernel<false, false><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); }
   return true;
 }
