@@ -28,7 +28,7 @@ At N = 1 the same JSON line carries the other configurations the metric and the 
 `config.metric_2d` in the printed line holds the metric's 2D configuration (1024^2 CNN) with its own roofline block and CPU baseline;
 `config.dropin` the reference's own call pattern beside the tuned figure, per configuration: [tuned ms, `simulate(mconf, batch_dict,
 net, method)` with four arguments and eager launches (plume.py:237), the same step operator by operator (`fused=False`)].
-Other names for --workload: plume3d_128_cnn, plume2d_1024_cnn_f4 (opt-in F(4x4) Winograd in 2D), plume3d_256_cnn_f2 (F(2x2) everywhere).
+Other names for --workload: plume3d_128_cnn, plume2d_1024_cnn_f2 / plume3d_256_cnn_f2 (F(2x2) Winograd everywhere: the default of rounds 2-5).
 
 State.  Every workload is first advanced by >= 100 untimed steps (`config.developed_steps`) so that a plume exists
 (advection cost is data dependent: zero-velocity cells leave the line trace at once); the CNN workloads are developed with
@@ -109,9 +109,9 @@ WORKLOADS = {
     # `simulate(..., 'convnet')` on the whole batch under no_grad; a step here is one such call on 32 samples
     "plume2d_128_b32_cnn": dict(res=128, D=1, method="convnet", iters=0, kind="plume", batch=32),
     "plume2d_128_b32_jacobi": dict(res=128, D=1, method="jacobi", iters=28, kind="plume", batch=32),   # configs[0]'s step on 32 samples: the lever a 36-us step has
-    # round 6, Winograd F(4x4,3x3) for the 64/128-output-channel 3x3(x3) layers: the default of 3D nets (..._cnn_f2: F(2x2) everywhere, the
-    # default of rounds 2-5, for comparison); opt-in for 2D nets (FNX_PRECISION_FP32_F4: no gain on the 1024^2 step)
-    "plume2d_1024_cnn_f4": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="fp32_f4"),
+    # round 6: Winograd F(4x4,3x3) for the 64/128-output-channel 3x3(x3) layers is the default; ..._cnn_f2: F(2x2) everywhere (the default of
+    # rounds 2-5) for comparison
+    "plume2d_1024_cnn_f2": dict(res=1024, D=1, method="convnet", iters=0, kind="plume", precision="fp32_f2"),
     "plume3d_256_cnn_f2": dict(res=256, D=256, method="convnet", iters=0, kind="plume", precision="fp32_f2"),
     # OPT-IN precision mode, never the headline: the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32
     # product (FNX_PRECISION_BF16X6; same 1e-5 |ref|max tolerance against the oracle as the exact-fp32 modes, tests/)
@@ -498,7 +498,7 @@ def run_workload(name, steps, warmup, use_graph, world, rank, dev, schedule="dee
                  (" in x,y, the three z taps in the contraction" if is3d else "") + ": 16 multiplies per 4 outputs "
                  "instead of 36, v_mfma_f32_32x32x2_f32); achieved/frac count DIRECT-convolution FLOPs and can exceed the "
                  "MFMA peak, mfma_util counts the FLOPs actually issued to the matrix cores")
-        if w.get("precision", "fp32") == "fp32_f4" or (is3d and w.get("precision", "fp32") == "fp32"):
+        if w.get("precision", "fp32") in ("fp32", "fp32_f4"):
             t3 = "true" if is3d else "false"
             kname = (f"conv3_wino4_kernel<{t3}> (round 6: the 64/128-output-channel 3x3{'x3' if is3d else ''} layers whose launch fills the chip -- 6 of the 10 MFMA launches of a "
                      "forward, 0.9 of their time -- in the Winograd F(4x4,3x3) domain" + (" in (y, x), the three z taps as stages" if is3d else "") + ": 36 multiplies per 16 "

@@ -34,5 +34,5 @@ for f in sorted(glob.glob(os.path.join(src, f"pmc_{tag}", "*_pmc_summary.txt")))
     cp(f, os.path.join(dst, "pmc", f"{pre}_{os.path.basename(f)}"))
 cp(os.path.join(src, f"pmc_{tag}", "advect3d_sq_counters.txt"), os.path.join(dst, "pmc", f"{pre}_advect3d_sq_counters.txt"))
 for name in ["pytest_gpu.log", "link_model.txt", "peer_probe.txt", "advect_ab.txt", "wino4_per_layer_trace.txt",
-             "bench_rehearsal_8_ranks_one_gpu.json"]:
+             "bench_rehearsal_8_ranks_one_gpu.json", "long_parity.txt", "step_span.txt"]:
     cp(os.path.join(src, f"{tag}_{name}"), os.path.join(dst, f"{pre}_{name}"))

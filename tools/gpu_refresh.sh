@@ -10,7 +10,7 @@ timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/prof_$tag/bench_
 grep "^{\"metric\"" gpurun_out/prof_$tag/bench_default.log | tail -1 > gpurun_out/prof_$tag/bench_default.json
 cp gpurun_out/bench_detail.json gpurun_out/prof_$tag/bench_detail.json
 timeout 300 tools/gpu_profile.sh $tag plume3d_slab_jacobi --steps 20 --warmup 3 --no-native
-for w in plume3d_256_jacobi plume2d_1024_cnn plume2d_1024_jacobi rt2d_2048_jacobi plume2d_128_jacobi plume2d_128_b32_cnn plume2d_128_b32_jacobi plume2d_1024_cnn_bf16x6 plume2d_1024_cnn_f4; do
+for w in plume3d_256_jacobi plume2d_1024_cnn plume2d_1024_jacobi rt2d_2048_jacobi plume2d_128_jacobi plume2d_128_b32_cnn plume2d_128_b32_jacobi plume2d_1024_cnn_bf16x6 plume2d_1024_cnn_f2; do
   timeout 300 tools/gpu_profile.sh $tag $w --steps 20 --warmup 3
 done
 for w in plume3d_256_cnn plume3d_hbm_jacobi plume3d_256_cnn_bf16x6 plume3d_256_cnn_f2; do

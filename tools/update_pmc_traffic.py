@@ -15,8 +15,8 @@ PICK = {   # workload -> substrings of the kernel names whose launches are avera
     "plume3d_hbm_jacobi": ["jacobi3d_march2_kernel<false, false, 3"],
     "rt2d_2048_jacobi": ["jacobi2d_wg_kernel<8, 8>"],
     "plume2d_1024_jacobi": ["jacobi2d_wg_kernel<8, 8>"],
-    "plume2d_1024_cnn": ["conv3_wino3_kernel<2, 2, false>", "conv3_wino3_kernel<1, 2, false>"],
-    "plume3d_256_cnn": ["conv3_wino4_kernel<true>", "conv3_wino3_kernel<2, 2, true>", "conv3_wino3_kernel<1, 2, true>"],
+    "plume2d_1024_cnn": ["conv3_wino4_kernel<false", "conv3_wino3_kernel<2, 2, false>", "conv3_wino3_kernel<1, 2, false>"],
+    "plume3d_256_cnn": ["conv3_wino4_kernel<true", "conv3_wino3_kernel<2, 2, true>", "conv3_wino3_kernel<1, 2, true>"],
 }
 
 
