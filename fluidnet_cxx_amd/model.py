@@ -48,8 +48,8 @@ class MultiScaleNet:
         # "fp32_direct": every convolution a direct sum over its taps (include/fluidnet_hip.h: FNX_PRECISION_*)
         # "bf16x6" (opt-in): the 64/128-output-channel Winograd layers as six bf16 MFMA products per fp32 product
         # "bf16x3" (opt-in): the same layers with the three products without a low piece (tolerance 1e-4 |ref|max)
-        # "fp32_f4": the 64/128-output-channel 3x3(x3) layers in the Winograd F(4x4,3x3) domain, exact-fp32 MFMAs -- what "fp32" runs for
-        # 3D nets since round 6 (in 2D by this name only); "fp32_f2": F(2x2) for every Winograd layer, the default of rounds 2-5
+        # "fp32_f4": the 64/128-output-channel 3x3(x3) layers in the Winograd F(4x4,3x3) domain, exact-fp32 MFMAs -- what "fp32" runs since
+        # round 6; "fp32_f2": F(2x2) for every Winograd layer, the default of rounds 2-5
         self.precision_mode = precision_mode
         blob = torch.from_numpy(blob_from_state_dict(state_dict, 3 if is3D else 2)).to(device)
         self.packed = ext.scalenet_pack(blob, self.is3D)

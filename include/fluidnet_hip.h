@@ -507,7 +507,7 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
 /* precision_mode of the CNN entry points (and FnxStepParams.precision_mode).  The first two are exact-fp32 arithmetic on
  * v_mfma_f32_*_f32; the last two are opt-in and carry their own labels in every report (bench.py never puts them in the headline):
  *   FNX_PRECISION_FP32         the default: 3x3(x3) layers of launches that fill the chip run in the Winograd domain -- F(2x2,3x3)
- *                              (2.25x fewer multiplies) and, since round 6 in 3D nets, F(4x4,3x3) in (y, x) (4x fewer) for the 64- and
+ *                              (2.25x fewer multiplies) and, since round 6, F(4x4,3x3) in (y, x) (4x fewer) for the 64- and
  *                              128-output-channel layers; not the summation order of a direct convolution; within 1e-5 |ref|max of the
  *                              torch reference (tests/test_parity_gpu.py)
  *   FNX_PRECISION_FP32_DIRECT  every convolution as a direct sum over its taps (implicit GEMM), no Winograd
@@ -525,9 +525,9 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
  *   FNX_PRECISION_FP32_F4      (round 6) the 64- and 128-output-channel 3x3(x3) layers in the Winograd F(4x4,3x3) domain (conv3_wino4_kernel: 36
  *                              multiplies per 16 outputs instead of F(2x2)'s 64; 3D: in (y, x), the z taps as stages): exact-fp32 MFMAs,
  *                              the transforms round more (multipliers 4, 5, 8, 1/6, 1/24) -- measured 2x F(2x2)'s error, 0.07 of the
- *                              tests' 1e-5 |ref|max.  What FNX_PRECISION_FP32 runs for 3D nets (256^3 step 6 % faster); in 2D by this
- *                              name only (1024^2 step: no gain)
- *   FNX_PRECISION_FP32_F2      F(2x2,3x3) for every Winograd layer: the default of rounds 2-5 (kept for A/B timing of 3D nets) */
+ *                              tests' 1e-5 |ref|max.  What FNX_PRECISION_FP32 runs since round 6 (256^3 CNN step 92.2 -> 82.4 ms,
+ *                              1024^2 2.29 -> 2.25 ms)
+ *   FNX_PRECISION_FP32_F2      F(2x2,3x3) for every Winograd layer: the default of rounds 2-5 (kept for A/B timing) */
 enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2, FNX_PRECISION_BF16X3 = 3, FNX_PRECISION_FP32_F4 = 4,
        FNX_PRECISION_FP32_F2 = 5 };
 /* x: (B,2,D,H,W) [div/s, occupancy] -> p (B,1,D,H,W) */
