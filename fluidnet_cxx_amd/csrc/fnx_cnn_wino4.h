@@ -289,19 +289,26 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!(W4_ABL & 4) && (KIND == 0 || (KIND == 3 && s + 2 < nchunk))) { fetch_raw(s + 2, rawF); fetch_w(s + 2, gF); }
-    const bool nxt = !(W4_ABL & 2) && (KIND < 2 || (KIND == 3 && s + 1 < nchunk));
+    constexpr bool nxt = !(W4_ABL & 2) && (KIND < 2 || KIND == 3);
     constexpr bool mm = !(W4_ABL & 1);
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0)
     if (mm) { op_load(0, xtC); g_xform(AIC4<0>{}); }
+    W4_FENCE;
     if (nxt) p1_load(rawN);
+    W4_FENCE;
     if (mm) { op_load(1, xtC); mfma9(0); }
     if (nxt) p1_store(rawN);
+    W4_FENCE;
     if (mm) { op_load(2, xtC); mfma9(1); }
     __syncthreads();
     if (nxt) p2_load();
+    W4_FENCE;
     if (mm) { g_xform(AIC4<1>{}); op_load(3, xtC); mfma9(2); }
     if (nxt) p2_store(xtN);
+    W4_FENCE;
     if (mm) mfma9(3);
-    if (KIND < 2 || (KIND == 3 && s + 1 < nchunk)) g_load(gN);
+#undef W4_FENCE
+    if (KIND < 2 || KIND == 3) g_load(gN);
   };
   // prologue: tiles 0 and 1 and the taps of stages 0 and 1 in flight; tile 0 transformed into xt0; the taps of stage 0 in registers
   fetch_raw(0, raw0); fetch_w(0, gw0);
