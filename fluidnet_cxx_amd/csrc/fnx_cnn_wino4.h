@@ -30,7 +30,7 @@
 #define W4_V16 1
 #endif
 #ifndef W4_NT
-#define W4_NT 2         // cache policy: 1 = halo-tile DMA non-temporal (measured 5 % slower), 2 = output stores non-temporal (3 % faster)
+#define W4_NT 2         // cache policy: 2 = output stores non-temporal (3 % faster; non-temporal halo DMA measured 5 % slower: removed)
 #endif
 constexpr int W4C = 4;                       // input channels per stage
 constexpr int W4_RAW = 4 * 18 * 34;          // 2448 floats of a stage's halo tile (4 bytes per lane: any W)
@@ -279,22 +279,26 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   // came from: receives the taps of stage s + 2.
   //   B1   everybody's DMA of the previous top has landed; xtC is complete; nobody reads rawF, xtN, tmp, gF any more
   //   DMA  halo tile s + 2 -> rawF, taps s + 2 -> gF
-  //   G g G^T rows 0-2 in registers; nine MFMAs x 2 with pass 1 of stage s + 1 (rawN -> tmp) between them;  B2 (tmp complete);
-  //   G g G^T rows 3-5; nine MFMAs x 2 with pass 2 of stage s + 1 (tmp -> xtN) between them; the taps of stage s + 1 into registers
-  // (KIND 0: a stage of the loop -- two more stages follow: no conditions in it; 1: the last but one; 2: the last; 3: any stage, the
-  //  conditions at run time -- the 3D instantiation: the peeled form measured 3.6 % SLOWER there and 1.5 % faster in 2D)
+  //   operands of the first nine MFMAs and the loads of pass 1 of stage s + 1 (rawN); G g G^T rows 0-2 in registers while they fly;
+  //   nine MFMAs x 2 with the arithmetic and stores of pass 1 (-> tmp) between them;  B2 (tmp complete);  the loads of pass 2;
+  //   G g G^T rows 3-5; nine MFMAs x 2 with pass 2's arithmetic and stores (-> xtN) between them; the taps of stage s + 1 into registers
+  // The order is pinned with scheduling fences: left alone the compiler regroups the loads, transforms and MFMAs of the (branch-free)
+  // stage, and every variant of the order that was measured is within +-2 % of this one -- on whole replayed steps: this order with
+  // the fences 1024^2 2.250 -> 2.17 ms, 256^3 82.6 -> 81.5 ms (docs/history/r06_notes.md, versions 17-20).
+  // (KIND 0: a stage of the loop -- two more stages follow; 1: the last but one: no DMA request; 2: the last: no transforms either)
   auto stage = [&](auto ksel, int s, float (&rawN)[W4_RAWP], float (&rawF)[W4_RAWP], float (&xtC)[36 * 2 * 64], float (&xtN)[36 * 2 * 64],
                    float (&gN)[W4_GST], float (&gF)[W4_GST]) __attribute__((always_inline)) {
     constexpr int KIND = decltype(ksel)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!(W4_ABL & 4) && (KIND == 0 || (KIND == 3 && s + 2 < nchunk))) { fetch_raw(s + 2, rawF); fetch_w(s + 2, gF); }
-    constexpr bool nxt = !(W4_ABL & 2) && (KIND < 2 || KIND == 3);
+    if (!(W4_ABL & 4) && KIND == 0) { fetch_raw(s + 2, rawF); fetch_w(s + 2, gF); }
+    constexpr bool nxt = !(W4_ABL & 2) && KIND < 2;
     constexpr bool mm = !(W4_ABL & 1);
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0)
-    if (mm) { op_load(0, xtC); g_xform(AIC4<0>{}); }
-    W4_FENCE;
+    if (mm) op_load(0, xtC);
     if (nxt) p1_load(rawN);
+    W4_FENCE;
+    if (mm) g_xform(AIC4<0>{});
     W4_FENCE;
     if (mm) { op_load(1, xtC); mfma9(0); }
     if (nxt) p1_store(rawN);
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     W4_FENCE;
     if (mm) mfma9(3);
 #undef W4_FENCE
-    if (KIND < 2 || KIND == 3) g_load(gN);
+    if (KIND < 2) g_load(gN);
   };
   // prologue: tiles 0 and 1 and the taps of stages 0 and 1 in flight; tile 0 transformed into xt0; the taps of stage 0 in registers
   fetch_raw(0, raw0); fetch_w(0, gw0);
@@ -319,19 +323,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   g_load(gw0);
   __syncthreads();
   p2_load(); p2_store(xt0);
-  if (IS3D) {
-    for (int s = 0; s < nchunk; s += 2) {                    // (cin % 16 == 0: an even number of stages)
-      stage(AIC4<3>{}, s, raw1, raw0, xt0, xt1, gw1, gw0);
-      stage(AIC4<3>{}, s + 1, raw0, raw1, xt1, xt0, gw0, gw1);
-    }
-  } else {
-    for (int s = 0; s + 2 < nchunk; s += 2) {                // (at least four stages)
-      stage(AIC4<0>{}, s, raw1, raw0, xt0, xt1, gw1, gw0);
-      stage(AIC4<0>{}, s + 1, raw0, raw1, xt1, xt0, gw0, gw1);
-    }
-    stage(AIC4<1>{}, nchunk - 2, raw1, raw0, xt0, xt1, gw1, gw0);
-    stage(AIC4<2>{}, nchunk - 1, raw0, raw1, xt1, xt0, gw0, gw1);
+  for (int s = 0; s + 2 < nchunk; s += 2) {                  // (cin % 16 == 0: an even number of stages, at least four)
+    stage(AIC4<0>{}, s, raw1, raw0, xt0, xt1, gw1, gw0);
+    stage(AIC4<0>{}, s + 1, raw0, raw1, xt1, xt0, gw0, gw1);
   }
+  stage(AIC4<1>{}, nchunk - 2, raw1, raw0, xt0, xt1, gw1, gw0);
+  stage(AIC4<2>{}, nchunk - 1, raw0, raw1, xt1, xt0, gw0, gw1);
 
   // ---- epilogue: A^T M A per accumulator register (an output channel), bias, ReLU, 4 x 4 pixels per block
   const int n = ng * 16 + (lane & 15), bx = n & 7, by = n >> 3;
