@@ -296,13 +296,17 @@ def jacobi_replay_launch_ms(ext, bd, is3d, iters, launches_per_solve):
         for _ in range(2):
             g.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        best = None
+        for _ in range(3):                                   # (the least disturbed of three timings of `reps` replays)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            best = t if best is None or t < best else best
+        return best
     return (solve_ms(2 * iters) - solve_ms(iters)) / launches_per_solve
 
 

@@ -1,8 +1,9 @@
 // 3x3 convolution in the Winograd F(4x4, 3x3) domain, 2D, exact fp32 on v_mfma_f32_16x16x4_f32 (included by fnx_cnn.hip inside
 // namespace fnx, after its DMA helpers).  Round 6; FNX_PRECISION_FP32_F4 = what FNX_PRECISION_FP32 runs for the 64- / 128-output-channel
-// 3x3(x3) layers whose launch fills the chip (256^3 CNN step 92.2 -> 82.4 ms, 1024^2 2.292 -> 2.252 ms; FNX_PRECISION_FP32_F2 keeps them
-// on conv3_wino3_kernel).  docs/history/r06_notes.md section 3 has the sixteen versions that were measured and the cycle accounting (this
-// file is the third + versions 13-15: what paid was removing instructions from every wave's path, never reordering them).
+// 3x3(x3) layers whose launch fills the chip (256^3 CNN step 92.2 -> 81.0 ms, 1024^2 2.29 -> 2.17 ms; FNX_PRECISION_FP32_F2 keeps them
+// on conv3_wino3_kernel).  docs/history/r06_notes.md section 3 has the twenty versions that were measured and the cycle accounting (this
+// file is the third + versions 13-15 and 18-20: what paid was removing instructions from every wave's path and pinning the order of a
+// stage, never moving work between waves or phases).
 //
 //   Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A      d = 6x6 input patch of a 4x4 output block (Lavin & Gray, points 0, +-1, +-2, inf)
 //
