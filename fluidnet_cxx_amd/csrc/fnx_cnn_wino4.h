@@ -1,9 +1,9 @@
-// 3x3 convolution in the Winograd F(4x4, 3x3) domain, 2D, exact fp32 on v_mfma_f32_16x16x4_f32 (included by fnx_cnn.hip inside
+// 3x3(x3) convolution in the Winograd F(4x4, 3x3) domain in (y, x), exact fp32 on v_mfma_f32_16x16x4_f32 (included by fnx_cnn.hip inside
 // namespace fnx, after its DMA helpers).  Round 6; FNX_PRECISION_FP32_F4 = what FNX_PRECISION_FP32 runs for the 64- / 128-output-channel
-// 3x3(x3) layers whose launch fills the chip (256^3 CNN step 92.2 -> 81.0 ms, 1024^2 2.29 -> 2.17 ms; FNX_PRECISION_FP32_F2 keeps them
-// on conv3_wino3_kernel).  docs/history/r06_notes.md section 3 has the twenty versions that were measured and the cycle accounting (this
-// file is the third + versions 13-15 and 18-20: what paid was removing instructions from every wave's path and pinning the order of a
-// stage, never moving work between waves or phases).
+// 3x3(x3) layers whose launch fills the chip (256^3 CNN step 92.2 -> 81.0 ms, 1024^2 2.29 -> 2.14 ms; FNX_PRECISION_FP32_F2 keeps them
+// on conv3_wino3_kernel).  docs/history/r06_notes.md section 3 has the twenty-two versions that were measured and the cycle accounting:
+// what paid was removing instructions from every wave's path, pinning the order of a stage with scheduling fences and not draining the
+// pipeline between tiles -- never moving work between waves or phases.
 //
 //   Y = A^T [ sum_cin (G g G^T) . (B^T d B) ] A      d = 6x6 input patch of a 4x4 output block (Lavin & Gray, points 0, +-1, +-2, inf)
 //
@@ -14,21 +14,27 @@
 // output transform A^T M A runs on registers alone -- no exchange between waves (conv3_wino3_kernel splits its 16 positions over
 // two waves and swaps half of its outputs through LDS).  Workgroup = 8 waves = 64 output channels (4 groups of 16) x 32 blocks
 // (2 groups of 16) = a 32 x 16-pixel tile; the four channel groups share the tile's transformed input, the two block groups share
-// the stage's weights.  One workgroup per CU (113 KB of LDS, two waves per SIMD at 256 registers).
+// the stage's weights.  One PERSISTENT workgroup per CU (99 KB of LDS, two waves per SIMD at 256 registers) walks the tiles; the
+// stages of its tiles form one stream (the last two stages of a tile request and transform the first chunks of the next).
 //
 // Stage = 4 input channels:
-//   raw halo tile   4 x 18 x 34 floats, global -> LDS by DMA (buffer_load_dword ... lds; zeros outside the image), one stage ahead
-//   weights         the stage's nine taps per (output channel, k) pair, [9][4 groups][4 k][16] = 9 KB, global -> LDS by DMA three stages
-//                   ahead; G g G^T is formed IN REGISTERS, one pair per lane -- the lane that feeds it to the MFMA (90 VALU per stage
+//   raw halo tile   4 x 18 x 40 floats (16-byte DMA pieces; W % 4 != 0: 4 x 18 x 34 by dwords), global -> LDS by DMA (buffer_load ... lds;
+//                   zeros outside the image), two stages ahead
+//   weights         the stage's nine taps per (output channel, k) pair, [9][4 groups][4 k][16] = 9 KB, global -> LDS by DMA two stages
+//                   ahead; G g G^T is formed IN REGISTERS, one pair per lane -- the lane that feeds it to the MFMA (81 VALU per stage
 //                   and wave instead of a 36 KB stream per stage and workgroup through L2 and LDS)
 //   B^T d B         two passes through LDS, all threads: columns (raw -> tmp), barrier, rows (tmp -> xt [36][2 groups][4 k][16])
 //   36 MFMAs        per wave; A from registers, B ONE conflict-free ds_read_b32 (64 consecutive floats per wave)
-// Two barriers per stage; the transforms of stage s + 1 ride between the MFMA groups of stage s.  No persistent tile loop.
+// Two barriers per stage; the transforms of stage s + 1 ride between the MFMA groups of stage s.  3D: the z taps are three times the
+// stages (input plane z + dz - 1; a plane outside the grid is skipped).
 //
 // Numerics: the transforms are not exact in binary (G has 1/6, 1/24; B^T and A^T multiply by 2, 4, 5, 8): measured 2x the error of
 // F(2x2) against an fp64 evaluation of the net, 0.07 of the tests' 1e-5 |ref|max (tools/wino_f4_error_probe.py).
 #ifndef W4_V16
 #define W4_V16 1
+#endif
+#ifndef W4_NWG
+#define W4_NWG 256      // workgroups of a launch: one per CU (99 KB of LDS each)
 #endif
 #ifndef W4_NT
 #define W4_NT 2         // cache policy: 2 = output stores non-temporal (3 % faster; non-temporal halo DMA measured 5 % slower: removed)
@@ -89,9 +95,10 @@ template <int N> struct AIC4 { static constexpr int value = N; };
 // IS3D: F(4x4) in (y, x), the three z taps as three times the stages (input plane z + dz - 1, the taps image of dz; a tap whose plane is
 // outside the grid is skipped: zero padding)
 // V16: the halo tile as 16-byte pieces (W % 4 == 0: a piece is inside the image or outside it) -- 12 DMA instructions per stage instead
-// of 40 (each costs its wave an M0 write, a wait state and the issue)
+// of 40 (each costs its wave an M0 write, a wait state and the issue).  (The dword form, five offsets per lane instead of two, spills 15
+// registers to scratch since the stream runs across tiles: widths that are not a multiple of 4 only.)
 template <bool IS3D, bool V16>
-__global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const float* __restrict__ wt, int ntx, int nty) {
+__global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const float* __restrict__ wt, int ntx, int nty, int ntiles) {
   __shared__ __attribute__((aligned(16))) float raw0[W4_RAWP];
   __shared__ __attribute__((aligned(16))) float raw1[W4_RAWP];
   __shared__ __attribute__((aligned(16))) float tmp[128 * W4_TP];
@@ -103,41 +110,56 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   const int cg = wave & 3, ng = wave >> 2;
   const int ngrp = a.cout / 64, nch = a.cin / W4C;
   const size_t plane = (size_t)a.H * a.W, vol = plane * a.D;
-  int t = blockIdx.x;
-  const int tx = t % ntx; t /= ntx;
-  const int ty = t % nty; t /= nty;
-  int z = 0;
-  if (IS3D) { z = t % a.D; t /= a.D; }
-  const int grp = t % ngrp, b = t / ngrp;
-  const int dz_lo = IS3D && z == 0 ? 1 : 0, dz_hi = IS3D ? (z == a.D - 1 ? 2 : 3) : 1;
-  const int nchunk = (dz_hi - dz_lo) * nch;                 // stages: (z tap, four input channels), z tap slowest
-  const int x0 = tx * 32, y0 = ty * 16;
+  // PERSISTENT, ONE STREAM OF STAGES ACROSS TILES: a workgroup walks the tiles blockIdx.x, + gridDim.x, ...; the stages of all of them form
+  // one sequence -- stage g multiplies chunk g, transforms chunk g + 1 and requests chunk g + 2 whatever tile those belong to -- so only
+  // the first tile of a workgroup pays the prologue (DMA latency + two transform passes, ~4 us of the ~8 us a tile cost beside its stages);
+  // between two tiles there is the output transform of the one and the clearing of the accumulators.
+  struct Tile { int x0, y0, z, grp, b, dz_lo, nchunk; };
+  auto decode = [&](int tile) __attribute__((always_inline)) {
+    Tile T;
+    int t = tile;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    T.z = 0;
+    if (IS3D) { T.z = t % a.D; t /= a.D; }
+    T.grp = t % ngrp; T.b = t / ngrp;
+    T.dz_lo = IS3D && T.z == 0 ? 1 : 0;
+    const int dz_hi = IS3D ? (T.z == a.D - 1 ? 2 : 3) : 1;
+    T.nchunk = (dz_hi - T.dz_lo) * nch;                     // stages: (z tap, four input channels), z tap slowest
+    T.x0 = tx * 32; T.y0 = ty * 16;
+    return T;
+  };
 
-  // ---- halo-tile DMA: slot idx = q * 512 + tid of the [4][18][34] tile (V16: piece idx of the [4][18][10] tile, q = 1 is waves 0-3's);
-  // out of the image (or beyond the tile) -> an offset the range check refuses (zeros land in LDS)
+  // ---- the request iterator: the next chunk of the stream (tile f_tile, chunk f_c of it).  Halo-tile DMA: slot idx = q * 512 + tid of the
+  // [4][18][34] tile (V16: piece idx of the [4][18][10] tile, q = 1 is waves 0-3's); out of the image (or beyond the tile) -> an offset the
+  // range check refuses (zeros land in LDS)
   constexpr int NQ = V16 ? 2 : 5, RP = V16 ? 40 : 34, CO = V16 ? 3 : 0;     // DMA instructions per wave, row pitch, column of x0 - 1
-  unsigned uoff[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int idx = q * 512 + tid;
-    const int rowlen = V16 ? 10 : 34;
-    const int c = idx / (18 * rowlen), rem = idx - c * (18 * rowlen);
-    const int row = rem / rowlen, col = rem - row * rowlen;
-    const int gy = y0 - 1 + row, gx = V16 ? x0 - 4 + 4 * col : x0 - 1 + col;
-    const bool ok = (idx < (V16 ? W4_RAW16 : W4_RAW)) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
-    uoff[q] = ok ? (unsigned)(((size_t)c * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
-  }
-  const float* xb = a.x + (size_t)b * a.cin * vol;
   const unsigned stage_bytes = (unsigned)(((size_t)(W4C - 1) * vol + plane) * 4);
   const BufRsrcC wrs = make_rsrc_c(wt, 0x7ffffff0u);
   const unsigned wlane = (unsigned)(wave * 256 + lane * 4) * 4u;
-  // the stages' halo tiles are requested in order: the input pointer of the next request walks four channels per stage and, in 3D, from
-  // the last channel group of a z tap to the first of the next (30 scalar instructions of 64-bit address arithmetic per stage otherwise)
-  const float* raw_src = xb + (size_t)(IS3D ? z + dz_lo - 1 : 0) * plane;
   const ptrdiff_t raw_step = (ptrdiff_t)W4C * (ptrdiff_t)vol, raw_wrap = (ptrdiff_t)plane - (ptrdiff_t)(nch - 1) * raw_step;
-  int raw_c = 0;                                            // channel group of the next request
-  auto fetch_raw = [&](int chunk, float (&rawdst)[W4_RAWP]) __attribute__((always_inline)) {
-    (void)chunk;
+  int raw_c = 0;
+  unsigned uoff[NQ], w_next = 0;
+  const float* raw_src = a.x;
+  auto f_setup = [&](int f_tile) __attribute__((always_inline)) {     // the requests' state at chunk 0 of tile f_tile
+    const Tile T = decode(f_tile);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int idx = q * 512 + tid;
+      const int rowlen = V16 ? 10 : 34;
+      const int c = idx / (18 * rowlen), rem = idx - c * (18 * rowlen);
+      const int row = rem / rowlen, col = rem - row * rowlen;
+      const int gy = T.y0 - 1 + row, gx = V16 ? T.x0 - 4 + 4 * col : T.x0 - 1 + col;
+      const bool ok = (idx < (V16 ? W4_RAW16 : W4_RAW)) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+      uoff[q] = ok ? (unsigned)(((size_t)c * vol + (size_t)gy * a.W + gx) * 4) : 0xfffffff0u;
+    }
+    // the input pointer walks four channels per stage and, in 3D, from the last channel group of a z tap to the first of the next
+    raw_src = a.x + (size_t)T.b * a.cin * vol + (size_t)(IS3D ? T.z + T.dz_lo - 1 : 0) * plane;
+    raw_c = 0;
+    w_next = (unsigned)(((size_t)(T.dz_lo * nch) * ngrp + T.grp) * W4_GST * 4);
+  };
+  f_setup(blockIdx.x);
+  auto fetch_next = [&](float (&rawdst)[W4_RAWP], float (&wdst)[W4_GST]) __attribute__((always_inline)) {
     const BufRsrcC r = make_rsrc_c(raw_src, stage_bytes);
     if (IS3D && raw_c + 1 == nch) { raw_src += raw_wrap; raw_c = 0; } else { raw_src += raw_step; ++raw_c; }
     if (V16) {
@@ -147,10 +169,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
 #pragma unroll
       for (int q = 0; q < NQ; ++q) dma4_to_lds(r, (LdsF)&rawdst[0] + q * 512 + wave * 64, uoff[q]);
     }
-  };
-  unsigned w_next = (unsigned)(((size_t)(dz_lo * nch) * ngrp + grp) * W4_GST * 4);   // (requested in order, like the halo tiles)
-  auto fetch_w = [&](int chunk, float (&wdst)[W4_GST]) __attribute__((always_inline)) {
-    (void)chunk;
     const unsigned sb = w_next;
     w_next += (unsigned)(ngrp * W4_GST * 4);
 #pragma unroll
@@ -222,8 +240,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   };
 
   w4f4 acc[36];
-#pragma unroll
-  for (int p = 0; p < 36; ++p) acc[p] = (w4f4){0.f, 0.f, 0.f, 0.f};
   // 36 MFMAs per stage in four groups of nine positions; a group's operands are read ahead of the MFMAs of the group before (left to
   // itself the compiler reads two positions, waits for the LDS, issues two MFMAs).
   // A operands: G g G^T of this wave's (output channel, k) pairs -- one pair per lane, lane = k * 16 + cout % 16, exactly the lane that
@@ -286,16 +302,19 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
   // The order is pinned with scheduling fences: left alone the compiler regroups the loads, transforms and MFMAs of the (branch-free)
   // stage, and every variant of the order that was measured is within +-2 % of this one -- on whole replayed steps: this order with
   // the fences 1024^2 2.250 -> 2.17 ms, 256^3 82.6 -> 81.5 ms (docs/history/r06_notes.md, versions 17-20).
-  // (KIND 0: a stage of the loop -- two more stages follow; 1: the last but one: no DMA request; 2: the last: no transforms either)
-  auto stage = [&](auto ksel, int s, float (&rawN)[W4_RAWP], float (&rawF)[W4_RAWP], float (&xtC)[36 * 2 * 64], float (&xtN)[36 * 2 * 64],
+  // (KIND 0: a stage of a tile's loop: requests chunk s + 2 of the tile, no condition in it; 1: one of the tile's last two stages: requests
+  //  chunk 0 / 1 of the workgroup's NEXT tile if there is one.  The last stage of the workgroup's last tile transforms a stale tile and
+  //  reads stale taps: LDS only, nobody uses the results)
+  auto stage = [&](auto ksel, bool has_next, float (&rawN)[W4_RAWP], float (&rawF)[W4_RAWP], float (&xtC)[36 * 2 * 64], float (&xtN)[36 * 2 * 64],
                    float (&gN)[W4_GST], float (&gF)[W4_GST]) __attribute__((always_inline)) {
     constexpr int KIND = decltype(ksel)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!(W4_ABL & 4) && KIND == 0) { fetch_raw(s + 2, rawF); fetch_w(s + 2, gF); }
-    constexpr bool nxt = !(W4_ABL & 2) && KIND < 2;
+    if (!(W4_ABL & 4) && (KIND == 0 || has_next)) fetch_next(rawF, gF);
+    constexpr bool nxt = !(W4_ABL & 2);
     constexpr bool mm = !(W4_ABL & 1);
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0)
+    W4_FENCE;
     if (mm) op_load(0, xtC);
     if (nxt) p1_load(rawN);
     W4_FENCE;
@@ -313,23 +332,30 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
     W4_FENCE;
     if (mm) mfma9(3);
 #undef W4_FENCE
-    if (KIND < 2) g_load(gN);
+    g_load(gN);
   };
-  // prologue: tiles 0 and 1 and the taps of stages 0 and 1 in flight; tile 0 transformed into xt0; the taps of stage 0 in registers
-  fetch_raw(0, raw0); fetch_w(0, gw0);
-  if (nchunk > 1) { fetch_raw(1, raw1); fetch_w(1, gw1); }
+  // prologue (the workgroup's first tile only): chunks 0 and 1 in flight; tile 0 transformed into xt0; the taps of stage 0 in registers
+  fetch_next(raw0, gw0);
+  fetch_next(raw1, gw1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   p1_load(raw0); p1_store(raw0);
   g_load(gw0);
   __syncthreads();
   p2_load(); p2_store(xt0);
-  for (int s = 0; s + 2 < nchunk; s += 2) {                  // (cin % 16 == 0: an even number of stages, at least four)
-    stage(AIC4<0>{}, s, raw1, raw0, xt0, xt1, gw1, gw0);
-    stage(AIC4<0>{}, s + 1, raw0, raw1, xt1, xt0, gw0, gw1);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const Tile T = decode(tile);
+  const int x0 = T.x0, y0 = T.y0, z = T.z, grp = T.grp, b = T.b;
+#pragma unroll
+  for (int p = 0; p < 36; ++p) acc[p] = (w4f4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s + 2 < T.nchunk; s += 2) {                // (cin % 16 == 0: an even number of stages per tile, at least four)
+    stage(AIC4<0>{}, true, raw1, raw0, xt0, xt1, gw1, gw0);
+    stage(AIC4<0>{}, true, raw0, raw1, xt1, xt0, gw0, gw1);
   }
-  stage(AIC4<1>{}, nchunk - 2, raw1, raw0, xt0, xt1, gw1, gw0);
-  stage(AIC4<2>{}, nchunk - 1, raw0, raw1, xt1, xt0, gw0, gw1);
+  const bool has_next = tile + (int)gridDim.x < ntiles;
+  if (has_next) f_setup(tile + gridDim.x);                   // (this tile's last request went out two stages ago)
+  stage(AIC4<1>{}, has_next, raw1, raw0, xt0, xt1, gw1, gw0);
+  stage(AIC4<1>{}, has_next, raw0, raw1, xt1, xt0, gw0, gw1);
 
   // ---- epilogue: A^T M A per accumulator register (an output channel), bias, ReLU, 4 x 4 pixels per block
   const int n = ng * 16 + (lane & 15), bx = n & 7, by = n >> 3;
@@ -338,18 +364,18 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = grp * 64 + cg * 16 + 4 * (lane >> 4) + r;
-    float T[6][4];
+    float Tm[6][4];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      w4_at(acc[i * 6 + 0][r], acc[i * 6 + 1][r], acc[i * 6 + 2][r], acc[i * 6 + 3][r], acc[i * 6 + 4][r], acc[i * 6 + 5][r], T[i]);
+      w4_at(acc[i * 6 + 0][r], acc[i * 6 + 1][r], acc[i * 6 + 2][r], acc[i * 6 + 3][r], acc[i * 6 + 4][r], acc[i * 6 + 5][r], Tm[i]);
     const float bias = a.bias[co];
     float* yo = a.y + ((size_t)b * a.cout + co) * vol + (size_t)z * plane;
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {                     // output column bb of the block: A^T along i
       float y[4];
-      w4_at(T[0][bb], T[1][bb], T[2][bb], T[3][bb], T[4][bb], T[5][bb], y);
+      w4_at(Tm[0][bb], Tm[1][bb], Tm[2][bb], Tm[3][bb], Tm[4][bb], Tm[5][bb], y);
 #pragma unroll
-      for (int aa = 0; aa < 4; ++aa) T[aa][bb] = fmaxf(y[aa] + bias, lo);      // (reuse T[0..3][bb] for the outputs of row aa)
+      for (int aa = 0; aa < 4; ++aa) Tm[aa][bb] = fmaxf(y[aa] + bias, lo);      // (reuse Tm[0..3][bb] for the outputs of row aa)
     }
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) {
@@ -357,15 +383,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wino4_kernel(ConvArgs a, const f
       if (yy >= a.H) continue;
       float* row = yo + (size_t)yy * a.W + px;
       if (px + 3 < a.W && ((a.W & 3) == 0)) {
-        const w4f4 v = {T[aa][0], T[aa][1], T[aa][2], T[aa][3]};
+        const w4f4 v = {Tm[aa][0], Tm[aa][1], Tm[aa][2], Tm[aa][3]};
         if (W4_NT & 2) __builtin_nontemporal_store(v, (w4f4*)row); else *(w4f4*)row = v;
       }
       else {
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb)
-          if (px + bb < a.W) row[bb] = T[aa][bb];
+          if (px + bb < a.W) row[bb] = Tm[aa][bb];
       }
     }
+  }
   }
 }
 
@@ -377,7 +404,9 @@ bool launch_conv_wino4(const ConvArgs& a, const float* wt4, bool is3d, hipStream
   const long nt = (long)ntx * nty * a.D * a.B * (a.cout / 64);
   if (nt < 256 || nt > 0x7fffffffl) return false;        // a launch that does not fill the chip stays on the F(2x2) / direct kernels
   const bool v16 = (a.W & 3) == 0 && W4_V16;
-  if (is3d) { if (v16) conv3_wino4_kernel<true, true><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); else conv3_wino4_kernel<true, false><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); }
-  else { if (v16) conv3_wino4_kernel<false, true><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); else conv3_wino4_kernel<false, false><<<(unsigned)nt, 512, 0, s>>>(a, wt4, ntx, nty); }
+  const unsigned nwg = (unsigned)(nt < W4_NWG ? nt : W4_NWG);        // persistent: one workgroup per CU walks the tiles
+  const int nti = (int)nt;
+  if (is3d) { if (v16) conv3_wino4_kernel<true, true><<<nwg, 512, 0, s>>>(a, wt4, ntx, nty, nti); else conv3_wino4_kernel<true, false><<<nwg, 512, 0, s>>>(a, wt4, ntx, nty, nti); }
+  else { if (v16) conv3_wino4_kernel<false, true><<<nwg, 512, 0, s>>>(a, wt4, ntx, nty, nti); else conv3_wino4_kernel<false, false><<<nwg, 512, 0, s>>>(a, wt4, ntx, nty, nti); }
   return true;
 }
