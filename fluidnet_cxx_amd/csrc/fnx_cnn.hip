@@ -1325,7 +1325,7 @@ void launch_conv(const ConvLayer& L, bool is3d, int mode, const float* packed, c
   if (mfma_layer(L) && (size_t)MF_CHUNK * D * H * W * 4 < 0xf0000000ull) {
     ProfScope ps(FNX_PROF_CONV_MFMA, s);
     const double px = (double)B * D * H * W, mac = 2.0 * L.cin * L.cout;
-    // F(4x4): the default (256^3 CNN step 92.2 -> 81.0 ms; 1024^2 2.29 -> 2.17 ms: replayed graphs, alternating runs on one box)
+    // F(4x4): the default (256^3 CNN step 92.2 -> 81.0 ms; 1024^2 2.29 -> 2.14 ms: replayed graphs, alternating runs on one box)
     if ((mode == FNX_PRECISION_FP32_F4 || mode == FNX_PRECISION_FP32) && wino4_layer_(L, is3d) &&
         launch_conv_wino4(a, packed + pl.w_off + wino4_offset(L, is3d), is3d, s)) {
       prof_add_work(FNX_PROF_CONV_MFMA, px * mac * 2.25 * (is3d ? 3 : 1));  // 36 multiplies per 4x4 outputs (per z tap)

@@ -526,7 +526,7 @@ int fnx_scalenet_pack(int is3D, const float* weights_blob, void* packed, void* s
  *                              multiplies per 16 outputs instead of F(2x2)'s 64; 3D: in (y, x), the z taps as stages): exact-fp32 MFMAs,
  *                              the transforms round more (multipliers 4, 5, 8, 1/6, 1/24) -- measured 2x F(2x2)'s error, 0.07 of the
  *                              tests' 1e-5 |ref|max.  What FNX_PRECISION_FP32 runs since round 6 (256^3 CNN step 92.2 -> 81.0 ms,
- *                              1024^2 2.29 -> 2.17 ms)
+ *                              1024^2 2.29 -> 2.14 ms)
  *   FNX_PRECISION_FP32_F2      F(2x2,3x3) for every Winograd layer: the default of rounds 2-5 (kept for A/B timing) */
 enum { FNX_PRECISION_FP32 = 0, FNX_PRECISION_FP32_DIRECT = 1, FNX_PRECISION_BF16X6 = 2, FNX_PRECISION_BF16X3 = 3, FNX_PRECISION_FP32_F4 = 4,
        FNX_PRECISION_FP32_F2 = 5 };
