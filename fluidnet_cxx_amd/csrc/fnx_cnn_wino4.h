@@ -1,7 +1,7 @@
 // 3x3(x3) convolution in the Winograd F(4x4, 3x3) domain in (y, x), exact fp32 on v_mfma_f32_16x16x4_f32 (included by fnx_cnn.hip inside
 // namespace fnx, after its DMA helpers).  Round 6; FNX_PRECISION_FP32_F4 = what FNX_PRECISION_FP32 runs for the 64- / 128-output-channel
 // 3x3(x3) layers whose launch fills the chip (256^3 CNN step 92.2 -> 81.0 ms, 1024^2 2.29 -> 2.14 ms; FNX_PRECISION_FP32_F2 keeps them
-// on conv3_wino3_kernel).  docs/history/r06_notes.md section 3 has the twenty-two versions that were measured and the cycle accounting:
+// on conv3_wino3_kernel).  docs/history/r06_notes.md section 3 has the twenty-four versions that were measured and the cycle accounting:
 // what paid was removing instructions from every wave's path, pinning the order of a stage with scheduling fences and not draining the
 // pipeline between tiles -- never moving work between waves or phases.
 //
